@@ -1,0 +1,101 @@
+"""Seeded synthetic Eulerian-token batches with the reference's input contract.
+
+Build-side counterpart of the host collator + SMTP masking:
+  * `DataCollatorForGST.__call__` (reference src/data/collator.py:70-111): right padding with 0 to
+    S = 8*ceil(max_len/8), attention_mask 1/0, position_ids 0..len-1 (0 on pads);
+  * `prepare_inputs_for_pretrain_mlm` + `_mask_stacked_input_ids_v2`
+    (reference src/utils/tokenizer_utils.py:222-363, :112-148): per sample t = umr_min +
+    (umr_max-umr_min)*U, alpha = 1 - t**power, ceil(alpha*len*F) cells of the sample's own len*F
+    cells chosen uniformly, masked cell -> <mask> id 1, labels = original id at masked cells else -100,
+    optional dLM weight power/t.
+Token ids are drawn from [first_id, V) which is arithmetically equivalent to the real vocab ranges
+(SURVEY.md §8d).  NumPy RNG => identical batches here and on the GPU box.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+
+MASK_TOKEN_ID = 1
+PAD_TOKEN_ID = 0
+LABEL_PAD = -100
+
+
+def _lengths(rng, B, S, mode: str, min_len: int):
+    if mode == "full":
+        return np.full(B, S, np.int64)
+    if mode == "uniform":
+        return rng.randint(min_len, S + 1, size=B).astype(np.int64)
+    if mode == "pcqm":  # clipped N(22, 6), min 6
+        ln = np.rint(rng.normal(22.0, 6.0, size=B)).astype(np.int64)
+        return np.clip(ln, max(6, min_len), S)
+    raise ValueError(mode)
+
+
+def make_pretrain_batch(B: int, S: int, F: int, V: int, seed: int = 1234, *, lengths: str = "pcqm",
+                        min_len: int = 4, first_id: int = 22, power: float = 1.0,
+                        umr_clip=(0.01, 0.99), dlm_wgt: bool = False, force_full_row: bool = True
+                        ) -> Dict[str, np.ndarray]:
+    """SMTP pre-train batch: input_ids/labels i64 [B,S,F], attention_mask/position_ids i64 [B,S]."""
+    assert S % 8 == 0 or True  # collator pads to a multiple of 8; callers choose S accordingly
+    rng = np.random.RandomState(seed)
+    lens = _lengths(rng, B, S, lengths, min_len)
+    if force_full_row and lengths != "full":
+        lens[rng.randint(B)] = S  # the batch max defines S in the real collator
+    ids = np.zeros((B, S, F), np.int64)
+    labels = np.full((B, S, F), LABEL_PAD, np.int64)
+    att = np.zeros((B, S), np.int64)
+    pos = np.zeros((B, S), np.int64)
+    wgt = np.zeros((B,), np.float32)
+    lo = min(first_id, V - 1)
+    for b in range(B):
+        n = int(lens[b])
+        tok = rng.randint(lo, V, size=(n, F)).astype(np.int64)
+        t = umr_clip[0] + (umr_clip[1] - umr_clip[0]) * rng.random_sample()
+        alpha = 1.0 - t ** power
+        wgt[b] = power / t
+        k = int(np.ceil(n * F * alpha))
+        flat = rng.permutation(n * F)[:k]
+        lab = np.full((n * F,), LABEL_PAD, np.int64)
+        flat_tok = tok.reshape(-1)
+        lab[flat] = flat_tok[flat]
+        flat_tok[flat] = MASK_TOKEN_ID
+        ids[b, :n] = flat_tok.reshape(n, F)
+        labels[b, :n] = lab.reshape(n, F)
+        att[b, :n] = 1
+        pos[b, :n] = np.arange(n)
+    out = dict(input_ids=ids, labels=labels, attention_mask=att, position_ids=pos, lengths=lens)
+    if dlm_wgt:
+        out["wgt"] = wgt
+    return out
+
+
+def make_task_batch(B: int, S: int, F: int, V: int, seed: int = 1234, *, lengths: str = "uniform",
+                    min_len: int = 8, first_id: int = 22, num_labels: int = 2,
+                    regression: bool = False) -> Dict[str, np.ndarray]:
+    """Fine-tune batch (edge/graph-level): ids, attention_mask, position_ids, task_labels [B]."""
+    rng = np.random.RandomState(seed)
+    lens = _lengths(rng, B, S, lengths, min_len)
+    if lengths != "full":
+        lens[rng.randint(B)] = S
+    ids = np.zeros((B, S, F), np.int64)
+    att = np.zeros((B, S), np.int64)
+    pos = np.zeros((B, S), np.int64)
+    lo = min(first_id, V - 1)
+    for b in range(B):
+        n = int(lens[b])
+        ids[b, :n] = rng.randint(lo, V, size=(n, F))
+        att[b, :n] = 1
+        pos[b, :n] = np.arange(n)
+    if regression:
+        y = rng.standard_normal(size=(B,)).astype(np.float32)
+    else:
+        y = rng.randint(0, num_labels, size=(B,)).astype(np.int64)
+    return dict(input_ids=ids, attention_mask=att, position_ids=pos, task_labels=y, lengths=lens)
+
+
+def real_tokens(batch: Dict[str, np.ndarray]) -> int:
+    """Un-padded graph tokens in the batch = the unit of the headline metric
+    (reference src/conf/stats_configs.py:69-76, src/utils/misc_utils.py:349-378)."""
+    return int(batch["attention_mask"].sum())

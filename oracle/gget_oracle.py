@@ -1,0 +1,308 @@
+"""CPU oracle for the GraphGPT Graph-Eulerian-Transformer hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import this
+module; the product path (graph-gpt_amd/) never does and fails loudly without its HIP library.
+
+What it is: a plain PyTorch-CPU restatement (explicit tensor arithmetic, no nn.Module, no
+transformers import) of the reference's algorithm for SURVEY.md §8a rows A1-A12.  Each function
+cites the reference file:line (paths relative to the reference repo root; "hf:" = the un-vendored
+third-party `transformers.models.llama.modeling_llama`, pinned ==4.53.3 by the reference's
+requirements.txt:20, line numbers from the 5.15.0 copy the survey read).
+
+Parity status: PINNED against golden vectors captured by importing the real reference in the build
+container (`tools/make_golden.py` -> `tests/golden/*.npz`, checked by tests/test_oracle_golden.py).
+The reference itself ships no tests for this path, so those fixtures are the anchor.
+
+dtype: pass torch.float32 for the exact restatement; torch.bfloat16 reproduces the reference's
+bf16 module path (bf16 parameters/activations with fp32 islands: RMSNorm statistics, RoPE tables,
+softmax, cross-entropy) which is what the HIP kernels are compared against.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as Fnn
+
+LABEL_PAD = -100
+_EPSILON = 1e-7  # reference modeling_helpers.py `_EPSILON`
+
+
+# --------------------------------------------------------------------------- K1  (row A1)
+def stacked_embed(emb_w: torch.Tensor, input_ids: torch.Tensor, gate_w: Optional[torch.Tensor]):
+    """`_get_stacked_inputs_embeds` (modeling_helpers.py:89-114) + `StackedFeatAggregation.forward`
+    (modeling_common.py:127-135).  ids [B,S,F] (or [B,S]) -> [B,S,d]; returns (embeds, in_)."""
+    e = emb_w[input_ids]                      # nn.Embedding gather; pad row is a zero row
+    if input_ids.dim() == 3:
+        if gate_w is not None:
+            e = torch.einsum("nsfd,fd->nsd", e, gate_w)
+        else:
+            e = torch.sum(e, dim=-2)
+        in_ = input_ids[:, :, 0]
+    else:
+        in_ = input_ids
+    return e, in_
+
+
+# --------------------------------------------------------------------------- K4  (row A4a)
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float):
+    """hf LlamaRMSNorm.forward :62-67 - statistics in fp32, cast back, then scale by weight."""
+    dt = x.dtype
+    h = x.to(torch.float32)
+    var = h.pow(2).mean(-1, keepdim=True)
+    h = h * torch.rsqrt(var + eps)
+    return w * h.to(dt)
+
+
+# --------------------------------------------------------------------------- K3  (row A4)
+def rope_cos_sin(position_ids: torch.Tensor, head_dim: int, theta: float, dtype):
+    """hf LlamaRotaryEmbedding.forward :111-127 (default rope): fp32 tables cast to the act dtype."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    freqs = position_ids.to(torch.float32)[:, :, None] * inv_freq[None, None, :]   # [B,S,dh/2]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def _rotate_half(x):
+    """hf rotate_half :130-135."""
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+def apply_rope(q, k, cos, sin):
+    """hf apply_rotary_pos_emb :138-160 (q,k are [B,H,S,dh]; cos/sin [B,S,dh])."""
+    cos = cos.unsqueeze(1)
+    sin = sin.unsqueeze(1)
+    return (q * cos) + (_rotate_half(q) * sin), (k * cos) + (_rotate_half(k) * sin)
+
+
+# --------------------------------------------------------------------------- K2  (row A3)
+def additive_mask(attention_mask: torch.Tensor, S: int, dtype, causal: bool):
+    """Key-padding mask of `_update_causal_mask` -> `_prepare_4d_attention_mask`
+    (modeling_helpers.py:38-48): 0 where the key is real, finfo.min where it is padding; no causal
+    term when causal_attention=False.  With causal_attention=True the reference hands the 2-D mask to
+    hf LlamaModel which builds causal AND padding (hf :394-400).  Returns [B,1,S,S]."""
+    B = attention_mask.shape[0]
+    neg = torch.finfo(dtype).min
+    m = torch.zeros(B, 1, S, S, dtype=dtype)
+    m = m.masked_fill(attention_mask[:, None, None, :] == 0, neg)
+    if causal:
+        tri = torch.ones(S, S, dtype=torch.bool).tril()
+        m = m.masked_fill(~tri[None, None], neg)
+    return m
+
+
+# --------------------------------------------------------------------------- K5-K8 (row A4b)
+def attention(x, p, pre, mask4d, cos, sin, H, dh):
+    """hf LlamaAttention.forward :243-281 with eager_attention_forward :191-214 (dropout p=0)."""
+    B, S, d = x.shape
+    q = Fnn.linear(x, p[pre + "q_proj.weight"]).view(B, S, H, dh).transpose(1, 2)
+    k = Fnn.linear(x, p[pre + "k_proj.weight"]).view(B, S, H, dh).transpose(1, 2)
+    v = Fnn.linear(x, p[pre + "v_proj.weight"]).view(B, S, H, dh).transpose(1, 2)
+    q, k = apply_rope(q, k, cos, sin)
+    w = torch.matmul(q, k.transpose(2, 3)) * (dh ** -0.5)
+    w = w + mask4d
+    w = Fnn.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+    o = torch.matmul(w, v).transpose(1, 2).contiguous().view(B, S, d)
+    return Fnn.linear(o, p[pre + "o_proj.weight"])
+
+
+# --------------------------------------------------------------------------- K9  (row A4c)
+def mlp(x, p, pre):
+    """hf LlamaMLP.forward :174-176 with hidden_act="gelu" = exact erf GELU
+    (reference configs/model/base.yaml:21)."""
+    g = Fnn.gelu(Fnn.linear(x, p[pre + "gate_proj.weight"]))
+    u = Fnn.linear(x, p[pre + "up_proj.weight"])
+    return Fnn.linear(g * u, p[pre + "down_proj.weight"])
+
+
+def backbone(spec, p: Dict[str, torch.Tensor], x, attention_mask, position_ids, collect=None):
+    """hf LlamaModel.forward :367-418 / LlamaDecoderLayer.forward :295-325; LayerScale variant
+    utils_graphgpt.LlamaDecoderLayer.forward (utils_graphgpt.py:107-173, eval mode: DropPath = id)."""
+    B, S, d = x.shape
+    if position_ids is None:
+        position_ids = torch.arange(S)[None, :].expand(B, S)      # hf :389-392
+    cos, sin = rope_cos_sin(position_ids, spec.head_dim, spec.rope_theta, x.dtype)
+    mask4d = additive_mask(attention_mask, S, x.dtype, spec.causal)
+    for i in range(spec.num_layers):
+        pre = f"model.layers.{i}."
+        h = rmsnorm(x, p[pre + "input_layernorm.weight"], spec.rms_eps)
+        a = attention(h, p, pre + "self_attn.", mask4d, cos, sin, spec.num_heads, spec.head_dim)
+        if spec.layer_scale_init > 0:
+            a = p[pre + "lambda_1"] * a
+        x = x + a
+        h = rmsnorm(x, p[pre + "post_attention_layernorm.weight"], spec.rms_eps)
+        m = mlp(h, p, pre + "mlp.")
+        if spec.layer_scale_init > 0:
+            m = p[pre + "lambda_2"] * m
+        x = x + m
+        if collect is not None:
+            collect.append(x)
+    return rmsnorm(x, p["model.norm.weight"], spec.rms_eps)
+
+
+# --------------------------------------------------------------------------- K11-K14 (rows A5-A7)
+def smtp_head(spec, p, hidden, labels, sample_wgt=None):
+    """`prepare_for_stacked_feat_labels` (modeling_helpers.py:362-393), "short" stacking:
+    no wgt -> `_prepare_for_stacked_feat_labels_per_mix_lvl` (:263-301);
+    wgt    -> `_prepare_for_stacked_feat_labels_wgt_per_feat_lvl` (:345-359);
+    then lm_head (modeling_pretrain.py:218) and `_get_ce_loss` (:145-177) or `_get_dlm_ce_loss`
+    (:180-198) / (B*S*F) (modeling_pretrain.py:230-236).  labels None => logits for every cell."""
+    B, S, d = hidden.shape
+    n = spec.next_n_token
+    proj = p.get("n_token_proj.weight")
+
+    def _proj(h):
+        return Fnn.linear(h, proj) if proj is not None else h
+
+    wgt = None
+    if labels is not None and labels.dim() == 2:
+        labels = labels[:, :, None]
+    if sample_wgt is None:
+        if labels is not None:
+            mask = labels != LABEL_PAD
+            mask_m = mask.any(dim=-1)
+            mask = mask[mask_m]
+        else:
+            mask_m = torch.ones(B, S, dtype=torch.bool)
+        hs = _proj(hidden[mask_m]).reshape(-1, d)
+        if labels is not None:
+            labels = labels[mask_m][mask]
+            hs = hs[mask.reshape(-1)]
+    else:
+        hs = _proj(hidden).reshape(B, S, n, d)
+        mask_m = labels != LABEL_PAD
+        hs = hs[mask_m]
+        wgt = sample_wgt[:, None, None].repeat(1, S, n)[mask_m]
+        labels = labels[mask_m]
+    logits = Fnn.linear(hs, p["lm_head.weight"])
+    loss = None
+    if labels is not None:
+        if wgt is None:
+            loss = Fnn.cross_entropy(logits.float(), labels)
+        else:
+            l_ = Fnn.cross_entropy(logits.float(), labels, reduction="none")
+            loss = (l_ * wgt.view(-1)).float().sum() / (B * S * n)
+    return loss, logits
+
+
+def pretrain_forward(spec, p, input_ids, attention_mask, labels=None, sample_wgt=None,
+                     position_ids=None, collect=None):
+    """`GraphGPTPretrainBase.forward` (modeling_pretrain.py:152-266), generative head only."""
+    x, _ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"))
+    hidden = backbone(spec, p, x, attention_mask, position_ids, collect)
+    loss, logits = smtp_head(spec, p, hidden, labels, sample_wgt)
+    return dict(head1_loss=loss, head1_logits=logits, hidden=hidden)
+
+
+# --------------------------------------------------------------------------- K15 (row A10)
+def task_forward(spec, p, input_ids, attention_mask, position_ids=None, task_labels=None,
+                 sample_wgt=None, problem_type="single_label_classification", loss_type=None):
+    """`GraphGPTTaskModel.forward` (modeling_finetune.py:236-326) + `calculate_task_loss`
+    (:167-234) + `_get_sequence_len` (modeling_helpers.py:78-86); Linear score head, "last" pooling."""
+    if input_ids.dim() == 3:
+        input_ids = input_ids[:, :, : spec.stacked_feat]
+    x, in_ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"))
+    hidden = backbone(spec, p, x, attention_mask, position_ids)
+    logits = Fnn.linear(hidden, p["score.weight"], p.get("score.bias"))
+    B = hidden.shape[0]
+    seq_len = (in_ != spec.pad_token_id).sum(-1) - 1
+    pooled = logits[torch.arange(B), seq_len]
+    pooled_h = hidden[torch.arange(B), seq_len]
+    loss = None
+    if task_labels is not None:
+        if problem_type == "regression":
+            y = task_labels.to(pooled.dtype)
+            if loss_type == "l1":
+                loss = Fnn.l1_loss(pooled.squeeze(), y.squeeze())
+            else:
+                loss = Fnn.mse_loss(pooled.squeeze(), y.squeeze())
+        elif problem_type == "single_label_classification":
+            if sample_wgt is None:
+                loss = Fnn.cross_entropy(pooled.view(-1, spec.num_labels).float(), task_labels.view(-1))
+            else:
+                l_ = Fnn.cross_entropy(pooled.view(-1, spec.num_labels).float(), task_labels.view(-1),
+                                       reduction="none")
+                loss = (l_.float().view(-1) * sample_wgt.float().view(-1)).sum() / sample_wgt.float().sum()
+        elif problem_type == "multi_label_classification":
+            is_l = task_labels == task_labels
+            loss = Fnn.binary_cross_entropy_with_logits(pooled[is_l], task_labels[is_l])
+        else:
+            raise ValueError(problem_type)
+    return dict(task_loss=loss, task_logits=pooled.float(), task_hidden_states=pooled_h, hidden=hidden)
+
+
+# --------------------------------------------------------------------------- params / grads
+def to_params(state: Dict[str, "object"], dtype=torch.float32, requires_grad=True):
+    out = {}
+    for k, v in state.items():
+        t = torch.as_tensor(v).to(dtype).clone()
+        t.requires_grad_(requires_grad)
+        out[k] = t
+    return out
+
+
+def loss_and_grads(fn, p: Dict[str, torch.Tensor], loss_key: str, **kw):
+    for t in p.values():
+        t.grad = None
+    out = fn(p, **kw)
+    out[loss_key].backward()
+    grads = {k: (t.grad.detach().clone() if t.grad is not None else torch.zeros_like(t)) for k, t in p.items()}
+    return out, grads
+
+
+# --------------------------------------------------------------------------- K16 (rows A11/A12)
+def clip_coef(grads: Dict[str, torch.Tensor], max_norm: float):
+    """torch.nn.utils.clip_grad_norm_ as called at training_utils.py:72 (L2, eps 1e-6, clamp 1)."""
+    tot = torch.sqrt(sum((g.float() ** 2).sum() for g in grads.values()))
+    return float(torch.clamp(max_norm / (tot + 1e-6), max=1.0)), float(tot)
+
+
+def adamw_step(master: Dict[str, torch.Tensor], grads, m, v, step: int, lr, beta1, beta2, eps, wd,
+               max_grad_norm: float = 0.0):
+    """One clip-then-AdamW update on fp32 master weights: torch.optim.AdamW semantics
+    (opt_utils.py:18-24; decoupled decay `p *= 1-lr*wd`, bias-corrected m/v,
+    denom = sqrt(v)/sqrt(bc2) + eps) = DeepSpeed FusedAdam adam_w_mode (ds_config2_pt.json:11-19).
+    `step` is 1-based.  Returns the gradient global norm (pre-clip)."""
+    coef, gnorm = (1.0, 0.0)
+    if max_grad_norm and max_grad_norm > 0:
+        coef, gnorm = clip_coef(grads, max_grad_norm)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    for k, w in master.items():
+        g = grads[k].float() * coef
+        m[k].mul_(beta1).add_(g, alpha=1 - beta1)
+        v[k].mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        w.mul_(1 - lr * wd)
+        denom = (v[k].sqrt() / math.sqrt(bc2)).add_(eps)
+        w.addcdiv_(m[k], denom, value=-lr / bc1)
+    return gnorm
+
+
+def one_cycle_lr(step: int, max_lr: float, total_steps: int, pct_start: float, min_lr: float = 0.0):
+    """torch OneCycleLR(anneal="cos", three_phase=False, div_factor 25) as configured by
+    `_py_one_cycle` (loss_utils.py:322-367): value at 0-based scheduler step `step`."""
+    div = 25.0
+    initial = max_lr / div
+    final = min_lr if min_lr > 0 else initial / 1e4
+    up_end = float(pct_start * total_steps) - 1
+    down_end = total_steps - 1
+
+    def cos_anneal(a, b, pct):
+        return b + (a - b) / 2.0 * (math.cos(math.pi * pct) + 1)
+
+    if step <= up_end:
+        return cos_anneal(initial, max_lr, step / up_end if up_end > 0 else 1.0)
+    return cos_anneal(max_lr, final, (step - up_end) / (down_end - up_end))
+
+
+def warmup_decay_lr(step: int, max_lr: float, min_lr: float, warmup: int, total: int):
+    """DeepSpeed WarmupDecayLR (log warmup then linear decay), the scheduler named by
+    examples/ds_config2_pt.json:20-28.  DeepSpeed is not installed in the build container, so this
+    restates its published formula (deepspeed/runtime/lr_schedules.py); parity for it is UNPINNED."""
+    if step < warmup:
+        gamma = math.log(step + 1) / math.log(max(2, warmup))
+    else:
+        gamma = max(0.0, (total - step) / max(1.0, total - warmup))
+    return min_lr + (max_lr - min_lr) * gamma

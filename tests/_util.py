@@ -1,0 +1,43 @@
+"""Shared helpers for the parity tests (fixtures <-> spec/weights/batches)."""
+import importlib
+import os
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+pkg = importlib.import_module("graph-gpt_amd")
+spec_mod = importlib.import_module("graph-gpt_amd.spec")
+weights_mod = importlib.import_module("graph-gpt_amd.weights")
+synth = importlib.import_module("graph-gpt_amd.synth")
+
+PT_CASES = ["pt_tiny_f13_a", "pt_tiny_f13_b", "pt_tiny_f1", "pt_tiny_causal", "pt_tiny_gated", "pt_tiny_wgt",
+            "pt_tiny_bigw", "pt_tiny_s72"]
+FT_CASES = ["ft_tiny_f4", "ft_tiny_ls", "ft_tiny_reg"]
+ADAM = dict(lr=1e-3, beta1=0.9, beta2=0.95, eps=1e-8, wd=0.1)
+CLIP = 1.0
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = [int(x) for x in z["meta_spec"]]
+    spec = spec_mod.ModelSpec(kind=m[0], vocab_size=m[1], hidden_size=m[2], intermediate_size=m[3], num_layers=m[4],
+                              num_heads=m[5], head_dim=64, stacked_feat=m[6], next_n_token=m[7], gated_agg=bool(m[8]),
+                              causal=bool(m[9]), max_position=m[10], num_labels=m[11], score_bias=bool(m[12]),
+                              pad_token_id=m[13], layer_scale_init=float(z["meta_layer_scale"]))
+    std, head_std, seed = [float(x) for x in z["meta_init"]]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=std, head_std=None if head_std < 0 else head_std)
+    batch = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    return z, spec, state, batch
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def tb(batch):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in batch.items()}

@@ -1,0 +1,100 @@
+"""Pins the CPU oracle (oracle/gget_oracle.py) against golden vectors captured from the real
+reference (tools/make_golden.py).  fp32: tight; bf16: the reference's own bf16 module path."""
+import numpy as np
+import pytest
+import torch
+
+from _util import ADAM, CLIP, FT_CASES, PT_CASES, load_case, rel_l2, tb
+from oracle import gget_oracle as O
+
+
+def _fwd_fn(spec, b, kind):
+    if kind == "pt":
+        def fn(p):
+            return O.pretrain_forward(spec, p, b["input_ids"], b["attention_mask"], b["labels"], b.get("wgt"))
+        return fn, "head1_loss", "head1_logits"
+    reg = spec.num_labels == 1
+
+    def fn(p):
+        return O.task_forward(spec, p, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"],
+                              problem_type="regression" if reg else "single_label_classification",
+                              loss_type="l1" if reg else None)
+    return fn, "task_loss", "task_logits"
+
+
+@pytest.mark.parametrize("name", PT_CASES + FT_CASES)
+def test_oracle_fp32_matches_reference(name):
+    z, spec, state, batch = load_case(name)
+    kind = "pt" if name.startswith("pt") else "ft"
+    b = tb(batch)
+    p = O.to_params(state, torch.float32)
+    fn, lk, gk = _fwd_fn(spec, b, kind)
+    out, grads = O.loss_and_grads(fn, p, lk)
+    assert abs(out[lk].item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"])) + 1e-6
+    lg = out[gk].detach().float().numpy()
+    assert tuple(lg.shape) == tuple(int(x) for x in z["logits_shape"])
+    np.testing.assert_allclose(lg[:64], z["logits"], rtol=2e-4, atol=2e-5)
+    names = list(state.keys())
+    gn = np.array([float(grads[n].norm()) for n in names])
+    np.testing.assert_allclose(gn, z["grad_norms"], rtol=2e-4, atol=1e-7)
+    assert rel_l2(grads["model.embed_tokens.weight"].numpy(), z["grad_embed"]) < 1e-4
+    assert rel_l2(grads["model.layers.0.self_attn.q_proj.weight"].numpy(), z["grad_l0_q"]) < 1e-4
+    assert rel_l2(grads["model.layers.1.mlp.down_proj.weight"].numpy(), z["grad_l1_down"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["pt_tiny_f13_a", "pt_tiny_bigw", "pt_tiny_s72", "ft_tiny_f4", "ft_tiny_ls"])
+def test_oracle_bf16_tracks_reference_bf16(name):
+    z, spec, state, batch = load_case(name)
+    kind = "pt" if name.startswith("pt") else "ft"
+    b = tb(batch)
+    p = O.to_params(state, torch.bfloat16, requires_grad=False)
+    fn, lk, gk = _fwd_fn(spec, b, kind)
+    with torch.no_grad():
+        out = fn(p)
+    # same arithmetic as the reference's bf16 module path -> agreement far below bf16 noise vs fp32
+    assert abs(out[lk].item() - float(z["loss_bf16"])) <= 2e-3 * abs(float(z["loss_bf16"])) + 1e-3
+    assert rel_l2(out[gk].float().numpy()[:64], z["logits_bf16"]) < 2e-2
+
+
+@pytest.mark.parametrize("name", ["pt_tiny_f13_a", "pt_tiny_bigw", "pt_tiny_wgt", "ft_tiny_f4", "ft_tiny_reg"])
+def test_oracle_adamw_trajectory(name):
+    z, spec, state, batch = load_case(name)
+    kind = "pt" if name.startswith("pt") else "ft"
+    b = tb(batch)
+    p = O.to_params(state, torch.float32)
+    fn, lk, _ = _fwd_fn(spec, b, kind)
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(v_) for k, v_ in p.items()}
+    losses, gns = [], []
+    for step in range(1, 4):
+        out, grads = O.loss_and_grads(fn, p, lk)
+        losses.append(out[lk].item())
+        with torch.no_grad():
+            gns.append(O.adamw_step({k: t for k, t in p.items()}, grads, m, v, step, ADAM["lr"], ADAM["beta1"],
+                                    ADAM["beta2"], ADAM["eps"], ADAM["wd"], CLIP))
+    with torch.no_grad():
+        losses.append(fn(p)[lk].item())
+    np.testing.assert_allclose(losses, z["adamw_losses"], rtol=3e-4, atol=1e-5)
+    np.testing.assert_allclose(gns, z["adamw_gnorms"], rtol=3e-4)
+    fin = np.array([float(p[n].detach().norm()) for n in state.keys()])
+    np.testing.assert_allclose(fin, z["adamw_final_norms"], rtol=1e-4)
+
+
+def test_lr_schedules():
+    import os
+    from _util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "lr_schedules.npz"))
+    for tag in ("a", "b"):
+        max_lr, min_lr, total, warm = z["onecycle_" + tag + "_params"]
+        got = [O.one_cycle_lr(s, max_lr, int(total) + 1, warm / total, min_lr) for s in range(int(total))]
+        np.testing.assert_allclose(got, z["onecycle_" + tag], rtol=1e-9, atol=1e-15)
+
+
+def test_inputs_regenerate():
+    """The committed inputs are exactly what our seeded generator produces (so the GPU box can rebuild
+    larger batches from seeds alone)."""
+    from _util import synth
+    z, spec, state, batch = load_case("pt_tiny_f13_a")
+    again = synth.make_pretrain_batch(B=4, S=24, F=13, V=756, seed=0)
+    for k in ("input_ids", "labels", "attention_mask", "position_ids"):
+        np.testing.assert_array_equal(again[k], batch[k])

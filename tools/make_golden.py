@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by importing the REAL reference (alibaba/graph-gpt at /root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box).  Fixtures hold data
+only: seeded inputs produced by our own generators (graph-gpt_amd/synth.py, weights.py) and the
+reference's outputs on them (losses, logits, hidden-state slices, per-parameter gradient norms,
+AdamW trajectories, LR-schedule samples).  Import recipe = SURVEY.md Appendix A.
+
+    python tools/make_golden.py            # rewrites every fixture
+"""
+import importlib
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+gg = importlib.import_module("graph-gpt_amd")
+from importlib import import_module  # noqa: E402
+
+spec_mod = import_module("graph-gpt_amd.spec")
+weights_mod = import_module("graph-gpt_amd.weights")
+synth = import_module("graph-gpt_amd.synth")
+
+
+# ----------------------------------------------------------------------------- reference import
+def import_reference():
+    sys.path.insert(0, REF)
+
+    class _Stub(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            full = self.__name__ + "." + name
+            return sys.modules.get(full) or type(name, (), {"__init__": lambda self, *a, **k: None})
+
+    def stub(name):
+        parts = name.split(".")
+        for i in range(1, len(parts) + 1):
+            n = ".".join(parts[:i])
+            if n not in sys.modules:
+                m = _Stub(n)
+                m.__path__ = []
+                m.__spec__ = importlib.machinery.ModuleSpec(n, None, is_package=True)
+                sys.modules[n] = m
+
+    def bare_pkg(name, path):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None, is_package=True)
+        sys.modules[name] = m
+
+    # our repo also has a top-level `src` package (the drop-in surface); make sure the reference's wins here
+    for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        del sys.modules[k]
+    bare_pkg("src", REF + "/src")
+    bare_pkg("src.utils", REF + "/src/utils")
+    for n in ["torch_geometric", "torch_geometric.data", "ogb", "ogb.utils", "ogb.utils.features",
+              "omegaconf", "timm", "timm.utils", "timm.models", "timm.utils.model"]:
+        stub(n)
+    sys.modules["omegaconf"].MISSING = "???"
+    import transformers.utils.import_utils as iu
+    if not hasattr(iu, "is_torch_fx_available"):
+        iu.is_torch_fx_available = lambda: False
+    from src.models import GraphGPTPretrainBase, GraphGPTTaskModel, GraphGPTConfig
+    from src.models.graphgpt import utils_graphgpt
+    # transformers>=5 decoder layers must return a tensor; the reference's LayerScale layer returns a tuple
+    _orig = utils_graphgpt.LlamaDecoderLayer.forward
+
+    def _fwd(self, *a, **k):
+        return _orig(self, *a, **k)[0]
+
+    utils_graphgpt.LlamaDecoderLayer.forward = _fwd
+    return GraphGPTPretrainBase, GraphGPTTaskModel, GraphGPTConfig
+
+
+def ref_config(GraphGPTConfig, spec, **extra):
+    kw = dict(vocab_size=spec.vocab_size, hidden_size=spec.hidden_size,
+              intermediate_size=spec.intermediate_size, num_hidden_layers=spec.num_layers,
+              num_attention_heads=spec.num_heads, head_dim=spec.head_dim, hidden_act="gelu",
+              max_position_embeddings=spec.max_position, rms_norm_eps=spec.rms_eps,
+              causal_attention=spec.causal, stacked_feat=spec.stacked_feat, stack_method="short",
+              stacked_feat_agg_method="gated" if spec.gated_agg else "sum",
+              next_n_token=spec.next_n_token, attention_dropout=0.0, use_cache=False,
+              layer_scale_init_value=spec.layer_scale_init, pad_token_id=0, tie_word_embeddings=False)
+    kw.update(extra)
+    return GraphGPTConfig(**kw)
+
+
+def load_weights(model, state):
+    sd = {k: torch.from_numpy(v.copy()) for k, v in state.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing = [m for m in missing if "rotary_emb" not in m]
+    assert not missing and not unexpected, (missing, unexpected)
+
+
+def grad_norms(model, names):
+    g = dict(model.named_parameters())
+    return np.array([float(g[n].grad.float().norm()) if g[n].grad is not None else 0.0 for n in names], np.float64)
+
+
+CASES = [
+    # name, kind, spec kwargs, batch kwargs, init kwargs
+    ("pt_tiny_f13_a", "pt", dict(vocab_size=756, stacked_feat=13, next_n_token=13), dict(B=4, S=24, seed=0), {}),
+    ("pt_tiny_f13_b", "pt", dict(vocab_size=756, stacked_feat=13, next_n_token=13), dict(B=2, S=40, seed=1), {}),
+    ("pt_tiny_f1", "pt", dict(vocab_size=300, stacked_feat=1, next_n_token=1), dict(B=4, S=24, seed=2, lengths="uniform"), {}),
+    ("pt_tiny_causal", "pt", dict(vocab_size=756, stacked_feat=13, next_n_token=13, causal=True), dict(B=4, S=24, seed=3), {}),
+    ("pt_tiny_gated", "pt", dict(vocab_size=756, stacked_feat=13, next_n_token=13, gated_agg=True), dict(B=4, S=24, seed=4), {}),
+    ("pt_tiny_wgt", "pt", dict(vocab_size=756, stacked_feat=13, next_n_token=13), dict(B=4, S=24, seed=5, dlm_wgt=True), {}),
+    ("pt_tiny_bigw", "pt", dict(vocab_size=756, stacked_feat=13, next_n_token=13), dict(B=4, S=24, seed=6),
+     dict(std=0.06, head_std=0.15)),
+    ("pt_tiny_s72", "pt", dict(vocab_size=756, stacked_feat=13, next_n_token=13), dict(B=3, S=72, seed=7, lengths="uniform", min_len=20),
+     dict(std=0.06, head_std=0.15)),
+    ("ft_tiny_f4", "ft", dict(vocab_size=1000, stacked_feat=4, next_n_token=1, num_labels=2), dict(B=4, S=24, seed=8), {}),
+    ("ft_tiny_ls", "ft", dict(vocab_size=1000, stacked_feat=4, next_n_token=1, num_labels=2, layer_scale_init=1.0),
+     dict(B=4, S=40, seed=9), dict(std=0.06, head_std=0.15)),
+    ("ft_tiny_reg", "ft", dict(vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=1, score_bias=True),
+     dict(B=4, S=24, seed=10, regression=True), dict(std=0.06, head_std=0.15)),
+]
+
+ADAM = dict(lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+CLIP = 1.0
+
+
+def run_case(name, kind, skw, bkw, ikw, classes):
+    PT, FT, Cfg = classes
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN if kind == "pt" else spec_mod.KIND_TASK, **skw)
+    state = weights_mod.make_state_dict(spec, seed=100 + bkw["seed"], **ikw)
+    names = list(state.keys())
+    out = {}
+    if kind == "pt":
+        batch = synth.make_pretrain_batch(F=spec.stacked_feat, V=spec.vocab_size, **bkw)
+        cfg = ref_config(Cfg, spec)
+        model = PT(cfg)
+    else:
+        reg = bkw.pop("regression", False)
+        batch = synth.make_task_batch(F=spec.stacked_feat, V=spec.vocab_size, num_labels=spec.num_labels,
+                                      regression=reg, **bkw)
+        extra = dict(num_labels=spec.num_labels, loss_type="l1" if reg else None, mlp=[],
+                     problem_type="regression" if reg else "single_label_classification")
+        cfg = ref_config(Cfg, spec, **extra)
+        model = FT(cfg)
+    load_weights(model, state)
+    model.eval()  # dropout-free arithmetic (attention_dropout=0 anyway; DropPath = identity)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+
+    def fwd(m, dtype=None):
+        if kind == "pt":
+            return m(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"], labels=tb["labels"],
+                     inputs_raw_embeds=None, sample_wgt=tb.get("wgt"))
+        return m(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"],
+                 position_ids=tb["position_ids"], task_labels=tb["task_labels"])
+
+    o = fwd(model)
+    loss = o.head1_loss if kind == "pt" else o.task_loss
+    logits = o.head1_logits if kind == "pt" else o.task_logits
+    model.zero_grad()
+    loss.backward()
+    out["loss"] = np.float64(loss.item())
+    out["logits"] = logits.detach().float().numpy()[:64]
+    out["logits_shape"] = np.array(logits.shape)
+    out["grad_norms"] = grad_norms(model, names)
+    # one full gradient for a mid-stack matrix and the embedding (tight check of backward)
+    g = dict(model.named_parameters())
+    out["grad_embed"] = g["model.embed_tokens.weight"].grad.numpy().copy()
+    out["grad_l0_q"] = g["model.layers.0.self_attn.q_proj.weight"].grad.numpy().copy()
+    out["grad_l1_down"] = g["model.layers.1.mlp.down_proj.weight"].grad.numpy().copy()
+    # final hidden states
+    with torch.no_grad():
+        if kind == "pt":
+            ids3, emb, _ = model.prepare_inputs_embeds(tb["input_ids"], None, None, tb["labels"])
+        else:
+            ids3, emb, _ = model.prepare_inputs_embeds(tb["input_ids"][:, :, : spec.stacked_feat], None, None)
+        out["embeds"] = emb.numpy()[:, :4, :16].copy()
+        if kind == "ft":
+            out["task_hidden"] = o.task_hidden_states.detach().numpy().copy()
+    # bf16 module path of the reference itself
+    mb = (PT if kind == "pt" else FT)(cfg)
+    load_weights(mb, state)
+    mb = mb.to(torch.bfloat16).eval()
+    with torch.no_grad():
+        ob = fwd(mb)
+    lb = ob.head1_loss if kind == "pt" else ob.task_loss
+    out["loss_bf16"] = np.float64(lb.item())
+    out["logits_bf16"] = (ob.head1_logits if kind == "pt" else ob.task_logits).float().numpy()[:64]
+    # three clip+AdamW steps on the same batch (training_utils.py:53-86 order: clip then step)
+    model.zero_grad()
+    opt = torch.optim.AdamW(model.parameters(), **ADAM)
+    traj = []
+    gn = []
+    for _ in range(3):
+        opt.zero_grad()
+        o = fwd(model)
+        l_ = o.head1_loss if kind == "pt" else o.task_loss
+        l_.backward()
+        gn.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), CLIP)))
+        opt.step()
+        traj.append(l_.item())
+    with torch.no_grad():
+        o = fwd(model)
+    traj.append((o.head1_loss if kind == "pt" else o.task_loss).item())
+    out["adamw_losses"] = np.array(traj, np.float64)
+    out["adamw_gnorms"] = np.array(gn, np.float64)
+    sd = model.state_dict()
+    out["adamw_final_norms"] = np.array([float(sd[n].float().norm()) for n in names], np.float64)
+    # meta (so the tests rebuild inputs from the same generators and cross-check them against the stored copy)
+    for k, v in batch.items():
+        out["in_" + k] = v
+    out["meta_spec"] = np.array(spec.as_c_ints(), np.int64)
+    out["meta_layer_scale"] = np.float64(spec.layer_scale_init)
+    out["meta_init"] = np.array([ikw.get("std", 0.02), ikw.get("head_std", -1.0), 100 + bkw["seed"]], np.float64)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + ".npz"), **out)
+    print(f"{name}: loss {out['loss']:.6f} bf16 {out['loss_bf16']:.6f} logits {tuple(out['logits_shape'])} "
+          f"adamw {np.round(out['adamw_losses'], 5)}")
+
+
+def lr_fixture():
+    """OneCycleLR samples with the parameters `_py_one_cycle` (reference loss_utils.py:322-367) sets."""
+    res = {}
+    for tag, (max_lr, min_lr, total, warm) in {"a": (3e-4, 0.0, 1000, 100), "b": (1e-3, 1e-5, 50, 5)}.items():
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=max_lr)
+        div = 25.0
+        initial = max_lr / div
+        fdf = initial / min_lr if min_lr > 0 else 1e4
+        sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=[max_lr], total_steps=total + 1,
+                                                   pct_start=warm / total, anneal_strategy="cos",
+                                                   cycle_momentum=False, div_factor=div, final_div_factor=fdf)
+        lrs = []
+        for _ in range(total):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        res["onecycle_" + tag] = np.array(lrs, np.float64)
+        res["onecycle_" + tag + "_params"] = np.array([max_lr, min_lr, total, warm], np.float64)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "lr_schedules.npz"), **res)
+    print("lr_schedules written")
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    classes = import_reference()
+    only = set(sys.argv[1:])
+    for name, kind, skw, bkw, ikw in CASES:
+        if only and name not in only:
+            continue
+        run_case(name, kind, dict(skw), dict(bkw), dict(ikw), classes)
+    if not only:
+        lr_fixture()
+
+
+if __name__ == "__main__":
+    main()

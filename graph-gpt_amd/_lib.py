@@ -1,0 +1,100 @@
+"""ctypes binding of libgget_hip.so (C ABI: include/gget.h).  There is NO CPU fallback: if the
+library is missing or does not load, importing the engine raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgget_hip.so")
+
+i32, i64, u64, f32, vp, cp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p, C.c_char_p
+
+
+class GgetConfig(C.Structure):
+    _fields_ = [(n, i32) for n in ("kind", "vocab_size", "hidden_size", "intermediate_size", "num_layers", "num_heads",
+                                   "stacked_feat", "next_n_token", "gated_agg", "causal", "max_position", "num_labels",
+                                   "score_bias", "pad_token_id")] + \
+               [("rms_eps", f32), ("rope_theta", f32), ("layer_scale_init", f32), ("max_tokens", i32), ("max_batch", i32)]
+
+
+class GgetSizes(C.Structure):
+    _fields_ = [(n, u64) for n in ("n_params", "param_bf16_bytes", "master_bytes", "adam_bytes", "grad_bf16_bytes",
+                                   "workspace_bytes")]
+
+
+class GgetBuffers(C.Structure):
+    _fields_ = [(n, vp) for n in ("param_bf16_dev", "master_dev", "adam_m_dev", "adam_v_dev", "grad_bf16_dev",
+                                  "workspace_dev", "rope_cos_dev", "rope_sin_dev")]
+
+
+class GgetParamInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("ndim", i32), ("shape", i64 * 2), ("offset", u64), ("layer", i32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/gget.h
+SIGNATURES = {
+    "gget_last_error": (cp, []),
+    "gget_version": (i32, []),
+    "gget_query_sizes": (i32, [C.POINTER(GgetConfig), C.POINTER(GgetSizes)]),
+    "gget_create": (i32, [C.POINTER(GgetConfig), C.POINTER(GgetBuffers), C.POINTER(vp)]),
+    "gget_destroy": (i32, [vp]),
+    "gget_param_count": (i32, [vp]),
+    "gget_param_info": (i32, [vp, i32, C.POINTER(GgetParamInfo)]),
+    "gget_bucket_count": (i32, [vp]),
+    "gget_bucket_range": (i32, [vp, i32, C.POINTER(u64), C.POINTER(u64)]),
+    "gget_sync_params": (i32, [vp, vp]),
+    "gget_forward_pretrain": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    "gget_forward_task": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
+    "gget_backward": (i32, [vp, f32, vp]),
+    "gget_backward_begin": (i32, [vp, f32, vp]),
+    "gget_backward_layer": (i32, [vp, i32, vp]),
+    "gget_backward_end": (i32, [vp, vp]),
+    "gget_adamw_step": (i32, [vp, f32, f32, f32, f32, f32, f32, f32, i32, vp, vp]),
+    "gget_head_counts": (i32, [vp, C.POINTER(i32 * 2), vp]),
+    "gget_head_logits": (i32, [vp, C.POINTER(vp), C.POINTER(i32)]),
+    "gget_hidden_states": (i32, [vp, C.POINTER(vp)]),
+    "gget_op_gemm": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "gget_op_rmsnorm_fwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
+    "gget_op_rmsnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "gget_op_embed_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "gget_op_embed_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "gget_op_rope": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "gget_op_attn_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "gget_op_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "gget_op_geglu_fwd": (i32, [vp, vp, i32, i32, vp]),
+    "gget_op_geglu_bwd": (i32, [vp, vp, vp, i32, i32, vp]),
+    "gget_op_ce_fwd_bwd": (i32, [vp, i32, vp, vp, vp, i32, i32, vp, vp, f32, i32, vp]),
+}
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_NONE, EPI_RESIDUAL, EPI_ATOMIC_F32 = 0, 1, 2
+PROBLEM_SINGLE_LABEL, PROBLEM_REGRESSION_L1, PROBLEM_REGRESSION_MSE = 0, 1, 2
+
+_lib = None
+
+
+class GgetError(RuntimeError):
+    pass
+
+
+def load(path: str = LIB_PATH):
+    """dlopen the engine.  Raises (never falls back) when the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise GgetError(f"{path} is missing: build it with `python graph-gpt_amd/build.py` "
+                        "(or __graft_entry__.build()); this engine has no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise GgetError(f"gget error {rc}: {load().gget_last_error().decode()}")

@@ -1,0 +1,345 @@
+// Self-attention core of the Graph Eulerian Transformer on gfx950 MFMA (32x32x16 bf16).
+// reference: hf eager_attention_forward :191-214 / SDPA as selected by LlamaAttention.forward :243-281:
+//   P = softmax_fp32(Q K^T * dh^-1/2 + mask) ; O = bf16(P) V, bidirectional or causal, keys >= key_len[b]
+// masked (the reference's additive [B,1,S,S] mask is never materialised: right padding => a length).
+// q/k arrive already rotated (rope_kernel), laid out as qkv[T,3d] (q | k | v, head h at column h*64).
+//
+// Formulation (one wave per 32-row tile, dh = 64): scores are computed TRANSPOSED,
+//   S^T[key][query] = K_tile Q_tile^T, so a lane owns ONE query column: the softmax statistics
+// (m, l, lse, delta) are lane-local scalars, and the bf16 P^T accumulator registers are directly the
+// B operand of the next MFMA  O^T[dh][query] += V^T[dh][key] P^T[key][query].  The only transposed
+// operand (V^T, K^T, Q^T, dO^T: contraction index strided in memory) is read from a 4 KB LDS tile with
+// gfx950's ds_read_b64_tr_b16.  Backward = delta kernel + dQ kernel (per query tile) + dK/dV kernel
+// (per key tile); no atomics, P recomputed from the saved log-sum-exp.
+#include "common.h"
+#include "kernels.h"
+
+#define LDS_AS __attribute__((address_space(3)))
+
+namespace {
+
+constexpr float kScale = 0.125f;  // head_dim^-0.5, head_dim = 64
+
+__device__ __forceinline__ int swz(int row, int byte_in_row) {
+  return row * 128 + (byte_in_row ^ (((row >> 1) & 1) << 6));
+}
+
+// [32 rows][64 dh] bf16 tile -> LDS (rows >= row_lim are zero-filled so masked probabilities never meet NaNs)
+__device__ __forceinline__ void load_tile(unsigned char* lds, const bf16_t* __restrict__ base, int r0, int row_lim,
+                                          size_t pitch, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + i * 64;
+    const int row = c >> 3, ch = c & 7;
+    const int gr = r0 + row;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (gr < row_lim) v = *reinterpret_cast<const uint4*>(base + (size_t)gr * pitch + ch * 8);
+    *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = v;
+  }
+}
+
+// MFMA operand whose "row/col" index is the tile row (lane&31) and whose k-chunk is dh [16s + 8*hi, +8)
+__device__ __forceinline__ bf16x8_t frag_rows(const unsigned char* lds, int s, int lane) {
+  const uint4 v = *reinterpret_cast<const uint4*>(lds + swz(lane & 31, (2 * s + (lane >> 5)) * 16));
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ bf16x8_t frag_global(const bf16_t* __restrict__ base, int row, int row_lim, size_t pitch, int s,
+                                                int lane) {
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (row < row_lim) v = *reinterpret_cast<const uint4*>(base + (size_t)row * pitch + 16 * s + (lane >> 5) * 8);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+// transposed operand: MFMA row = dh (dhb*32 + lane&31), k = tile rows {16j + 4hi + (e&3) + 8(e>>2)}
+__device__ __forceinline__ bf16x8_t frag_tr(const unsigned char* lds, int dhb, int j, int lane) {
+  const int li = lane & 15, g = lane >> 4, hi = lane >> 5;
+  const int colb = (dhb * 32 + (g & 1) * 16 + (li & 3) * 4) * 2;
+  const int ra = 16 * j + 4 * hi + (li >> 2);
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(lds + swz(ra, colb)));
+  const bf16x4_t up = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(lds + swz(ra + 8, colb)));
+  bf16x8_t o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+  o[4] = up[0]; o[5] = up[1]; o[6] = up[2]; o[7] = up[3];
+  return o;
+}
+// accumulator registers [8j, 8j+8) -> bf16 B operand (k = tile rows in the same order as frag_tr)
+__device__ __forceinline__ bf16x8_t acc_to_b(const f32x16_t& a, int j) {
+  uint4 v;
+  v.x = pack2bf(a[8 * j + 0], a[8 * j + 1]);
+  v.y = pack2bf(a[8 * j + 2], a[8 * j + 3]);
+  v.z = pack2bf(a[8 * j + 4], a[8 * j + 5]);
+  v.w = pack2bf(a[8 * j + 6], a[8 * j + 7]);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ f32x16_t zero16() {
+  f32x16_t z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// store a transposed accumulator pair (O^T[dh][row]) as row-major bf16 [row][64 dh]; lane owns row (lane&31)
+__device__ __forceinline__ void store_t(bf16_t* __restrict__ dst_row, const f32x16_t& a0, const f32x16_t& a1, float mul,
+                                        int hi) {
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    uint2 o;
+    o.x = pack2bf(a0[4 * rr + 0] * mul, a0[4 * rr + 1] * mul);
+    o.y = pack2bf(a0[4 * rr + 2] * mul, a0[4 * rr + 3] * mul);
+    *reinterpret_cast<uint2*>(dst_row + 8 * rr + 4 * hi) = o;
+    o.x = pack2bf(a1[4 * rr + 0] * mul, a1[4 * rr + 1] * mul);
+    o.y = pack2bf(a1[4 * rr + 2] * mul, a1[4 * rr + 3] * mul);
+    *reinterpret_cast<uint2*>(dst_row + 32 + 8 * rr + 4 * hi) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
+                                                      bf16_t* __restrict__ out, float* __restrict__ lse, int B, int S,
+                                                      int H, int causal) {
+  __shared__ __attribute__((aligned(16))) unsigned char vt[4096];
+  const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+  const int d = H * 64;
+  const size_t pitch = (size_t)3 * d;
+  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* kb = qb + d;
+  const bf16_t* vb = qb + 2 * d;
+  const int klen = key_len ? key_len[b] : S;
+  const int qrow = q0 + l31;
+
+  bf16x8_t qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = frag_global(qb, qrow, S, pitch, s, lane);
+  f32x16_t o0 = zero16(), o1 = zero16();
+  float m = -INFINITY, l = 0.f;
+  const int kend = causal ? min(klen, q0 + 32) : klen;
+  for (int k0 = 0; k0 < kend; k0 += 32) {
+    f32x16_t sc = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8_t kf = frag_global(kb, k0 + l31, S, pitch, s, lane);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc, 0, 0, 0);
+    }
+    __syncthreads();  // previous tile's transposed reads are done
+    load_tile(vt, vb, k0, S, pitch, lane);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + acc_row(r, hi);
+      const bool ok = key < klen && (!causal || key <= qrow);
+      sc[r] = ok ? sc[r] * kScale : -INFINITY;
+      mx = fmaxf(mx, sc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    const bool dead = m_new == -INFINITY;
+    const float alpha = dead ? 1.f : __expf(m - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = dead ? 0.f : __expf(sc[r] - m_new);
+      sc[r] = p;
+      rs += p;
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    const bf16x8_t pb0 = acc_to_b(sc, 0), pb1 = acc_to_b(sc, 1);
+    __syncthreads();  // V tile visible
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 0, lane), pb0, o0, 0, 0, 0);
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 1, lane), pb1, o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 0, lane), pb0, o1, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 1, lane), pb1, o1, 0, 0, 0);
+  }
+  if (qrow < S) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    store_t(out + ((size_t)b * S + qrow) * d + h * 64, o0, o1, inv, hi);
+    if (hi == 0 && lse) lse[((size_t)b * H + h) * S + qrow] = l > 0.f ? m + __logf(l) : 0.f;
+  }
+}
+
+// delta[b,h,q] = sum_dh dO*O  (8 lanes per (token, head))
+__global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+                                                         float* __restrict__ delta, int B, int S, int H) {
+  const long total = (long)B * S * H * 8;
+  const int d = H * 64;
+  for (long w = (long)blockIdx.x * 256 + threadIdx.x; w < total; w += (long)gridDim.x * 256) {
+    const int c = (int)(w & 7);
+    const long th = w >> 3;
+    const int h = (int)(th % H);
+    const long t = th / H;
+    float a[8], g[8];
+    unpack8(*reinterpret_cast<const uint4*>(out + t * d + h * 64 + c * 8), a);
+    unpack8(*reinterpret_cast<const uint4*>(dout + t * d + h * 64 + c * 8), g);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += a[e] * g[e];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (c == 0) {
+      const int bb = (int)(t / S), ss = (int)(t % S);
+      delta[((size_t)bb * H + h) * S + ss] = s;
+    }
+  }
+}
+
+// dQ^T[dh][q] = sum_keys K^T[dh][key] dS^T[key][q],  dS^T = P^T (dP^T - delta_q) * scale
+__global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                         const float* __restrict__ lse, const float* __restrict__ delta,
+                                                         const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
+                                                         int B, int S, int H, int causal) {
+  __shared__ __attribute__((aligned(16))) unsigned char kt[4096];
+  const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+  const int d = H * 64;
+  const size_t pitch = (size_t)3 * d;
+  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* kb = qb + d;
+  const bf16_t* vb = qb + 2 * d;
+  const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
+  const int klen = key_len ? key_len[b] : S;
+  const int qrow = q0 + l31;
+  bf16x8_t qf[4], dof[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qf[s] = frag_global(qb, qrow, S, pitch, s, lane);
+    dof[s] = frag_global(dob, qrow, S, (size_t)d, s, lane);
+  }
+  const size_t sidx = ((size_t)b * H + h) * S + min(qrow, S - 1);
+  const float lse_q = lse[sidx], dl_q = delta[sidx];
+  f32x16_t a0 = zero16(), a1 = zero16();
+  const int kend = causal ? min(klen, q0 + 32) : klen;
+  for (int k0 = 0; k0 < kend; k0 += 32) {
+    __syncthreads();
+    load_tile(kt, kb, k0, S, pitch, lane);
+    f32x16_t dp = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8_t vf = frag_global(vb, k0 + l31, S, pitch, s, lane);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dp, 0, 0, 0);
+    }
+    __syncthreads();
+    f32x16_t sc = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), qf[s], sc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + acc_row(r, hi);
+      const bool ok = key < klen && (!causal || key <= qrow) && qrow < S;
+      const float p = ok ? __expf(sc[r] * kScale - lse_q) : 0.f;
+      sc[r] = p * (dp[r] - dl_q) * kScale;
+    }
+    const bf16x8_t ds0 = acc_to_b(sc, 0), ds1 = acc_to_b(sc, 1);
+    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 0, lane), ds0, a0, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 1, lane), ds1, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 0, lane), ds0, a1, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 1, lane), ds1, a1, 0, 0, 0);
+  }
+  if (qrow < S) store_t(dqkv + ((size_t)b * S + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
+}
+
+// dV^T[dh][key] = sum_q dO^T[dh][q] P[q][key] ; dK^T[dh][key] = sum_q Q^T[dh][q] dS[q][key]
+__global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
+                                                          int B, int S, int H, int causal) {
+  __shared__ __attribute__((aligned(16))) unsigned char qt[4096];
+  __shared__ __attribute__((aligned(16))) unsigned char dot_[4096];
+  __shared__ float lse_s[32], dl_s[32];
+  const int k0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+  const int d = H * 64;
+  const size_t pitch = (size_t)3 * d;
+  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* kb = qb + d;
+  const bf16_t* vb = qb + 2 * d;
+  const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
+  const int klen = key_len ? key_len[b] : S;
+  const int krow = k0 + l31;
+  bf16x8_t kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = frag_global(kb, krow, S, pitch, s, lane);
+    vf[s] = frag_global(vb, krow, S, pitch, s, lane);
+  }
+  f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+  const bool key_ok = krow < klen;
+  const int qstart = causal ? k0 : 0;  // queries before the key tile never see it
+  if (k0 < klen) {
+    for (int q0 = qstart; q0 < S; q0 += 32) {
+      __syncthreads();
+      load_tile(qt, qb, q0, S, pitch, lane);
+      load_tile(dot_, dob, q0, S, (size_t)d, lane);
+      if (lane < 32) {
+        const int q = min(q0 + lane, S - 1);
+        lse_s[lane] = lse[((size_t)b * H + h) * S + q];
+        dl_s[lane] = delta[((size_t)b * H + h) * S + q];
+      }
+      __syncthreads();
+      f32x16_t sc = zero16(), dp = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, s, lane), kf[s], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dot_, s, lane), vf[s], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = acc_row(r, hi);
+        const int q = q0 + qi;
+        const bool ok = key_ok && q < S && (!causal || krow <= q);
+        const float p = ok ? __expf(sc[r] * kScale - lse_s[qi]) : 0.f;
+        sc[r] = p;
+        dp[r] = p * (dp[r] - dl_s[qi]) * kScale;
+      }
+      const bf16x8_t p0 = acc_to_b(sc, 0), p1 = acc_to_b(sc, 1);
+      const bf16x8_t s0 = acc_to_b(dp, 0), s1 = acc_to_b(dp, 1);
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 0, lane), p0, dv0, 0, 0, 0);
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 1, lane), p1, dv0, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 1, 0, lane), p0, dv1, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 1, 1, lane), p1, dv1, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 0, 0, lane), s0, dk0, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 0, 1, lane), s1, dk0, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 0, lane), s0, dk1, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 1, lane), s1, dk1, 0, 0, 0);
+    }
+  }
+  if (krow < S) {
+    bf16_t* row = dqkv + ((size_t)b * S + krow) * pitch + h * 64;
+    store_t(row + d, dk0, dk1, 1.f, hi);
+    store_t(row + 2 * d, dv0, dv1, 1.f, hi);
+  }
+}
+
+}  // namespace
+
+int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
+               hipStream_t st) {
+  if (B == 0 || S == 0) return 0;
+  dim3 grid((S + 31) / 32, H, B);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, key_len, (bf16_t*)out, lse, B, S, H,
+                     causal);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
+               float* delta_ws, int B, int S, int H, int causal, hipStream_t st) {
+  if (B == 0 || S == 0) return 0;
+  const long work = (long)B * S * H * 8;
+  int g = (int)((work + 255) / 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta_ws, B, S,
+                     H);
+  dim3 grid((S + 31) / 32, H, B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta_ws,
+                     key_len, (bf16_t*)dqkv, B, S, H, causal);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta_ws,
+                     key_len, (bf16_t*)dqkv, B, S, H, causal);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,815 @@
+// libgget_hip.so - engine object behind the C ABI of include/gget.h.
+// Owns no memory: the caller (PyTorch in our binding) hands in the parameter / optimizer / gradient /
+// workspace arenas; the engine lays tensors out inside them and enqueues HIP kernels on the caller's
+// stream.  Forward/backward structure follows the reference call stack:
+//   GraphGPTPretrainBase.forward  modeling_pretrain.py:152-266   -> gget_forward_pretrain
+//   GraphGPTTaskModel.forward     modeling_finetune.py:236-326   -> gget_forward_task
+//   hf LlamaModel / LlamaDecoderLayer.forward :367-418 / :295-325 -> layer_forward / layer_backward
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "gemm.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void gget_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* gget_last_error(void) { return g_err; }
+extern "C" int gget_version(void) { return 100; }
+
+namespace {
+
+inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+struct ParamRec {
+  std::string name;
+  int ndim;
+  int64_t shape[2];
+  uint64_t off;     // elements into flat arrays
+  uint64_t count;   // elements (unpadded)
+  int layer;        // -1 embeddings, 0..L-1, L = final norm + heads
+  bool accum32;     // gradient accumulated in fp32 scratch (atomics), converted to bf16 afterwards
+  uint64_t off32;   // element offset in the fp32 scratch
+};
+
+struct LayerOff {
+  uint64_t ln1, wqkv, wo, lam1, ln2, wgu, wdown, lam2;
+  uint64_t ln1_32, lam1_32, ln2_32, lam2_32;
+};
+
+struct Plan {
+  std::vector<ParamRec> params;
+  uint64_t n_params = 0;    // padded flat length
+  uint64_t n_scratch32 = 0; // fp32 accumulation elements
+  std::vector<LayerOff> layers;
+  uint64_t emb = 0, emb32 = 0, gate = 0, gate32 = 0, normf = 0, normf32 = 0;
+  uint64_t ntp = 0, lm = 0, lm32 = 0, score = 0, score32 = 0, sbias = 0, sbias32 = 0;
+  bool has_gate = false, has_ntp = false, has_ls = false;
+};
+
+void add_param(Plan& pl, const std::string& name, int64_t r, int64_t c, int layer, bool accum32, uint64_t* off_out,
+               uint64_t* off32_out) {
+  ParamRec p;
+  p.name = name;
+  p.ndim = c > 0 ? 2 : 1;
+  p.shape[0] = r;
+  p.shape[1] = c > 0 ? c : 0;
+  p.count = (uint64_t)r * (uint64_t)(c > 0 ? c : 1);
+  p.off = pl.n_params;
+  p.layer = layer;
+  p.accum32 = accum32;
+  p.off32 = 0;
+  pl.n_params += align_up(p.count, 128);
+  if (accum32) {
+    p.off32 = pl.n_scratch32;
+    pl.n_scratch32 += align_up(p.count, 128);
+  }
+  if (off_out) *off_out = p.off;
+  if (off32_out) *off32_out = p.off32;
+  pl.params.push_back(p);
+}
+
+// Parameter table = reference state-dict keys ("Checkpoint / resume" row).
+Plan make_plan(const gget_config_t& c) {
+  Plan pl;
+  const int64_t d = c.hidden_size, ff = c.intermediate_size, V = c.vocab_size, F = c.stacked_feat, L = c.num_layers;
+  pl.has_gate = c.gated_agg != 0;
+  pl.has_ls = c.layer_scale_init > 0.f;
+  pl.has_ntp = c.kind == GGET_KIND_PRETRAIN && c.next_n_token > 1;
+  add_param(pl, "model.embed_tokens.weight", V, d, -1, true, &pl.emb, &pl.emb32);
+  if (pl.has_gate) add_param(pl, "stacked_feat_agg.weight", F, d, -1, true, &pl.gate, &pl.gate32);
+  pl.layers.resize(L);
+  for (int i = 0; i < L; ++i) {
+    LayerOff& lo = pl.layers[i];
+    const std::string p = "model.layers." + std::to_string(i) + ".";
+    add_param(pl, p + "input_layernorm.weight", d, 0, i, true, &lo.ln1, &lo.ln1_32);
+    add_param(pl, p + "self_attn.q_proj.weight", d, d, i, false, &lo.wqkv, nullptr);
+    add_param(pl, p + "self_attn.k_proj.weight", d, d, i, false, nullptr, nullptr);
+    add_param(pl, p + "self_attn.v_proj.weight", d, d, i, false, nullptr, nullptr);
+    add_param(pl, p + "self_attn.o_proj.weight", d, d, i, false, &lo.wo, nullptr);
+    if (pl.has_ls) add_param(pl, p + "lambda_1", d, 0, i, true, &lo.lam1, &lo.lam1_32);
+    add_param(pl, p + "post_attention_layernorm.weight", d, 0, i, true, &lo.ln2, &lo.ln2_32);
+    add_param(pl, p + "mlp.gate_proj.weight", ff, d, i, false, &lo.wgu, nullptr);
+    add_param(pl, p + "mlp.up_proj.weight", ff, d, i, false, nullptr, nullptr);
+    add_param(pl, p + "mlp.down_proj.weight", d, ff, i, false, &lo.wdown, nullptr);
+    if (pl.has_ls) add_param(pl, p + "lambda_2", d, 0, i, true, &lo.lam2, &lo.lam2_32);
+  }
+  add_param(pl, "model.norm.weight", d, 0, (int)L, true, &pl.normf, &pl.normf32);
+  if (c.kind == GGET_KIND_PRETRAIN) {
+    if (pl.has_ntp) add_param(pl, "n_token_proj.weight", (int64_t)c.next_n_token * d, d, (int)L, false, &pl.ntp, nullptr);
+    add_param(pl, "lm_head.weight", V, d, (int)L, true, &pl.lm, &pl.lm32);
+  } else {
+    add_param(pl, "score.weight", c.num_labels, d, (int)L, true, &pl.score, &pl.score32);
+    if (c.score_bias) add_param(pl, "score.bias", c.num_labels, 0, (int)L, true, &pl.sbias, &pl.sbias32);
+  }
+  return pl;
+}
+
+// bump allocator over the workspace arena
+struct Bump {
+  uint64_t off = 0;
+  uint64_t take(uint64_t bytes) {
+    const uint64_t o = off;
+    off += align_up(bytes, 256);
+    return o;
+  }
+};
+
+struct LayerWs {
+  uint64_t rstd1, xn1, qkv, lse, attn, araw, xmid, rstd2, xn2, gu, h, mraw;
+};
+
+struct Ws {
+  uint64_t key_len, pool_row, cos_tab, sin_tab;
+  std::vector<uint64_t> xres;  // L+1 residual-stream snapshots
+  std::vector<LayerWs> lw;
+  uint64_t rstd_f, hidden;
+  uint64_t dxa, dxb, dxc, dxn, dqkv, dattn, dgu, dh, delta, dscaled;
+  uint64_t scratch32, loss_sum, sqnorm, counts, segs;
+  // pre-train head
+  uint64_t cnt, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
+  // task head
+  uint64_t tlogits, tdlogits, pooled_h;
+  uint64_t total;
+};
+
+Ws make_ws(const gget_config_t& c, const Plan& pl) {
+  Ws w;
+  Bump b;
+  const uint64_t T = c.max_tokens, d = c.hidden_size, ff = c.intermediate_size, H = c.num_heads, L = c.num_layers;
+  const uint64_t Bm = c.max_batch;
+  w.key_len = b.take(Bm * 4);
+  w.pool_row = b.take(Bm * 4);
+  w.cos_tab = b.take((uint64_t)c.max_position * 32 * 4);
+  w.sin_tab = b.take((uint64_t)c.max_position * 32 * 4);
+  w.xres.resize(L + 1);
+  for (uint64_t i = 0; i <= L; ++i) w.xres[i] = b.take(T * d * 2);
+  w.lw.resize(L);
+  for (uint64_t i = 0; i < L; ++i) {
+    LayerWs& l = w.lw[i];
+    l.rstd1 = b.take(T * 4);
+    l.xn1 = b.take(T * d * 2);
+    l.qkv = b.take(T * 3 * d * 2);
+    l.lse = b.take(T * H * 4);
+    l.attn = b.take(T * d * 2);
+    l.araw = pl.has_ls ? b.take(T * d * 2) : 0;
+    l.xmid = b.take(T * d * 2);
+    l.rstd2 = b.take(T * 4);
+    l.xn2 = b.take(T * d * 2);
+    l.gu = b.take(T * 2 * ff * 2);
+    l.h = b.take(T * ff * 2);
+    l.mraw = pl.has_ls ? b.take(T * d * 2) : 0;
+  }
+  w.rstd_f = b.take(T * 4);
+  w.hidden = b.take(T * d * 2);
+  w.dxa = b.take(T * d * 2);
+  w.dxb = b.take(T * d * 2);
+  w.dxc = b.take(T * d * 2);
+  w.dxn = b.take(T * d * 2);
+  w.dqkv = b.take(T * 3 * d * 2);
+  w.dattn = b.take(T * d * 2);
+  w.dgu = b.take(T * 2 * ff * 2);
+  w.dh = b.take(T * ff * 2);
+  w.delta = b.take(T * H * 4);
+  w.dscaled = pl.has_ls ? b.take(T * d * 2) : 0;
+  w.scratch32 = b.take(pl.n_scratch32 * 4);
+  w.loss_sum = b.take(256);
+  w.sqnorm = b.take(256);
+  w.counts = b.take(256);
+  w.segs = b.take((uint64_t)pl.params.size() * sizeof(GgetSegment));
+  if (c.kind == GGET_KIND_PRETRAIN) {
+    const uint64_t n = c.next_n_token, Vp = align_up(c.vocab_size, 64);
+    w.cnt = b.take(T * 4);
+    w.m_off = b.take(T * 4);
+    w.l_off = b.take(T * 4);
+    w.row_idx = b.take(T * 4);
+    w.sel_src = b.take(T * n * 4);
+    w.sel_label = b.take(T * n * 4);
+    w.sel_tok = b.take(T * n * 4);
+    w.Hm = b.take(T * d * 2);
+    w.dHm = b.take(T * d * 2);
+    if (n > 1) {
+      w.Pp = b.take(T * n * d * 2);
+      w.Hl = b.take(T * n * d * 2);
+      w.dHl = b.take(T * n * d * 2);
+      w.dP = b.take(T * n * d * 2);
+    } else {
+      w.Pp = w.Hl = w.Hm;
+      w.dHl = w.dP = w.dHm;
+    }
+    w.logits = b.take(T * n * Vp * 2);
+    w.dlogits = b.take(T * n * Vp * 2);
+  } else {
+    w.tlogits = b.take(Bm * c.num_labels * 4);
+    w.tdlogits = b.take(Bm * c.num_labels * 4);
+    w.pooled_h = b.take(Bm * d * 2);
+  }
+  w.total = b.off;
+  return w;
+}
+
+int check_cfg(const gget_config_t* c) {
+  GGET_REQUIRE(c != nullptr, "null config");
+  GGET_REQUIRE(c->hidden_size > 0 && c->hidden_size % 64 == 0, "hidden_size must be a positive multiple of 64");
+  GGET_REQUIRE(c->num_heads * 64 == c->hidden_size, "num_heads*64 must equal hidden_size (head_dim is 64)");
+  GGET_REQUIRE(c->intermediate_size > 0 && c->intermediate_size % 64 == 0, "intermediate_size must be a multiple of 64");
+  GGET_REQUIRE(c->hidden_size <= 2048, "hidden_size > 2048 not supported by the norm kernels");
+  GGET_REQUIRE(c->vocab_size > 1 && c->num_layers >= 1 && c->stacked_feat >= 1, "bad vocab/layers/stacked_feat");
+  GGET_REQUIRE(c->kind == GGET_KIND_PRETRAIN || c->kind == GGET_KIND_TASK, "bad kind");
+  GGET_REQUIRE(c->max_tokens > 0 && c->max_batch > 0 && c->max_position > 0, "bad capacities");
+  if (c->kind == GGET_KIND_PRETRAIN) GGET_REQUIRE(c->next_n_token >= 1, "next_n_token must be >= 1");
+  else GGET_REQUIRE(c->num_labels >= 1, "num_labels must be >= 1");
+  return 0;
+}
+
+}  // namespace
+
+struct gget_engine {
+  gget_config_t cfg;
+  Plan plan;
+  Ws ws;
+  bf16_t* P;
+  float* master;
+  float* am;
+  float* av;
+  bf16_t* G;
+  unsigned char* W;
+  const float* cos_tab;
+  const float* sin_tab;
+  // bucket -> [first,last) params, segments
+  std::vector<std::pair<uint64_t, uint64_t>> bucket_range;  // elements
+  std::vector<std::pair<int, int>> bucket_segs;              // [first, count) into the device segment table
+  // state of the last forward
+  int B = 0, S = 0, T = 0;
+  const int64_t* ids = nullptr;
+  const int64_t* pos = nullptr;
+  const float* sample_wgt = nullptr;
+  bool have_labels = false;
+  int problem = 0;
+  bool fwd_valid = false;
+  bf16_t* dx_cur = nullptr;  // gradient w.r.t. the residual stream entering the next backward stage
+
+  template <typename Tp>
+  Tp* wsp(uint64_t off) const { return reinterpret_cast<Tp*>(W + off); }
+  int bucket_of_layer(int layer) const {  // completion order: heads(L) first, then L-1..0, then embeddings(-1)
+    const int L = cfg.num_layers;
+    if (layer == L) return 0;
+    if (layer < 0) return L + 1;
+    return L - layer;
+  }
+};
+
+// ================================================================================================
+// creation / introspection
+// ================================================================================================
+extern "C" int gget_query_sizes(const gget_config_t* cfg, gget_sizes_t* out) {
+  if (int e = check_cfg(cfg)) return e;
+  GGET_REQUIRE(out != nullptr, "null out");
+  Plan pl = make_plan(*cfg);
+  Ws w = make_ws(*cfg, pl);
+  out->n_params = pl.n_params;
+  out->param_bf16_bytes = pl.n_params * 2;
+  out->master_bytes = pl.n_params * 4;
+  out->adam_bytes = pl.n_params * 8;
+  out->grad_bf16_bytes = pl.n_params * 2;
+  out->workspace_bytes = w.total;
+  return 0;
+}
+
+extern "C" int gget_create(const gget_config_t* cfg, const gget_buffers_t* bufs, gget_handle_t* out) {
+  if (int e = check_cfg(cfg)) return e;
+  GGET_REQUIRE(bufs && out, "null argument");
+  GGET_REQUIRE(bufs->param_bf16_dev && bufs->grad_bf16_dev && bufs->workspace_dev, "missing device arenas");
+  gget_engine* h = new gget_engine();
+  h->cfg = *cfg;
+  h->plan = make_plan(*cfg);
+  h->ws = make_ws(*cfg, h->plan);
+  h->P = static_cast<bf16_t*>(bufs->param_bf16_dev);
+  h->master = static_cast<float*>(bufs->master_dev);
+  h->am = static_cast<float*>(bufs->adam_m_dev);
+  h->av = static_cast<float*>(bufs->adam_v_dev);
+  h->G = static_cast<bf16_t*>(bufs->grad_bf16_dev);
+  h->W = static_cast<unsigned char*>(bufs->workspace_dev);
+  // gradient buckets in completion order + fp32->bf16 conversion segments per bucket
+  const int L = cfg->num_layers;
+  const int nb = L + 2;
+  h->bucket_range.assign(nb, {UINT64_MAX, 0});
+  std::vector<std::vector<GgetSegment>> segs(nb);
+  for (const ParamRec& p : h->plan.params) {
+    const int b = h->bucket_of_layer(p.layer);
+    auto& r = h->bucket_range[b];
+    r.first = std::min(r.first, p.off);
+    r.second = std::max(r.second, p.off + align_up(p.count, 128));
+    if (p.accum32) segs[b].push_back(GgetSegment{p.off32, p.off, align_up(p.count, 128)});
+  }
+  std::vector<GgetSegment> flat;
+  h->bucket_segs.resize(nb);
+  for (int b = 0; b < nb; ++b) {
+    h->bucket_segs[b] = {(int)flat.size(), (int)segs[b].size()};
+    flat.insert(flat.end(), segs[b].begin(), segs[b].end());
+  }
+  if (!flat.empty()) {
+    hipError_t e = hipMemcpy(h->W + h->ws.segs, flat.data(), flat.size() * sizeof(GgetSegment), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      gget_set_error("segment table upload failed: %s", hipGetErrorString(e));
+      delete h;
+      return 1;
+    }
+  }
+  if (bufs->rope_cos_dev && bufs->rope_sin_dev) {
+    h->cos_tab = bufs->rope_cos_dev;
+    h->sin_tab = bufs->rope_sin_dev;
+  } else {
+    float* ct = h->wsp<float>(h->ws.cos_tab);
+    float* st = h->wsp<float>(h->ws.sin_tab);
+    if (k_rope_table(ct, st, cfg->max_position, cfg->rope_theta, nullptr)) { delete h; return 1; }
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { gget_set_error("rope table: %s", hipGetErrorString(e)); delete h; return 1; }
+    h->cos_tab = ct;
+    h->sin_tab = st;
+  }
+  *out = h;
+  return 0;
+}
+
+extern "C" int gget_destroy(gget_handle_t h) {
+  delete h;
+  return 0;
+}
+
+extern "C" int gget_param_count(gget_handle_t h) { return h ? (int)h->plan.params.size() : -1; }
+
+extern "C" int gget_param_info(gget_handle_t h, int index, gget_param_info_t* out) {
+  GGET_REQUIRE(h && out, "null argument");
+  GGET_REQUIRE(index >= 0 && index < (int)h->plan.params.size(), "param index %d out of range", index);
+  const ParamRec& p = h->plan.params[index];
+  memset(out, 0, sizeof(*out));
+  snprintf(out->name, sizeof(out->name), "%s", p.name.c_str());
+  out->ndim = p.ndim;
+  out->shape[0] = p.shape[0];
+  out->shape[1] = p.shape[1];
+  out->offset = p.off;
+  out->layer = p.layer;
+  return 0;
+}
+
+extern "C" int gget_bucket_count(gget_handle_t h) { return h ? (int)h->bucket_range.size() : -1; }
+
+extern "C" int gget_bucket_range(gget_handle_t h, int bucket, uint64_t* offset, uint64_t* count) {
+  GGET_REQUIRE(h && offset && count, "null argument");
+  GGET_REQUIRE(bucket >= 0 && bucket < (int)h->bucket_range.size(), "bucket %d out of range", bucket);
+  const auto& r = h->bucket_range[bucket];
+  *offset = r.first;
+  *count = r.second - r.first;
+  return 0;
+}
+
+extern "C" int gget_sync_params(gget_handle_t h, void* stream) {
+  GGET_REQUIRE(h && h->master, "sync_params needs the fp32 master arena");
+  return k_f32_to_bf16(h->master, h->P, h->plan.n_params, (hipStream_t)stream);
+}
+
+// ================================================================================================
+// forward
+// ================================================================================================
+namespace {
+
+int gemm_nt(const void* A, const void* Bw, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
+            const int* m_dev, hipStream_t st) {
+  return gget_gemm_single(GGET_GEMM_NT, R ? GGET_EPI_RESIDUAL : GGET_EPI_NONE, A, Bw, C, R, M, N, K, lda, ldb, ldc, m_dev,
+                          nullptr, 1, st);
+}
+int gemm_nn(const void* A, const void* Bw, void* C, int M, int N, int K, int lda, int ldb, int ldc, const int* m_dev,
+            hipStream_t st) {
+  return gget_gemm_single(GGET_GEMM_NN, GGET_EPI_NONE, A, Bw, C, nullptr, M, N, K, lda, ldb, ldc, m_dev, nullptr, 1, st);
+}
+
+// out = res + lam * y   (LayerScale residual, utils_graphgpt.py:153-166) ; bwd: dscaled = lam*dy, dlam += sum_t dy*y
+__global__ void __launch_bounds__(256) ls_fwd_kernel(const bf16_t* __restrict__ res, const bf16_t* __restrict__ y,
+                                                     const bf16_t* __restrict__ lam, bf16_t* __restrict__ out, long T, int d) {
+  const int cpr = d >> 3;
+  const long total = T * cpr;
+  for (long w = (long)blockIdx.x * 256 + threadIdx.x; w < total; w += (long)gridDim.x * 256) {
+    const int c = (int)(w % cpr);
+    float r[8], v[8], l[8];
+    unpack8(*reinterpret_cast<const uint4*>(res + w * 8), r);
+    unpack8(*reinterpret_cast<const uint4*>(y + w * 8), v);
+    unpack8(*reinterpret_cast<const uint4*>(lam + c * 8), l);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] += bf2f(f2bf(l[e] * v[e]));
+    *reinterpret_cast<uint4*>(out + w * 8) = pack8(r);
+  }
+}
+__global__ void __launch_bounds__(256) ls_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
+                                                     const bf16_t* __restrict__ lam, bf16_t* __restrict__ dscaled,
+                                                     float* __restrict__ dlam, int T, int d) {
+  // one thread per 8 channels, rows strided over blockIdx.y
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c * 8 >= d) return;
+  float l[8], acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unpack8(*reinterpret_cast<const uint4*>(lam + c * 8), l);
+  for (int t = blockIdx.y; t < T; t += gridDim.y) {
+    float g[8], v[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(dy + (size_t)t * d + c * 8), g);
+    unpack8(*reinterpret_cast<const uint4*>(y + (size_t)t * d + c * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o[e] = l[e] * g[e]; acc[e] += g[e] * v[e]; }
+    *reinterpret_cast<uint4*>(dscaled + (size_t)t * d + c * 8) = pack8(o);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dlam + c * 8 + e, acc[e]);
+}
+
+int layer_forward(gget_engine* h, int i, hipStream_t st) {
+  const gget_config_t& c = h->cfg;
+  const int T = h->T, d = c.hidden_size, ff = c.intermediate_size, H = c.num_heads;
+  const LayerOff& lo = h->plan.layers[i];
+  const LayerWs& lw = h->ws.lw[i];
+  bf16_t* x_in = h->wsp<bf16_t>(h->ws.xres[i]);
+  bf16_t* x_out = h->wsp<bf16_t>(h->ws.xres[i + 1]);
+  bf16_t* xn1 = h->wsp<bf16_t>(lw.xn1);
+  bf16_t* qkv = h->wsp<bf16_t>(lw.qkv);
+  bf16_t* attn = h->wsp<bf16_t>(lw.attn);
+  bf16_t* xmid = h->wsp<bf16_t>(lw.xmid);
+  bf16_t* xn2 = h->wsp<bf16_t>(lw.xn2);
+  bf16_t* gu = h->wsp<bf16_t>(lw.gu);
+  bf16_t* hh = h->wsp<bf16_t>(lw.h);
+  if (int e = k_rmsnorm_fwd(x_in, h->P + lo.ln1, xn1, h->wsp<float>(lw.rstd1), T, d, c.rms_eps, st)) return e;
+  if (int e = gemm_nt(xn1, h->P + lo.wqkv, qkv, nullptr, T, 3 * d, d, d, d, 3 * d, nullptr, st)) return e;
+  if (int e = k_rope(qkv, h->cos_tab, h->sin_tab, h->pos, T, h->S, H, 0, st)) return e;
+  if (int e = k_attn_fwd(qkv, h->wsp<int32_t>(h->ws.key_len), attn, h->wsp<float>(lw.lse), h->B, h->S, H, c.causal, st))
+    return e;
+  if (h->plan.has_ls) {
+    bf16_t* araw = h->wsp<bf16_t>(lw.araw);
+    bf16_t* mraw = h->wsp<bf16_t>(lw.mraw);
+    const int g = (int)std::min<long>(4096, ((long)T * (d / 8) + 255) / 256);
+    if (int e = gemm_nt(attn, h->P + lo.wo, araw, nullptr, T, d, d, d, d, d, nullptr, st)) return e;
+    hipLaunchKernelGGL(ls_fwd_kernel, dim3(g), dim3(256), 0, st, x_in, araw, h->P + lo.lam1, xmid, (long)T, d);
+    if (int e = k_rmsnorm_fwd(xmid, h->P + lo.ln2, xn2, h->wsp<float>(lw.rstd2), T, d, c.rms_eps, st)) return e;
+    if (int e = gemm_nt(xn2, h->P + lo.wgu, gu, nullptr, T, 2 * ff, d, d, d, 2 * ff, nullptr, st)) return e;
+    if (int e = k_geglu_fwd(gu, hh, T, ff, st)) return e;
+    if (int e = gemm_nt(hh, h->P + lo.wdown, mraw, nullptr, T, d, ff, ff, ff, d, nullptr, st)) return e;
+    hipLaunchKernelGGL(ls_fwd_kernel, dim3(g), dim3(256), 0, st, xmid, mraw, h->P + lo.lam2, x_out, (long)T, d);
+    GGET_LAUNCH_CHECK();
+    return 0;
+  }
+  if (int e = gemm_nt(attn, h->P + lo.wo, xmid, x_in, T, d, d, d, d, d, nullptr, st)) return e;
+  if (int e = k_rmsnorm_fwd(xmid, h->P + lo.ln2, xn2, h->wsp<float>(lw.rstd2), T, d, c.rms_eps, st)) return e;
+  if (int e = gemm_nt(xn2, h->P + lo.wgu, gu, nullptr, T, 2 * ff, d, d, d, 2 * ff, nullptr, st)) return e;
+  if (int e = k_geglu_fwd(gu, hh, T, ff, st)) return e;
+  if (int e = gemm_nt(hh, h->P + lo.wdown, x_out, xmid, T, d, ff, ff, ff, d, nullptr, st)) return e;
+  return 0;
+}
+
+int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t* mask, const int64_t* pos, int B, int S,
+                     hipStream_t st) {
+  const gget_config_t& c = h->cfg;
+  GGET_REQUIRE(B > 0 && S > 0, "empty batch");
+  GGET_REQUIRE((long)B * S <= c.max_tokens && B <= c.max_batch, "batch %dx%d exceeds capacity (%d tokens, %d rows)", B, S,
+               c.max_tokens, c.max_batch);
+  GGET_REQUIRE(S <= c.max_position, "sequence length %d exceeds max_position %d", S, c.max_position);
+  h->B = B; h->S = S; h->T = B * S;
+  h->ids = ids; h->pos = pos;
+  const int d = c.hidden_size;
+  if (int e = k_lengths(mask, c.kind == GGET_KIND_TASK ? ids : nullptr, ldF, c.pad_token_id,
+                        h->wsp<int32_t>(h->ws.key_len), c.kind == GGET_KIND_TASK ? h->wsp<int32_t>(h->ws.pool_row) : nullptr,
+                        B, S, st))
+    return e;
+  if (int e = k_embed_fwd(ids, h->P + h->plan.emb, h->plan.has_gate ? h->P + h->plan.gate : nullptr,
+                          h->wsp<bf16_t>(h->ws.xres[0]), h->T, c.stacked_feat, ldF, d, st))
+    return e;
+  for (int i = 0; i < c.num_layers; ++i)
+    if (int e = layer_forward(h, i, st)) return e;
+  return k_rmsnorm_fwd(h->wsp<bf16_t>(h->ws.xres[c.num_layers]), h->P + h->plan.normf, h->wsp<bf16_t>(h->ws.hidden),
+                       h->wsp<float>(h->ws.rstd_f), h->T, d, c.rms_eps, st);
+}
+
+}  // namespace
+
+extern "C" int gget_forward_pretrain(gget_handle_t h, const int64_t* input_ids_dev, const int64_t* attention_mask_dev,
+                                     const int64_t* labels_dev, const float* sample_wgt_dev,
+                                     const int64_t* position_ids_dev, int B, int S, float* loss_dev, void* stream) {
+  GGET_REQUIRE(h && input_ids_dev, "null argument");
+  GGET_REQUIRE(h->cfg.kind == GGET_KIND_PRETRAIN, "handle was not created as a pre-train model");
+  hipStream_t st = (hipStream_t)stream;
+  const gget_config_t& c = h->cfg;
+  h->fwd_valid = false;
+  if (int e = backbone_forward(h, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st)) return e;
+  const Ws& w = h->ws;
+  const int T = h->T, d = c.hidden_size, n = c.next_n_token, V = c.vocab_size;
+  const int Vp = (int)align_up(V, 64);
+  int32_t* counts = h->wsp<int32_t>(w.counts);
+  if (int e = k_head_compact(labels_dev, T, n, h->wsp<int32_t>(w.cnt), h->wsp<int32_t>(w.m_off), h->wsp<int32_t>(w.l_off),
+                             counts, h->wsp<int32_t>(w.row_idx), h->wsp<int32_t>(w.sel_src), h->wsp<int32_t>(w.sel_label),
+                             h->wsp<int32_t>(w.sel_tok), st))
+    return e;
+  if (int e = k_gather_rows(h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.row_idx), counts, h->wsp<bf16_t>(w.Hm), T, d, 0, st))
+    return e;
+  if (h->plan.has_ntp) {
+    if (int e = gemm_nt(h->wsp<bf16_t>(w.Hm), h->P + h->plan.ntp, h->wsp<bf16_t>(w.Pp), nullptr, T, n * d, d, d, d, n * d,
+                        counts, st))
+      return e;
+    if (int e = k_gather_rows(h->wsp<bf16_t>(w.Pp), h->wsp<int32_t>(w.sel_src), counts + 1, h->wsp<bf16_t>(w.Hl), T * n, d, 0,
+                              st))
+      return e;
+  }
+  if (int e = gemm_nt(h->wsp<bf16_t>(w.Hl), h->P + h->plan.lm, h->wsp<bf16_t>(w.logits), nullptr, T * n, V, d, d, d, Vp,
+                      counts + 1, st))
+    return e;
+  h->have_labels = labels_dev != nullptr;
+  h->sample_wgt = sample_wgt_dev;
+  if (labels_dev) {
+    const int mean_rows = sample_wgt_dev == nullptr;
+    const float base = 1.0f / (float)((long)B * S * n);  // dLM normaliser, modeling_pretrain.py:230-236
+    if (int e = k_ce_fwd_bwd(h->wsp<bf16_t>(w.logits), Vp, h->wsp<int32_t>(w.sel_label), h->wsp<int32_t>(w.sel_tok),
+                             sample_wgt_dev, S, counts + 1, T * n, V, h->wsp<float>(w.loss_sum), h->wsp<bf16_t>(w.dlogits),
+                             base, mean_rows, loss_dev, st))
+      return e;
+  }
+  h->fwd_valid = true;
+  return 0;
+}
+
+extern "C" int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, const int64_t* attention_mask_dev,
+                                 const int64_t* position_ids_dev, const void* task_labels_dev, const float* sample_wgt_dev,
+                                 int problem_type, int B, int S, float* loss_dev, float* task_logits_dev,
+                                 void* task_hidden_dev, void* stream) {
+  GGET_REQUIRE(h && input_ids_dev, "null argument");
+  GGET_REQUIRE(h->cfg.kind == GGET_KIND_TASK, "handle was not created as a task model");
+  hipStream_t st = (hipStream_t)stream;
+  const gget_config_t& c = h->cfg;
+  h->fwd_valid = false;
+  if (int e = backbone_forward(h, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st)) return e;
+  const Ws& w = h->ws;
+  const int d = c.hidden_size, C = c.num_labels;
+  float* lg = h->wsp<float>(w.tlogits);
+  if (int e = k_score_fwd(h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.pool_row), h->P + h->plan.score,
+                          c.score_bias ? h->P + h->plan.sbias : nullptr, lg, h->wsp<bf16_t>(w.pooled_h), B, C, d, st))
+    return e;
+  if (task_logits_dev) GGET_HIP_CHECK(hipMemcpyAsync(task_logits_dev, lg, (size_t)B * C * 4, hipMemcpyDeviceToDevice, st));
+  if (task_hidden_dev)
+    GGET_HIP_CHECK(hipMemcpyAsync(task_hidden_dev, h->wsp<bf16_t>(w.pooled_h), (size_t)B * d * 2, hipMemcpyDeviceToDevice, st));
+  h->have_labels = task_labels_dev != nullptr;
+  h->problem = problem_type;
+  if (task_labels_dev) {
+    GGET_REQUIRE(loss_dev != nullptr, "loss_dev is required when task labels are given");
+    if (int e = k_task_loss(lg, task_labels_dev, sample_wgt_dev, problem_type, B, C, loss_dev, h->wsp<float>(w.tdlogits), st))
+      return e;
+  }
+  h->fwd_valid = true;
+  return 0;
+}
+
+// ================================================================================================
+// backward
+// ================================================================================================
+namespace {
+
+int convert_bucket(gget_engine* h, int bucket, hipStream_t st) {
+  const auto& bs = h->bucket_segs[bucket];
+  return k_convert_segments(h->wsp<float>(h->ws.scratch32), h->G,
+                            reinterpret_cast<const GgetSegment*>(h->W + h->ws.segs) + bs.first, bs.second, st);
+}
+
+int layer_backward(gget_engine* h, int i, hipStream_t st) {
+  const gget_config_t& c = h->cfg;
+  const int T = h->T, d = c.hidden_size, ff = c.intermediate_size, H = c.num_heads;
+  const LayerOff& lo = h->plan.layers[i];
+  const LayerWs& lw = h->ws.lw[i];
+  const Ws& w = h->ws;
+  float* s32 = h->wsp<float>(w.scratch32);
+  bf16_t* bufs[3] = {h->wsp<bf16_t>(w.dxa), h->wsp<bf16_t>(w.dxb), h->wsp<bf16_t>(w.dxc)};
+  bf16_t* dx_out = h->dx_cur;
+  int oi = 0;
+  while (oi < 3 && bufs[oi] != dx_out) ++oi;
+  GGET_REQUIRE(oi < 3, "backward stages called out of order");
+  bf16_t* dx_mid = bufs[(oi + 1) % 3];
+  bf16_t* dx_in = bufs[(oi + 2) % 3];
+  bf16_t* x_in = h->wsp<bf16_t>(w.xres[i]);
+  bf16_t* xmid = h->wsp<bf16_t>(lw.xmid);
+  bf16_t* dxn = h->wsp<bf16_t>(w.dxn);
+  bf16_t* dqkv = h->wsp<bf16_t>(w.dqkv);
+  bf16_t* dattn = h->wsp<bf16_t>(w.dattn);
+  bf16_t* dgu = h->wsp<bf16_t>(w.dgu);
+  bf16_t* dh = h->wsp<bf16_t>(w.dh);
+  const bf16_t* dy_down = dx_out;  // gradient of the down_proj output
+  const bf16_t* dy_o = nullptr;    // gradient of the o_proj output
+  dim3 lsgrid((d / 8 + 255) / 256, 64);
+  if (h->plan.has_ls) {
+    // m_out = lam2 * mraw  =>  d mraw = lam2 * dx_out, dlam2 += sum dx_out * mraw
+    bf16_t* dsc = h->wsp<bf16_t>(w.dscaled);
+    hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), 0, st, dx_out, h->wsp<bf16_t>(lw.mraw), h->P + lo.lam2, dsc,
+                       s32 + lo.lam2_32, T, d);
+    // the grouped wgrad at the end needs this buffer alive; reuse dattn's slot later for the o_proj one
+    dy_down = dsc;
+  }
+  // MLP: dh = dy_down W_down ; dgu = geglu'(dh) ; dxn2 = dgu W_gu
+  if (int e = gemm_nn(dy_down, h->P + lo.wdown, dh, T, ff, d, d, ff, ff, nullptr, st)) return e;
+  if (int e = k_geglu_bwd(h->wsp<bf16_t>(lw.gu), dh, dgu, T, ff, st)) return e;
+  if (int e = gemm_nn(dgu, h->P + lo.wgu, dxn, T, d, 2 * ff, 2 * ff, d, d, nullptr, st)) return e;
+  if (int e = k_rmsnorm_bwd(dxn, xmid, h->P + lo.ln2, h->wsp<float>(lw.rstd2), dx_out, dx_mid, s32 + lo.ln2_32, T, d, st))
+    return e;
+  // wgrad of the MLP now (its dY buffers get reused below when LayerScale is on)
+  {
+    GemmGroup g;
+    memset(&g, 0, sizeof(g));
+    g.count = 2;
+    g.p[0] = GemmProblem{dgu, h->wsp<bf16_t>(lw.xn2), h->G + lo.wgu, nullptr, 2 * ff, d, T, 2 * ff, d, d, nullptr, nullptr, 0, 0};
+    g.p[1] = GemmProblem{dy_down, h->wsp<bf16_t>(lw.h), h->G + lo.wdown, nullptr, d, ff, T, d, ff, ff, nullptr, nullptr, 0, 0};
+    if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_NONE, g, 1, st)) return e;
+  }
+  dy_o = dx_mid;
+  if (h->plan.has_ls) {
+    bf16_t* dsc = h->wsp<bf16_t>(w.dscaled);
+    hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), 0, st, dx_mid, h->wsp<bf16_t>(lw.araw), h->P + lo.lam1, dsc,
+                       s32 + lo.lam1_32, T, d);
+    dy_o = dsc;
+  }
+  // attention: dattn = dy_o W_o ; (dq,dk,dv) ; inverse RoPE ; dxn1 = dqkv W_qkv
+  if (int e = gemm_nn(dy_o, h->P + lo.wo, dattn, T, d, d, d, d, d, nullptr, st)) return e;
+  if (int e = k_attn_bwd(h->wsp<bf16_t>(lw.qkv), h->wsp<bf16_t>(lw.attn), dattn, h->wsp<float>(lw.lse),
+                         h->wsp<int32_t>(w.key_len), dqkv, h->wsp<float>(w.delta), h->B, h->S, H, c.causal, st))
+    return e;
+  if (int e = k_rope(dqkv, h->cos_tab, h->sin_tab, h->pos, T, h->S, H, 1, st)) return e;
+  if (int e = gemm_nn(dqkv, h->P + lo.wqkv, dxn, T, d, 3 * d, 3 * d, d, d, nullptr, st)) return e;
+  if (int e = k_rmsnorm_bwd(dxn, x_in, h->P + lo.ln1, h->wsp<float>(lw.rstd1), dx_mid, dx_in, s32 + lo.ln1_32, T, d, st))
+    return e;
+  {
+    GemmGroup g;
+    memset(&g, 0, sizeof(g));
+    g.count = 2;
+    g.p[0] = GemmProblem{dqkv, h->wsp<bf16_t>(lw.xn1), h->G + lo.wqkv, nullptr, 3 * d, d, T, 3 * d, d, d, nullptr, nullptr, 0, 0};
+    g.p[1] = GemmProblem{dy_o, h->wsp<bf16_t>(lw.attn), h->G + lo.wo, nullptr, d, d, T, d, d, d, nullptr, nullptr, 0, 0};
+    if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_NONE, g, 1, st)) return e;
+  }
+  h->dx_cur = dx_in;
+  return convert_bucket(h, h->bucket_of_layer(i), st);
+}
+
+}  // namespace
+
+extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stream) {
+  GGET_REQUIRE(h, "null handle");
+  GGET_REQUIRE(h->fwd_valid && h->have_labels, "backward needs a preceding forward with labels");
+  GGET_REQUIRE(loss_scale == 1.0f, "loss scaling is not used on the bf16 path (pass 1.0)");
+  hipStream_t st = (hipStream_t)stream;
+  const gget_config_t& c = h->cfg;
+  const Ws& w = h->ws;
+  const int T = h->T, d = c.hidden_size;
+  float* s32 = h->wsp<float>(w.scratch32);
+  GGET_HIP_CHECK(hipMemsetAsync(s32, 0, h->plan.n_scratch32 * 4, st));
+  bf16_t* dhid = h->wsp<bf16_t>(w.dxb);  // gradient w.r.t. the final-norm output
+  GGET_HIP_CHECK(hipMemsetAsync(dhid, 0, (size_t)T * d * 2, st));
+  if (c.kind == GGET_KIND_PRETRAIN) {
+    const int n = c.next_n_token, V = c.vocab_size, Vp = (int)align_up(V, 64);
+    int32_t* counts = h->wsp<int32_t>(w.counts);
+    bf16_t* dlog = h->wsp<bf16_t>(w.dlogits);
+    // lm_head: dHl = dlogits W_lm ; dW_lm = dlogits^T Hl (split-K, fp32 atomics: only 6x6 output tiles)
+    if (int e = gemm_nn(dlog, h->P + h->plan.lm, h->wsp<bf16_t>(w.dHl), T * n, d, V, Vp, d, d, counts + 1, st)) return e;
+    if (int e = gget_gemm_single(GGET_GEMM_TN, GGET_EPI_ATOMIC_F32, dlog, h->wsp<bf16_t>(w.Hl), s32 + h->plan.lm32, nullptr, V,
+                                 d, T * n, Vp, d, d, nullptr, counts + 1, 16, st))
+      return e;
+    if (h->plan.has_ntp) {
+      bf16_t* dP = h->wsp<bf16_t>(w.dP);
+      GGET_HIP_CHECK(hipMemsetAsync(dP, 0, (size_t)T * n * d * 2, st));
+      if (int e = k_gather_rows(h->wsp<bf16_t>(w.dHl), h->wsp<int32_t>(w.sel_src), counts + 1, dP, T * n, d, 1, st)) return e;
+      if (int e = gemm_nn(dP, h->P + h->plan.ntp, h->wsp<bf16_t>(w.dHm), T, d, n * d, n * d, d, d, counts, st)) return e;
+      if (int e = gget_gemm_single(GGET_GEMM_TN, GGET_EPI_NONE, dP, h->wsp<bf16_t>(w.Hm), h->G + h->plan.ntp, nullptr, n * d, d,
+                                   T, n * d, d, d, nullptr, counts, 1, st))
+        return e;
+    }
+    if (int e = k_gather_rows(h->wsp<bf16_t>(w.dHm), h->wsp<int32_t>(w.row_idx), counts, dhid, T, d, 1, st)) return e;
+  } else {
+    if (int e = k_score_bwd(h->wsp<float>(w.tdlogits), h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.pool_row),
+                            h->P + h->plan.score, s32 + h->plan.score32, c.score_bias ? s32 + h->plan.sbias32 : nullptr, dhid,
+                            h->B, c.num_labels, d, st))
+      return e;
+  }
+  bf16_t* dx = h->wsp<bf16_t>(w.dxa);
+  if (int e = k_rmsnorm_bwd(dhid, h->wsp<bf16_t>(w.xres[c.num_layers]), h->P + h->plan.normf, h->wsp<float>(w.rstd_f), nullptr,
+                            dx, s32 + h->plan.normf32, T, d, st))
+    return e;
+  h->dx_cur = dx;
+  return convert_bucket(h, 0, st);
+}
+
+extern "C" int gget_backward_layer(gget_handle_t h, int layer, void* stream) {
+  GGET_REQUIRE(h && h->fwd_valid && h->dx_cur, "backward_layer before backward_begin");
+  GGET_REQUIRE(layer >= 0 && layer < h->cfg.num_layers, "layer %d out of range", layer);
+  return layer_backward(h, layer, (hipStream_t)stream);
+}
+
+extern "C" int gget_backward_end(gget_handle_t h, void* stream) {
+  GGET_REQUIRE(h && h->fwd_valid && h->dx_cur, "backward_end before backward_begin");
+  hipStream_t st = (hipStream_t)stream;
+  const gget_config_t& c = h->cfg;
+  float* s32 = h->wsp<float>(h->ws.scratch32);
+  if (int e = k_embed_bwd(h->ids, h->dx_cur, h->P + h->plan.emb, h->plan.has_gate ? h->P + h->plan.gate : nullptr,
+                          s32 + h->plan.emb32, h->plan.has_gate ? s32 + h->plan.gate32 : nullptr, h->T, c.stacked_feat,
+                          c.stacked_feat, c.hidden_size, c.pad_token_id, /*hot_id=<mask>*/ 1, st))
+    return e;
+  h->dx_cur = nullptr;
+  return convert_bucket(h, c.num_layers + 1, st);
+}
+
+extern "C" int gget_backward(gget_handle_t h, float loss_scale, void* stream) {
+  if (int e = gget_backward_begin(h, loss_scale, stream)) return e;
+  for (int i = h->cfg.num_layers - 1; i >= 0; --i)
+    if (int e = gget_backward_layer(h, i, stream)) return e;
+  return gget_backward_end(h, stream);
+}
+
+extern "C" int gget_adamw_step(gget_handle_t h, float lr, float beta1, float beta2, float eps, float weight_decay,
+                               float max_grad_norm, float grad_scale, int step, float* gnorm_dev, void* stream) {
+  GGET_REQUIRE(h && h->master && h->am && h->av, "adamw needs master/m/v arenas");
+  GGET_REQUIRE(step >= 1, "step is 1-based");
+  hipStream_t st = (hipStream_t)stream;
+  float* sq = h->wsp<float>(h->ws.sqnorm);
+  const bool need_norm = max_grad_norm > 0.f || gnorm_dev != nullptr;
+  if (need_norm)
+    if (int e = k_grad_sqnorm(h->G, h->plan.n_params, sq, st)) return e;
+  return k_adamw(h->master, h->am, h->av, h->G, h->P, h->plan.n_params, lr, beta1, beta2, eps, weight_decay, step,
+                 max_grad_norm, grad_scale, need_norm ? sq : nullptr, gnorm_dev, st);
+}
+
+extern "C" int gget_head_counts(gget_handle_t h, int32_t counts[2], void* stream) {
+  GGET_REQUIRE(h && counts, "null argument");
+  GGET_REQUIRE(h->cfg.kind == GGET_KIND_PRETRAIN, "head counts exist only for the pre-train head");
+  GGET_HIP_CHECK(hipMemcpyAsync(counts, h->wsp<int32_t>(h->ws.counts), 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  GGET_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int gget_head_logits(gget_handle_t h, const void** logits_dev, int32_t* ld) {
+  GGET_REQUIRE(h && logits_dev && ld, "null argument");
+  GGET_REQUIRE(h->cfg.kind == GGET_KIND_PRETRAIN, "head logits exist only for the pre-train head");
+  *logits_dev = h->wsp<bf16_t>(h->ws.logits);
+  *ld = (int32_t)align_up(h->cfg.vocab_size, 64);
+  return 0;
+}
+
+extern "C" int gget_hidden_states(gget_handle_t h, const void** hidden_dev) {
+  GGET_REQUIRE(h && hidden_dev, "null argument");
+  *hidden_dev = h->wsp<bf16_t>(h->ws.hidden);
+  return 0;
+}
+
+// ================================================================================================
+// operator-level entry points
+// ================================================================================================
+extern "C" int gget_op_gemm(int mode, int epilogue, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
+                            int lda, int ldb, int ldc, int split_k, void* stream) {
+  return gget_gemm_single(mode, epilogue, A, B, C, R, M, N, K, lda, ldb, ldc, nullptr, nullptr, split_k, (hipStream_t)stream);
+}
+extern "C" int gget_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, void* stream) {
+  return k_rmsnorm_fwd(x, w, y, rstd, T, d, eps, (hipStream_t)stream);
+}
+extern "C" int gget_op_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                                   float* dw_accum, int T, int d, void* stream) {
+  return k_rmsnorm_bwd(dy, x, w, rstd, dres, dx, dw_accum, T, d, (hipStream_t)stream);
+}
+extern "C" int gget_op_embed_fwd(const int64_t* ids, const void* emb, const void* gate, void* out, int T, int F, int ldF, int d,
+                                 void* stream) {
+  return k_embed_fwd(ids, emb, gate, out, T, F, ldF, d, (hipStream_t)stream);
+}
+extern "C" int gget_op_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* gate, float* demb_accum,
+                                 float* dgate_accum, int T, int F, int ldF, int d, int V, int pad_id, void* stream) {
+  (void)V;
+  return k_embed_bwd(ids, dx, emb, gate, demb_accum, dgate_accum, T, F, ldF, d, pad_id, 1, (hipStream_t)stream);
+}
+extern "C" int gget_op_rope(void* qkv, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, int B, int S,
+                            int H, int inverse, void* stream) {
+  return k_rope(qkv, cos_tab, sin_tab, position_ids, B * S, S, H, inverse, (hipStream_t)stream);
+}
+extern "C" int gget_op_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
+                                void* stream) {
+  return k_attn_fwd(qkv, key_len, out, lse, B, S, H, causal, (hipStream_t)stream);
+}
+extern "C" int gget_op_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len,
+                                void* dqkv, float* delta_ws, int B, int S, int H, int causal, void* stream) {
+  return k_attn_bwd(qkv, out, dout, lse, key_len, dqkv, delta_ws, B, S, H, causal, (hipStream_t)stream);
+}
+extern "C" int gget_op_geglu_fwd(const void* gu, void* h, int T, int ff, void* stream) {
+  return k_geglu_fwd(gu, h, T, ff, (hipStream_t)stream);
+}
+extern "C" int gget_op_geglu_bwd(const void* gu, const void* dh, void* dgu, int T, int ff, void* stream) {
+  return k_geglu_bwd(gu, dh, dgu, T, ff, (hipStream_t)stream);
+}
+extern "C" int gget_op_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const float* row_wgt,
+                                  const int32_t* n_rows_dev, int n_rows_cap, int V, float* loss_sum, void* dlogits,
+                                  float grad_scale_base, int mean_over_rows, void* stream) {
+  GGET_REQUIRE(row_wgt == nullptr, "per-row weights go through the engine path (sample_wgt)");
+  return k_ce_fwd_bwd(logits, ld, labels, nullptr, nullptr, 1, n_rows_dev, n_rows_cap, V, loss_sum, dlogits, grad_scale_base,
+                      mean_over_rows, nullptr, (hipStream_t)stream);
+}

@@ -1,0 +1,29 @@
+// Host-side descriptors for the grouped bf16 MFMA GEMM (gemm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/gget.h"
+#include "common.h"
+
+#define GGET_MAX_GROUP 4
+
+struct GemmProblem {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;            // bf16 (or fp32 for the atomic epilogue)
+  const bf16_t* R;    // residual, same shape/ld as C (EPI_RESIDUAL)
+  int M, N, K;
+  int lda, ldb, ldc;
+  const int* m_dev;   // optional: rows of C read from device memory (head compaction counts)
+  const int* k_dev;   // optional: reduction length read from device memory
+  int tiles_n, tile_begin;  // filled by the launcher
+};
+
+struct GemmGroup {
+  GemmProblem p[GGET_MAX_GROUP];
+  int count;
+};
+
+// mode: GGET_GEMM_NT/NN/TN, epi: GGET_EPI_*; problems of one group share mode and epilogue.
+int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t st);
+int gget_gemm_single(int mode, int epi, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
+                     int lda, int ldb, int ldc, const int* m_dev, const int* k_dev, int split_k, hipStream_t st);

@@ -1,0 +1,266 @@
+// bf16 MFMA GEMM for gfx950 (MI355X) - the contraction behind every Linear of the Graph Eulerian
+// Transformer (reference: hf LlamaAttention q/k/v/o_proj :253-280, LlamaMLP :174-176,
+// n_token_proj / lm_head modeling_pretrain.py:88-93,218) and their dgrad / wgrad.
+//
+// One kernel template, three operand layouts:
+//   NT  C[M,N] = A[M,K] B[N,K]^T     forward            (both operands K-contiguous)
+//   NN  C[M,N] = A[M,K] B[K,N]       dgrad  dx = dy W   (B is N-contiguous)
+//   TN  C[M,N] = A[K,M]^T B[K,N]     wgrad  dW = dy^T x (both operands M/N-contiguous)
+// K-contiguous tiles live in LDS as [rows][64] with a 16-byte-chunk XOR swizzle and are read with
+// ds_read_b128; M/N-contiguous tiles live as [64 k][rows] with a 32-byte-window XOR swizzle and are
+// read with gfx950's transposing ds_read_b64_tr_b16, so no operand is ever transposed in HBM.
+// MFMA: v_mfma_f32_16x16x32_bf16, operands swapped (D = Btile * Atile^T) so that a lane owns 4
+// consecutive N of one row of C => 8-byte epilogue stores.
+// Block = 256 threads = 4 waves (2x2), tile BM x BN x 64, double-buffered LDS, register-staged loads.
+#include "common.h"
+#include "gemm.h"
+
+#define LDS_AS __attribute__((address_space(3)))
+
+namespace {
+
+__device__ __forceinline__ int mc_swz(int krow) { return (krow & 3) | ((krow >> 1) & 4); }
+
+template <int ROWS, bool MC>
+struct TileIO {
+  static constexpr int CHUNKS = ROWS * 8;       // 16-byte chunks per 64-deep tile
+  static constexpr int PER_THREAD = CHUNKS / 256;
+  static constexpr int ROWB = ROWS * 2;         // bytes per k-row of an MC tile
+  static constexpr int CPR = ROWS / 8;          // chunks per k-row of an MC tile
+
+  // global -> registers
+  __device__ __forceinline__ static void load(uint4 (&r)[PER_THREAD], const bf16_t* __restrict__ base, int ld,
+                                              int row0, int row_lim, int k0, int k_lim, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int c = tid + i * 256;
+      int gr, gk;
+      const bf16_t* p;
+      bool ok;
+      if (!MC) {
+        gr = row0 + (c >> 3);
+        gk = k0 + (c & 7) * 8;
+        ok = (gr < row_lim) && (gk < k_lim);
+        p = base + (size_t)gr * ld + gk;
+      } else {
+        gk = k0 + c / CPR;
+        gr = row0 + (c % CPR) * 8;
+        ok = (gr < row_lim) && (gk < k_lim);
+        p = base + (size_t)gk * ld + gr;
+      }
+      r[i] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  // registers -> LDS (swizzled)
+  __device__ __forceinline__ static void store(const uint4 (&r)[PER_THREAD], unsigned char* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int c = tid + i * 256;
+      int off;
+      if (!MC) {
+        const int row = c >> 3, ch = c & 7;
+        off = row * 128 + ((ch ^ (row & 7)) << 4);
+      } else {
+        const int krow = c / CPR, mc = c % CPR;
+        off = krow * ROWB + ((((mc >> 1) ^ mc_swz(krow))) << 5) + ((mc & 1) << 4);
+      }
+      *reinterpret_cast<uint4*>(lds + off) = r[i];
+    }
+  }
+  // LDS -> MFMA fragment for 16-row sub-tile `sub` (index inside the block tile), k-step kk (0/1)
+  __device__ __forceinline__ static bf16x8_t frag(const unsigned char* lds, int sub, int kk, int lane) {
+    const int l15 = lane & 15, g = lane >> 4;
+    if (!MC) {
+      const int row = sub * 16 + l15;
+      const int ch = kk * 4 + g;
+      const uint4 v = *reinterpret_cast<const uint4*>(lds + row * 128 + ((ch ^ (row & 7)) << 4));
+      return __builtin_bit_cast(bf16x8_t, v);
+    } else {
+      const int kr0 = kk * 32 + g * 8 + (l15 >> 2);
+      const int kr1 = kr0 + 4;
+      const int inw = (l15 & 3) * 8;
+      const unsigned char* p0 = lds + kr0 * ROWB + ((sub ^ mc_swz(kr0)) << 5) + inw;
+      const unsigned char* p1 = lds + kr1 * ROWB + ((sub ^ mc_swz(kr1)) << 5) + inw;
+      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(p0));
+      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(p1));
+      bf16x8_t out;
+      out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; out[3] = lo[3];
+      out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
+      return out;
+    }
+  }
+};
+
+template <int BM, int BN, bool A_MC, bool B_MC, int EPI>
+__global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmGroup g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using TA = TileIO<BM, A_MC>;
+  using TB = TileIO<BN, B_MC>;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int MI = BM / 32, NJ = BN / 32;
+
+  int pi = 0;
+  const int tile = blockIdx.x;
+#pragma unroll
+  for (int i = 1; i < GGET_MAX_GROUP; ++i)
+    if (i < g.count && tile >= g.p[i].tile_begin) pi = i;
+  const GemmProblem& P = g.p[pi];
+  const int M = P.m_dev ? *P.m_dev : P.M;
+  const int K = P.k_dev ? *P.k_dev : P.K;
+  const int N = P.N;
+  const int lt = tile - P.tile_begin;
+  const int m0 = (lt / P.tiles_n) * BM;
+  const int n0 = (lt % P.tiles_n) * BN;
+  if (m0 >= M) return;
+  // split-K slice of this block (gridDim.y slices, 64-aligned)
+  const int ktiles = (K + 63) >> 6;
+  const int per = (ktiles + gridDim.y - 1) / gridDim.y;
+  const int kbeg = blockIdx.y * per * 64;
+  const int kend = min(K, kbeg + per * 64);
+  if (kbeg >= kend) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int STAGE = A_BYTES + B_BYTES;  // stage s: A at s*STAGE, B at s*STAGE + A_BYTES
+
+  f32x4_t acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[TA::PER_THREAD], rb[TB::PER_THREAD];
+  TA::load(ra, P.A, P.lda, m0, M, kbeg, kend, tid);
+  TB::load(rb, P.B, P.ldb, n0, N, kbeg, kend, tid);
+  TA::store(ra, smem, tid);
+  TB::store(rb, smem + A_BYTES, tid);
+  __syncthreads();
+
+  int cur = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += 64) {
+    const bool more = (k0 + 64) < kend;
+    if (more) {
+      TA::load(ra, P.A, P.lda, m0, M, k0 + 64, kend, tid);
+      TB::load(rb, P.B, P.ldb, n0, N, k0 + 64, kend, tid);
+    }
+    const unsigned char* a_l = smem + cur * STAGE;
+    const unsigned char* b_l = a_l + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t af[MI], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = TA::frag(a_l, wm * MI + i, kk, lane);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j] = TB::frag(b_l, wn * NJ + j, kk, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      TA::store(ra, smem + (cur ^ 1) * STAGE, tid);
+      TB::store(rb, smem + (cur ^ 1) * STAGE + A_BYTES, tid);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: lane owns C[m][n..n+3], m = m0 + (wm*MI+i)*16 + (lane&15), n = n0 + (wn*NJ+j)*16 + (lane>>4)*4
+  const int l15 = lane & 15, gq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + (wm * MI + i) * 16 + l15;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + (wn * NJ + j) * 16 + gq * 4;
+      if (n >= N) continue;
+      f32x4_t v = acc[i][j];
+      if (EPI == GGET_EPI_ATOMIC_F32) {
+        float* c = reinterpret_cast<float*>(P.C) + (size_t)m * P.ldc + n;
+        unsafeAtomicAdd(c + 0, v[0]); unsafeAtomicAdd(c + 1, v[1]);
+        unsafeAtomicAdd(c + 2, v[2]); unsafeAtomicAdd(c + 3, v[3]);
+      } else {
+        if (EPI == GGET_EPI_RESIDUAL) {
+          const uint2 r = *reinterpret_cast<const uint2*>(P.R + (size_t)m * P.ldc + n);
+          v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
+          v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+        }
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(P.C) + (size_t)m * P.ldc + n) = o;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, bool A_MC, bool B_MC, int EPI>
+int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
+  int total = 0;
+  for (int i = 0; i < g.count; ++i) {
+    GemmProblem& p = g.p[i];
+    const int tm = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    p.tile_begin = total;
+    total += tm * p.tiles_n;
+  }
+  if (total == 0) return 0;
+  constexpr int SMEM = 2 * (BM + BN) * 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, A_MC, B_MC, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_done = true;
+  }
+  dim3 grid(total, split_k > 0 ? split_k : 1, 1);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_MC, B_MC, EPI>), grid, dim3(256), SMEM, st, g);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+template <bool A_MC, bool B_MC>
+int launch_mode(GemmGroup& g, int epi, int split_k, hipStream_t st) {
+  switch (epi) {
+    case GGET_EPI_NONE: return launch_t<128, 128, A_MC, B_MC, GGET_EPI_NONE>(g, split_k, st);
+    case GGET_EPI_RESIDUAL: return launch_t<128, 128, A_MC, B_MC, GGET_EPI_RESIDUAL>(g, split_k, st);
+    case GGET_EPI_ATOMIC_F32: return launch_t<128, 128, A_MC, B_MC, GGET_EPI_ATOMIC_F32>(g, split_k, st);
+  }
+  gget_set_error("gemm: unknown epilogue %d", epi);
+  return 2;
+}
+
+}  // namespace
+
+int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t st) {
+  GGET_REQUIRE(g.count >= 1 && g.count <= GGET_MAX_GROUP, "gemm: bad group size %d", g.count);
+  GGET_REQUIRE(split_k <= 1 || epi == GGET_EPI_ATOMIC_F32, "gemm: split-K needs the fp32 atomic epilogue");
+  for (int i = 0; i < g.count; ++i) {
+    const GemmProblem& p = g.p[i];
+    GGET_REQUIRE((p.lda % 8) == 0 && (p.ldb % 8) == 0 && (p.ldc % 4) == 0 && (p.N % 4) == 0,
+                 "gemm: leading dims must be multiples of 8 (lda %d ldb %d ldc %d N %d)", p.lda, p.ldb, p.ldc, p.N);
+  }
+  switch (mode) {
+    case GGET_GEMM_NT: return launch_mode<false, false>(g, epi, split_k, st);
+    case GGET_GEMM_NN: return launch_mode<false, true>(g, epi, split_k, st);
+    case GGET_GEMM_TN: return launch_mode<true, true>(g, epi, split_k, st);
+  }
+  gget_set_error("gemm: unknown mode %d", mode);
+  return 2;
+}
+
+int gget_gemm_single(int mode, int epi, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
+                     int lda, int ldb, int ldc, const int* m_dev, const int* k_dev, int split_k, hipStream_t st) {
+  GemmGroup g;
+  g.count = 1;
+  GemmProblem& p = g.p[0];
+  p.A = static_cast<const bf16_t*>(A);
+  p.B = static_cast<const bf16_t*>(B);
+  p.C = C;
+  p.R = static_cast<const bf16_t*>(R);
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.m_dev = m_dev; p.k_dev = k_dev;
+  return gget_gemm_launch(mode, epi, g, split_k, st);
+}

@@ -1,0 +1,51 @@
+// Host launchers of the HBM-bound kernels (kernels.hip) and the attention core (attention.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/gget.h"
+#include "common.h"
+
+struct GgetSegment {
+  uint64_t src;    // element offset into the fp32 scratch
+  uint64_t dst;    // element offset into the bf16 gradient array
+  uint64_t count;  // elements (multiple of 4)
+};
+
+int k_embed_fwd(const int64_t* ids, const void* emb, const void* gate, void* out, int T, int F, int ldF, int d,
+                hipStream_t st);
+int k_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* gate, float* demb, float* dgate, int T,
+                int F, int ldF, int d, int pad_id, int hot_id, hipStream_t st);
+int k_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, hipStream_t st);
+int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                  float* dw_accum, int T, int d, hipStream_t st);
+int k_rope(void* qkv, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, int T, int S, int H,
+           int inverse, hipStream_t st);
+int k_rope_table(float* cos_tab, float* sin_tab, int max_pos, float theta, hipStream_t st);
+int k_geglu_fwd(const void* gu, void* h, int T, int ff, hipStream_t st);
+int k_geglu_bwd(const void* gu, const void* dh, void* dgu, int T, int ff, hipStream_t st);
+int k_lengths(const int64_t* mask, const int64_t* ids, int ldF, int pad_id, int32_t* key_len, int32_t* pool_row, int B,
+              int S, hipStream_t st);
+int k_head_compact(const int64_t* labels, int T, int n, int32_t* cnt, int32_t* m_off, int32_t* l_off, int32_t* counts,
+                   int32_t* row_idx, int32_t* sel_src, int32_t* sel_label, int32_t* sel_tok, hipStream_t st);
+int k_gather_rows(const void* src, const int32_t* idx, const int32_t* count, void* dst, int cap, int d, int scatter,
+                  hipStream_t st);
+int k_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const int32_t* sel_tok, const float* sample_wgt, int S,
+                 const int32_t* n_rows_dev, int n_rows_cap, int V, float* loss_sum, void* dlogits, float scale_base,
+                 int mean_over_rows, float* loss_out, hipStream_t st);
+int k_score_fwd(const void* hidden, const int32_t* pool_row, const void* w, const void* bias, float* logits,
+                void* pooled_h, int B, int C, int d, hipStream_t st);
+int k_task_loss(const float* logits, const void* labels, const float* sample_wgt, int problem, int B, int C,
+                float* loss_out, float* dlogits, hipStream_t st);
+int k_score_bwd(const float* dlogits, const void* hidden, const int32_t* pool_row, const void* w, float* dw, float* dbias,
+                void* dhidden, int B, int C, int d, hipStream_t st);
+int k_grad_sqnorm(const void* g, size_t n, float* out, hipStream_t st);
+int k_adamw(float* master, float* m, float* v, const void* grad, void* param, size_t n, float lr, float beta1, float beta2,
+            float eps, float wd, int step, float max_norm, float grad_scale, const float* sqnorm, float* gnorm_out,
+            hipStream_t st);
+int k_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st);
+int k_convert_segments(const float* scratch, void* grads, const GgetSegment* segs_dev, int nseg, hipStream_t st);
+
+// attention.hip
+int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
+               hipStream_t st);
+int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
+               float* delta_ws, int B, int S, int H, int causal, hipStream_t st);

@@ -1,0 +1,820 @@
+// HBM-bound kernels of the Graph Eulerian Transformer path (everything that is not a GEMM or the
+// attention core): stacked-token embedding gather / scatter-add, RMSNorm, RoPE, GEGLU, SMTP head
+// compaction + cross-entropy, fine-tune score head, AdamW.  All bf16 I/O with fp32 math, 16-byte
+// vector accesses, wave64 reductions.  Reference sites are cited per kernel.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ uint4 ldg16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void stg16(bf16_t* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+
+// ---------------------------------------------------------------------------------------------
+// K1  stacked-token embedding: E[t,:] = sum_f W[ids[t,f],:] (* G[f,:])
+// reference: _get_stacked_inputs_embeds (modeling_helpers.py:89-114), StackedFeatAggregation
+// (modeling_common.py:127-135).  One 128-thread block per token, 8 channels per thread.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) embed_fwd_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ emb,
+                                                        const bf16_t* __restrict__ gate, bf16_t* __restrict__ out,
+                                                        int T, int F, int ldF, int d) {
+  const int t = blockIdx.x;
+  const int64_t* row = ids + (size_t)t * ldF;
+  for (int c = threadIdx.x; c * 8 < d; c += blockDim.x) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int f = 0; f < F; ++f) {
+      const int64_t id = row[f];
+      float v[8];
+      unpack8(ldg16(emb + (size_t)id * d + c * 8), v);
+      if (gate) {
+        float gv[8];
+        unpack8(ldg16(gate + (size_t)f * d + c * 8), gv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e] * gv[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      }
+    }
+    stg16(out + (size_t)t * d + c * 8, pack8(acc));
+  }
+}
+
+// backward of K1: fp32 atomic scatter-add into dW[V,d]; the SMTP <mask> row (about half of all cells)
+// and any other hot id is pre-reduced inside the block before touching memory.
+constexpr int kEmbTok = 32;
+__global__ void __launch_bounds__(128) embed_bwd_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ dx,
+                                                        const bf16_t* __restrict__ emb, const bf16_t* __restrict__ gate,
+                                                        float* __restrict__ demb, float* __restrict__ dgate, int T,
+                                                        int F, int ldF, int d, int pad_id, int hot_id) {
+  const int t0 = blockIdx.x * kEmbTok;
+  for (int c = threadIdx.x; c * 8 < d; c += blockDim.x) {
+    float hot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool any_hot = false;
+    for (int tt = 0; tt < kEmbTok; ++tt) {
+      const int t = t0 + tt;
+      if (t >= T) break;
+      float g[8];
+      unpack8(ldg16(dx + (size_t)t * d + c * 8), g);
+      const int64_t* row = ids + (size_t)t * ldF;
+      for (int f = 0; f < F; ++f) {
+        const int id = (int)row[f];
+        float gv[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+        if (gate) {
+          unpack8(ldg16(gate + (size_t)f * d + c * 8), gv);
+          float ev[8];
+          unpack8(ldg16(emb + (size_t)id * d + c * 8), ev);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dgate + (size_t)f * d + c * 8 + e, g[e] * ev[e]);
+        }
+        if (id == pad_id) continue;  // nn.Embedding(padding_idx): the pad row never receives gradient
+        if (id == hot_id) {
+          any_hot = true;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) hot[e] += g[e] * gv[e];
+        } else {
+          float* dst = demb + (size_t)id * d + c * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dst + e, g[e] * gv[e]);
+        }
+      }
+    }
+    if (any_hot) {
+      float* dst = demb + (size_t)hot_id * d + c * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dst + e, hot[e]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4  RMSNorm (hf LlamaRMSNorm.forward :62-67): y = w * bf16(x * rsqrt(mean(x^2)+eps)); one wave per row.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxChunksPerLane = 4;  // d <= 2048
+__global__ void __launch_bounds__(kBlock) rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                             bf16_t* __restrict__ y, float* __restrict__ rstd_out,
+                                                             int T, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int nchunk = d >> 3;
+  for (int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); row < T; row += gridDim.x * (kBlock / 64)) {
+    float v[kMaxChunksPerLane][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxChunksPerLane; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        unpack8(ldg16(x + (size_t)row * d + c * 8), v[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+      }
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)d + eps);
+    if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+#pragma unroll
+    for (int i = 0; i < kMaxChunksPerLane; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        float wv[8], o[8];
+        unpack8(ldg16(w + c * 8), wv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = wv[e] * bf2f(f2bf(v[i][e] * rstd));
+        stg16(y + (size_t)row * d + c * 8, pack8(o));
+      }
+    }
+  }
+}
+
+// backward: dx = dres + rstd*(dy*w - xhat*mean(dy*w*xhat)),  dw += dy*xhat  (fp32 accumulators)
+__global__ void __launch_bounds__(kBlock) rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                             const bf16_t* __restrict__ w, const float* __restrict__ rstd_in,
+                                                             const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                                             float* __restrict__ dw_accum, int T, int d) {
+  extern __shared__ float dw_lds[];  // [4][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = d >> 3;
+  float dwp[kMaxChunksPerLane][8];
+  float wv[kMaxChunksPerLane][8];
+#pragma unroll
+  for (int i = 0; i < kMaxChunksPerLane; ++i) {
+    const int c = lane + i * 64;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dwp[i][e] = 0.f;
+    if (c < nchunk) unpack8(ldg16(w + c * 8), wv[i]);
+  }
+  for (int row = blockIdx.x * (kBlock / 64) + wave; row < T; row += gridDim.x * (kBlock / 64)) {
+    const float rstd = rstd_in[row];
+    float xh[kMaxChunksPerLane][8], g[kMaxChunksPerLane][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxChunksPerLane; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        float xv[8], dv[8];
+        unpack8(ldg16(x + (size_t)row * d + c * 8), xv);
+        unpack8(ldg16(dy + (size_t)row * d + c * 8), dv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[i][e] = xv[e] * rstd;
+          g[i][e] = dv[e] * wv[i][e];
+          dot += g[i][e] * xh[i][e];
+          dwp[i][e] += dv[e] * xh[i][e];
+        }
+      }
+    }
+    dot = wave_sum(dot) / (float)d;
+#pragma unroll
+    for (int i = 0; i < kMaxChunksPerLane; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        float o[8];
+        if (dres) unpack8(ldg16(dres + (size_t)row * d + c * 8), o);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += rstd * (g[i][e] - xh[i][e] * dot);
+        stg16(dx + (size_t)row * d + c * 8, pack8(o));
+      }
+    }
+  }
+  // block-level reduction of the dw partials, then one atomic per channel per block
+#pragma unroll
+  for (int i = 0; i < kMaxChunksPerLane; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dw_lds[wave * d + c * 8 + e] = dwp[i][e];
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < d; j += kBlock) {
+    const float s = dw_lds[j] + dw_lds[d + j] + dw_lds[2 * d + j] + dw_lds[3 * d + j];
+    unsafeAtomicAdd(dw_accum + j, s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6  RoPE in place on the q and k thirds of qkv [T,3d]
+// reference: hf apply_rotary_pos_emb :138-160 / rotate_half :130-135 (half-split pairing j <-> j+32).
+// inverse=1 applies the transpose rotation (backward).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) rope_kernel(bf16_t* __restrict__ qkv, const float* __restrict__ cos_tab,
+                                                      const float* __restrict__ sin_tab,
+                                                      const int64_t* __restrict__ position_ids, int T, int S, int H,
+                                                      int inverse) {
+  const int d = H * 64;
+  const long total = (long)T * 2 * H * 4;
+  for (long w = (long)blockIdx.x * kBlock + threadIdx.x; w < total; w += (long)gridDim.x * kBlock) {
+    const int j8 = (int)(w & 3);
+    long r = w >> 2;
+    const int h = (int)(r % H); r /= H;
+    const int sec = (int)(r & 1);
+    const int t = (int)(r >> 1);
+    const int pos = position_ids ? (int)position_ids[t] : (t % S);
+    bf16_t* p = qkv + (size_t)t * 3 * d + sec * d + h * 64 + j8 * 8;
+    float a[8], b[8], c[8], s[8];
+    unpack8(ldg16(p), a);
+    unpack8(ldg16(p + 32), b);
+    const float4* ct = reinterpret_cast<const float4*>(cos_tab + (size_t)pos * 32 + j8 * 8);
+    const float4* stb = reinterpret_cast<const float4*>(sin_tab + (size_t)pos * 32 + j8 * 8);
+    const float4 c0 = ct[0], c1 = ct[1], s0 = stb[0], s1 = stb[1];
+    c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+    s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
+    float oa[8], ob[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float sn = inverse ? -s[e] : s[e];
+      oa[e] = a[e] * c[e] - b[e] * sn;
+      ob[e] = b[e] * c[e] + a[e] * sn;
+    }
+    stg16(p, pack8(oa));
+    stg16(p + 32, pack8(ob));
+  }
+}
+
+// hf LlamaRotaryEmbedding.forward :111-127: fp32 freqs = pos * inv_freq, cos/sin in fp32
+__global__ void rope_table_kernel(float* cos_tab, float* sin_tab, int max_pos, float theta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= max_pos * 32) return;
+  const int pos = i >> 5, j = i & 31;
+  const float inv_freq = 1.0f / powf(theta, (float)(2 * j) / 64.0f);
+  const float fr = (float)pos * inv_freq;
+  cos_tab[i] = (float)cos((double)fr);
+  sin_tab[i] = (float)sin((double)fr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K9  GEGLU: h = bf16(gelu(g)) * u   (hf LlamaMLP.forward :174-176, exact-erf GELU)
+// gu is [T, 2ff] with gate columns [0,ff) and up columns [ff,2ff).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) geglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ h, long T,
+                                                           int ff) {
+  const int cpr = ff >> 3;
+  const long total = T * cpr;
+  for (long w = (long)blockIdx.x * kBlock + threadIdx.x; w < total; w += (long)gridDim.x * kBlock) {
+    const long t = w / cpr;
+    const int c = (int)(w % cpr);
+    float g[8], u[8], o[8];
+    unpack8(ldg16(gu + t * 2 * ff + c * 8), g);
+    unpack8(ldg16(gu + t * 2 * ff + ff + c * 8), u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(gelu_erf(g[e]))) * u[e];
+    stg16(h + t * ff + c * 8, pack8(o));
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) geglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dh,
+                                                           bf16_t* __restrict__ dgu, long T, int ff) {
+  const int cpr = ff >> 3;
+  const long total = T * cpr;
+  for (long w = (long)blockIdx.x * kBlock + threadIdx.x; w < total; w += (long)gridDim.x * kBlock) {
+    const long t = w / cpr;
+    const int c = (int)(w % cpr);
+    float g[8], u[8], dv[8], dg[8], du[8];
+    unpack8(ldg16(gu + t * 2 * ff + c * 8), g);
+    unpack8(ldg16(gu + t * 2 * ff + ff + c * 8), u);
+    unpack8(ldg16(dh + t * ff + c * 8), dv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dg[e] = dv[e] * u[e] * gelu_erf_grad(g[e]);
+      du[e] = dv[e] * gelu_erf(g[e]);
+    }
+    stg16(dgu + t * 2 * ff + c * 8, pack8(dg));
+    stg16(dgu + t * 2 * ff + ff + c * 8, pack8(du));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2  key lengths from the right-padded attention mask (replaces the [B,1,S,S] additive mask of
+// _update_causal_mask, modeling_helpers.py:38-48); also the "last" pooling row of the task head
+// (_get_sequence_len, modeling_helpers.py:78-86: (in_ != pad).sum(-1) - 1).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) lengths_kernel(const int64_t* __restrict__ mask, const int64_t* __restrict__ ids,
+                                                     int ldF, int pad_id, int32_t* __restrict__ key_len,
+                                                     int32_t* __restrict__ pool_row, int B, int S) {
+  const int b = blockIdx.x;
+  int n = 0, m = 0;
+  for (int s = threadIdx.x; s < S; s += 64) {
+    if (mask) n += mask[(size_t)b * S + s] != 0;
+    if (ids) m += ids[((size_t)b * S + s) * ldF] != pad_id;
+  }
+  n = (int)wave_sum((float)n);
+  m = (int)wave_sum((float)m);
+  if (threadIdx.x == 0) {
+    if (key_len) key_len[b] = mask ? n : S;
+    if (pool_row) pool_row[b] = b * S + ((m - 1 + S) % S);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K11  SMTP head compaction (modeling_helpers.py:263-301): positions with >=1 masked feature -> M rows,
+// masked (row,f) cells -> Lm rows, in (b,s,f) row-major order, without leaving the device.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) head_flags_kernel(const int64_t* __restrict__ labels, int32_t* __restrict__ cnt,
+                                                            int T, int n) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= T) return;
+  int c = n;
+  if (labels) {
+    c = 0;
+    for (int f = 0; f < n; ++f) c += labels[(size_t)t * n + f] != -100;
+  }
+  cnt[t] = c;
+}
+
+// single block: exclusive scans of (cnt>0) and cnt over T tokens; counts[0]=M, counts[1]=Lm
+__global__ void __launch_bounds__(1024) head_scan_kernel(const int32_t* __restrict__ cnt, int32_t* __restrict__ m_off,
+                                                         int32_t* __restrict__ l_off, int32_t* __restrict__ counts,
+                                                         int T) {
+  __shared__ int sm[1024], sl[1024];
+  __shared__ int carry_m, carry_l;
+  const int tid = threadIdx.x;
+  if (tid == 0) { carry_m = 0; carry_l = 0; }
+  __syncthreads();
+  for (int base = 0; base < T; base += 1024) {
+    const int t = base + tid;
+    const int c = t < T ? cnt[t] : 0;
+    const int f = c > 0;
+    sm[tid] = f; sl[tid] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int am = 0, al = 0;
+      if (tid >= o) { am = sm[tid - o]; al = sl[tid - o]; }
+      __syncthreads();
+      sm[tid] += am; sl[tid] += al;
+      __syncthreads();
+    }
+    if (t < T) { m_off[t] = carry_m + sm[tid] - f; l_off[t] = carry_l + sl[tid] - c; }
+    __syncthreads();
+    if (tid == 1023) { carry_m += sm[1023]; carry_l += sl[1023]; }
+    __syncthreads();
+  }
+  if (tid == 0) { counts[0] = carry_m; counts[1] = carry_l; }
+}
+
+__global__ void __launch_bounds__(kBlock) head_fill_kernel(const int64_t* __restrict__ labels, const int32_t* __restrict__ cnt,
+                                                           const int32_t* __restrict__ m_off, const int32_t* __restrict__ l_off,
+                                                           int32_t* __restrict__ row_idx, int32_t* __restrict__ sel_src,
+                                                           int32_t* __restrict__ sel_label, int32_t* __restrict__ sel_tok,
+                                                           int T, int n) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= T || cnt[t] == 0) return;
+  const int m = m_off[t];
+  row_idx[m] = t;
+  int j = l_off[t];
+  for (int f = 0; f < n; ++f) {
+    const int64_t lab = labels ? labels[(size_t)t * n + f] : 0;
+    if (!labels || lab != -100) {
+      sel_src[j] = m * n + f;
+      sel_label[j] = (int32_t)lab;
+      sel_tok[j] = t;
+      ++j;
+    }
+  }
+}
+
+// dst[i,:] = src[idx[i],:]  (i < *count)   /   scatter: dst[idx[i],:] = src[i,:]
+__global__ void __launch_bounds__(kBlock) gather_rows_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ idx,
+                                                             const int32_t* __restrict__ count, bf16_t* __restrict__ dst,
+                                                             int cap, int d, int scatter) {
+  const int n = min(cap, *count);
+  const int cpr = d >> 3;
+  const long total = (long)n * cpr;
+  for (long w = (long)blockIdx.x * kBlock + threadIdx.x; w < total; w += (long)gridDim.x * kBlock) {
+    const long i = w / cpr;
+    const int c = (int)(w % cpr);
+    const long r = idx[i];
+    if (scatter) stg16(dst + r * d + c * 8, ldg16(src + i * d + c * 8));
+    else stg16(dst + i * d + c * 8, ldg16(src + r * d + c * 8));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K14  cross-entropy over [rows, V] bf16 logits in fp32 (_get_ce_loss :145-177 / _get_dlm_ce_loss
+// :180-198) fused with its backward: dlogits = (softmax - onehot) * w_row * scale.
+// One wave per row, block-level loss reduction, one atomic per block.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) ce_fwd_bwd_kernel(const bf16_t* __restrict__ logits, int ld,
+                                                            const int32_t* __restrict__ labels,
+                                                            const int32_t* __restrict__ sel_tok,
+                                                            const float* __restrict__ sample_wgt, int S,
+                                                            const int32_t* __restrict__ n_rows_dev, int n_rows_cap, int V,
+                                                            float* __restrict__ loss_sum, bf16_t* __restrict__ dlogits,
+                                                            float scale_base, int mean_over_rows) {
+  __shared__ float part[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_rows = min(n_rows_cap, n_rows_dev ? *n_rows_dev : n_rows_cap);
+  const float scale = mean_over_rows ? (n_rows > 0 ? 1.0f / (float)n_rows : 0.f) : scale_base;
+  float local = 0.f;
+  for (int row = blockIdx.x * (kBlock / 64) + wave; row < n_rows; row += gridDim.x * (kBlock / 64)) {
+    const bf16_t* lp = logits + (size_t)row * ld;
+    float mx = -INFINITY;
+    for (int j = lane; j < V; j += 64) mx = fmaxf(mx, bf2f(lp[j]));
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int j = lane; j < V; j += 64) se += __expf(bf2f(lp[j]) - mx);
+    se = wave_sum(se);
+    const int y = labels[row];
+    const float w = sample_wgt ? sample_wgt[sel_tok[row] / S] : 1.0f;
+    const float lse = mx + __logf(se);
+    if (lane == 0) local += w * (lse - bf2f(lp[y]));
+    if (dlogits) {
+      bf16_t* dp = dlogits + (size_t)row * ld;
+      const float inv = 1.0f / se;
+      const float ws = w * scale;
+      for (int j = lane; j < ld; j += 64) {
+        float gval = 0.f;
+        if (j < V) gval = (__expf(bf2f(lp[j]) - mx) * inv - (j == y ? 1.0f : 0.0f)) * ws;
+        dp[j] = f2bf(gval);
+      }
+    }
+  }
+  if (lane == 0) part[wave] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < kBlock / 64; ++i) s += part[i];
+    if (s != 0.f) unsafeAtomicAdd(loss_sum, s);
+  }
+}
+
+__global__ void finalize_loss_kernel(const float* loss_sum, const int32_t* n_rows_dev, float scale_base,
+                                     int mean_over_rows, float* loss_out) {
+  const float sc = mean_over_rows ? (*n_rows_dev > 0 ? 1.0f / (float)(*n_rows_dev) : 0.f) : scale_base;
+  loss_out[0] = loss_sum[0] * sc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K15  fine-tune head on the pooled row only (modeling_finetune.py:281-296 computes `score` on all
+// rows then indexes; algebraically identical): logits[b,c] = bf16(h[row_b] . W[c] + bias[c]).float()
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) score_fwd_kernel(const bf16_t* __restrict__ hidden, const int32_t* __restrict__ pool_row,
+                                                       const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
+                                                       float* __restrict__ logits, bf16_t* __restrict__ pooled_h, int B,
+                                                       int C, int d) {
+  const int b = blockIdx.x / C, c = blockIdx.x % C;
+  const bf16_t* hp = hidden + (size_t)pool_row[b] * d;
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < d; j += 64) {
+    acc += bf2f(hp[j]) * bf2f(w[(size_t)c * d + j]);
+    if (c == 0 && pooled_h) pooled_h[(size_t)b * d + j] = hp[j];
+  }
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) logits[b * C + c] = bf2f(f2bf(acc + (bias ? bf2f(bias[c]) : 0.f)));
+}
+
+// task loss + dlogits (calculate_task_loss, modeling_finetune.py:167-234); single block.
+__global__ void __launch_bounds__(kBlock) task_loss_kernel(const float* __restrict__ logits, const void* __restrict__ labels,
+                                                           const float* __restrict__ sample_wgt, int problem, int B, int C,
+                                                           float* __restrict__ loss_out, float* __restrict__ dlogits) {
+  __shared__ float red[kBlock];
+  __shared__ float wsum_s;
+  float wsum = 0.f;
+  if (problem == GGET_PROBLEM_SINGLE_LABEL && sample_wgt) {
+    float p = 0.f;
+    for (int b = threadIdx.x; b < B; b += kBlock) p += sample_wgt[b];
+    red[threadIdx.x] = p;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) wsum_s = red[0];
+    __syncthreads();
+    wsum = wsum_s;
+    __syncthreads();
+  }
+  float local = 0.f;
+  for (int b = threadIdx.x; b < B; b += kBlock) {
+    if (problem == GGET_PROBLEM_SINGLE_LABEL) {
+      const int y = (int)reinterpret_cast<const int64_t*>(labels)[b];
+      float mx = -INFINITY;
+      for (int c = 0; c < C; ++c) mx = fmaxf(mx, logits[b * C + c]);
+      float se = 0.f;
+      for (int c = 0; c < C; ++c) se += __expf(logits[b * C + c] - mx);
+      const float lse = mx + __logf(se);
+      const float wgt = sample_wgt ? sample_wgt[b] / wsum : 1.0f / (float)B;
+      local += wgt * (lse - logits[b * C + y]);
+      for (int c = 0; c < C; ++c)
+        dlogits[b * C + c] = (__expf(logits[b * C + c] - mx) / se - (c == y ? 1.f : 0.f)) * wgt;
+    } else {
+      // regression on num_labels == 1 (squeeze) or elementwise over C
+      for (int c = 0; c < C; ++c) {
+        const float y = reinterpret_cast<const float*>(labels)[b * C + c];
+        const float df = logits[b * C + c] - y;
+        const float inv = 1.0f / (float)(B * C);
+        if (problem == GGET_PROBLEM_REGRESSION_L1) {
+          local += fabsf(df) * inv;
+          dlogits[b * C + c] = (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * inv;
+        } else {
+          local += df * df * inv;
+          dlogits[b * C + c] = 2.f * df * inv;
+        }
+      }
+    }
+  }
+  red[threadIdx.x] = local;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) loss_out[0] = red[0];
+}
+
+// backward of the score head: dW[c,:] += sum_b dl[b,c] h[row_b,:], dbias[c] += sum_b dl[b,c],
+// dhidden[row_b,:] = sum_c dl[b,c] W[c,:] (dhidden pre-zeroed).  grid = B + C blocks.
+__global__ void __launch_bounds__(kBlock) score_bwd_kernel(const float* __restrict__ dlogits, const bf16_t* __restrict__ hidden,
+                                                           const int32_t* __restrict__ pool_row, const bf16_t* __restrict__ w,
+                                                           float* __restrict__ dw, float* __restrict__ dbias,
+                                                           bf16_t* __restrict__ dhidden, int B, int C, int d) {
+  if ((int)blockIdx.x < B) {
+    const int b = blockIdx.x;
+    for (int j = threadIdx.x; j < d; j += kBlock) {
+      float s = 0.f;
+      for (int c = 0; c < C; ++c) s += dlogits[b * C + c] * bf2f(w[(size_t)c * d + j]);
+      dhidden[(size_t)pool_row[b] * d + j] = f2bf(s);
+    }
+  } else {
+    const int c = blockIdx.x - B;
+    for (int j = threadIdx.x; j < d; j += kBlock) {
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s += dlogits[b * C + c] * bf2f(hidden[(size_t)pool_row[b] * d + j]);
+      dw[(size_t)c * d + j] += s;
+    }
+    if (threadIdx.x == 0 && dbias) {
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s += dlogits[b * C + c];
+      dbias[c] += s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K16  optimizer: global grad norm, clip, AdamW on fp32 master weights, refresh of the bf16 copy
+// reference: torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW (training_utils.py:68-80,
+// opt_utils.py:18-24) == DeepSpeed FusedAdam adam_w_mode (examples/ds_config2_pt.json:11-19).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) grad_sqnorm_kernel(const bf16_t* __restrict__ g, size_t n, float* __restrict__ out) {
+  __shared__ float part[kBlock / 64];
+  float s = 0.f;
+  const size_t nv = n >> 3;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (size_t)gridDim.x * kBlock) {
+    float v[8];
+    unpack8(ldg16(g + i * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e] * v[e];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < kBlock / 64; ++i) t += part[i];
+    unsafeAtomicAdd(out, t);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) adamw_kernel(float* __restrict__ master, float* __restrict__ m_, float* __restrict__ v_,
+                                                       const bf16_t* __restrict__ grad, bf16_t* __restrict__ param, size_t n,
+                                                       float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                                       float bc2_sqrt, float max_norm, float grad_scale,
+                                                       const float* __restrict__ sqnorm, float* __restrict__ gnorm_out) {
+  float coef = grad_scale;
+  if (sqnorm) {
+    const float nrm = sqrtf(sqnorm[0]) * grad_scale;
+    if (max_norm > 0.f) coef *= fminf(1.0f, max_norm / (nrm + 1e-6f));
+    if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) gnorm_out[0] = nrm;
+  }
+  const size_t nv = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (size_t)gridDim.x * kBlock) {
+    const uint2 gr = *reinterpret_cast<const uint2*>(grad + i * 4);
+    float g[4] = {__uint_as_float(gr.x << 16), __uint_as_float(gr.x & 0xffff0000u), __uint_as_float(gr.y << 16),
+                  __uint_as_float(gr.y & 0xffff0000u)};
+    float4 w = reinterpret_cast<float4*>(master)[i];
+    float4 mm = reinterpret_cast<float4*>(m_)[i];
+    float4 vv = reinterpret_cast<float4*>(v_)[i];
+    float* wp = &w.x; float* mp = &mm.x; float* vp = &vv.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = g[e] * coef;
+      mp[e] = beta1 * mp[e] + (1.f - beta1) * ge;
+      vp[e] = beta2 * vp[e] + (1.f - beta2) * ge * ge;
+      wp[e] *= (1.f - lr * wd);
+      const float denom = sqrtf(vp[e]) / bc2_sqrt + eps;
+      wp[e] -= (lr / bc1) * (mp[e] / denom);
+    }
+    reinterpret_cast<float4*>(master)[i] = w;
+    reinterpret_cast<float4*>(m_)[i] = mm;
+    reinterpret_cast<float4*>(v_)[i] = vv;
+    uint2 o;
+    o.x = pack2bf(wp[0], wp[1]);
+    o.y = pack2bf(wp[2], wp[3]);
+    *reinterpret_cast<uint2*>(param + i * 4) = o;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+  const size_t nv = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (size_t)gridDim.x * kBlock) {
+    const float4 w = reinterpret_cast<const float4*>(src)[i];
+    uint2 o;
+    o.x = pack2bf(w.x, w.y);
+    o.y = pack2bf(w.z, w.w);
+    *reinterpret_cast<uint2*>(dst + i * 4) = o;
+  }
+}
+
+// fp32 accumulation segments (embedding, norm weights, ...) -> bf16 gradient array
+__global__ void __launch_bounds__(kBlock) convert_segments_kernel(const float* __restrict__ scratch, bf16_t* __restrict__ grads,
+                                                                  const GgetSegment* __restrict__ segs) {
+  const GgetSegment s = segs[blockIdx.y];
+  const size_t nv = s.count >> 2;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (size_t)gridDim.x * kBlock) {
+    const float4 w = reinterpret_cast<const float4*>(scratch + s.src)[i];
+    uint2 o;
+    o.x = pack2bf(w.x, w.y);
+    o.y = pack2bf(w.z, w.w);
+    *reinterpret_cast<uint2*>(grads + s.dst + i * 4) = o;
+  }
+}
+
+inline int grid_for(long work_items, int per_block = kBlock, int cap = 4096) {
+  long g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace
+
+// ================================================================================================
+// host launchers
+// ================================================================================================
+int k_embed_fwd(const int64_t* ids, const void* emb, const void* gate, void* out, int T, int F, int ldF, int d,
+                hipStream_t st) {
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(T), dim3(128), 0, st, ids, (const bf16_t*)emb, (const bf16_t*)gate,
+                     (bf16_t*)out, T, F, ldF, d);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* gate, float* demb, float* dgate, int T,
+                int F, int ldF, int d, int pad_id, int hot_id, hipStream_t st) {
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((T + kEmbTok - 1) / kEmbTok), dim3(128), 0, st, ids, (const bf16_t*)dx,
+                     (const bf16_t*)emb, (const bf16_t*)gate, demb, dgate, T, F, ldF, d, pad_id, hot_id);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, hipStream_t st) {
+  GGET_REQUIRE(d % 8 == 0 && d <= 64 * 8 * kMaxChunksPerLane, "rmsnorm: d=%d unsupported", d);
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(grid_for(T, 4, 2048)), dim3(kBlock), 0, st, (const bf16_t*)x,
+                     (const bf16_t*)w, (bf16_t*)y, rstd, T, d, eps);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                  float* dw_accum, int T, int d, hipStream_t st) {
+  GGET_REQUIRE(d % 8 == 0 && d <= 64 * 8 * kMaxChunksPerLane, "rmsnorm: d=%d unsupported", d);
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(grid_for(T, 4 * 8, 512)), dim3(kBlock), 4 * d * sizeof(float), st,
+                     (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx,
+                     dw_accum, T, d);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_rope(void* qkv, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, int T, int S, int H,
+           int inverse, hipStream_t st) {
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(rope_kernel, dim3(grid_for((long)T * 8 * H)), dim3(kBlock), 0, st, (bf16_t*)qkv, cos_tab, sin_tab,
+                     position_ids, T, S, H, inverse);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_rope_table(float* cos_tab, float* sin_tab, int max_pos, float theta, hipStream_t st) {
+  hipLaunchKernelGGL(rope_table_kernel, dim3((max_pos * 32 + 255) / 256), dim3(256), 0, st, cos_tab, sin_tab, max_pos,
+                     theta);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_geglu_fwd(const void* gu, void* h, int T, int ff, hipStream_t st) {
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for((long)T * (ff / 8))), dim3(kBlock), 0, st, (const bf16_t*)gu,
+                     (bf16_t*)h, (long)T, ff);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_geglu_bwd(const void* gu, const void* dh, void* dgu, int T, int ff, hipStream_t st) {
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for((long)T * (ff / 8))), dim3(kBlock), 0, st, (const bf16_t*)gu,
+                     (const bf16_t*)dh, (bf16_t*)dgu, (long)T, ff);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_lengths(const int64_t* mask, const int64_t* ids, int ldF, int pad_id, int32_t* key_len, int32_t* pool_row, int B,
+              int S, hipStream_t st) {
+  hipLaunchKernelGGL(lengths_kernel, dim3(B), dim3(64), 0, st, mask, ids, ldF, pad_id, key_len, pool_row, B, S);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_head_compact(const int64_t* labels, int T, int n, int32_t* cnt, int32_t* m_off, int32_t* l_off, int32_t* counts,
+                   int32_t* row_idx, int32_t* sel_src, int32_t* sel_label, int32_t* sel_tok, hipStream_t st) {
+  const int g = (T + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(head_flags_kernel, dim3(g), dim3(kBlock), 0, st, labels, cnt, T, n);
+  hipLaunchKernelGGL(head_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, m_off, l_off, counts, T);
+  hipLaunchKernelGGL(head_fill_kernel, dim3(g), dim3(kBlock), 0, st, labels, cnt, m_off, l_off, row_idx, sel_src,
+                     sel_label, sel_tok, T, n);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_gather_rows(const void* src, const int32_t* idx, const int32_t* count, void* dst, int cap, int d, int scatter,
+                  hipStream_t st) {
+  if (cap == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)cap * (d / 8))), dim3(kBlock), 0, st, (const bf16_t*)src,
+                     idx, count, (bf16_t*)dst, cap, d, scatter);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const int32_t* sel_tok, const float* sample_wgt, int S,
+                 const int32_t* n_rows_dev, int n_rows_cap, int V, float* loss_sum, void* dlogits, float scale_base,
+                 int mean_over_rows, float* loss_out, hipStream_t st) {
+  GGET_HIP_CHECK(hipMemsetAsync(loss_sum, 0, sizeof(float), st));
+  if (n_rows_cap > 0) {
+    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(grid_for(n_rows_cap, 4 * 8, 2048)), dim3(kBlock), 0, st,
+                       (const bf16_t*)logits, ld, labels, sel_tok, sample_wgt, S, n_rows_dev, n_rows_cap, V, loss_sum,
+                       (bf16_t*)dlogits, scale_base, mean_over_rows);
+  }
+  if (loss_out) hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(1), 0, st, loss_sum, n_rows_dev, scale_base,
+                                   mean_over_rows, loss_out);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_score_fwd(const void* hidden, const int32_t* pool_row, const void* w, const void* bias, float* logits,
+                void* pooled_h, int B, int C, int d, hipStream_t st) {
+  hipLaunchKernelGGL(score_fwd_kernel, dim3(B * C), dim3(64), 0, st, (const bf16_t*)hidden, pool_row, (const bf16_t*)w,
+                     (const bf16_t*)bias, logits, (bf16_t*)pooled_h, B, C, d);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_task_loss(const float* logits, const void* labels, const float* sample_wgt, int problem, int B, int C,
+                float* loss_out, float* dlogits, hipStream_t st) {
+  hipLaunchKernelGGL(task_loss_kernel, dim3(1), dim3(kBlock), 0, st, logits, labels, sample_wgt, problem, B, C, loss_out,
+                     dlogits);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_score_bwd(const float* dlogits, const void* hidden, const int32_t* pool_row, const void* w, float* dw, float* dbias,
+                void* dhidden, int B, int C, int d, hipStream_t st) {
+  hipLaunchKernelGGL(score_bwd_kernel, dim3(B + C), dim3(kBlock), 0, st, dlogits, (const bf16_t*)hidden, pool_row,
+                     (const bf16_t*)w, dw, dbias, (bf16_t*)dhidden, B, C, d);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_grad_sqnorm(const void* g, size_t n, float* out, hipStream_t st) {
+  GGET_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float), st));
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(grid_for((long)(n / 8), kBlock, 1024)), dim3(kBlock), 0, st,
+                     (const bf16_t*)g, n, out);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_adamw(float* master, float* m, float* v, const void* grad, void* param, size_t n, float lr, float beta1, float beta2,
+            float eps, float wd, int step, float max_norm, float grad_scale, const float* sqnorm, float* gnorm_out,
+            hipStream_t st) {
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((long)(n / 4), kBlock, 4096)), dim3(kBlock), 0, st, master, m, v,
+                     (const bf16_t*)grad, (bf16_t*)param, n, lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2), max_norm,
+                     grad_scale, sqnorm, gnorm_out);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for((long)(n / 4), kBlock, 4096)), dim3(kBlock), 0, st, src,
+                     (bf16_t*)dst, n);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_convert_segments(const float* scratch, void* grads, const GgetSegment* segs_dev, int nseg, hipStream_t st) {
+  if (nseg == 0) return 0;
+  hipLaunchKernelGGL(convert_segments_kernel, dim3(64, nseg), dim3(kBlock), 0, st, scratch, (bf16_t*)grads, segs_dev);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}

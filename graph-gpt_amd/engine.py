@@ -1,0 +1,211 @@
+"""Python host side of the engine: owns the HBM arenas (as torch tensors: PyTorch is the allocator
+and stream provider, nothing more), binds them to a `gget_handle_t`, and exposes forward / backward /
+optimizer step on raw device pointers.  Mirrors what the reference gets from
+`deepspeed.initialize(...)` / DDP+AdamW (SURVEY.md section 8b "Engine protocol")."""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .spec import KIND_PRETRAIN, KIND_TASK, ModelSpec
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rope_tables(max_position: int, head_dim: int, theta: float):
+    """fp32 cos/sin [max_position, head_dim/2], computed exactly like hf LlamaRotaryEmbedding.forward
+    :111-127 does on the host (fp32 inv_freq, fp32 outer product, fp32 cos/sin)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    freqs = torch.arange(max_position, dtype=torch.float32)[:, None] * inv_freq[None, :]
+    return freqs.cos().contiguous(), freqs.sin().contiguous()
+
+
+class Engine:
+    def __init__(self, spec: ModelSpec, max_tokens: int, max_batch: int, device: Optional[torch.device] = None,
+                 with_optimizer: bool = True):
+        if not torch.cuda.is_available():
+            raise L.GgetError("the gget engine needs a GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.lib = L.load()
+        self.spec = spec
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        cfg = L.GgetConfig()
+        (cfg.kind, cfg.vocab_size, cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads,
+         cfg.stacked_feat, cfg.next_n_token, cfg.gated_agg, cfg.causal, cfg.max_position, cfg.num_labels,
+         cfg.score_bias, cfg.pad_token_id) = spec.as_c_ints()
+        cfg.rms_eps, cfg.rope_theta, cfg.layer_scale_init = spec.rms_eps, spec.rope_theta, spec.layer_scale_init
+        cfg.max_tokens, cfg.max_batch = int(max_tokens), int(max_batch)
+        self.cfg = cfg
+        sz = L.GgetSizes()
+        L.check(self.lib.gget_query_sizes(C.byref(cfg), C.byref(sz)))
+        self.n_params = int(sz.n_params)
+        dev = self.device
+        with torch.cuda.device(dev):
+            self.param_bf16 = torch.zeros(self.n_params, dtype=torch.bfloat16, device=dev)
+            self.grad_bf16 = torch.zeros(self.n_params, dtype=torch.bfloat16, device=dev)
+            self.master = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+            if with_optimizer:
+                self.adam_m = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+                self.adam_v = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+            else:
+                self.adam_m = self.adam_v = None
+            self.workspace = torch.zeros(int(sz.workspace_bytes), dtype=torch.uint8, device=dev)
+            cos, sin = rope_tables(spec.max_position, spec.head_dim, spec.rope_theta)
+            self.rope_cos, self.rope_sin = cos.to(dev), sin.to(dev)
+            self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        bufs = L.GgetBuffers(_ptr(self.param_bf16), _ptr(self.master), _ptr(self.adam_m), _ptr(self.adam_v),
+                             _ptr(self.grad_bf16), _ptr(self.workspace), _ptr(self.rope_cos), _ptr(self.rope_sin))
+        h = C.c_void_p()
+        L.check(self.lib.gget_create(C.byref(cfg), C.byref(bufs), C.byref(h)))
+        self.h = h
+        self.workspace_bytes = int(sz.workspace_bytes)
+        # parameter table
+        self.params: "OrderedDict[str, dict]" = OrderedDict()
+        info = L.GgetParamInfo()
+        for i in range(self.lib.gget_param_count(self.h)):
+            L.check(self.lib.gget_param_info(self.h, i, C.byref(info)))
+            shape = tuple(int(info.shape[k]) for k in range(info.ndim))
+            n = int(np.prod(shape))
+            off = int(info.offset)
+            self.params[info.name.decode()] = dict(shape=shape, offset=off, numel=n, layer=int(info.layer))
+        self.buckets = []
+        o, c = C.c_uint64(), C.c_uint64()
+        for b in range(self.lib.gget_bucket_count(self.h)):
+            L.check(self.lib.gget_bucket_range(self.h, b, C.byref(o), C.byref(c)))
+            self.buckets.append((int(o.value), int(c.value)))
+        self.step_count = 0
+        self._keep = None  # keeps the last batch tensors alive until backward has consumed them
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.gget_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ parameters
+    def view(self, name: str, which: str = "master") -> torch.Tensor:
+        p = self.params[name]
+        arena = {"master": self.master, "bf16": self.param_bf16, "grad": self.grad_bf16, "m": self.adam_m,
+                 "v": self.adam_v}[which]
+        return arena[p["offset"]: p["offset"] + p["numel"]].view(p["shape"])
+
+    def load_state_dict(self, state: Dict[str, "np.ndarray | torch.Tensor"], strict: bool = True):
+        missing = [k for k in self.params if k not in state]
+        unexpected = [k for k in state if k not in self.params]
+        if strict and (missing or unexpected):
+            raise KeyError(f"state dict mismatch: missing {missing[:4]} unexpected {unexpected[:4]}")
+        for k, p in self.params.items():
+            if k in state:
+                t = torch.as_tensor(state[k]).to(torch.float32).reshape(p["shape"])
+                self.view(k, "master").copy_(t.to(self.device))
+        self.sync_params()
+        return missing, unexpected
+
+    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        return OrderedDict((k, self.view(k, "master").detach().clone()) for k in self.params)
+
+    def sync_params(self):
+        L.check(self.lib.gget_sync_params(self.h, _stream()))
+
+    def grads(self) -> "OrderedDict[str, torch.Tensor]":
+        return OrderedDict((k, self.view(k, "grad")) for k in self.params)
+
+    # ------------------------------------------------------------------ forward / backward / step
+    @staticmethod
+    def _i64(t, dev):
+        return None if t is None else t.to(device=dev, dtype=torch.int64).contiguous()
+
+    def forward_pretrain(self, input_ids, attention_mask, labels=None, sample_wgt=None, position_ids=None):
+        dev = self.device
+        ids = self._i64(input_ids, dev)
+        if ids.dim() == 2:
+            ids = ids[:, :, None].contiguous()
+        B, S, F = ids.shape
+        assert F == self.spec.stacked_feat, f"input_ids has {F} stacked features, model expects {self.spec.stacked_feat}"
+        att = self._i64(attention_mask, dev)
+        lab = self._i64(labels, dev)
+        if lab is not None and lab.dim() == 2:
+            lab = lab[:, :, None].contiguous()
+        wgt = None if sample_wgt is None else sample_wgt.to(device=dev, dtype=torch.float32).contiguous()
+        pos = self._i64(position_ids, dev)
+        self._keep = (ids, att, lab, wgt, pos)
+        L.check(self.lib.gget_forward_pretrain(self.h, _ptr(ids), _ptr(att), _ptr(lab), _ptr(wgt), _ptr(pos), B, S,
+                                               _ptr(self._loss), _stream()))
+        return self._loss[0] if lab is not None else None
+
+    def forward_task(self, input_ids, attention_mask, position_ids=None, task_labels=None, sample_wgt=None,
+                     problem: int = L.PROBLEM_SINGLE_LABEL):
+        dev = self.device
+        ids = self._i64(input_ids, dev)
+        if ids.dim() == 2:
+            ids = ids[:, :, None]
+        ids = ids[:, :, : self.spec.stacked_feat].contiguous()
+        B, S, _ = ids.shape
+        att = self._i64(attention_mask, dev)
+        pos = self._i64(position_ids, dev)
+        y = None
+        if task_labels is not None:
+            if problem == L.PROBLEM_SINGLE_LABEL:
+                y = task_labels.to(device=dev, dtype=torch.int64).contiguous()
+            else:
+                y = task_labels.to(device=dev, dtype=torch.float32).contiguous()
+        wgt = None if sample_wgt is None else sample_wgt.to(device=dev, dtype=torch.float32).contiguous()
+        logits = torch.empty(B, self.spec.num_labels, dtype=torch.float32, device=dev)
+        hid = torch.empty(B, self.spec.hidden_size, dtype=torch.bfloat16, device=dev)
+        self._keep = (ids, att, pos, y, wgt)
+        L.check(self.lib.gget_forward_task(self.h, _ptr(ids), _ptr(att), _ptr(pos), _ptr(y), _ptr(wgt), problem, B, S,
+                                           _ptr(self._loss), _ptr(logits), _ptr(hid), _stream()))
+        return (self._loss[0] if y is not None else None), logits, hid
+
+    def backward(self):
+        L.check(self.lib.gget_backward(self.h, 1.0, _stream()))
+
+    def backward_begin(self):
+        L.check(self.lib.gget_backward_begin(self.h, 1.0, _stream()))
+
+    def backward_layer(self, i: int):
+        L.check(self.lib.gget_backward_layer(self.h, i, _stream()))
+
+    def backward_end(self):
+        L.check(self.lib.gget_backward_end(self.h, _stream()))
+
+    def adamw_step(self, lr, beta1=0.9, beta2=0.95, eps=1e-8, weight_decay=0.1, max_grad_norm=1.0, grad_scale=1.0):
+        self.step_count += 1
+        L.check(self.lib.gget_adamw_step(self.h, lr, beta1, beta2, eps, weight_decay, max_grad_norm, grad_scale,
+                                         self.step_count, _ptr(self._gnorm), _stream()))
+        return self._gnorm[0]
+
+    # ------------------------------------------------------------------ head outputs
+    def head_counts(self):
+        c = (C.c_int32 * 2)()
+        L.check(self.lib.gget_head_counts(self.h, C.byref(c), _stream()))
+        return int(c[0]), int(c[1])
+
+    def head_logits(self) -> torch.Tensor:
+        """bf16 [Lm, V] logits of the last pre-train forward (a copy)."""
+        _, lm = self.head_counts()
+        p, ld = C.c_void_p(), C.c_int32()
+        L.check(self.lib.gget_head_logits(self.h, C.byref(p), C.byref(ld)))
+        off = p.value - self.workspace.data_ptr()
+        raw = self.workspace[off: off + lm * ld.value * 2].view(torch.bfloat16).view(lm, ld.value)
+        return raw[:, : self.spec.vocab_size].clone()
+
+    def hidden_states(self, B: int, S: int) -> torch.Tensor:
+        p = C.c_void_p()
+        L.check(self.lib.gget_hidden_states(self.h, C.byref(p)))
+        off = p.value - self.workspace.data_ptr()
+        d = self.spec.hidden_size
+        return self.workspace[off: off + B * S * d * 2].view(torch.bfloat16).view(B, S, d).clone()

@@ -1,0 +1,359 @@
+"""Python operator surface of the reference for the hot path, backed by the HIP engine.
+
+Mirrors (same names, argument meaning, return fields, error behaviour):
+  GraphGPTConfig                 reference src/models/graphgpt/configuration_graphgpt.py:6-207
+  DoubleHeadsModelOutput         reference src/models/graphgpt/modeling_common.py:55-99
+  GraphGPTPretrainBase.forward   reference src/models/graphgpt/modeling_pretrain.py:152-266
+  GraphGPTTaskModel.forward      reference src/models/graphgpt/modeling_finetune.py:236-326
+Parameters are `nn.Parameter`s whose storage IS the engine's fp32 master arena, under the reference's
+state-dict keys, so `state_dict()/load_state_dict()/named_parameters()` interchange with reference
+checkpoints.  The returned loss is autograd-connected: `loss.backward()` runs the HIP backward and
+(optionally) fills `.grad`, so the reference's DDP-style step (training_utils.py:53-86) works; the fast
+path is `graph-gpt_amd.training.GgetEngine` (DeepSpeed-engine protocol, fused AdamW, overlapped RCCL).
+"""
+from __future__ import annotations
+
+import dataclasses
+import json
+import os
+from collections import OrderedDict
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib as L
+from .engine import Engine
+from .spec import KIND_PRETRAIN, KIND_TASK, ModelSpec
+from .weights import make_state_dict
+
+
+class GraphGPTConfig:
+    """Field names follow the reference `GraphGPTConfig(LlamaConfig)`; only the fields that reach the hot path
+    are interpreted, every other keyword is stored verbatim (so reference config dicts round-trip)."""
+
+    model_type = "graphgpt"
+
+    def __init__(self, vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
+                 num_attention_heads=32, hidden_act="gelu", max_position_embeddings=2048, initializer_range=0.02,
+                 rms_norm_eps=1e-6, use_cache=False, pad_token_id=0, tie_word_embeddings=False, pooling_method="last",
+                 causal_attention=True, rope_range=0, embed_pdrop=0.0, path_pdrop=0.0, mlp_pdrop=0.0,
+                 layer_scale_init_value=0.0, stacked_feat=1, stack_method="short", stacked_feat_agg_method="sum",
+                 embed_dim=0, next_n_token=1, use_generative=True, use_discriminative=False, focal_gamma=0.0,
+                 smtp_inside=False, mlp=None, dropout=0.0, loss_type=None, num_labels=2, problem_type=None,
+                 attention_dropout=0.0, rope_theta=10000.0, head_dim=64, num_key_value_heads=None, **kwargs):
+        self.vocab_size, self.hidden_size, self.intermediate_size = vocab_size, hidden_size, intermediate_size
+        self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
+        self.hidden_act, self.max_position_embeddings = hidden_act, max_position_embeddings
+        self.initializer_range, self.rms_norm_eps, self.use_cache = initializer_range, rms_norm_eps, use_cache
+        self.pad_token_id, self.tie_word_embeddings, self.pooling_method = pad_token_id, tie_word_embeddings, pooling_method
+        self.causal_attention, self.rope_range = bool(causal_attention), rope_range
+        self.embed_pdrop, self.path_pdrop, self.mlp_pdrop = embed_pdrop, path_pdrop, mlp_pdrop
+        self.layer_scale_init_value = layer_scale_init_value
+        self.stacked_feat, self.stack_method, self.stacked_feat_agg_method = stacked_feat, stack_method, stacked_feat_agg_method
+        self.embed_dim, self.next_n_token = embed_dim, next_n_token
+        self.use_generative, self.use_discriminative, self.focal_gamma = use_generative, use_discriminative, focal_gamma
+        self.smtp_inside, self.mlp, self.dropout, self.loss_type = smtp_inside, list(mlp or []), dropout, loss_type
+        self.num_labels, self.problem_type, self.attention_dropout = num_labels, problem_type, attention_dropout
+        self.rope_theta, self.head_dim = rope_theta, head_dim
+        self.num_key_value_heads = num_key_value_heads or num_attention_heads
+        self.num_params = None
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    # ---- what the engine supports; anything else fails loudly instead of silently diverging from the reference
+    def to_spec(self, kind: int) -> ModelSpec:
+        def need(cond, msg):
+            if not cond:
+                raise NotImplementedError(f"gget engine: {msg} (out of the hot-path scope, see DESIGN.md)")
+        need(self.hidden_act == "gelu", f"hidden_act={self.hidden_act!r}; the reference configs use exact-erf 'gelu'")
+        need(self.head_dim == 64 and self.hidden_size == 64 * self.num_attention_heads, "head_dim must be 64")
+        need(self.num_key_value_heads == self.num_attention_heads, "GQA is not used by the reference configs")
+        need(self.embed_dim == 0, "raw-embedding inputs (embed_dim>0)")
+        need(self.stack_method in ("short", None), "stack_method='long'")
+        need(not self.use_discriminative and self.use_generative, "contrastive (pretrain-cl) head")
+        need(self.focal_gamma == 0, "focal loss")
+        need(self.rope_range == 0, "rope_range rescaling")
+        need(not self.smtp_inside, "in-model SMTP masking (next item N1)")
+        need(len(self.mlp) == 0, "MLP score head")
+        need(self.pooling_method == "last", "pooling other than 'last'")
+        return ModelSpec(kind=kind, vocab_size=self.vocab_size, hidden_size=self.hidden_size,
+                         intermediate_size=self.intermediate_size, num_layers=self.num_hidden_layers,
+                         num_heads=self.num_attention_heads, head_dim=64, stacked_feat=self.stacked_feat,
+                         next_n_token=self.next_n_token if kind == KIND_PRETRAIN else 1,
+                         gated_agg=self.stacked_feat_agg_method == "gated", causal=self.causal_attention,
+                         rms_eps=self.rms_norm_eps, rope_theta=self.rope_theta, max_position=self.max_position_embeddings,
+                         layer_scale_init=float(self.layer_scale_init_value), num_labels=self.num_labels,
+                         score_bias=self.problem_type == "regression", pad_token_id=self.pad_token_id)
+
+    def to_dict(self) -> Dict[str, Any]:
+        return {k: v for k, v in self.__dict__.items() if not k.startswith("_")}
+
+    def save_pretrained(self, save_directory: str):
+        os.makedirs(save_directory, exist_ok=True)
+        with open(os.path.join(save_directory, "config.json"), "w") as fh:
+            json.dump(dict(self.to_dict(), model_type=self.model_type), fh, indent=2, default=str)
+
+    @classmethod
+    def from_pretrained(cls, directory: str):
+        with open(os.path.join(directory, "config.json")) as fh:
+            d = json.load(fh)
+        d.pop("model_type", None)
+        return cls(**d)
+
+
+@dataclasses.dataclass
+class DoubleHeadsModelOutput:
+    pretrain_loss: Optional[torch.Tensor] = None
+    task_loss: Optional[torch.Tensor] = None
+    pretrain_logits: Optional[torch.Tensor] = None
+    task_logits: Optional[torch.Tensor] = None
+    head1_loss: Optional[torch.Tensor] = None
+    head2_loss: Optional[torch.Tensor] = None
+    head1_logits: Optional[torch.Tensor] = None
+    head2_logits: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Any = None
+    hidden_states: Any = None
+    task_hidden_states: Optional[torch.Tensor] = None
+    attentions: Any = None
+
+
+class _LazyLogits:
+    """head1_logits costs a device->host count read; fetch only when somebody looks at it."""
+
+    def __init__(self, model):
+        self._m, self._v = model, None
+
+    def get(self):
+        if self._v is None:
+            self._v = self._m._engine.head_logits()
+        return self._v
+
+
+class _PretrainOutput(DoubleHeadsModelOutput):
+    def __init__(self, loss, lazy):
+        super().__init__(head1_loss=loss)
+        self._lazy = lazy
+
+    def __getattribute__(self, name):
+        if name == "head1_logits":
+            return object.__getattribute__(self, "_lazy").get()
+        return object.__getattribute__(self, name)
+
+
+class _LossFn(torch.autograd.Function):
+    """Bridges the HIP backward into autograd so `loss.backward()` (reference training_utils.py:66) works."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, loss_val):
+        ctx.model = model
+        return loss_val.detach().clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.model._autograd_backward(g)
+        return None, None, None
+
+
+class _Namespace(nn.Module):
+    pass
+
+
+class _GgetModel(nn.Module):
+    kind = KIND_PRETRAIN
+
+    def __init__(self, config: GraphGPTConfig, seed: int = 0):
+        super().__init__()
+        self.config = config
+        self.spec = config.to_spec(self.kind)
+        self.num_labels = config.num_labels
+        self._engine: Optional[Engine] = None
+        self._anchor = None
+        self.materialize_grads = True   # fill nn.Parameter.grad (fp32) after backward, like autograd would
+        self._dirty = False             # master weights changed behind the engine's back (external optimizer)
+        state = make_state_dict(self.spec, seed=seed, std=config.initializer_range)
+        # module tree with the reference's attribute paths: model.embed_tokens / model.layers[i].* / model.norm ...
+        self._flat: "OrderedDict[str, nn.Parameter]" = OrderedDict()
+        for name, arr in state.items():
+            p = nn.Parameter(torch.from_numpy(arr.copy()))
+            self._flat[name] = p
+            mod = self
+            parts = name.split(".")
+            for i, part in enumerate(parts[:-1]):
+                if part.isdigit():
+                    lst = mod
+                    while len(lst) <= int(part):
+                        lst.append(_Namespace())
+                    mod = lst[int(part)]
+                else:
+                    if not hasattr(mod, part):
+                        nxt = nn.ModuleList() if (i + 1 < len(parts) - 1 and parts[i + 1].isdigit()) else _Namespace()
+                        setattr(mod, part, nxt)
+                    mod = getattr(mod, part)
+            mod.register_parameter(parts[-1], p)
+        self.config.num_params = sum(p.numel() for p in self._flat.values())
+
+    # ---- nn.Module protocol bits the reference pipeline touches
+    @property
+    def device(self):
+        return next(iter(self._flat.values())).device
+
+    @property
+    def dtype(self):
+        return torch.bfloat16
+
+    def gradient_checkpointing_enable(self, *a, **k):
+        return None  # activations for 288 GB HBM are kept; recompute is never needed on this path
+
+    def _apply(self, fn, *a, **k):
+        # `.to(device)` / `.cuda()`: parameters move into the engine arena on first GPU use instead
+        probe = fn(torch.zeros(1))
+        if probe.device.type == "cuda":
+            with torch.cuda.device(probe.device):
+                self._ensure_engine(1, 8)
+            return self
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        res = super().load_state_dict(state_dict, strict=strict)
+        self._dirty = True
+        return res
+
+    def mark_dirty(self):
+        self._dirty = True
+
+    # ---- engine management
+    def _ensure_engine(self, B: int, S: int):
+        need_tok, need_b = B * S, B
+        e = self._engine
+        if e is not None and need_tok <= e.cfg.max_tokens and need_b <= e.cfg.max_batch:
+            return e
+        if not torch.cuda.is_available():
+            raise L.GgetError("GraphGPT engine: no GPU visible and there is no CPU fallback "
+                              "(the CPU statement of this path lives in oracle/ and is test-only)")
+        cap_tok = max(need_tok, e.cfg.max_tokens if e else 0)
+        cap_b = max(need_b, e.cfg.max_batch if e else 0)
+        new = Engine(self.spec, cap_tok, cap_b)
+        for name, p in self._flat.items():
+            new.view(name, "master").copy_(p.data.to(new.device, torch.float32))
+        if e is not None:
+            new.adam_m.copy_(e.adam_m)
+            new.adam_v.copy_(e.adam_v)
+            new.step_count = e.step_count
+        for name, p in self._flat.items():
+            p.data = new.view(name, "master")
+        new.sync_params()
+        self._engine = new
+        self._anchor = torch.zeros(1, device=new.device, requires_grad=True)
+        self._dirty = False
+        return new
+
+    def _pre_forward(self, B, S):
+        e = self._ensure_engine(B, S)
+        if self._dirty:
+            e.sync_params()
+            self._dirty = False
+        return e
+
+    def _autograd_backward(self, g):
+        e = self._engine
+        e.backward()
+        if self.materialize_grads:
+            scale = g.to(torch.float32)
+            for name, p in self._flat.items():
+                p.grad = e.view(name, "grad").to(torch.float32) * scale
+        self._dirty = True  # an external optimizer will now touch the master weights
+
+    def _wrap_loss(self, loss):
+        if loss is None:
+            return None
+        if torch.is_grad_enabled():
+            return _LossFn.apply(self._anchor, self, loss)
+        return loss.detach().clone()
+
+
+class GraphGPTPretrainBase(_GgetModel):
+    kind = KIND_PRETRAIN
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                inputs_raw_embeds=None, labels=None, label_mask=None, sample_wgt=None, use_cache=None,
+                output_attentions=None, output_hidden_states=None, return_dict=None, cache_position=None):
+        assert inputs_embeds is None, "inputs_embeds is not supported (reference asserts the same, modeling_helpers.py:95)"
+        assert inputs_raw_embeds is None, "raw embeddings need embed_dim>0 which this engine rejects at construction"
+        if input_ids.dim() == 2:
+            input_ids = input_ids[:, :, None]
+        B, S = input_ids.shape[:2]
+        assert input_ids.shape[2] == self.spec.stacked_feat, \
+            f"stacked_feat: {self.spec.stacked_feat}\nx.shape: {tuple(input_ids.shape)}"  # modeling_common.py:131-133
+        if attention_mask is None:
+            attention_mask = torch.ones(B, S, dtype=torch.int64)
+        assert attention_mask.dim() == 2, "packed (3-D) attention masks are a 'next' item (SURVEY.md 8f N2)"
+        e = self._pre_forward(B, S)
+        loss = e.forward_pretrain(input_ids, attention_mask, labels, sample_wgt, position_ids)
+        return _PretrainOutput(self._wrap_loss(loss), _LazyLogits(self))
+
+
+class GraphGPTTaskModel(_GgetModel):
+    kind = KIND_TASK
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                inputs_raw_embeds=None, task_labels=None, cls_idx=None, sample_wgt=None, use_cache=None,
+                output_attentions=None, output_hidden_states=None, return_dict=None, **kwargs):
+        assert inputs_embeds is None and inputs_raw_embeds is None
+        if input_ids.dim() == 2:
+            input_ids = input_ids[:, :, None]
+        B, S = input_ids.shape[:2]
+        if attention_mask is None:
+            attention_mask = torch.ones(B, S, dtype=torch.int64)
+        cfg = self.config
+        problem = cfg.problem_type
+        if problem is None and task_labels is not None:  # modeling_finetune.py:175-183
+            if self.num_labels == 1:
+                problem = "regression"
+            elif task_labels.dtype in (torch.long, torch.int):
+                problem = "single_label_classification"
+            else:
+                problem = "multi_label_classification"
+            cfg.problem_type = problem
+        if problem == "regression":
+            code = L.PROBLEM_REGRESSION_L1 if cfg.loss_type == "l1" else L.PROBLEM_REGRESSION_MSE
+        elif problem in ("single_label_classification", None):
+            if cfg.loss_type in ("token_ce", "token_ce_intra", "auc"):
+                raise NotImplementedError(f"loss_type={cfg.loss_type!r} is outside the hot-path scope")
+            code = L.PROBLEM_SINGLE_LABEL
+        else:
+            raise NotImplementedError("multi-label BCE head is outside the hot-path scope")
+        e = self._pre_forward(B, S)
+        loss, logits, hid = e.forward_task(input_ids, attention_mask, position_ids, task_labels, sample_wgt, code)
+        return DoubleHeadsModelOutput(pretrain_loss=None, task_loss=self._wrap_loss(loss), pretrain_logits=None,
+                                      task_logits=logits, task_hidden_states=hid)
+
+
+def convert_to_legacy_config(model_cfg) -> GraphGPTConfig:
+    """Counterpart of reference configuration_graphgpt.py:210-342 for the fields of the hot path: accepts the
+    reference's nested `GraphGPTModelConfig`-like object (attributes or dicts) or a flat dict."""
+    def get(obj, path, default=None):
+        cur = obj
+        for part in path.split("."):
+            if cur is None:
+                return default
+            cur = cur.get(part, None) if isinstance(cur, dict) else getattr(cur, part, None)
+        return default if cur is None else cur
+
+    if isinstance(model_cfg, dict) and "hidden_size" in model_cfg and "graph_input" not in model_cfg:
+        return GraphGPTConfig(**model_cfg)
+    return GraphGPTConfig(
+        vocab_size=get(model_cfg, "vocab_size"), hidden_size=get(model_cfg, "hidden_size"),
+        intermediate_size=get(model_cfg, "intermediate_size"), num_hidden_layers=get(model_cfg, "num_hidden_layers"),
+        num_attention_heads=get(model_cfg, "num_attention_heads"), hidden_act=get(model_cfg, "hidden_act", "gelu"),
+        max_position_embeddings=get(model_cfg, "max_position_embeddings", 1024),
+        rms_norm_eps=get(model_cfg, "rms_norm_eps", 1e-6), causal_attention=get(model_cfg, "causal_attention", False),
+        stacked_feat=get(model_cfg, "graph_input.stacked_feat", 1), stack_method=get(model_cfg, "graph_input.stack_method", "short"),
+        stacked_feat_agg_method=get(model_cfg, "graph_input.stacked_feat_agg_method", "sum"),
+        next_n_token=get(model_cfg, "pt_head.next_n_token", 1), layer_scale_init_value=get(model_cfg, "dropout.layer_scale_init_value", 0.0),
+        path_pdrop=get(model_cfg, "dropout.path_pdrop", 0.0), mlp_pdrop=get(model_cfg, "dropout.mlp_pdrop", 0.0),
+        attention_dropout=get(model_cfg, "attention_dropout", 0.0), rope_theta=get(model_cfg, "rope_theta", 10000.0),
+        num_labels=get(model_cfg, "ft_head.num_labels", 2), problem_type=get(model_cfg, "ft_head.problem_type", None),
+        loss_type=get(model_cfg, "ft_head.loss_type", None))

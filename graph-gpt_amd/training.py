@@ -1,0 +1,316 @@
+"""Training-side surface for the hot path: the engine object the reference gets from
+`deepspeed.initialize` (SURVEY.md 8b "Engine protocol": .module/.backward/.step/.save_checkpoint/
+.load_checkpoint/.global_steps/.device), the per-step loop of `batch_training` / `ft_batch_training`
+(reference src/utils/training_utils.py:7-95, :98-205), the LR schedules (loss_utils.py:322-367,
+ds_config2_pt.json:20-28) and a lean `TrainingPipeline` / `TrainingMode` (reference
+src/training/pipeline.py:60-95, mode.py:46-89) that drives them from any iterable of collated batches.
+
+Data parallelism: one process per GPU; gradients live in ONE flat bf16 array cut into
+L+2 buckets in the order backward completes them; each bucket is all-reduced (RCCL, sum) on a side HIP
+stream as soon as its backward stage is enqueued, so communication overlaps the remaining backward;
+1/world is folded into the fused AdamW.  No DeepSpeed, no DDP hooks.
+"""
+from __future__ import annotations
+
+import abc
+import math
+import os
+import time
+from typing import Any, Callable, Dict, Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+from .modeling import GraphGPTPretrainBase, GraphGPTTaskModel, _GgetModel
+
+
+# ----------------------------------------------------------------------------- LR schedules
+def one_cycle_lr(step: int, max_lr: float, total_steps: int, pct_start: float, min_lr: float = 0.0) -> float:
+    """torch OneCycleLR(anneal='cos', div_factor=25) exactly as `_py_one_cycle` configures it
+    (reference src/utils/loss_utils.py:322-367); `step` is the 0-based scheduler step."""
+    initial = max_lr / 25.0
+    final = min_lr if min_lr > 0 else initial / 1e4
+    up_end = float(pct_start * total_steps) - 1
+    down_end = total_steps - 1
+
+    def cos_anneal(a, b, pct):
+        return b + (a - b) / 2.0 * (math.cos(math.pi * pct) + 1)
+
+    if step <= up_end:
+        return cos_anneal(initial, max_lr, step / up_end if up_end > 0 else 1.0)
+    return cos_anneal(max_lr, final, (step - up_end) / (down_end - up_end))
+
+
+def warmup_decay_lr(step: int, max_lr: float, min_lr: float, warmup: int, total: int) -> float:
+    """DeepSpeed WarmupDecayLR as named by examples/ds_config2_pt.json:20-28 (log warm-up, linear decay)."""
+    if step < warmup:
+        gamma = math.log(step + 1) / math.log(max(2, warmup))
+    else:
+        gamma = max(0.0, (total - step) / max(1.0, total - warmup))
+    return min_lr + (max_lr - min_lr) * gamma
+
+
+class OptimConfig:
+    """Defaults = the reference pre-train launch script (examples/graph_lvl/pcqm4m_v2_pretrain.sh:53-57)."""
+
+    def __init__(self, lr=3e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1, max_grad_norm=1.0, min_lr=0.0,
+                 warmup_num_steps=0, total_num_steps=0, schedule="constant"):
+        self.lr, self.betas, self.eps, self.weight_decay = lr, tuple(betas), eps, weight_decay
+        self.max_grad_norm, self.min_lr = max_grad_norm, min_lr
+        self.warmup_num_steps, self.total_num_steps, self.schedule = warmup_num_steps, total_num_steps, schedule
+
+    def lr_at(self, step: int) -> float:
+        if self.schedule == "onecycle" and self.total_num_steps > 0:
+            return one_cycle_lr(step, self.lr, self.total_num_steps + 1,
+                                self.warmup_num_steps / max(1, self.total_num_steps), self.min_lr)
+        if self.schedule == "warmup_decay" and self.total_num_steps > 0:
+            return warmup_decay_lr(step, self.lr, self.min_lr, self.warmup_num_steps, self.total_num_steps)
+        return self.lr
+
+
+# ----------------------------------------------------------------------------- engine protocol
+class GgetEngine:
+    """What `deepspeed.initialize(model=...)` returns in the reference (pretrain_mode.py:281-287), rebuilt on
+    the HIP engine: forward via `engine(...)`, `engine.backward(loss)`, `engine.step()`."""
+
+    def __init__(self, model: _GgetModel, optim: Optional[OptimConfig] = None, process_group=None):
+        self.module = model
+        self.optim = optim or OptimConfig()
+        self.global_steps = 0
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self._comm_stream = None
+        self._pending = []
+        model.materialize_grads = False  # fused path: gradients stay in the flat bf16 arena
+
+    @property
+    def device(self):
+        return self.module.device
+
+    def __call__(self, *a, **k):
+        return self.module(*a, **k)
+
+    def train(self, mode=True):
+        self.module.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    # -- backward with bucketed all-reduce overlapped on a side stream
+    def backward(self, loss=None):
+        e = self.module._engine
+        if self.world == 1:
+            e.backward()
+            return
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=e.device)
+        main = torch.cuda.current_stream()
+        L_ = e.spec.num_layers
+
+        def reduce_bucket(b):
+            off, cnt = e.buckets[b]
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._comm_stream.wait_event(ev)
+            with torch.cuda.stream(self._comm_stream):
+                w = dist.all_reduce(e.grad_bf16[off: off + cnt], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._pending.append(w)
+
+        e.backward_begin()
+        reduce_bucket(0)
+        for i in range(L_ - 1, -1, -1):
+            e.backward_layer(i)
+            reduce_bucket(L_ - i)
+        e.backward_end()
+        reduce_bucket(L_ + 1)
+
+    def step(self):
+        e = self.module._engine
+        if self._pending:
+            for w in self._pending:
+                w.wait()  # makes the current stream wait for the comm stream's collectives
+            self._pending = []
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        o = self.optim
+        lr = o.lr_at(self.global_steps)
+        gn = e.adamw_step(lr, o.betas[0], o.betas[1], o.eps, o.weight_decay, o.max_grad_norm, 1.0 / self.world)
+        self.global_steps += 1
+        self.last_lr, self.last_grad_norm = lr, gn
+        return gn
+
+    # -- checkpoint = reference DDP layout (misc_utils.py:105-121): model.pt / optimizer.pt keyed by state-dict names
+    def save_checkpoint(self, save_dir: str, tag: Optional[str] = None):
+        d = os.path.join(save_dir, tag) if tag else save_dir
+        os.makedirs(d, exist_ok=True)
+        e = self.module._engine
+        torch.save({k: v.cpu() for k, v in e.state_dict().items()}, os.path.join(d, "model.pt"))
+        torch.save({"m": {k: e.view(k, "m").cpu() for k in e.params}, "v": {k: e.view(k, "v").cpu() for k in e.params},
+                    "step": e.step_count, "global_steps": self.global_steps}, os.path.join(d, "optimizer.pt"))
+        self.module.config.save_pretrained(d)
+
+    def load_checkpoint(self, load_dir: str, tag: Optional[str] = None):
+        d = os.path.join(load_dir, tag) if tag else load_dir
+        e = self.module._engine
+        if e is None:
+            e = self.module._ensure_engine(1, 8)
+        e.load_state_dict(torch.load(os.path.join(d, "model.pt"), map_location="cpu"))
+        opt_path = os.path.join(d, "optimizer.pt")
+        if os.path.exists(opt_path):
+            st = torch.load(opt_path, map_location="cpu")
+            for k in e.params:
+                e.view(k, "m").copy_(st["m"][k].to(e.device))
+                e.view(k, "v").copy_(st["v"][k].to(e.device))
+            e.step_count = int(st["step"])
+            self.global_steps = int(st["global_steps"])
+        return d, {}
+
+
+def initialize(model: _GgetModel, optim: Optional[OptimConfig] = None, process_group=None) -> GgetEngine:
+    return GgetEngine(model, optim, process_group)
+
+
+# ----------------------------------------------------------------------------- one optimisation step
+def batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine):
+    """reference training_utils.batch_training DeepSpeed branch (:30-45): loss = head1 (+head2); backward; step.
+    position_ids are NOT passed in pre-training (reference comments them out at :35)."""
+    out = engine(input_ids=data["input_ids"], attention_mask=data["attention_mask"], labels=data["labels"],
+                 inputs_raw_embeds=None, sample_wgt=data.get("wgt"))
+    loss = out.head1_loss
+    if out.head2_loss is not None:
+        loss = loss + out.head2_loss
+    engine.backward(loss)
+    engine.step()
+    return loss
+
+
+def ft_batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine, label_key: str = "task_labels"):
+    """reference training_utils.ft_batch_training (:98-205): passes position_ids, task labels, sample weights."""
+    out = engine(input_ids=data["input_ids"], attention_mask=data["attention_mask"], position_ids=data.get("position_ids"),
+                 task_labels=data[label_key], cls_idx=data.get("cls_idx"), sample_wgt=data.get("wgt"))
+    loss = out.task_loss
+    engine.backward(loss)
+    engine.step()
+    return loss, out.task_logits
+
+
+# ----------------------------------------------------------------------------- distributed env
+def set_dist_env(backend: Optional[str] = None):
+    """reference misc_utils.set_dist_env (:507-539): env:// rendezvous, one process per GPU, barrier."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, init_method="env://", **kw)
+        dist.barrier()
+    return rank, local, world
+
+
+# ----------------------------------------------------------------------------- pipeline (lean)
+class TrainingMode(abc.ABC):
+    """Strategy interface of the reference (src/training/mode.py:46-89) reduced to what the hot path needs; the
+    dataset/tokenizer halves of `prepare_data` stay on the host and are supplied as an iterable of batches."""
+
+    model_cls = GraphGPTPretrainBase
+
+    @abc.abstractmethod
+    def train_step(self, engine: GgetEngine, batch) -> torch.Tensor: ...
+
+    def update_config(self, pipeline) -> None:
+        return None
+
+    def prepare_data(self, pipeline) -> None:
+        return None
+
+    def post_model_setup(self, pipeline) -> bool:
+        return False
+
+    def setup_optimizer(self, pipeline) -> None:
+        pipeline.engine = initialize(pipeline.model, pipeline.optim)
+
+    def setup_training(self, pipeline) -> None:
+        return None
+
+    def run_training(self, pipeline) -> None:
+        t0 = time.time()
+        tokens = 0
+        for step, batch in enumerate(pipeline.batches):
+            loss = self.train_step(pipeline.engine, batch)
+            tokens += int(batch["attention_mask"].sum())
+            if pipeline.log_every and (step + 1) % pipeline.log_every == 0:
+                torch.cuda.synchronize()
+                dt = time.time() - t0
+                pipeline.log(f"step {step + 1} loss {float(loss):.5f} lr {pipeline.engine.last_lr:.3e} "
+                             f"tokens/s/gpu {tokens / dt:.0f}")
+            if pipeline.max_steps and step + 1 >= pipeline.max_steps:
+                break
+
+
+class PretrainMode(TrainingMode):
+    model_cls = GraphGPTPretrainBase
+
+    def train_step(self, engine, batch):
+        return batch_training(batch, engine)
+
+
+class FinetuneMode(TrainingMode):
+    model_cls = GraphGPTTaskModel
+
+    def train_step(self, engine, batch):
+        return ft_batch_training(batch, engine)[0]
+
+
+class TrainingPipeline:
+    """`TrainingPipeline(cfg, mode).run()` (reference pipeline.py:60-95).  `cfg` is a dict / object with `model`
+    (GraphGPTConfig or kwargs), `optim` (OptimConfig or kwargs), `batches` (iterable of collated batches),
+    optional `max_steps`, `log_every`, `output_dir`, `resume_from`."""
+
+    def __init__(self, cfg: Any, mode: TrainingMode):
+        get = (lambda k, d=None: cfg.get(k, d)) if isinstance(cfg, dict) else (lambda k, d=None: getattr(cfg, k, d))
+        from .modeling import GraphGPTConfig
+        mc = get("model")
+        self.model_config = mc if isinstance(mc, GraphGPTConfig) else GraphGPTConfig(**mc)
+        oc = get("optim", {})
+        self.optim = oc if isinstance(oc, OptimConfig) else OptimConfig(**(oc or {}))
+        self.batches: Iterable = get("batches")
+        self.max_steps, self.log_every = get("max_steps", 0), get("log_every", 0)
+        self.output_dir, self.resume_from = get("output_dir"), get("resume_from")
+        self.mode = mode
+        self.model = None
+        self.engine: Optional[GgetEngine] = None
+        self.rank = 0
+
+    def log(self, msg: str):
+        if self.rank == 0:
+            print(msg, flush=True)
+
+    def run(self):
+        self.rank, _, _ = set_dist_env()
+        self.mode.update_config(self)
+        self.mode.prepare_data(self)
+        self.model = self.mode.model_cls(self.model_config)
+        self.model.gradient_checkpointing_enable()
+        self.model.config.use_cache = False
+        if self.mode.post_model_setup(self):
+            return self
+        self.model.cuda()
+        self.mode.setup_optimizer(self)
+        if self.resume_from:
+            self.engine.load_checkpoint(self.resume_from)
+        self.mode.setup_training(self)
+        self.mode.run_training(self)
+        if self.output_dir and self.rank == 0:
+            self.engine.save_checkpoint(self.output_dir)
+        return self
+
+
+def launch(fn: Callable, *args, **kwargs):
+    """reference `launch(train)` (pipeline.py:229-257) strips launcher args and calls the entry point; ranks are
+    created by `python -m torch.distributed.run`, one per GPU."""
+    return fn(*args, **kwargs)

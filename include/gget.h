@@ -1,0 +1,193 @@
+/*
+ * gget.h - C ABI of libgget_hip.so, the MI355X (gfx950) engine for the GraphGPT
+ * Graph-Eulerian-Transformer hot path.
+ *
+ * The reference (alibaba/graph-gpt) has no FFI layer: its operator API for this path is the
+ * Python nn.Module surface.  This header is the boundary a binding for that
+ * surface sits on; every entry point cites the reference interface it replaces
+ * (paths relative to the reference repo root).  The build's own ctypes binding is
+ * graph-gpt_amd/_lib.py; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; gget_last_error() gives the text;
+ *     nothing throws across the ABI;
+ *   - all pointers named *_dev are device (HBM) pointers owned by the caller; the engine never
+ *     allocates, frees or copies across PCIe behind the caller's back (the caller - PyTorch in
+ *     our binding - owns memory and streams);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no host sync unless
+ *     the function says so;
+ *   - not thread-safe per handle; one handle per GPU per process (one process per GPU).
+ *   - integer batch tensors use the reference's dtypes: int64 ids/labels/masks.
+ */
+#ifndef GGET_H_
+#define GGET_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGET_KIND_PRETRAIN 0 /* GraphGPTPretrainBase (src/models/graphgpt/modeling_pretrain.py:57) */
+#define GGET_KIND_TASK 1     /* GraphGPTTaskModel    (src/models/graphgpt/modeling_finetune.py:64) */
+
+#define GGET_PROBLEM_SINGLE_LABEL 0 /* CrossEntropy on pooled logits (modeling_finetune.py:209-214) */
+#define GGET_PROBLEM_REGRESSION_L1 1 /* L1Loss  (modeling_finetune.py:183-197) */
+#define GGET_PROBLEM_REGRESSION_MSE 2 /* MSELoss */
+
+/* Field meaning = GraphGPTConfig (src/models/graphgpt/configuration_graphgpt.py:26-110). */
+typedef struct gget_config_t {
+  int32_t kind;           /* GGET_KIND_* */
+  int32_t vocab_size;
+  int32_t hidden_size;    /* d, multiple of 64 */
+  int32_t intermediate_size; /* ff, multiple of 64 */
+  int32_t num_layers;
+  int32_t num_heads;      /* d / 64 (head_dim is 64: src/utils/modules_utils.py:37-42) */
+  int32_t stacked_feat;   /* F */
+  int32_t next_n_token;   /* pre-train: F; 1 => n_token_proj is Identity */
+  int32_t gated_agg;      /* stacked_feat_agg_method == "gated" */
+  int32_t causal;         /* causal_attention */
+  int32_t max_position;   /* max_position_embeddings */
+  int32_t num_labels;     /* fine-tune head width */
+  int32_t score_bias;     /* problem_type == "regression" */
+  int32_t pad_token_id;
+  float rms_eps;
+  float rope_theta;
+  float layer_scale_init; /* >0 => lambda_1 / lambda_2 per layer (utils_graphgpt.py:95-104) */
+  int32_t max_tokens;     /* capacity: max B*S of any forward call */
+  int32_t max_batch;      /* capacity: max B */
+} gget_config_t;
+
+/* Arena sizes the caller must provide (all 256-byte aligned device buffers). */
+typedef struct gget_sizes_t {
+  uint64_t n_params;        /* parameter elements (flat) */
+  uint64_t param_bf16_bytes;/* compute copy of the parameters, bf16 [n_params] */
+  uint64_t master_bytes;    /* fp32 master weights [n_params] */
+  uint64_t adam_bytes;      /* fp32 m and v, 2*[n_params] */
+  uint64_t grad_bf16_bytes; /* bf16 gradients [n_params] (what the DP all-reduce moves) */
+  uint64_t workspace_bytes; /* activations + scratch for max_tokens */
+} gget_sizes_t;
+
+typedef struct gget_buffers_t {
+  void* param_bf16_dev;
+  void* master_dev;
+  void* adam_m_dev;
+  void* adam_v_dev;
+  void* grad_bf16_dev;
+  void* workspace_dev;
+  const float* rope_cos_dev; /* [max_position][32] fp32, hf LlamaRotaryEmbedding tables; NULL => engine computes */
+  const float* rope_sin_dev;
+} gget_buffers_t;
+
+typedef struct gget_param_info_t {
+  char name[96];      /* reference state-dict key, e.g. "model.layers.3.mlp.down_proj.weight" */
+  int32_t ndim;
+  int64_t shape[2];
+  uint64_t offset;    /* element offset into the flat param / master / adam / grad arrays */
+  int32_t layer;      /* decoder layer index, -1 embeddings, num_layers = final norm + heads */
+} gget_param_info_t;
+
+typedef struct gget_engine* gget_handle_t;
+
+const char* gget_last_error(void);
+int gget_version(void);
+
+/* replaces: GraphGPTPretrainBase.__init__/GraphGPTTaskModel.__init__ (modeling_pretrain.py:58-117,
+ * modeling_finetune.py:67-105): computes the flat parameter layout and workspace need. */
+int gget_query_sizes(const gget_config_t* cfg, gget_sizes_t* out);
+int gget_create(const gget_config_t* cfg, const gget_buffers_t* bufs, gget_handle_t* out);
+int gget_destroy(gget_handle_t h);
+
+/* replaces: nn.Module.named_parameters()/state_dict() key+shape enumeration. */
+int gget_param_count(gget_handle_t h);
+int gget_param_info(gget_handle_t h, int index, gget_param_info_t* out);
+/* number of DP gradient buckets (embeddings | one per decoder layer | final norm + heads) and their
+ * element ranges in the flat gradient array, in the order backward completes them. */
+int gget_bucket_count(gget_handle_t h);
+int gget_bucket_range(gget_handle_t h, int bucket, uint64_t* offset, uint64_t* count);
+
+/* replaces: load_state_dict + `.to(bfloat16)`: refresh the bf16 compute copy from the fp32 master. */
+int gget_sync_params(gget_handle_t h, void* stream);
+
+/* replaces: GraphGPTPretrainBase.forward (modeling_pretrain.py:152-266).
+ *   input_ids i64 [B,S,F]; attention_mask i64 [B,S] (1 real / 0 right padding);
+ *   labels i64 [B,S,next_n] (-100 = not predicted) or NULL (=> logits for every cell, no loss);
+ *   sample_wgt f32 [B] or NULL (dLM weighting, modeling_pretrain.py:230-236);
+ *   position_ids i64 [B,S] or NULL (=> arange(S), hf LlamaModel.forward :389-392).
+ *   loss_dev: f32[1] device scalar (head1_loss).  Logits stay in the workspace: gget_head_logits. */
+int gget_forward_pretrain(gget_handle_t h, const int64_t* input_ids_dev, const int64_t* attention_mask_dev,
+                          const int64_t* labels_dev, const float* sample_wgt_dev, const int64_t* position_ids_dev,
+                          int B, int S, float* loss_dev, void* stream);
+
+/* replaces: GraphGPTTaskModel.forward + calculate_task_loss (modeling_finetune.py:236-326, :167-234).
+ *   task_labels: i64 [B] (single label) or f32 [B] (regression), NULL => no loss;
+ *   task_logits_dev f32 [B,num_labels] (pooled "last" row, returned as .float());
+ *   task_hidden_dev bf16 [B,d] or NULL. */
+int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, const int64_t* attention_mask_dev,
+                      const int64_t* position_ids_dev, const void* task_labels_dev, const float* sample_wgt_dev,
+                      int problem_type, int B, int S, float* loss_dev, float* task_logits_dev,
+                      void* task_hidden_dev, void* stream);
+
+/* replaces: loss.backward() / engine.backward(loss) (src/utils/training_utils.py:44,66).
+ * Full backward of the last forward; bf16 gradients of every parameter land in grad_bf16_dev.
+ * The staged form lets the caller overlap the DP all-reduce of bucket k with the backward of the
+ * next layers (one HIP event per bucket on the caller's side):
+ *   gget_backward_begin  -> head + final norm   (bucket 0 complete)
+ *   gget_backward_layer(i) for i = L-1..0       (bucket L-i complete)
+ *   gget_backward_end    -> embedding scatter   (last bucket complete)  */
+int gget_backward(gget_handle_t h, float loss_scale, void* stream);
+int gget_backward_begin(gget_handle_t h, float loss_scale, void* stream);
+int gget_backward_layer(gget_handle_t h, int layer, void* stream);
+int gget_backward_end(gget_handle_t h, void* stream);
+
+/* replaces: clip_grad_norm_ + AdamW.step / FusedAdam (training_utils.py:68-80, opt_utils.py:18-24,
+ * examples/ds_config2_pt.json:11-19).  grad_scale multiplies every gradient first (1/world after a
+ * sum all-reduce); max_grad_norm <= 0 disables clipping; step is 1-based.
+ * gnorm_dev (f32[1], may be NULL) receives the pre-clip global L2 norm. */
+int gget_adamw_step(gget_handle_t h, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    float max_grad_norm, float grad_scale, int step, float* gnorm_dev, void* stream);
+
+/* Head bookkeeping of the last pre-train forward.  counts[0] = M (positions with >=1 masked
+ * feature), counts[1] = Lm (masked feature tokens).  Synchronises `stream`.
+ * logits: bf16 [Lm][ld] with ld = round_up(V,64) (pad columns are zero). */
+int gget_head_counts(gget_handle_t h, int32_t counts[2], void* stream);
+int gget_head_logits(gget_handle_t h, const void** logits_dev, int32_t* ld);
+/* final hidden states bf16 [B*S][d] of the last forward (outputs[0] of the backbone) */
+int gget_hidden_states(gget_handle_t h, const void** hidden_dev);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator-level entry points (the individual HIP kernels), used by the parity tests and by
+ * callers that only want one op.  bf16 tensors unless stated; row-major; ld* in elements.
+ * ------------------------------------------------------------------------------------------ */
+#define GGET_GEMM_NT 0 /* C[M,N] = A[M,K] * B[N,K]^T   (forward  y = x W^T) */
+#define GGET_GEMM_NN 1 /* C[M,N] = A[M,K] * B[K,N]     (dgrad    dx = dy W) */
+#define GGET_GEMM_TN 2 /* C[M,N] = A[K,M]^T * B[K,N]   (wgrad    dW = dy^T x) */
+#define GGET_EPI_NONE 0
+#define GGET_EPI_RESIDUAL 1 /* C = A*B + R (R bf16 [M,N], ldr = ldc) */
+#define GGET_EPI_ATOMIC_F32 2 /* C is fp32, C += A*B with atomics (split-K over blockIdx.z) */
+int gget_op_gemm(int mode, int epilogue, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
+                 int lda, int ldb, int ldc, int split_k, void* stream);
+int gget_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, void* stream);
+int gget_op_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
+                        void* dx, float* dw_accum, int T, int d, void* stream);
+int gget_op_embed_fwd(const int64_t* ids, const void* emb, const void* gate, void* out, int T, int F, int ldF,
+                      int d, void* stream);
+int gget_op_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* gate, float* demb_accum,
+                      float* dgate_accum, int T, int F, int ldF, int d, int V, int pad_id, void* stream);
+int gget_op_rope(void* qkv, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, int B, int S,
+                 int H, int inverse, void* stream);
+int gget_op_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H,
+                     int causal, void* stream);
+int gget_op_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len,
+                     void* dqkv, float* delta_ws, int B, int S, int H, int causal, void* stream);
+int gget_op_geglu_fwd(const void* gu, void* h, int T, int ff, void* stream);
+int gget_op_geglu_bwd(const void* gu, const void* dh, void* dgu, int T, int ff, void* stream);
+int gget_op_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const float* row_wgt, const int32_t* n_rows_dev,
+                       int n_rows_cap, int V, float* loss_sum, void* dlogits, float grad_scale_base, int mean_over_rows,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGET_H_ */

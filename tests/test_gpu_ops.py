@@ -1,0 +1,264 @@
+"""Kernel-level parity: every HIP op, called through the C ABI (include/gget.h, gget_op_*), against a
+plain fp32 PyTorch statement of the same arithmetic on the same bf16 inputs (tolerances written per test)."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from _util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+L = importlib.import_module("graph-gpt_amd._lib")
+
+
+def P(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def ST():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return L.load()
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).cuda()
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("mode", [L.GEMM_NT, L.GEMM_NN, L.GEMM_TN])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (200, 136, 72), (1000, 756, 128), (64, 2304, 768),
+                                   (333, 768, 3072)])
+def test_gemm_modes(lib, mode, M, N, K):
+    # asymmetric operands (catches transposed outputs); sizes include ragged M/N/K tails
+    if mode == L.GEMM_NT:
+        A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+        ref = A.float() @ B.float().T
+        lda, ldb = K, K
+    elif mode == L.GEMM_NN:
+        if N % 8:
+            pytest.skip("N-contiguous operand needs N % 8 == 0")
+        A, B = rnd(M, K, seed=1), rnd(K, N, seed=2)
+        ref = A.float() @ B.float()
+        lda, ldb = K, N
+    else:
+        if N % 8 or M % 8:
+            pytest.skip("M/N-contiguous operands need M,N % 8 == 0")
+        A, B = rnd(K, M, seed=1), rnd(K, N, seed=2)
+        ref = A.float().T @ B.float()
+        lda, ldb = M, N
+    ldc = (N + 7) // 8 * 8
+    Cm = torch.full((M, ldc), 7.0, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.gget_op_gemm(mode, L.EPI_NONE, P(A), P(B), P(Cm), None, M, N, K, lda, ldb, ldc, 1, ST()))
+    torch.cuda.synchronize()
+    got = Cm[:, :N].float()
+    err = rel_l2(got.cpu().numpy(), ref.cpu().numpy())
+    assert err < 4e-3, f"mode {mode} {M}x{N}x{K}: rel-L2 {err}"  # bf16 output rounding ~ 2^-9
+    if ldc > N:
+        assert torch.all(Cm[:, N:] == 7.0), "wrote outside the N bound"
+
+
+def test_gemm_residual_and_atomic(lib):
+    M, N, K = 300, 256, 320
+    A, B, R = rnd(M, K, seed=3), rnd(N, K, seed=4), rnd(M, N, seed=5)
+    Cm = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.gget_op_gemm(L.GEMM_NT, L.EPI_RESIDUAL, P(A), P(B), P(Cm), P(R), M, N, K, K, K, N, 1, ST()))
+    ref = A.float() @ B.float().T + R.float()
+    assert rel_l2(Cm.float().cpu().numpy(), ref.cpu().numpy()) < 4e-3
+    Cf = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_gemm(L.GEMM_NT, L.EPI_ATOMIC_F32, P(A), P(B), P(Cf), None, M, N, K, K, K, N, 3, ST()))
+    ref2 = A.float() @ B.float().T
+    assert rel_l2(Cf.cpu().numpy(), ref2.cpu().numpy()) < 1e-5  # fp32 accumulate, no output rounding
+
+
+def test_gemm_identity_layout(lib):
+    # A = I with an asymmetric B: the output must be B^T exactly (bit-exact, catches row/col swaps)
+    n = 128
+    A = torch.eye(n, dtype=torch.bfloat16, device="cuda")
+    B = rnd(n, n, seed=6)
+    Cm = torch.zeros(n, n, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.gget_op_gemm(L.GEMM_NT, L.EPI_NONE, P(A), P(B), P(Cm), None, n, n, n, n, n, n, 1, ST()))
+    assert torch.equal(Cm, B.T.contiguous())
+    L.check(lib.gget_op_gemm(L.GEMM_NN, L.EPI_NONE, P(A), P(B), P(Cm), None, n, n, n, n, n, n, 1, ST()))
+    assert torch.equal(Cm, B)
+    L.check(lib.gget_op_gemm(L.GEMM_TN, L.EPI_NONE, P(B), P(A), P(Cm), None, n, n, n, n, n, n, 1, ST()))
+    assert torch.equal(Cm, B.T.contiguous())
+
+
+# ------------------------------------------------------------------------------------------ RMSNorm
+@pytest.mark.parametrize("T,d", [(37, 128), (512, 768), (100, 1024)])
+def test_rmsnorm(lib, T, d):
+    x, w, dy, dres = rnd(T, d, seed=1), (rnd(d, seed=2) * 0.1 + 1).to(torch.bfloat16), rnd(T, d, seed=3), rnd(T, d, seed=4)
+    y = torch.empty_like(x)
+    rstd = torch.empty(T, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_rmsnorm_fwd(P(x), P(w), P(y), P(rstd), T, d, 1e-6, ST()))
+    xf = x.float().requires_grad_(True)
+    wf = w.float().requires_grad_(True)
+    var = xf.pow(2).mean(-1, keepdim=True)
+    ref = wf * (xf * torch.rsqrt(var + 1e-6))
+    assert rel_l2(y.float().cpu().numpy(), ref.detach().cpu().numpy()) < 6e-3  # two bf16 roundings (hf :62-67)
+    np.testing.assert_allclose(rstd.cpu().numpy(), torch.rsqrt(var + 1e-6).squeeze(-1).detach().cpu().numpy(), rtol=1e-5)
+    ref.backward(dy.float())
+    dx = torch.empty_like(x)
+    dw = torch.zeros(d, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_rmsnorm_bwd(P(dy), P(x), P(w), P(rstd), P(dres), P(dx), P(dw), T, d, ST()))
+    assert rel_l2(dx.float().cpu().numpy(), (xf.grad + dres.float()).cpu().numpy()) < 4e-3
+    assert rel_l2(dw.cpu().numpy(), wf.grad.cpu().numpy()) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ embedding
+@pytest.mark.parametrize("gated", [False, True])
+def test_embed(lib, gated):
+    T, F, d, V = 300, 13, 128, 97
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, V, (T, F), generator=g)
+    ids[::3, ::2] = 1   # hot <mask> id
+    ids[5:9] = 0        # pad rows
+    ids = ids.cuda()
+    emb = rnd(V, d, seed=1)
+    emb[0] = 0
+    gate = rnd(F, d, seed=2) if gated else None
+    out = torch.empty(T, d, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.gget_op_embed_fwd(P(ids), P(emb), P(gate), P(out), T, F, F, d, ST()))
+    ef = emb.float().requires_grad_(True)
+    gf = gate.float().requires_grad_(True) if gated else None
+    e = ef[ids]
+    ref = torch.einsum("tfd,fd->td", e, gf) if gated else e.sum(1)
+    assert rel_l2(out.float().cpu().numpy(), ref.detach().cpu().numpy()) < 4e-3
+    dx = rnd(T, d, seed=3)
+    ref.backward(dx.float())
+    demb = torch.zeros(V, d, dtype=torch.float32, device="cuda")
+    dgate = torch.zeros(F, d, dtype=torch.float32, device="cuda") if gated else None
+    L.check(lib.gget_op_embed_bwd(P(ids), P(dx), P(emb), P(gate), P(demb), P(dgate), T, F, F, d, V, 0, ST()))
+    want = ef.grad.clone()
+    want[0] = 0  # padding_idx row receives no gradient
+    assert rel_l2(demb.cpu().numpy(), want.cpu().numpy()) < 1e-4
+    if gated:
+        assert rel_l2(dgate.cpu().numpy(), gf.grad.cpu().numpy()) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ RoPE + attention
+def _rope_ref(x, pos, theta=10000.0):
+    # x [B,S,H,64] fp32, pos [B,S]
+    inv = 1.0 / (theta ** (torch.arange(0, 64, 2, dtype=torch.float32, device=x.device) / 64))
+    fr = pos.float()[:, :, None] * inv
+    emb = torch.cat((fr, fr), -1)[:, :, None, :]
+    x1, x2 = x[..., :32], x[..., 32:]
+    return x * emb.cos() + torch.cat((-x2, x1), -1) * emb.sin()
+
+
+def _tables(maxpos):
+    eng = importlib.import_module("graph-gpt_amd.engine")
+    c, s = eng.rope_tables(maxpos, 64, 10000.0)
+    return c.cuda(), s.cuda()
+
+
+@pytest.mark.parametrize("with_pos", [False, True])
+def test_rope(lib, with_pos):
+    B, S, H = 3, 40, 2
+    d = H * 64
+    qkv = rnd(B * S, 3 * d, seed=1)
+    orig = qkv.clone()
+    cos, sin = _tables(64)
+    pos = None
+    if with_pos:
+        pos = torch.arange(S)[None].repeat(B, 1)
+        pos[1, 20:] = 0
+        pos = pos.cuda()
+    L.check(lib.gget_op_rope(P(qkv), P(cos), P(sin), P(pos), B, S, H, 0, ST()))
+    pr = pos if with_pos else torch.arange(S, device="cuda")[None].repeat(B, 1)
+    x = orig.float().view(B, S, 3, H, 64)
+    want_q, want_k = _rope_ref(x[:, :, 0], pr), _rope_ref(x[:, :, 1], pr)
+    got = qkv.float().view(B, S, 3, H, 64)
+    assert rel_l2(got[:, :, 0].cpu().numpy(), want_q.cpu().numpy()) < 3e-3
+    assert rel_l2(got[:, :, 1].cpu().numpy(), want_k.cpu().numpy()) < 3e-3
+    assert torch.equal(got[:, :, 2], x[:, :, 2])  # v untouched
+    # inverse rotation brings q,k back (orthogonality), up to two bf16 roundings
+    L.check(lib.gget_op_rope(P(qkv), P(cos), P(sin), P(pos), B, S, H, 1, ST()))
+    assert rel_l2(qkv.float().cpu().numpy(), orig.float().cpu().numpy()) < 6e-3
+
+
+def _attn_ref(qkv, lens, B, S, H, causal):
+    d = H * 64
+    x = qkv.float().view(B, S, 3, H, 64)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))  # [B,H,S,64]
+    w = q @ k.transpose(2, 3) * 0.125
+    keym = torch.arange(S, device=qkv.device)[None, :] >= lens[:, None]  # [B,S] True = masked
+    w = w.masked_fill(keym[:, None, None, :], float("-inf"))
+    if causal:
+        tri = torch.ones(S, S, dtype=torch.bool, device=qkv.device).tril()
+        w = w.masked_fill(~tri[None, None], float("-inf"))
+    p = torch.softmax(w, -1)
+    o = (p @ v).transpose(1, 2).reshape(B, S, d)
+    return o
+
+
+@pytest.mark.parametrize("causal", [0, 1])
+@pytest.mark.parametrize("B,S,H", [(3, 24, 2), (2, 32, 12), (2, 72, 2), (1, 160, 3)])
+def test_attention_fwd_bwd(lib, B, S, H, causal):
+    d = H * 64
+    qkv = rnd(B * S, 3 * d, seed=7, scale=1.0)
+    lens = torch.tensor([S, max(5, S // 2), max(1, S - 3)][:B], dtype=torch.int32).cuda()
+    out = torch.zeros(B * S, d, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_attn_fwd(P(qkv), P(lens), P(out), P(lse), B, S, H, causal, ST()))
+    qf = qkv.float().requires_grad_(True)
+    ref = _attn_ref(qf, lens, B, S, H, causal)
+    valid = (torch.arange(S, device="cuda")[None, :] < lens[:, None])  # real query rows
+    got = out.float().view(B, S, d)
+    e = rel_l2(got[valid].cpu().numpy(), ref.detach()[valid].cpu().numpy())
+    assert e < 8e-3, f"attn fwd rel-L2 {e}"  # bf16 P and O roundings
+    # backward: upstream gradient is zero on pad query rows (as in the real model)
+    dout = rnd(B * S, d, seed=8)
+    dout = (dout.view(B, S, d) * valid[:, :, None]).reshape(B * S, d).contiguous()
+    (ref * dout.float().view(B, S, d)).sum().backward()
+    dqkv = torch.zeros(B * S, 3 * d, dtype=torch.bfloat16, device="cuda")
+    delta = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_attn_bwd(P(qkv), P(out), P(dout), P(lse), P(lens), P(dqkv), P(delta), B, S, H, causal, ST()))
+    g = dqkv.float().view(B, S, 3, d)
+    w = qf.grad.view(B, S, 3, d)
+    for i, nm in enumerate("qkv"):
+        e = rel_l2(g[:, :, i].cpu().numpy(), w[:, :, i].cpu().numpy())
+        assert e < 2e-2, f"attn bwd d{nm} rel-L2 {e}"
+
+
+# ------------------------------------------------------------------------------------------ GEGLU / CE
+def test_geglu(lib):
+    T, ff = 77, 512
+    gu, dh = rnd(T, 2 * ff, seed=1), rnd(T, ff, seed=2)
+    h = torch.empty(T, ff, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.gget_op_geglu_fwd(P(gu), P(h), T, ff, ST()))
+    gf = gu.float().requires_grad_(True)
+    ref = torch.nn.functional.gelu(gf[:, :ff]) * gf[:, ff:]
+    assert rel_l2(h.float().cpu().numpy(), ref.detach().cpu().numpy()) < 6e-3
+    ref.backward(dh.float())
+    dgu = torch.empty_like(gu)
+    L.check(lib.gget_op_geglu_bwd(P(gu), P(dh), P(dgu), T, ff, ST()))
+    assert rel_l2(dgu.float().cpu().numpy(), gf.grad.cpu().numpy()) < 4e-3
+
+
+def test_cross_entropy(lib):
+    rows, V, ld = 500, 756, 768
+    logits = torch.zeros(rows, ld, dtype=torch.bfloat16, device="cuda")
+    logits[:, :V] = rnd(rows, V, seed=1, scale=2.0)
+    labels = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(2)).to(torch.int32).cuda()
+    n_rows = torch.tensor([rows - 37], dtype=torch.int32).cuda()
+    loss_sum = torch.zeros(1, dtype=torch.float32, device="cuda")
+    dl = torch.full((rows, ld), 3.0, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.gget_op_ce_fwd_bwd(P(logits), ld, P(labels), None, P(n_rows), rows, V, P(loss_sum), P(dl), 0.0, 1, ST()))
+    n = rows - 37
+    lf = logits[:n, :V].float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lf, labels[:n].long())
+    ref.backward()
+    got = loss_sum.item() / n
+    assert abs(got - ref.item()) < 1e-5 * abs(ref.item()) + 1e-6
+    assert rel_l2(dl[:n, :V].float().cpu().numpy(), lf.grad.cpu().numpy()) < 5e-3
+    assert torch.all(dl[:n, V:] == 0), "pad columns of dlogits must be zero (they feed the dgrad GEMM)"
+    assert torch.all(dl[n:] == 3.0), "rows beyond the device-side count must not be touched"

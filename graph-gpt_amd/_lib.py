@@ -83,6 +83,10 @@ def load(path: str = LIB_PATH):
     global _lib
     if _lib is not None:
         return _lib
+    # The HIP runtime must be the one PyTorch ships (torch/lib/libamdhip64.so): torch owns the device memory and the
+    # streams we are handed, and a second runtime loaded first does not see the GPU on the pool's boxes.  Importing
+    # torch first makes our DT_NEEDED libamdhip64 resolve to the already-loaded copy.
+    import torch  # noqa: F401
     if not os.path.exists(path):
         raise GgetError(f"{path} is missing: build it with `python graph-gpt_amd/build.py` "
                         "(or __graft_entry__.build()); this engine has no CPU fallback")

@@ -120,7 +120,7 @@ CASES = [
     ("ft_tiny_ls", "ft", dict(vocab_size=1000, stacked_feat=4, next_n_token=1, num_labels=2, layer_scale_init=1.0),
      dict(B=4, S=40, seed=9), dict(std=0.06, head_std=0.15)),
     ("ft_tiny_reg", "ft", dict(vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=1, score_bias=True),
-     dict(B=4, S=24, seed=10, regression=True), dict(std=0.06, head_std=0.15)),
+     dict(B=4, S=24, seed=12, regression=True), dict(std=0.06, head_std=0.15)),
 ]
 
 ADAM = dict(lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
@@ -162,6 +162,11 @@ def run_case(name, kind, skw, bkw, ikw, classes):
     model.zero_grad()
     loss.backward()
     out["loss"] = np.float64(loss.item())
+    if kind == "ft" and spec.num_labels == 1:
+        # L1 regression: the gradient is sign(pred - y); keep every sample far from the kink so that bf16-level
+        # differences in `pred` cannot flip a sign (the parity tests compare gradients)
+        margin = (logits.detach().float().view(-1) - tb["task_labels"].float().view(-1)).abs().min().item()
+        assert margin > 0.15, f"{name}: |pred-y| margin {margin} too small, pick another seed"
     out["logits"] = logits.detach().float().numpy()[:64]
     out["logits_shape"] = np.array(logits.shape)
     out["grad_norms"] = grad_norms(model, names)

@@ -68,6 +68,20 @@ class OptimConfig:
         return self.lr
 
 
+# ----------------------------------------------------------------------------- DP exchange step
+def all_reduce_bucket(flat: torch.Tensor, bucket, group=None, async_op: bool = True):
+    """Sum-all-reduce ONE gradient bucket (a contiguous [offset, offset+count) slice of the flat gradient array).
+    Device-agnostic: RCCL on GPU tensors, gloo on CPU tensors (the CPU tests drive exactly this function)."""
+    off, cnt = bucket
+    return dist.all_reduce(flat[off: off + cnt], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def shard_seed(base_seed: int, rank: int) -> int:
+    """Per-rank data seed: ranks draw independent batches (reference misc_utils.py:536-538 seeds with
+    `initial_seed - rank`; the synthetic generator uses base + rank)."""
+    return int(base_seed) + int(rank)
+
+
 # ----------------------------------------------------------------------------- engine protocol
 class GgetEngine:
     """What `deepspeed.initialize(model=...)` returns in the reference (pretrain_mode.py:281-287), rebuilt on
@@ -114,7 +128,7 @@ class GgetEngine:
             ev.record(main)
             self._comm_stream.wait_event(ev)
             with torch.cuda.stream(self._comm_stream):
-                w = dist.all_reduce(e.grad_bf16[off: off + cnt], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                w = all_reduce_bucket(e.grad_bf16, (off, cnt), self.pg, async_op=True)
             self._pending.append(w)
 
         e.backward_begin()

@@ -1,0 +1,65 @@
+"""world_size-2 gloo tests of the N>1 host path (runs on CPU): env:// rendezvous, per-rank data sharding, and the
+bucketed gradient exchange in the order backward completes the buckets, followed by the 1/world scaling."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+tr = importlib.import_module("graph-gpt_amd.training")
+synth = importlib.import_module("graph-gpt_amd.synth")
+spec_mod = importlib.import_module("graph-gpt_amd.spec")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, _, w = tr.set_dist_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    # bucket layout of a tiny model: embeddings | layers | final norm + heads, contiguous, completion order
+    spec = spec_mod.spec_from_size("tiny", vocab_size=300, stacked_feat=1, next_n_token=1)
+    sizes = []
+    for name, shp in spec.param_table().items():
+        sizes.append(int(np.prod(shp)))
+    n = sum(sizes)
+    cut = [0, sizes[0], n - sizes[-1] - sizes[-2], n]
+    buckets = [(cut[2], cut[3] - cut[2]), (cut[1], cut[2] - cut[1]), (cut[0], cut[1] - cut[0])]  # heads, layers, embed
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(n, generator=g)
+    mine = flat.clone()
+    works = [tr.all_reduce_bucket(flat, b, None, async_op=True) for b in buckets]
+    for wk in works:
+        wk.wait()
+    other = torch.randn(n, generator=torch.Generator().manual_seed(100 + (1 - rank)))
+    ok = torch.allclose(flat, mine + other, atol=1e-6)
+    # data sharding: distinct seeds => distinct batches, same shapes
+    b = synth.make_pretrain_batch(B=4, S=16, F=1, V=300, seed=tr.shard_seed(1234, rank))
+    q.put((rank, bool(ok), int(b["input_ids"].sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1], "bucketed sum all-reduce mismatch"
+    assert res[0][2] != res[1][2], "ranks must draw different batches"

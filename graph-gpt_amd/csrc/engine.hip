@@ -136,7 +136,7 @@ struct Ws {
   std::vector<LayerWs> lw;
   uint64_t rstd_f, hidden;
   uint64_t dxa, dxb, dxc, dxn, dqkv, dattn, dgu, dh, delta, dscaled;
-  uint64_t scratch32, loss_sum, sqnorm, counts, segs;
+  uint64_t scratch32, loss_sum, sqnorm, counts, segs, emb_sort;
   // pre-train head
   uint64_t cnt, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
   // task head
@@ -188,6 +188,7 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.sqnorm = b.take(256);
   w.counts = b.take(256);
   w.segs = b.take((uint64_t)pl.params.size() * sizeof(GgetSegment));
+  w.emb_sort = b.take(k_embed_bwd_ws_elems(T * (uint64_t)c.stacked_feat, (uint64_t)c.vocab_size) * 4);
   if (c.kind == GGET_KIND_PRETRAIN) {
     const uint64_t n = c.next_n_token, Vp = align_up(c.vocab_size, 64);
     w.cnt = b.take(T * 4);
@@ -717,7 +718,7 @@ extern "C" int gget_backward_end(gget_handle_t h, void* stream) {
   float* s32 = h->wsp<float>(h->ws.scratch32);
   if (int e = k_embed_bwd(h->ids, h->dx_cur, h->P + h->plan.emb, h->plan.has_gate ? h->P + h->plan.gate : nullptr,
                           s32 + h->plan.emb32, h->plan.has_gate ? s32 + h->plan.gate32 : nullptr, h->T, c.stacked_feat,
-                          c.stacked_feat, c.hidden_size, c.pad_token_id, /*hot_id=<mask>*/ 1, st))
+                          c.stacked_feat, c.hidden_size, c.vocab_size, c.pad_token_id, h->wsp<int32_t>(h->ws.emb_sort), st))
     return e;
   h->dx_cur = nullptr;
   return convert_bucket(h, c.num_layers + 1, st);
@@ -785,8 +786,12 @@ extern "C" int gget_op_embed_fwd(const int64_t* ids, const void* emb, const void
 }
 extern "C" int gget_op_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* gate, float* demb_accum,
                                  float* dgate_accum, int T, int F, int ldF, int d, int V, int pad_id, void* stream) {
-  (void)V;
-  return k_embed_bwd(ids, dx, emb, gate, demb_accum, dgate_accum, T, F, ldF, d, pad_id, 1, (hipStream_t)stream);
+  int32_t* ws = nullptr;
+  GGET_HIP_CHECK(hipMalloc(&ws, k_embed_bwd_ws_elems((size_t)T * F, (size_t)V) * sizeof(int32_t)));  // test-only entry point
+  const int rc = k_embed_bwd(ids, dx, emb, gate, demb_accum, dgate_accum, T, F, ldF, d, V, pad_id, ws, (hipStream_t)stream);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(ws);
+  return rc;
 }
 extern "C" int gget_op_rope(void* qkv, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, int B, int S,
                             int H, int inverse, void* stream) {

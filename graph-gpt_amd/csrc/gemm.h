@@ -21,6 +21,7 @@ struct GemmProblem {
 struct GemmGroup {
   GemmProblem p[GGET_MAX_GROUP];
   int count;
+  int ablate;  // diagnostics (env GGET_GEMM_ABLATE): bit0 skip LDS-DMA, bit1 skip MFMA, bit2 skip the C store
 };
 
 // mode: GGET_GEMM_NT/NN/TN, epi: GGET_EPI_*; problems of one group share mode and epilogue.

@@ -11,7 +11,19 @@
 // read with gfx950's transposing ds_read_b64_tr_b16, so no operand is ever transposed in HBM.
 // MFMA: v_mfma_f32_16x16x32_bf16, operands swapped (D = Btile * Atile^T) so that a lane owns 4
 // consecutive N of one row of C => 8-byte epilogue stores.
-// Block = 256 threads = 4 waves (2x2), tile BM x BN x 64, double-buffered LDS, register-staged loads.
+//
+// Pipeline: block = WM x WN waves, each wave a 64x64 sub-tile (4x4 MFMA accumulators); K is walked in
+// 64-deep tiles through a 3-slot LDS ring filled by LDS-DMA (global_load_lds_dwordx4, swizzle applied
+// on the per-lane SOURCE address because the LDS image of one DMA instruction is lane-linear).
+// Two tiles are in flight while one is computed: a COUNTED s_waitcnt vmcnt(pieces-per-tile) + ONE
+// barrier per K-tile (the barrier both publishes tile t and retires the reads of tile t-1, whose slot
+// the DMA of tile t+2 then overwrites).  The DMA is issued from inline asm: hipcc (ROCm 7.2) otherwise
+// drains vmcnt(0) in front of the next ds_read and nothing overlaps.
+// Tile order: XCD-aware (block b -> XCD b%8 gets a contiguous run of tile ids) and, inside that run,
+// 8-row super-tiles walked column-wise so the ~64 blocks resident on one XCD share 8 A-panels and
+// 8 B-panels in its 4 MiB L2 instead of streaming all of B from Infinity Cache for every row panel.
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm.h"
 
@@ -21,33 +33,80 @@ namespace {
 
 __device__ __forceinline__ int mc_swz(int krow) { return (krow & 3) | ((krow >> 1) & 4); }
 
-template <int ROWS, bool MC>
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KiB), lane-linear.
+// M0 (LDS base) is written in the same statement that uses it and restored afterwards.
+__device__ __forceinline__ void glds16(const void* gsrc, const unsigned char* lds_dst) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(LDS_AS const void*)lds_dst);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(dst)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int ROWS, bool MC, int NTHREADS>
 struct TileIO {
+  static constexpr int NWAVES = NTHREADS / 64;
   static constexpr int CHUNKS = ROWS * 8;       // 16-byte chunks per 64-deep tile
-  static constexpr int PER_THREAD = CHUNKS / 256;
+  static constexpr int PER_THREAD = CHUNKS / NTHREADS;
   static constexpr int ROWB = ROWS * 2;         // bytes per k-row of an MC tile
   static constexpr int CPR = ROWS / 8;          // chunks per k-row of an MC tile
+  static constexpr int PIECES = (ROWS / 8) / NWAVES;  // LDS-DMA instructions per wave per tile
+  static_assert(CHUNKS % NTHREADS == 0 && (ROWS / 8) % NWAVES == 0, "tile/thread shape");
+  static_assert(!MC || ROWS == 64 || ROWS == 128 || ROWS == 256, "M/N-contiguous tiles need power-of-two rows");
 
-  // global -> registers
+  // global -> LDS by DMA; out-of-range rows are clamped (they only feed C rows/columns that are never stored),
+  // the K range must be a full 64-deep tile.
+  __device__ __forceinline__ static void glds(unsigned char* lds, const bf16_t* __restrict__ base, int ld, int row0,
+                                              int row_lim, int k0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int q = wave + i * NWAVES;
+      const bf16_t* p;
+      if (!MC) {
+        const int r = q * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ (r & 7);
+        const int gr = min(row0 + r, row_lim - 1);
+        p = base + (size_t)gr * ld + k0 + lc * 8;
+      } else {
+        constexpr int RPI = 64 / CPR;  // k-rows per DMA instruction
+        const int kr = q * RPI + lane / CPR;
+        const int sl = lane % CPR;
+        const int lw = (sl >> 1) ^ mc_swz(kr);
+        // a partial last chunk (row_lim % 8 != 0) is still read in full: the leading dimension covers it
+        const int gm = min(row0 + lw * 16 + (sl & 1) * 8, ((row_lim + 7) & ~7) - 8);
+        p = base + (size_t)(k0 + kr) * ld + gm;
+      }
+      glds16(p, lds + q * 1024);
+    }
+  }
+  // global -> registers (zero fill outside [row_lim) x [k_lim)) : used for a partial last K tile only
   __device__ __forceinline__ static void load(uint4 (&r)[PER_THREAD], const bf16_t* __restrict__ base, int ld,
                                               int row0, int row_lim, int k0, int k_lim, int tid) {
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i) {
-      const int c = tid + i * 256;
+      const int c = tid + i * NTHREADS;
       int gr, gk;
       const bf16_t* p;
-      bool ok;
       if (!MC) {
         gr = row0 + (c >> 3);
         gk = k0 + (c & 7) * 8;
-        ok = (gr < row_lim) && (gk < k_lim);
         p = base + (size_t)gr * ld + gk;
       } else {
         gk = k0 + c / CPR;
         gr = row0 + (c % CPR) * 8;
-        ok = (gr < row_lim) && (gk < k_lim);
         p = base + (size_t)gk * ld + gr;
       }
+      const bool ok = (gr < row_lim) && (gk < k_lim);
       r[i] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
     }
   }
@@ -55,7 +114,7 @@ struct TileIO {
   __device__ __forceinline__ static void store(const uint4 (&r)[PER_THREAD], unsigned char* lds, int tid) {
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i) {
-      const int c = tid + i * 256;
+      const int c = tid + i * NTHREADS;
       int off;
       if (!MC) {
         const int row = c >> 3, ch = c & 7;
@@ -91,16 +150,25 @@ struct TileIO {
   }
 };
 
-template <int BM, int BN, bool A_MC, bool B_MC, int EPI>
-__global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmGroup g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using TA = TileIO<BM, A_MC>;
-  using TB = TileIO<BN, B_MC>;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-  constexpr int MI = BM / 32, NJ = BN / 32;
+constexpr int kStages = 3;
+constexpr int kSuper = 8;  // row panels per L2 super-tile
 
+template <int WM, int WN, bool A_MC, bool B_MC, int EPI>
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const GemmGroup g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64;
+  using TA = TileIO<BM, A_MC, NT>;
+  using TB = TileIO<BN, B_MC, NT>;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int PIECES = TA::PIECES + TB::PIECES;  // LDS-DMA instructions per wave per K-tile
+  constexpr int MI = 4, NJ = 4;
+
+  // ---- tile id: XCD-contiguous, then 8-row super-tiles walked column-wise inside the problem
+  const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7;
+  const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
   int pi = 0;
-  const int tile = blockIdx.x;
 #pragma unroll
   for (int i = 1; i < GGET_MAX_GROUP; ++i)
     if (i < g.count && tile >= g.p[i].tile_begin) pi = i;
@@ -109,8 +177,12 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmGroup g) {
   const int K = P.k_dev ? *P.k_dev : P.K;
   const int N = P.N;
   const int lt = tile - P.tile_begin;
-  const int m0 = (lt / P.tiles_n) * BM;
-  const int n0 = (lt % P.tiles_n) * BN;
+  const int tiles_m = (P.M + BM - 1) / BM;
+  const int per_super = kSuper * P.tiles_n;
+  const int sup = lt / per_super, rem = lt - sup * per_super;
+  const int rows_here = min(kSuper, tiles_m - sup * kSuper);
+  const int m0 = (sup * kSuper + rem % rows_here) * BM;
+  const int n0 = (rem / rows_here) * BN;
   if (m0 >= M) return;
   // split-K slice of this block (gridDim.y slices, 64-aligned)
   const int ktiles = (K + 63) >> 6;
@@ -119,9 +191,9 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmGroup g) {
   const int kend = min(K, kbeg + per * 64);
   if (kbeg >= kend) return;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  constexpr int STAGE = A_BYTES + B_BYTES;  // stage s: A at s*STAGE, B at s*STAGE + A_BYTES
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
 
   f32x4_t acc[MI][NJ];
 #pragma unroll
@@ -129,21 +201,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmGroup g) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  uint4 ra[TA::PER_THREAD], rb[TB::PER_THREAD];
-  TA::load(ra, P.A, P.lda, m0, M, kbeg, kend, tid);
-  TB::load(rb, P.B, P.ldb, n0, N, kbeg, kend, tid);
-  TA::store(ra, smem, tid);
-  TB::store(rb, smem + A_BYTES, tid);
-  __syncthreads();
-
-  int cur = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += 64) {
-    const bool more = (k0 + 64) < kend;
-    if (more) {
-      TA::load(ra, P.A, P.lda, m0, M, k0 + 64, kend, tid);
-      TB::load(rb, P.B, P.ldb, n0, N, k0 + 64, kend, tid);
-    }
-    const unsigned char* a_l = smem + cur * STAGE;
+  auto compute = [&](const unsigned char* a_l) {
     const unsigned char* b_l = a_l + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -158,16 +216,51 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmGroup g) {
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
-    if (more) {
-      TA::store(ra, smem + (cur ^ 1) * STAGE, tid);
-      TB::store(rb, smem + (cur ^ 1) * STAGE + A_BYTES, tid);
-    }
+  };
+  auto issue = [&](int t, int slot) {
+    unsigned char* s = smem + slot * STAGE;
+    TA::glds(s, P.A, P.lda, m0, M, kbeg + t * 64, wave, lane);
+    TB::glds(s + A_BYTES, P.B, P.ldb, n0, N, kbeg + t * 64, wave, lane);
+  };
+
+  const int nfull = (kend - kbeg) >> 6;
+  const bool tail = ((kend - kbeg) & 63) != 0;
+  const int abl = g.ablate;  // diagnostics only (GGET_GEMM_ABLATE): 1 = no DMA, 2 = no MFMA/ds_read, 4 = no C store
+  // ---- pipelined main loop over the full K tiles (3-slot ring, 2 tiles in flight)
+  if (nfull > 0 && !(abl & 1)) issue(0, 0);
+  if (nfull > 1 && !(abl & 1)) issue(1, 1);
+  int slot = 0;
+  for (int t = 0; t < nfull; ++t) {
+    if (t + 1 < nfull) vm_wait<PIECES>(); else vm_wait<0>();   // this wave's pieces of tile t have landed
+    __syncthreads();                                           // everyone's have; tile t-1 is fully consumed
+    if (t + 2 < nfull && !(abl & 1)) issue(t + 2, slot == 0 ? 2 : slot - 1); // refill the slot tile t-1 lived in
+    if (!(abl & 2)) compute(smem + slot * STAGE);
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  // ---- partial last K tile: zero-filling register path (rare: vocab-sized or data-dependent K)
+  if (tail) {
+    uint4 ra[TA::PER_THREAD], rb[TB::PER_THREAD];
+    const int kt = kbeg + nfull * 64;
+    TA::load(ra, P.A, P.lda, m0, M, kt, kend, tid);
+    TB::load(rb, P.B, P.ldb, n0, N, kt, kend, tid);
     __syncthreads();
-    cur ^= 1;
+    TA::store(ra, smem, tid);
+    TB::store(rb, smem + A_BYTES, tid);
+    __syncthreads();
+    compute(smem);
   }
 
-  // epilogue: lane owns C[m][n..n+3], m = m0 + (wm*MI+i)*16 + (lane&15), n = n0 + (wn*NJ+j)*16 + (lane>>4)*4
+  // ---- epilogue: lane owns C[m][n..n+3], m = m0 + (wm*4+i)*16 + (lane&15), n = n0 + (wn*4+j)*16 + (lane>>4)*4
   const int l15 = lane & 15, gq = lane >> 4;
+  if (abl & 4) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sacc == 1.2345e-30f) reinterpret_cast<bf16_t*>(P.C)[0] = 1;  // keep the accumulators live
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = m0 + (wm * MI + i) * 16 + l15;
@@ -196,8 +289,9 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmGroup g) {
   }
 }
 
-template <int BM, int BN, bool A_MC, bool B_MC, int EPI>
+template <int WM, int WN, bool A_MC, bool B_MC, int EPI>
 int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
+  constexpr int BM = WM * 64, BN = WN * 64;
   int total = 0;
   for (int i = 0; i < g.count; ++i) {
     GemmProblem& p = g.p[i];
@@ -207,25 +301,36 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
     total += tm * p.tiles_n;
   }
   if (total == 0) return 0;
-  constexpr int SMEM = 2 * (BM + BN) * 128;
+  constexpr int SMEM = kStages * (BM + BN) * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, A_MC, B_MC, EPI>),
+    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN, A_MC, B_MC, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
   dim3 grid(total, split_k > 0 ? split_k : 1, 1);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_MC, B_MC, EPI>), grid, dim3(256), SMEM, st, g);
+  hipLaunchKernelGGL((gemm_kernel<WM, WN, A_MC, B_MC, EPI>), grid, dim3(WM * WN * 64), SMEM, st, g);
   GGET_LAUNCH_CHECK();
   return 0;
+}
+
+// Tile choice: 256x128 (8 waves, 1 block/CU, 0.75x the LDS-fill traffic per FLOP of 128x128) when it still yields
+// at least ~1.5 tiles per CU; 128x128 (4 waves) otherwise, so the narrow N=d GEMMs keep every CU busy.
+template <bool A_MC, bool B_MC, int EPI>
+int launch_shape(GemmGroup& g, int split_k, hipStream_t st) {
+  long tiles_big = 0;
+  for (int i = 0; i < g.count; ++i) tiles_big += (long)((g.p[i].M + 255) / 256) * ((g.p[i].N + 127) / 128);
+  tiles_big *= (split_k > 1 ? split_k : 1);
+  if (tiles_big >= 384) return launch_t<4, 2, A_MC, B_MC, EPI>(g, split_k, st);
+  return launch_t<2, 2, A_MC, B_MC, EPI>(g, split_k, st);
 }
 
 template <bool A_MC, bool B_MC>
 int launch_mode(GemmGroup& g, int epi, int split_k, hipStream_t st) {
   switch (epi) {
-    case GGET_EPI_NONE: return launch_t<128, 128, A_MC, B_MC, GGET_EPI_NONE>(g, split_k, st);
-    case GGET_EPI_RESIDUAL: return launch_t<128, 128, A_MC, B_MC, GGET_EPI_RESIDUAL>(g, split_k, st);
-    case GGET_EPI_ATOMIC_F32: return launch_t<128, 128, A_MC, B_MC, GGET_EPI_ATOMIC_F32>(g, split_k, st);
+    case GGET_EPI_NONE: return launch_shape<A_MC, B_MC, GGET_EPI_NONE>(g, split_k, st);
+    case GGET_EPI_RESIDUAL: return launch_shape<A_MC, B_MC, GGET_EPI_RESIDUAL>(g, split_k, st);
+    case GGET_EPI_ATOMIC_F32: return launch_shape<A_MC, B_MC, GGET_EPI_ATOMIC_F32>(g, split_k, st);
   }
   gget_set_error("gemm: unknown epilogue %d", epi);
   return 2;
@@ -235,6 +340,9 @@ int launch_mode(GemmGroup& g, int epi, int split_k, hipStream_t st) {
 
 int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t st) {
   GGET_REQUIRE(g.count >= 1 && g.count <= GGET_MAX_GROUP, "gemm: bad group size %d", g.count);
+  static int ablate = -1;
+  if (ablate < 0) { const char* e = getenv("GGET_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
+  g.ablate = ablate;
   GGET_REQUIRE(split_k <= 1 || epi == GGET_EPI_ATOMIC_F32, "gemm: split-K needs the fp32 atomic epilogue");
   for (int i = 0; i < g.count; ++i) {
     const GemmProblem& p = g.p[i];

@@ -12,8 +12,10 @@ struct GgetSegment {
 
 int k_embed_fwd(const int64_t* ids, const void* emb, const void* gate, void* out, int T, int F, int ldF, int d,
                 hipStream_t st);
+// sort_ws: int32 scratch of k_embed_bwd_ws_elems(T*F, V) elements (device-side counting sort of the cells by id)
 int k_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* gate, float* demb, float* dgate, int T,
-                int F, int ldF, int d, int pad_id, int hot_id, hipStream_t st);
+                int F, int ldF, int d, int V, int pad_id, int32_t* sort_ws, hipStream_t st);
+inline size_t k_embed_bwd_ws_elems(size_t ncell, size_t V) { return 3 * V + 1 + 2 * ncell; }
 int k_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, hipStream_t st);
 int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
                   float* dw_accum, int T, int d, hipStream_t st);

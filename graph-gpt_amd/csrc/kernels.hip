@@ -42,50 +42,178 @@ __global__ void __launch_bounds__(128) embed_fwd_kernel(const int64_t* __restric
   }
 }
 
-// backward of K1: fp32 atomic scatter-add into dW[V,d]; the SMTP <mask> row (about half of all cells)
-// and any other hot id is pre-reduced inside the block before touching memory.
-constexpr int kEmbTok = 32;
-__global__ void __launch_bounds__(128) embed_bwd_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ dx,
-                                                        const bf16_t* __restrict__ emb, const bf16_t* __restrict__ gate,
-                                                        float* __restrict__ demb, float* __restrict__ dgate, int T,
-                                                        int F, int ldF, int d, int pad_id, int hot_id) {
-  const int t0 = blockIdx.x * kEmbTok;
-  for (int c = threadIdx.x; c * 8 < d; c += blockDim.x) {
-    float hot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool any_hot = false;
-    for (int tt = 0; tt < kEmbTok; ++tt) {
-      const int t = t0 + tt;
-      if (t >= T) break;
-      float g[8];
-      unpack8(ldg16(dx + (size_t)t * d + c * 8), g);
-      const int64_t* row = ids + (size_t)t * ldF;
-      for (int f = 0; f < F; ++f) {
-        const int id = (int)row[f];
-        float gv[8] = {1, 1, 1, 1, 1, 1, 1, 1};
-        if (gate) {
-          unpack8(ldg16(gate + (size_t)f * d + c * 8), gv);
-          float ev[8];
-          unpack8(ldg16(emb + (size_t)id * d + c * 8), ev);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dgate + (size_t)f * d + c * 8 + e, g[e] * ev[e]);
-        }
-        if (id == pad_id) continue;  // nn.Embedding(padding_idx): the pad row never receives gradient
-        if (id == hot_id) {
-          any_hot = true;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) hot[e] += g[e] * gv[e];
-        } else {
-          float* dst = demb + (size_t)id * d + c * 8;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dst + e, g[e] * gv[e]);
-        }
+// backward of K1: dW[v,:] = sum over cells (t,f) with ids[t,f]==v of dx[t,:] (* G[f,:]).
+// SMTP batches hit a few hundred vocabulary rows with ~10^5 cells (half of them the <mask> row), so a direct
+// atomic scatter serialises on hot rows.  Instead: counting sort of the cells by id on the device
+// (histogram -> single-block scan -> fill), then every block walks 128 consecutive SORTED cells, accumulates each
+// run of equal ids in registers and flushes one fp32 atomic per run: ~(cells/128 + distinct ids) x d atomics.
+// Both passes pre-aggregate per block in LDS (vocabularies up to kEmbLdsV ids) so the hot <mask> row costs one
+// global atomic per block instead of one per cell; larger vocabularies aggregate the hot id per wave with a ballot.
+constexpr int kEmbLdsV = 8192;   // 2*V*4 B of dynamic LDS in the fill pass stays <= 64 KiB
+constexpr int kEmbCells = 4096;  // cells per block
+template <bool LDS_PATH>
+__global__ void __launch_bounds__(256) embed_hist_kernel(const int64_t* __restrict__ ids, int32_t* __restrict__ hist,
+                                                         long ncell, int F, int ldF, int pad_id, int V, int hot_id) {
+  extern __shared__ int lh[];
+  const long c0 = (long)blockIdx.x * kEmbCells;
+  if (LDS_PATH) {
+    for (int v = threadIdx.x; v < V; v += 256) lh[v] = 0;
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < kEmbCells; i += 256) {
+    const long c = c0 + i;
+    const bool in = c < ncell;
+    const int id = in ? (int)ids[(c / F) * ldF + (c % F)] : pad_id;
+    if (LDS_PATH) {
+      if (id != pad_id) atomicAdd(lh + id, 1);
+    } else {
+      const unsigned long long hot = __ballot(id == hot_id && id != pad_id);
+      if (id == hot_id) {
+        if ((threadIdx.x & 63) == __builtin_ctzll(hot)) atomicAdd(hist + id, (int)__builtin_popcountll(hot));
+      } else if (id != pad_id) {
+        atomicAdd(hist + id, 1);
       }
     }
-    if (any_hot) {
-      float* dst = demb + (size_t)hot_id * d + c * 8;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dst + e, hot[e]);
+  }
+  if (LDS_PATH) {
+    __syncthreads();
+    for (int v = threadIdx.x; v < V; v += 256)
+      if (lh[v]) atomicAdd(hist + v, lh[v]);
+  }
+}
+// exclusive scan of hist[V] -> offs[V] (+ total in offs[V]); cursor[v] = offs[v]
+__global__ void __launch_bounds__(1024) embed_scan_kernel(const int32_t* __restrict__ hist, int32_t* __restrict__ offs,
+                                                          int32_t* __restrict__ cursor, int V) {
+  __shared__ int sm[1024];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < V; base += 1024) {
+    const int v = base + tid;
+    const int c = v < V ? hist[v] : 0;
+    sm[tid] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int a = 0;
+      if (tid >= o) a = sm[tid - o];
+      __syncthreads();
+      sm[tid] += a;
+      __syncthreads();
     }
+    if (v < V) { const int e = carry + sm[tid] - c; offs[v] = e; cursor[v] = e; }
+    __syncthreads();
+    if (tid == 1023) carry += sm[1023];
+    __syncthreads();
+  }
+  if (tid == 0) offs[V] = carry;
+}
+template <bool LDS_PATH>
+__global__ void __launch_bounds__(256) embed_fill_kernel(const int64_t* __restrict__ ids, int32_t* __restrict__ cursor,
+                                                         int32_t* __restrict__ cell_sorted, int32_t* __restrict__ id_sorted,
+                                                         long ncell, int F, int ldF, int pad_id, int V, int hot_id) {
+  extern __shared__ int lh[];  // LDS_PATH: local counts [V] then global bases [V]
+  const long c0 = (long)blockIdx.x * kEmbCells;
+  if (LDS_PATH) {
+    int* base = lh + V;
+    for (int v = threadIdx.x; v < V; v += 256) lh[v] = 0;
+    __syncthreads();
+    int rank[kEmbCells / 256], idv[kEmbCells / 256];
+#pragma unroll
+    for (int k = 0; k < kEmbCells / 256; ++k) {
+      const long c = c0 + threadIdx.x + k * 256;
+      idv[k] = c < ncell ? (int)ids[(c / F) * ldF + (c % F)] : pad_id;
+      rank[k] = idv[k] != pad_id ? atomicAdd(lh + idv[k], 1) : 0;
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < V; v += 256)
+      if (lh[v]) base[v] = atomicAdd(cursor + v, lh[v]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kEmbCells / 256; ++k) {
+      if (idv[k] == pad_id) continue;
+      const int pos = base[idv[k]] + rank[k];
+      cell_sorted[pos] = (int)(c0 + threadIdx.x + k * 256);
+      id_sorted[pos] = idv[k];
+    }
+  } else {
+    for (int i = threadIdx.x; i < kEmbCells; i += 256) {
+      const long c = c0 + i;
+      const int id = c < ncell ? (int)ids[(c / F) * ldF + (c % F)] : pad_id;
+      const unsigned long long hot = __ballot(id == hot_id && id != pad_id);
+      int pos = -1;
+      if (id == hot_id && id != pad_id) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __builtin_ctzll(hot);
+        int b0 = 0;
+        if (lane == leader) b0 = atomicAdd(cursor + id, (int)__builtin_popcountll(hot));
+        b0 = __shfl(b0, leader, 64);
+        pos = b0 + (int)__builtin_popcountll(hot & ((1ull << lane) - 1ull));
+      } else if (id != pad_id) {
+        pos = atomicAdd(cursor + id, 1);
+      }
+      if (pos >= 0) { cell_sorted[pos] = (int)c; id_sorted[pos] = id; }
+    }
+  }
+}
+constexpr int kEmbSeg = 128;
+__global__ void __launch_bounds__(128) embed_reduce_kernel(const int32_t* __restrict__ cell_sorted,
+                                                           const int32_t* __restrict__ id_sorted,
+                                                           const int32_t* __restrict__ offs, int V,
+                                                           const bf16_t* __restrict__ dx, const bf16_t* __restrict__ gate,
+                                                           float* __restrict__ demb, int F, int d) {
+  const int n = offs[V];
+  const int beg = blockIdx.x * kEmbSeg;
+  if (beg >= n) return;
+  const int end = min(n, beg + kEmbSeg);
+  for (int c = threadIdx.x; c * 8 < d; c += blockDim.x) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int cur = id_sorted[beg];
+    for (int j = beg; j < end; ++j) {
+      const int id = id_sorted[j];
+      if (id != cur) {
+        float* dst = demb + (size_t)cur * d + c * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { unsafeAtomicAdd(dst + e, acc[e]); acc[e] = 0.f; }
+        cur = id;
+      }
+      const int cell = cell_sorted[j];
+      float g[8];
+      unpack8(ldg16(dx + (size_t)(cell / F) * d + c * 8), g);
+      if (gate) {
+        float gv[8];
+        unpack8(ldg16(gate + (size_t)(cell % F) * d + c * 8), gv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += g[e] * gv[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += g[e];
+      }
+    }
+    float* dst = demb + (size_t)cur * d + c * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dst + e, acc[e]);
+  }
+}
+// gated stacking only: dG[f,:] = sum_t dx[t,:] * W[ids[t,f],:]  (block-local accumulation, one atomic per block)
+constexpr int kEmbTok = 64;
+__global__ void __launch_bounds__(128) embed_dgate_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ dx,
+                                                          const bf16_t* __restrict__ emb, float* __restrict__ dgate, int T,
+                                                          int F, int ldF, int d) {
+  const int t0 = blockIdx.x * kEmbTok;
+  const int f = blockIdx.y;
+  for (int c = threadIdx.x; c * 8 < d; c += blockDim.x) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int tt = 0; tt < kEmbTok && t0 + tt < T; ++tt) {
+      const int t = t0 + tt;
+      float g[8], ev[8];
+      unpack8(ldg16(dx + (size_t)t * d + c * 8), g);
+      unpack8(ldg16(emb + (size_t)ids[(size_t)t * ldF + f] * d + c * 8), ev);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += g[e] * ev[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dgate + (size_t)f * d + c * 8 + e, acc[e]);
   }
 }
 
@@ -659,10 +787,37 @@ int k_embed_fwd(const int64_t* ids, const void* emb, const void* gate, void* out
 }
 
 int k_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* gate, float* demb, float* dgate, int T,
-                int F, int ldF, int d, int pad_id, int hot_id, hipStream_t st) {
+                int F, int ldF, int d, int V, int pad_id, int32_t* sort_ws, hipStream_t st) {
   if (T == 0) return 0;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((T + kEmbTok - 1) / kEmbTok), dim3(128), 0, st, ids, (const bf16_t*)dx,
-                     (const bf16_t*)emb, (const bf16_t*)gate, demb, dgate, T, F, ldF, d, pad_id, hot_id);
+  // sort_ws: hist[V] | offs[V+1] | cursor[V] | cell_sorted[T*F] | id_sorted[T*F]
+  const long ncell = (long)T * F;
+  int32_t* hist = sort_ws;
+  int32_t* offs = hist + V;
+  int32_t* cursor = offs + V + 1;
+  int32_t* cell_sorted = cursor + V;
+  int32_t* id_sorted = cell_sorted + ncell;
+  GGET_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)V * sizeof(int32_t), st));
+  const int g = (int)((ncell + kEmbCells - 1) / kEmbCells);
+  const int hot_id = 1;  // <mask> token id of the SMTP collator (tokenizer_utils.py: mask id 1)
+  if (V <= kEmbLdsV) {
+    hipLaunchKernelGGL(embed_hist_kernel<true>, dim3(g), dim3(256), V * sizeof(int), st, ids, hist, ncell, F, ldF, pad_id,
+                       V, hot_id);
+  } else {
+    hipLaunchKernelGGL(embed_hist_kernel<false>, dim3(g), dim3(256), 0, st, ids, hist, ncell, F, ldF, pad_id, V, hot_id);
+  }
+  hipLaunchKernelGGL(embed_scan_kernel, dim3(1), dim3(1024), 0, st, hist, offs, cursor, V);
+  if (V <= kEmbLdsV) {
+    hipLaunchKernelGGL(embed_fill_kernel<true>, dim3(g), dim3(256), 2 * V * sizeof(int), st, ids, cursor, cell_sorted,
+                       id_sorted, ncell, F, ldF, pad_id, V, hot_id);
+  } else {
+    hipLaunchKernelGGL(embed_fill_kernel<false>, dim3(g), dim3(256), 0, st, ids, cursor, cell_sorted, id_sorted, ncell, F,
+                       ldF, pad_id, V, hot_id);
+  }
+  hipLaunchKernelGGL(embed_reduce_kernel, dim3((int)((ncell + kEmbSeg - 1) / kEmbSeg)), dim3(128), 0, st, cell_sorted,
+                     id_sorted, offs, V, (const bf16_t*)dx, (const bf16_t*)gate, demb, F, d);
+  if (gate)
+    hipLaunchKernelGGL(embed_dgate_kernel, dim3((T + kEmbTok - 1) / kEmbTok, F), dim3(128), 0, st, ids, (const bf16_t*)dx,
+                       (const bf16_t*)emb, dgate, T, F, ldF, d);
   GGET_LAUNCH_CHECK();
   return 0;
 }
@@ -680,7 +835,7 @@ int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rst
                   float* dw_accum, int T, int d, hipStream_t st) {
   GGET_REQUIRE(d % 8 == 0 && d <= 64 * 8 * kMaxChunksPerLane, "rmsnorm: d=%d unsupported", d);
   if (T == 0) return 0;
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(grid_for(T, 4 * 8, 512)), dim3(kBlock), 4 * d * sizeof(float), st,
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(grid_for(T, 4 * 2, 2048)), dim3(kBlock), 4 * d * sizeof(float), st,
                      (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx,
                      dw_accum, T, d);
   GGET_LAUNCH_CHECK();

@@ -21,6 +21,7 @@ struct GemmProblem {
 struct GemmGroup {
   GemmProblem p[GGET_MAX_GROUP];
   int count;
+  int super;   // row panels per L2 super-tile (tile order)
   int ablate;  // diagnostics (env GGET_GEMM_ABLATE): bit0 skip LDS-DMA, bit1 skip MFMA, bit2 skip the C store
 };
 

@@ -153,6 +153,83 @@ struct TileIO {
 constexpr int kStages = 3;
 constexpr int kSuper = 8;  // row panels per L2 super-tile
 
+// Epilogue of one wave's 64x64 sub-tile.  After the swapped MFMA a lane owns C[m][n..n+3] (m = lane&15, n-group = lane>>4)
+// of each 16x16 accumulator; lanes l and l^16 trade halves of two neighbouring accumulators so that every lane ends
+// up with 8 consecutive columns => 16-byte stores, 64-byte row segments, half the store instructions (the C store is
+// issue-bound, not bandwidth-bound).
+template <int EPI>
+__device__ __forceinline__ void store_tile(f32x4_t (&acc)[4][4], const GemmProblem& P, int M, int N, int mw, int nw, int lane) {
+  const int l15 = lane & 15, gq = lane >> 4;
+  if (EPI == GGET_EPI_ATOMIC_F32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mw + i * 16 + l15;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = nw + j * 16 + gq * 4;
+        if (n >= N) continue;
+        float* c = reinterpret_cast<float*>(P.C) + (size_t)m * P.ldc + n;
+        unsafeAtomicAdd(c + 0, acc[i][j][0]); unsafeAtomicAdd(c + 1, acc[i][j][1]);
+        unsafeAtomicAdd(c + 2, acc[i][j][2]); unsafeAtomicAdd(c + 3, acc[i][j][3]);
+      }
+    }
+    return;
+  }
+  const bool odd = gq & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mw + i * 16 + l15;
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      // even lanes keep accumulator 2jp and fetch the partner's half of it; odd lanes keep 2jp+1
+      f32x4_t keep = odd ? acc[i][2 * jp + 1] : acc[i][2 * jp];
+      f32x4_t give = odd ? acc[i][2 * jp] : acc[i][2 * jp + 1];
+      f32x4_t got;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) got[e] = __shfl_xor(give[e], 16, 64);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = odd ? got[e] : keep[e];
+        v[4 + e] = odd ? keep[e] : got[e];
+      }
+      const int n = nw + (2 * jp + (odd ? 1 : 0)) * 16 + (gq & 2) * 4;
+      if (m >= M || n >= N) continue;
+      bf16_t* cp = reinterpret_cast<bf16_t*>(P.C) + (size_t)m * P.ldc + n;
+      if (n + 8 <= N) {
+        if (EPI == GGET_EPI_RESIDUAL) {
+          float r[8];
+          unpack8(*reinterpret_cast<const uint4*>(P.R + (size_t)m * P.ldc + n), r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        *reinterpret_cast<uint4*>(cp) = pack8(v);
+      } else {  // N % 8 == 4 : only the first half of this chunk exists
+        if (EPI == GGET_EPI_RESIDUAL) {
+          const uint2 r = *reinterpret_cast<const uint2*>(P.R + (size_t)m * P.ldc + n);
+          v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
+          v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+        }
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(cp) = o;
+      }
+    }
+  }
+}
+
+// (tile id inside one problem) -> (m0, n0): 8-row super-tiles walked column-wise (L2 reuse of A and B panels)
+__device__ __forceinline__ void tile_origin(const GemmProblem& P, int lt, int BM, int BN, int kSup, int& m0, int& n0) {
+  const int tiles_m = (P.M + BM - 1) / BM;
+  const int per_super = kSup * P.tiles_n;
+  const int sup = lt / per_super, rem = lt - sup * per_super;
+  const int rows_here = min(kSup, tiles_m - sup * kSup);
+  m0 = (sup * kSup + rem % rows_here) * BM;
+  n0 = (rem / rows_here) * BN;
+}
+
 template <int WM, int WN, bool A_MC, bool B_MC, int EPI>
 __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const GemmGroup g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -176,13 +253,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const
   const int M = P.m_dev ? *P.m_dev : P.M;
   const int K = P.k_dev ? *P.k_dev : P.K;
   const int N = P.N;
-  const int lt = tile - P.tile_begin;
-  const int tiles_m = (P.M + BM - 1) / BM;
-  const int per_super = kSuper * P.tiles_n;
-  const int sup = lt / per_super, rem = lt - sup * per_super;
-  const int rows_here = min(kSuper, tiles_m - sup * kSuper);
-  const int m0 = (sup * kSuper + rem % rows_here) * BM;
-  const int n0 = (rem / rows_here) * BN;
+  int m0, n0;
+  tile_origin(P, tile - P.tile_begin, BM, BN, g.super, m0, n0);
   if (m0 >= M) return;
   // split-K slice of this block (gridDim.y slices, 64-aligned)
   const int ktiles = (K + 63) >> 6;
@@ -250,8 +322,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const
     compute(smem);
   }
 
-  // ---- epilogue: lane owns C[m][n..n+3], m = m0 + (wm*4+i)*16 + (lane&15), n = n0 + (wn*4+j)*16 + (lane>>4)*4
-  const int l15 = lane & 15, gq = lane >> 4;
+  // ---- epilogue
   if (abl & 4) {
     float sacc = 0.f;
 #pragma unroll
@@ -261,30 +332,104 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const
     if (sacc == 1.2345e-30f) reinterpret_cast<bf16_t*>(P.C)[0] = 1;  // keep the accumulators live
     return;
   }
+  store_tile<EPI>(acc, P, M, N, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+
+// Persistent variant (static shapes, K % 64 == 0, no split-K): one block per CU walks its list of output tiles and
+// treats all their K-tiles as ONE stream through the LDS ring, so the DMA of the next tile's first K-tiles is already
+// in flight while the current tile finishes and its C stores drain: prologue and epilogue of every tile but the
+// first/last are hidden (at K = 768 they are ~30 % of a non-persistent tile's life).
+// Counted waits stay valid with stores in flight: vmcnt <= PIECES means >= (stores + PIECES) older operations have
+// retired, and loads retire in order among themselves, so the oldest PIECES loads (the tile being waited for) are in.
+template <int WM, int WN, bool A_MC, bool B_MC, int EPI>
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_persist_kernel(const GemmGroup g, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64;
+  using TA = TileIO<BM, A_MC, NT>;
+  using TB = TileIO<BN, B_MC, NT>;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int PIECES = TA::PIECES + TB::PIECES;
+  constexpr int MI = 4, NJ = 4;
+
+  const int G = gridDim.x;                                     // multiple of 8
+  const int perm = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);  // XCD-contiguous inside every round
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  struct Ctx { int pi, m0, n0, nk; };
+  auto tile_at = [&](int r, Ctx& c) -> bool {
+    const int tile = r * G + perm;
+    if (tile >= total_tiles) return false;
+    int pi = 0;
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int m = m0 + (wm * MI + i) * 16 + l15;
-    if (m >= M) continue;
+    for (int i = 1; i < GGET_MAX_GROUP; ++i)
+      if (i < g.count && tile >= g.p[i].tile_begin) pi = i;
+    c.pi = pi;
+    tile_origin(g.p[pi], tile - g.p[pi].tile_begin, BM, BN, g.super, c.m0, c.n0);
+    c.nk = g.p[pi].K >> 6;
+    return true;
+  };
+
+  f32x4_t acc[MI][NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int n = n0 + (wn * NJ + j) * 16 + gq * 4;
-      if (n >= N) continue;
-      f32x4_t v = acc[i][j];
-      if (EPI == GGET_EPI_ATOMIC_F32) {
-        float* c = reinterpret_cast<float*>(P.C) + (size_t)m * P.ldc + n;
-        unsafeAtomicAdd(c + 0, v[0]); unsafeAtomicAdd(c + 1, v[1]);
-        unsafeAtomicAdd(c + 2, v[2]); unsafeAtomicAdd(c + 3, v[3]);
-      } else {
-        if (EPI == GGET_EPI_RESIDUAL) {
-          const uint2 r = *reinterpret_cast<const uint2*>(P.R + (size_t)m * P.ldc + n);
-          v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
-          v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
-        }
-        uint2 o;
-        o.x = pack2bf(v[0], v[1]);
-        o.y = pack2bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(P.C) + (size_t)m * P.ldc + n) = o;
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  Ctx ic, cc;
+  int ir = 0, ik = 0, cr = 0, ck = 0;
+  bool ivalid = tile_at(0, ic);
+  bool cvalid = ivalid;
+  cc = ic;
+  int islot = 0, cslot = 0, inflight = 0;
+  auto issue_next = [&]() {
+    if (!ivalid) return;
+    const GemmProblem& P = g.p[ic.pi];
+    unsigned char* s = smem + islot * STAGE;
+    TA::glds(s, P.A, P.lda, ic.m0, P.M, ik * 64, wave, lane);
+    TB::glds(s + A_BYTES, P.B, P.ldb, ic.n0, P.N, ik * 64, wave, lane);
+    islot = islot == 2 ? 0 : islot + 1;
+    ++inflight;
+    if (++ik == ic.nk) { ik = 0; ++ir; ivalid = tile_at(ir, ic); }
+  };
+  issue_next();
+  issue_next();
+  while (cvalid) {
+    if (inflight >= 2) vm_wait<PIECES>(); else vm_wait<0>();
+    __syncthreads();
+    issue_next();
+    --inflight;
+    {
+      const unsigned char* a_l = smem + cslot * STAGE;
+      const unsigned char* b_l = a_l + A_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8_t af[MI], bf[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = TA::frag(a_l, wm * MI + i, kk, lane);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bf[j] = TB::frag(b_l, wn * NJ + j, kk, lane);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
       }
+    }
+    cslot = cslot == 2 ? 0 : cslot + 1;
+    if (++ck == cc.nk) {
+      const GemmProblem& P = g.p[cc.pi];
+      store_tile<EPI>(acc, P, P.M, P.N, cc.m0 + wm * 64, cc.n0 + wn * 64, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      ck = 0;
+      ++cr;
+      cvalid = tile_at(cr, cc);
     }
   }
 }
@@ -302,6 +447,30 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
   }
   if (total == 0) return 0;
   constexpr int SMEM = kStages * (BM + BN) * 128;
+  bool persist = split_k <= 1 && EPI != GGET_EPI_ATOMIC_F32 && !g.ablate && getenv("GGET_GEMM_NO_PERSIST") == nullptr;
+  for (int i = 0; i < g.count; ++i)
+    persist = persist && g.p[i].m_dev == nullptr && g.p[i].k_dev == nullptr && (g.p[i].K % 64) == 0 && g.p[i].K >= 64;
+  if (persist) {
+    static int num_cu = 0;
+    if (!num_cu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      GGET_HIP_CHECK(hipGetDevice(&dev));
+      GGET_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+      num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    static bool pattr_done = false;
+    if (!pattr_done) {
+      GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<WM, WN, A_MC, B_MC, EPI>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+      pattr_done = true;
+    }
+    int G = total < num_cu ? total : num_cu;
+    G = (G + 7) & ~7;  // the XCD permutation needs a multiple of 8 (idle blocks exit at once)
+    hipLaunchKernelGGL((gemm_persist_kernel<WM, WN, A_MC, B_MC, EPI>), dim3(G), dim3(WM * WN * 64), SMEM, st, g, total);
+    GGET_LAUNCH_CHECK();
+    return 0;
+  }
   static bool attr_done = false;
   if (!attr_done) {
     GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN, A_MC, B_MC, EPI>),
@@ -321,7 +490,7 @@ int launch_shape(GemmGroup& g, int split_k, hipStream_t st) {
   long tiles_big = 0;
   for (int i = 0; i < g.count; ++i) tiles_big += (long)((g.p[i].M + 255) / 256) * ((g.p[i].N + 127) / 128);
   tiles_big *= (split_k > 1 ? split_k : 1);
-  if (tiles_big >= 384) return launch_t<4, 2, A_MC, B_MC, EPI>(g, split_k, st);
+  if (tiles_big >= 160) return launch_t<4, 2, A_MC, B_MC, EPI>(g, split_k, st);
   return launch_t<2, 2, A_MC, B_MC, EPI>(g, split_k, st);
 }
 
@@ -343,10 +512,13 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
   static int ablate = -1;
   if (ablate < 0) { const char* e = getenv("GGET_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
   g.ablate = ablate;
+  static int super = -1;
+  if (super < 0) { const char* e = getenv("GGET_GEMM_SUPER"); super = e ? atoi(e) : 0; }
+  g.super = super > 0 ? super : (mode == GGET_GEMM_TN ? 1 : kSuper);
   GGET_REQUIRE(split_k <= 1 || epi == GGET_EPI_ATOMIC_F32, "gemm: split-K needs the fp32 atomic epilogue");
   for (int i = 0; i < g.count; ++i) {
     const GemmProblem& p = g.p[i];
-    GGET_REQUIRE((p.lda % 8) == 0 && (p.ldb % 8) == 0 && (p.ldc % 4) == 0 && (p.N % 4) == 0,
+    GGET_REQUIRE((p.lda % 8) == 0 && (p.ldb % 8) == 0 && (p.ldc % 8) == 0 && (p.N % 4) == 0,
                  "gemm: leading dims must be multiples of 8 (lda %d ldb %d ldc %d N %d)", p.lda, p.ldb, p.ldc, p.N);
   }
   switch (mode) {

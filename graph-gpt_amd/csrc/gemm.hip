@@ -434,6 +434,111 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_persist_kern
   }
 }
 
+
+// Ping-pong variant (static shapes, K % 64 == 0): the two waves that share a SIMD (wave w and w+4) run the same
+// program ONE PHASE apart, and every K-tile is cut into 4 phases {read kk0, mfma kk0, read kk1, mfma kk1} separated
+// by barriers, so while one wave of a SIMD issues its 16 MFMAs the other one is in its LDS-read / DMA-issue phase:
+// the matrix pipe and the LDS pipe are both busy all the time instead of alternating (the 1-barrier-per-tile loop
+// keeps the two waves in the same phase).  s_setprio favours the wave in its MFMA phase.
+template <int WM, int WN, bool A_MC, bool B_MC, int EPI>
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_pp_kernel(const GemmGroup g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64;
+  static_assert(WM * WN == 8, "ping-pong needs 8 waves (two per SIMD)");
+  using TA = TileIO<BM, A_MC, NT>;
+  using TB = TileIO<BN, B_MC, NT>;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int PIECES = TA::PIECES + TB::PIECES;
+  constexpr int MI = 4, NJ = 4;
+
+  const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7;
+  const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GGET_MAX_GROUP; ++i)
+    if (i < g.count && tile >= g.p[i].tile_begin) pi = i;
+  const GemmProblem& P = g.p[pi];
+  const int M = P.M, N = P.N, K = P.K;
+  int m0, n0;
+  tile_origin(P, tile - P.tile_begin, BM, BN, g.super, m0, n0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const bool late = wave >= 4;  // the second wave of every SIMD runs one phase behind
+  const int nk = K >> 6;
+
+  f32x4_t acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t af[MI], bf[NJ];
+
+  auto issue = [&](int t, int slot) {
+    unsigned char* s = smem + slot * STAGE;
+    TA::glds(s, P.A, P.lda, m0, M, t * 64, wave, lane);
+    TB::glds(s + A_BYTES, P.B, P.ldb, n0, N, t * 64, wave, lane);
+  };
+  auto rd = [&](int slot, int kk) {
+    const unsigned char* a_l = smem + slot * STAGE;
+    const unsigned char* b_l = a_l + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af[i] = TA::frag(a_l, wm * MI + i, kk, lane);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bf[j] = TB::frag(b_l, wn * NJ + j, kk, lane);
+  };
+  auto mm = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // prologue: tiles 0 and 1 in flight, tile 0 landed and published
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  if (nk > 1) vm_wait<PIECES>(); else vm_wait<0>();
+  bar();
+  if (late) bar();           // one-phase stagger of waves 4-7
+  rd(0, 0);
+  bar();
+  int slot = 0;
+  for (int t = 0; t < nk; ++t) {
+    const int s1 = slot == 2 ? 0 : slot + 1;   // slot of tile t+1
+    const int s2 = slot == 0 ? 2 : slot - 1;   // slot of tile t-1 == slot of tile t+2
+    mm();                                       // M0
+    bar();
+    rd(slot, 1);                                // R1 (+ refill the slot tile t-1 left: every wave finished reading it
+    if (t + 2 < nk) issue(t + 2, s2);           //      two phases ago at the latest)
+    // tile t+1 is first read by the EARLY waves two barriers from here, i.e. one barrier from here in the late
+    // waves' program: the late waves must have their pieces in before THIS barrier, the early ones before the next.
+    if (late && t + 1 < nk) {
+      if (t + 2 < nk) vm_wait<PIECES>(); else vm_wait<0>();
+    }
+    bar();
+    mm();                                       // M1
+    if (!late && t + 1 < nk) {
+      if (t + 2 < nk) vm_wait<PIECES>(); else vm_wait<0>();
+    }
+    bar();
+    if (t + 1 < nk) rd(s1, 0);                  // R0 of the next tile
+    bar();
+    slot = s1;
+  }
+  if (!late) bar();          // barrier counts of the two groups match
+  store_tile<EPI>(acc, P, M, N, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
 template <int WM, int WN, bool A_MC, bool B_MC, int EPI>
 int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
   constexpr int BM = WM * 64, BN = WN * 64;
@@ -450,6 +555,19 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
   bool persist = split_k <= 1 && EPI != GGET_EPI_ATOMIC_F32 && !g.ablate && getenv("GGET_GEMM_NO_PERSIST") == nullptr;
   for (int i = 0; i < g.count; ++i)
     persist = persist && g.p[i].m_dev == nullptr && g.p[i].k_dev == nullptr && (g.p[i].K % 64) == 0 && g.p[i].K >= 64;
+  if constexpr (WM * WN == 8) {
+    if (persist && getenv("GGET_GEMM_PP") != nullptr) {
+      static bool ppattr = false;
+      if (!ppattr) {
+        GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<WM, WN, A_MC, B_MC, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        ppattr = true;
+      }
+      hipLaunchKernelGGL((gemm_pp_kernel<WM, WN, A_MC, B_MC, EPI>), dim3(total), dim3(512), SMEM, st, g);
+      GGET_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (persist) {
     static int num_cu = 0;
     if (!num_cu) {

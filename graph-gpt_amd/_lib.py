@@ -60,15 +60,15 @@ SIGNATURES = {
     "gget_op_embed_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "gget_op_embed_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "gget_op_rope": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "gget_op_attn_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "gget_op_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "gget_op_attn_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "gget_op_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "gget_op_geglu_fwd": (i32, [vp, vp, i32, i32, vp]),
     "gget_op_geglu_bwd": (i32, [vp, vp, vp, i32, i32, vp]),
     "gget_op_ce_fwd_bwd": (i32, [vp, i32, vp, vp, vp, i32, i32, vp, vp, f32, i32, vp]),
 }
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-EPI_NONE, EPI_RESIDUAL, EPI_ATOMIC_F32 = 0, 1, 2
+EPI_NONE, EPI_RESIDUAL, EPI_ATOMIC_F32, EPI_SLAB_F32 = 0, 1, 2, 3
 PROBLEM_SINGLE_LABEL, PROBLEM_REGRESSION_L1, PROBLEM_REGRESSION_MSE = 0, 1, 2
 
 _lib = None

@@ -2,7 +2,7 @@
 // reference: hf eager_attention_forward :191-214 / SDPA as selected by LlamaAttention.forward :243-281:
 //   P = softmax_fp32(Q K^T * dh^-1/2 + mask) ; O = bf16(P) V, bidirectional or causal, keys >= key_len[b]
 // masked (the reference's additive [B,1,S,S] mask is never materialised: right padding => a length).
-// q/k arrive already rotated (rope_kernel), laid out as qkv[T,3d] (q | k | v, head h at column h*64).
+// qkv is [T,3d] (q | k | v, head h at column h*64), q/k UN-rotated: RoPE is applied on the operand loads.
 //
 // Formulation (one wave per 32-row tile, dh = 64): scores are computed TRANSPOSED,
 //   S^T[key][query] = K_tile Q_tile^T, so a lane owns ONE query column: the softmax statistics
@@ -24,6 +24,37 @@ __device__ __forceinline__ int swz(int row, int byte_in_row) {
   return row * 128 + (byte_in_row ^ (((row >> 1) & 1) << 6));
 }
 
+// RoPE fused into the operand loads (hf apply_rotary_pos_emb :138-160, half-split pairing j <-> j+32): q and k stay
+// un-rotated in HBM; they are rotated in registers on the way into the MFMAs and dq/dk are rotated back on the way out.
+struct Rope {
+  const float* cos_tab;  // [max_pos][32] fp32, nullptr => no rotation (plain attention op)
+  const float* sin_tab;
+  const int64_t* pos;    // [B,S] or nullptr => position = index in the sequence
+  int S;
+};
+__device__ __forceinline__ int rope_pos(const Rope& R, int b, int s) {
+  return R.pos ? (int)R.pos[(size_t)b * R.S + s] : s;
+}
+// lo holds dh [j0, j0+8), up holds dh [j0+32, j0+40); rotate both in place by the angle table row `pos`
+__device__ __forceinline__ void rope_pair(uint4& lo, uint4& up, const Rope& R, int pos, int j0) {
+  float a[8], b[8], c[8], sn[8];
+  unpack8(lo, a);
+  unpack8(up, b);
+  const float4* ct = reinterpret_cast<const float4*>(R.cos_tab + (size_t)pos * 32 + j0);
+  const float4* st = reinterpret_cast<const float4*>(R.sin_tab + (size_t)pos * 32 + j0);
+  const float4 c0 = ct[0], c1 = ct[1], s0 = st[0], s1 = st[1];
+  c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+  sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+  float oa[8], ob[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    oa[e] = a[e] * c[e] - b[e] * sn[e];
+    ob[e] = b[e] * c[e] + a[e] * sn[e];
+  }
+  lo = pack8(oa);
+  up = pack8(ob);
+}
+
 // [32 rows][64 dh] bf16 tile -> LDS (rows >= row_lim are zero-filled so masked probabilities never meet NaNs)
 __device__ __forceinline__ void load_tile(unsigned char* lds, const bf16_t* __restrict__ base, int r0, int row_lim,
                                           size_t pitch, int lane) {
@@ -34,6 +65,26 @@ __device__ __forceinline__ void load_tile(unsigned char* lds, const bf16_t* __re
     const int gr = r0 + row;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (gr < row_lim) v = *reinterpret_cast<const uint4*>(base + (size_t)gr * pitch + ch * 8);
+    *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = v;
+  }
+}
+// same, rotating every row by its position (each lane fetches its chunk and the chunk 32 channels away)
+__device__ __forceinline__ void load_tile_rope(unsigned char* lds, const bf16_t* __restrict__ base, int r0, int row_lim,
+                                               size_t pitch, int lane, const Rope& R, int b) {
+  if (!R.cos_tab) { load_tile(lds, base, r0, row_lim, pitch, lane); return; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + i * 64;
+    const int row = c >> 3, ch = c & 7;
+    const int gr = r0 + row;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (gr < row_lim) {
+      const bf16_t* rp = base + (size_t)gr * pitch;
+      uint4 lo = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8);
+      uint4 up = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8 + 32);
+      rope_pair(lo, up, R, rope_pos(R, b, gr), (ch & 3) * 8);
+      v = (ch & 4) ? up : lo;
+    }
     *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = v;
   }
 }
@@ -48,6 +99,23 @@ __device__ __forceinline__ bf16x8_t frag_global(const bf16_t* __restrict__ base,
   uint4 v = make_uint4(0, 0, 0, 0);
   if (row < row_lim) v = *reinterpret_cast<const uint4*>(base + (size_t)row * pitch + 16 * s + (lane >> 5) * 8);
   return __builtin_bit_cast(bf16x8_t, v);
+}
+// the 4 dh-fragments of one row (dh chunk [16s + 8hi, +8), s = 0..3), rotated: chunks s and s+2 are 32 channels apart
+__device__ __forceinline__ void frags_global_rope(bf16x8_t (&f)[4], const bf16_t* __restrict__ base, int row, int row_lim,
+                                                  size_t pitch, int lane, const Rope& R, int b) {
+  uint4 v[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    v[s] = make_uint4(0, 0, 0, 0);
+    if (row < row_lim) v[s] = *reinterpret_cast<const uint4*>(base + (size_t)row * pitch + 16 * s + (lane >> 5) * 8);
+  }
+  if (R.cos_tab && row < row_lim) {
+    const int pos = rope_pos(R, b, row);
+    rope_pair(v[0], v[2], R, pos, (lane >> 5) * 8);
+    rope_pair(v[1], v[3], R, pos, 16 + (lane >> 5) * 8);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) f[s] = __builtin_bit_cast(bf16x8_t, v[s]);
 }
 // transposed operand: MFMA row = dh (dhb*32 + lane&31), k = tile rows {16j + 4hi + (e&3) + 8(e>>2)}
 __device__ __forceinline__ bf16x8_t frag_tr(const unsigned char* lds, int dhb, int j, int lane) {
@@ -94,10 +162,28 @@ __device__ __forceinline__ void store_t(bf16_t* __restrict__ dst_row, const f32x
   }
 }
 
+// gradient of a rotated row back to the un-rotated one: x = R(-theta) x'   (a0 = dh 0..31, a1 = dh 32..63)
+__device__ __forceinline__ void unrope_acc(f32x16_t& a0, f32x16_t& a1, const Rope& R, int pos, int hi) {
+  if (!R.cos_tab) return;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int j0 = 8 * rr + 4 * hi;
+    const float4 c = *reinterpret_cast<const float4*>(R.cos_tab + (size_t)pos * 32 + j0);
+    const float4 sn = *reinterpret_cast<const float4*>(R.sin_tab + (size_t)pos * 32 + j0);
+    const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = a0[4 * rr + e], up = a1[4 * rr + e];
+      a0[4 * rr + e] = lo * cc[e] + up * ss[e];
+      a1[4 * rr + e] = up * cc[e] - lo * ss[e];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
                                                       bf16_t* __restrict__ out, float* __restrict__ lse, int B, int S,
-                                                      int H, int causal) {
+                                                      int H, int causal, Rope R) {
   __shared__ __attribute__((aligned(16))) unsigned char vt[4096];
   const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
@@ -110,18 +196,16 @@ __global__ void __launch_bounds__(64) attn_fwd_kernel(const bf16_t* __restrict__
   const int qrow = q0 + l31;
 
   bf16x8_t qf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = frag_global(qb, qrow, S, pitch, s, lane);
+  frags_global_rope(qf, qb, qrow, S, pitch, lane, R, b);
   f32x16_t o0 = zero16(), o1 = zero16();
   float m = -INFINITY, l = 0.f;
   const int kend = causal ? min(klen, q0 + 32) : klen;
   for (int k0 = 0; k0 < kend; k0 += 32) {
     f32x16_t sc = zero16();
+    bf16x8_t kf[4];
+    frags_global_rope(kf, kb, k0 + l31, S, pitch, lane, R, b);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8_t kf = frag_global(kb, k0 + l31, S, pitch, s, lane);
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc, 0, 0, 0);
-    }
+    for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sc, 0, 0, 0);
     __syncthreads();  // previous tile's transposed reads are done
     load_tile(vt, vb, k0, S, pitch, lane);
     float mx = -INFINITY;
@@ -192,7 +276,7 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restric
 __global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
                                                          const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
-                                                         int B, int S, int H, int causal) {
+                                                         int B, int S, int H, int causal, Rope R) {
   __shared__ __attribute__((aligned(16))) unsigned char kt[4096];
   const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
@@ -205,18 +289,16 @@ __global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const bf16_t* __restric
   const int klen = key_len ? key_len[b] : S;
   const int qrow = q0 + l31;
   bf16x8_t qf[4], dof[4];
+  frags_global_rope(qf, qb, qrow, S, pitch, lane, R, b);
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    qf[s] = frag_global(qb, qrow, S, pitch, s, lane);
-    dof[s] = frag_global(dob, qrow, S, (size_t)d, s, lane);
-  }
+  for (int s = 0; s < 4; ++s) dof[s] = frag_global(dob, qrow, S, (size_t)d, s, lane);
   const size_t sidx = ((size_t)b * H + h) * S + min(qrow, S - 1);
   const float lse_q = lse[sidx], dl_q = delta[sidx];
   f32x16_t a0 = zero16(), a1 = zero16();
   const int kend = causal ? min(klen, q0 + 32) : klen;
   for (int k0 = 0; k0 < kend; k0 += 32) {
     __syncthreads();
-    load_tile(kt, kb, k0, S, pitch, lane);
+    load_tile_rope(kt, kb, k0, S, pitch, lane, R, b);
     f32x16_t dp = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -240,14 +322,17 @@ __global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const bf16_t* __restric
     a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 0, lane), ds0, a1, 0, 0, 0);
     a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 1, lane), ds1, a1, 0, 0, 0);
   }
-  if (qrow < S) store_t(dqkv + ((size_t)b * S + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
+  if (qrow < S) {
+    unrope_acc(a0, a1, R, rope_pos(R, b, qrow), hi);
+    store_t(dqkv + ((size_t)b * S + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
+  }
 }
 
 // dV^T[dh][key] = sum_q dO^T[dh][q] P[q][key] ; dK^T[dh][key] = sum_q Q^T[dh][q] dS[q][key]
 __global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
-                                                          int B, int S, int H, int causal) {
+                                                          int B, int S, int H, int causal, Rope R) {
   __shared__ __attribute__((aligned(16))) unsigned char qt[4096];
   __shared__ __attribute__((aligned(16))) unsigned char dot_[4096];
   __shared__ float lse_s[32], dl_s[32];
@@ -262,18 +347,16 @@ __global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const bf16_t* __restri
   const int klen = key_len ? key_len[b] : S;
   const int krow = k0 + l31;
   bf16x8_t kf[4], vf[4];
+  frags_global_rope(kf, kb, krow, S, pitch, lane, R, b);
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    kf[s] = frag_global(kb, krow, S, pitch, s, lane);
-    vf[s] = frag_global(vb, krow, S, pitch, s, lane);
-  }
+  for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, krow, S, pitch, s, lane);
   f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
   const bool key_ok = krow < klen;
   const int qstart = causal ? k0 : 0;  // queries before the key tile never see it
   if (k0 < klen) {
     for (int q0 = qstart; q0 < S; q0 += 32) {
       __syncthreads();
-      load_tile(qt, qb, q0, S, pitch, lane);
+      load_tile_rope(qt, qb, q0, S, pitch, lane, R, b);
       load_tile(dot_, dob, q0, S, (size_t)d, lane);
       if (lane < 32) {
         const int q = min(q0 + lane, S - 1);
@@ -310,6 +393,7 @@ __global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const bf16_t* __restri
   }
   if (krow < S) {
     bf16_t* row = dqkv + ((size_t)b * S + krow) * pitch + h * 64;
+    unrope_acc(dk0, dk1, R, rope_pos(R, b, krow), hi);
     store_t(row + d, dk0, dk1, 1.f, hi);
     store_t(row + 2 * d, dv0, dv1, 1.f, hi);
   }
@@ -318,18 +402,21 @@ __global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const bf16_t* __restri
 }  // namespace
 
 int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
-               hipStream_t st) {
+               const float* cos_tab, const float* sin_tab, const int64_t* position_ids, hipStream_t st) {
   if (B == 0 || S == 0) return 0;
   dim3 grid((S + 31) / 32, H, B);
+  const Rope R{cos_tab, sin_tab, position_ids, S};
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, key_len, (bf16_t*)out, lse, B, S, H,
-                     causal);
+                     causal, R);
   GGET_LAUNCH_CHECK();
   return 0;
 }
 
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
-               float* delta_ws, int B, int S, int H, int causal, hipStream_t st) {
+               float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
+               const int64_t* position_ids, hipStream_t st) {
   if (B == 0 || S == 0) return 0;
+  const Rope R{cos_tab, sin_tab, position_ids, S};
   const long work = (long)B * S * H * 8;
   int g = (int)((work + 255) / 256);
   if (g > 4096) g = 4096;
@@ -337,9 +424,9 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
                      H);
   dim3 grid((S + 31) / 32, H, B);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta_ws,
-                     key_len, (bf16_t*)dqkv, B, S, H, causal);
+                     key_len, (bf16_t*)dqkv, B, S, H, causal, R);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta_ws,
-                     key_len, (bf16_t*)dqkv, B, S, H, causal);
+                     key_len, (bf16_t*)dqkv, B, S, H, causal, R);
   GGET_LAUNCH_CHECK();
   return 0;
 }

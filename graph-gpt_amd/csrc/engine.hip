@@ -31,6 +31,8 @@ extern "C" int gget_version(void) { return 100; }
 namespace {
 
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+constexpr int kWgSplit = 3;    // K slices of the attention-projection wgrad (72 output tiles -> 216 blocks)
+constexpr int kLmSplit = 16;   // K slices of the lm_head wgrad (6x6 output tiles, K = Lm ~ 5e4)
 
 struct ParamRec {
   std::string name;
@@ -108,7 +110,7 @@ Plan make_plan(const gget_config_t& c) {
   add_param(pl, "model.norm.weight", d, 0, (int)L, true, &pl.normf, &pl.normf32);
   if (c.kind == GGET_KIND_PRETRAIN) {
     if (pl.has_ntp) add_param(pl, "n_token_proj.weight", (int64_t)c.next_n_token * d, d, (int)L, false, &pl.ntp, nullptr);
-    add_param(pl, "lm_head.weight", V, d, (int)L, true, &pl.lm, &pl.lm32);
+    add_param(pl, "lm_head.weight", V, d, (int)L, false, &pl.lm, nullptr);
   } else {
     add_param(pl, "score.weight", c.num_labels, d, (int)L, true, &pl.score, &pl.score32);
     if (c.score_bias) add_param(pl, "score.bias", c.num_labels, 0, (int)L, true, &pl.sbias, &pl.sbias32);
@@ -136,7 +138,7 @@ struct Ws {
   std::vector<LayerWs> lw;
   uint64_t rstd_f, hidden;
   uint64_t dxa, dxb, dxc, dxn, dqkv, dattn, dgu, dh, delta, dscaled;
-  uint64_t scratch32, loss_sum, sqnorm, counts, segs, emb_sort;
+  uint64_t scratch32, loss_sum, sqnorm, counts, segs, emb_sort, wg32, lm_slab;
   // pre-train head
   uint64_t cnt, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
   // task head
@@ -188,6 +190,7 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.sqnorm = b.take(256);
   w.counts = b.take(256);
   w.segs = b.take((uint64_t)pl.params.size() * sizeof(GgetSegment));
+  w.wg32 = b.take(kWgSplit * 4 * d * d * 4);   // split-K slabs of the q|k|v|o wgrad
   w.emb_sort = b.take(k_embed_bwd_ws_elems(T * (uint64_t)c.stacked_feat, (uint64_t)c.vocab_size) * 4);
   if (c.kind == GGET_KIND_PRETRAIN) {
     const uint64_t n = c.next_n_token, Vp = align_up(c.vocab_size, 64);
@@ -209,6 +212,7 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
       w.Pp = w.Hl = w.Hm;
       w.dHl = w.dP = w.dHm;
     }
+    w.lm_slab = b.take((uint64_t)kLmSplit * c.vocab_size * d * 4);
     w.logits = b.take(T * n * Vp * 2);
     w.dlogits = b.take(T * n * Vp * 2);
   } else {
@@ -448,8 +452,9 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
   bf16_t* hh = h->wsp<bf16_t>(lw.h);
   if (int e = k_rmsnorm_fwd(x_in, h->P + lo.ln1, xn1, h->wsp<float>(lw.rstd1), T, d, c.rms_eps, st)) return e;
   if (int e = gemm_nt(xn1, h->P + lo.wqkv, qkv, nullptr, T, 3 * d, d, d, d, 3 * d, nullptr, st)) return e;
-  if (int e = k_rope(qkv, h->cos_tab, h->sin_tab, h->pos, T, h->S, H, 0, st)) return e;
-  if (int e = k_attn_fwd(qkv, h->wsp<int32_t>(h->ws.key_len), attn, h->wsp<float>(lw.lse), h->B, h->S, H, c.causal, st))
+  // RoPE is fused into the attention kernels' operand loads (qkv stays un-rotated in HBM)
+  if (int e = k_attn_fwd(qkv, h->wsp<int32_t>(h->ws.key_len), attn, h->wsp<float>(lw.lse), h->B, h->S, H, c.causal,
+                         h->cos_tab, h->sin_tab, h->pos, st))
     return e;
   if (h->plan.has_ls) {
     bf16_t* araw = h->wsp<bf16_t>(lw.araw);
@@ -640,19 +645,26 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   // attention: dattn = dy_o W_o ; (dq,dk,dv) ; inverse RoPE ; dxn1 = dqkv W_qkv
   if (int e = gemm_nn(dy_o, h->P + lo.wo, dattn, T, d, d, d, d, d, nullptr, st)) return e;
   if (int e = k_attn_bwd(h->wsp<bf16_t>(lw.qkv), h->wsp<bf16_t>(lw.attn), dattn, h->wsp<float>(lw.lse),
-                         h->wsp<int32_t>(w.key_len), dqkv, h->wsp<float>(w.delta), h->B, h->S, H, c.causal, st))
+                         h->wsp<int32_t>(w.key_len), dqkv, h->wsp<float>(w.delta), h->B, h->S, H, c.causal, h->cos_tab,
+                         h->sin_tab, h->pos, st))
     return e;
-  if (int e = k_rope(dqkv, h->cos_tab, h->sin_tab, h->pos, T, h->S, H, 1, st)) return e;
   if (int e = gemm_nn(dqkv, h->P + lo.wqkv, dxn, T, d, 3 * d, 3 * d, d, d, nullptr, st)) return e;
   if (int e = k_rmsnorm_bwd(dxn, x_in, h->P + lo.ln1, h->wsp<float>(lw.rstd1), dx_mid, dx_in, s32 + lo.ln1_32, T, d, st))
     return e;
   {
+    // wgrad of q|k|v and o: only 72 output tiles of 256x128 with K = T, so K is cut into kWgSplit slices (216 blocks);
+    // every slice writes its own fp32 slab with wide stores (fp32 atomics are ~3x slower: one TA op per 4 bytes) and a
+    // small kernel sums the slabs into the bf16 gradient array (q|k|v|o are contiguous there).
+    float* wg = h->wsp<float>(w.wg32);
+    const long slab = (long)4 * d * d;
     GemmGroup g;
     memset(&g, 0, sizeof(g));
     g.count = 2;
-    g.p[0] = GemmProblem{dqkv, h->wsp<bf16_t>(lw.xn1), h->G + lo.wqkv, nullptr, 3 * d, d, T, 3 * d, d, d, nullptr, nullptr, 0, 0};
-    g.p[1] = GemmProblem{dy_o, h->wsp<bf16_t>(lw.attn), h->G + lo.wo, nullptr, d, d, T, d, d, d, nullptr, nullptr, 0, 0};
-    if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_NONE, g, 1, st)) return e;
+    g.p[0] = GemmProblem{dqkv, h->wsp<bf16_t>(lw.xn1), wg, nullptr, 3 * d, d, T, 3 * d, d, d, nullptr, nullptr, 0, 0, slab};
+    g.p[1] = GemmProblem{dy_o, h->wsp<bf16_t>(lw.attn), wg + (size_t)3 * d * d, nullptr, d, d, T, d, d, d, nullptr, nullptr, 0, 0, slab};
+    const int split = T >= kWgSplit * 1024 ? kWgSplit : 1;
+    if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_SLAB_F32, g, split, st)) return e;
+    if (int e = k_slab_reduce(wg, slab, split, h->G + lo.wqkv, (size_t)4 * d * d, st)) return e;
   }
   h->dx_cur = dx_in;
   return convert_bucket(h, h->bucket_of_layer(i), st);
@@ -678,9 +690,19 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
     bf16_t* dlog = h->wsp<bf16_t>(w.dlogits);
     // lm_head: dHl = dlogits W_lm ; dW_lm = dlogits^T Hl (split-K, fp32 atomics: only 6x6 output tiles)
     if (int e = gemm_nn(dlog, h->P + h->plan.lm, h->wsp<bf16_t>(w.dHl), T * n, d, V, Vp, d, d, counts + 1, st)) return e;
-    if (int e = gget_gemm_single(GGET_GEMM_TN, GGET_EPI_ATOMIC_F32, dlog, h->wsp<bf16_t>(w.Hl), s32 + h->plan.lm32, nullptr, V,
-                                 d, T * n, Vp, d, d, nullptr, counts + 1, 16, st))
-      return e;
+    {
+      // K = Lm (device-side count, ~5e4) over only 6x6 output tiles: kLmSplit K-slices, one fp32 slab each, then a sum.
+      // Slices that fall beyond a short Lm write nothing, so the slabs are cleared first.
+      float* slabs = h->wsp<float>(w.lm_slab);
+      const long slab = (long)V * d;
+      GGET_HIP_CHECK(hipMemsetAsync(slabs, 0, (size_t)kLmSplit * slab * sizeof(float), st));
+      GemmGroup g;
+      memset(&g, 0, sizeof(g));
+      g.count = 1;
+      g.p[0] = GemmProblem{dlog, h->wsp<bf16_t>(w.Hl), slabs, nullptr, V, d, T * n, Vp, d, d, nullptr, counts + 1, 0, 0, slab};
+      if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_SLAB_F32, g, kLmSplit, st)) return e;
+      if (int e = k_slab_reduce(slabs, slab, kLmSplit, h->G + h->plan.lm, (size_t)V * d, st)) return e;
+    }
     if (h->plan.has_ntp) {
       bf16_t* dP = h->wsp<bf16_t>(w.dP);
       GGET_HIP_CHECK(hipMemsetAsync(dP, 0, (size_t)T * n * d * 2, st));
@@ -798,12 +820,14 @@ extern "C" int gget_op_rope(void* qkv, const float* cos_tab, const float* sin_ta
   return k_rope(qkv, cos_tab, sin_tab, position_ids, B * S, S, H, inverse, (hipStream_t)stream);
 }
 extern "C" int gget_op_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
-                                void* stream) {
-  return k_attn_fwd(qkv, key_len, out, lse, B, S, H, causal, (hipStream_t)stream);
+                                const float* cos_tab, const float* sin_tab, const int64_t* position_ids, void* stream) {
+  return k_attn_fwd(qkv, key_len, out, lse, B, S, H, causal, cos_tab, sin_tab, position_ids, (hipStream_t)stream);
 }
 extern "C" int gget_op_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len,
-                                void* dqkv, float* delta_ws, int B, int S, int H, int causal, void* stream) {
-  return k_attn_bwd(qkv, out, dout, lse, key_len, dqkv, delta_ws, B, S, H, causal, (hipStream_t)stream);
+                                void* dqkv, float* delta_ws, int B, int S, int H, int causal, const float* cos_tab,
+                                const float* sin_tab, const int64_t* position_ids, void* stream) {
+  return k_attn_bwd(qkv, out, dout, lse, key_len, dqkv, delta_ws, B, S, H, causal, cos_tab, sin_tab, position_ids,
+                    (hipStream_t)stream);
 }
 extern "C" int gget_op_geglu_fwd(const void* gu, void* h, int T, int ff, void* stream) {
   return k_geglu_fwd(gu, h, T, ff, (hipStream_t)stream);

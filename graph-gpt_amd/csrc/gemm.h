@@ -16,6 +16,7 @@ struct GemmProblem {
   const int* m_dev;   // optional: rows of C read from device memory (head compaction counts)
   const int* k_dev;   // optional: reduction length read from device memory
   int tiles_n, tile_begin;  // filled by the launcher
+  long slab_stride;         // EPI_SLAB_F32: elements between the fp32 slabs of consecutive K slices
 };
 
 struct GemmGroup {

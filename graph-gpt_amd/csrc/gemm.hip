@@ -158,7 +158,8 @@ constexpr int kSuper = 8;  // row panels per L2 super-tile
 // up with 8 consecutive columns => 16-byte stores, 64-byte row segments, half the store instructions (the C store is
 // issue-bound, not bandwidth-bound).
 template <int EPI>
-__device__ __forceinline__ void store_tile(f32x4_t (&acc)[4][4], const GemmProblem& P, int M, int N, int mw, int nw, int lane) {
+__device__ __forceinline__ void store_tile(f32x4_t (&acc)[4][4], const GemmProblem& P, int M, int N, int mw, int nw, int lane,
+                                           int kslice = 0) {
   const int l15 = lane & 15, gq = lane >> 4;
   if (EPI == GGET_EPI_ATOMIC_F32) {
 #pragma unroll
@@ -196,6 +197,12 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[4][4], const GemmProbl
       }
       const int n = nw + (2 * jp + (odd ? 1 : 0)) * 16 + (gq & 2) * 4;
       if (m >= M || n >= N) continue;
+      if (EPI == GGET_EPI_SLAB_F32) {
+        float* fp = reinterpret_cast<float*>(P.C) + (size_t)kslice * P.slab_stride + (size_t)m * P.ldc + n;
+        *reinterpret_cast<float4*>(fp) = make_float4(v[0], v[1], v[2], v[3]);
+        if (n + 8 <= N) *reinterpret_cast<float4*>(fp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        continue;
+      }
       bf16_t* cp = reinterpret_cast<bf16_t*>(P.C) + (size_t)m * P.ldc + n;
       if (n + 8 <= N) {
         if (EPI == GGET_EPI_RESIDUAL) {
@@ -332,7 +339,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const
     if (sacc == 1.2345e-30f) reinterpret_cast<bf16_t*>(P.C)[0] = 1;  // keep the accumulators live
     return;
   }
-  store_tile<EPI>(acc, P, M, N, m0 + wm * 64, n0 + wn * 64, lane);
+  store_tile<EPI>(acc, P, M, N, m0 + wm * 64, n0 + wn * 64, lane, blockIdx.y);
 }
 
 
@@ -552,7 +559,7 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
   }
   if (total == 0) return 0;
   constexpr int SMEM = kStages * (BM + BN) * 128;
-  bool persist = split_k <= 1 && EPI != GGET_EPI_ATOMIC_F32 && !g.ablate && getenv("GGET_GEMM_NO_PERSIST") == nullptr;
+  bool persist = split_k <= 1 && EPI != GGET_EPI_ATOMIC_F32 && EPI != GGET_EPI_SLAB_F32 && !g.ablate && getenv("GGET_GEMM_NO_PERSIST") == nullptr;
   for (int i = 0; i < g.count; ++i)
     persist = persist && g.p[i].m_dev == nullptr && g.p[i].k_dev == nullptr && (g.p[i].K % 64) == 0 && g.p[i].K >= 64;
   if constexpr (WM * WN == 8) {
@@ -618,6 +625,7 @@ int launch_mode(GemmGroup& g, int epi, int split_k, hipStream_t st) {
     case GGET_EPI_NONE: return launch_shape<A_MC, B_MC, GGET_EPI_NONE>(g, split_k, st);
     case GGET_EPI_RESIDUAL: return launch_shape<A_MC, B_MC, GGET_EPI_RESIDUAL>(g, split_k, st);
     case GGET_EPI_ATOMIC_F32: return launch_shape<A_MC, B_MC, GGET_EPI_ATOMIC_F32>(g, split_k, st);
+    case GGET_EPI_SLAB_F32: return launch_shape<A_MC, B_MC, GGET_EPI_SLAB_F32>(g, split_k, st);
   }
   gget_set_error("gemm: unknown epilogue %d", epi);
   return 2;
@@ -633,7 +641,8 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
   static int super = -1;
   if (super < 0) { const char* e = getenv("GGET_GEMM_SUPER"); super = e ? atoi(e) : 0; }
   g.super = super > 0 ? super : (mode == GGET_GEMM_TN ? 1 : kSuper);
-  GGET_REQUIRE(split_k <= 1 || epi == GGET_EPI_ATOMIC_F32, "gemm: split-K needs the fp32 atomic epilogue");
+  GGET_REQUIRE(split_k <= 1 || epi == GGET_EPI_ATOMIC_F32 || epi == GGET_EPI_SLAB_F32,
+               "gemm: split-K needs the fp32 atomic or slab epilogue");
   for (int i = 0; i < g.count; ++i) {
     const GemmProblem& p = g.p[i];
     GGET_REQUIRE((p.lda % 8) == 0 && (p.ldb % 8) == 0 && (p.ldc % 8) == 0 && (p.N % 4) == 0,
@@ -660,5 +669,6 @@ int gget_gemm_single(int mode, int epi, const void* A, const void* B, void* C, c
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.m_dev = m_dev; p.k_dev = k_dev;
+  p.slab_stride = (long)M * ldc;  // EPI_SLAB_F32 through the op-level entry: dense [split_k][M][ldc] slabs
   return gget_gemm_launch(mode, epi, g, split_k, st);
 }

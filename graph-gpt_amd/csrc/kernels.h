@@ -44,10 +44,13 @@ int k_adamw(float* master, float* m, float* v, const void* grad, void* param, si
             float eps, float wd, int step, float max_norm, float grad_scale, const float* sqnorm, float* gnorm_out,
             hipStream_t st);
 int k_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st);
+int k_slab_reduce(const float* slabs, long slab_stride, int nslab, void* dst, size_t n, hipStream_t st);
 int k_convert_segments(const float* scratch, void* grads, const GgetSegment* segs_dev, int nseg, hipStream_t st);
 
 // attention.hip
+// cos_tab/sin_tab ([max_pos][32] fp32) non-null => RoPE is applied to q,k on load and undone on dq,dk (qkv stays un-rotated)
 int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
-               hipStream_t st);
+               const float* cos_tab, const float* sin_tab, const int64_t* position_ids, hipStream_t st);
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
-               float* delta_ws, int B, int S, int H, int causal, hipStream_t st);
+               float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
+               const int64_t* position_ids, hipStream_t st);

@@ -256,6 +256,8 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_fwd_kernel(const bf16_t* __res
 }
 
 // backward: dx = dres + rstd*(dy*w - xhat*mean(dy*w*xhat)),  dw += dy*xhat  (fp32 accumulators)
+// NCH = 16-byte chunks per lane (2 covers d <= 1024: fewer live registers => more waves to hide HBM latency).
+template <int NCH>
 __global__ void __launch_bounds__(kBlock) rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                              const bf16_t* __restrict__ w, const float* __restrict__ rstd_in,
                                                              const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
@@ -263,10 +265,10 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_bwd_kernel(const bf16_t* __res
   extern __shared__ float dw_lds[];  // [4][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = d >> 3;
-  float dwp[kMaxChunksPerLane][8];
-  float wv[kMaxChunksPerLane][8];
+  float dwp[NCH][8];
+  float wv[NCH][8];
 #pragma unroll
-  for (int i = 0; i < kMaxChunksPerLane; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int c = lane + i * 64;
 #pragma unroll
     for (int e = 0; e < 8; ++e) dwp[i][e] = 0.f;
@@ -274,15 +276,25 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_bwd_kernel(const bf16_t* __res
   }
   for (int row = blockIdx.x * (kBlock / 64) + wave; row < T; row += gridDim.x * (kBlock / 64)) {
     const float rstd = rstd_in[row];
-    float xh[kMaxChunksPerLane][8], g[kMaxChunksPerLane][8];
+    uint4 xr[NCH], dr[NCH], rr[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {   // issue every load of the row before touching any of them
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        xr[i] = ldg16(x + (size_t)row * d + c * 8);
+        dr[i] = ldg16(dy + (size_t)row * d + c * 8);
+        rr[i] = dres ? ldg16(dres + (size_t)row * d + c * 8) : make_uint4(0, 0, 0, 0);
+      }
+    }
+    float xh[NCH][8], g[NCH][8];
     float dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxChunksPerLane; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int c = lane + i * 64;
       if (c < nchunk) {
         float xv[8], dv[8];
-        unpack8(ldg16(x + (size_t)row * d + c * 8), xv);
-        unpack8(ldg16(dy + (size_t)row * d + c * 8), dv);
+        unpack8(xr[i], xv);
+        unpack8(dr[i], dv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           xh[i][e] = xv[e] * rstd;
@@ -294,15 +306,11 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_bwd_kernel(const bf16_t* __res
     }
     dot = wave_sum(dot) / (float)d;
 #pragma unroll
-    for (int i = 0; i < kMaxChunksPerLane; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int c = lane + i * 64;
       if (c < nchunk) {
         float o[8];
-        if (dres) unpack8(ldg16(dres + (size_t)row * d + c * 8), o);
-        else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = 0.f;
-        }
+        unpack8(rr[i], o);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += rstd * (g[i][e] - xh[i][e] * dot);
         stg16(dx + (size_t)row * d + c * 8, pack8(o));
@@ -311,7 +319,7 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_bwd_kernel(const bf16_t* __res
   }
   // block-level reduction of the dw partials, then one atomic per channel per block
 #pragma unroll
-  for (int i = 0; i < kMaxChunksPerLane; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int c = lane + i * 64;
     if (c < nchunk) {
 #pragma unroll
@@ -751,6 +759,23 @@ __global__ void __launch_bounds__(kBlock) f32_to_bf16_kernel(const float* __rest
   }
 }
 
+// sum of `nslab` fp32 slabs (split-K partial products) -> bf16; rows beyond *rows_dev (if given) are left as they are
+__global__ void __launch_bounds__(kBlock) slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int nslab,
+                                                             bf16_t* __restrict__ dst, size_t n) {
+  const size_t nv = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (size_t)gridDim.x * kBlock) {
+    float4 a = reinterpret_cast<const float4*>(slabs)[i];
+    for (int s = 1; s < nslab; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(slabs + (size_t)s * slab_stride)[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    uint2 o;
+    o.x = pack2bf(a.x, a.y);
+    o.y = pack2bf(a.z, a.w);
+    *reinterpret_cast<uint2*>(dst + i * 4) = o;
+  }
+}
+
 // fp32 accumulation segments (embedding, norm weights, ...) -> bf16 gradient array
 __global__ void __launch_bounds__(kBlock) convert_segments_kernel(const float* __restrict__ scratch, bf16_t* __restrict__ grads,
                                                                   const GgetSegment* __restrict__ segs) {
@@ -835,9 +860,13 @@ int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rst
                   float* dw_accum, int T, int d, hipStream_t st) {
   GGET_REQUIRE(d % 8 == 0 && d <= 64 * 8 * kMaxChunksPerLane, "rmsnorm: d=%d unsupported", d);
   if (T == 0) return 0;
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(grid_for(T, 4 * 2, 2048)), dim3(kBlock), 4 * d * sizeof(float), st,
-                     (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx,
-                     dw_accum, T, d);
+  const int grid = grid_for(T, 4 * 4, 1024);  // 4 rows per wave: enough rows to amortise the dw atomics
+  if (d <= 1024)
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<2>, dim3(grid), dim3(kBlock), 4 * d * sizeof(float), st, (const bf16_t*)dy,
+                       (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_accum, T, d);
+  else
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, dim3(grid), dim3(kBlock), 4 * d * sizeof(float), st, (const bf16_t*)dy,
+                       (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_accum, T, d);
   GGET_LAUNCH_CHECK();
   return 0;
 }
@@ -963,6 +992,13 @@ int k_adamw(float* master, float* m, float* v, const void* grad, void* param, si
 int k_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st) {
   hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for((long)(n / 4), kBlock, 4096)), dim3(kBlock), 0, st, src,
                      (bf16_t*)dst, n);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_slab_reduce(const float* slabs, long slab_stride, int nslab, void* dst, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)(n / 4), kBlock, 2048)), dim3(kBlock), 0, st, slabs,
+                     slab_stride, nslab, (bf16_t*)dst, n);
   GGET_LAUNCH_CHECK();
   return 0;
 }

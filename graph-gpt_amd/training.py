@@ -95,6 +95,7 @@ class GgetEngine:
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self._comm_stream = None
         self._pending = []
+        self.force_staged = bool(int(os.environ.get("GGET_FORCE_STAGED", "0")))  # run the bucketed path at world 1
         model.materialize_grads = False  # fused path: gradients stay in the flat bf16 arena
 
     @property
@@ -114,7 +115,7 @@ class GgetEngine:
     # -- backward with bucketed all-reduce overlapped on a side stream
     def backward(self, loss=None):
         e = self.module._engine
-        if self.world == 1:
+        if self.world == 1 and not self.force_staged:
             e.backward()
             return
         if self._comm_stream is None:
@@ -128,8 +129,10 @@ class GgetEngine:
             ev.record(main)
             self._comm_stream.wait_event(ev)
             with torch.cuda.stream(self._comm_stream):
-                w = all_reduce_bucket(e.grad_bf16, (off, cnt), self.pg, async_op=True)
-            self._pending.append(w)
+                if self.world > 1:
+                    self._pending.append(all_reduce_bucket(e.grad_bf16, (off, cnt), self.pg, async_op=True))
+                else:  # single-rank dry run of the staged path (tests): the exchange is the identity
+                    self._pending.append(None)
 
         e.backward_begin()
         reduce_bucket(0)
@@ -143,7 +146,8 @@ class GgetEngine:
         e = self.module._engine
         if self._pending:
             for w in self._pending:
-                w.wait()  # makes the current stream wait for the comm stream's collectives
+                if w is not None:
+                    w.wait()  # makes the current stream wait for the comm stream's collectives
             self._pending = []
             torch.cuda.current_stream().wait_stream(self._comm_stream)
         o = self.optim

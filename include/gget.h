@@ -165,7 +165,8 @@ int gget_hidden_states(gget_handle_t h, const void** hidden_dev);
 #define GGET_GEMM_TN 2 /* C[M,N] = A[K,M]^T * B[K,N]   (wgrad    dW = dy^T x) */
 #define GGET_EPI_NONE 0
 #define GGET_EPI_RESIDUAL 1 /* C = A*B + R (R bf16 [M,N], ldr = ldc) */
-#define GGET_EPI_ATOMIC_F32 2 /* C is fp32, C += A*B with atomics (split-K over blockIdx.z) */
+#define GGET_EPI_ATOMIC_F32 2 /* C is fp32, C += A*B with atomics (split-K) */
+#define GGET_EPI_SLAB_F32 3 /* C is fp32 [split_k][M][ldc]: slice s of K writes slab s (reduced by the caller) */
 int gget_op_gemm(int mode, int epilogue, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
                  int lda, int ldb, int ldc, int split_k, void* stream);
 int gget_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, void* stream);
@@ -177,10 +178,13 @@ int gget_op_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const
                       float* dgate_accum, int T, int F, int ldF, int d, int V, int pad_id, void* stream);
 int gget_op_rope(void* qkv, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, int B, int S,
                  int H, int inverse, void* stream);
+/* cos_tab/sin_tab ([max_pos][32] fp32, hf LlamaRotaryEmbedding tables) non-NULL: RoPE (hf apply_rotary_pos_emb
+ * :138-160) is applied to q,k inside the kernels and undone on dq,dk; qkv / dqkv are the UN-rotated projections. */
 int gget_op_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H,
-                     int causal, void* stream);
+                     int causal, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, void* stream);
 int gget_op_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len,
-                     void* dqkv, float* delta_ws, int B, int S, int H, int causal, void* stream);
+                     void* dqkv, float* delta_ws, int B, int S, int H, int causal, const float* cos_tab,
+                     const float* sin_tab, const int64_t* position_ids, void* stream);
 int gget_op_geglu_fwd(const void* gu, void* h, int T, int ff, void* stream);
 int gget_op_geglu_bwd(const void* gu, const void* dh, void* dgu, int T, int ff, void* stream);
 int gget_op_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const float* row_wgt, const int32_t* n_rows_dev,

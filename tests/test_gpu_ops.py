@@ -76,6 +76,10 @@ def test_gemm_residual_and_atomic(lib):
     L.check(lib.gget_op_gemm(L.GEMM_NT, L.EPI_ATOMIC_F32, P(A), P(B), P(Cf), None, M, N, K, K, K, N, 3, ST()))
     ref2 = A.float() @ B.float().T
     assert rel_l2(Cf.cpu().numpy(), ref2.cpu().numpy()) < 1e-5  # fp32 accumulate, no output rounding
+    # split-K into per-slice fp32 slabs (what the wgrad of the attention projections and of lm_head use)
+    Cs = torch.zeros(4, M, N, dtype=torch.float32, device="cuda")  # slices past the end of K write nothing
+    L.check(lib.gget_op_gemm(L.GEMM_NT, L.EPI_SLAB_F32, P(A), P(B), P(Cs), None, M, N, K, K, K, N, 4, ST()))
+    assert rel_l2(Cs.sum(0).cpu().numpy(), ref2.cpu().numpy()) < 1e-5
 
 
 def test_gemm_identity_layout(lib):
@@ -187,7 +191,7 @@ def test_rope(lib, with_pos):
 
 def _attn_ref(qkv, lens, B, S, H, causal):
     d = H * 64
-    x = qkv.float().view(B, S, 3, H, 64)
+    x = qkv.view(B, S, 3, H, 64)
     q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))  # [B,H,S,64]
     w = q @ k.transpose(2, 3) * 0.125
     keym = torch.arange(S, device=qkv.device)[None, :] >= lens[:, None]  # [B,S] True = masked
@@ -201,16 +205,31 @@ def _attn_ref(qkv, lens, B, S, H, causal):
 
 
 @pytest.mark.parametrize("causal", [0, 1])
-@pytest.mark.parametrize("B,S,H", [(3, 24, 2), (2, 32, 12), (2, 72, 2), (1, 160, 3)])
-def test_attention_fwd_bwd(lib, B, S, H, causal):
+@pytest.mark.parametrize("rope", [False, True])
+@pytest.mark.parametrize("B,S,H", [(3, 24, 2), (2, 32, 12), (2, 72, 2), (1, 160, 3), (2, 520, 2)])
+def test_attention_fwd_bwd(lib, B, S, H, causal, rope):
+    """QK^T / softmax / PV and their backward, with key-length + causal masking; rope=True also checks the fused
+    rotary embedding (q,k rotated on load, dq,dk rotated back) against autograd through the un-rotated q,k."""
     d = H * 64
     qkv = rnd(B * S, 3 * d, seed=7, scale=1.0)
     lens = torch.tensor([S, max(5, S // 2), max(1, S - 3)][:B], dtype=torch.int32).cuda()
+    cos = sin = pos = None
+    if rope:
+        cos, sin = _tables(1024)
+        pos = torch.arange(S)[None].repeat(B, 1)
+        pos[0, S // 2:] += 7  # arbitrary (fine-tune style) position ids
+        pos = pos.cuda()
     out = torch.zeros(B * S, d, dtype=torch.bfloat16, device="cuda")
     lse = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
-    L.check(lib.gget_op_attn_fwd(P(qkv), P(lens), P(out), P(lse), B, S, H, causal, ST()))
+    L.check(lib.gget_op_attn_fwd(P(qkv), P(lens), P(out), P(lse), B, S, H, causal, P(cos), P(sin), P(pos), ST()))
     qf = qkv.float().requires_grad_(True)
-    ref = _attn_ref(qf, lens, B, S, H, causal)
+    x = qf.view(B, S, 3, H, 64)
+    if rope:
+        qr, kr = _rope_ref(x[:, :, 0], pos), _rope_ref(x[:, :, 1], pos)
+        xin = torch.stack((qr, kr, x[:, :, 2]), dim=2).reshape(B * S, 3 * d)
+    else:
+        xin = qf
+    ref = _attn_ref(xin, lens, B, S, H, causal)
     valid = (torch.arange(S, device="cuda")[None, :] < lens[:, None])  # real query rows
     got = out.float().view(B, S, d)
     e = rel_l2(got[valid].cpu().numpy(), ref.detach()[valid].cpu().numpy())
@@ -221,7 +240,8 @@ def test_attention_fwd_bwd(lib, B, S, H, causal):
     (ref * dout.float().view(B, S, d)).sum().backward()
     dqkv = torch.zeros(B * S, 3 * d, dtype=torch.bfloat16, device="cuda")
     delta = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
-    L.check(lib.gget_op_attn_bwd(P(qkv), P(out), P(dout), P(lse), P(lens), P(dqkv), P(delta), B, S, H, causal, ST()))
+    L.check(lib.gget_op_attn_bwd(P(qkv), P(out), P(dout), P(lse), P(lens), P(dqkv), P(delta), B, S, H, causal, P(cos),
+                                 P(sin), P(pos), ST()))
     g = dqkv.float().view(B, S, 3, d)
     w = qf.grad.view(B, S, 3, d)
     for i, nm in enumerate("qkv"):

@@ -53,19 +53,30 @@ __device__ __forceinline__ void vm_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int ROWS, bool MC, int NTHREADS>
+template <int ROWS, bool MC, int NTHREADS, int BK = 64>
 struct TileIO {
+  static_assert(BK == 64 || BK == 32, "K-tile depth");
   static constexpr int NWAVES = NTHREADS / 64;
-  static constexpr int CHUNKS = ROWS * 8;       // 16-byte chunks per 64-deep tile
+  static constexpr int CHUNKS = ROWS * BK / 8;  // 16-byte chunks per tile
   static constexpr int PER_THREAD = CHUNKS / NTHREADS;
-  static constexpr int ROWB = ROWS * 2;         // bytes per k-row of an MC tile
-  static constexpr int CPR = ROWS / 8;          // chunks per k-row of an MC tile
-  static constexpr int PIECES = (ROWS / 8) / NWAVES;  // LDS-DMA instructions per wave per tile
-  static_assert(CHUNKS % NTHREADS == 0 && (ROWS / 8) % NWAVES == 0, "tile/thread shape");
+  static constexpr int RB = BK * 2;             // bytes per row of a K-contiguous tile
+  static constexpr int CR = BK / 8;             // chunks per row of a K-contiguous tile
+  static constexpr int RPP = 1024 / RB;         // rows per DMA piece of a K-contiguous tile
+  static constexpr int ROWB = ROWS * 2;         // bytes per k-row of an M/N-contiguous tile
+  static constexpr int CPR = ROWS / 8;          // chunks per k-row of an M/N-contiguous tile
+  static constexpr int NPIECE = ROWS * BK * 2 / 1024;
+  static constexpr int PIECES = NPIECE / NWAVES;  // LDS-DMA instructions per wave per tile
+  static_assert(CHUNKS % NTHREADS == 0 && NPIECE % NWAVES == 0, "tile/thread shape");
   static_assert(!MC || ROWS == 64 || ROWS == 128 || ROWS == 256, "M/N-contiguous tiles need power-of-two rows");
 
+  // swizzle of the 16-byte chunk index inside a K-contiguous row (conflict-free ds_read_b128 of 16 rows x 1 chunk):
+  // 128-byte rows: chunk ^= row & 7 ; 64-byte rows (4 rows per 256-byte bank row): chunk ^= {0,3,2,1}[(row >> 2) & 3]
+  __device__ __forceinline__ static int kc_swz(int row) {
+    return BK == 64 ? (row & 7) : ((4 - ((row >> 2) & 3)) & 3);
+  }
+
   // global -> LDS by DMA; out-of-range rows are clamped (they only feed C rows/columns that are never stored),
-  // the K range must be a full 64-deep tile.
+  // the K range must be a full BK-deep tile.
   __device__ __forceinline__ static void glds(unsigned char* lds, const bf16_t* __restrict__ base, int ld, int row0,
                                               int row_lim, int k0, int wave, int lane) {
 #pragma unroll
@@ -73,8 +84,8 @@ struct TileIO {
       const int q = wave + i * NWAVES;
       const bf16_t* p;
       if (!MC) {
-        const int r = q * 8 + (lane >> 3);
-        const int lc = (lane & 7) ^ (r & 7);
+        const int r = q * RPP + lane / CR;
+        const int lc = (lane % CR) ^ kc_swz(r);
         const int gr = min(row0 + r, row_lim - 1);
         p = base + (size_t)gr * ld + k0 + lc * 8;
       } else {
@@ -98,8 +109,8 @@ struct TileIO {
       int gr, gk;
       const bf16_t* p;
       if (!MC) {
-        gr = row0 + (c >> 3);
-        gk = k0 + (c & 7) * 8;
+        gr = row0 + c / CR;
+        gk = k0 + (c % CR) * 8;
         p = base + (size_t)gr * ld + gk;
       } else {
         gk = k0 + c / CPR;
@@ -117,8 +128,8 @@ struct TileIO {
       const int c = tid + i * NTHREADS;
       int off;
       if (!MC) {
-        const int row = c >> 3, ch = c & 7;
-        off = row * 128 + ((ch ^ (row & 7)) << 4);
+        const int row = c / CR, ch = c % CR;
+        off = row * RB + ((ch ^ kc_swz(row)) << 4);
       } else {
         const int krow = c / CPR, mc = c % CPR;
         off = krow * ROWB + ((((mc >> 1) ^ mc_swz(krow))) << 5) + ((mc & 1) << 4);
@@ -126,13 +137,13 @@ struct TileIO {
       *reinterpret_cast<uint4*>(lds + off) = r[i];
     }
   }
-  // LDS -> MFMA fragment for 16-row sub-tile `sub` (index inside the block tile), k-step kk (0/1)
+  // LDS -> MFMA fragment for 16-row sub-tile `sub` (index inside the block tile), 32-deep k-step kk (< BK/32)
   __device__ __forceinline__ static bf16x8_t frag(const unsigned char* lds, int sub, int kk, int lane) {
     const int l15 = lane & 15, g = lane >> 4;
     if (!MC) {
       const int row = sub * 16 + l15;
       const int ch = kk * 4 + g;
-      const uint4 v = *reinterpret_cast<const uint4*>(lds + row * 128 + ((ch ^ (row & 7)) << 4));
+      const uint4 v = *reinterpret_cast<const uint4*>(lds + row * RB + ((ch ^ kc_swz(row)) << 4));
       return __builtin_bit_cast(bf16x8_t, v);
     } else {
       const int kr0 = kk * 32 + g * 8 + (l15 >> 2);
@@ -151,23 +162,25 @@ struct TileIO {
 };
 
 constexpr int kStages = 3;
+// LDS ring depth of the persistent kernel for a given stage size: 4 slots when they fit in 160 KiB, else 3
+constexpr int persist_slots(int stage_bytes) { return (160 * 1024 / stage_bytes) >= 4 ? 4 : 3; }
 constexpr int kSuper = 8;  // row panels per L2 super-tile
 
 // Epilogue of one wave's 64x64 sub-tile.  After the swapped MFMA a lane owns C[m][n..n+3] (m = lane&15, n-group = lane>>4)
 // of each 16x16 accumulator; lanes l and l^16 trade halves of two neighbouring accumulators so that every lane ends
 // up with 8 consecutive columns => 16-byte stores, 64-byte row segments, half the store instructions (the C store is
 // issue-bound, not bandwidth-bound).
-template <int EPI>
-__device__ __forceinline__ void store_tile(f32x4_t (&acc)[4][4], const GemmProblem& P, int M, int N, int mw, int nw, int lane,
+template <int EPI, int MI, int NJ>
+__device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmProblem& P, int M, int N, int mw, int nw, int lane,
                                            int kslice = 0) {
   const int l15 = lane & 15, gq = lane >> 4;
   if (EPI == GGET_EPI_ATOMIC_F32) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const int m = mw + i * 16 + l15;
       if (m >= M) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int n = nw + j * 16 + gq * 4;
         if (n >= N) continue;
         float* c = reinterpret_cast<float*>(P.C) + (size_t)m * P.ldc + n;
@@ -179,10 +192,10 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[4][4], const GemmProbl
   }
   const bool odd = gq & 1;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MI; ++i) {
     const int m = mw + i * 16 + l15;
 #pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
+    for (int jp = 0; jp < NJ / 2; ++jp) {
       // even lanes keep accumulator 2jp and fetch the partner's half of it; odd lanes keep 2jp+1
       f32x4_t keep = odd ? acc[i][2 * jp + 1] : acc[i][2 * jp];
       f32x4_t give = odd ? acc[i][2 * jp] : acc[i][2 * jp + 1];
@@ -339,7 +352,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const
     if (sacc == 1.2345e-30f) reinterpret_cast<bf16_t*>(P.C)[0] = 1;  // keep the accumulators live
     return;
   }
-  store_tile<EPI>(acc, P, M, N, m0 + wm * 64, n0 + wn * 64, lane, blockIdx.y);
+  store_tile<EPI, MI, NJ>(acc, P, M, N, m0 + wm * 64, n0 + wn * 64, lane, blockIdx.y);
 }
 
 
@@ -349,16 +362,18 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const
 // first/last are hidden (at K = 768 they are ~30 % of a non-persistent tile's life).
 // Counted waits stay valid with stores in flight: vmcnt <= PIECES means >= (stores + PIECES) older operations have
 // retired, and loads retire in order among themselves, so the oldest PIECES loads (the tile being waited for) are in.
-template <int WM, int WN, bool A_MC, bool B_MC, int EPI>
-__global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_persist_kernel(const GemmGroup g, int total_tiles) {
+template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI>
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_persist_kernel(const GemmGroup g, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64;
-  using TA = TileIO<BM, A_MC, NT>;
-  using TB = TileIO<BN, B_MC, NT>;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int NT = WM * WN * 64;
+  using TA = TileIO<BM, A_MC, NT, BK>;
+  using TB = TileIO<BN, B_MC, NT, BK>;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int NSLOT = persist_slots(STAGE);   // 256x128x64: 3 x 48 KiB ; 256x256x32 and 128x128x64: 4 x 32 KiB
   constexpr int PIECES = TA::PIECES + TB::PIECES;
-  constexpr int MI = 4, NJ = 4;
+  constexpr int MI = BM / WM / 16, NJ = BN / WN / 16;
+  constexpr int KSH = BK == 64 ? 6 : 5;
 
   const int G = gridDim.x;                                     // multiple of 8
   const int perm = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);  // XCD-contiguous inside every round
@@ -376,7 +391,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_persist_kern
       if (i < g.count && tile >= g.p[i].tile_begin) pi = i;
     c.pi = pi;
     tile_origin(g.p[pi], tile - g.p[pi].tile_begin, BM, BN, g.super, c.m0, c.n0);
-    c.nk = g.p[pi].K >> 6;
+    c.nk = g.p[pi].K >> KSH;
     return true;
   };
 
@@ -396,24 +411,27 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_persist_kern
     if (!ivalid) return;
     const GemmProblem& P = g.p[ic.pi];
     unsigned char* s = smem + islot * STAGE;
-    TA::glds(s, P.A, P.lda, ic.m0, P.M, ik * 64, wave, lane);
-    TB::glds(s + A_BYTES, P.B, P.ldb, ic.n0, P.N, ik * 64, wave, lane);
-    islot = islot == 2 ? 0 : islot + 1;
+    TA::glds(s, P.A, P.lda, ic.m0, P.M, ik * BK, wave, lane);
+    TB::glds(s + A_BYTES, P.B, P.ldb, ic.n0, P.N, ik * BK, wave, lane);
+    islot = islot == NSLOT - 1 ? 0 : islot + 1;
     ++inflight;
     if (++ik == ic.nk) { ik = 0; ++ir; ivalid = tile_at(ir, ic); }
   };
-  issue_next();
-  issue_next();
+#pragma unroll
+  for (int i = 0; i < NSLOT - 1; ++i) issue_next();
   while (cvalid) {
-    if (inflight >= 2) vm_wait<PIECES>(); else vm_wait<0>();
-    __syncthreads();
-    issue_next();
+    // the oldest K-tile in flight must have landed: allow (inflight-1) younger tiles' pieces to stay outstanding
+    if (inflight >= 3) vm_wait<2 * PIECES>();
+    else if (inflight == 2) vm_wait<PIECES>();
+    else vm_wait<0>();
+    __syncthreads();   // publishes that tile; also every wave is done with the slot consumed last iteration
+    issue_next();      // ... which is the slot refilled here
     --inflight;
     {
       const unsigned char* a_l = smem + cslot * STAGE;
       const unsigned char* b_l = a_l + A_BYTES;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
+      for (int kk = 0; kk < BK / 32; ++kk) {
         bf16x8_t af[MI], bf[NJ];
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[i] = TA::frag(a_l, wm * MI + i, kk, lane);
@@ -426,10 +444,10 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_persist_kern
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
       }
     }
-    cslot = cslot == 2 ? 0 : cslot + 1;
+    cslot = cslot == NSLOT - 1 ? 0 : cslot + 1;
     if (++ck == cc.nk) {
       const GemmProblem& P = g.p[cc.pi];
-      store_tile<EPI>(acc, P, P.M, P.N, cc.m0 + wm * 64, cc.n0 + wn * 64, lane);
+      store_tile<EPI, MI, NJ>(acc, P, P.M, P.N, cc.m0 + wm * (MI * 16), cc.n0 + wn * (NJ * 16), lane);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -439,111 +457,6 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_persist_kern
       cvalid = tile_at(cr, cc);
     }
   }
-}
-
-
-// Ping-pong variant (static shapes, K % 64 == 0): the two waves that share a SIMD (wave w and w+4) run the same
-// program ONE PHASE apart, and every K-tile is cut into 4 phases {read kk0, mfma kk0, read kk1, mfma kk1} separated
-// by barriers, so while one wave of a SIMD issues its 16 MFMAs the other one is in its LDS-read / DMA-issue phase:
-// the matrix pipe and the LDS pipe are both busy all the time instead of alternating (the 1-barrier-per-tile loop
-// keeps the two waves in the same phase).  s_setprio favours the wave in its MFMA phase.
-template <int WM, int WN, bool A_MC, bool B_MC, int EPI>
-__global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_pp_kernel(const GemmGroup g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64;
-  static_assert(WM * WN == 8, "ping-pong needs 8 waves (two per SIMD)");
-  using TA = TileIO<BM, A_MC, NT>;
-  using TB = TileIO<BN, B_MC, NT>;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-  constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int PIECES = TA::PIECES + TB::PIECES;
-  constexpr int MI = 4, NJ = 4;
-
-  const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7;
-  const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
-  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < GGET_MAX_GROUP; ++i)
-    if (i < g.count && tile >= g.p[i].tile_begin) pi = i;
-  const GemmProblem& P = g.p[pi];
-  const int M = P.M, N = P.N, K = P.K;
-  int m0, n0;
-  tile_origin(P, tile - P.tile_begin, BM, BN, g.super, m0, n0);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const bool late = wave >= 4;  // the second wave of every SIMD runs one phase behind
-  const int nk = K >> 6;
-
-  f32x4_t acc[MI][NJ];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  bf16x8_t af[MI], bf[NJ];
-
-  auto issue = [&](int t, int slot) {
-    unsigned char* s = smem + slot * STAGE;
-    TA::glds(s, P.A, P.lda, m0, M, t * 64, wave, lane);
-    TB::glds(s + A_BYTES, P.B, P.ldb, n0, N, t * 64, wave, lane);
-  };
-  auto rd = [&](int slot, int kk) {
-    const unsigned char* a_l = smem + slot * STAGE;
-    const unsigned char* b_l = a_l + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) af[i] = TA::frag(a_l, wm * MI + i, kk, lane);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) bf[j] = TB::frag(b_l, wn * NJ + j, kk, lane);
-  };
-  auto mm = [&]() {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  auto bar = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  // prologue: tiles 0 and 1 in flight, tile 0 landed and published
-  issue(0, 0);
-  if (nk > 1) issue(1, 1);
-  if (nk > 1) vm_wait<PIECES>(); else vm_wait<0>();
-  bar();
-  if (late) bar();           // one-phase stagger of waves 4-7
-  rd(0, 0);
-  bar();
-  int slot = 0;
-  for (int t = 0; t < nk; ++t) {
-    const int s1 = slot == 2 ? 0 : slot + 1;   // slot of tile t+1
-    const int s2 = slot == 0 ? 2 : slot - 1;   // slot of tile t-1 == slot of tile t+2
-    mm();                                       // M0
-    bar();
-    rd(slot, 1);                                // R1 (+ refill the slot tile t-1 left: every wave finished reading it
-    if (t + 2 < nk) issue(t + 2, s2);           //      two phases ago at the latest)
-    // tile t+1 is first read by the EARLY waves two barriers from here, i.e. one barrier from here in the late
-    // waves' program: the late waves must have their pieces in before THIS barrier, the early ones before the next.
-    if (late && t + 1 < nk) {
-      if (t + 2 < nk) vm_wait<PIECES>(); else vm_wait<0>();
-    }
-    bar();
-    mm();                                       // M1
-    if (!late && t + 1 < nk) {
-      if (t + 2 < nk) vm_wait<PIECES>(); else vm_wait<0>();
-    }
-    bar();
-    if (t + 1 < nk) rd(s1, 0);                  // R0 of the next tile
-    bar();
-    slot = s1;
-  }
-  if (!late) bar();          // barrier counts of the two groups match
-  store_tile<EPI>(acc, P, M, N, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 template <int WM, int WN, bool A_MC, bool B_MC, int EPI>
@@ -559,22 +472,10 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
   }
   if (total == 0) return 0;
   constexpr int SMEM = kStages * (BM + BN) * 128;
+  constexpr int PSMEM = persist_slots((BM + BN) * 128) * (BM + BN) * 128;
   bool persist = split_k <= 1 && EPI != GGET_EPI_ATOMIC_F32 && EPI != GGET_EPI_SLAB_F32 && !g.ablate && getenv("GGET_GEMM_NO_PERSIST") == nullptr;
   for (int i = 0; i < g.count; ++i)
     persist = persist && g.p[i].m_dev == nullptr && g.p[i].k_dev == nullptr && (g.p[i].K % 64) == 0 && g.p[i].K >= 64;
-  if constexpr (WM * WN == 8) {
-    if (persist && getenv("GGET_GEMM_PP") != nullptr) {
-      static bool ppattr = false;
-      if (!ppattr) {
-        GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<WM, WN, A_MC, B_MC, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        ppattr = true;
-      }
-      hipLaunchKernelGGL((gemm_pp_kernel<WM, WN, A_MC, B_MC, EPI>), dim3(total), dim3(512), SMEM, st, g);
-      GGET_LAUNCH_CHECK();
-      return 0;
-    }
-  }
   if (persist) {
     static int num_cu = 0;
     if (!num_cu) {
@@ -584,15 +485,48 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
       GGET_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
       num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    // wide tile for the widest forward GEMM: 256x256x32 (8 waves of 128x64, 4-slot ring) moves 2/3 of the bytes per
+    // FLOP of the 256x128 tile
+    if constexpr (WM == 4 && WN == 2 && !A_MC && EPI != GGET_EPI_SLAB_F32 && EPI != GGET_EPI_ATOMIC_F32) {
+      long t256 = 0;
+      bool ok256 = getenv("GGET_GEMM_NO_256") == nullptr;
+      for (int i = 0; i < g.count; ++i) {
+        t256 += (long)((g.p[i].M + 255) / 256) * ((g.p[i].N + 255) / 256);
+        ok256 = ok256 && (g.p[i].N % 256) == 0;
+      }
+      // measured (profiles/r01_gemm_tiles.txt): pays only with >= ~2.5 tiles per CU (FFN gate|up), loses on N = 2304 / 3072
+      if (ok256 && t256 >= (5 * num_cu) / 2) {
+        constexpr int SM2 = persist_slots((256 + 256) * 32 * 2) * (256 + 256) * 32 * 2;
+        int tot2 = 0;
+        for (int i = 0; i < g.count; ++i) {
+          GemmProblem& p = g.p[i];
+          p.tiles_n = (p.N + 255) / 256;
+          p.tile_begin = tot2;
+          tot2 += ((p.M + 255) / 256) * p.tiles_n;
+        }
+        int G2 = tot2 < num_cu ? tot2 : num_cu;
+        G2 = (G2 + 7) & ~7;
+        static bool a2 = false;
+        if (!a2) {
+          GGET_HIP_CHECK(hipFuncSetAttribute(
+              reinterpret_cast<const void*>(&gemm_persist_kernel<256, 256, 32, 2, 4, A_MC, B_MC, EPI>),
+              hipFuncAttributeMaxDynamicSharedMemorySize, SM2));
+          a2 = true;
+        }
+        hipLaunchKernelGGL((gemm_persist_kernel<256, 256, 32, 2, 4, A_MC, B_MC, EPI>), dim3(G2), dim3(512), SM2, st, g, tot2);
+        GGET_LAUNCH_CHECK();
+        return 0;
+      }
+    }
     static bool pattr_done = false;
     if (!pattr_done) {
-      GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<WM, WN, A_MC, B_MC, EPI>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+      GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BM, BN, 64, WM, WN, A_MC, B_MC, EPI>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, PSMEM));
       pattr_done = true;
     }
     int G = total < num_cu ? total : num_cu;
     G = (G + 7) & ~7;  // the XCD permutation needs a multiple of 8 (idle blocks exit at once)
-    hipLaunchKernelGGL((gemm_persist_kernel<WM, WN, A_MC, B_MC, EPI>), dim3(G), dim3(WM * WN * 64), SMEM, st, g, total);
+    hipLaunchKernelGGL((gemm_persist_kernel<BM, BN, 64, WM, WN, A_MC, B_MC, EPI>), dim3(G), dim3(WM * WN * 64), PSMEM, st, g, total);
     GGET_LAUNCH_CHECK();
     return 0;
   }

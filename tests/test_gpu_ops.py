@@ -35,7 +35,8 @@ def rnd(*shape, scale=1.0, seed=0):
 # ------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("mode", [L.GEMM_NT, L.GEMM_NN, L.GEMM_TN])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (200, 136, 72), (1000, 756, 128), (64, 2304, 768),
-                                   (333, 768, 3072), (4096, 2304, 128), (2048, 768, 512)])
+                                   (333, 768, 3072), (4096, 2304, 128), (2048, 768, 512),
+                                   (4096, 4096, 192), (8192, 2304, 64)])  # the last two take the 256x256x32 tile
 def test_gemm_modes(lib, mode, M, N, K):
     # asymmetric operands (catches transposed outputs); sizes include ragged M/N/K tails
     if mode == L.GEMM_NT:

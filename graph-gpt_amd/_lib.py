@@ -60,8 +60,9 @@ SIGNATURES = {
     "gget_op_embed_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "gget_op_embed_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "gget_op_rope": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "gget_op_attn_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
-    "gget_op_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "gget_op_attn_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, f32, C.c_uint32, vp]),
+    "gget_op_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, f32, C.c_uint32, vp]),
+    "gget_set_attention_dropout": (i32, [vp, f32, C.c_uint32]),
     "gget_op_geglu_fwd": (i32, [vp, vp, i32, i32, vp]),
     "gget_op_geglu_bwd": (i32, [vp, vp, vp, i32, i32, vp]),
     "gget_op_ce_fwd_bwd": (i32, [vp, i32, vp, vp, vp, i32, i32, vp, vp, f32, i32, vp]),

@@ -100,6 +100,22 @@ __device__ __forceinline__ bf16x8_t frag_global(const bf16_t* __restrict__ base,
   if (row < row_lim) v = *reinterpret_cast<const uint4*>(base + (size_t)row * pitch + 16 * s + (lane >> 5) * 8);
   return __builtin_bit_cast(bf16x8_t, v);
 }
+// Attention dropout (hf eager_attention_forward :210: dropout on the softmax output, training only; every reference
+// launch script sets attention_dropout=0.1).  Counter-based: the keep decision of element (batch*head, query, key) is a
+// hash of (seed, coordinates), so forward and the two backward kernels regenerate the same mask without storing it.
+struct Drop {
+  unsigned thresh;   // drop when hash24 < thresh  (thresh = p * 2^24); 0 => no dropout
+  float inv_keep;    // 1 / (1 - p)
+  unsigned seed;
+};
+__device__ __forceinline__ float drop_mul(const Drop& D, unsigned bh, unsigned q, unsigned k) {
+  if (D.thresh == 0) return 1.f;
+  unsigned x = D.seed ^ (bh * 0x9E3779B1u);
+  x += q * 0x85EBCA77u + k * 0xC2B2AE3Du;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return (x >> 8) < D.thresh ? 0.f : D.inv_keep;
+}
+
 // the 4 dh-fragments of one row (dh chunk [16s + 8hi, +8), s = 0..3), rotated: chunks s and s+2 are 32 channels apart
 __device__ __forceinline__ void frags_global_rope(bf16x8_t (&f)[4], const bf16_t* __restrict__ base, int row, int row_lim,
                                                   size_t pitch, int lane, const Rope& R, int b) {
@@ -183,7 +199,7 @@ __device__ __forceinline__ void unrope_acc(f32x16_t& a0, f32x16_t& a1, const Rop
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
                                                       bf16_t* __restrict__ out, float* __restrict__ lse, int B, int S,
-                                                      int H, int causal, Rope R) {
+                                                      int H, int causal, Rope R, Drop D) {
   __shared__ __attribute__((aligned(16))) unsigned char vt[4096];
   const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
@@ -224,8 +240,8 @@ __global__ void __launch_bounds__(64) attn_fwd_kernel(const bf16_t* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float p = dead ? 0.f : __expf(sc[r] - m_new);
-      sc[r] = p;
-      rs += p;
+      rs += p;                                                                    // softmax normaliser: before dropout
+      sc[r] = p * drop_mul(D, b * H + h, qrow, k0 + acc_row(r, hi));              // what multiplies V
     }
     rs += __shfl_xor(rs, 32, 64);
     l = l * alpha + rs;
@@ -240,7 +256,7 @@ __global__ void __launch_bounds__(64) attn_fwd_kernel(const bf16_t* __restrict__
     o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 1, lane), pb1, o1, 0, 0, 0);
   }
   if (qrow < S) {
-    const float inv = l > 0.f ? 1.f / l : 0.f;
+    const float inv = l > 0.f ? 1.f / l : 0.f;   // (the keep scale 1/(1-p) is already folded into the dropped P)
     store_t(out + ((size_t)b * S + qrow) * d + h * 64, o0, o1, inv, hi);
     if (hi == 0 && lse) lse[((size_t)b * H + h) * S + qrow] = l > 0.f ? m + __logf(l) : 0.f;
   }
@@ -276,7 +292,7 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restric
 __global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
                                                          const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
-                                                         int B, int S, int H, int causal, Rope R) {
+                                                         int B, int S, int H, int causal, Rope R, Drop D) {
   __shared__ __attribute__((aligned(16))) unsigned char kt[4096];
   const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
@@ -314,7 +330,7 @@ __global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const bf16_t* __restric
       const int key = k0 + acc_row(r, hi);
       const bool ok = key < klen && (!causal || key <= qrow) && qrow < S;
       const float p = ok ? __expf(sc[r] * kScale - lse_q) : 0.f;
-      sc[r] = p * (dp[r] - dl_q) * kScale;
+      sc[r] = p * (dp[r] * drop_mul(D, b * H + h, qrow, key) - dl_q) * kScale;
     }
     const bf16x8_t ds0 = acc_to_b(sc, 0), ds1 = acc_to_b(sc, 1);
     a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 0, lane), ds0, a0, 0, 0, 0);
@@ -332,7 +348,7 @@ __global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const bf16_t* __restric
 __global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
-                                                          int B, int S, int H, int causal, Rope R) {
+                                                          int B, int S, int H, int causal, Rope R, Drop D) {
   __shared__ __attribute__((aligned(16))) unsigned char qt[4096];
   __shared__ __attribute__((aligned(16))) unsigned char dot_[4096];
   __shared__ float lse_s[32], dl_s[32];
@@ -376,8 +392,9 @@ __global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const bf16_t* __restri
         const int q = q0 + qi;
         const bool ok = key_ok && q < S && (!causal || krow <= q);
         const float p = ok ? __expf(sc[r] * kScale - lse_s[qi]) : 0.f;
-        sc[r] = p;
-        dp[r] = p * (dp[r] - dl_s[qi]) * kScale;
+        const float dm = drop_mul(D, b * H + h, q, krow);
+        sc[r] = p * dm;                                  // dropped probabilities: what multiplied V in forward
+        dp[r] = p * (dp[r] * dm - dl_s[qi]) * kScale;
       }
       const bf16x8_t p0 = acc_to_b(sc, 0), p1 = acc_to_b(sc, 1);
       const bf16x8_t s0 = acc_to_b(dp, 0), s1 = acc_to_b(dp, 1);
@@ -399,24 +416,35 @@ __global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const bf16_t* __restri
   }
 }
 
+Drop make_drop(float p, unsigned seed) {
+  Drop d;
+  d.thresh = p > 0.f ? (unsigned)(p * 16777216.0f) : 0u;
+  d.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  d.seed = seed;
+  return d;
+}
+
 }  // namespace
 
 int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
-               const float* cos_tab, const float* sin_tab, const int64_t* position_ids, hipStream_t st) {
+               const float* cos_tab, const float* sin_tab, const int64_t* position_ids, float dropout_p,
+               unsigned dropout_seed, hipStream_t st) {
   if (B == 0 || S == 0) return 0;
   dim3 grid((S + 31) / 32, H, B);
   const Rope R{cos_tab, sin_tab, position_ids, S};
+  const Drop D = make_drop(dropout_p, dropout_seed);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, key_len, (bf16_t*)out, lse, B, S, H,
-                     causal, R);
+                     causal, R, D);
   GGET_LAUNCH_CHECK();
   return 0;
 }
 
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
-               const int64_t* position_ids, hipStream_t st) {
+               const int64_t* position_ids, float dropout_p, unsigned dropout_seed, hipStream_t st) {
   if (B == 0 || S == 0) return 0;
   const Rope R{cos_tab, sin_tab, position_ids, S};
+  const Drop D = make_drop(dropout_p, dropout_seed);
   const long work = (long)B * S * H * 8;
   int g = (int)((work + 255) / 256);
   if (g > 4096) g = 4096;
@@ -424,9 +452,9 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
                      H);
   dim3 grid((S + 31) / 32, H, B);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta_ws,
-                     key_len, (bf16_t*)dqkv, B, S, H, causal, R);
+                     key_len, (bf16_t*)dqkv, B, S, H, causal, R, D);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta_ws,
-                     key_len, (bf16_t*)dqkv, B, S, H, causal, R);
+                     key_len, (bf16_t*)dqkv, B, S, H, causal, R, D);
   GGET_LAUNCH_CHECK();
   return 0;
 }

@@ -263,6 +263,8 @@ struct gget_engine {
   bool have_labels = false;
   int problem = 0;
   bool fwd_valid = false;
+  float attn_drop_p = 0.f;        // attention dropout of the NEXT forward (training mode); 0 = off
+  unsigned attn_drop_seed = 0;
   bf16_t* dx_cur = nullptr;  // gradient w.r.t. the residual stream entering the next backward stage
 
   template <typename Tp>
@@ -380,6 +382,14 @@ extern "C" int gget_bucket_range(gget_handle_t h, int bucket, uint64_t* offset, 
   return 0;
 }
 
+extern "C" int gget_set_attention_dropout(gget_handle_t h, float p, uint32_t seed) {
+  GGET_REQUIRE(h, "null handle");
+  GGET_REQUIRE(p >= 0.f && p < 1.f, "dropout probability %f out of range", (double)p);
+  h->attn_drop_p = p;
+  h->attn_drop_seed = seed;
+  return 0;
+}
+
 extern "C" int gget_sync_params(gget_handle_t h, void* stream) {
   GGET_REQUIRE(h && h->master, "sync_params needs the fp32 master arena");
   return k_f32_to_bf16(h->master, h->P, h->plan.n_params, (hipStream_t)stream);
@@ -454,7 +464,7 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
   if (int e = gemm_nt(xn1, h->P + lo.wqkv, qkv, nullptr, T, 3 * d, d, d, d, 3 * d, nullptr, st)) return e;
   // RoPE is fused into the attention kernels' operand loads (qkv stays un-rotated in HBM)
   if (int e = k_attn_fwd(qkv, h->wsp<int32_t>(h->ws.key_len), attn, h->wsp<float>(lw.lse), h->B, h->S, H, c.causal,
-                         h->cos_tab, h->sin_tab, h->pos, st))
+                         h->cos_tab, h->sin_tab, h->pos, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st))
     return e;
   if (h->plan.has_ls) {
     bf16_t* araw = h->wsp<bf16_t>(lw.araw);
@@ -646,7 +656,7 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   if (int e = gemm_nn(dy_o, h->P + lo.wo, dattn, T, d, d, d, d, d, nullptr, st)) return e;
   if (int e = k_attn_bwd(h->wsp<bf16_t>(lw.qkv), h->wsp<bf16_t>(lw.attn), dattn, h->wsp<float>(lw.lse),
                          h->wsp<int32_t>(w.key_len), dqkv, h->wsp<float>(w.delta), h->B, h->S, H, c.causal, h->cos_tab,
-                         h->sin_tab, h->pos, st))
+                         h->sin_tab, h->pos, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st))
     return e;
   if (int e = gemm_nn(dqkv, h->P + lo.wqkv, dxn, T, d, 3 * d, 3 * d, d, d, nullptr, st)) return e;
   if (int e = k_rmsnorm_bwd(dxn, x_in, h->P + lo.ln1, h->wsp<float>(lw.rstd1), dx_mid, dx_in, s32 + lo.ln1_32, T, d, st))
@@ -820,14 +830,17 @@ extern "C" int gget_op_rope(void* qkv, const float* cos_tab, const float* sin_ta
   return k_rope(qkv, cos_tab, sin_tab, position_ids, B * S, S, H, inverse, (hipStream_t)stream);
 }
 extern "C" int gget_op_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
-                                const float* cos_tab, const float* sin_tab, const int64_t* position_ids, void* stream) {
-  return k_attn_fwd(qkv, key_len, out, lse, B, S, H, causal, cos_tab, sin_tab, position_ids, (hipStream_t)stream);
+                                const float* cos_tab, const float* sin_tab, const int64_t* position_ids, float dropout_p,
+                                uint32_t dropout_seed, void* stream) {
+  return k_attn_fwd(qkv, key_len, out, lse, B, S, H, causal, cos_tab, sin_tab, position_ids, dropout_p, dropout_seed,
+                    (hipStream_t)stream);
 }
 extern "C" int gget_op_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len,
                                 void* dqkv, float* delta_ws, int B, int S, int H, int causal, const float* cos_tab,
-                                const float* sin_tab, const int64_t* position_ids, void* stream) {
+                                const float* sin_tab, const int64_t* position_ids, float dropout_p, uint32_t dropout_seed,
+                                void* stream) {
   return k_attn_bwd(qkv, out, dout, lse, key_len, dqkv, delta_ws, B, S, H, causal, cos_tab, sin_tab, position_ids,
-                    (hipStream_t)stream);
+                    dropout_p, dropout_seed, (hipStream_t)stream);
 }
 extern "C" int gget_op_geglu_fwd(const void* gu, void* h, int T, int ff, void* stream) {
   return k_geglu_fwd(gu, h, T, ff, (hipStream_t)stream);

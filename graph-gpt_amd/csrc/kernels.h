@@ -50,7 +50,8 @@ int k_convert_segments(const float* scratch, void* grads, const GgetSegment* seg
 // attention.hip
 // cos_tab/sin_tab ([max_pos][32] fp32) non-null => RoPE is applied to q,k on load and undone on dq,dk (qkv stays un-rotated)
 int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
-               const float* cos_tab, const float* sin_tab, const int64_t* position_ids, hipStream_t st);
+               const float* cos_tab, const float* sin_tab, const int64_t* position_ids, float dropout_p,
+               unsigned dropout_seed, hipStream_t st);
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
-               const int64_t* position_ids, hipStream_t st);
+               const int64_t* position_ids, float dropout_p, unsigned dropout_seed, hipStream_t st);

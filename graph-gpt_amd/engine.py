@@ -170,6 +170,10 @@ class Engine:
                                            _ptr(self._loss), _ptr(logits), _ptr(hid), _stream()))
         return (self._loss[0] if y is not None else None), logits, hid
 
+    def set_attention_dropout(self, p: float, seed: int = 0):
+        """Dropout on the attention probabilities for the NEXT forward/backward (training mode); 0 disables it."""
+        L.check(self.lib.gget_set_attention_dropout(self.h, float(p), int(seed) & 0xFFFFFFFF))
+
     def backward(self):
         L.check(self.lib.gget_backward(self.h, 1.0, _stream()))
 

@@ -78,6 +78,8 @@ class GraphGPTConfig:
         need(not self.smtp_inside, "in-model SMTP masking (next item N1)")
         need(len(self.mlp) == 0, "MLP score head")
         need(self.pooling_method == "last", "pooling other than 'last'")
+        need(self.path_pdrop == 0 and self.mlp_pdrop == 0 and self.embed_pdrop == 0 and self.dropout == 0,
+             "DropPath / MLP / embedding dropout (statistical-parity items of a later round; attention dropout IS supported)")
         return ModelSpec(kind=kind, vocab_size=self.vocab_size, hidden_size=self.hidden_size,
                          intermediate_size=self.intermediate_size, num_layers=self.num_hidden_layers,
                          num_heads=self.num_attention_heads, head_dim=64, stacked_feat=self.stacked_feat,
@@ -171,6 +173,7 @@ class _GgetModel(nn.Module):
         self.num_labels = config.num_labels
         self._engine: Optional[Engine] = None
         self._anchor = None
+        self.dropout_seed, self._drop_step = seed, 0
         self.materialize_grads = True   # fill nn.Parameter.grad (fp32) after backward, like autograd would
         self._dirty = False             # master weights changed behind the engine's back (external optimizer)
         state = make_state_dict(self.spec, seed=seed, std=config.initializer_range)
@@ -255,6 +258,16 @@ class _GgetModel(nn.Module):
         if self._dirty:
             e.sync_params()
             self._dirty = False
+        # attention dropout exactly when the reference applies it: module in training mode and attention_dropout > 0
+        # (hf eager_attention_forward :210).  A fresh mask every step, different on every rank.
+        p = float(self.config.attention_dropout) if self.training else 0.0
+        if p > 0:
+            self._drop_step += 1
+            rank = int(os.environ.get("RANK", "0"))
+            seed = (self.dropout_seed * 0x9E3779B1 + self._drop_step * 0x85EBCA6B + rank * 0xC2B2AE35) & 0xFFFFFFFF
+            e.set_attention_dropout(p, seed)
+        else:
+            e.set_attention_dropout(0.0, 0)
         return e
 
     def _autograd_backward(self, g):

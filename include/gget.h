@@ -107,6 +107,11 @@ int gget_param_info(gget_handle_t h, int index, gget_param_info_t* out);
 int gget_bucket_count(gget_handle_t h);
 int gget_bucket_range(gget_handle_t h, int bucket, uint64_t* offset, uint64_t* count);
 
+/* replaces: `attention_dropout` of the config + model.train()/eval() (reference launch scripts set 0.1, e.g.
+ * examples/graph_lvl/pcqm4m_v2_pretrain.sh:20): dropout probability and RNG seed used by the NEXT forward and its
+ * backward; p = 0 (default) is evaluation behaviour. */
+int gget_set_attention_dropout(gget_handle_t h, float p, uint32_t seed);
+
 /* replaces: load_state_dict + `.to(bfloat16)`: refresh the bf16 compute copy from the fp32 master. */
 int gget_sync_params(gget_handle_t h, void* stream);
 
@@ -179,12 +184,16 @@ int gget_op_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const
 int gget_op_rope(void* qkv, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, int B, int S,
                  int H, int inverse, void* stream);
 /* cos_tab/sin_tab ([max_pos][32] fp32, hf LlamaRotaryEmbedding tables) non-NULL: RoPE (hf apply_rotary_pos_emb
- * :138-160) is applied to q,k inside the kernels and undone on dq,dk; qkv / dqkv are the UN-rotated projections. */
+ * :138-160) is applied to q,k inside the kernels and undone on dq,dk; qkv / dqkv are the UN-rotated projections.
+ * dropout_p > 0: attention dropout on the softmax output (hf eager_attention_forward :210), counter-based mask
+ * keyed by (dropout_seed, batch*head, query, key) - see drop_mul() in csrc/attention.hip. */
 int gget_op_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H,
-                     int causal, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, void* stream);
+                     int causal, const float* cos_tab, const float* sin_tab, const int64_t* position_ids,
+                     float dropout_p, uint32_t dropout_seed, void* stream);
 int gget_op_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len,
                      void* dqkv, float* delta_ws, int B, int S, int H, int causal, const float* cos_tab,
-                     const float* sin_tab, const int64_t* position_ids, void* stream);
+                     const float* sin_tab, const int64_t* position_ids, float dropout_p, uint32_t dropout_seed,
+                     void* stream);
 int gget_op_geglu_fwd(const void* gu, void* h, int T, int ff, void* stream);
 int gget_op_geglu_bwd(const void* gu, const void* dh, void* dgu, int T, int ff, void* stream);
 int gget_op_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const float* row_wgt, const int32_t* n_rows_dev,

@@ -222,7 +222,7 @@ def test_attention_fwd_bwd(lib, B, S, H, causal, rope):
         pos = pos.cuda()
     out = torch.zeros(B * S, d, dtype=torch.bfloat16, device="cuda")
     lse = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
-    L.check(lib.gget_op_attn_fwd(P(qkv), P(lens), P(out), P(lse), B, S, H, causal, P(cos), P(sin), P(pos), ST()))
+    L.check(lib.gget_op_attn_fwd(P(qkv), P(lens), P(out), P(lse), B, S, H, causal, P(cos), P(sin), P(pos), 0.0, 0, ST()))
     qf = qkv.float().requires_grad_(True)
     x = qf.view(B, S, 3, H, 64)
     if rope:
@@ -242,12 +242,62 @@ def test_attention_fwd_bwd(lib, B, S, H, causal, rope):
     dqkv = torch.zeros(B * S, 3 * d, dtype=torch.bfloat16, device="cuda")
     delta = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
     L.check(lib.gget_op_attn_bwd(P(qkv), P(out), P(dout), P(lse), P(lens), P(dqkv), P(delta), B, S, H, causal, P(cos),
-                                 P(sin), P(pos), ST()))
+                                 P(sin), P(pos), 0.0, 0, ST()))
     g = dqkv.float().view(B, S, 3, d)
     w = qf.grad.view(B, S, 3, d)
     for i, nm in enumerate("qkv"):
         e = rel_l2(g[:, :, i].cpu().numpy(), w[:, :, i].cpu().numpy())
         assert e < 2e-2, f"attn bwd d{nm} rel-L2 {e}"
+
+
+def _drop_mask(seed, B, H, S, p):
+    """Python twin of drop_mul() in csrc/attention.hip: keep-multiplier [B,H,S(query),S(key)] of the counter-based mask."""
+    bh = np.arange(B * H, dtype=np.uint64)[:, None, None]
+    q = np.arange(S, dtype=np.uint64)[None, :, None]
+    k = np.arange(S, dtype=np.uint64)[None, None, :]
+    M32 = np.uint64(0xFFFFFFFF)
+    x = (np.uint64(seed) ^ ((bh * np.uint64(0x9E3779B1)) & M32)) & M32
+    x = (x + q * np.uint64(0x85EBCA77) + k * np.uint64(0xC2B2AE3D)) & M32
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & M32
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & M32
+    x ^= x >> np.uint64(16)
+    thresh = np.uint64(int(np.float32(p) * np.float32(16777216.0)))
+    keep = (x >> np.uint64(8)) >= thresh
+    return torch.from_numpy((keep.astype(np.float32) / (1.0 - p)).reshape(B, H, S, S))
+
+
+def test_attention_dropout(lib):
+    """Dropout on the softmax output (hf eager_attention_forward :210): the kernels regenerate the same counter-based
+    mask in forward, dQ and dK/dV; checked against autograd with the identical mask, and the drop rate is ~p."""
+    B, S, H, p, seed = 2, 72, 3, 0.1, 12345
+    d = H * 64
+    qkv = rnd(B * S, 3 * d, seed=17)
+    lens = torch.tensor([S, 50], dtype=torch.int32).cuda()
+    mask = _drop_mask(seed, B, H, S, p).cuda()
+    assert abs(float((mask == 0).float().mean()) - p) < 0.01
+    out = torch.zeros(B * S, d, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_attn_fwd(P(qkv), P(lens), P(out), P(lse), B, S, H, 0, None, None, None, p, seed, ST()))
+    qf = qkv.float().requires_grad_(True)
+    x = qf.view(B, S, 3, H, 64)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    w = q @ k.transpose(2, 3) * 0.125
+    keym = torch.arange(S, device="cuda")[None, :] >= lens[:, None]
+    w = w.masked_fill(keym[:, None, None, :], float("-inf"))
+    ref = ((torch.softmax(w, -1) * mask) @ v).transpose(1, 2).reshape(B, S, d)
+    valid = ~keym
+    got = out.float().view(B, S, d)
+    assert rel_l2(got[valid].cpu().numpy(), ref.detach()[valid].cpu().numpy()) < 8e-3
+    dout = (rnd(B * S, d, seed=18).view(B, S, d) * valid[:, :, None]).reshape(B * S, d).contiguous()
+    (ref * dout.float().view(B, S, d)).sum().backward()
+    dqkv = torch.zeros(B * S, 3 * d, dtype=torch.bfloat16, device="cuda")
+    delta = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_attn_bwd(P(qkv), P(out), P(dout), P(lse), P(lens), P(dqkv), P(delta), B, S, H, 0, None, None,
+                                 None, p, seed, ST()))
+    g, wg = dqkv.float().view(B, S, 3, d), qf.grad.view(B, S, 3, d)
+    for i, nm in enumerate("qkv"):
+        e = rel_l2(g[:, :, i].cpu().numpy(), wg[:, :, i].cpu().numpy())
+        assert e < 2e-2, f"dropout attn bwd d{nm} rel-L2 {e}"
 
 
 # ------------------------------------------------------------------------------------------ GEGLU / CE

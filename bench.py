@@ -124,7 +124,8 @@ def main():
     sz = spec_mod.MODEL_SIZES[size]
     cfg = modeling.GraphGPTConfig(vocab_size=V, hidden_size=sz["hidden_size"], intermediate_size=4 * sz["hidden_size"],
                                   num_hidden_layers=sz["num_layers"], num_attention_heads=sz["hidden_size"] // 64,
-                                  max_position_embeddings=1024, causal_attention=False, stacked_feat=F, next_n_token=F)
+                                  max_position_embeddings=1024, causal_attention=False, stacked_feat=F, next_n_token=F,
+                                  attention_dropout=0.1)   # every reference pre-train script trains with 0.1
     model = modeling.GraphGPTPretrainBase(cfg, seed=0)   # same random-init weights on every rank (DP replicas)
     spec = model.spec
     model._ensure_engine(B, S)
@@ -175,7 +176,7 @@ def main():
             "config": {"workload": a.workload, "model": f"{size} d{spec.hidden_size}/L{spec.num_layers}/H{spec.num_heads} "
                        f"({spec.num_params() / 1e6:.1f}M params)", "per_gpu_batch": B, "global_batch": B * world,
                        "seq_len": S, "stacked_feat": F, "vocab": V, "parallelism": f"dp{world}",
-                       "step": "fwd+bwd+allreduce+clip+AdamW", "attention_dropout": 0.0},
+                       "step": "fwd+bwd+allreduce+clip+AdamW", "attention_dropout": cfg.attention_dropout},
             "smtp_loss": mean_loss,
             "padded_tokens_per_s": B * S * world * a.steps / dt,
             "tokens_per_s_per_gpu": tot_real * a.steps / dt / world,

@@ -15,7 +15,8 @@ class GgetConfig(C.Structure):
     _fields_ = [(n, i32) for n in ("kind", "vocab_size", "hidden_size", "intermediate_size", "num_layers", "num_heads",
                                    "stacked_feat", "next_n_token", "gated_agg", "causal", "max_position", "num_labels",
                                    "score_bias", "pad_token_id")] + \
-               [("rms_eps", f32), ("rope_theta", f32), ("layer_scale_init", f32), ("max_tokens", i32), ("max_batch", i32)]
+               [("rms_eps", f32), ("rope_theta", f32), ("layer_scale_init", f32), ("max_tokens", i32), ("max_batch", i32),
+                ("path_pdrop", f32)]
 
 
 class GgetSizes(C.Structure):
@@ -62,7 +63,7 @@ SIGNATURES = {
     "gget_op_rope": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "gget_op_attn_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, f32, C.c_uint32, vp]),
     "gget_op_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, f32, C.c_uint32, vp]),
-    "gget_set_attention_dropout": (i32, [vp, f32, C.c_uint32]),
+    "gget_set_dropout": (i32, [vp, f32, f32, C.c_uint32]),
     "gget_op_geglu_fwd": (i32, [vp, vp, i32, i32, vp]),
     "gget_op_geglu_bwd": (i32, [vp, vp, vp, i32, i32, vp]),
     "gget_op_ce_fwd_bwd": (i32, [vp, i32, vp, vp, vp, i32, i32, vp, vp, f32, i32, vp]),

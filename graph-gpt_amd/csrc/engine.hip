@@ -26,7 +26,9 @@ void gget_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* gget_last_error(void) { return g_err; }
-extern "C" int gget_version(void) { return 100; }
+extern "C" int gget_version(void) { return 101; }
+
+struct PathDropArg { float rate; unsigned seed; int S; };
 
 namespace {
 
@@ -58,6 +60,7 @@ struct Plan {
   uint64_t emb = 0, emb32 = 0, gate = 0, gate32 = 0, normf = 0, normf32 = 0;
   uint64_t ntp = 0, lm = 0, lm32 = 0, score = 0, score32 = 0, sbias = 0, sbias32 = 0;
   bool has_gate = false, has_ntp = false, has_ls = false;
+  bool has_res = false;  // residual adds run as their own kernels (LayerScale and/or DropPath) instead of GEMM epilogues
 };
 
 void add_param(Plan& pl, const std::string& name, int64_t r, int64_t c, int layer, bool accum32, uint64_t* off_out,
@@ -88,6 +91,7 @@ Plan make_plan(const gget_config_t& c) {
   const int64_t d = c.hidden_size, ff = c.intermediate_size, V = c.vocab_size, F = c.stacked_feat, L = c.num_layers;
   pl.has_gate = c.gated_agg != 0;
   pl.has_ls = c.layer_scale_init > 0.f;
+  pl.has_res = pl.has_ls || c.path_pdrop > 0.f;
   pl.has_ntp = c.kind == GGET_KIND_PRETRAIN && c.next_n_token > 1;
   add_param(pl, "model.embed_tokens.weight", V, d, -1, true, &pl.emb, &pl.emb32);
   if (pl.has_gate) add_param(pl, "stacked_feat_agg.weight", F, d, -1, true, &pl.gate, &pl.gate32);
@@ -165,13 +169,13 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
     l.qkv = b.take(T * 3 * d * 2);
     l.lse = b.take(T * H * 4);
     l.attn = b.take(T * d * 2);
-    l.araw = pl.has_ls ? b.take(T * d * 2) : 0;
+    l.araw = pl.has_res ? b.take(T * d * 2) : 0;
     l.xmid = b.take(T * d * 2);
     l.rstd2 = b.take(T * 4);
     l.xn2 = b.take(T * d * 2);
     l.gu = b.take(T * 2 * ff * 2);
     l.h = b.take(T * ff * 2);
-    l.mraw = pl.has_ls ? b.take(T * d * 2) : 0;
+    l.mraw = pl.has_res ? b.take(T * d * 2) : 0;
   }
   w.rstd_f = b.take(T * 4);
   w.hidden = b.take(T * d * 2);
@@ -184,7 +188,7 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.dgu = b.take(T * 2 * ff * 2);
   w.dh = b.take(T * ff * 2);
   w.delta = b.take(T * H * 4);
-  w.dscaled = pl.has_ls ? b.take(T * d * 2) : 0;
+  w.dscaled = pl.has_res ? b.take(T * d * 2) : 0;
   w.scratch32 = b.take(pl.n_scratch32 * 4);
   w.loss_sum = b.take(256);
   w.sqnorm = b.take(256);
@@ -264,7 +268,13 @@ struct gget_engine {
   int problem = 0;
   bool fwd_valid = false;
   float attn_drop_p = 0.f;        // attention dropout of the NEXT forward (training mode); 0 = off
+  float path_drop_p = 0.f;        // stochastic-depth rate of the last layer (layer l: p*l/(L-1))
   unsigned attn_drop_seed = 0;
+  PathDropArg path_drop(int layer, int which) const {
+    const int L = cfg.num_layers;
+    const float rate = (path_drop_p > 0.f && L > 1) ? path_drop_p * (float)layer / (float)(L - 1) : 0.f;
+    return PathDropArg{rate, attn_drop_seed ^ (0xD6E8FEB8u * (unsigned)(layer * 2 + which + 1)), S};
+  }
   bf16_t* dx_cur = nullptr;  // gradient w.r.t. the residual stream entering the next backward stage
 
   template <typename Tp>
@@ -382,10 +392,12 @@ extern "C" int gget_bucket_range(gget_handle_t h, int bucket, uint64_t* offset, 
   return 0;
 }
 
-extern "C" int gget_set_attention_dropout(gget_handle_t h, float p, uint32_t seed) {
+extern "C" int gget_set_dropout(gget_handle_t h, float attention_p, float path_p, uint32_t seed) {
   GGET_REQUIRE(h, "null handle");
-  GGET_REQUIRE(p >= 0.f && p < 1.f, "dropout probability %f out of range", (double)p);
-  h->attn_drop_p = p;
+  GGET_REQUIRE(attention_p >= 0.f && attention_p < 1.f && path_p >= 0.f && path_p < 1.f, "dropout probability out of range");
+  GGET_REQUIRE(path_p == 0.f || h->plan.has_res, "path dropout needs a handle created with config.path_pdrop > 0");
+  h->attn_drop_p = attention_p;
+  h->path_drop_p = path_p;
   h->attn_drop_seed = seed;
   return 0;
 }
@@ -410,40 +422,55 @@ int gemm_nn(const void* A, const void* Bw, void* C, int M, int N, int K, int lda
   return gget_gemm_single(GGET_GEMM_NN, GGET_EPI_NONE, A, Bw, C, nullptr, M, N, K, lda, ldb, ldc, m_dev, nullptr, 1, st);
 }
 
-// out = res + lam * y   (LayerScale residual, utils_graphgpt.py:153-166) ; bwd: dscaled = lam*dy, dlam += sum_t dy*y
+// Residual add as its own kernel: out = res + keep_b * (lam * y)
+//   lam  : LayerScale vector (utils_graphgpt.py:153-166) or nullptr (= 1)
+//   keep_b: DropPath / stochastic depth per SAMPLE (utils_graphgpt.py:64-66 = transformers BeitDropPath): 0 with
+//           probability `rate`, else 1/(1-rate); counter-based so backward regenerates it.
+typedef PathDropArg PathDrop;
+__device__ __forceinline__ float path_keep(const PathDrop& D, long t) {
+  if (D.rate <= 0.f) return 1.f;
+  unsigned x = D.seed + (unsigned)(t / D.S) * 0x85EBCA77u;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return (float)(x >> 8) * (1.0f / 16777216.0f) < D.rate ? 0.f : 1.0f / (1.0f - D.rate);
+}
 __global__ void __launch_bounds__(256) ls_fwd_kernel(const bf16_t* __restrict__ res, const bf16_t* __restrict__ y,
-                                                     const bf16_t* __restrict__ lam, bf16_t* __restrict__ out, long T, int d) {
+                                                     const bf16_t* __restrict__ lam, bf16_t* __restrict__ out, long T, int d,
+                                                     PathDrop D) {
   const int cpr = d >> 3;
   const long total = T * cpr;
   for (long w = (long)blockIdx.x * 256 + threadIdx.x; w < total; w += (long)gridDim.x * 256) {
     const int c = (int)(w % cpr);
-    float r[8], v[8], l[8];
+    const float keep = path_keep(D, w / cpr);
+    float r[8], v[8], l[8] = {1, 1, 1, 1, 1, 1, 1, 1};
     unpack8(*reinterpret_cast<const uint4*>(res + w * 8), r);
     unpack8(*reinterpret_cast<const uint4*>(y + w * 8), v);
-    unpack8(*reinterpret_cast<const uint4*>(lam + c * 8), l);
+    if (lam) unpack8(*reinterpret_cast<const uint4*>(lam + c * 8), l);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] += bf2f(f2bf(l[e] * v[e]));
+    for (int e = 0; e < 8; ++e) r[e] += keep * bf2f(f2bf(l[e] * v[e]));
     *reinterpret_cast<uint4*>(out + w * 8) = pack8(r);
   }
 }
 __global__ void __launch_bounds__(256) ls_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
                                                      const bf16_t* __restrict__ lam, bf16_t* __restrict__ dscaled,
-                                                     float* __restrict__ dlam, int T, int d) {
+                                                     float* __restrict__ dlam, int T, int d, PathDrop D) {
   // one thread per 8 channels, rows strided over blockIdx.y
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c * 8 >= d) return;
-  float l[8], acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unpack8(*reinterpret_cast<const uint4*>(lam + c * 8), l);
+  float l[8] = {1, 1, 1, 1, 1, 1, 1, 1}, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (lam) unpack8(*reinterpret_cast<const uint4*>(lam + c * 8), l);
   for (int t = blockIdx.y; t < T; t += gridDim.y) {
+    const float keep = path_keep(D, t);
     float g[8], v[8], o[8];
     unpack8(*reinterpret_cast<const uint4*>(dy + (size_t)t * d + c * 8), g);
     unpack8(*reinterpret_cast<const uint4*>(y + (size_t)t * d + c * 8), v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { o[e] = l[e] * g[e]; acc[e] += g[e] * v[e]; }
+    for (int e = 0; e < 8; ++e) { o[e] = l[e] * keep * g[e]; acc[e] += keep * g[e] * v[e]; }
     *reinterpret_cast<uint4*>(dscaled + (size_t)t * d + c * 8) = pack8(o);
   }
+  if (dlam) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dlam + c * 8 + e, acc[e]);
+    for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dlam + c * 8 + e, acc[e]);
+  }
 }
 
 int layer_forward(gget_engine* h, int i, hipStream_t st) {
@@ -466,17 +493,20 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
   if (int e = k_attn_fwd(qkv, h->wsp<int32_t>(h->ws.key_len), attn, h->wsp<float>(lw.lse), h->B, h->S, H, c.causal,
                          h->cos_tab, h->sin_tab, h->pos, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st))
     return e;
-  if (h->plan.has_ls) {
+  if (h->plan.has_res) {
     bf16_t* araw = h->wsp<bf16_t>(lw.araw);
     bf16_t* mraw = h->wsp<bf16_t>(lw.mraw);
+    const bf16_t* lam1 = h->plan.has_ls ? h->P + lo.lam1 : nullptr;
+    const bf16_t* lam2 = h->plan.has_ls ? h->P + lo.lam2 : nullptr;
+    const PathDrop pd1 = h->path_drop(i, 0), pd2 = h->path_drop(i, 1);
     const int g = (int)std::min<long>(4096, ((long)T * (d / 8) + 255) / 256);
     if (int e = gemm_nt(attn, h->P + lo.wo, araw, nullptr, T, d, d, d, d, d, nullptr, st)) return e;
-    hipLaunchKernelGGL(ls_fwd_kernel, dim3(g), dim3(256), 0, st, x_in, araw, h->P + lo.lam1, xmid, (long)T, d);
+    hipLaunchKernelGGL(ls_fwd_kernel, dim3(g), dim3(256), 0, st, x_in, araw, lam1, xmid, (long)T, d, pd1);
     if (int e = k_rmsnorm_fwd(xmid, h->P + lo.ln2, xn2, h->wsp<float>(lw.rstd2), T, d, c.rms_eps, st)) return e;
     if (int e = gemm_nt(xn2, h->P + lo.wgu, gu, nullptr, T, 2 * ff, d, d, d, 2 * ff, nullptr, st)) return e;
     if (int e = k_geglu_fwd(gu, hh, T, ff, st)) return e;
     if (int e = gemm_nt(hh, h->P + lo.wdown, mraw, nullptr, T, d, ff, ff, ff, d, nullptr, st)) return e;
-    hipLaunchKernelGGL(ls_fwd_kernel, dim3(g), dim3(256), 0, st, xmid, mraw, h->P + lo.lam2, x_out, (long)T, d);
+    hipLaunchKernelGGL(ls_fwd_kernel, dim3(g), dim3(256), 0, st, xmid, mraw, lam2, x_out, (long)T, d, pd2);
     GGET_LAUNCH_CHECK();
     return 0;
   }
@@ -622,11 +652,12 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   const bf16_t* dy_down = dx_out;  // gradient of the down_proj output
   const bf16_t* dy_o = nullptr;    // gradient of the o_proj output
   dim3 lsgrid((d / 8 + 255) / 256, 64);
-  if (h->plan.has_ls) {
-    // m_out = lam2 * mraw  =>  d mraw = lam2 * dx_out, dlam2 += sum dx_out * mraw
+  if (h->plan.has_res) {
+    // x_out = xmid + keep_b * lam2 * mraw  =>  d mraw = keep_b * lam2 * dx_out, dlam2 += sum keep_b * dx_out * mraw
     bf16_t* dsc = h->wsp<bf16_t>(w.dscaled);
-    hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), 0, st, dx_out, h->wsp<bf16_t>(lw.mraw), h->P + lo.lam2, dsc,
-                       s32 + lo.lam2_32, T, d);
+    hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), 0, st, dx_out, h->wsp<bf16_t>(lw.mraw),
+                       h->plan.has_ls ? h->P + lo.lam2 : nullptr, dsc, h->plan.has_ls ? s32 + lo.lam2_32 : nullptr, T, d,
+                       h->path_drop(i, 1));
     // the grouped wgrad at the end needs this buffer alive; reuse dattn's slot later for the o_proj one
     dy_down = dsc;
   }
@@ -646,10 +677,11 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
     if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_NONE, g, 1, st)) return e;
   }
   dy_o = dx_mid;
-  if (h->plan.has_ls) {
+  if (h->plan.has_res) {
     bf16_t* dsc = h->wsp<bf16_t>(w.dscaled);
-    hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), 0, st, dx_mid, h->wsp<bf16_t>(lw.araw), h->P + lo.lam1, dsc,
-                       s32 + lo.lam1_32, T, d);
+    hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), 0, st, dx_mid, h->wsp<bf16_t>(lw.araw),
+                       h->plan.has_ls ? h->P + lo.lam1 : nullptr, dsc, h->plan.has_ls ? s32 + lo.lam1_32 : nullptr, T, d,
+                       h->path_drop(i, 0));
     dy_o = dsc;
   }
   // attention: dattn = dy_o W_o ; (dq,dk,dv) ; inverse RoPE ; dxn1 = dqkv W_qkv

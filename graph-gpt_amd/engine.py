@@ -45,6 +45,7 @@ class Engine:
          cfg.score_bias, cfg.pad_token_id) = spec.as_c_ints()
         cfg.rms_eps, cfg.rope_theta, cfg.layer_scale_init = spec.rms_eps, spec.rope_theta, spec.layer_scale_init
         cfg.max_tokens, cfg.max_batch = int(max_tokens), int(max_batch)
+        cfg.path_pdrop = float(getattr(spec, "path_pdrop", 0.0))
         self.cfg = cfg
         sz = L.GgetSizes()
         L.check(self.lib.gget_query_sizes(C.byref(cfg), C.byref(sz)))
@@ -170,9 +171,9 @@ class Engine:
                                            _ptr(self._loss), _ptr(logits), _ptr(hid), _stream()))
         return (self._loss[0] if y is not None else None), logits, hid
 
-    def set_attention_dropout(self, p: float, seed: int = 0):
-        """Dropout on the attention probabilities for the NEXT forward/backward (training mode); 0 disables it."""
-        L.check(self.lib.gget_set_attention_dropout(self.h, float(p), int(seed) & 0xFFFFFFFF))
+    def set_dropout(self, attention_p: float = 0.0, path_p: float = 0.0, seed: int = 0):
+        """Attention dropout / stochastic depth for the NEXT forward+backward (training mode); zeros = eval."""
+        L.check(self.lib.gget_set_dropout(self.h, float(attention_p), float(path_p), int(seed) & 0xFFFFFFFF))
 
     def backward(self):
         L.check(self.lib.gget_backward(self.h, 1.0, _stream()))

@@ -78,8 +78,8 @@ class GraphGPTConfig:
         need(not self.smtp_inside, "in-model SMTP masking (next item N1)")
         need(len(self.mlp) == 0, "MLP score head")
         need(self.pooling_method == "last", "pooling other than 'last'")
-        need(self.path_pdrop == 0 and self.mlp_pdrop == 0 and self.embed_pdrop == 0 and self.dropout == 0,
-             "DropPath / MLP / embedding dropout (statistical-parity items of a later round; attention dropout IS supported)")
+        need(self.mlp_pdrop == 0 and self.embed_pdrop == 0 and self.dropout == 0,
+             "MLP / embedding / head dropout (attention dropout and DropPath ARE supported)")
         return ModelSpec(kind=kind, vocab_size=self.vocab_size, hidden_size=self.hidden_size,
                          intermediate_size=self.intermediate_size, num_layers=self.num_hidden_layers,
                          num_heads=self.num_attention_heads, head_dim=64, stacked_feat=self.stacked_feat,
@@ -87,7 +87,8 @@ class GraphGPTConfig:
                          gated_agg=self.stacked_feat_agg_method == "gated", causal=self.causal_attention,
                          rms_eps=self.rms_norm_eps, rope_theta=self.rope_theta, max_position=self.max_position_embeddings,
                          layer_scale_init=float(self.layer_scale_init_value), num_labels=self.num_labels,
-                         score_bias=self.problem_type == "regression", pad_token_id=self.pad_token_id)
+                         score_bias=self.problem_type == "regression", pad_token_id=self.pad_token_id,
+                         path_pdrop=float(self.path_pdrop))
 
     def to_dict(self) -> Dict[str, Any]:
         return {k: v for k, v in self.__dict__.items() if not k.startswith("_")}
@@ -261,13 +262,14 @@ class _GgetModel(nn.Module):
         # attention dropout exactly when the reference applies it: module in training mode and attention_dropout > 0
         # (hf eager_attention_forward :210).  A fresh mask every step, different on every rank.
         p = float(self.config.attention_dropout) if self.training else 0.0
-        if p > 0:
+        pp = float(self.config.path_pdrop) if self.training else 0.0
+        if p > 0 or pp > 0:
             self._drop_step += 1
             rank = int(os.environ.get("RANK", "0"))
             seed = (self.dropout_seed * 0x9E3779B1 + self._drop_step * 0x85EBCA6B + rank * 0xC2B2AE35) & 0xFFFFFFFF
-            e.set_attention_dropout(p, seed)
+            e.set_dropout(p, pp, seed)
         else:
-            e.set_attention_dropout(0.0, 0)
+            e.set_dropout(0.0, 0.0, 0)
         return e
 
     def _autograd_backward(self, g):

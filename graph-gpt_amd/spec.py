@@ -36,6 +36,7 @@ class ModelSpec:
     num_labels: int = 2             # fine-tune head width
     score_bias: bool = False        # problem_type == "regression"
     pad_token_id: int = 0
+    path_pdrop: float = 0.0         # stochastic depth (DropPath) rate of the last layer; 0 = feature not allocated
 
     def __post_init__(self):
         assert self.hidden_size == self.num_heads * self.head_dim, "no GQA / odd head dims on this path"

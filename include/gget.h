@@ -57,6 +57,7 @@ typedef struct gget_config_t {
   float layer_scale_init; /* >0 => lambda_1 / lambda_2 per layer (utils_graphgpt.py:95-104) */
   int32_t max_tokens;     /* capacity: max B*S of any forward call */
   int32_t max_batch;      /* capacity: max B */
+  float path_pdrop;       /* >0 => stochastic depth is available (rate linspace(0,path_pdrop,L), utils_graphgpt.py:184) */
 } gget_config_t;
 
 /* Arena sizes the caller must provide (all 256-byte aligned device buffers). */
@@ -107,10 +108,12 @@ int gget_param_info(gget_handle_t h, int index, gget_param_info_t* out);
 int gget_bucket_count(gget_handle_t h);
 int gget_bucket_range(gget_handle_t h, int bucket, uint64_t* offset, uint64_t* count);
 
-/* replaces: `attention_dropout` of the config + model.train()/eval() (reference launch scripts set 0.1, e.g.
- * examples/graph_lvl/pcqm4m_v2_pretrain.sh:20): dropout probability and RNG seed used by the NEXT forward and its
- * backward; p = 0 (default) is evaluation behaviour. */
-int gget_set_attention_dropout(gget_handle_t h, float p, uint32_t seed);
+/* replaces: `attention_dropout` / `path_pdrop` of the config + model.train()/eval() (reference launch scripts set
+ * attention_dropout 0.1, e.g. examples/graph_lvl/pcqm4m_v2_pretrain.sh:20; ogbl-ppa fine-tuning adds path dropout 0.2,
+ * examples/edge_lvl/ppa_supervised.sh:21-25): probabilities and RNG seed used by the NEXT forward and its backward;
+ * zeros (default) are evaluation behaviour.  path_p is the LAST layer's rate (layer l uses path_p*l/(L-1)) and needs a
+ * handle created with config.path_pdrop > 0. */
+int gget_set_dropout(gget_handle_t h, float attention_p, float path_p, uint32_t seed);
 
 /* replaces: load_state_dict + `.to(bfloat16)`: refresh the bf16 compute copy from the fp32 master. */
 int gget_sync_params(gget_handle_t h, void* stream);

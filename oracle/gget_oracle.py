@@ -117,9 +117,10 @@ def mlp(x, p, pre):
     return Fnn.linear(g * u, p[pre + "down_proj.weight"])
 
 
-def backbone(spec, p: Dict[str, torch.Tensor], x, attention_mask, position_ids, collect=None):
+def backbone(spec, p: Dict[str, torch.Tensor], x, attention_mask, position_ids, collect=None, path_mult=None):
     """hf LlamaModel.forward :367-418 / LlamaDecoderLayer.forward :295-325; LayerScale variant
-    utils_graphgpt.LlamaDecoderLayer.forward (utils_graphgpt.py:107-173, eval mode: DropPath = id)."""
+    utils_graphgpt.LlamaDecoderLayer.forward (utils_graphgpt.py:107-173).  `path_mult(layer, which)` -> [B] tensor of
+    DropPath multipliers (0 or 1/keep_prob per sample, utils_graphgpt.py:64-66 / BeitDropPath); None = eval mode."""
     B, S, d = x.shape
     if position_ids is None:
         position_ids = torch.arange(S)[None, :].expand(B, S)      # hf :389-392
@@ -131,11 +132,15 @@ def backbone(spec, p: Dict[str, torch.Tensor], x, attention_mask, position_ids, 
         a = attention(h, p, pre + "self_attn.", mask4d, cos, sin, spec.num_heads, spec.head_dim)
         if spec.layer_scale_init > 0:
             a = p[pre + "lambda_1"] * a
+        if path_mult is not None:
+            a = a * path_mult(i, 0)[:, None, None].to(a.dtype)
         x = x + a
         h = rmsnorm(x, p[pre + "post_attention_layernorm.weight"], spec.rms_eps)
         m = mlp(h, p, pre + "mlp.")
         if spec.layer_scale_init > 0:
             m = p[pre + "lambda_2"] * m
+        if path_mult is not None:
+            m = m * path_mult(i, 1)[:, None, None].to(m.dtype)
         x = x + m
         if collect is not None:
             collect.append(x)
@@ -198,13 +203,13 @@ def pretrain_forward(spec, p, input_ids, attention_mask, labels=None, sample_wgt
 
 # --------------------------------------------------------------------------- K15 (row A10)
 def task_forward(spec, p, input_ids, attention_mask, position_ids=None, task_labels=None,
-                 sample_wgt=None, problem_type="single_label_classification", loss_type=None):
+                 sample_wgt=None, problem_type="single_label_classification", loss_type=None, path_mult=None):
     """`GraphGPTTaskModel.forward` (modeling_finetune.py:236-326) + `calculate_task_loss`
     (:167-234) + `_get_sequence_len` (modeling_helpers.py:78-86); Linear score head, "last" pooling."""
     if input_ids.dim() == 3:
         input_ids = input_ids[:, :, : spec.stacked_feat]
     x, in_ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"))
-    hidden = backbone(spec, p, x, attention_mask, position_ids)
+    hidden = backbone(spec, p, x, attention_mask, position_ids, path_mult=path_mult)
     logits = Fnn.linear(hidden, p["score.weight"], p.get("score.bias"))
     B = hidden.shape[0]
     seq_len = (in_ != spec.pad_token_id).sum(-1) - 1

@@ -243,3 +243,55 @@ def test_staged_backward_equals_monolithic():
     for off, cnt in e.buckets:
         cover[off: off + cnt] += 1
     assert int(cover.min()) == 1 and int(cover.max()) == 1
+
+
+def _path_keep(seed, layer, which, B, rate):
+    """Python twin of path_keep() in csrc/engine.hip."""
+    if rate <= 0:
+        return torch.ones(B)
+    M32 = 0xFFFFFFFF
+    s = (seed ^ ((0xD6E8FEB8 * (layer * 2 + which + 1)) & M32)) & M32
+    out = []
+    for b in range(B):
+        x = (s + b * 0x85EBCA77) & M32
+        x ^= x >> 16; x = (x * 0x7FEB352D) & M32
+        x ^= x >> 15; x = (x * 0x846CA68B) & M32
+        x ^= x >> 16
+        u = np.float32(x >> 8) * np.float32(1.0 / 16777216.0)
+        out.append(0.0 if u < np.float32(rate) else float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate))))
+    return torch.tensor(out)
+
+
+@pytest.mark.parametrize("layer_scale", [0.0, 1.0])
+def test_drop_path_matches_oracle_with_same_mask(layer_scale):
+    """Stochastic depth (utils_graphgpt.py:64-66,184: per-sample DropPath, rate linspace(0, path_pdrop, L)) as used by
+    the ogbl-ppa fine-tune config (path 0.2 + LayerScale 1): the engine's counter-based per-sample mask is rebuilt in
+    Python and fed to the oracle, forward loss and every gradient must agree."""
+    from _util import spec_mod, weights_mod, synth
+    B, S, seed, rate = 16, 24, 777, 0.5
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=1000, stacked_feat=4, next_n_token=1,
+                                   num_labels=2, layer_scale_init=layer_scale, path_pdrop=rate)
+    state = weights_mod.make_state_dict(spec, seed=9, std=0.05, head_std=0.1)
+    batch = synth.make_task_batch(B=B, S=S, F=4, V=1000, seed=33)
+    b = tb(batch)
+    e = eng_mod.Engine(spec, B * S, B)
+    e.load_state_dict(state)
+    e.set_dropout(0.0, rate, seed)
+    loss, logits, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], None,
+                                     L.PROBLEM_SINGLE_LABEL)
+    e.backward()
+    torch.cuda.synchronize()
+    L_ = spec.num_layers
+    pm = lambda l, w: _path_keep(seed, l, w, B, rate * l / (L_ - 1))
+    assert any(float(pm(L_ - 1, w).min()) == 0.0 for w in (0, 1)), "mask should drop something at rate 0.5"
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32)
+    out, grads = O.loss_and_grads(lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"],
+                                                           b["task_labels"], path_mult=pm), p, "task_loss")
+    assert abs(loss.item() - out["task_loss"].item()) <= 2e-2 * abs(out["task_loss"].item())
+    got = e.grads()
+    gmax = max(float(g.norm()) for g in grads.values())
+    for k in state:
+        w = grads[k].numpy()
+        err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        assert err < 6e-2, f"{k}: {err}"

@@ -49,7 +49,7 @@ def cpu_baseline(spec, state, F, V, seed, threads):
     from oracle import gget_oracle as O
     synth = importlib.import_module("graph-gpt_amd.synth")
     torch.set_num_threads(threads)
-    Bc, Sc = 4, 32
+    Bc, Sc = 16, 32
     b = synth.make_pretrain_batch(B=Bc, S=Sc, F=F, V=V, seed=seed)
     tb = {k: torch.from_numpy(v) for k, v in b.items()}
     p = O.to_params(state, torch.float32)
@@ -58,7 +58,7 @@ def cpu_baseline(spec, state, F, V, seed, threads):
     fn = lambda q: O.pretrain_forward(spec, q, tb["input_ids"], tb["attention_mask"], tb["labels"])
     times = []
     t_begin = time.time()
-    for it in range(4):
+    for it in range(6):
         t0 = time.time()
         _, grads = O.loss_and_grads(fn, p, "head1_loss")
         with torch.no_grad():
@@ -182,7 +182,7 @@ def main():
             "tokens_per_s_per_gpu": tot_real * a.steps / dt / world,
             "step_mfma": {"flops_per_step": fstep, "achieved_tflops_per_gpu": step_tflops,
                           "frac_of_peak": step_tflops / PEAK_BF16_TFLOPS},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<128,128,NT> FFN gate|up [T,d]x[d,2ff]",
+            "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<256,256,32,NT> FFN gate|up [T,d]x[d,2ff] (26% of step FLOPs)",
                          "achieved": k_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": k_tflops / PEAK_BF16_TFLOPS, "traffic": None, "avg_launch_ms": k_ms},
         }

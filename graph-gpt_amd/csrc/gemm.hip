@@ -362,15 +362,15 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const
 // first/last are hidden (at K = 768 they are ~30 % of a non-persistent tile's life).
 // Counted waits stay valid with stores in flight: vmcnt <= PIECES means >= (stores + PIECES) older operations have
 // retired, and loads retire in order among themselves, so the oldest PIECES loads (the tile being waited for) are in.
-template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI>
-__global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_persist_kernel(const GemmGroup g, int total_tiles) {
+template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0, int BPC = 1>
+__global__ void __launch_bounds__(WM * WN * 64, ((WM * WN) >= 8 ? 2 : 1) * BPC) gemm_persist_kernel(const GemmGroup g, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = WM * WN * 64;
   using TA = TileIO<BM, A_MC, NT, BK>;
   using TB = TileIO<BN, B_MC, NT, BK>;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int NSLOT = persist_slots(STAGE);   // 256x128x64: 3 x 48 KiB ; 256x256x32 and 128x128x64: 4 x 32 KiB
+  constexpr int NSLOT = NSLOT_ > 0 ? NSLOT_ : persist_slots(STAGE);   // 256x128x64: 3 x 48 KiB ; 256x256x32, 128x128x64: 4 x 32 KiB
   constexpr int PIECES = TA::PIECES + TB::PIECES;
   constexpr int MI = BM / WM / 16, NJ = BN / WN / 16;
   constexpr int KSH = BK == 64 ? 6 : 5;

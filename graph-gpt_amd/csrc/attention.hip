@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restric
 __global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
                                                          const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
-                                                         int B, int S, int H, int causal, Rope R, Drop D) {
+                                                         int B, int S, int H, int causal, Rope Rin, Rope R, Drop D) {
   __shared__ __attribute__((aligned(16))) unsigned char kt[4096];
   const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const bf16_t* __restric
   const int klen = key_len ? key_len[b] : S;
   const int qrow = q0 + l31;
   bf16x8_t qf[4], dof[4];
-  frags_global_rope(qf, qb, qrow, S, pitch, lane, R, b);
+  frags_global_rope(qf, qb, qrow, S, pitch, lane, Rin, b);
 #pragma unroll
   for (int s = 0; s < 4; ++s) dof[s] = frag_global(dob, qrow, S, (size_t)d, s, lane);
   const size_t sidx = ((size_t)b * H + h) * S + min(qrow, S - 1);
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const bf16_t* __restric
   const int kend = causal ? min(klen, q0 + 32) : klen;
   for (int k0 = 0; k0 < kend; k0 += 32) {
     __syncthreads();
-    load_tile_rope(kt, kb, k0, S, pitch, lane, R, b);
+    load_tile_rope(kt, kb, k0, S, pitch, lane, Rin, b);
     f32x16_t dp = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const bf16_t* __restric
 __global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
-                                                          int B, int S, int H, int causal, Rope R, Drop D) {
+                                                          int B, int S, int H, int causal, Rope Rin, Rope R, Drop D) {
   __shared__ __attribute__((aligned(16))) unsigned char qt[4096];
   __shared__ __attribute__((aligned(16))) unsigned char dot_[4096];
   __shared__ float lse_s[32], dl_s[32];
@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const bf16_t* __restri
   const int klen = key_len ? key_len[b] : S;
   const int krow = k0 + l31;
   bf16x8_t kf[4], vf[4];
-  frags_global_rope(kf, kb, krow, S, pitch, lane, R, b);
+  frags_global_rope(kf, kb, krow, S, pitch, lane, Rin, b);
 #pragma unroll
   for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, krow, S, pitch, s, lane);
   f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const bf16_t* __restri
   if (k0 < klen) {
     for (int q0 = qstart; q0 < S; q0 += 32) {
       __syncthreads();
-      load_tile_rope(qt, qb, q0, S, pitch, lane, R, b);
+      load_tile_rope(qt, qb, q0, S, pitch, lane, Rin, b);
       load_tile(dot_, dob, q0, S, (size_t)d, lane);
       if (lane < 32) {
         const int q = min(q0 + lane, S - 1);
@@ -441,9 +441,10 @@ int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, i
 
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
-               const int64_t* position_ids, float dropout_p, unsigned dropout_seed, hipStream_t st) {
+               const int64_t* position_ids, int qk_rotated, float dropout_p, unsigned dropout_seed, hipStream_t st) {
   if (B == 0 || S == 0) return 0;
-  const Rope R{cos_tab, sin_tab, position_ids, S};
+  const Rope R{cos_tab, sin_tab, position_ids, S};     // rotation of dq, dk back to the un-rotated projections
+  const Rope Rin = qk_rotated ? Rope{nullptr, nullptr, nullptr, S} : R;   // q,k in memory are already rotated?
   const Drop D = make_drop(dropout_p, dropout_seed);
   const long work = (long)B * S * H * 8;
   int g = (int)((work + 255) / 256);
@@ -452,9 +453,9 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
                      H);
   dim3 grid((S + 31) / 32, H, B);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta_ws,
-                     key_len, (bf16_t*)dqkv, B, S, H, causal, R, D);
+                     key_len, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta_ws,
-                     key_len, (bf16_t*)dqkv, B, S, H, causal, R, D);
+                     key_len, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);
   GGET_LAUNCH_CHECK();
   return 0;
 }

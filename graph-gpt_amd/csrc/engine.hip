@@ -488,10 +488,20 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
   bf16_t* gu = h->wsp<bf16_t>(lw.gu);
   bf16_t* hh = h->wsp<bf16_t>(lw.h);
   if (int e = k_rmsnorm_fwd(x_in, h->P + lo.ln1, xn1, h->wsp<float>(lw.rstd1), T, d, c.rms_eps, st)) return e;
-  if (int e = gemm_nt(xn1, h->P + lo.wqkv, qkv, nullptr, T, 3 * d, d, d, d, 3 * d, nullptr, st)) return e;
-  // RoPE is fused into the attention kernels' operand loads (qkv stays un-rotated in HBM)
+  {
+    // q|k|v projection with RoPE applied to the q and k columns in the GEMM epilogue (fp32 accumulators, one rounding):
+    // qkv holds ROTATED q,k; attention consumes them as they are, its backward rotates dq,dk back.
+    GemmGroup g;
+    memset(&g, 0, sizeof(g));
+    g.count = 1;
+    GemmProblem& p = g.p[0];
+    p.A = xn1; p.B = h->P + lo.wqkv; p.C = qkv;
+    p.M = T; p.N = 3 * d; p.K = d; p.lda = d; p.ldb = d; p.ldc = 3 * d;
+    p.rope_cos = h->cos_tab; p.rope_sin = h->sin_tab; p.rope_pos = h->pos; p.rope_S = h->S; p.rope_cols = 2 * d;
+    if (int e = gget_gemm_launch(GGET_GEMM_NT, GGET_EPI_ROPE, g, 1, st)) return e;
+  }
   if (int e = k_attn_fwd(qkv, h->wsp<int32_t>(h->ws.key_len), attn, h->wsp<float>(lw.lse), h->B, h->S, H, c.causal,
-                         h->cos_tab, h->sin_tab, h->pos, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st))
+                         nullptr, nullptr, nullptr, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st))
     return e;
   if (h->plan.has_res) {
     bf16_t* araw = h->wsp<bf16_t>(lw.araw);
@@ -688,7 +698,7 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   if (int e = gemm_nn(dy_o, h->P + lo.wo, dattn, T, d, d, d, d, d, nullptr, st)) return e;
   if (int e = k_attn_bwd(h->wsp<bf16_t>(lw.qkv), h->wsp<bf16_t>(lw.attn), dattn, h->wsp<float>(lw.lse),
                          h->wsp<int32_t>(w.key_len), dqkv, h->wsp<float>(w.delta), h->B, h->S, H, c.causal, h->cos_tab,
-                         h->sin_tab, h->pos, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st))
+                         h->sin_tab, h->pos, /*qk_rotated=*/1, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st))
     return e;
   if (int e = gemm_nn(dqkv, h->P + lo.wqkv, dxn, T, d, 3 * d, 3 * d, d, d, nullptr, st)) return e;
   if (int e = k_rmsnorm_bwd(dxn, x_in, h->P + lo.ln1, h->wsp<float>(lw.rstd1), dx_mid, dx_in, s32 + lo.ln1_32, T, d, st))
@@ -872,7 +882,7 @@ extern "C" int gget_op_attn_bwd(const void* qkv, const void* out, const void* do
                                 const float* sin_tab, const int64_t* position_ids, float dropout_p, uint32_t dropout_seed,
                                 void* stream) {
   return k_attn_bwd(qkv, out, dout, lse, key_len, dqkv, delta_ws, B, S, H, causal, cos_tab, sin_tab, position_ids,
-                    dropout_p, dropout_seed, (hipStream_t)stream);
+                    /*qk_rotated=*/0, dropout_p, dropout_seed, (hipStream_t)stream);
 }
 extern "C" int gget_op_geglu_fwd(const void* gu, void* h, int T, int ff, void* stream) {
   return k_geglu_fwd(gu, h, T, ff, (hipStream_t)stream);

@@ -17,6 +17,11 @@ struct GemmProblem {
   const int* k_dev;   // optional: reduction length read from device memory
   int tiles_n, tile_begin;  // filled by the launcher
   long slab_stride;         // EPI_SLAB_F32: elements between the fp32 slabs of consecutive K slices
+  // EPI_ROPE: rotate columns [0, rope_cols) head-wise (64-wide heads, pair j <-> j+32) by the row's position
+  const float* rope_cos;    // [max_pos][32] fp32
+  const float* rope_sin;
+  const int64_t* rope_pos;  // [M] or nullptr => position = row % rope_S
+  int rope_S, rope_cols;
 };
 
 struct GemmGroup {

@@ -190,6 +190,28 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
     }
     return;
   }
+  if (EPI == GGET_EPI_ROPE && NJ == 4 && nw < P.rope_cols) {
+    // hf apply_rotary_pos_emb :138-160 on the fp32 accumulators: the wave's 64 columns are exactly one head, channel
+    // c (< 32) sits in accumulator j = c/16 and its partner c+32 in accumulator j+2 of the same lane and register.
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = mw + i * 16 + l15;
+      if (m >= M) continue;
+      const int pos = P.rope_pos ? (int)P.rope_pos[m] : (m % P.rope_S);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float4 c = *reinterpret_cast<const float4*>(P.rope_cos + (size_t)pos * 32 + j * 16 + gq * 4);
+        const float4 sn = *reinterpret_cast<const float4*>(P.rope_sin + (size_t)pos * 32 + j * 16 + gq * 4);
+        const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = acc[i][j][e], b = acc[i][j + 2][e];
+          acc[i][j][e] = a * cc[e] - b * ss[e];
+          acc[i][j + 2][e] = b * cc[e] + a * ss[e];
+        }
+      }
+    }
+  }
   const bool odd = gq & 1;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -487,7 +509,7 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
     }
     // wide tile for the widest forward GEMM: 256x256x32 (8 waves of 128x64, 4-slot ring) moves 2/3 of the bytes per
     // FLOP of the 256x128 tile
-    if constexpr (WM == 4 && WN == 2 && !A_MC && EPI != GGET_EPI_SLAB_F32 && EPI != GGET_EPI_ATOMIC_F32) {
+    if constexpr (WM == 4 && WN == 2 && !A_MC && EPI != GGET_EPI_SLAB_F32 && EPI != GGET_EPI_ATOMIC_F32 && EPI != GGET_EPI_ROPE) {
       long t256 = 0;
       bool ok256 = getenv("GGET_GEMM_NO_256") == nullptr;
       for (int i = 0; i < g.count; ++i) {
@@ -560,6 +582,9 @@ int launch_mode(GemmGroup& g, int epi, int split_k, hipStream_t st) {
     case GGET_EPI_RESIDUAL: return launch_shape<A_MC, B_MC, GGET_EPI_RESIDUAL>(g, split_k, st);
     case GGET_EPI_ATOMIC_F32: return launch_shape<A_MC, B_MC, GGET_EPI_ATOMIC_F32>(g, split_k, st);
     case GGET_EPI_SLAB_F32: return launch_shape<A_MC, B_MC, GGET_EPI_SLAB_F32>(g, split_k, st);
+    case GGET_EPI_ROPE:
+      if constexpr (!A_MC && !B_MC) return launch_shape<false, false, GGET_EPI_ROPE>(g, split_k, st);
+      break;
   }
   gget_set_error("gemm: unknown epilogue %d", epi);
   return 2;

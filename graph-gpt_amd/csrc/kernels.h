@@ -48,10 +48,11 @@ int k_slab_reduce(const float* slabs, long slab_stride, int nslab, void* dst, si
 int k_convert_segments(const float* scratch, void* grads, const GgetSegment* segs_dev, int nseg, hipStream_t st);
 
 // attention.hip
-// cos_tab/sin_tab ([max_pos][32] fp32) non-null => RoPE is applied to q,k on load and undone on dq,dk (qkv stays un-rotated)
+// cos_tab/sin_tab ([max_pos][32] fp32) non-null => RoPE is applied to q,k on load (unless qk_rotated: the projection GEMM
+// already rotated them) and undone on dq,dk, so dqkv is always the gradient of the UN-rotated projections
 int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
                const float* cos_tab, const float* sin_tab, const int64_t* position_ids, float dropout_p,
                unsigned dropout_seed, hipStream_t st);
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
-               const int64_t* position_ids, float dropout_p, unsigned dropout_seed, hipStream_t st);
+               const int64_t* position_ids, int qk_rotated, float dropout_p, unsigned dropout_seed, hipStream_t st);

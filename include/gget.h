@@ -174,6 +174,7 @@ int gget_hidden_states(gget_handle_t h, const void** hidden_dev);
 #define GGET_EPI_NONE 0
 #define GGET_EPI_RESIDUAL 1 /* C = A*B + R (R bf16 [M,N], ldr = ldc) */
 #define GGET_EPI_ATOMIC_F32 2 /* C is fp32, C += A*B with atomics (split-K) */
+#define GGET_EPI_ROPE 4 /* C = rope(A*B) on columns [0, rope_cols): RoPE fused into the q|k|v projection (engine only) */
 #define GGET_EPI_SLAB_F32 3 /* C is fp32 [split_k][M][ldc]: slice s of K writes slab s (reduced by the caller) */
 int gget_op_gemm(int mode, int epilogue, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
                  int lda, int ldb, int ldc, int split_k, void* stream);

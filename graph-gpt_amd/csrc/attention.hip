@@ -68,7 +68,31 @@ __device__ __forceinline__ void load_tile(unsigned char* lds, const bf16_t* __re
     *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = v;
   }
 }
-// same, rotating every row by its position (each lane fetches its chunk and the chunk 32 channels away)
+// same, rotating every row by its position (each lane fetches its chunk and the chunk 32 channels away).
+// Cooperative: the NT threads of the block split the tile's 256 16-byte chunks.
+template <int NT>
+__device__ __forceinline__ void load_tile_coop(unsigned char* lds, const bf16_t* __restrict__ base, int r0, int row_lim,
+                                               size_t pitch, int tid, const Rope& R, int b) {
+#pragma unroll
+  for (int i = 0; i < 256 / NT; ++i) {
+    const int c = tid + i * NT;
+    const int row = c >> 3, ch = c & 7;
+    const int gr = r0 + row;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (gr < row_lim) {
+      const bf16_t* rp = base + (size_t)gr * pitch;
+      if (R.cos_tab) {
+        uint4 lo = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8);
+        uint4 up = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8 + 32);
+        rope_pair(lo, up, R, rope_pos(R, b, gr), (ch & 3) * 8);
+        v = (ch & 4) ? up : lo;
+      } else {
+        v = *reinterpret_cast<const uint4*>(rp + ch * 8);
+      }
+    }
+    *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = v;
+  }
+}
 __device__ __forceinline__ void load_tile_rope(unsigned char* lds, const bf16_t* __restrict__ base, int r0, int row_lim,
                                                size_t pitch, int lane, const Rope& R, int b) {
   if (!R.cos_tab) { load_tile(lds, base, r0, row_lim, pitch, lane); return; }
@@ -197,12 +221,19 @@ __device__ __forceinline__ void unrope_acc(f32x16_t& a0, f32x16_t& a1, const Rop
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
-                                                      bf16_t* __restrict__ out, float* __restrict__ lse, int B, int S,
-                                                      int H, int causal, Rope R, Drop D) {
+// Block = NW waves = NW consecutive 32-query tiles of one (batch, head); every 32-key K tile and V tile is brought into
+// LDS ONCE per block (K rotated on the way in when R is given) and shared by the NW waves: K as the A operand of
+// S^T = K Q^T (ds_read_b128), V through the transposing read for O^T += V^T P^T.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
+                                                           bf16_t* __restrict__ out, float* __restrict__ lse, int B, int S,
+                                                           int H, int causal, Rope R, Drop D) {
+  __shared__ __attribute__((aligned(16))) unsigned char kt[4096];
   __shared__ __attribute__((aligned(16))) unsigned char vt[4096];
-  const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
-  const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = (blockIdx.x * NW + wave) * 32;
   const int d = H * 64;
   const size_t pitch = (size_t)3 * d;
   const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
@@ -210,20 +241,24 @@ __global__ void __launch_bounds__(64) attn_fwd_kernel(const bf16_t* __restrict__
   const bf16_t* vb = qb + 2 * d;
   const int klen = key_len ? key_len[b] : S;
   const int qrow = q0 + l31;
+  const Rope Rnone{nullptr, nullptr, nullptr, S};
 
   bf16x8_t qf[4];
   frags_global_rope(qf, qb, qrow, S, pitch, lane, R, b);
   f32x16_t o0 = zero16(), o1 = zero16();
   float m = -INFINITY, l = 0.f;
-  const int kend = causal ? min(klen, q0 + 32) : klen;
-  for (int k0 = 0; k0 < kend; k0 += 32) {
+  const int q_end_blk = min(S, (int)(blockIdx.x + 1) * NW * 32);       // one past the block's last query row
+  const int kend_blk = causal ? min(klen, q_end_blk) : klen;
+  const int kend = (q0 < S) ? (causal ? min(klen, q0 + 32) : klen) : 0;   // this wave's own key range
+  for (int k0 = 0; k0 < kend_blk; k0 += 32) {
+    __syncthreads();  // previous tile fully consumed
+    load_tile_coop<NW * 64>(kt, kb, k0, S, pitch, tid, R, b);
+    load_tile_coop<NW * 64>(vt, vb, k0, S, pitch, tid, Rnone, b);
+    __syncthreads();
+    if (k0 >= kend) continue;
     f32x16_t sc = zero16();
-    bf16x8_t kf[4];
-    frags_global_rope(kf, kb, k0 + l31, S, pitch, lane, R, b);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sc, 0, 0, 0);
-    __syncthreads();  // previous tile's transposed reads are done
-    load_tile(vt, vb, k0, S, pitch, lane);
+    for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), qf[s], sc, 0, 0, 0);
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -249,7 +284,6 @@ __global__ void __launch_bounds__(64) attn_fwd_kernel(const bf16_t* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
     const bf16x8_t pb0 = acc_to_b(sc, 0), pb1 = acc_to_b(sc, 1);
-    __syncthreads();  // V tile visible
     o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 0, lane), pb0, o0, 0, 0, 0);
     o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 1, lane), pb1, o0, 0, 0, 0);
     o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 0, lane), pb0, o1, 0, 0, 0);
@@ -289,13 +323,18 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restric
 }
 
 // dQ^T[dh][q] = sum_keys K^T[dh][key] dS^T[key][q],  dS^T = P^T (dP^T - delta_q) * scale
-__global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                         const float* __restrict__ lse, const float* __restrict__ delta,
-                                                         const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
-                                                         int B, int S, int H, int causal, Rope Rin, Rope R, Drop D) {
+// Block = NW query tiles; the K tile (rotated if Rin) and the V tile are shared through LDS.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
+                                                              int B, int S, int H, int causal, Rope Rin, Rope R, Drop D) {
   __shared__ __attribute__((aligned(16))) unsigned char kt[4096];
-  const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
-  const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+  __shared__ __attribute__((aligned(16))) unsigned char vt[4096];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = (blockIdx.x * NW + wave) * 32;
   const int d = H * 64;
   const size_t pitch = (size_t)3 * d;
   const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
@@ -304,6 +343,7 @@ __global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const bf16_t* __restric
   const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
   const int klen = key_len ? key_len[b] : S;
   const int qrow = q0 + l31;
+  const Rope Rnone{nullptr, nullptr, nullptr, S};
   bf16x8_t qf[4], dof[4];
   frags_global_rope(qf, qb, qrow, S, pitch, lane, Rin, b);
 #pragma unroll
@@ -311,20 +351,21 @@ __global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const bf16_t* __restric
   const size_t sidx = ((size_t)b * H + h) * S + min(qrow, S - 1);
   const float lse_q = lse[sidx], dl_q = delta[sidx];
   f32x16_t a0 = zero16(), a1 = zero16();
-  const int kend = causal ? min(klen, q0 + 32) : klen;
-  for (int k0 = 0; k0 < kend; k0 += 32) {
+  const int q_end_blk = min(S, (int)(blockIdx.x + 1) * NW * 32);
+  const int kend_blk = causal ? min(klen, q_end_blk) : klen;
+  const int kend = (q0 < S) ? (causal ? min(klen, q0 + 32) : klen) : 0;
+  for (int k0 = 0; k0 < kend_blk; k0 += 32) {
     __syncthreads();
-    load_tile_rope(kt, kb, k0, S, pitch, lane, Rin, b);
-    f32x16_t dp = zero16();
+    load_tile_coop<NW * 64>(kt, kb, k0, S, pitch, tid, Rin, b);
+    load_tile_coop<NW * 64>(vt, vb, k0, S, pitch, tid, Rnone, b);
+    __syncthreads();
+    if (k0 >= kend) continue;
+    f32x16_t dp = zero16(), sc = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const bf16x8_t vf = frag_global(vb, k0 + l31, S, pitch, s, lane);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, s, lane), dof[s], dp, 0, 0, 0);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), qf[s], sc, 0, 0, 0);
     }
-    __syncthreads();
-    f32x16_t sc = zero16();
-#pragma unroll
-    for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), qf[s], sc, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + acc_row(r, hi);
@@ -345,15 +386,19 @@ __global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const bf16_t* __restric
 }
 
 // dV^T[dh][key] = sum_q dO^T[dh][q] P[q][key] ; dK^T[dh][key] = sum_q Q^T[dh][q] dS[q][key]
-__global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
-                                                          int B, int S, int H, int causal, Rope Rin, Rope R, Drop D) {
+// Block = NW key tiles; every 32-query Q tile (rotated if Rin), dO tile and their lse/delta are shared through LDS.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
+                                                               int B, int S, int H, int causal, Rope Rin, Rope R, Drop D) {
   __shared__ __attribute__((aligned(16))) unsigned char qt[4096];
   __shared__ __attribute__((aligned(16))) unsigned char dot_[4096];
   __shared__ float lse_s[32], dl_s[32];
-  const int k0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
-  const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int k0 = (blockIdx.x * NW + wave) * 32;
   const int d = H * 64;
   const size_t pitch = (size_t)3 * d;
   const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
@@ -362,24 +407,27 @@ __global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const bf16_t* __restri
   const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
   const int klen = key_len ? key_len[b] : S;
   const int krow = k0 + l31;
+  const Rope Rnone{nullptr, nullptr, nullptr, S};
   bf16x8_t kf[4], vf[4];
   frags_global_rope(kf, kb, krow, S, pitch, lane, Rin, b);
 #pragma unroll
   for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, krow, S, pitch, s, lane);
   f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
   const bool key_ok = krow < klen;
-  const int qstart = causal ? k0 : 0;  // queries before the key tile never see it
-  if (k0 < klen) {
+  const int kblk0 = blockIdx.x * NW * 32;          // first key of the block
+  const int qstart = causal ? kblk0 : 0;           // queries before the block's first key never see it
+  if (kblk0 < klen) {
     for (int q0 = qstart; q0 < S; q0 += 32) {
       __syncthreads();
-      load_tile_rope(qt, qb, q0, S, pitch, lane, Rin, b);
-      load_tile(dot_, dob, q0, S, (size_t)d, lane);
-      if (lane < 32) {
-        const int q = min(q0 + lane, S - 1);
-        lse_s[lane] = lse[((size_t)b * H + h) * S + q];
-        dl_s[lane] = delta[((size_t)b * H + h) * S + q];
+      load_tile_coop<NW * 64>(qt, qb, q0, S, pitch, tid, Rin, b);
+      load_tile_coop<NW * 64>(dot_, dob, q0, S, (size_t)d, tid, Rnone, b);
+      if (tid < 32) {
+        const int q = min(q0 + tid, S - 1);
+        lse_s[tid] = lse[((size_t)b * H + h) * S + q];
+        dl_s[tid] = delta[((size_t)b * H + h) * S + q];
       }
       __syncthreads();
+      if (k0 >= klen || (causal && q0 + 31 < k0)) continue;   // this wave's keys are padding / all in the future
       f32x16_t sc = zero16(), dp = zero16();
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -416,6 +464,9 @@ __global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const bf16_t* __restri
   }
 }
 
+// waves (= 32-row tiles) per block: long sequences share each K/V (or Q/dO) tile among 4 waves through LDS
+int attn_waves(int S) { return S >= 128 ? 4 : (S >= 64 ? 2 : 1); }
+
 Drop make_drop(float p, unsigned seed) {
   Drop d;
   d.thresh = p > 0.f ? (unsigned)(p * 16777216.0f) : 0u;
@@ -430,11 +481,14 @@ int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, i
                const float* cos_tab, const float* sin_tab, const int64_t* position_ids, float dropout_p,
                unsigned dropout_seed, hipStream_t st) {
   if (B == 0 || S == 0) return 0;
-  dim3 grid((S + 31) / 32, H, B);
   const Rope R{cos_tab, sin_tab, position_ids, S};
   const Drop D = make_drop(dropout_p, dropout_seed);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, key_len, (bf16_t*)out, lse, B, S, H,
-                     causal, R, D);
+  const int nw = attn_waves(S);
+  dim3 grid((S + 32 * nw - 1) / (32 * nw), H, B);
+#define GGET_ATTN_FWD(NW) hipLaunchKernelGGL(attn_fwd_kernel<NW>, grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, key_len, \
+                                             (bf16_t*)out, lse, B, S, H, causal, R, D)
+  if (nw == 4) GGET_ATTN_FWD(4); else if (nw == 2) GGET_ATTN_FWD(2); else GGET_ATTN_FWD(1);
+#undef GGET_ATTN_FWD
   GGET_LAUNCH_CHECK();
   return 0;
 }
@@ -451,11 +505,17 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta_ws, B, S,
                      H);
-  dim3 grid((S + 31) / 32, H, B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta_ws,
-                     key_len, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta_ws,
-                     key_len, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);
+  const int nw = attn_waves(S);
+  dim3 grid((S + 32 * nw - 1) / (32 * nw), H, B);
+#define GGET_ATTN_BWD(NW)                                                                                                  \
+  do {                                                                                                                     \
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<NW>, grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,   \
+                       delta_ws, key_len, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);                                      \
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NW>, grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,  \
+                       delta_ws, key_len, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);                                      \
+  } while (0)
+  if (nw == 4) GGET_ATTN_BWD(4); else if (nw == 2) GGET_ATTN_BWD(2); else GGET_ATTN_BWD(1);
+#undef GGET_ATTN_BWD
   GGET_LAUNCH_CHECK();
   return 0;
 }

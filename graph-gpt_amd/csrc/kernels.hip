@@ -274,19 +274,27 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_bwd_kernel(const bf16_t* __res
     for (int e = 0; e < 8; ++e) dwp[i][e] = 0.f;
     if (c < nchunk) unpack8(ldg16(w + c * 8), wv[i]);
   }
-  for (int row = blockIdx.x * (kBlock / 64) + wave; row < T; row += gridDim.x * (kBlock / 64)) {
-    const float rstd = rstd_in[row];
-    uint4 xr[NCH], dr[NCH], rr[NCH];
+  // software-pipelined over rows: the loads of the next row are in flight while the current one is reduced and stored
+  const int stride = gridDim.x * (kBlock / 64);
+  int row = blockIdx.x * (kBlock / 64) + wave;
+  uint4 xr[NCH], dr[NCH], rr[NCH];
+  float rstd = 0.f;
+  auto fetch = [&](int r) {
+    rstd = rstd_in[r];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {   // issue every load of the row before touching any of them
+    for (int i = 0; i < NCH; ++i) {
       const int c = lane + i * 64;
       if (c < nchunk) {
-        xr[i] = ldg16(x + (size_t)row * d + c * 8);
-        dr[i] = ldg16(dy + (size_t)row * d + c * 8);
-        rr[i] = dres ? ldg16(dres + (size_t)row * d + c * 8) : make_uint4(0, 0, 0, 0);
+        xr[i] = ldg16(x + (size_t)r * d + c * 8);
+        dr[i] = ldg16(dy + (size_t)r * d + c * 8);
+        rr[i] = dres ? ldg16(dres + (size_t)r * d + c * 8) : make_uint4(0, 0, 0, 0);
       }
     }
-    float xh[NCH][8], g[NCH][8];
+  };
+  if (row < T) fetch(row);
+  for (; row < T; row += stride) {
+    const float rs = rstd;
+    float xh[NCH][8], g[NCH][8], res[NCH][8];
     float dot = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -295,24 +303,25 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_bwd_kernel(const bf16_t* __res
         float xv[8], dv[8];
         unpack8(xr[i], xv);
         unpack8(dr[i], dv);
+        unpack8(rr[i], res[i]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          xh[i][e] = xv[e] * rstd;
+          xh[i][e] = xv[e] * rs;
           g[i][e] = dv[e] * wv[i][e];
           dot += g[i][e] * xh[i][e];
           dwp[i][e] += dv[e] * xh[i][e];
         }
       }
     }
+    if (row + stride < T) fetch(row + stride);
     dot = wave_sum(dot) / (float)d;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = lane + i * 64;
       if (c < nchunk) {
         float o[8];
-        unpack8(rr[i], o);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += rstd * (g[i][e] - xh[i][e] * dot);
+        for (int e = 0; e < 8; ++e) o[e] = res[i][e] + rs * (g[i][e] - xh[i][e] * dot);
         stg16(dx + (size_t)row * d + c * 8, pack8(o));
       }
     }
@@ -860,7 +869,7 @@ int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rst
                   float* dw_accum, int T, int d, hipStream_t st) {
   GGET_REQUIRE(d % 8 == 0 && d <= 64 * 8 * kMaxChunksPerLane, "rmsnorm: d=%d unsupported", d);
   if (T == 0) return 0;
-  const int grid = grid_for(T, 4 * 4, 1024);  // 4 rows per wave: enough rows to amortise the dw atomics
+  const int grid = grid_for(T, 4 * 4, 1024);  // >= 4 rows per wave: amortises the dw atomics, pipelined row loads
   if (d <= 1024)
     hipLaunchKernelGGL(rmsnorm_bwd_kernel<2>, dim3(grid), dim3(kBlock), 4 * d * sizeof(float), st, (const bf16_t*)dy,
                        (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_accum, T, d);

@@ -97,6 +97,18 @@ def time_dominant_kernel(spec, T, iters=20):
     return fl / (ms * 1e-3) / 1e12, ms
 
 
+def pmc_traffic():
+    """L2<->fabric bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r01_gu_gemm_pmc.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc runs); None when
+    the summary is absent.  PMC counters cannot be collected from inside the process being timed."""
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gu_gemm_pmc.json")
+    try:
+        with open(p) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,7 +196,8 @@ def main():
                           "frac_of_peak": step_tflops / PEAK_BF16_TFLOPS},
             "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<256,256,32,NT> FFN gate|up [T,d]x[d,2ff] (26% of step FLOPs)",
                          "achieved": k_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": k_tflops / PEAK_BF16_TFLOPS, "traffic": None, "avg_launch_ms": k_ms},
+                         "frac": k_tflops / PEAK_BF16_TFLOPS, "traffic": pmc_traffic() if B * S == 8192 and spec.hidden_size == 768 else None,
+                         "avg_launch_ms": k_ms},
         }
         if world == 1 and not a.no_cpu_baseline:
             state = weights.make_state_dict(spec, seed=0)

@@ -847,6 +847,19 @@ extern "C" int gget_op_gemm(int mode, int epilogue, const void* A, const void* B
                             int lda, int ldb, int ldc, int split_k, void* stream) {
   return gget_gemm_single(mode, epilogue, A, B, C, R, M, N, K, lda, ldb, ldc, nullptr, nullptr, split_k, (hipStream_t)stream);
 }
+extern "C" int gget_op_qkv_rope(const void* x, const void* wqkv, void* qkv, const float* cos_tab, const float* sin_tab,
+                                const int64_t* position_ids, int T, int S, int d, void* stream) {
+  GGET_REQUIRE(x && wqkv && qkv && cos_tab && sin_tab, "qkv_rope: null argument");
+  GGET_REQUIRE(d > 0 && d % 64 == 0 && T > 0 && S > 0, "qkv_rope: bad shape T %d S %d d %d", T, S, d);
+  GemmGroup g;
+  memset(&g, 0, sizeof(g));
+  g.count = 1;
+  GemmProblem& p = g.p[0];
+  p.A = static_cast<const bf16_t*>(x); p.B = static_cast<const bf16_t*>(wqkv); p.C = qkv;
+  p.M = T; p.N = 3 * d; p.K = d; p.lda = d; p.ldb = d; p.ldc = 3 * d;
+  p.rope_cos = cos_tab; p.rope_sin = sin_tab; p.rope_pos = position_ids; p.rope_S = S; p.rope_cols = 2 * d;
+  return gget_gemm_launch(GGET_GEMM_NT, GGET_EPI_ROPE, g, 1, (hipStream_t)stream);
+}
 extern "C" int gget_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, void* stream) {
   return k_rmsnorm_fwd(x, w, y, rstd, T, d, eps, (hipStream_t)stream);
 }

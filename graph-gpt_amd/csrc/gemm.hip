@@ -67,7 +67,21 @@ struct TileIO {
   static constexpr int NPIECE = ROWS * BK * 2 / 1024;
   static constexpr int PIECES = NPIECE / NWAVES;  // LDS-DMA instructions per wave per tile
   static_assert(CHUNKS % NTHREADS == 0 && NPIECE % NWAVES == 0, "tile/thread shape");
-  static_assert(!MC || ROWS == 64 || ROWS == 128 || ROWS == 256, "M/N-contiguous tiles need power-of-two rows");
+  static_assert(!MC || ROWS == 128 || ROWS == 192 || ROWS == 256, "M/N-contiguous tile widths");
+  static constexpr int NWIN = ROWS / 16;        // 32-byte windows per k-row of an M/N-contiguous tile
+
+  // M/N-contiguous tiles: a k-row is NWIN 32-byte windows (16 rows each); the window holding rows [16w, 16w+16) of
+  // k-row kr sits at LDS window mc_lds_win(kr, w) so that one ds_read_b64_tr_b16 (8 k-rows x one window per 32 lanes)
+  // touches 8 distinct 32-byte bank windows.  256/128-row tiles (512/256-byte k-rows): XOR with 3 bits of kr.
+  // 192-row tiles (384-byte k-rows, 12 windows): rotation by ((kr>>3)&1) + 2*((kr>>1)&1), found by exhaustive search.
+  __device__ __forceinline__ static int mc_lds_win(int kr, int w) {
+    if (ROWS == 192) { const int t = w + ((kr >> 3) & 1) + ((kr & 2)); return t >= NWIN ? t - NWIN : t; }
+    return w ^ mc_swz(kr);
+  }
+  __device__ __forceinline__ static int mc_src_win(int kr, int wl) {   // inverse: which rows the LDS window wl holds
+    if (ROWS == 192) { const int t = wl - ((kr >> 3) & 1) - ((kr & 2)); return t < 0 ? t + NWIN : t; }
+    return wl ^ mc_swz(kr);
+  }
 
   // swizzle of the 16-byte chunk index inside a K-contiguous row (conflict-free ds_read_b128 of 16 rows x 1 chunk):
   // 128-byte rows: chunk ^= row & 7 ; 64-byte rows (4 rows per 256-byte bank row): chunk ^= {0,3,2,1}[(row >> 2) & 3]
@@ -89,10 +103,10 @@ struct TileIO {
         const int gr = min(row0 + r, row_lim - 1);
         p = base + (size_t)gr * ld + k0 + lc * 8;
       } else {
-        constexpr int RPI = 64 / CPR;  // k-rows per DMA instruction
-        const int kr = q * RPI + lane / CPR;
-        const int sl = lane % CPR;
-        const int lw = (sl >> 1) ^ mc_swz(kr);
+        const int c = q * 64 + lane;   // 16-byte chunk of the tile image; a DMA instruction covers 64 of them
+        const int kr = c / CPR;
+        const int sl = c % CPR;
+        const int lw = mc_src_win(kr, sl >> 1);
         // a partial last chunk (row_lim % 8 != 0) is still read in full: the leading dimension covers it
         const int gm = min(row0 + lw * 16 + (sl & 1) * 8, ((row_lim + 7) & ~7) - 8);
         p = base + (size_t)(k0 + kr) * ld + gm;
@@ -149,8 +163,8 @@ struct TileIO {
       const int kr0 = kk * 32 + g * 8 + (l15 >> 2);
       const int kr1 = kr0 + 4;
       const int inw = (l15 & 3) * 8;
-      const unsigned char* p0 = lds + kr0 * ROWB + ((sub ^ mc_swz(kr0)) << 5) + inw;
-      const unsigned char* p1 = lds + kr1 * ROWB + ((sub ^ mc_swz(kr1)) << 5) + inw;
+      const unsigned char* p0 = lds + kr0 * ROWB + (mc_lds_win(kr0, sub) << 5) + inw;
+      const unsigned char* p1 = lds + kr1 * ROWB + (mc_lds_win(kr1, sub) << 5) + inw;
       const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(p0));
       const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(p1));
       bf16x8_t out;
@@ -170,10 +184,28 @@ constexpr int kSuper = 8;  // row panels per L2 super-tile
 // of each 16x16 accumulator; lanes l and l^16 trade halves of two neighbouring accumulators so that every lane ends
 // up with 8 consecutive columns => 16-byte stores, 64-byte row segments, half the store instructions (the C store is
 // issue-bound, not bandwidth-bound).
-template <int EPI, int MI, int NJ>
+// ILV (RoPE epilogue on a 192-wide block tile, two waves across N): the wave's six accumulators are not six adjacent
+// 16-column groups but the even (wave 0) or odd (wave 1) 16-column groups of each 32-channel half of three heads, so
+// that a channel c < 32 and its partner c + 32 still sit in the same lane: accumulator j covers columns
+// nw + (j/2)*64 + (j%2)*32 .. +15 with nw = tile origin + 16*wave, i.e. head j/2, channels chan0 + (j%2)*32 .. +15.
+template <int EPI, int MI, int NJ, bool ILV = false>
 __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmProblem& P, int M, int N, int mw, int nw, int lane,
-                                           int kslice = 0) {
+                                           int kslice = 0, bool fake_rows = false, int chan0 = 0) {
   const int l15 = lane & 15, gq = lane >> 4;
+  auto col_of = [](int j) { return ILV ? (j >> 1) * 64 + (j & 1) * 32 : j * 16; };
+  if (fake_rows) {   // timing experiment: same bytes, full-line addresses (8 rows x 128 B per instruction), wrong placement
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int jp = 0; jp < NJ / 2; ++jp) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jp][e]; v[4 + e] = acc[i][2 * jp + 1][e]; }
+        const int m = mw + i * 16 + jp * 8 + (lane >> 3), n = nw + (lane & 7) * 8;
+        if (m < M && n + 8 <= N) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(P.C) + (size_t)m * P.ldc + n) = pack8(v);
+      }
+    return;
+  }
   if (EPI == GGET_EPI_ATOMIC_F32) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -181,7 +213,7 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
       if (m >= M) continue;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int n = nw + j * 16 + gq * 4;
+        const int n = nw + col_of(j) + gq * 4;
         if (n >= N) continue;
         float* c = reinterpret_cast<float*>(P.C) + (size_t)m * P.ldc + n;
         unsafeAtomicAdd(c + 0, acc[i][j][0]); unsafeAtomicAdd(c + 1, acc[i][j][1]);
@@ -190,24 +222,30 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
     }
     return;
   }
-  if (EPI == GGET_EPI_ROPE && NJ == 4 && nw < P.rope_cols) {
-    // hf apply_rotary_pos_emb :138-160 on the fp32 accumulators: the wave's 64 columns are exactly one head, channel
-    // c (< 32) sits in accumulator j = c/16 and its partner c+32 in accumulator j+2 of the same lane and register.
+  if (EPI == GGET_EPI_ROPE) {
+    // hf apply_rotary_pos_emb :138-160 on the fp32 accumulators: channel c (< 32) of a head and its partner c + 32 sit
+    // in the same lane and register of two accumulators of this wave (j and j+2 when the wave's 64 columns are one head).
+    static_assert(EPI != GGET_EPI_ROPE || ILV || NJ == 4, "RoPE epilogue: a wave owns one 64-column head");
+    constexpr int NP = ILV ? NJ / 2 : 2;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = mw + i * 16 + l15;
       if (m >= M) continue;
       const int pos = P.rope_pos ? (int)P.rope_pos[m] : (m % P.rope_S);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float4 c = *reinterpret_cast<const float4*>(P.rope_cos + (size_t)pos * 32 + j * 16 + gq * 4);
-        const float4 sn = *reinterpret_cast<const float4*>(P.rope_sin + (size_t)pos * 32 + j * 16 + gq * 4);
+      for (int p = 0; p < NP; ++p) {
+        const int ja = ILV ? 2 * p : p, jb = ILV ? 2 * p + 1 : p + 2;
+        const int headcol = ILV ? nw - chan0 + p * 64 : nw;
+        if (headcol >= P.rope_cols) continue;
+        const int ch = (ILV ? chan0 : p * 16) + gq * 4;
+        const float4 c = *reinterpret_cast<const float4*>(P.rope_cos + (size_t)pos * 32 + ch);
+        const float4 sn = *reinterpret_cast<const float4*>(P.rope_sin + (size_t)pos * 32 + ch);
         const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float a = acc[i][j][e], b = acc[i][j + 2][e];
-          acc[i][j][e] = a * cc[e] - b * ss[e];
-          acc[i][j + 2][e] = b * cc[e] + a * ss[e];
+          const float a = acc[i][ja][e], b = acc[i][jb][e];
+          acc[i][ja][e] = a * cc[e] - b * ss[e];
+          acc[i][jb][e] = b * cc[e] + a * ss[e];
         }
       }
     }
@@ -230,7 +268,7 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
         v[e] = odd ? got[e] : keep[e];
         v[4 + e] = odd ? keep[e] : got[e];
       }
-      const int n = nw + (2 * jp + (odd ? 1 : 0)) * 16 + (gq & 2) * 4;
+      const int n = nw + (odd ? col_of(2 * jp + 1) : col_of(2 * jp)) + (gq & 2) * 4;
       if (m >= M || n >= N) continue;
       if (EPI == GGET_EPI_SLAB_F32) {
         float* fp = reinterpret_cast<float*>(P.C) + (size_t)kslice * P.slab_stride + (size_t)m * P.ldc + n;
@@ -396,6 +434,8 @@ __global__ void __launch_bounds__(WM * WN * 64, ((WM * WN) >= 8 ? 2 : 1) * BPC) 
   constexpr int PIECES = TA::PIECES + TB::PIECES;
   constexpr int MI = BM / WM / 16, NJ = BN / WN / 16;
   constexpr int KSH = BK == 64 ? 6 : 5;
+  constexpr bool ILV = EPI == GGET_EPI_ROPE && BN == 192;   // see store_tile
+  static_assert(!ILV || WN == 2, "interleaved RoPE tile: two waves across N");
 
   const int G = gridDim.x;                                     // multiple of 8
   const int perm = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);  // XCD-contiguous inside every round
@@ -428,7 +468,7 @@ __global__ void __launch_bounds__(WM * WN * 64, ((WM * WN) >= 8 ? 2 : 1) * BPC) 
   bool ivalid = tile_at(0, ic);
   bool cvalid = ivalid;
   cc = ic;
-  int islot = 0, cslot = 0, inflight = 0;
+  int islot = 0, cslot = 0, inflight = 0, loose = 0;
   auto issue_next = [&]() {
     if (!ivalid) return;
     const GemmProblem& P = g.p[ic.pi];
@@ -443,7 +483,8 @@ __global__ void __launch_bounds__(WM * WN * 64, ((WM * WN) >= 8 ? 2 : 1) * BPC) 
   for (int i = 0; i < NSLOT - 1; ++i) issue_next();
   while (cvalid) {
     // the oldest K-tile in flight must have landed: allow (inflight-1) younger tiles' pieces to stay outstanding
-    if (inflight >= 3) vm_wait<2 * PIECES>();
+    if (g.ablate == 8 && loose > 0) { vm_wait<(2 * PIECES + MI * NJ / 2 > 63 ? 63 : 2 * PIECES + MI * NJ / 2)>(); --loose; }  // timing experiment only
+    else if (inflight >= 3) vm_wait<2 * PIECES>();
     else if (inflight == 2) vm_wait<PIECES>();
     else vm_wait<0>();
     __syncthreads();   // publishes that tile; also every wave is done with the slot consumed last iteration
@@ -458,7 +499,7 @@ __global__ void __launch_bounds__(WM * WN * 64, ((WM * WN) >= 8 ? 2 : 1) * BPC) 
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[i] = TA::frag(a_l, wm * MI + i, kk, lane);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bf[j] = TB::frag(b_l, wn * NJ + j, kk, lane);
+        for (int j = 0; j < NJ; ++j) bf[j] = TB::frag(b_l, ILV ? (j >> 1) * 4 + (j & 1) * 2 + wn : wn * NJ + j, kk, lane);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -469,13 +510,15 @@ __global__ void __launch_bounds__(WM * WN * 64, ((WM * WN) >= 8 ? 2 : 1) * BPC) 
     cslot = cslot == NSLOT - 1 ? 0 : cslot + 1;
     if (++ck == cc.nk) {
       const GemmProblem& P = g.p[cc.pi];
-      store_tile<EPI, MI, NJ>(acc, P, P.M, P.N, cc.m0 + wm * (MI * 16), cc.n0 + wn * (NJ * 16), lane);
+      if (g.ablate != 32 || acc[0][0][0] == 123.456f)
+        store_tile<EPI, MI, NJ, ILV>(acc, P, P.M, P.N, cc.m0 + wm * (MI * 16), cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, g.ablate == 16, wn * 16);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       ck = 0;
       ++cr;
+      loose = 8;
       cvalid = tile_at(cr, cc);
     }
   }
@@ -495,7 +538,7 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
   if (total == 0) return 0;
   constexpr int SMEM = kStages * (BM + BN) * 128;
   constexpr int PSMEM = persist_slots((BM + BN) * 128) * (BM + BN) * 128;
-  bool persist = split_k <= 1 && EPI != GGET_EPI_ATOMIC_F32 && EPI != GGET_EPI_SLAB_F32 && !g.ablate && getenv("GGET_GEMM_NO_PERSIST") == nullptr;
+  bool persist = split_k <= 1 && EPI != GGET_EPI_ATOMIC_F32 && EPI != GGET_EPI_SLAB_F32 && (!g.ablate || g.ablate >= 8) && getenv("GGET_GEMM_NO_PERSIST") == nullptr;
   for (int i = 0; i < g.count; ++i)
     persist = persist && g.p[i].m_dev == nullptr && g.p[i].k_dev == nullptr && (g.p[i].K % 64) == 0 && g.p[i].K >= 64;
   if (persist) {
@@ -536,6 +579,42 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
           a2 = true;
         }
         hipLaunchKernelGGL((gemm_persist_kernel<256, 256, 32, 2, 4, A_MC, B_MC, EPI>), dim3(G2), dim3(512), SM2, st, g, tot2);
+        GGET_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+    // 128x192 tile for the N = d outputs (o/down projections and the dgrads into the residual stream): M/128 x N/192
+    // tiles fill the chip where 256x128 leaves a quarter of the CUs idle (8192 x 768: 256 tiles vs 192)
+    if constexpr (!A_MC && (EPI == GGET_EPI_NONE || EPI == GGET_EPI_RESIDUAL || EPI == GGET_EPI_ROPE)) {
+      static int use192 = -1;
+      if (use192 < 0) { const char* e = getenv("GGET_GEMM_192"); use192 = e ? atoi(e) : 1; }
+      bool ok = use192 != 0;
+      long t192 = 0;
+      for (int i = 0; i < g.count; ++i) {
+        ok = ok && (g.p[i].N % 192) == 0;
+        t192 += (long)((g.p[i].M + 127) / 128) * (g.p[i].N / 192);
+      }
+      // rounds x tile area: take 128x192 when it needs less per-CU work than the default tile
+      const long cur_rounds = (total + num_cu - 1) / num_cu, r192 = (t192 + num_cu - 1) / num_cu;
+      if (ok && r192 * 128 * 192 < cur_rounds * BM * BN) {
+        constexpr int SM3 = persist_slots((128 + 192) * 128) * (128 + 192) * 128;
+        int tot3 = 0;
+        for (int i = 0; i < g.count; ++i) {
+          GemmProblem& p = g.p[i];
+          p.tiles_n = p.N / 192;
+          p.tile_begin = tot3;
+          tot3 += ((p.M + 127) / 128) * p.tiles_n;
+        }
+        int G3 = tot3 < num_cu ? tot3 : num_cu;
+        G3 = (G3 + 7) & ~7;
+        static bool a3 = false;
+        if (!a3) {
+          GGET_HIP_CHECK(hipFuncSetAttribute(
+              reinterpret_cast<const void*>(&gemm_persist_kernel<128, 192, 64, 4, 2, A_MC, B_MC, EPI>),
+              hipFuncAttributeMaxDynamicSharedMemorySize, SM3));
+          a3 = true;
+        }
+        hipLaunchKernelGGL((gemm_persist_kernel<128, 192, 64, 4, 2, A_MC, B_MC, EPI>), dim3(G3), dim3(512), SM3, st, g, tot3);
         GGET_LAUNCH_CHECK();
         return 0;
       }

@@ -178,6 +178,11 @@ int gget_hidden_states(gget_handle_t h, const void** hidden_dev);
 #define GGET_EPI_SLAB_F32 3 /* C is fp32 [split_k][M][ldc]: slice s of K writes slab s (reduced by the caller) */
 int gget_op_gemm(int mode, int epilogue, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
                  int lda, int ldb, int ldc, int split_k, void* stream);
+/* replaces: q_proj/k_proj/v_proj + apply_rotary_pos_emb (hf LlamaAttention.forward :253-262, :138-160) as ONE GEMM:
+ * qkv[T,3d] = x[T,d] * wqkv[3d,d]^T with RoPE applied to the q|k columns in the fp32 accumulators (position of row t is
+ * position_ids[t], or t % S when position_ids is NULL; cos/sin tables [max_position][32] fp32). */
+int gget_op_qkv_rope(const void* x, const void* wqkv, void* qkv, const float* cos_tab, const float* sin_tab,
+                     const int64_t* position_ids, int T, int S, int d, void* stream);
 int gget_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, void* stream);
 int gget_op_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
                         void* dx, float* dw_accum, int T, int d, void* stream);

@@ -83,6 +83,18 @@ def test_gemm_residual_and_atomic(lib):
     assert rel_l2(Cs.sum(0).cpu().numpy(), ref2.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("mode", [L.GEMM_NT, L.GEMM_NN])
+@pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (1000, 768, 256), (40000, 384, 128)])
+def test_gemm_tile_128x192(lib, mode, M, N, K):
+    # N = d outputs take the 128x192 persistent tile (N % 192 == 0); residual epilogue, ragged M, several tiles per block
+    A, R = rnd(M, K, seed=11), rnd(M, N, seed=13)
+    B = rnd(N, K, seed=12) if mode == L.GEMM_NT else rnd(K, N, seed=12)
+    ref = A.float() @ (B.float().T if mode == L.GEMM_NT else B.float()) + R.float()
+    Cm = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.gget_op_gemm(mode, L.EPI_RESIDUAL, P(A), P(B), P(Cm), P(R), M, N, K, K, K if mode == L.GEMM_NT else N, N, 1, ST()))
+    assert rel_l2(Cm.float().cpu().numpy(), ref.cpu().numpy()) < 4e-3
+
+
 def test_gemm_identity_layout(lib):
     # A = I with an asymmetric B: the output must be B^T exactly (bit-exact, catches row/col swaps)
     n = 128
@@ -188,6 +200,25 @@ def test_rope(lib, with_pos):
     # inverse rotation brings q,k back (orthogonality), up to two bf16 roundings
     L.check(lib.gget_op_rope(P(qkv), P(cos), P(sin), P(pos), B, S, H, 1, ST()))
     assert rel_l2(qkv.float().cpu().numpy(), orig.float().cpu().numpy()) < 6e-3
+
+
+@pytest.mark.parametrize("B,S,d,with_pos", [(3, 40, 128, True), (64, 32, 768, False), (256, 32, 768, True), (128, 64, 384, False),
+                                            (16, 72, 1024, True), (64, 64, 1024, True)])
+def test_qkv_rope_fused(lib, B, S, d, with_pos):
+    """q|k|v projection with RoPE in the GEMM epilogue (every tile shape the launcher picks: 128x128, 256x128 and the
+    interleaved 128x192, incl. a 192-wide tile that straddles the k|v boundary) vs projection in fp32 followed by
+    hf apply_rotary_pos_emb; v columns stay un-rotated."""
+    T, H = B * S, d // 64
+    x, w = rnd(T, d, seed=21), rnd(3 * d, d, scale=d ** -0.5, seed=22)
+    g = torch.Generator().manual_seed(5)
+    pos = torch.stack([torch.randperm(S + 7, generator=g)[:S] for _ in range(B)]).cuda() if with_pos else None
+    cos, sin = _tables(max(1024, S + 16))
+    qkv = torch.empty(T, 3 * d, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.gget_op_qkv_rope(P(x), P(w), P(qkv), P(cos), P(sin), P(pos) if with_pos else None, T, S, d, ST()))
+    ref = (x.float() @ w.float().T).view(B, S, 3, H, 64)
+    pr = pos if with_pos else torch.arange(S, device="cuda")[None].expand(B, S)
+    want = torch.stack([_rope_ref(ref[:, :, 0], pr), _rope_ref(ref[:, :, 1], pr), ref[:, :, 2]], dim=2).reshape(T, 3 * d)
+    assert rel_l2(qkv.float().cpu().numpy(), want.cpu().numpy()) < 4e-3
 
 
 def _attn_ref(qkv, lens, B, S, H, causal):

@@ -141,7 +141,7 @@ struct Ws {
   std::vector<uint64_t> xres;  // L+1 residual-stream snapshots
   std::vector<LayerWs> lw;
   uint64_t rstd_f, hidden;
-  uint64_t dxa, dxb, dxc, dxn, dqkv, dattn, dgu, dh, delta, dscaled;
+  uint64_t dxa, dxb, dxc, dxn, dqkv, dattn, dgu, dh, delta, dscaled, dscaled2;
   uint64_t scratch32, loss_sum, sqnorm, counts, segs, emb_sort, wg32, lm_slab;
   // pre-train head
   uint64_t cnt, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
@@ -189,6 +189,7 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.dh = b.take(T * ff * 2);
   w.delta = b.take(T * H * 4);
   w.dscaled = pl.has_res ? b.take(T * d * 2) : 0;
+  w.dscaled2 = pl.has_res ? b.take(T * d * 2) : 0;
   w.scratch32 = b.take(pl.n_scratch32 * 4);
   w.loss_sum = b.take(256);
   w.sqnorm = b.take(256);
@@ -668,8 +669,7 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
     hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), 0, st, dx_out, h->wsp<bf16_t>(lw.mraw),
                        h->plan.has_ls ? h->P + lo.lam2 : nullptr, dsc, h->plan.has_ls ? s32 + lo.lam2_32 : nullptr, T, d,
                        h->path_drop(i, 1));
-    // the grouped wgrad at the end needs this buffer alive; reuse dattn's slot later for the o_proj one
-    dy_down = dsc;
+    dy_down = dsc;   // stays alive for the grouped wgrad at the end of the layer (the o_proj branch has its own buffer)
   }
   // MLP: dh = dy_down W_down ; dgu = geglu'(dh) ; dxn2 = dgu W_gu
   if (int e = gemm_nn(dy_down, h->P + lo.wdown, dh, T, ff, d, d, ff, ff, nullptr, st)) return e;
@@ -677,18 +677,9 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   if (int e = gemm_nn(dgu, h->P + lo.wgu, dxn, T, d, 2 * ff, 2 * ff, d, d, nullptr, st)) return e;
   if (int e = k_rmsnorm_bwd(dxn, xmid, h->P + lo.ln2, h->wsp<float>(lw.rstd2), dx_out, dx_mid, s32 + lo.ln2_32, T, d, st))
     return e;
-  // wgrad of the MLP now (its dY buffers get reused below when LayerScale is on)
-  {
-    GemmGroup g;
-    memset(&g, 0, sizeof(g));
-    g.count = 2;
-    g.p[0] = GemmProblem{dgu, h->wsp<bf16_t>(lw.xn2), h->G + lo.wgu, nullptr, 2 * ff, d, T, 2 * ff, d, d, nullptr, nullptr, 0, 0};
-    g.p[1] = GemmProblem{dy_down, h->wsp<bf16_t>(lw.h), h->G + lo.wdown, nullptr, d, ff, T, d, ff, ff, nullptr, nullptr, 0, 0};
-    if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_NONE, g, 1, st)) return e;
-  }
   dy_o = dx_mid;
   if (h->plan.has_res) {
-    bf16_t* dsc = h->wsp<bf16_t>(w.dscaled);
+    bf16_t* dsc = h->wsp<bf16_t>(w.dscaled2);
     hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), 0, st, dx_mid, h->wsp<bf16_t>(lw.araw),
                        h->plan.has_ls ? h->P + lo.lam1 : nullptr, dsc, h->plan.has_ls ? s32 + lo.lam1_32 : nullptr, T, d,
                        h->path_drop(i, 0));
@@ -703,7 +694,29 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   if (int e = gemm_nn(dqkv, h->P + lo.wqkv, dxn, T, d, 3 * d, 3 * d, d, d, nullptr, st)) return e;
   if (int e = k_rmsnorm_bwd(dxn, x_in, h->P + lo.ln1, h->wsp<float>(lw.rstd1), dx_mid, dx_in, s32 + lo.ln1_32, T, d, st))
     return e;
-  {
+  // weight gradients of the layer (dW = dY^T X, K = T).  All four dY / X pairs are still alive here.
+  const GemmProblem wg_gu{dgu, h->wsp<bf16_t>(lw.xn2), h->G + lo.wgu, nullptr, 2 * ff, d, T, 2 * ff, d, d, nullptr, nullptr, 0, 0};
+  const GemmProblem wg_dn{dy_down, h->wsp<bf16_t>(lw.h), h->G + lo.wdown, nullptr, d, ff, T, d, ff, ff, nullptr, nullptr, 0, 0};
+  if (d % 192 == 0 && ff % 192 == 0) {
+    // one persistent launch of 192x192 tiles over gate|up, down, q|k|v and o: (2ff*d + d*ff + 4d*d) / 192^2 tiles, which for
+    // d = 768 is exactly 256 - every CU owns one tile and walks the full K, no split-K slabs, no reduce pass
+    GemmGroup g;
+    memset(&g, 0, sizeof(g));
+    g.count = 4;
+    g.p[0] = wg_gu;
+    g.p[1] = wg_dn;
+    g.p[2] = GemmProblem{dqkv, h->wsp<bf16_t>(lw.xn1), h->G + lo.wqkv, nullptr, 3 * d, d, T, 3 * d, d, d, nullptr, nullptr, 0, 0};
+    g.p[3] = GemmProblem{dy_o, h->wsp<bf16_t>(lw.attn), h->G + lo.wo, nullptr, d, d, T, d, d, d, nullptr, nullptr, 0, 0};
+    if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_NONE, g, 1, st)) return e;
+  } else {
+    {
+      GemmGroup g;
+      memset(&g, 0, sizeof(g));
+      g.count = 2;
+      g.p[0] = wg_gu;
+      g.p[1] = wg_dn;
+      if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_NONE, g, 1, st)) return e;
+    }
     // wgrad of q|k|v and o: only 72 output tiles of 256x128 with K = T, so K is cut into kWgSplit slices (216 blocks);
     // every slice writes its own fp32 slab with wide stores (fp32 atomics are ~3x slower: one TA op per 4 bytes) and a
     // small kernel sums the slabs into the bf16 gradient array (q|k|v|o are contiguous there).

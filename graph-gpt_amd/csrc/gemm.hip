@@ -619,6 +619,41 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
         return 0;
       }
     }
+    // 192x192 tile for the weight gradients (TN, K = T): for d = 768 the four wgrads of a decoder layer
+    // (gate|up 6144x768, down 768x3072, q|k|v 2304x768, o 768x768) are exactly 256 such tiles - one per CU, full K,
+    // no split-K slabs.  Taken whenever it needs less per-CU work than the 256x128 tiling.
+    if constexpr (A_MC && B_MC && EPI == GGET_EPI_NONE) {
+      static int use192 = -1;
+      if (use192 < 0) { const char* e = getenv("GGET_GEMM_192"); use192 = e ? atoi(e) : 1; }
+      bool ok = use192 != 0;
+      long t192 = 0;
+      for (int i = 0; i < g.count; ++i) {
+        ok = ok && (g.p[i].N % 192) == 0 && (g.p[i].M % 192) == 0;
+        t192 += (long)(g.p[i].M / 192) * (g.p[i].N / 192);
+      }
+      const long cur_rounds = (total + num_cu - 1) / num_cu, r192 = (t192 + num_cu - 1) / num_cu;
+      if (ok && r192 * 192 * 192 < cur_rounds * BM * BN) {
+        constexpr int SM4 = 3 * (192 + 192) * 128;
+        int tot4 = 0;
+        for (int i = 0; i < g.count; ++i) {
+          GemmProblem& p = g.p[i];
+          p.tiles_n = p.N / 192;
+          p.tile_begin = tot4;
+          tot4 += (p.M / 192) * p.tiles_n;
+        }
+        int G4 = tot4 < num_cu ? tot4 : num_cu;
+        G4 = (G4 + 7) & ~7;
+        static bool a4 = false;
+        if (!a4) {
+          GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<192, 192, 64, 4, 2, true, true, EPI>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, SM4));
+          a4 = true;
+        }
+        hipLaunchKernelGGL((gemm_persist_kernel<192, 192, 64, 4, 2, true, true, EPI>), dim3(G4), dim3(512), SM4, st, g, tot4);
+        GGET_LAUNCH_CHECK();
+        return 0;
+      }
+    }
     static bool pattr_done = false;
     if (!pattr_done) {
       GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BM, BN, 64, WM, WN, A_MC, B_MC, EPI>),

@@ -95,6 +95,16 @@ def test_gemm_tile_128x192(lib, mode, M, N, K):
     assert rel_l2(Cm.float().cpu().numpy(), ref.cpu().numpy()) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(1536, 768, 2048), (768, 3072, 1024), (768, 768, 8192), (6144, 768, 512)])
+def test_gemm_tn_tile_192x192(lib, M, N, K):
+    # weight-gradient shapes (M, N multiples of 192) take the 192x192 persistent TN tile when it fills the chip better
+    A, B = rnd(K, M, seed=31), rnd(K, N, seed=32)
+    ref = A.float().T @ B.float()
+    Cm = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.gget_op_gemm(L.GEMM_TN, L.EPI_NONE, P(A), P(B), P(Cm), None, M, N, K, M, N, N, 1, ST()))
+    assert rel_l2(Cm.float().cpu().numpy(), ref.cpu().numpy()) < 4e-3
+
+
 def test_gemm_identity_layout(lib):
     # A = I with an asymmetric B: the output must be B^T exactly (bit-exact, catches row/col swaps)
     n = 128

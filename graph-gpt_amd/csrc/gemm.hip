@@ -48,6 +48,23 @@ __device__ __forceinline__ void glds16(const void* gsrc, const unsigned char* ld
       : "v"(gsrc), "s"(dst)
       : "memory");
 }
+// same, address = uniform 64-bit base (SGPR pair) + per-lane unsigned 32-bit byte offset: nothing to compute per K-tile
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, const unsigned char* lds_dst) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(LDS_AS const void*)lds_dst);
+  const unsigned long long b = (unsigned long long)(uintptr_t)sbase;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sb), "s"(dst)
+      : "memory");
+}
 template <int N>
 __device__ __forceinline__ void vm_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -94,7 +111,11 @@ struct TileIO {
   __device__ __forceinline__ static void glds(unsigned char* lds, const bf16_t* __restrict__ base, int ld, int row0,
                                               int row_lim, int k0, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
+    for (int i = 0; i < PIECES; ++i) glds_piece(lds, base, ld, row0, row_lim, k0, wave, lane, i);
+  }
+  __device__ __forceinline__ static void glds_piece(unsigned char* lds, const bf16_t* __restrict__ base, int ld, int row0,
+                                                    int row_lim, int k0, int wave, int lane, int i) {
+    {
       const int q = wave + i * NWAVES;
       const bf16_t* p;
       if (!MC) {
@@ -113,6 +134,30 @@ struct TileIO {
       }
       glds16(p, lds + q * 1024);
     }
+  }
+  // The same DMA split into a per-tile part (the lane's byte offset from the K-origin of the operand, < 4 GiB) and a
+  // per-K-tile part (the uniform K-origin): the persistent kernel computes the offsets once per output tile.
+  __device__ __forceinline__ static unsigned piece_off(int ld, int row0, int row_lim, int wave, int lane, int i) {
+    const int q = wave + i * NWAVES;
+    if (!MC) {
+      const int r = q * RPP + lane / CR;
+      const int lc = (lane % CR) ^ kc_swz(r);
+      const int gr = min(row0 + r, row_lim - 1);
+      return ((unsigned)gr * (unsigned)ld + (unsigned)(lc * 8)) * 2u;
+    } else {
+      const int c = q * 64 + lane;
+      const int kr = c / CPR;
+      const int sl = c % CPR;
+      const int lw = mc_src_win(kr, sl >> 1);
+      const int gm = min(row0 + lw * 16 + (sl & 1) * 8, ((row_lim + 7) & ~7) - 8);
+      return ((unsigned)kr * (unsigned)ld + (unsigned)gm) * 2u;
+    }
+  }
+  __device__ __forceinline__ static const bf16_t* k_origin(const bf16_t* base, int ld, int k0) {
+    return MC ? base + (size_t)k0 * ld : base + k0;
+  }
+  __device__ __forceinline__ static void glds_at(unsigned char* lds, const bf16_t* korg, unsigned voff, int wave, int i) {
+    glds16s(korg, voff, lds + (wave + i * NWAVES) * 1024);
   }
   // global -> registers (zero fill outside [row_lim) x [k_lim)) : used for a partial last K tile only
   __device__ __forceinline__ static void load(uint4 (&r)[PER_THREAD], const bf16_t* __restrict__ base, int ld,
@@ -422,8 +467,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const
 // first/last are hidden (at K = 768 they are ~30 % of a non-persistent tile's life).
 // Counted waits stay valid with stores in flight: vmcnt <= PIECES means >= (stores + PIECES) older operations have
 // retired, and loads retire in order among themselves, so the oldest PIECES loads (the tile being waited for) are in.
-template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0, int BPC = 1>
-__global__ void __launch_bounds__(WM * WN * 64, ((WM * WN) >= 8 ? 2 : 1) * BPC) gemm_persist_kernel(const GemmGroup g, int total_tiles) {
+template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0>
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_persist_kernel(const GemmGroup g, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = WM * WN * 64;
   using TA = TileIO<BM, A_MC, NT, BK>;
@@ -468,27 +513,69 @@ __global__ void __launch_bounds__(WM * WN * 64, ((WM * WN) >= 8 ? 2 : 1) * BPC) 
   bool ivalid = tile_at(0, ic);
   bool cvalid = ivalid;
   cc = ic;
-  int islot = 0, cslot = 0, inflight = 0, loose = 0;
-  auto issue_next = [&]() {
+  int islot = 0, cslot = 0, inflight = 0;
+  // issue side: operand bases / leading dims of the tile being streamed and the per-lane DMA offsets, refreshed only
+  // when the stream moves on to the next output tile (a K-tile's DMA is then PIECES x {M0, global_load_lds})
+  const bf16_t* iA = nullptr;
+  const bf16_t* iB = nullptr;
+  int ilda = 0, ildb = 0;
+  unsigned offA[TA::PIECES], offB[TB::PIECES];
+  auto load_issue_tile = [&]() {
     if (!ivalid) return;
     const GemmProblem& P = g.p[ic.pi];
-    unsigned char* s = smem + islot * STAGE;
-    TA::glds(s, P.A, P.lda, ic.m0, P.M, ik * BK, wave, lane);
-    TB::glds(s + A_BYTES, P.B, P.ldb, ic.n0, P.N, ik * BK, wave, lane);
+    iA = P.A; iB = P.B; ilda = P.lda; ildb = P.ldb;
+#pragma unroll
+    for (int i = 0; i < TA::PIECES; ++i) offA[i] = TA::piece_off(P.lda, ic.m0, P.M, wave, lane, i);
+#pragma unroll
+    for (int i = 0; i < TB::PIECES; ++i) offB[i] = TB::piece_off(P.ldb, ic.n0, P.N, wave, lane, i);
+  };
+  load_issue_tile();
+  auto issue_piece = [&](int q) {       // piece q of the K-tile (ic, ik) into slot islot
+    unsigned char* sl = smem + islot * STAGE;
+    if (q < TA::PIECES) TA::glds_at(sl, TA::k_origin(iA, ilda, ik * BK), offA[q < TA::PIECES ? q : 0], wave, q);
+    else TB::glds_at(sl + A_BYTES, TB::k_origin(iB, ildb, ik * BK), offB[q >= TA::PIECES ? q - TA::PIECES : 0], wave, q - TA::PIECES);
+  };
+  auto issue_advance = [&]() {
     islot = islot == NSLOT - 1 ? 0 : islot + 1;
     ++inflight;
-    if (++ik == ic.nk) { ik = 0; ++ir; ivalid = tile_at(ir, ic); }
+    if (++ik == ic.nk) { ik = 0; ++ir; ivalid = tile_at(ir, ic); load_issue_tile(); }
+  };
+  auto issue_next = [&]() {
+    if (!ivalid) return;
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) issue_piece(q);
+    issue_advance();
   };
 #pragma unroll
   for (int i = 0; i < NSLOT - 1; ++i) issue_next();
-  while (cvalid) {
-    // the oldest K-tile in flight must have landed: allow (inflight-1) younger tiles' pieces to stay outstanding
-    if (g.ablate == 8 && loose > 0) { vm_wait<(2 * PIECES + MI * NJ / 2 > 63 ? 63 : 2 * PIECES + MI * NJ / 2)>(); --loose; }  // timing experiment only
-    else if (inflight >= 3) vm_wait<2 * PIECES>();
+  // wait until this wave's pieces of the OLDEST K-tile in flight have landed: the (inflight - 1) younger K-tiles may
+  // stay outstanding (stores in flight only make the count conservative, see above)
+  auto wait_oldest = [&]() {
+    if (NSLOT > 3 && inflight >= 4) vm_wait<3 * PIECES>();
+    else if (inflight == 3) vm_wait<2 * PIECES>();
     else if (inflight == 2) vm_wait<PIECES>();
     else vm_wait<0>();
+  };
+  auto finish_tile = [&]() {
+    const GemmProblem& P = g.p[cc.pi];
+    if (g.ablate != 32 || acc[0][0][0] == 123.456f)
+      store_tile<EPI, MI, NJ, ILV>(acc, P, P.M, P.N, cc.m0 + wm * (MI * 16), cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, g.ablate == 16, wn * 16);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    ck = 0;
+    ++cr;
+    cvalid = tile_at(cr, cc);
+  };
+  while (cvalid) {
+    wait_oldest();
     __syncthreads();   // publishes that tile; also every wave is done with the slot consumed last iteration
-    issue_next();      // ... which is the slot refilled here
+    // ... which is the slot refilled here.  Measured alternatives that were slower: spreading the DMA pieces between
+    // the MFMA groups (-5..20 %), and a ping-pong schedule with the two waves of a SIMD half a K-tile apart (two
+    // barriers per K-tile; in-kernel s_memtime stamps showed MFMA issue stretching to ~24 cycles beside the partner's
+    // DMA / ds_read traffic): -5..15 % except on the 256x256 tile (+2 %).
+    issue_next();
     --inflight;
     {
       const unsigned char* a_l = smem + cslot * STAGE;
@@ -508,20 +595,26 @@ __global__ void __launch_bounds__(WM * WN * 64, ((WM * WN) >= 8 ? 2 : 1) * BPC) 
       }
     }
     cslot = cslot == NSLOT - 1 ? 0 : cslot + 1;
-    if (++ck == cc.nk) {
-      const GemmProblem& P = g.p[cc.pi];
-      if (g.ablate != 32 || acc[0][0][0] == 123.456f)
-        store_tile<EPI, MI, NJ, ILV>(acc, P, P.M, P.N, cc.m0 + wm * (MI * 16), cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, g.ablate == 16, wn * 16);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      ck = 0;
-      ++cr;
-      loose = 8;
-      cvalid = tile_at(cr, cc);
-    }
+    if (++ck == cc.nk) finish_tile();
   }
+}
+
+// launch one persistent configuration: one block per CU (grid rounded to the 8 XCDs)
+template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI>
+int launch_persist_cfg(GemmGroup& g, int total, int num_cu, hipStream_t st) {
+  constexpr int STG = (BM + BN) * BK * 2;
+  constexpr int SM = persist_slots(STG) * STG;
+  int G = total < num_cu ? total : num_cu;
+  G = (G + 7) & ~7;  // the XCD permutation needs a multiple of 8 (idle blocks exit at once)
+  static bool attr0 = false;
+  if (!attr0) {
+    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BM, BN, BK, WM, WN, A_MC, B_MC, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SM));
+    attr0 = true;
+  }
+  hipLaunchKernelGGL((gemm_persist_kernel<BM, BN, BK, WM, WN, A_MC, B_MC, EPI>), dim3(G), dim3(WM * WN * 64), SM, st, g, total);
+  GGET_LAUNCH_CHECK();
+  return 0;
 }
 
 template <int WM, int WN, bool A_MC, bool B_MC, int EPI>
@@ -537,10 +630,11 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
   }
   if (total == 0) return 0;
   constexpr int SMEM = kStages * (BM + BN) * 128;
-  constexpr int PSMEM = persist_slots((BM + BN) * 128) * (BM + BN) * 128;
   bool persist = split_k <= 1 && EPI != GGET_EPI_ATOMIC_F32 && EPI != GGET_EPI_SLAB_F32 && (!g.ablate || g.ablate >= 8) && getenv("GGET_GEMM_NO_PERSIST") == nullptr;
   for (int i = 0; i < g.count; ++i)
-    persist = persist && g.p[i].m_dev == nullptr && g.p[i].k_dev == nullptr && (g.p[i].K % 64) == 0 && g.p[i].K >= 64;
+    persist = persist && g.p[i].m_dev == nullptr && g.p[i].k_dev == nullptr && (g.p[i].K % 64) == 0 && g.p[i].K >= 64 &&
+              // per-lane DMA offsets are unsigned 32-bit byte offsets from the operand's K-origin
+              ((size_t)g.p[i].M + 64) * (size_t)g.p[i].lda * 2 < (1ull << 32) && ((size_t)g.p[i].N + 64) * (size_t)g.p[i].ldb * 2 < (1ull << 32);
   if (persist) {
     static int num_cu = 0;
     if (!num_cu) {
@@ -561,7 +655,6 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
       }
       // measured (profiles/r01_gemm_tiles.txt): pays only with >= ~2.5 tiles per CU (FFN gate|up), loses on N = 2304 / 3072
       if (ok256 && t256 >= (5 * num_cu) / 2) {
-        constexpr int SM2 = persist_slots((256 + 256) * 32 * 2) * (256 + 256) * 32 * 2;
         int tot2 = 0;
         for (int i = 0; i < g.count; ++i) {
           GemmProblem& p = g.p[i];
@@ -569,18 +662,7 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
           p.tile_begin = tot2;
           tot2 += ((p.M + 255) / 256) * p.tiles_n;
         }
-        int G2 = tot2 < num_cu ? tot2 : num_cu;
-        G2 = (G2 + 7) & ~7;
-        static bool a2 = false;
-        if (!a2) {
-          GGET_HIP_CHECK(hipFuncSetAttribute(
-              reinterpret_cast<const void*>(&gemm_persist_kernel<256, 256, 32, 2, 4, A_MC, B_MC, EPI>),
-              hipFuncAttributeMaxDynamicSharedMemorySize, SM2));
-          a2 = true;
-        }
-        hipLaunchKernelGGL((gemm_persist_kernel<256, 256, 32, 2, 4, A_MC, B_MC, EPI>), dim3(G2), dim3(512), SM2, st, g, tot2);
-        GGET_LAUNCH_CHECK();
-        return 0;
+        return launch_persist_cfg<256, 256, 32, 2, 4, A_MC, B_MC, EPI>(g, tot2, num_cu, st);
       }
     }
     // 128x192 tile for the N = d outputs (o/down projections and the dgrads into the residual stream): M/128 x N/192
@@ -597,7 +679,6 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
       // rounds x tile area: take 128x192 when it needs less per-CU work than the default tile
       const long cur_rounds = (total + num_cu - 1) / num_cu, r192 = (t192 + num_cu - 1) / num_cu;
       if (ok && r192 * 128 * 192 < cur_rounds * BM * BN) {
-        constexpr int SM3 = persist_slots((128 + 192) * 128) * (128 + 192) * 128;
         int tot3 = 0;
         for (int i = 0; i < g.count; ++i) {
           GemmProblem& p = g.p[i];
@@ -605,18 +686,7 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
           p.tile_begin = tot3;
           tot3 += ((p.M + 127) / 128) * p.tiles_n;
         }
-        int G3 = tot3 < num_cu ? tot3 : num_cu;
-        G3 = (G3 + 7) & ~7;
-        static bool a3 = false;
-        if (!a3) {
-          GGET_HIP_CHECK(hipFuncSetAttribute(
-              reinterpret_cast<const void*>(&gemm_persist_kernel<128, 192, 64, 4, 2, A_MC, B_MC, EPI>),
-              hipFuncAttributeMaxDynamicSharedMemorySize, SM3));
-          a3 = true;
-        }
-        hipLaunchKernelGGL((gemm_persist_kernel<128, 192, 64, 4, 2, A_MC, B_MC, EPI>), dim3(G3), dim3(512), SM3, st, g, tot3);
-        GGET_LAUNCH_CHECK();
-        return 0;
+        return launch_persist_cfg<128, 192, 64, 4, 2, A_MC, B_MC, EPI>(g, tot3, num_cu, st);
       }
     }
     // 192x192 tile for the weight gradients (TN, K = T): for d = 768 the four wgrads of a decoder layer
@@ -633,7 +703,6 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
       }
       const long cur_rounds = (total + num_cu - 1) / num_cu, r192 = (t192 + num_cu - 1) / num_cu;
       if (ok && r192 * 192 * 192 < cur_rounds * BM * BN) {
-        constexpr int SM4 = 3 * (192 + 192) * 128;
         int tot4 = 0;
         for (int i = 0; i < g.count; ++i) {
           GemmProblem& p = g.p[i];
@@ -641,30 +710,10 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
           p.tile_begin = tot4;
           tot4 += (p.M / 192) * p.tiles_n;
         }
-        int G4 = tot4 < num_cu ? tot4 : num_cu;
-        G4 = (G4 + 7) & ~7;
-        static bool a4 = false;
-        if (!a4) {
-          GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<192, 192, 64, 4, 2, true, true, EPI>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, SM4));
-          a4 = true;
-        }
-        hipLaunchKernelGGL((gemm_persist_kernel<192, 192, 64, 4, 2, true, true, EPI>), dim3(G4), dim3(512), SM4, st, g, tot4);
-        GGET_LAUNCH_CHECK();
-        return 0;
+        return launch_persist_cfg<192, 192, 64, 4, 2, true, true, EPI>(g, tot4, num_cu, st);
       }
     }
-    static bool pattr_done = false;
-    if (!pattr_done) {
-      GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BM, BN, 64, WM, WN, A_MC, B_MC, EPI>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, PSMEM));
-      pattr_done = true;
-    }
-    int G = total < num_cu ? total : num_cu;
-    G = (G + 7) & ~7;  // the XCD permutation needs a multiple of 8 (idle blocks exit at once)
-    hipLaunchKernelGGL((gemm_persist_kernel<BM, BN, 64, WM, WN, A_MC, B_MC, EPI>), dim3(G), dim3(WM * WN * 64), PSMEM, st, g, total);
-    GGET_LAUNCH_CHECK();
-    return 0;
+    return launch_persist_cfg<BM, BN, 64, WM, WN, A_MC, B_MC, EPI>(g, total, num_cu, st);
   }
   static bool attr_done = false;
   if (!attr_done) {

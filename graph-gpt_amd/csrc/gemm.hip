@@ -414,10 +414,20 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
   };
+  // per-lane DMA offsets of this block's tile (fixed), K-origin advanced per K-tile (uniform)
+  unsigned offA[TA::PIECES], offB[TB::PIECES];
+#pragma unroll
+  for (int i = 0; i < TA::PIECES; ++i) offA[i] = TA::piece_off(P.lda, m0, M, wave, lane, i);
+#pragma unroll
+  for (int i = 0; i < TB::PIECES; ++i) offB[i] = TB::piece_off(P.ldb, n0, N, wave, lane, i);
   auto issue = [&](int t, int slot) {
     unsigned char* s = smem + slot * STAGE;
-    TA::glds(s, P.A, P.lda, m0, M, kbeg + t * 64, wave, lane);
-    TB::glds(s + A_BYTES, P.B, P.ldb, n0, N, kbeg + t * 64, wave, lane);
+    const bf16_t* ka = TA::k_origin(P.A, P.lda, kbeg + t * 64);
+    const bf16_t* kb = TB::k_origin(P.B, P.ldb, kbeg + t * 64);
+#pragma unroll
+    for (int i = 0; i < TA::PIECES; ++i) TA::glds_at(s, ka, offA[i], wave, i);
+#pragma unroll
+    for (int i = 0; i < TB::PIECES; ++i) TB::glds_at(s + A_BYTES, kb, offB[i], wave, i);
   };
 
   const int nfull = (kend - kbeg) >> 6;
@@ -666,9 +676,7 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
   constexpr int SMEM = kStages * (BM + BN) * 128;
   bool persist = split_k <= 1 && EPI != GGET_EPI_ATOMIC_F32 && EPI != GGET_EPI_SLAB_F32 && (!g.ablate || g.ablate >= 8) && getenv("GGET_GEMM_NO_PERSIST") == nullptr;
   for (int i = 0; i < g.count; ++i)
-    persist = persist && g.p[i].m_dev == nullptr && g.p[i].k_dev == nullptr && (g.p[i].K % 64) == 0 && g.p[i].K >= 64 &&
-              // per-lane DMA offsets are unsigned 32-bit byte offsets from the operand's K-origin
-              ((size_t)g.p[i].M + 64) * (size_t)g.p[i].lda * 2 < (1ull << 32) && ((size_t)g.p[i].N + 64) * (size_t)g.p[i].ldb * 2 < (1ull << 32);
+    persist = persist && g.p[i].m_dev == nullptr && g.p[i].k_dev == nullptr && (g.p[i].K % 64) == 0 && g.p[i].K >= 64;
   if (persist) {
     static int num_cu = 0;
     if (!num_cu) {
@@ -803,6 +811,9 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
     const GemmProblem& p = g.p[i];
     GGET_REQUIRE((p.lda % 8) == 0 && (p.ldb % 8) == 0 && (p.ldc % 8) == 0 && (p.N % 4) == 0,
                  "gemm: leading dims must be multiples of 8 (lda %d ldb %d ldc %d N %d)", p.lda, p.ldb, p.ldc, p.N);
+    // the LDS-DMA addresses are a uniform 64-bit K-origin plus an unsigned 32-bit per-lane byte offset
+    GGET_REQUIRE(((size_t)p.M + 64) * (size_t)p.lda * 2 < (1ull << 32) && ((size_t)p.N + 64) * (size_t)p.ldb * 2 < (1ull << 32),
+                 "gemm: operand spans more than 4 GiB (M %d lda %d N %d ldb %d)", p.M, p.lda, p.N, p.ldb);
   }
   switch (mode) {
     case GGET_GEMM_NT: return launch_mode<false, false>(g, epi, split_k, st);

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libgget_hip.so")
+LIB_PATH = os.environ.get("GGET_LIB_PATH") or os.path.join(HERE, "lib", "libgget_hip.so")   # override: A/B builds in one run
 
 i32, i64, u64, f32, vp, cp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p, C.c_char_p
 

@@ -14,16 +14,17 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 __device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((unsigned)x) << 16); }
 
 // round-to-nearest-even f32 -> bf16 (NaN kept quiet)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two values per
+// instruction; NaN -> quiet NaN), which clang emits for a float -> __bf16 cast.
+typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  const hw_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hw_bf16x2_t));
 }
+
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);

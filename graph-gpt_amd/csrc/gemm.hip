@@ -31,6 +31,8 @@
 
 namespace {
 
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ int mc_swz(int krow) { return (krow & 3) | ((krow >> 1) & 4); }
 
 // One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KiB), lane-linear.
@@ -301,17 +303,17 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
     const int m = mw + i * 16 + l15;
 #pragma unroll
     for (int jp = 0; jp < NJ / 2; ++jp) {
-      // even lanes keep accumulator 2jp and fetch the partner's half of it; odd lanes keep 2jp+1
-      f32x4_t keep = odd ? acc[i][2 * jp + 1] : acc[i][2 * jp];
-      f32x4_t give = odd ? acc[i][2 * jp] : acc[i][2 * jp + 1];
-      f32x4_t got;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) got[e] = __shfl_xor(give[e], 16, 64);
+      // even 16-lane rows keep accumulator 2jp and take the partner row's quarter of it, odd rows keep 2jp+1:
+      // v_permlane16_swap (odd rows of the first operand <-> even rows of the second) does the whole exchange in one
+      // VALU instruction per register - even rows end up with {own X, X of row+1}, odd rows with {Y of row-1, own Y},
+      // i.e. 8 consecutive columns in (first, second) order on every lane.  (A __shfl_xor here is a ds_bpermute through
+      // the LDS crossbar: 64 dependent ones per 256x256 tile cost more than the stores themselves.)
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[e] = odd ? got[e] : keep[e];
-        v[4 + e] = odd ? keep[e] : got[e];
+        const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * jp][e]), __float_as_uint(acc[i][2 * jp + 1][e]), false, false);
+        v[e] = __uint_as_float(r[0]);
+        v[4 + e] = __uint_as_float(r[1]);
       }
       const int n = nw + (odd ? col_of(2 * jp + 1) : col_of(2 * jp)) + (gq & 2) * 4;
       if (m >= M || n >= N) continue;

@@ -237,22 +237,9 @@ constexpr int kSuper = 8;  // row panels per L2 super-tile
 // nw + (j/2)*64 + (j%2)*32 .. +15 with nw = tile origin + 16*wave, i.e. head j/2, channels chan0 + (j%2)*32 .. +15.
 template <int EPI, int MI, int NJ, bool ILV = false>
 __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmProblem& P, int M, int N, int mw, int nw, int lane,
-                                           int kslice = 0, bool fake_rows = false, int chan0 = 0) {
+                                           int kslice = 0, int chan0 = 0) {
   const int l15 = lane & 15, gq = lane >> 4;
   auto col_of = [](int j) { return ILV ? (j >> 1) * 64 + (j & 1) * 32 : j * 16; };
-  if (fake_rows) {   // timing experiment: same bytes, full-line addresses (8 rows x 128 B per instruction), wrong placement
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int jp = 0; jp < NJ / 2; ++jp) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jp][e]; v[4 + e] = acc[i][2 * jp + 1][e]; }
-        const int m = mw + i * 16 + jp * 8 + (lane >> 3), n = nw + (lane & 7) * 8;
-        if (m < M && n + 8 <= N) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(P.C) + (size_t)m * P.ldc + n) = pack8(v);
-      }
-    return;
-  }
   if (EPI == GGET_EPI_ATOMIC_F32) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -570,8 +557,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
   };
   auto finish_tile = [&]() {
     const GemmProblem& P = g.p[cc.pi];
-    if (g.ablate != 32 || acc[0][0][0] == 123.456f)
-      store_tile<EPI, MI, NJ, ILV>(acc, P, P.M, P.N, cc.m0 + wm * (MI * 16), cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, g.ablate == 16, wn * 16);
+    if (g.ablate != 32 || acc[0][0][0] == 123.456f)   // GGET_GEMM_ABLATE=32: persistent kernel without the epilogue (timing only)
+      store_tile<EPI, MI, NJ, ILV>(acc, P, P.M, P.N, cc.m0 + wm * (MI * 16), cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, wn * 16);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll

@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels of libgget_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits in memory
@@ -40,15 +41,29 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   return v;
 }
 
+// Wave-wide all-reduce without the LDS crossbar (a __shfl_xor is a ds_bpermute: ~100 cycles of dependent latency each,
+// six of them per reduction): four DPP steps reduce inside each 16-lane row, then gfx950's v_permlane16_swap /
+// v_permlane32_swap fold the four rows.  Every lane ends up with the full result.
+typedef unsigned hw_u32x2_t __attribute__((ext_vector_type(2)));
+template <typename Op>
+__device__ __forceinline__ float wave_allreduce(float v, Op op) {
+  auto dpp = [](float x, auto ctrl) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));    // quad_perm [1,0,3,2]
+  v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));    // quad_perm [2,3,0,1]
+  v = op(v, dpp(v, std::integral_constant<int, 0x141>{}));   // row_half_mirror
+  v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));   // row_mirror
+  hw_u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return wave_allreduce(v, [](float a, float b) { return a + b; });
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  return wave_allreduce(v, [](float a, float b) { return fmaxf(a, b); });
 }
 
 // exact (erf) GELU, the reference's hidden_act="gelu" (transformers/activations.py GELUActivation)

@@ -78,7 +78,7 @@ void add_param(Plan& pl, const std::string& name, int64_t r, int64_t c, int laye
   pl.n_params += align_up(p.count, 128);
   if (accum32) {
     p.off32 = pl.n_scratch32;
-    pl.n_scratch32 += align_up(p.count, 128);
+    pl.n_scratch32 += align_up(p.count, 128) * (p.count <= kAccumCopyMax ? kAccumCopies : 1);
   }
   if (off_out) *off_out = p.off;
   if (off32_out) *off32_out = p.off32;
@@ -329,7 +329,9 @@ extern "C" int gget_create(const gget_config_t* cfg, const gget_buffers_t* bufs,
     auto& r = h->bucket_range[b];
     r.first = std::min(r.first, p.off);
     r.second = std::max(r.second, p.off + align_up(p.count, 128));
-    if (p.accum32) segs[b].push_back(GgetSegment{p.off32, p.off, align_up(p.count, 128)});
+    if (p.accum32)
+      segs[b].push_back(GgetSegment{p.off32, p.off, align_up(p.count, 128),
+                                    (uint64_t)(p.count <= kAccumCopyMax ? kAccumCopies : 1), align_up(p.count, 128)});
   }
   std::vector<GgetSegment> flat;
   h->bucket_segs.resize(nb);
@@ -675,7 +677,7 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   if (int e = gemm_nn(dy_down, h->P + lo.wdown, dh, T, ff, d, d, ff, ff, nullptr, st)) return e;
   if (int e = k_geglu_bwd(h->wsp<bf16_t>(lw.gu), dh, dgu, T, ff, st)) return e;
   if (int e = gemm_nn(dgu, h->P + lo.wgu, dxn, T, d, 2 * ff, 2 * ff, d, d, nullptr, st)) return e;
-  if (int e = k_rmsnorm_bwd(dxn, xmid, h->P + lo.ln2, h->wsp<float>(lw.rstd2), dx_out, dx_mid, s32 + lo.ln2_32, T, d, st))
+  if (int e = k_rmsnorm_bwd(dxn, xmid, h->P + lo.ln2, h->wsp<float>(lw.rstd2), dx_out, dx_mid, s32 + lo.ln2_32, T, d, st, kAccumCopies, align_up((uint64_t)d, 128)))
     return e;
   dy_o = dx_mid;
   if (h->plan.has_res) {
@@ -692,7 +694,7 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
                          h->sin_tab, h->pos, /*qk_rotated=*/1, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st))
     return e;
   if (int e = gemm_nn(dqkv, h->P + lo.wqkv, dxn, T, d, 3 * d, 3 * d, d, d, nullptr, st)) return e;
-  if (int e = k_rmsnorm_bwd(dxn, x_in, h->P + lo.ln1, h->wsp<float>(lw.rstd1), dx_mid, dx_in, s32 + lo.ln1_32, T, d, st))
+  if (int e = k_rmsnorm_bwd(dxn, x_in, h->P + lo.ln1, h->wsp<float>(lw.rstd1), dx_mid, dx_in, s32 + lo.ln1_32, T, d, st, kAccumCopies, align_up((uint64_t)d, 128)))
     return e;
   // weight gradients of the layer (dW = dY^T X, K = T).  All four dY / X pairs are still alive here.
   const GemmProblem wg_gu{dgu, h->wsp<bf16_t>(lw.xn2), h->G + lo.wgu, nullptr, 2 * ff, d, T, 2 * ff, d, d, nullptr, nullptr, 0, 0};
@@ -786,7 +788,7 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
   }
   bf16_t* dx = h->wsp<bf16_t>(w.dxa);
   if (int e = k_rmsnorm_bwd(dhid, h->wsp<bf16_t>(w.xres[c.num_layers]), h->P + h->plan.normf, h->wsp<float>(w.rstd_f), nullptr,
-                            dx, s32 + h->plan.normf32, T, d, st))
+                            dx, s32 + h->plan.normf32, T, d, st, kAccumCopies, align_up((uint64_t)d, 128)))
     return e;
   h->dx_cur = dx;
   return convert_bucket(h, 0, st);

@@ -4,10 +4,17 @@
 #include "../../include/gget.h"
 #include "common.h"
 
+// Small fp32 accumulators (norm weights, LayerScale, ...) exist in kAccumCopies copies, `stride` elements apart: a block
+// adds into copy blockIdx % copies (an atomic add of 512 blocks into ONE 768-float vector serialises in L2: that was
+// the whole cost of the RMSNorm backward), and the bf16 conversion sums the copies.
+constexpr int kAccumCopies = 8;
+constexpr uint64_t kAccumCopyMax = 8192;   // parameters up to this many elements are replicated
 struct GgetSegment {
-  uint64_t src;    // element offset into the fp32 scratch
+  uint64_t src;    // element offset into the fp32 scratch (copy 0)
   uint64_t dst;    // element offset into the bf16 gradient array
   uint64_t count;  // elements (multiple of 4)
+  uint64_t copies; // number of fp32 copies to sum
+  uint64_t stride; // elements between copies
 };
 
 int k_embed_fwd(const int64_t* ids, const void* emb, const void* gate, void* out, int T, int F, int ldF, int d,
@@ -17,8 +24,9 @@ int k_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void*
                 int F, int ldF, int d, int V, int pad_id, int32_t* sort_ws, hipStream_t st);
 inline size_t k_embed_bwd_ws_elems(size_t ncell, size_t V) { return 3 * V + 1 + 2 * ncell; }
 int k_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, hipStream_t st);
+// dw_accum: fp32 [copies][copy_stride] accumulators (see GgetSegment); copies = 1 for a plain vector
 int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
-                  float* dw_accum, int T, int d, hipStream_t st);
+                  float* dw_accum, int T, int d, hipStream_t st, int copies = 1, uint64_t copy_stride = 0);
 int k_rope(void* qkv, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, int T, int S, int H,
            int inverse, hipStream_t st);
 int k_rope_table(float* cos_tab, float* sin_tab, int max_pos, float theta, hipStream_t st);

@@ -261,7 +261,8 @@ template <int NCH>
 __global__ void __launch_bounds__(kBlock) rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                              const bf16_t* __restrict__ w, const float* __restrict__ rstd_in,
                                                              const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
-                                                             float* __restrict__ dw_accum, int T, int d) {
+                                                             float* __restrict__ dw_accum, int T, int d, int copies,
+                                                             uint64_t copy_stride) {
   extern __shared__ float dw_lds[];  // [4][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = d >> 3;
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_bwd_kernel(const bf16_t* __res
   __syncthreads();
   for (int j = threadIdx.x; j < d; j += kBlock) {
     const float s = dw_lds[j] + dw_lds[d + j] + dw_lds[2 * d + j] + dw_lds[3 * d + j];
-    unsafeAtomicAdd(dw_accum + j, s);
+    unsafeAtomicAdd(dw_accum + (size_t)(blockIdx.x % copies) * copy_stride + j, s);
   }
 }
 
@@ -791,7 +792,11 @@ __global__ void __launch_bounds__(kBlock) convert_segments_kernel(const float* _
   const GgetSegment s = segs[blockIdx.y];
   const size_t nv = s.count >> 2;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (size_t)gridDim.x * kBlock) {
-    const float4 w = reinterpret_cast<const float4*>(scratch + s.src)[i];
+    float4 w = reinterpret_cast<const float4*>(scratch + s.src)[i];
+    for (uint64_t c = 1; c < s.copies; ++c) {
+      const float4 u = reinterpret_cast<const float4*>(scratch + s.src + c * s.stride)[i];
+      w.x += u.x; w.y += u.y; w.z += u.z; w.w += u.w;
+    }
     uint2 o;
     o.x = pack2bf(w.x, w.y);
     o.y = pack2bf(w.z, w.w);
@@ -866,16 +871,19 @@ int k_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int
 }
 
 int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
-                  float* dw_accum, int T, int d, hipStream_t st) {
+                  float* dw_accum, int T, int d, hipStream_t st, int copies, uint64_t copy_stride) {
   GGET_REQUIRE(d % 8 == 0 && d <= 64 * 8 * kMaxChunksPerLane, "rmsnorm: d=%d unsupported", d);
   if (T == 0) return 0;
-  const int grid = grid_for(T, 4 * 4, 1024);  // >= 4 rows per wave: amortises the dw atomics, pipelined row loads
+  if (copies < 1) copies = 1;
+  static int rpw = 0;
+  if (!rpw) { const char* e = getenv("GGET_RMS_ROWS"); rpw = e ? atoi(e) : 4; }
+  const int grid = grid_for(T, 4 * rpw, 4096);  // rows per wave: amortises the dw atomics, pipelined row loads
   if (d <= 1024)
     hipLaunchKernelGGL(rmsnorm_bwd_kernel<2>, dim3(grid), dim3(kBlock), 4 * d * sizeof(float), st, (const bf16_t*)dy,
-                       (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_accum, T, d);
+                       (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_accum, T, d, copies, copy_stride);
   else
     hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, dim3(grid), dim3(kBlock), 4 * d * sizeof(float), st, (const bf16_t*)dy,
-                       (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_accum, T, d);
+                       (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_accum, T, d, copies, copy_stride);
   GGET_LAUNCH_CHECK();
   return 0;
 }

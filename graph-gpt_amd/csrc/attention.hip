@@ -225,7 +225,7 @@ __device__ __forceinline__ void unrope_acc(f32x16_t& a0, f32x16_t& a1, const Rop
 // LDS ONCE per block (K rotated on the way in when R is given) and shared by the NW waves: K as the A operand of
 // S^T = K Q^T (ds_read_b128), V through the transposing read for O^T += V^T P^T.
 template <int NW>
-__global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
+__global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
                                                            bf16_t* __restrict__ out, float* __restrict__ lse, int B, int S,
                                                            int H, int causal, Rope R, Drop D) {
   __shared__ __attribute__((aligned(16))) unsigned char kt[4096];
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restric
 // dQ^T[dh][q] = sum_keys K^T[dh][key] dS^T[key][q],  dS^T = P^T (dP^T - delta_q) * scale
 // Block = NW query tiles; the K tile (rotated if Rin) and the V tile are shared through LDS.
 template <int NW>
-__global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
                                                               int B, int S, int H, int causal, Rope Rin, Rope R, Drop D) {
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const bf16_t* __re
 // dV^T[dh][key] = sum_q dO^T[dh][q] P[q][key] ; dK^T[dh][key] = sum_q Q^T[dh][q] dS[q][key]
 // Block = NW key tiles; every 32-query Q tile (rotated if Rin), dO tile and their lse/delta are shared through LDS.
 template <int NW>
-__global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
                                                                int B, int S, int H, int causal, Rope Rin, Rope R, Drop D) {

@@ -285,6 +285,70 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
     }
   }
   const bool odd = gq & 1;
+  // Full-line fast path (bf16 C, 64-column groups aligned to 128 B): the exchange below leaves a lane with 16 bytes of
+  // row (lane & 15) - an instruction would then touch 16 rows x 64 B.  One more exchange between lanes l and l^8
+  // (DPP row_ror:8 on the packed words) regroups two such pieces into rows (lane & 7) and 8 + (lane & 7), so that every
+  // store instruction writes 8 rows x 128 B = whole cache lines: the C store is what a K = 768 GEMM loses most time in
+  // (the write path takes ~9 B/clk/CU when all CUs store at once), and whole lines cut it by a third to a half.
+  if constexpr ((EPI == GGET_EPI_NONE || EPI == GGET_EPI_RESIDUAL || EPI == GGET_EPI_ROPE) && !ILV && (NJ % 4 == 0 || NJ == 6)) {
+    // NJ == 6 (96-column wave tile of the 128x192 block tile): the wave whose tile starts mid-line stores its first 32
+    // columns the plain way and regroups the other 64, the other wave the reverse
+    const int lead = (NJ == 6 && (nw & 63) == 32) ? 1 : 0;
+    if ((N & 63) == 0 && (P.ldc & 63) == 0 && ((nw & 63) == 0 || lead) && ((uintptr_t)P.C & 127) == 0) {
+      const bool low = (l15 & 8) == 0;
+      const int c0 = 2 * (gq & 1) + (gq >> 1);   // 16-byte chunk (of the 8 in a 64-column group) this lane holds for the first jp
+      auto piece = [&](int i, int jp, int m) {   // epilogue math of (i, jp): the lane's 8 columns of row m, packed
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * jp][e]), __float_as_uint(acc[i][2 * jp + 1][e]), false, false);
+          v[e] = __uint_as_float(r[0]);
+          v[4 + e] = __uint_as_float(r[1]);
+        }
+        if (EPI == GGET_EPI_RESIDUAL) {
+          const int n = nw + jp * 32 + c0 * 8;
+          if (m < M && n < N) {
+            float r[8];
+            unpack8(*reinterpret_cast<const uint4*>(P.R + (size_t)m * P.ldc + n), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+          }
+        }
+        return pack8(v);
+      };
+      auto ror8 = [](unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true); };
+      bf16_t* C = reinterpret_cast<bf16_t*>(P.C);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = mw + i * 16 + l15;          // the row whose values this lane holds before the regrouping
+        const int ma = mw + i * 16 + (l15 & 7), mb = ma + 8;
+#pragma unroll
+        for (int jq = 0; jq < NJ / 4; ++jq) {
+          const int ja = 2 * jq + lead;           // group = (ja, ja + 1): 64 columns from nw + 32 * ja
+          const uint4 x = lead ? piece(i, 2 * jq + 1, m) : piece(i, 2 * jq, m);
+          const uint4 y = lead ? piece(i, 2 * jq + 2 < NJ / 2 ? 2 * jq + 2 : NJ / 2 - 1, m) : piece(i, 2 * jq + 1, m);
+          const uint4 xr = make_uint4(ror8(x.x), ror8(x.y), ror8(x.z), ror8(x.w));
+          const uint4 yr = make_uint4(ror8(y.x), ror8(y.y), ror8(y.z), ror8(y.w));
+          // first instruction: rows 0..7 of the 16 (low lanes keep their first piece, high lanes carry the second piece of
+          // row-8); second instruction: rows 8..15
+          const uint4 pa = low ? x : yr;
+          const uint4 pb = low ? xr : y;
+          const int n = nw + ja * 32 + (low ? c0 : c0 + 4) * 8;
+          if (n < N) {
+            if (ma < M) *reinterpret_cast<uint4*>(C + (size_t)ma * P.ldc + n) = pa;
+            if (mb < M) *reinterpret_cast<uint4*>(C + (size_t)mb * P.ldc + n) = pb;
+          }
+        }
+        if constexpr (NJ == 6) {   // the remaining 32 columns: 16 rows x 64 B per instruction
+          const int jl = lead ? 0 : 2;
+          const uint4 z = lead ? piece(i, 0, m) : piece(i, NJ / 2 - 1, m);
+          const int n = nw + jl * 32 + c0 * 8;
+          if (m < M && n < N) *reinterpret_cast<uint4*>(C + (size_t)m * P.ldc + n) = z;
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = mw + i * 16 + l15;

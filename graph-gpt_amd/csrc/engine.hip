@@ -875,6 +875,14 @@ extern "C" int gget_op_qkv_rope(const void* x, const void* wqkv, void* qkv, cons
   p.rope_cos = cos_tab; p.rope_sin = sin_tab; p.rope_pos = position_ids; p.rope_S = S; p.rope_cols = 2 * d;
   return gget_gemm_launch(GGET_GEMM_NT, GGET_EPI_ROPE, g, 1, (hipStream_t)stream);
 }
+extern "C" int gget_op_smtp2d(const int64_t* ids_in, int ld_in, const int64_t* node_idx, int ld_node, int64_t* ids_out,
+                              int64_t* labels_out, int B, int S, int F, float smtp_2d_rate, float power, float replace_rate,
+                              int vocab, int global_2d_mask, uint32_t seed, void* stream) {
+  GGET_REQUIRE(ids_in && node_idx && ids_out && labels_out, "smtp2d: null argument");
+  GGET_REQUIRE(B >= 0 && S >= 0 && F >= 1 && ld_in >= F && ld_node >= 1 && vocab >= 2, "smtp2d: bad shape");
+  return k_smtp2d(ids_in, ld_in, node_idx, ld_node, ids_out, labels_out, B, S, F, smtp_2d_rate, power, replace_rate, vocab,
+                  global_2d_mask, seed, (hipStream_t)stream);
+}
 extern "C" int gget_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, void* stream) {
   return k_rmsnorm_fwd(x, w, y, rstd, T, d, eps, (hipStream_t)stream);
 }

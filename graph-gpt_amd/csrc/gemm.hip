@@ -520,7 +520,9 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const
     if (sacc == 1.2345e-30f) reinterpret_cast<bf16_t*>(P.C)[0] = 1;  // keep the accumulators live
     return;
   }
-  store_tile<EPI, MI, NJ>(acc, P, M, N, m0 + wm * 64, n0 + wn * 64, lane, blockIdx.y);
+  // a width that is not a multiple of 4 (odd vocabularies) is stored up to the next multiple: the caller's ldc covers
+  // the pad columns (checked by the launcher) and their values (the clamped last B row again) are never read
+  store_tile<EPI, MI, NJ>(acc, P, M, (N + 3) & ~3, m0 + wm * 64, n0 + wn * 64, lane, blockIdx.y);
 }
 
 
@@ -622,7 +624,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
   auto finish_tile = [&]() {
     const GemmProblem& P = g.p[cc.pi];
     if (g.ablate != 32 || acc[0][0][0] == 123.456f)   // GGET_GEMM_ABLATE=32: persistent kernel without the epilogue (timing only)
-      store_tile<EPI, MI, NJ, ILV>(acc, P, P.M, P.N, cc.m0 + wm * (MI * 16), cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, wn * 16);
+      store_tile<EPI, MI, NJ, ILV>(acc, P, P.M, (P.N + 3) & ~3, cc.m0 + wm * (MI * 16), cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, wn * 16);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -862,8 +864,12 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
                "gemm: split-K needs the fp32 atomic or slab epilogue");
   for (int i = 0; i < g.count; ++i) {
     const GemmProblem& p = g.p[i];
-    GGET_REQUIRE((p.lda % 8) == 0 && (p.ldb % 8) == 0 && (p.ldc % 8) == 0 && (p.N % 4) == 0,
-                 "gemm: leading dims must be multiples of 8 (lda %d ldb %d ldc %d N %d)", p.lda, p.ldb, p.ldc, p.N);
+    GGET_REQUIRE((p.lda % 8) == 0 && (p.ldb % 8) == 0 && (p.ldc % 8) == 0,
+                 "gemm: leading dims must be multiples of 8 (lda %d ldb %d ldc %d)", p.lda, p.ldb, p.ldc);
+    // N % 4 != 0 (e.g. the 41 245-entry ogbl-ppa vocabulary): C is written up to the next multiple of 4, which must fit in
+    // ldc; only the forward layout (B = [N,K], rows clamped) supports it
+    GGET_REQUIRE((p.N % 4) == 0 || (mode == GGET_GEMM_NT && p.ldc >= ((p.N + 3) & ~3) && epi != GGET_EPI_RESIDUAL),
+                 "gemm: N = %d must be a multiple of 4 (or NT mode with ldc >= N rounded up to 4)", p.N);
     // the LDS-DMA addresses are a uniform 64-bit K-origin plus an unsigned 32-bit per-lane byte offset
     GGET_REQUIRE(((size_t)p.M + 64) * (size_t)p.lda * 2 < (1ull << 32) && ((size_t)p.N + 64) * (size_t)p.ldb * 2 < (1ull << 32),
                  "gemm: operand spans more than 4 GiB (M %d lda %d N %d ldb %d)", p.M, p.lda, p.N, p.ldb);

@@ -64,3 +64,6 @@ int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, i
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
                const int64_t* position_ids, int qk_rotated, float dropout_p, unsigned dropout_seed, hipStream_t st);
+int k_smtp2d(const int64_t* ids_in, int ld_in, const int64_t* node_idx, int ld_node, int64_t* ids_out, int64_t* labels_out,
+             int B, int S, int F, float rate, float power, float replace_rate, int vocab, int global_mask, unsigned seed,
+             hipStream_t st);

@@ -804,6 +804,60 @@ __global__ void __launch_bounds__(kBlock) convert_segments_kernel(const float* _
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// In-model SMTP masking
+// reference: prepare_for_2d_smtp_inputs_labels + _get_gaussian_rnd_tokens (src/models/graphgpt/modeling_helpers.py:399-468)
+// One thread per (sample, position, feature) cell.  torch's Philox stream cannot be reproduced, so the draws are a
+// counter hash of (seed, stream, sample, cell) - graph-gpt_amd/smtp.py holds the Python twin the parity tests feed to the
+// oracle:  stream 0 sample mask, 1 mask rate of the sample, 2 per-(node, feature) draw, 3 replace draw, 16..27 the twelve
+// uniforms whose sum (Irwin-Hall, variance 1) stands in for randn; everything after the draws is integer-exact.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned smtp_rng(unsigned seed, unsigned stream, unsigned a, unsigned b) {
+  unsigned x = seed ^ (stream * 0x9E3779B1u);
+  x += a * 0x85EBCA77u + b * 0xC2B2AE3Du;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x >> 8;   // 24 bits: u = value * 2^-24 is exact in fp32
+}
+__global__ void __launch_bounds__(kBlock) smtp2d_kernel(const int64_t* __restrict__ ids_in, int ld_in,
+                                                        const int64_t* __restrict__ node_idx, int ld_node,
+                                                        int64_t* __restrict__ ids_out, int64_t* __restrict__ labels_out,
+                                                        int B, int S, int F, float rate, float power, float replace_rate,
+                                                        int vocab, int global_mask, unsigned seed, int mask_id) {
+  const long total = (long)B * S * F;
+  const float inv24 = 1.0f / 16777216.0f;
+  for (long w = (long)blockIdx.x * kBlock + threadIdx.x; w < total; w += (long)gridDim.x * kBlock) {
+    const int f = (int)(w % F);
+    const long bs = w / F;
+    const int sidx = (int)(bs % S), b = (int)(bs / S);
+    const int64_t id = ids_in[bs * ld_in + f];
+    const int ni = (int)node_idx[bs * ld_node];
+    const bool sample = (float)smtp_rng(seed, 0, b, 0) * inv24 < rate;
+    const float mr = (float)smtp_rng(seed, 1, b, 0) * inv24;
+    const float thr = power == 1.0f ? mr : powf(mr, power);
+    bool m = (float)smtp_rng(seed, 2, b, (unsigned)(ni * F + f)) * inv24 > thr;
+    if (!global_mask) m = m && sample;
+    m = m && id > 0;
+    int64_t out = m ? (int64_t)mask_id : id;
+    if (replace_rate > 0.f && m) {
+      const unsigned cell = (unsigned)(sidx * F + f);
+      if ((float)smtp_rng(seed, 3, b, cell) * inv24 < replace_rate) {
+        long long s12 = 0;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) s12 += smtp_rng(seed, 16 + k, b, cell);
+        const long long num = 10 * s12 - 60ll * 16777216ll;       // 10 * (sum - 6) in units of 2^-24
+        long long q = num >> 24;
+        const long long r = num & 16777215ll;
+        if (r > 8388608ll || (r == 8388608ll && (q & 1))) ++q;     // round half to even, like torch.round
+        long long t = (id + q) % vocab;
+        if (t < 0) t += vocab;                                     // python-style modulo
+        out = t;
+      }
+    }
+    ids_out[w] = out;
+    labels_out[w] = m ? id : (int64_t)-100;
+  }
+}
+
 inline int grid_for(long work_items, int per_block = kBlock, int cap = 4096) {
   long g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -1023,6 +1077,16 @@ int k_slab_reduce(const float* slabs, long slab_stride, int nslab, void* dst, si
 int k_convert_segments(const float* scratch, void* grads, const GgetSegment* segs_dev, int nseg, hipStream_t st) {
   if (nseg == 0) return 0;
   hipLaunchKernelGGL(convert_segments_kernel, dim3(64, nseg), dim3(kBlock), 0, st, scratch, (bf16_t*)grads, segs_dev);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_smtp2d(const int64_t* ids_in, int ld_in, const int64_t* node_idx, int ld_node, int64_t* ids_out, int64_t* labels_out,
+             int B, int S, int F, float rate, float power, float replace_rate, int vocab, int global_mask, unsigned seed,
+             hipStream_t st) {
+  if ((long)B * S * F == 0) return 0;
+  hipLaunchKernelGGL(smtp2d_kernel, dim3(grid_for((long)B * S * F)), dim3(kBlock), 0, st, ids_in, ld_in, node_idx, ld_node,
+                     ids_out, labels_out, B, S, F, rate, power, replace_rate, vocab, global_mask, seed, 1);
   GGET_LAUNCH_CHECK();
   return 0;
 }

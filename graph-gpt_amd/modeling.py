@@ -75,7 +75,6 @@ class GraphGPTConfig:
         need(not self.use_discriminative and self.use_generative, "contrastive (pretrain-cl) head")
         need(self.focal_gamma == 0, "focal loss")
         need(self.rope_range == 0, "rope_range rescaling")
-        need(not self.smtp_inside, "in-model SMTP masking (next item N1)")
         need(len(self.mlp) == 0, "MLP score head")
         need(self.pooling_method == "last", "pooling other than 'last'")
         need(self.mlp_pdrop == 0 and self.embed_pdrop == 0 and self.dropout == 0,
@@ -299,6 +298,17 @@ class GraphGPTPretrainBase(_GgetModel):
         assert inputs_raw_embeds is None, "raw embeddings need embed_dim>0 which this engine rejects at construction"
         if input_ids.dim() == 2:
             input_ids = input_ids[:, :, None]
+        if getattr(self.config, "smtp_inside", False):
+            # reference modeling_pretrain.py:175-189: the batch carries 4 extra columns (pos_deco), column F+2 is the node
+            # index; ids are masked and labels produced on the device (HIP kernel behind gget_op_smtp2d)
+            from .smtp import smtp2d_mask
+            F = self.spec.stacked_feat
+            full = input_ids.to(device=self.device if self._engine is not None else torch.device("cuda"), dtype=torch.int64).contiguous()
+            self._smtp_step = getattr(self, "_smtp_step", 0) + 1
+            seed = (self.dropout_seed * 0x9E3779B1 + self._smtp_step * 0x85EBCA77 + int(os.environ.get("RANK", "0")) * 0xC2B2AE3D) & 0xFFFFFFFF
+            input_ids, labels = smtp2d_mask(full, full[:, :, F + 2], F, smtp_2d_rate=1.0,
+                                            power=float(getattr(self.config, "smtp_power", 1.0)), replace_rate=0.0,
+                                            vocab=self.config.vocab_size, global_2d_mask=False, seed=seed)
         B, S = input_ids.shape[:2]
         assert input_ids.shape[2] == self.spec.stacked_feat, \
             f"stacked_feat: {self.spec.stacked_feat}\nx.shape: {tuple(input_ids.shape)}"  # modeling_common.py:131-133

@@ -183,6 +183,15 @@ int gget_op_gemm(int mode, int epilogue, const void* A, const void* B, void* C, 
  * position_ids[t], or t % S when position_ids is NULL; cos/sin tables [max_position][32] fp32). */
 int gget_op_qkv_rope(const void* x, const void* wqkv, void* qkv, const float* cos_tab, const float* sin_tab,
                      const int64_t* position_ids, int T, int S, int d, void* stream);
+/* replaces: prepare_for_2d_smtp_inputs_labels (src/models/graphgpt/modeling_helpers.py:399-449) as called by
+ * GraphGPTPretrainBase.forward when config.smtp_inside (modeling_pretrain.py:175-189): per-sample mask rate r ~ U, a cell
+ * (node, feature) is masked when U > r^power (looked up through node_idx), masked ids -> 1, labels = original id or -100,
+ * optional replacement of masked cells by id + round(10 * N(0,1)) mod vocab.  ids_in [B,S,ld_in] (first F columns are
+ * used), node_idx [B,S] with element stride ld_node, outputs dense [B,S,F].  Draws are a counter hash of `seed`
+ * (graph-gpt_amd/smtp.py is the bit-exact Python twin). */
+int gget_op_smtp2d(const int64_t* ids_in, int ld_in, const int64_t* node_idx, int ld_node, int64_t* ids_out, int64_t* labels_out,
+                   int B, int S, int F, float smtp_2d_rate, float power, float replace_rate, int vocab, int global_2d_mask,
+                   uint32_t seed, void* stream);
 int gget_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, void* stream);
 int gget_op_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
                         void* dx, float* dw_accum, int T, int d, void* stream);

@@ -311,3 +311,29 @@ def warmup_decay_lr(step: int, max_lr: float, min_lr: float, warmup: int, total:
     else:
         gamma = max(0.0, (total - step) / max(1.0, total - warmup))
     return min_lr + (max_lr - min_lr) * gamma
+
+
+# ----------------------------------------------------------------------------- in-model SMTP masking (row A9 / N1)
+def smtp_2d_inputs_labels(input_ids, node_idx, u_sample, u_rate, u_cell, token_shift, u_replace, *, smtp_2d_rate: float,
+                          power: float, replace_rate: float, vocab: int, global_2d_mask: bool = False,
+                          mask_token_id: int = 1, label_pad_token_id: int = -100):
+    """reference prepare_for_2d_smtp_inputs_labels (src/models/graphgpt/modeling_helpers.py:399-449) and
+    _get_gaussian_rnd_tokens (:460-468) with the random draws passed in, in the order the reference makes them:
+    u_sample [B] ~U (sample mask, :418-420), u_rate [B] ~U (mask rate of the sample, :427), u_cell [B,S,F] ~U (per
+    (node, feature) draw, :429-432), token_shift [B,S,F] = randn*10 before rounding (:463-464), u_replace [B,S,F] ~U (:444-446).
+    The 3-D `pos` branch (:422-425) is outside the hot path (no 3-D models)."""
+    bz = input_ids.shape[0]
+    bz_idx = torch.arange(bz).view(-1, 1)
+    sample_mask = (u_sample.view(bz, 1, 1) < smtp_2d_rate)
+    mask_per_node = u_cell > (u_rate.view(bz, 1, 1).to(torch.float32) ** power)
+    if not global_2d_mask:
+        mask_per_node = mask_per_node & sample_mask
+    mask_per_token = mask_per_node[bz_idx, node_idx]
+    mask_per_token = mask_per_token & (input_ids > 0)
+    labels = input_ids.clone().masked_fill_(~mask_per_token, label_pad_token_id)
+    ids = input_ids.clone().masked_fill_(mask_per_token, mask_token_id)
+    shift = token_shift.round().long().masked_fill(input_ids <= 0, 0)
+    rnd_tokens = (input_ids + shift) % vocab
+    replace_mask = mask_per_token & (u_replace < replace_rate)
+    ids = ids * (~replace_mask).long() + rnd_tokens * replace_mask.long()
+    return ids, labels

@@ -295,3 +295,35 @@ def test_drop_path_matches_oracle_with_same_mask(layer_scale):
         w = grads[k].numpy()
         err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
         assert err < 6e-2, f"{k}: {err}"
+
+
+@pytest.mark.gpu
+def test_smtp_inside_forward_matches_explicit_masking():
+    """config.smtp_inside (reference modeling_pretrain.py:175-189): the model masks on the device; its loss equals the
+    loss of a plain model fed with the oracle's masked ids / labels for the same draws."""
+    import importlib
+    from oracle import gget_oracle as O
+    modeling = importlib.import_module("graph-gpt_amd.modeling")
+    smtp = importlib.import_module("graph-gpt_amd.smtp")
+    F, V, B, S = 4, 211, 6, 24
+    kw = dict(vocab_size=V, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+              max_position_embeddings=64, causal_attention=False, stacked_feat=F, next_n_token=F)
+    m_in = modeling.GraphGPTPretrainBase(modeling.GraphGPTConfig(smtp_inside=True, smtp_power=1.0, **kw), seed=4).cuda().eval()
+    m_ex = modeling.GraphGPTPretrainBase(modeling.GraphGPTConfig(**kw), seed=4).cuda().eval()
+    g = torch.Generator().manual_seed(9)
+    lens = torch.randint(10, S + 1, (B,), generator=g)
+    full = torch.zeros(B, S, F + 4, dtype=torch.int64)
+    full[:, :, :F] = torch.randint(2, V, (B, S, F), generator=g)
+    att = torch.zeros(B, S, dtype=torch.int64)
+    for b in range(B):
+        full[b, lens[b]:, :F] = 0
+        att[b, : lens[b]] = 1
+        full[b, : lens[b], F + 2] = torch.randint(0, int(lens[b]) // 2 + 1, (int(lens[b]),), generator=g)
+    out_in = m_in(input_ids=full.cuda(), attention_mask=att.cuda())
+    seed = (m_in.dropout_seed * 0x9E3779B1 + 1 * 0x85EBCA77) & 0xFFFFFFFF
+    us, ur, uc, sh, urep = smtp.draws(seed, B, S, F)
+    ids, lab = O.smtp_2d_inputs_labels(full[:, :, :F].contiguous(), full[:, :, F + 2].contiguous(), us, ur, uc, sh, urep,
+                                       smtp_2d_rate=1.0, power=1.0, replace_rate=0.0, vocab=V)
+    out_ex = m_ex(input_ids=ids.cuda(), attention_mask=att.cuda(), labels=lab.cuda())
+    assert (lab != -100).any()
+    assert float(out_in.head1_loss.detach()) == pytest.approx(float(out_ex.head1_loss.detach()), rel=1e-6)

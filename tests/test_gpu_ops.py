@@ -105,6 +105,19 @@ def test_gemm_tn_tile_192x192(lib, M, N, K):
     assert rel_l2(Cm.float().cpu().numpy(), ref.cpu().numpy()) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 211, 128), (5000, 41245 // 8 + 1, 64)])
+def test_gemm_nt_odd_width(lib, M, N, K):
+    # vocabulary-sized outputs need not be multiples of 4 (ogbl-ppa: 41 245): C is written up to the next multiple of 4
+    # inside ldc, columns beyond stay untouched
+    A, B = rnd(M, K, seed=41), rnd(N, K, seed=42)
+    ldc = (N + 63) // 64 * 64
+    Cm = torch.full((M, ldc), 7.0, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.gget_op_gemm(L.GEMM_NT, L.EPI_NONE, P(A), P(B), P(Cm), None, M, N, K, K, K, ldc, 1, ST()))
+    ref = A.float() @ B.float().T
+    assert rel_l2(Cm[:, :N].float().cpu().numpy(), ref.cpu().numpy()) < 4e-3
+    assert torch.all(Cm[:, (N + 3) // 4 * 4:] == 7.0)
+
+
 def test_gemm_identity_layout(lib):
     # A = I with an asymmetric B: the output must be B^T exactly (bit-exact, catches row/col swaps)
     n = 128
@@ -374,3 +387,37 @@ def test_cross_entropy(lib):
     assert rel_l2(dl[:n, :V].float().cpu().numpy(), lf.grad.cpu().numpy()) < 5e-3
     assert torch.all(dl[:n, V:] == 0), "pad columns of dlogits must be zero (they feed the dgrad GEMM)"
     assert torch.all(dl[n:] == 3.0), "rows beyond the device-side count must not be touched"
+
+
+# ------------------------------------------------------------------------------------------ in-model SMTP masking (N1)
+@pytest.mark.parametrize("B,S,F,V,rate,power,rep,glob", [(5, 24, 13, 756, 1.0, 1.0, 0.0, False), (64, 40, 4, 300, 0.5, 1.0, 0.4, False),
+                                                        (7, 16, 1, 97, 0.3, 0.5, 0.5, True), (256, 32, 13, 756, 1.0, 1.0, 0.0, False)])
+def test_smtp2d_kernel_matches_oracle(lib, B, S, F, V, rate, power, rep, glob):
+    """gget_op_smtp2d vs the oracle (pinned against the reference's prepare_for_2d_smtp_inputs_labels) fed with the Python
+    twin of the kernel's counter-hash draws: masked ids and labels are bit-exact; the batch layout is the reference's
+    (F feature columns + 4 pos_deco columns, node index in column F+2)."""
+    from oracle import gget_oracle as O
+    smtp = importlib.import_module("graph-gpt_amd.smtp")
+    g = torch.Generator().manual_seed(B * 131 + S)
+    lens = torch.randint(S // 2, S + 1, (B,), generator=g)
+    full = torch.zeros(B, S, F + 4, dtype=torch.int64)
+    full[:, :, :F] = torch.randint(2, V, (B, S, F), generator=g)
+    for b in range(B):
+        full[b, lens[b]:, :F] = 0
+        full[b, : lens[b], F + 2] = torch.randint(0, max(2, int(lens[b]) * 2 // 3), (int(lens[b]),), generator=g)
+    seed = 0xC0FFEE + B
+    dev = full.cuda()
+    got_ids, got_lab = smtp.smtp2d_mask(dev, dev[:, :, F + 2], F, smtp_2d_rate=rate, power=power, replace_rate=rep, vocab=V,
+                                        global_2d_mask=glob, seed=seed)
+    us, ur, uc, sh, urep = smtp.draws(seed, B, S, F)
+    want_ids, want_lab = O.smtp_2d_inputs_labels(full[:, :, :F].contiguous(), full[:, :, F + 2].contiguous(), us, ur, uc, sh, urep,
+                                                 smtp_2d_rate=rate, power=power, replace_rate=rep, vocab=V, global_2d_mask=glob)
+    assert torch.equal(got_lab.cpu(), want_lab)
+    assert torch.equal(got_ids.cpu(), want_ids)
+    masked = (want_lab != -100)
+    assert masked.any() and not masked.all()
+    # statistics of the draws themselves: uniform in [0,1), shift ~ N(0, 10^2)
+    assert float(uc.min()) >= 0 and float(uc.max()) < 1
+    if B * S * F > 5000:
+        assert abs(float(uc.mean()) - 0.5) < 0.02
+        assert abs(float(sh.std()) - 10.0) < 0.5 and abs(float(sh.mean())) < 0.5

@@ -98,3 +98,19 @@ def test_inputs_regenerate():
     again = synth.make_pretrain_batch(B=4, S=24, F=13, V=756, seed=0)
     for k in ("input_ids", "labels", "attention_mask", "position_ids"):
         np.testing.assert_array_equal(again[k], batch[k])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_smtp2d_masking_matches_reference(tag):
+    """In-model SMTP masking (row A9 / N1): the oracle fed with the reference's own random draws (recorded in call order
+    by tools/make_golden.py) reproduces the reference's masked ids and labels exactly."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "smtp2d.npz"))
+    T = lambda k: torch.from_numpy(g[f"{tag}_{k}"])
+    rate, power, rep, V, glob = g[f"{tag}_params"]
+    ids, labels = O.smtp_2d_inputs_labels(T("ids"), T("node_idx"), T("u_sample"), T("u_rate"), T("u_cell"), T("token_shift"),
+                                          T("u_replace"), smtp_2d_rate=float(rate), power=float(power),
+                                          replace_rate=float(rep), vocab=int(V), global_2d_mask=bool(glob))
+    assert torch.equal(ids, T("out_ids"))
+    assert torch.equal(labels, T("out_labels"))
+    assert (labels != -100).any() and (ids == 1).any()

@@ -247,6 +247,58 @@ def lr_fixture():
     print("lr_schedules written")
 
 
+def smtp2d_fixture():
+    """In-model SMTP masking: the reference function run under a recording torch.rand / torch.randn, so the fixture holds
+    the draws (in call order) next to inputs and outputs."""
+    import_reference()
+    helpers = sys.modules["src.models.graphgpt.modeling_helpers"]
+    res = {}
+    cases = {"a": dict(B=5, S=24, F=13, V=756, smtp_2d_rate=1.0, power=1.0, replace_rate=0.0, global_2d_mask=False),
+             "b": dict(B=4, S=40, F=4, V=300, smtp_2d_rate=0.5, power=2.0, replace_rate=0.3, global_2d_mask=False),
+             "c": dict(B=3, S=16, F=1, V=97, smtp_2d_rate=0.3, power=0.5, replace_rate=0.5, global_2d_mask=True)}
+    for tag, c in cases.items():
+        g = torch.Generator().manual_seed(100 + ord(tag))
+        B, S, F, V = c["B"], c["S"], c["F"], c["V"]
+        lens = torch.randint(S // 2, S + 1, (B,), generator=g)
+        ids = torch.randint(2, V, (B, S, F), generator=g)
+        node_idx = torch.zeros(B, S, dtype=torch.long)
+        for b in range(B):
+            ids[b, lens[b]:] = 0
+            # Eulerian-path style node indices: tokens revisit nodes, values < number of distinct nodes <= len
+            nn_ = max(2, int(lens[b]) * 2 // 3)
+            node_idx[b, : lens[b]] = torch.randint(0, nn_, (int(lens[b]),), generator=g)
+        rec = []
+        real_rand, real_randn = torch.rand, torch.randn
+
+        def rand(*a, **k):
+            k.pop("device", None)
+            t = real_rand(*a, generator=g, **k)
+            rec.append(t.clone())
+            return t
+
+        def randn(*a, **k):
+            k.pop("device", None)
+            t = real_randn(*a, generator=g, **k)
+            rec.append(t.clone())
+            return t
+
+        torch.rand, torch.randn = rand, randn
+        try:
+            out_ids, out_lab = helpers.prepare_for_2d_smtp_inputs_labels(
+                ids.clone(), node_idx, smtp_2d_rate=c["smtp_2d_rate"], power=c["power"], replace_rate=c["replace_rate"],
+                vocab=V, global_2d_mask=c["global_2d_mask"])
+        finally:
+            torch.rand, torch.randn = real_rand, real_randn
+        assert len(rec) == 5, len(rec)
+        res.update({f"{tag}_ids": ids.numpy(), f"{tag}_node_idx": node_idx.numpy(),
+                    f"{tag}_u_sample": rec[0].reshape(B).numpy(), f"{tag}_u_rate": rec[1].reshape(B).numpy(),
+                    f"{tag}_u_cell": rec[2].numpy(), f"{tag}_token_shift": (rec[3] * 10).numpy(), f"{tag}_u_replace": rec[4].numpy(),
+                    f"{tag}_out_ids": out_ids.numpy(), f"{tag}_out_labels": out_lab.numpy(),
+                    f"{tag}_params": np.array([c["smtp_2d_rate"], c["power"], c["replace_rate"], V, int(c["global_2d_mask"])], np.float64)})
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "smtp2d.npz"), **res)
+    print("smtp2d written")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -258,6 +310,8 @@ def main():
         run_case(name, kind, dict(skw), dict(bkw), dict(ikw), classes)
     if not only:
         lr_fixture()
+    if not only or "smtp2d" in only:
+        smtp2d_fixture()
 
 
 if __name__ == "__main__":

@@ -455,24 +455,39 @@ __global__ void __launch_bounds__(256) ls_fwd_kernel(const bf16_t* __restrict__ 
 }
 __global__ void __launch_bounds__(256) ls_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
                                                      const bf16_t* __restrict__ lam, bf16_t* __restrict__ dscaled,
-                                                     float* __restrict__ dlam, int T, int d, PathDrop D) {
-  // one thread per 8 channels, rows strided over blockIdx.y
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c * 8 >= d) return;
+                                                     float* __restrict__ dlam, int T, int d, PathDrop D, int copies,
+                                                     uint64_t copy_stride) {
+  // thread = (row lane, 8-channel chunk); a block walks rows blockIdx.x*RL + lane, stride gridDim.x*RL.  The dlam partials
+  // of the block's row lanes are summed through LDS and added to accumulator copy blockIdx.x % copies (GgetSegment).
+  extern __shared__ float ls_lds[];   // [RL][d]
+  const int CH = d >> 3, RL = 256 / CH;
+  const int c = threadIdx.x % CH, rl = threadIdx.x / CH;
+  const bool active = rl < RL;
   float l[8] = {1, 1, 1, 1, 1, 1, 1, 1}, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (lam) unpack8(*reinterpret_cast<const uint4*>(lam + c * 8), l);
-  for (int t = blockIdx.y; t < T; t += gridDim.y) {
-    const float keep = path_keep(D, t);
-    float g[8], v[8], o[8];
-    unpack8(*reinterpret_cast<const uint4*>(dy + (size_t)t * d + c * 8), g);
-    unpack8(*reinterpret_cast<const uint4*>(y + (size_t)t * d + c * 8), v);
+  if (lam && active) unpack8(*reinterpret_cast<const uint4*>(lam + c * 8), l);
+  if (active) {
+    for (int t = blockIdx.x * RL + rl; t < T; t += gridDim.x * RL) {
+      const float keep = path_keep(D, t);
+      float g[8], v[8], o[8];
+      unpack8(*reinterpret_cast<const uint4*>(dy + (size_t)t * d + c * 8), g);
+      unpack8(*reinterpret_cast<const uint4*>(y + (size_t)t * d + c * 8), v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { o[e] = l[e] * keep * g[e]; acc[e] += keep * g[e] * v[e]; }
-    *reinterpret_cast<uint4*>(dscaled + (size_t)t * d + c * 8) = pack8(o);
+      for (int e = 0; e < 8; ++e) { o[e] = l[e] * keep * g[e]; acc[e] += keep * g[e] * v[e]; }
+      *reinterpret_cast<uint4*>(dscaled + (size_t)t * d + c * 8) = pack8(o);
+    }
   }
   if (dlam) {
+    if (active) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dlam + c * 8 + e, acc[e]);
+      for (int e = 0; e < 8; ++e) ls_lds[rl * d + c * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    float* dst = dlam + (size_t)(blockIdx.x % copies) * copy_stride;
+    for (int j = threadIdx.x; j < d; j += 256) {
+      float sum = 0.f;
+      for (int r = 0; r < RL; ++r) sum += ls_lds[r * d + j];
+      unsafeAtomicAdd(dst + j, sum);
+    }
   }
 }
 
@@ -664,13 +679,16 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   bf16_t* dh = h->wsp<bf16_t>(w.dh);
   const bf16_t* dy_down = dx_out;  // gradient of the down_proj output
   const bf16_t* dy_o = nullptr;    // gradient of the o_proj output
-  dim3 lsgrid((d / 8 + 255) / 256, 64);
+  // LayerScale / DropPath backward: d/8 <= 256 chunks per row (d <= 2048 is checked at create), 512 blocks
+  const int ls_rl = 256 / (d / 8);
+  dim3 lsgrid((unsigned)std::min(512, (T + ls_rl - 1) / ls_rl));
+  const size_t ls_lds_bytes = (size_t)ls_rl * d * sizeof(float);
   if (h->plan.has_res) {
     // x_out = xmid + keep_b * lam2 * mraw  =>  d mraw = keep_b * lam2 * dx_out, dlam2 += sum keep_b * dx_out * mraw
     bf16_t* dsc = h->wsp<bf16_t>(w.dscaled);
-    hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), 0, st, dx_out, h->wsp<bf16_t>(lw.mraw),
+    hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), ls_lds_bytes, st, dx_out, h->wsp<bf16_t>(lw.mraw),
                        h->plan.has_ls ? h->P + lo.lam2 : nullptr, dsc, h->plan.has_ls ? s32 + lo.lam2_32 : nullptr, T, d,
-                       h->path_drop(i, 1));
+                       h->path_drop(i, 1), kAccumCopies, align_up((uint64_t)d, 128));
     dy_down = dsc;   // stays alive for the grouped wgrad at the end of the layer (the o_proj branch has its own buffer)
   }
   // MLP: dh = dy_down W_down ; dgu = geglu'(dh) ; dxn2 = dgu W_gu
@@ -682,9 +700,9 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   dy_o = dx_mid;
   if (h->plan.has_res) {
     bf16_t* dsc = h->wsp<bf16_t>(w.dscaled2);
-    hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), 0, st, dx_mid, h->wsp<bf16_t>(lw.araw),
+    hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), ls_lds_bytes, st, dx_mid, h->wsp<bf16_t>(lw.araw),
                        h->plan.has_ls ? h->P + lo.lam1 : nullptr, dsc, h->plan.has_ls ? s32 + lo.lam1_32 : nullptr, T, d,
-                       h->path_drop(i, 0));
+                       h->path_drop(i, 0), kAccumCopies, align_up((uint64_t)d, 128));
     dy_o = dsc;
   }
   // attention: dattn = dy_o W_o ; (dq,dk,dv) ; inverse RoPE ; dxn1 = dqkv W_qkv

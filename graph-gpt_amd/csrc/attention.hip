@@ -93,6 +93,51 @@ __device__ __forceinline__ void load_tile_coop(unsigned char* lds, const bf16_t*
     *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = v;
   }
 }
+// Register-prefetched variant of load_tile_coop: `tile_fetch` only issues the global loads of a tile (they stay in flight
+// while the block computes on the tile already in LDS), `tile_commit` rotates (if asked) and writes them to LDS later.
+template <int NT>
+struct TilePref {
+  uint4 lo[256 / NT];
+  uint4 up[256 / NT];   // the chunk 32 channels away (RoPE partner); only loaded when a rotation is applied
+};
+template <int NT>
+__device__ __forceinline__ void tile_fetch(TilePref<NT>& p, const bf16_t* __restrict__ base, int r0, int row_lim, size_t pitch,
+                                           int tid, const Rope& R) {
+#pragma unroll
+  for (int i = 0; i < 256 / NT; ++i) {
+    const int c = tid + i * NT;
+    const int row = c >> 3, ch = c & 7;
+    const int gr = r0 + row;
+    p.lo[i] = make_uint4(0, 0, 0, 0);
+    p.up[i] = make_uint4(0, 0, 0, 0);
+    if (gr < row_lim) {
+      const bf16_t* rp = base + (size_t)gr * pitch;
+      if (R.cos_tab) {
+        p.lo[i] = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8);
+        p.up[i] = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8 + 32);
+      } else {
+        p.lo[i] = *reinterpret_cast<const uint4*>(rp + ch * 8);
+      }
+    }
+  }
+}
+template <int NT>
+__device__ __forceinline__ void tile_commit(unsigned char* lds, TilePref<NT>& p, int r0, int row_lim, int tid, const Rope& R,
+                                            int b) {
+#pragma unroll
+  for (int i = 0; i < 256 / NT; ++i) {
+    const int c = tid + i * NT;
+    const int row = c >> 3, ch = c & 7;
+    const int gr = r0 + row;
+    uint4 v = p.lo[i];
+    if (R.cos_tab && gr < row_lim) {
+      uint4 lo = p.lo[i], up = p.up[i];
+      rope_pair(lo, up, R, rope_pos(R, b, gr), (ch & 3) * 8);
+      v = (ch & 4) ? up : lo;
+    }
+    *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = v;
+  }
+}
 __device__ __forceinline__ void load_tile_rope(unsigned char* lds, const bf16_t* __restrict__ base, int r0, int row_lim,
                                                size_t pitch, int lane, const Rope& R, int b) {
   if (!R.cos_tab) { load_tile(lds, base, r0, row_lim, pitch, lane); return; }
@@ -132,12 +177,19 @@ struct Drop {
   float inv_keep;    // 1 / (1 - p)
   unsigned seed;
 };
-__device__ __forceinline__ float drop_mul(const Drop& D, unsigned bh, unsigned q, unsigned k) {
+// hash(seed, bh, q, k) = mix((seed ^ bh*C0) + q*C1 + k*C2), mix = one multiply between two xor-shifts: the softmax loop is
+// VALU-bound (head_dim 64) and integer multiplies are quarter rate, so the per-element cost is kept to 2 adds + 1 multiply:
+// callers pass the partial sum of everything that is fixed for the lane (drop_base) and add the moving coordinate's term.
+__device__ __forceinline__ unsigned drop_base(const Drop& D, unsigned bh, unsigned q_or_0, unsigned k_or_0) {
+  return (D.seed ^ (bh * 0x9E3779B1u)) + q_or_0 * 0x85EBCA77u + k_or_0 * 0xC2B2AE3Du;
+}
+__device__ __forceinline__ float drop_mul_x(const Drop& D, unsigned x) {
   if (D.thresh == 0) return 1.f;
-  unsigned x = D.seed ^ (bh * 0x9E3779B1u);
-  x += q * 0x85EBCA77u + k * 0xC2B2AE3Du;
-  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  x ^= x >> 16; x *= 0x045D9F3Bu; x ^= x >> 16;
   return (x >> 8) < D.thresh ? 0.f : D.inv_keep;
+}
+__device__ __forceinline__ float drop_mul(const Drop& D, unsigned bh, unsigned q, unsigned k) {
+  return drop_mul_x(D, drop_base(D, bh, q, k));
 }
 
 // the 4 dh-fragments of one row (dh chunk [16s + 8hi, +8), s = 0..3), rotated: chunks s and s+2 are 32 channels apart
@@ -247,14 +299,30 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
   frags_global_rope(qf, qb, qrow, S, pitch, lane, R, b);
   f32x16_t o0 = zero16(), o1 = zero16();
   float m = -INFINITY, l = 0.f;
+  const unsigned dbase = drop_base(D, b * H + h, qrow, 0);
   const int q_end_blk = min(S, (int)(blockIdx.x + 1) * NW * 32);       // one past the block's last query row
   const int kend_blk = causal ? min(klen, q_end_blk) : klen;
   const int kend = (q0 < S) ? (causal ? min(klen, q0 + 32) : klen) : 0;   // this wave's own key range
+  constexpr bool PF = NW > 1;   // single-wave blocks see one tile (S <= 32): nothing to prefetch, registers are tight
+  TilePref<NW * 64> pk, pv;
+  if (PF && kend_blk > 0) {
+    tile_fetch<NW * 64>(pk, kb, 0, S, pitch, tid, R);
+    tile_fetch<NW * 64>(pv, vb, 0, S, pitch, tid, Rnone);
+  }
   for (int k0 = 0; k0 < kend_blk; k0 += 32) {
     __syncthreads();  // previous tile fully consumed
-    load_tile_coop<NW * 64>(kt, kb, k0, S, pitch, tid, R, b);
-    load_tile_coop<NW * 64>(vt, vb, k0, S, pitch, tid, Rnone, b);
+    if constexpr (PF) {
+      tile_commit<NW * 64>(kt, pk, k0, S, tid, R, b);
+      tile_commit<NW * 64>(vt, pv, k0, S, tid, Rnone, b);
+    } else {
+      load_tile_coop<NW * 64>(kt, kb, k0, S, pitch, tid, R, b);
+      load_tile_coop<NW * 64>(vt, vb, k0, S, pitch, tid, Rnone, b);
+    }
     __syncthreads();
+    if (PF && k0 + 32 < kend_blk) {   // next tile's loads fly while this one is computed
+      tile_fetch<NW * 64>(pk, kb, k0 + 32, S, pitch, tid, R);
+      tile_fetch<NW * 64>(pv, vb, k0 + 32, S, pitch, tid, Rnone);
+    }
     if (k0 >= kend) continue;
     f32x16_t sc = zero16();
 #pragma unroll
@@ -276,7 +344,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
     for (int r = 0; r < 16; ++r) {
       const float p = dead ? 0.f : __expf(sc[r] - m_new);
       rs += p;                                                                    // softmax normaliser: before dropout
-      sc[r] = p * drop_mul(D, b * H + h, qrow, k0 + acc_row(r, hi));              // what multiplies V
+      sc[r] = p * drop_mul_x(D, dbase + (unsigned)(k0 + acc_row(r, hi)) * 0xC2B2AE3Du);   // what multiplies V
     }
     rs += __shfl_xor(rs, 32, 64);
     l = l * alpha + rs;
@@ -350,15 +418,31 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
   for (int s = 0; s < 4; ++s) dof[s] = frag_global(dob, qrow, S, (size_t)d, s, lane);
   const size_t sidx = ((size_t)b * H + h) * S + min(qrow, S - 1);
   const float lse_q = lse[sidx], dl_q = delta[sidx];
+  const unsigned dbase = drop_base(D, b * H + h, qrow, 0);
   f32x16_t a0 = zero16(), a1 = zero16();
   const int q_end_blk = min(S, (int)(blockIdx.x + 1) * NW * 32);
   const int kend_blk = causal ? min(klen, q_end_blk) : klen;
   const int kend = (q0 < S) ? (causal ? min(klen, q0 + 32) : klen) : 0;
+  constexpr bool PF = NW > 1;
+  TilePref<NW * 64> pk, pv;
+  if (PF && kend_blk > 0) {
+    tile_fetch<NW * 64>(pk, kb, 0, S, pitch, tid, Rin);
+    tile_fetch<NW * 64>(pv, vb, 0, S, pitch, tid, Rnone);
+  }
   for (int k0 = 0; k0 < kend_blk; k0 += 32) {
     __syncthreads();
-    load_tile_coop<NW * 64>(kt, kb, k0, S, pitch, tid, Rin, b);
-    load_tile_coop<NW * 64>(vt, vb, k0, S, pitch, tid, Rnone, b);
+    if constexpr (PF) {
+      tile_commit<NW * 64>(kt, pk, k0, S, tid, Rin, b);
+      tile_commit<NW * 64>(vt, pv, k0, S, tid, Rnone, b);
+    } else {
+      load_tile_coop<NW * 64>(kt, kb, k0, S, pitch, tid, Rin, b);
+      load_tile_coop<NW * 64>(vt, vb, k0, S, pitch, tid, Rnone, b);
+    }
     __syncthreads();
+    if (PF && k0 + 32 < kend_blk) {
+      tile_fetch<NW * 64>(pk, kb, k0 + 32, S, pitch, tid, Rin);
+      tile_fetch<NW * 64>(pv, vb, k0 + 32, S, pitch, tid, Rnone);
+    }
     if (k0 >= kend) continue;
     f32x16_t dp = zero16(), sc = zero16();
 #pragma unroll
@@ -371,7 +455,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
       const int key = k0 + acc_row(r, hi);
       const bool ok = key < klen && (!causal || key <= qrow) && qrow < S;
       const float p = ok ? __expf(sc[r] * kScale - lse_q) : 0.f;
-      sc[r] = p * (dp[r] * drop_mul(D, b * H + h, qrow, key) - dl_q) * kScale;
+      sc[r] = p * (dp[r] * drop_mul_x(D, dbase + (unsigned)key * 0xC2B2AE3Du) - dl_q) * kScale;
     }
     const bf16x8_t ds0 = acc_to_b(sc, 0), ds1 = acc_to_b(sc, 1);
     a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 0, lane), ds0, a0, 0, 0, 0);
@@ -414,19 +498,40 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
   for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, krow, S, pitch, s, lane);
   f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
   const bool key_ok = krow < klen;
+  const unsigned dbase = drop_base(D, b * H + h, 0, krow);
   const int kblk0 = blockIdx.x * NW * 32;          // first key of the block
   const int qstart = causal ? kblk0 : 0;           // queries before the block's first key never see it
   if (kblk0 < klen) {
-    for (int q0 = qstart; q0 < S; q0 += 32) {
-      __syncthreads();
-      load_tile_coop<NW * 64>(qt, qb, q0, S, pitch, tid, Rin, b);
-      load_tile_coop<NW * 64>(dot_, dob, q0, S, (size_t)d, tid, Rnone, b);
+    TilePref<NW * 64> pq, pdo;
+    float p_lse = 0.f, p_dl = 0.f;
+    auto fetch_q = [&](int q0) {
+      tile_fetch<NW * 64>(pq, qb, q0, S, pitch, tid, Rin);
+      tile_fetch<NW * 64>(pdo, dob, q0, S, (size_t)d, tid, Rnone);
       if (tid < 32) {
         const int q = min(q0 + tid, S - 1);
-        lse_s[tid] = lse[((size_t)b * H + h) * S + q];
-        dl_s[tid] = delta[((size_t)b * H + h) * S + q];
+        p_lse = lse[((size_t)b * H + h) * S + q];
+        p_dl = delta[((size_t)b * H + h) * S + q];
+      }
+    };
+    constexpr bool PF = NW > 1;
+    if (PF && qstart < S) fetch_q(qstart);
+    for (int q0 = qstart; q0 < S; q0 += 32) {
+      __syncthreads();
+      if constexpr (PF) {
+        tile_commit<NW * 64>(qt, pq, q0, S, tid, Rin, b);
+        tile_commit<NW * 64>(dot_, pdo, q0, S, tid, Rnone, b);
+        if (tid < 32) { lse_s[tid] = p_lse; dl_s[tid] = p_dl; }
+      } else {
+        load_tile_coop<NW * 64>(qt, qb, q0, S, pitch, tid, Rin, b);
+        load_tile_coop<NW * 64>(dot_, dob, q0, S, (size_t)d, tid, Rnone, b);
+        if (tid < 32) {
+          const int q = min(q0 + tid, S - 1);
+          lse_s[tid] = lse[((size_t)b * H + h) * S + q];
+          dl_s[tid] = delta[((size_t)b * H + h) * S + q];
+        }
       }
       __syncthreads();
+      if (PF && q0 + 32 < S) fetch_q(q0 + 32);
       if (k0 >= klen || (causal && q0 + 31 < k0)) continue;   // this wave's keys are padding / all in the future
       f32x16_t sc = zero16(), dp = zero16();
 #pragma unroll
@@ -440,7 +545,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
         const int q = q0 + qi;
         const bool ok = key_ok && q < S && (!causal || krow <= q);
         const float p = ok ? __expf(sc[r] * kScale - lse_s[qi]) : 0.f;
-        const float dm = drop_mul(D, b * H + h, q, krow);
+        const float dm = drop_mul_x(D, dbase + (unsigned)q * 0x85EBCA77u);
         sc[r] = p * dm;                                  // dropped probabilities: what multiplied V in forward
         dp[r] = p * (dp[r] * dm - dl_s[qi]) * kScale;
       }

@@ -312,8 +312,7 @@ def _drop_mask(seed, B, H, S, p):
     M32 = np.uint64(0xFFFFFFFF)
     x = (np.uint64(seed) ^ ((bh * np.uint64(0x9E3779B1)) & M32)) & M32
     x = (x + q * np.uint64(0x85EBCA77) + k * np.uint64(0xC2B2AE3D)) & M32
-    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & M32
-    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & M32
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x045D9F3B)) & M32
     x ^= x >> np.uint64(16)
     thresh = np.uint64(int(np.float32(p) * np.float32(16777216.0)))
     keep = (x >> np.uint64(8)) >= thresh

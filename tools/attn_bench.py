@@ -1,0 +1,24 @@
+"""Attention fwd/bwd micro-benchmark through the C ABI (HIP events): (B,S,H) list, dropout 0 / 0.1."""
+import ctypes as C, importlib, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+L = importlib.import_module("graph-gpt_amd._lib"); lib = L.load()
+P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def t(f, n=10):
+    for _ in range(3): f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+for (B, S, H) in [(256, 32, 12), (256, 256, 12), (16, 2048, 12)]:
+    d = H * 64; T = B * S
+    qkv = torch.randn(T, 3 * d, device="cuda").to(torch.bfloat16); out = torch.empty(T, d, dtype=torch.bfloat16, device="cuda")
+    dout = torch.randn(T, d, device="cuda").to(torch.bfloat16); dqkv = torch.empty_like(qkv)
+    lse = torch.empty(B * H * S, device="cuda"); delta = torch.empty(B * H * S, device="cuda")
+    lens = torch.full((B,), S, dtype=torch.int32, device="cuda")
+    fl = 4.0 * B * H * S * S * 64
+    for p in (0.0, 0.1):
+        f = t(lambda: L.check(lib.gget_op_attn_fwd(P(qkv), P(lens), P(out), P(lse), B, S, H, 0, None, None, None, p, 7, st)))
+        b = t(lambda: L.check(lib.gget_op_attn_bwd(P(qkv), P(out), P(dout), P(lse), P(lens), P(dqkv), P(delta), B, S, H, 0, None, None, None, p, 7, st)))
+        print(f"B={B} S={S} H={H} p={p}: fwd {f:8.1f} us ({fl/f/1e6:6.1f} TF)  bwd {b:8.1f} us ({2.5*fl/b/1e6:6.1f} TF)")

@@ -19,6 +19,8 @@
 namespace {
 
 constexpr float kScale = 0.125f;  // head_dim^-0.5, head_dim = 64
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kScaleL2 = kScale * kLog2e;   // scores are carried in the log2 domain: p = exp2(s * kScaleL2 - m2)
 
 __device__ __forceinline__ int swz(int row, int byte_in_row) {
   return row * 128 + (byte_in_row ^ (((row >> 1) & 1) << 6));
@@ -327,30 +329,42 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
     f32x16_t sc = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), qf[s], sc, 0, 0, 0);
+    // The loop is VALU-bound (head_dim 64: ~0.25 MFMA cycles but several VALU cycles per score), so: scores stay raw
+    // until one fma + exp2 (scale and log2(e) folded, running max kept in the log2 domain); the key / causal mask is only
+    // evaluated on tiles that touch the sequence end or the diagonal; O is rescaled only when some lane's max moved.
+    const bool edge = (k0 + 32 > klen) || (causal && k0 + 31 > q0) || (q0 + 32 > S);
     float mx = -INFINITY;
+    if (edge) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + acc_row(r, hi);
-      const bool ok = key < klen && (!causal || key <= qrow);
-      sc[r] = ok ? sc[r] * kScale : -INFINITY;
-      mx = fmaxf(mx, sc[r]);
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + acc_row(r, hi);
+        const bool ok = key < klen && (!causal || key <= qrow);
+        sc[r] = ok ? sc[r] : -INFINITY;
+        mx = fmaxf(mx, sc[r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m, mx);
+    const float m_new = fmaxf(m, mx * kScaleL2);     // kScaleL2 > 0: max commutes with the scaling
     const bool dead = m_new == -INFINITY;
-    const float alpha = dead ? 1.f : __expf(m - m_new);
+    const float alpha = dead ? 1.f : exp2f(m - m_new);
+    const float nm = dead ? 0.f : -m_new;
     float rs = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = dead ? 0.f : __expf(sc[r] - m_new);
+      const float p = dead ? 0.f : exp2f(fmaf(sc[r], kScaleL2, nm));
       rs += p;                                                                    // softmax normaliser: before dropout
       sc[r] = p * drop_mul_x(D, dbase + (unsigned)(k0 + acc_row(r, hi)) * 0xC2B2AE3Du);   // what multiplies V
     }
     rs += __shfl_xor(rs, 32, 64);
     l = l * alpha + rs;
     m = m_new;
+    if (__any(alpha != 1.f)) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    }
     const bf16x8_t pb0 = acc_to_b(sc, 0), pb1 = acc_to_b(sc, 1);
     o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 0, lane), pb0, o0, 0, 0, 0);
     o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 1, lane), pb1, o0, 0, 0, 0);
@@ -360,7 +374,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
   if (qrow < S) {
     const float inv = l > 0.f ? 1.f / l : 0.f;   // (the keep scale 1/(1-p) is already folded into the dropped P)
     store_t(out + ((size_t)b * S + qrow) * d + h * 64, o0, o1, inv, hi);
-    if (hi == 0 && lse) lse[((size_t)b * H + h) * S + qrow] = l > 0.f ? m + __logf(l) : 0.f;
+    if (hi == 0 && lse) lse[((size_t)b * H + h) * S + qrow] = l > 0.f ? (m + log2f(l)) * (1.0f / kLog2e) : 0.f;   // natural log
   }
 }
 
@@ -417,7 +431,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
 #pragma unroll
   for (int s = 0; s < 4; ++s) dof[s] = frag_global(dob, qrow, S, (size_t)d, s, lane);
   const size_t sidx = ((size_t)b * H + h) * S + min(qrow, S - 1);
-  const float lse_q = lse[sidx], dl_q = delta[sidx];
+  const float nlse2 = -lse[sidx] * kLog2e, ndl = -delta[sidx];
   const unsigned dbase = drop_base(D, b * H + h, qrow, 0);
   f32x16_t a0 = zero16(), a1 = zero16();
   const int q_end_blk = min(S, (int)(blockIdx.x + 1) * NW * 32);
@@ -450,12 +464,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, s, lane), dof[s], dp, 0, 0, 0);
       sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), qf[s], sc, 0, 0, 0);
     }
+    const bool edge = (k0 + 32 > klen) || (causal && k0 + 31 > q0) || (q0 + 32 > S);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + acc_row(r, hi);
-      const bool ok = key < klen && (!causal || key <= qrow) && qrow < S;
-      const float p = ok ? __expf(sc[r] * kScale - lse_q) : 0.f;
-      sc[r] = p * (dp[r] * drop_mul_x(D, dbase + (unsigned)key * 0xC2B2AE3Du) - dl_q) * kScale;
+      float p = exp2f(fmaf(sc[r], kScaleL2, nlse2));
+      if (edge) p = (key < klen && (!causal || key <= qrow) && qrow < S) ? p : 0.f;
+      sc[r] = p * fmaf(dp[r], drop_mul_x(D, dbase + (unsigned)key * 0xC2B2AE3Du), ndl) * kScale;
     }
     const bf16x8_t ds0 = acc_to_b(sc, 0), ds1 = acc_to_b(sc, 1);
     a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 0, lane), ds0, a0, 0, 0, 0);
@@ -520,14 +535,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
       if constexpr (PF) {
         tile_commit<NW * 64>(qt, pq, q0, S, tid, Rin, b);
         tile_commit<NW * 64>(dot_, pdo, q0, S, tid, Rnone, b);
-        if (tid < 32) { lse_s[tid] = p_lse; dl_s[tid] = p_dl; }
+        if (tid < 32) { lse_s[tid] = -p_lse * kLog2e; dl_s[tid] = -p_dl; }
       } else {
         load_tile_coop<NW * 64>(qt, qb, q0, S, pitch, tid, Rin, b);
         load_tile_coop<NW * 64>(dot_, dob, q0, S, (size_t)d, tid, Rnone, b);
         if (tid < 32) {
           const int q = min(q0 + tid, S - 1);
-          lse_s[tid] = lse[((size_t)b * H + h) * S + q];
-          dl_s[tid] = delta[((size_t)b * H + h) * S + q];
+          lse_s[tid] = -lse[((size_t)b * H + h) * S + q] * kLog2e;
+          dl_s[tid] = -delta[((size_t)b * H + h) * S + q];
         }
       }
       __syncthreads();
@@ -539,15 +554,16 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
         sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, s, lane), kf[s], sc, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dot_, s, lane), vf[s], dp, 0, 0, 0);
       }
+      const bool edge = (k0 + 32 > klen) || (q0 + 32 > S) || (causal && k0 + 31 > q0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qi = acc_row(r, hi);
         const int q = q0 + qi;
-        const bool ok = key_ok && q < S && (!causal || krow <= q);
-        const float p = ok ? __expf(sc[r] * kScale - lse_s[qi]) : 0.f;
+        float p = exp2f(fmaf(sc[r], kScaleL2, lse_s[qi]));          // lse_s holds -lse * log2(e)
+        if (edge) p = (key_ok && q < S && (!causal || krow <= q)) ? p : 0.f;
         const float dm = drop_mul_x(D, dbase + (unsigned)q * 0x85EBCA77u);
         sc[r] = p * dm;                                  // dropped probabilities: what multiplied V in forward
-        dp[r] = p * (dp[r] * dm - dl_s[qi]) * kScale;
+        dp[r] = p * fmaf(dp[r], dm, dl_s[qi]) * kScale;  // dl_s holds -delta
       }
       const bf16x8_t p0 = acc_to_b(sc, 0), p1 = acc_to_b(sc, 1);
       const bf16x8_t s0 = acc_to_b(dp, 0), s1 = acc_to_b(dp, 1);

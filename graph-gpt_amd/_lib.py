@@ -73,7 +73,7 @@ SIGNATURES = {
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_NONE, EPI_RESIDUAL, EPI_ATOMIC_F32, EPI_SLAB_F32 = 0, 1, 2, 3
-PROBLEM_SINGLE_LABEL, PROBLEM_REGRESSION_L1, PROBLEM_REGRESSION_MSE = 0, 1, 2
+PROBLEM_SINGLE_LABEL, PROBLEM_REGRESSION_L1, PROBLEM_REGRESSION_MSE, PROBLEM_MULTI_LABEL = 0, 1, 2, 3
 
 _lib = None
 

@@ -631,9 +631,37 @@ __global__ void __launch_bounds__(kBlock) task_loss_kernel(const float* __restri
     wsum = wsum_s;
     __syncthreads();
   }
+  if (problem == GGET_PROBLEM_MULTI_LABEL) {   // mean over the labelled (non-NaN) entries: count them first
+    float p = 0.f;
+    for (int i = threadIdx.x; i < B * C; i += kBlock) {
+      const float y = reinterpret_cast<const float*>(labels)[i];
+      p += (y == y) ? 1.f : 0.f;
+    }
+    red[threadIdx.x] = p;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) wsum_s = red[0];
+    __syncthreads();
+    wsum = wsum_s;
+    __syncthreads();
+  }
   float local = 0.f;
   for (int b = threadIdx.x; b < B; b += kBlock) {
-    if (problem == GGET_PROBLEM_SINGLE_LABEL) {
+    if (problem == GGET_PROBLEM_MULTI_LABEL) {
+      // BCEWithLogitsLoss (pos_weight None) on labelled entries, modeling_finetune.py:227-230:
+      // l = max(x, 0) - x*y + log(1 + exp(-|x|)),  dl/dx = sigmoid(x) - y
+      const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
+      for (int c = 0; c < C; ++c) {
+        const float y = reinterpret_cast<const float*>(labels)[b * C + c];
+        const float x = logits[b * C + c];
+        if (y == y) {
+          local += (fmaxf(x, 0.f) - x * y + log1pf(__expf(-fabsf(x)))) * inv;
+          dlogits[b * C + c] = (1.0f / (1.0f + __expf(-x)) - y) * inv;
+        } else {
+          dlogits[b * C + c] = 0.f;
+        }
+      }
+    } else if (problem == GGET_PROBLEM_SINGLE_LABEL) {
       const int y = (int)reinterpret_cast<const int64_t*>(labels)[b];
       float mx = -INFINITY;
       for (int c = 0; c < C; ++c) mx = fmaxf(mx, logits[b * C + c]);

@@ -349,7 +349,7 @@ class GraphGPTTaskModel(_GgetModel):
                 raise NotImplementedError(f"loss_type={cfg.loss_type!r} is outside the hot-path scope")
             code = L.PROBLEM_SINGLE_LABEL
         else:
-            raise NotImplementedError("multi-label BCE head is outside the hot-path scope")
+            code = L.PROBLEM_MULTI_LABEL   # BCE-with-logits on the labelled entries (modeling_finetune.py:227-230)
         e = self._pre_forward(B, S)
         loss, logits, hid = e.forward_task(input_ids, attention_mask, position_ids, task_labels, sample_wgt, code)
         return DoubleHeadsModelOutput(pretrain_loss=None, task_loss=self._wrap_loss(loss), pretrain_logits=None,

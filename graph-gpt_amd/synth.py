@@ -73,8 +73,10 @@ def make_pretrain_batch(B: int, S: int, F: int, V: int, seed: int = 1234, *, len
 
 def make_task_batch(B: int, S: int, F: int, V: int, seed: int = 1234, *, lengths: str = "uniform",
                     min_len: int = 8, first_id: int = 22, num_labels: int = 2,
-                    regression: bool = False) -> Dict[str, np.ndarray]:
-    """Fine-tune batch (edge/graph-level): ids, attention_mask, position_ids, task_labels [B]."""
+                    regression: bool = False, multi_label: bool = False) -> Dict[str, np.ndarray]:
+    """Fine-tune batch (edge/graph-level): ids, attention_mask, position_ids, task_labels [B]
+    (multi_label: float [B, num_labels] in {0, 1} with NaN = unlabelled, the ogbg-molpcba convention the reference's
+    `is_labeled = labels == labels` relies on, modeling_finetune.py:227-230)."""
     rng = np.random.RandomState(seed)
     lens = _lengths(rng, B, S, lengths, min_len)
     if lengths != "full":
@@ -90,6 +92,10 @@ def make_task_batch(B: int, S: int, F: int, V: int, seed: int = 1234, *, lengths
         pos[b, :n] = np.arange(n)
     if regression:
         y = rng.standard_normal(size=(B,)).astype(np.float32)
+    elif multi_label:
+        y = rng.randint(0, 2, size=(B, num_labels)).astype(np.float32)
+        y[rng.rand(B, num_labels) < 0.25] = np.nan
+        y[0, 0] = 1.0   # at least one labelled entry
     else:
         y = rng.randint(0, num_labels, size=(B,)).astype(np.int64)
     return dict(input_ids=ids, attention_mask=att, position_ids=pos, task_labels=y, lengths=lens)

@@ -35,6 +35,7 @@ extern "C" {
 #define GGET_PROBLEM_SINGLE_LABEL 0 /* CrossEntropy on pooled logits (modeling_finetune.py:209-214) */
 #define GGET_PROBLEM_REGRESSION_L1 1 /* L1Loss  (modeling_finetune.py:183-197) */
 #define GGET_PROBLEM_REGRESSION_MSE 2 /* MSELoss */
+#define GGET_PROBLEM_MULTI_LABEL 3 /* BCEWithLogitsLoss on the non-NaN entries of float labels [B,num_labels] (modeling_finetune.py:227-230) */
 
 /* Field meaning = GraphGPTConfig (src/models/graphgpt/configuration_graphgpt.py:26-110). */
 typedef struct gget_config_t {

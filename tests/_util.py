@@ -15,7 +15,17 @@ synth = importlib.import_module("graph-gpt_amd.synth")
 
 PT_CASES = ["pt_tiny_f13_a", "pt_tiny_f13_b", "pt_tiny_f1", "pt_tiny_causal", "pt_tiny_gated", "pt_tiny_wgt",
             "pt_tiny_bigw", "pt_tiny_s72"]
-FT_CASES = ["ft_tiny_f4", "ft_tiny_ls", "ft_tiny_reg"]
+FT_CASES = ["ft_tiny_f4", "ft_tiny_ls", "ft_tiny_reg", "ft_tiny_ml"]
+
+
+def ft_problem(spec, b):
+    """(problem_type, loss_type) of a fine-tune fixture, as the reference infers it (modeling_finetune.py:175-183)."""
+    import torch
+    if spec.num_labels == 1:
+        return "regression", "l1"
+    if torch.is_floating_point(b["task_labels"]):
+        return "multi_label_classification", None
+    return "single_label_classification", None
 ADAM = dict(lr=1e-3, beta1=0.9, beta2=0.95, eps=1e-8, wd=0.1)
 CLIP = 1.0
 

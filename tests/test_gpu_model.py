@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import ADAM, CLIP, FT_CASES, PT_CASES, load_case, rel_l2, tb
+from _util import ADAM, CLIP, FT_CASES, PT_CASES, ft_problem, load_case, rel_l2, tb
 from oracle import gget_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -28,8 +28,8 @@ def run_forward(e, spec, b, kind):
     if kind == "pt":
         loss = e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], b.get("wgt"))
         return loss, None
-    reg = spec.num_labels == 1
-    problem = L.PROBLEM_REGRESSION_L1 if reg else L.PROBLEM_SINGLE_LABEL
+    problem = {"regression": L.PROBLEM_REGRESSION_L1, "multi_label_classification": L.PROBLEM_MULTI_LABEL,
+               "single_label_classification": L.PROBLEM_SINGLE_LABEL}[ft_problem(spec, b)[0]]
     loss, logits, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], None, problem)
     return loss, logits
 
@@ -38,15 +38,14 @@ def oracle_fn(spec, b, kind):
     if kind == "pt":
         return (lambda p: O.pretrain_forward(spec, p, b["input_ids"], b["attention_mask"], b["labels"], b.get("wgt"))), \
             "head1_loss", "head1_logits"
-    reg = spec.num_labels == 1
+    problem, loss_type = ft_problem(spec, b)
     return (lambda p: O.task_forward(spec, p, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"],
-                                     problem_type="regression" if reg else "single_label_classification",
-                                     loss_type="l1" if reg else None)), "task_loss", "task_logits"
+                                     problem_type=problem, loss_type=loss_type)), "task_loss", "task_logits"
 
 
 # loss tolerance: north_star asks 1e-4 relative on bf16; the reference's OWN bf16 path is 1.3e-4 away from its fp32
 # path on the big-weight S=72 case, so big-weight cases get 6e-4.
-LOSS_TOL = {"pt_tiny_bigw": 6e-4, "pt_tiny_s72": 6e-4, "ft_tiny_f4": 3e-3, "ft_tiny_ls": 3e-2, "ft_tiny_reg": 8e-3}
+LOSS_TOL = {"pt_tiny_bigw": 6e-4, "pt_tiny_s72": 6e-4, "ft_tiny_f4": 3e-3, "ft_tiny_ls": 3e-2, "ft_tiny_reg": 8e-3, "ft_tiny_ml": 3e-3}
 
 
 @pytest.mark.parametrize("name", PT_CASES + FT_CASES)
@@ -77,7 +76,7 @@ def test_forward_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", ["pt_tiny_f13_a", "pt_tiny_f1", "pt_tiny_causal", "pt_tiny_gated", "pt_tiny_wgt",
-                                  "pt_tiny_bigw", "pt_tiny_s72", "ft_tiny_f4", "ft_tiny_ls", "ft_tiny_reg"])
+                                  "pt_tiny_bigw", "pt_tiny_s72", "ft_tiny_f4", "ft_tiny_ls", "ft_tiny_reg", "ft_tiny_ml"])
 def test_backward_matches_oracle(name):
     z, spec, state, batch = load_case(name)
     kind = "pt" if name.startswith("pt") else "ft"

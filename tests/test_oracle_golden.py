@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import ADAM, CLIP, FT_CASES, PT_CASES, load_case, rel_l2, tb
+from _util import ADAM, CLIP, FT_CASES, PT_CASES, ft_problem, load_case, rel_l2, tb
 from oracle import gget_oracle as O
 
 
@@ -13,12 +13,11 @@ def _fwd_fn(spec, b, kind):
         def fn(p):
             return O.pretrain_forward(spec, p, b["input_ids"], b["attention_mask"], b["labels"], b.get("wgt"))
         return fn, "head1_loss", "head1_logits"
-    reg = spec.num_labels == 1
+    problem, loss_type = ft_problem(spec, b)
 
     def fn(p):
         return O.task_forward(spec, p, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"],
-                              problem_type="regression" if reg else "single_label_classification",
-                              loss_type="l1" if reg else None)
+                              problem_type=problem, loss_type=loss_type)
     return fn, "task_loss", "task_logits"
 
 

@@ -121,6 +121,8 @@ CASES = [
      dict(B=4, S=40, seed=9), dict(std=0.06, head_std=0.15)),
     ("ft_tiny_reg", "ft", dict(vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=1, score_bias=True),
      dict(B=4, S=24, seed=12, regression=True), dict(std=0.06, head_std=0.15)),
+    ("ft_tiny_ml", "ft", dict(vocab_size=1000, stacked_feat=4, next_n_token=1, num_labels=5),
+     dict(B=6, S=24, seed=13, multi_label=True), dict(std=0.06, head_std=0.15)),
 ]
 
 ADAM = dict(lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
@@ -139,10 +141,11 @@ def run_case(name, kind, skw, bkw, ikw, classes):
         model = PT(cfg)
     else:
         reg = bkw.pop("regression", False)
+        ml = bkw.pop("multi_label", False)
         batch = synth.make_task_batch(F=spec.stacked_feat, V=spec.vocab_size, num_labels=spec.num_labels,
-                                      regression=reg, **bkw)
+                                      regression=reg, multi_label=ml, **bkw)
         extra = dict(num_labels=spec.num_labels, loss_type="l1" if reg else None, mlp=[],
-                     problem_type="regression" if reg else "single_label_classification")
+                     problem_type="regression" if reg else ("multi_label_classification" if ml else "single_label_classification"))
         cfg = ref_config(Cfg, spec, **extra)
         model = FT(cfg)
     load_weights(model, state)

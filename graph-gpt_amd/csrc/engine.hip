@@ -901,6 +901,11 @@ extern "C" int gget_op_smtp2d(const int64_t* ids_in, int ld_in, const int64_t* n
   return k_smtp2d(ids_in, ld_in, node_idx, ld_node, ids_out, labels_out, B, S, F, smtp_2d_rate, power, replace_rate, vocab,
                   global_2d_mask, seed, (hipStream_t)stream);
 }
+extern "C" int gget_op_token_confidence(const void* logits, int ld, int R, int V, int mode, float* conf, int64_t* tok, void* stream) {
+  GGET_REQUIRE(logits && conf && tok, "token_confidence: null argument");
+  GGET_REQUIRE(R >= 0 && V >= 2 && ld >= V && mode >= 0 && mode <= 2, "token_confidence: bad arguments (R %d V %d ld %d mode %d)", R, V, ld, mode);
+  return k_token_confidence(logits, ld, R, V, mode, conf, tok, (hipStream_t)stream);
+}
 extern "C" int gget_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, void* stream) {
   return k_rmsnorm_fwd(x, w, y, rstd, T, d, eps, (hipStream_t)stream);
 }

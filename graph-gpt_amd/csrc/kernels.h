@@ -67,3 +67,4 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
 int k_smtp2d(const int64_t* ids_in, int ld_in, const int64_t* node_idx, int ld_node, int64_t* ids_out, int64_t* labels_out,
              int B, int S, int F, float rate, float power, float replace_rate, int vocab, int global_mask, unsigned seed,
              hipStream_t st);
+int k_token_confidence(const void* logits, int ld, int R, int V, int mode, float* conf, int64_t* tok, hipStream_t st);

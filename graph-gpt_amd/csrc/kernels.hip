@@ -886,6 +886,51 @@ __global__ void __launch_bounds__(kBlock) smtp2d_kernel(const int64_t* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Unmasking confidence of the MaskGIT / dLLM generation loop
+// reference: sample_tokens at temperature 0 (src/utils/generation_utils.py:45-82): probs = softmax(logits),
+// x0 = argmax, confidence = max prob | top1 - top2 prob (margin) | sum p log(p + 1e-10) (negative entropy).
+// One wave per row of bf16 logits [R, ld] (V valid columns); fp32 arithmetic; ties -> lowest index (torch.max).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) token_confidence_kernel(const bf16_t* __restrict__ logits, int ld, int R, int V, int mode,
+                                                                  float* __restrict__ conf, int64_t* __restrict__ tok) {
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); row < R; row += gridDim.x * (kBlock / 64)) {
+    const bf16_t* x = logits + (size_t)row * ld;
+    float m1 = -INFINITY, m2 = -INFINITY;   // largest and second largest value seen by this lane
+    int i1 = 0x7fffffff;
+    for (int c = lane; c < V; c += 64) {
+      const float v = bf2f(x[c]);
+      if (v > m1) { m2 = m1; m1 = v; i1 = c; } else if (v > m2) { m2 = v; }
+    }
+    // wave reduction of (max, argmax with lowest index on ties, second max)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om1 = __shfl_xor(m1, o, 64), om2 = __shfl_xor(m2, o, 64);
+      const int oi1 = __shfl_xor(i1, o, 64);
+      if (om1 > m1 || (om1 == m1 && oi1 < i1)) { m2 = fmaxf(m1, om2); m1 = om1; i1 = oi1; }
+      else { m2 = fmaxf(m2, om1); }
+    }
+    float se = 0.f;
+    for (int c = lane; c < V; c += 64) se += __expf(bf2f(x[c]) - m1);
+    se = wave_sum(se);
+    float out;
+    if (mode == 2) {
+      float ent = 0.f;
+      for (int c = lane; c < V; c += 64) {
+        const float p = __expf(bf2f(x[c]) - m1) / se;
+        ent += p * __logf(p + 1e-10f);
+      }
+      out = wave_sum(ent);
+    } else if (mode == 1) {
+      out = 1.0f / se - __expf(m2 - m1) / se;
+    } else {
+      out = 1.0f / se;
+    }
+    if (lane == 0) { conf[row] = out; tok[row] = i1; }
+  }
+}
+
 inline int grid_for(long work_items, int per_block = kBlock, int cap = 4096) {
   long g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -1115,6 +1160,14 @@ int k_smtp2d(const int64_t* ids_in, int ld_in, const int64_t* node_idx, int ld_n
   if ((long)B * S * F == 0) return 0;
   hipLaunchKernelGGL(smtp2d_kernel, dim3(grid_for((long)B * S * F)), dim3(kBlock), 0, st, ids_in, ld_in, node_idx, ld_node,
                      ids_out, labels_out, B, S, F, rate, power, replace_rate, vocab, global_mask, seed, 1);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_token_confidence(const void* logits, int ld, int R, int V, int mode, float* conf, int64_t* tok, hipStream_t st) {
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(token_confidence_kernel, dim3(grid_for(R, kBlock / 64, 4096)), dim3(kBlock), 0, st, (const bf16_t*)logits,
+                     ld, R, V, mode, conf, tok);
   GGET_LAUNCH_CHECK();
   return 0;
 }

@@ -208,6 +208,17 @@ class Engine:
         raw = self.workspace[off: off + lm * ld.value * 2].view(torch.bfloat16).view(lm, ld.value)
         return raw[:, : self.spec.vocab_size].clone()
 
+    def token_confidence(self, rows: int, mode: int = 0):
+        """Arg-max token and unmasking confidence of the first `rows` rows of the head logits of the last forward, computed
+        in place on the workspace (no copy of the [rows, V] logits): (conf f32 [rows], token i64 [rows])."""
+        p, ld = C.c_void_p(), C.c_int32()
+        L.check(self.lib.gget_head_logits(self.h, C.byref(p), C.byref(ld)))
+        conf = torch.empty(rows, dtype=torch.float32, device=self.device)
+        tok = torch.empty(rows, dtype=torch.int64, device=self.device)
+        L.check(self.lib.gget_op_token_confidence(p, ld.value, int(rows), self.spec.vocab_size, int(mode), _ptr(conf), _ptr(tok),
+                                                  _stream()))
+        return conf, tok
+
     def hidden_states(self, B: int, S: int) -> torch.Tensor:
         p = C.c_void_p()
         L.check(self.lib.gget_hidden_states(self.h, C.byref(p)))

@@ -193,6 +193,14 @@ int gget_op_qkv_rope(const void* x, const void* wqkv, void* qkv, const float* co
 int gget_op_smtp2d(const int64_t* ids_in, int ld_in, const int64_t* node_idx, int ld_node, int64_t* ids_out, int64_t* labels_out,
                    int B, int S, int F, float smtp_2d_rate, float power, float replace_rate, int vocab, int global_2d_mask,
                    uint32_t seed, void* stream);
+/* replaces: sample_tokens at temperature 0 (src/utils/generation_utils.py:45-82) inside the unmasking loop
+ * (_batch_unmask_without_for_loop :139-237): per row of bf16 logits [R, ld] (V valid columns) the arg-max token and its
+ * confidence: mode 0 max softmax probability ("maskgit_plus"), 1 top1 - top2 probability ("topk_margin"),
+ * 2 sum p log(p + 1e-10) ("entropy").  Ties resolve to the lowest index. */
+#define GGET_CONF_MAXPROB 0
+#define GGET_CONF_MARGIN 1
+#define GGET_CONF_NEG_ENTROPY 2
+int gget_op_token_confidence(const void* logits, int ld, int R, int V, int mode, float* conf, int64_t* tok, void* stream);
 int gget_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, void* stream);
 int gget_op_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
                         void* dx, float* dw_accum, int T, int d, void* stream);

@@ -337,3 +337,57 @@ def smtp_2d_inputs_labels(input_ids, node_idx, u_sample, u_rate, u_cell, token_s
     replace_mask = mask_per_token & (u_replace < replace_rate)
     ids = ids * (~replace_mask).long() + rnd_tokens * replace_mask.long()
     return ids, labels
+
+
+# ----------------------------------------------------------------------------- generation loop (next item N3)
+def sample_tokens_t0(logits: torch.Tensor, margin_confidence: bool = False, neg_entropy: bool = False):
+    """reference sample_tokens at temperature 0 without top-p / top-k (src/utils/generation_utils.py:45-82)."""
+    probs = torch.softmax(logits, dim=-1)
+    confidence, x0 = probs.max(dim=-1)
+    if margin_confidence:
+        sp, _ = torch.sort(probs, dim=-1, descending=True)
+        confidence = sp[..., 0] - sp[..., 1]
+    if neg_entropy:
+        confidence = torch.sum(probs * torch.log(probs + 1e-10), dim=-1)
+    return confidence, x0
+
+
+def sample_per_batch(logits_fn, input_ids: torch.Tensor, *, alg: str, steps: int, eps: float, mask_token_id: int,
+                     conf_fn=None):
+    """reference sample_per_batch + _batch_unmask_without_for_loop (generation_utils.py:84-237) for the deterministic
+    algorithms ("maskgit_plus" | "topk_margin" | "entropy", temperature 0, alg_temp None).  `logits_fn(ids [B,S,F])` returns
+    logits [B*S*F, V]; `conf_fn(logits [B,N,V]) -> (confidence, candidates)` defaults to sample_tokens_t0.  Returns
+    (tokens [B, S*F], history list of [B,S,F])."""
+    bz, seq, next_n = input_ids.shape
+    x = input_ids.clone().view(bz, seq * next_n)
+    m = x == mask_token_id
+    n_steps = min(int(torch.max(m.sum(dim=-1).float()).item()), steps)
+    timesteps = torch.linspace(1, eps, n_steps + 1)
+    hist = []
+    i = 0
+    while i < n_steps:
+        logits = logits_fn(x.view(bz, seq, next_n)).view(bz, seq * next_n, -1)
+        mask_index = x == mask_token_id
+        k = 0
+        num_masked = mask_index.sum(dim=1)
+        num_all = num_masked.sum().item()
+        num_transfer = torch.zeros_like(num_masked).int()
+        while (k == 0) and (num_all > 0) and (i < n_steps):
+            t, s = timesteps[i], timesteps[i + 1]
+            p_transfer = 1 - s / t if i < n_steps - 1 else 1.0
+            num_transfer = torch.floor(num_masked * p_transfer).int()
+            k = num_transfer.max().item()
+            i += 1
+        if conf_fn is None:
+            confidence, cand = sample_tokens_t0(logits, margin_confidence=(alg == "topk_margin"), neg_entropy=(alg == "entropy"))
+        else:
+            confidence, cand = conf_fn(logits)
+        confidence = confidence.clone()
+        confidence[~mask_index] = -torch.inf
+        _, idx = torch.topk(confidence, k=k, dim=1)
+        updates = torch.gather(cand, 1, idx)
+        mask_out = torch.arange(k)[None, :] >= num_transfer[:, None]
+        final = torch.where(mask_out, mask_token_id, updates)
+        x.scatter_(1, idx, final)
+        hist.append(x.view(bz, seq, next_n).clone())
+    return x, hist

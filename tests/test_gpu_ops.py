@@ -420,3 +420,29 @@ def test_smtp2d_kernel_matches_oracle(lib, B, S, F, V, rate, power, rep, glob):
     if B * S * F > 5000:
         assert abs(float(uc.mean()) - 0.5) < 0.02
         assert abs(float(sh.std()) - 10.0) < 0.5 and abs(float(sh.mean())) < 0.5
+
+
+# ------------------------------------------------------------------------------------------ generation confidence (N3)
+@pytest.mark.parametrize("R,V", [(50, 97), (1000, 756), (333, 41245)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_token_confidence(lib, R, V, mode):
+    """gget_op_token_confidence vs sample_tokens at temperature 0 (oracle) on the same bf16 logits: identical arg-max
+    tokens, confidences to fp32 round-off."""
+    from oracle import gget_oracle as O
+    ld = (V + 63) // 64 * 64
+    g = torch.Generator().manual_seed(R + V)
+    logits = (torch.randn(R, ld, generator=g) * 3).to(torch.bfloat16)
+    logits[0, :V] = logits[0, 0]          # a full tie: lowest index wins (torch.max semantics)
+    dev = logits.cuda()
+    conf = torch.empty(R, dtype=torch.float32, device="cuda")
+    tok = torch.empty(R, dtype=torch.int64, device="cuda")
+    L.check(lib.gget_op_token_confidence(P(dev), ld, R, V, mode, P(conf), P(tok), ST()))
+    want_c, want_t = O.sample_tokens_t0(logits[:, :V].float(), margin_confidence=(mode == 1), neg_entropy=(mode == 2))
+    got_t = tok.cpu()
+    # bf16 logits tie often: the kernel and torch must agree on the VALUE of the chosen logit, and on the index when unique
+    picked = logits[:, :V].float().gather(1, got_t[:, None])[:, 0]
+    assert torch.equal(picked, logits[:, :V].float().max(dim=1).values)
+    uniq = (logits[:, :V].float() == picked[:, None]).sum(1) == 1
+    assert torch.equal(got_t[uniq], want_t[uniq])
+    assert int(got_t[0]) == 0
+    np.testing.assert_allclose(conf.cpu().numpy(), want_c.numpy(), rtol=2e-5, atol=2e-6)

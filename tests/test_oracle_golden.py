@@ -113,3 +113,31 @@ def test_smtp2d_masking_matches_reference(tag):
     assert torch.equal(ids, T("out_ids"))
     assert torch.equal(labels, T("out_labels"))
     assert (labels != -100).any() and (ids == 1).any()
+
+
+@pytest.mark.parametrize("alg", ["maskgit_plus", "topk_margin", "entropy"])
+def test_generation_loop_matches_reference(alg):
+    """Generation (next item N3): the oracle's restatement of sample_per_batch / _batch_unmask_without_for_loop, driven by
+    the oracle forward (labels=None -> logits for every feature token), reproduces the reference's token grid after every
+    iteration (fixture: reference loop + reference model on CPU)."""
+    import importlib
+    import os
+    spec_mod = importlib.import_module("graph-gpt_amd.spec")
+    weights = importlib.import_module("graph-gpt_amd.weights")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "generation.npz"))
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=300, stacked_feat=4, next_n_token=4)
+    assert list(g["meta_spec"]) == spec.as_c_ints()
+    std, head_std, seed = g["meta_init"]
+    p = O.to_params(weights.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(head_std)), torch.float32,
+                    requires_grad=False)
+    ids, att = torch.from_numpy(g["in_input_ids"]), torch.from_numpy(g["in_attention_mask"])
+
+    def logits_fn(x):
+        with torch.no_grad():
+            return O.pretrain_forward(spec, p, x, att, labels=None)["head1_logits"]
+
+    x, hist = O.sample_per_batch(logits_fn, ids, alg=alg, steps=6, eps=1e-3, mask_token_id=1)
+    assert len(hist) == len(g[f"{alg}_hist"])
+    for a, b in zip(hist, g[f"{alg}_hist"]):
+        assert torch.equal(a, torch.from_numpy(b))
+    assert torch.equal(x, torch.from_numpy(g[f"{alg}_x"]))

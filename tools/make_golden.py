@@ -302,6 +302,35 @@ def smtp2d_fixture():
     print("smtp2d written")
 
 
+def generation_fixture():
+    """Deterministic MaskGIT-style generation: the reference `sample_per_batch` (src/utils/generation_utils.py:84-237) driven
+    by the reference tiny pre-train model on CPU (fp32), one run per confidence algorithm."""
+    import types
+    classes = import_reference()
+    PT, FT, Cfg = classes
+    import importlib
+    gen = importlib.import_module("src.utils.generation_utils")
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=300, stacked_feat=4, next_n_token=4)
+    state = weights_mod.make_state_dict(spec, seed=321, std=0.08, head_std=0.2)
+    model = PT(ref_config(Cfg, spec))
+    load_weights(model, state)
+    model.eval()
+    batch = synth.make_pretrain_batch(B=3, S=16, F=4, V=300, seed=77)
+    ids = torch.from_numpy(batch["input_ids"])
+    att = torch.from_numpy(batch["attention_mask"])
+    res = {"in_input_ids": batch["input_ids"], "in_attention_mask": batch["attention_mask"],
+           "meta_spec": np.array(spec.as_c_ints(), np.int64), "meta_init": np.array([0.08, 0.2, 321], np.float64)}
+    for alg in ("maskgit_plus", "topk_margin", "entropy"):
+        cfg = types.SimpleNamespace(eps=1e-3, steps=6, mask_token_id=1, output_history=True, temperature=0.0, top_p=None,
+                                    top_k=None, alg=alg, alg_temp=None)
+        x, hist = gen.sample_per_batch(model, cfg, input_ids=ids.clone(), attention_mask=att, inputs_raw_embeds=None)
+        res[f"{alg}_x"] = x.numpy()
+        res[f"{alg}_hist"] = np.stack([h.numpy() for h in hist])
+        print(alg, "steps run", len(hist), "masked left", int((x == 1).sum()))
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "generation.npz"), **res)
+    print("generation written")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -315,6 +344,8 @@ def main():
         lr_fixture()
     if not only or "smtp2d" in only:
         smtp2d_fixture()
+    if not only or "generation" in only:
+        generation_fixture()
 
 
 if __name__ == "__main__":

@@ -46,6 +46,7 @@ SIGNATURES = {
     "gget_bucket_range": (i32, [vp, i32, C.POINTER(u64), C.POINTER(u64)]),
     "gget_sync_params": (i32, [vp, vp]),
     "gget_forward_pretrain": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    "gget_forward_pretrain_packed": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "gget_forward_task": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "gget_backward": (i32, [vp, f32, vp]),
     "gget_backward_begin": (i32, [vp, f32, vp]),
@@ -66,6 +67,9 @@ SIGNATURES = {
     "gget_op_rope": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "gget_op_attn_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, f32, C.c_uint32, vp]),
     "gget_op_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, f32, C.c_uint32, vp]),
+    "gget_op_attn_fwd_ranges": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint32, vp]),
+    "gget_op_attn_bwd_ranges": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint32, vp]),
+    "gget_op_ranges_from_mask3d": (i32, [vp, vp, vp, i32, i32, vp]),
     "gget_set_dropout": (i32, [vp, f32, f32, C.c_uint32]),
     "gget_op_geglu_fwd": (i32, [vp, vp, i32, i32, vp]),
     "gget_op_geglu_bwd": (i32, [vp, vp, vp, i32, i32, vp]),

@@ -194,6 +194,18 @@ __device__ __forceinline__ float drop_mul(const Drop& D, unsigned bh, unsigned q
   return drop_mul_x(D, drop_base(D, bh, q, k));
 }
 
+// Which keys a query may attend: right padding gives one length per batch row (key_len[b], keys [0, len)); packed rows
+// (several graphs back to back, block-diagonal [B,S,S] mask of reference src/utils/tokenizer_utils.py:349-355 /
+// modeling_helpers.py:51-64) give every token the inclusive key range [lo, hi] of its own graph.
+struct KeyRange {
+  const int32_t* key_len;   // [B] or nullptr (=> S); ignored when lo/hi are given
+  const int32_t* lo;        // [B,S] or nullptr
+  const int32_t* hi;        // [B,S]
+};
+// wave-uniform min / max of small non-negative integers (exact in fp32)
+__device__ __forceinline__ int wave_imin(int v) { return (int)-wave_max(-(float)v); }
+__device__ __forceinline__ int wave_imax(int v) { return (int)wave_max((float)v); }
+
 // the 4 dh-fragments of one row (dh chunk [16s + 8hi, +8), s = 0..3), rotated: chunks s and s+2 are 32 channels apart
 __device__ __forceinline__ void frags_global_rope(bf16x8_t (&f)[4], const bf16_t* __restrict__ base, int row, int row_lim,
                                                   size_t pitch, int lane, const Rope& R, int b) {
@@ -279,7 +291,7 @@ __device__ __forceinline__ void unrope_acc(f32x16_t& a0, f32x16_t& a1, const Rop
 // LDS ONCE per block (K rotated on the way in when R is given) and shared by the NW waves: K as the A operand of
 // S^T = K Q^T (ds_read_b128), V through the transposing read for O^T += V^T P^T.
 template <int NW>
-__global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
+__global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(const bf16_t* __restrict__ qkv, KeyRange KR,
                                                            bf16_t* __restrict__ out, float* __restrict__ lse, int B, int S,
                                                            int H, int causal, Rope R, Drop D) {
   __shared__ __attribute__((aligned(16))) unsigned char kt[4096];
@@ -293,9 +305,21 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
   const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
   const bf16_t* kb = qb + d;
   const bf16_t* vb = qb + 2 * d;
-  const int klen = key_len ? key_len[b] : S;
   const int qrow = q0 + l31;
   const Rope Rnone{nullptr, nullptr, nullptr, S};
+  // per-lane inclusive key range [qlo, qhi]; wave-uniform union [ulo, uhi] (tiles outside are skipped) and intersection
+  // [ilo, ihi] (tiles inside need no mask)
+  const bool packed = KR.lo != nullptr;
+  int qlo = 0, qhi = (KR.key_len ? KR.key_len[b] : S) - 1;
+  int ulo = 0, uhi = qhi, ilo = 0, ihi = qhi;
+  if (packed) {
+    const bool v = qrow < S;
+    qlo = v ? KR.lo[(size_t)b * S + qrow] : 0;
+    qhi = v ? KR.hi[(size_t)b * S + qrow] : -1;
+    ulo = wave_imin(qhi >= qlo ? qlo : S); uhi = wave_imax(qhi >= qlo ? qhi + 1 : 0) - 1;
+    ilo = wave_imax(v ? qlo : 0); ihi = wave_imin(v ? qhi + 1 : S) - 1;
+  }
+  const int klen = packed ? S : qhi + 1;     // block-level upper bound of the key loop
 
   bf16x8_t qf[4];
   frags_global_rope(qf, qb, qrow, S, pitch, lane, R, b);
@@ -304,7 +328,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
   const unsigned dbase = drop_base(D, b * H + h, qrow, 0);
   const int q_end_blk = min(S, (int)(blockIdx.x + 1) * NW * 32);       // one past the block's last query row
   const int kend_blk = causal ? min(klen, q_end_blk) : klen;
-  const int kend = (q0 < S) ? (causal ? min(klen, q0 + 32) : klen) : 0;   // this wave's own key range
+  const int kend = (q0 < S) ? min(uhi + 1, causal ? q0 + 32 : S) : 0;  // this wave's own key range
   constexpr bool PF = NW > 1;   // single-wave blocks see one tile (S <= 32): nothing to prefetch, registers are tight
   TilePref<NW * 64> pk, pv;
   if (PF && kend_blk > 0) {
@@ -325,20 +349,20 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
       tile_fetch<NW * 64>(pk, kb, k0 + 32, S, pitch, tid, R);
       tile_fetch<NW * 64>(pv, vb, k0 + 32, S, pitch, tid, Rnone);
     }
-    if (k0 >= kend) continue;
+    if (k0 >= kend || k0 + 31 < ulo) continue;
     f32x16_t sc = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), qf[s], sc, 0, 0, 0);
     // The loop is VALU-bound (head_dim 64: ~0.25 MFMA cycles but several VALU cycles per score), so: scores stay raw
     // until one fma + exp2 (scale and log2(e) folded, running max kept in the log2 domain); the key / causal mask is only
     // evaluated on tiles that touch the sequence end or the diagonal; O is rescaled only when some lane's max moved.
-    const bool edge = (k0 + 32 > klen) || (causal && k0 + 31 > q0) || (q0 + 32 > S);
+    const bool edge = (k0 < ilo) || (k0 + 31 > ihi) || (causal && k0 + 31 > q0) || (q0 + 32 > S);
     float mx = -INFINITY;
     if (edge) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = k0 + acc_row(r, hi);
-        const bool ok = key < klen && (!causal || key <= qrow);
+        const bool ok = key >= qlo && key <= qhi && (!causal || key <= qrow);
         sc[r] = ok ? sc[r] : -INFINITY;
         mx = fmaxf(mx, sc[r]);
       }
@@ -409,7 +433,7 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restric
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
-                                                              const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
+                                                              KeyRange KR, bf16_t* __restrict__ dqkv,
                                                               int B, int S, int H, int causal, Rope Rin, Rope R, Drop D) {
   __shared__ __attribute__((aligned(16))) unsigned char kt[4096];
   __shared__ __attribute__((aligned(16))) unsigned char vt[4096];
@@ -423,9 +447,19 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
   const bf16_t* kb = qb + d;
   const bf16_t* vb = qb + 2 * d;
   const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
-  const int klen = key_len ? key_len[b] : S;
   const int qrow = q0 + l31;
   const Rope Rnone{nullptr, nullptr, nullptr, S};
+  const bool packed = KR.lo != nullptr;      // see attn_fwd_kernel
+  int qlo = 0, qhi = (KR.key_len ? KR.key_len[b] : S) - 1;
+  int ulo = 0, uhi = qhi, ilo = 0, ihi = qhi;
+  if (packed) {
+    const bool v = qrow < S;
+    qlo = v ? KR.lo[(size_t)b * S + qrow] : 0;
+    qhi = v ? KR.hi[(size_t)b * S + qrow] : -1;
+    ulo = wave_imin(qhi >= qlo ? qlo : S); uhi = wave_imax(qhi >= qlo ? qhi + 1 : 0) - 1;
+    ilo = wave_imax(v ? qlo : 0); ihi = wave_imin(v ? qhi + 1 : S) - 1;
+  }
+  const int klen = packed ? S : qhi + 1;
   bf16x8_t qf[4], dof[4];
   frags_global_rope(qf, qb, qrow, S, pitch, lane, Rin, b);
 #pragma unroll
@@ -436,7 +470,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
   f32x16_t a0 = zero16(), a1 = zero16();
   const int q_end_blk = min(S, (int)(blockIdx.x + 1) * NW * 32);
   const int kend_blk = causal ? min(klen, q_end_blk) : klen;
-  const int kend = (q0 < S) ? (causal ? min(klen, q0 + 32) : klen) : 0;
+  const int kend = (q0 < S) ? min(uhi + 1, causal ? q0 + 32 : S) : 0;
   constexpr bool PF = NW > 1;
   TilePref<NW * 64> pk, pv;
   if (PF && kend_blk > 0) {
@@ -457,19 +491,19 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
       tile_fetch<NW * 64>(pk, kb, k0 + 32, S, pitch, tid, Rin);
       tile_fetch<NW * 64>(pv, vb, k0 + 32, S, pitch, tid, Rnone);
     }
-    if (k0 >= kend) continue;
+    if (k0 >= kend || k0 + 31 < ulo) continue;
     f32x16_t dp = zero16(), sc = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, s, lane), dof[s], dp, 0, 0, 0);
       sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), qf[s], sc, 0, 0, 0);
     }
-    const bool edge = (k0 + 32 > klen) || (causal && k0 + 31 > q0) || (q0 + 32 > S);
+    const bool edge = (k0 < ilo) || (k0 + 31 > ihi) || (causal && k0 + 31 > q0) || (q0 + 32 > S);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + acc_row(r, hi);
       float p = exp2f(fmaf(sc[r], kScaleL2, nlse2));
-      if (edge) p = (key < klen && (!causal || key <= qrow) && qrow < S) ? p : 0.f;
+      if (edge) p = (key >= qlo && key <= qhi && (!causal || key <= qrow) && qrow < S) ? p : 0.f;
       sc[r] = p * fmaf(dp[r], drop_mul_x(D, dbase + (unsigned)key * 0xC2B2AE3Du), ndl) * kScale;
     }
     const bf16x8_t ds0 = acc_to_b(sc, 0), ds1 = acc_to_b(sc, 1);
@@ -489,11 +523,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
+                                                               KeyRange KR, bf16_t* __restrict__ dqkv,
                                                                int B, int S, int H, int causal, Rope Rin, Rope R, Drop D) {
   __shared__ __attribute__((aligned(16))) unsigned char qt[4096];
   __shared__ __attribute__((aligned(16))) unsigned char dot_[4096];
   __shared__ float lse_s[32], dl_s[32];
+  __shared__ int qlo_s[32], qhi_s[32];   // packed rows: inclusive key range of each query of the tile
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
@@ -504,7 +539,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
   const bf16_t* kb = qb + d;
   const bf16_t* vb = qb + 2 * d;
   const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
-  const int klen = key_len ? key_len[b] : S;
+  const bool packed = KR.lo != nullptr;
+  const int klen = packed ? S : (KR.key_len ? KR.key_len[b] : S);
   const int krow = k0 + l31;
   const Rope Rnone{nullptr, nullptr, nullptr, S};
   bf16x8_t kf[4], vf[4];
@@ -512,13 +548,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
 #pragma unroll
   for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, krow, S, pitch, s, lane);
   f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
-  const bool key_ok = krow < klen;
   const unsigned dbase = drop_base(D, b * H + h, 0, krow);
   const int kblk0 = blockIdx.x * NW * 32;          // first key of the block
   const int qstart = causal ? kblk0 : 0;           // queries before the block's first key never see it
   if (kblk0 < klen) {
     TilePref<NW * 64> pq, pdo;
     float p_lse = 0.f, p_dl = 0.f;
+    int p_lo = 0, p_hi = klen - 1;
     auto fetch_q = [&](int q0) {
       tile_fetch<NW * 64>(pq, qb, q0, S, pitch, tid, Rin);
       tile_fetch<NW * 64>(pdo, dob, q0, S, (size_t)d, tid, Rnone);
@@ -526,6 +562,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
         const int q = min(q0 + tid, S - 1);
         p_lse = lse[((size_t)b * H + h) * S + q];
         p_dl = delta[((size_t)b * H + h) * S + q];
+        if (packed) {
+          const bool v = q0 + tid < S;
+          p_lo = v ? KR.lo[(size_t)b * S + q] : 0;
+          p_hi = v ? KR.hi[(size_t)b * S + q] : -1;
+        }
       }
     };
     constexpr bool PF = NW > 1;
@@ -535,7 +576,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
       if constexpr (PF) {
         tile_commit<NW * 64>(qt, pq, q0, S, tid, Rin, b);
         tile_commit<NW * 64>(dot_, pdo, q0, S, tid, Rnone, b);
-        if (tid < 32) { lse_s[tid] = -p_lse * kLog2e; dl_s[tid] = -p_dl; }
+        if (tid < 32) { lse_s[tid] = -p_lse * kLog2e; dl_s[tid] = -p_dl; qlo_s[tid] = p_lo; qhi_s[tid] = p_hi; }
       } else {
         load_tile_coop<NW * 64>(qt, qb, q0, S, pitch, tid, Rin, b);
         load_tile_coop<NW * 64>(dot_, dob, q0, S, (size_t)d, tid, Rnone, b);
@@ -543,24 +584,35 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
           const int q = min(q0 + tid, S - 1);
           lse_s[tid] = -lse[((size_t)b * H + h) * S + q] * kLog2e;
           dl_s[tid] = -delta[((size_t)b * H + h) * S + q];
+          const bool v = q0 + tid < S;
+          qlo_s[tid] = packed ? (v ? KR.lo[(size_t)b * S + q] : 0) : 0;
+          qhi_s[tid] = packed ? (v ? KR.hi[(size_t)b * S + q] : -1) : klen - 1;
         }
       }
       __syncthreads();
       if (PF && q0 + 32 < S) fetch_q(q0 + 32);
       if (k0 >= klen || (causal && q0 + 31 < k0)) continue;   // this wave's keys are padding / all in the future
+      // packed rows: union / intersection of the tile's query ranges decide skipping and masking for this wave's 32 keys
+      bool edge = (k0 + 32 > klen) || (q0 + 32 > S) || (causal && k0 + 31 > q0);
+      if (packed) {
+        const int lo = qlo_s[l31], hi_ = qhi_s[l31];
+        const int ulo = wave_imin(hi_ >= lo ? lo : S), uhi = wave_imax(hi_ >= lo ? hi_ + 1 : 0) - 1;
+        if (uhi < k0 || ulo > k0 + 31) continue;
+        const int ilo = wave_imax(lo), ihi = wave_imin(hi_ + 1) - 1;
+        edge = edge || ilo > k0 || ihi < k0 + 31;
+      }
       f32x16_t sc = zero16(), dp = zero16();
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, s, lane), kf[s], sc, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dot_, s, lane), vf[s], dp, 0, 0, 0);
       }
-      const bool edge = (k0 + 32 > klen) || (q0 + 32 > S) || (causal && k0 + 31 > q0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qi = acc_row(r, hi);
         const int q = q0 + qi;
         float p = exp2f(fmaf(sc[r], kScaleL2, lse_s[qi]));          // lse_s holds -lse * log2(e)
-        if (edge) p = (key_ok && q < S && (!causal || krow <= q)) ? p : 0.f;
+        if (edge) p = (krow >= qlo_s[qi] && krow <= qhi_s[qi] && q < S && (!causal || krow <= q)) ? p : 0.f;
         const float dm = drop_mul_x(D, dbase + (unsigned)q * 0x85EBCA77u);
         sc[r] = p * dm;                                  // dropped probabilities: what multiplied V in forward
         dp[r] = p * fmaf(dp[r], dm, dl_s[qi]) * kScale;  // dl_s holds -delta
@@ -600,13 +652,14 @@ Drop make_drop(float p, unsigned seed) {
 
 int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
                const float* cos_tab, const float* sin_tab, const int64_t* position_ids, float dropout_p,
-               unsigned dropout_seed, hipStream_t st) {
+               unsigned dropout_seed, hipStream_t st, const int32_t* key_lo, const int32_t* key_hi) {
+  const KeyRange KR{key_len, key_lo, key_hi};
   if (B == 0 || S == 0) return 0;
   const Rope R{cos_tab, sin_tab, position_ids, S};
   const Drop D = make_drop(dropout_p, dropout_seed);
   const int nw = attn_waves(S);
   dim3 grid((S + 32 * nw - 1) / (32 * nw), H, B);
-#define GGET_ATTN_FWD(NW) hipLaunchKernelGGL(attn_fwd_kernel<NW>, grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, key_len, \
+#define GGET_ATTN_FWD(NW) hipLaunchKernelGGL(attn_fwd_kernel<NW>, grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, KR, \
                                              (bf16_t*)out, lse, B, S, H, causal, R, D)
   if (nw == 4) GGET_ATTN_FWD(4); else if (nw == 2) GGET_ATTN_FWD(2); else GGET_ATTN_FWD(1);
 #undef GGET_ATTN_FWD
@@ -616,7 +669,9 @@ int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, i
 
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
-               const int64_t* position_ids, int qk_rotated, float dropout_p, unsigned dropout_seed, hipStream_t st) {
+               const int64_t* position_ids, int qk_rotated, float dropout_p, unsigned dropout_seed, hipStream_t st,
+               const int32_t* key_lo, const int32_t* key_hi) {
+  const KeyRange KR{key_len, key_lo, key_hi};
   if (B == 0 || S == 0) return 0;
   const Rope R{cos_tab, sin_tab, position_ids, S};     // rotation of dq, dk back to the un-rotated projections
   const Rope Rin = qk_rotated ? Rope{nullptr, nullptr, nullptr, S} : R;   // q,k in memory are already rotated?
@@ -631,9 +686,9 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
 #define GGET_ATTN_BWD(NW)                                                                                                  \
   do {                                                                                                                     \
     hipLaunchKernelGGL(attn_bwd_dq_kernel<NW>, grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,   \
-                       delta_ws, key_len, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);                                      \
+                       delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);                                      \
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<NW>, grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,  \
-                       delta_ws, key_len, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);                                      \
+                       delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);                                      \
   } while (0)
   if (nw == 4) GGET_ATTN_BWD(4); else if (nw == 2) GGET_ATTN_BWD(2); else GGET_ATTN_BWD(1);
 #undef GGET_ATTN_BWD

@@ -137,7 +137,7 @@ struct LayerWs {
 };
 
 struct Ws {
-  uint64_t key_len, pool_row, cos_tab, sin_tab;
+  uint64_t key_len, pool_row, cos_tab, sin_tab, key_lo, key_hi;
   std::vector<uint64_t> xres;  // L+1 residual-stream snapshots
   std::vector<LayerWs> lw;
   uint64_t rstd_f, hidden;
@@ -156,6 +156,8 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   const uint64_t T = c.max_tokens, d = c.hidden_size, ff = c.intermediate_size, H = c.num_heads, L = c.num_layers;
   const uint64_t Bm = c.max_batch;
   w.key_len = b.take(Bm * 4);
+  w.key_lo = b.take(T * 4);   // packed rows: per-token key range (block-diagonal mask)
+  w.key_hi = b.take(T * 4);
   w.pool_row = b.take(Bm * 4);
   w.cos_tab = b.take((uint64_t)c.max_position * 32 * 4);
   w.sin_tab = b.take((uint64_t)c.max_position * 32 * 4);
@@ -277,6 +279,9 @@ struct gget_engine {
     return PathDropArg{rate, attn_drop_seed ^ (0xD6E8FEB8u * (unsigned)(layer * 2 + which + 1)), S};
   }
   bf16_t* dx_cur = nullptr;  // gradient w.r.t. the residual stream entering the next backward stage
+  bool packed = false;       // last forward used a 3-D block-diagonal attention mask (per-token key ranges)
+  const int32_t* klo() const { return packed ? wsp<int32_t>(ws.key_lo) : nullptr; }
+  const int32_t* khi() const { return packed ? wsp<int32_t>(ws.key_hi) : nullptr; }
 
   template <typename Tp>
   Tp* wsp(uint64_t off) const { return reinterpret_cast<Tp*>(W + off); }
@@ -519,7 +524,8 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
     if (int e = gget_gemm_launch(GGET_GEMM_NT, GGET_EPI_ROPE, g, 1, st)) return e;
   }
   if (int e = k_attn_fwd(qkv, h->wsp<int32_t>(h->ws.key_len), attn, h->wsp<float>(lw.lse), h->B, h->S, H, c.causal,
-                         nullptr, nullptr, nullptr, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st))
+                         nullptr, nullptr, nullptr, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st, h->klo(),
+                         h->khi()))
     return e;
   if (h->plan.has_res) {
     bf16_t* araw = h->wsp<bf16_t>(lw.araw);
@@ -547,7 +553,7 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
 }
 
 int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t* mask, const int64_t* pos, int B, int S,
-                     hipStream_t st) {
+                     hipStream_t st, bool mask_is_3d = false) {
   const gget_config_t& c = h->cfg;
   GGET_REQUIRE(B > 0 && S > 0, "empty batch");
   GGET_REQUIRE((long)B * S <= c.max_tokens && B <= c.max_batch, "batch %dx%d exceeds capacity (%d tokens, %d rows)", B, S,
@@ -556,10 +562,15 @@ int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t*
   h->B = B; h->S = S; h->T = B * S;
   h->ids = ids; h->pos = pos;
   const int d = c.hidden_size;
-  if (int e = k_lengths(mask, c.kind == GGET_KIND_TASK ? ids : nullptr, ldF, c.pad_token_id,
-                        h->wsp<int32_t>(h->ws.key_len), c.kind == GGET_KIND_TASK ? h->wsp<int32_t>(h->ws.pool_row) : nullptr,
-                        B, S, st))
+  h->packed = mask_is_3d;
+  if (mask_is_3d) {
+    GGET_REQUIRE(mask != nullptr && c.kind == GGET_KIND_PRETRAIN, "a 3-D (packed) attention mask needs the pre-train model and a mask");
+    if (int e = k_ranges_from_mask3d(mask, h->wsp<int32_t>(h->ws.key_lo), h->wsp<int32_t>(h->ws.key_hi), B, S, st)) return e;
+  } else if (int e = k_lengths(mask, c.kind == GGET_KIND_TASK ? ids : nullptr, ldF, c.pad_token_id,
+                               h->wsp<int32_t>(h->ws.key_len),
+                               c.kind == GGET_KIND_TASK ? h->wsp<int32_t>(h->ws.pool_row) : nullptr, B, S, st)) {
     return e;
+  }
   if (int e = k_embed_fwd(ids, h->P + h->plan.emb, h->plan.has_gate ? h->P + h->plan.gate : nullptr,
                           h->wsp<bf16_t>(h->ws.xres[0]), h->T, c.stacked_feat, ldF, d, st))
     return e;
@@ -571,15 +582,16 @@ int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t*
 
 }  // namespace
 
-extern "C" int gget_forward_pretrain(gget_handle_t h, const int64_t* input_ids_dev, const int64_t* attention_mask_dev,
-                                     const int64_t* labels_dev, const float* sample_wgt_dev,
-                                     const int64_t* position_ids_dev, int B, int S, float* loss_dev, void* stream) {
+static int forward_pretrain_impl(gget_handle_t h, const int64_t* input_ids_dev, const int64_t* attention_mask_dev,
+                                 bool mask_is_3d, const int64_t* labels_dev, const float* sample_wgt_dev,
+                                 const int64_t* position_ids_dev, int B, int S, float* loss_dev, void* stream) {
   GGET_REQUIRE(h && input_ids_dev, "null argument");
   GGET_REQUIRE(h->cfg.kind == GGET_KIND_PRETRAIN, "handle was not created as a pre-train model");
   hipStream_t st = (hipStream_t)stream;
   const gget_config_t& c = h->cfg;
   h->fwd_valid = false;
-  if (int e = backbone_forward(h, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st)) return e;
+  if (int e = backbone_forward(h, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st, mask_is_3d))
+    return e;
   const Ws& w = h->ws;
   const int T = h->T, d = c.hidden_size, n = c.next_n_token, V = c.vocab_size;
   const int Vp = (int)align_up(V, 64);
@@ -613,6 +625,21 @@ extern "C" int gget_forward_pretrain(gget_handle_t h, const int64_t* input_ids_d
   }
   h->fwd_valid = true;
   return 0;
+}
+
+extern "C" int gget_forward_pretrain(gget_handle_t h, const int64_t* input_ids_dev, const int64_t* attention_mask_dev,
+                                     const int64_t* labels_dev, const float* sample_wgt_dev,
+                                     const int64_t* position_ids_dev, int B, int S, float* loss_dev, void* stream) {
+  return forward_pretrain_impl(h, input_ids_dev, attention_mask_dev, false, labels_dev, sample_wgt_dev, position_ids_dev, B, S,
+                               loss_dev, stream);
+}
+
+extern "C" int gget_forward_pretrain_packed(gget_handle_t h, const int64_t* input_ids_dev, const int64_t* attention_mask3d_dev,
+                                            const int64_t* labels_dev, const float* sample_wgt_dev,
+                                            const int64_t* position_ids_dev, int B, int S, float* loss_dev, void* stream) {
+  GGET_REQUIRE(attention_mask3d_dev != nullptr, "the packed forward needs the [B,S,S] mask");
+  return forward_pretrain_impl(h, input_ids_dev, attention_mask3d_dev, true, labels_dev, sample_wgt_dev, position_ids_dev, B, S,
+                               loss_dev, stream);
 }
 
 extern "C" int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, const int64_t* attention_mask_dev,
@@ -709,7 +736,8 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   if (int e = gemm_nn(dy_o, h->P + lo.wo, dattn, T, d, d, d, d, d, nullptr, st)) return e;
   if (int e = k_attn_bwd(h->wsp<bf16_t>(lw.qkv), h->wsp<bf16_t>(lw.attn), dattn, h->wsp<float>(lw.lse),
                          h->wsp<int32_t>(w.key_len), dqkv, h->wsp<float>(w.delta), h->B, h->S, H, c.causal, h->cos_tab,
-                         h->sin_tab, h->pos, /*qk_rotated=*/1, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st))
+                         h->sin_tab, h->pos, /*qk_rotated=*/1, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st,
+                         h->klo(), h->khi()))
     return e;
   if (int e = gemm_nn(dqkv, h->P + lo.wqkv, dxn, T, d, 3 * d, 3 * d, d, d, nullptr, st)) return e;
   if (int e = k_rmsnorm_bwd(dxn, x_in, h->P + lo.ln1, h->wsp<float>(lw.rstd1), dx_mid, dx_in, s32 + lo.ln1_32, T, d, st, kAccumCopies, align_up((uint64_t)d, 128)))
@@ -935,6 +963,23 @@ extern "C" int gget_op_attn_fwd(const void* qkv, const int32_t* key_len, void* o
                                 uint32_t dropout_seed, void* stream) {
   return k_attn_fwd(qkv, key_len, out, lse, B, S, H, causal, cos_tab, sin_tab, position_ids, dropout_p, dropout_seed,
                     (hipStream_t)stream);
+}
+extern "C" int gget_op_attn_fwd_ranges(const void* qkv, const int32_t* key_lo, const int32_t* key_hi, void* out, float* lse, int B,
+                                       int S, int H, int causal, float dropout_p, uint32_t dropout_seed, void* stream) {
+  GGET_REQUIRE(key_lo && key_hi, "attn_fwd_ranges: null ranges");
+  return k_attn_fwd(qkv, nullptr, out, lse, B, S, H, causal, nullptr, nullptr, nullptr, dropout_p, dropout_seed,
+                    (hipStream_t)stream, key_lo, key_hi);
+}
+extern "C" int gget_op_attn_bwd_ranges(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_lo,
+                                       const int32_t* key_hi, void* dqkv, float* delta_ws, int B, int S, int H, int causal,
+                                       float dropout_p, uint32_t dropout_seed, void* stream) {
+  GGET_REQUIRE(key_lo && key_hi, "attn_bwd_ranges: null ranges");
+  return k_attn_bwd(qkv, out, dout, lse, nullptr, dqkv, delta_ws, B, S, H, causal, nullptr, nullptr, nullptr, 0, dropout_p,
+                    dropout_seed, (hipStream_t)stream, key_lo, key_hi);
+}
+extern "C" int gget_op_ranges_from_mask3d(const int64_t* mask3d, int32_t* key_lo, int32_t* key_hi, int B, int S, void* stream) {
+  GGET_REQUIRE(mask3d && key_lo && key_hi, "ranges_from_mask3d: null argument");
+  return k_ranges_from_mask3d(mask3d, key_lo, key_hi, B, S, (hipStream_t)stream);
 }
 extern "C" int gget_op_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len,
                                 void* dqkv, float* delta_ws, int B, int S, int H, int causal, const float* cos_tab,

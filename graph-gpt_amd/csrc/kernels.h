@@ -60,10 +60,13 @@ int k_convert_segments(const float* scratch, void* grads, const GgetSegment* seg
 // already rotated them) and undone on dq,dk, so dqkv is always the gradient of the UN-rotated projections
 int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
                const float* cos_tab, const float* sin_tab, const int64_t* position_ids, float dropout_p,
-               unsigned dropout_seed, hipStream_t st);
+               unsigned dropout_seed, hipStream_t st, const int32_t* key_lo = nullptr, const int32_t* key_hi = nullptr);
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
-               const int64_t* position_ids, int qk_rotated, float dropout_p, unsigned dropout_seed, hipStream_t st);
+               const int64_t* position_ids, int qk_rotated, float dropout_p, unsigned dropout_seed, hipStream_t st,
+               const int32_t* key_lo = nullptr, const int32_t* key_hi = nullptr);
+// packed rows: inclusive key range [lo, hi] of every token from the block-diagonal mask [B,S,S] (first / last 1 of its row)
+int k_ranges_from_mask3d(const int64_t* mask3d, int32_t* key_lo, int32_t* key_hi, int B, int S, hipStream_t st);
 int k_smtp2d(const int64_t* ids_in, int ld_in, const int64_t* node_idx, int ld_node, int64_t* ids_out, int64_t* labels_out,
              int B, int S, int F, float rate, float power, float replace_rate, int vocab, int global_mask, unsigned seed,
              hipStream_t st);

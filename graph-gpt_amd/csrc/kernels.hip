@@ -931,6 +931,23 @@ __global__ void __launch_bounds__(kBlock) token_confidence_kernel(const bf16_t* 
   }
 }
 
+// first / last non-zero of every row of a [B,S,S] int64 mask: one wave per row (block-diagonal packing masks,
+// reference src/utils/tokenizer_utils.py:349-355).  An all-zero row (padding) gives lo = 0, hi = -1 (attends nothing).
+__global__ void __launch_bounds__(kBlock) ranges_from_mask3d_kernel(const int64_t* __restrict__ mask, int32_t* __restrict__ lo,
+                                                                    int32_t* __restrict__ hi, int rows, int S) {
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); row < rows; row += gridDim.x * (kBlock / 64)) {
+    const int64_t* m = mask + (size_t)row * S;
+    int first = S, last = -1;
+    for (int c = lane; c < S; c += 64) {
+      if (m[c] != 0) { first = min(first, c); last = max(last, c); }
+    }
+    first = (int)-wave_max(-(float)first);
+    last = (int)wave_max((float)last);
+    if (lane == 0) { lo[row] = last >= 0 ? first : 0; hi[row] = last; }
+  }
+}
+
 inline int grid_for(long work_items, int per_block = kBlock, int cap = 4096) {
   long g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -1168,6 +1185,14 @@ int k_token_confidence(const void* logits, int ld, int R, int V, int mode, float
   if (R == 0) return 0;
   hipLaunchKernelGGL(token_confidence_kernel, dim3(grid_for(R, kBlock / 64, 4096)), dim3(kBlock), 0, st, (const bf16_t*)logits,
                      ld, R, V, mode, conf, tok);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_ranges_from_mask3d(const int64_t* mask3d, int32_t* key_lo, int32_t* key_hi, int B, int S, hipStream_t st) {
+  if (B * S == 0) return 0;
+  hipLaunchKernelGGL(ranges_from_mask3d_kernel, dim3(grid_for((long)B * S, kBlock / 64, 4096)), dim3(kBlock), 0, st, mask3d,
+                     key_lo, key_hi, B * S, S);
   GGET_LAUNCH_CHECK();
   return 0;
 }

@@ -143,8 +143,12 @@ class Engine:
         wgt = None if sample_wgt is None else sample_wgt.to(device=dev, dtype=torch.float32).contiguous()
         pos = self._i64(position_ids, dev)
         self._keep = (ids, att, lab, wgt, pos)
-        L.check(self.lib.gget_forward_pretrain(self.h, _ptr(ids), _ptr(att), _ptr(lab), _ptr(wgt), _ptr(pos), B, S,
-                                               _ptr(self._loss), _stream()))
+        if att is not None and att.dim() == 3:      # packed rows: block-diagonal [B,S,S] mask
+            assert att.shape == (B, S, S), f"3-D attention mask must be [B,S,S], got {tuple(att.shape)}"
+            fn = self.lib.gget_forward_pretrain_packed
+        else:
+            fn = self.lib.gget_forward_pretrain
+        L.check(fn(self.h, _ptr(ids), _ptr(att), _ptr(lab), _ptr(wgt), _ptr(pos), B, S, _ptr(self._loss), _stream()))
         return self._loss[0] if lab is not None else None
 
     def forward_task(self, input_ids, attention_mask, position_ids=None, task_labels=None, sample_wgt=None,

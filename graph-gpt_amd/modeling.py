@@ -314,7 +314,9 @@ class GraphGPTPretrainBase(_GgetModel):
             f"stacked_feat: {self.spec.stacked_feat}\nx.shape: {tuple(input_ids.shape)}"  # modeling_common.py:131-133
         if attention_mask is None:
             attention_mask = torch.ones(B, S, dtype=torch.int64)
-        assert attention_mask.dim() == 2, "packed (3-D) attention masks are a 'next' item (SURVEY.md 8f N2)"
+        assert attention_mask.dim() in (2, 3), "attention_mask is [B,S] (right padding) or [B,S,S] (packed, block-diagonal)"
+        if attention_mask.dim() == 3:
+            assert not self.spec.causal, "the reference only builds the 3-D mask for bi-directional attention (modeling_pretrain.py:197-198)"
         e = self._pre_forward(B, S)
         loss = e.forward_pretrain(input_ids, attention_mask, labels, sample_wgt, position_ids)
         return _PretrainOutput(self._wrap_loss(loss), _LazyLogits(self))

@@ -71,6 +71,48 @@ def make_pretrain_batch(B: int, S: int, F: int, V: int, seed: int = 1234, *, len
     return out
 
 
+def make_packed_pretrain_batch(B: int, S: int, F: int, V: int, seed: int = 1234, *, mean_len: int = 12, min_len: int = 4,
+                               first_id: int = 22, eos_id: int = 3) -> Dict[str, np.ndarray]:
+    """Token packing (reference GraphsMapDataset.pack_token_seq, src/data/tokenizer.py:359-415, and
+    prepare_inputs_for_pretrain_mlm, src/utils/tokenizer_utils.py:340-355): every row holds several graphs back to back,
+    separated by one all-<eos> position, until the row is (nearly) full; position_ids run on across graphs, the attention
+    mask is the 3-D block-diagonal matrix [B,S,S] (bi-directional inside a graph, the separator belongs to the graph it
+    closes), rows beyond the packed length are zero.  Masking as in make_pretrain_batch, per packed row."""
+    rng = np.random.RandomState(seed)
+    ids = np.zeros((B, S, F), np.int64)
+    labels = np.full((B, S, F), LABEL_PAD, np.int64)
+    att = np.zeros((B, S, S), np.int64)
+    pos = np.zeros((B, S), np.int64)
+    seg = np.full((B, S), -1, np.int64)
+    lo = min(first_id, V - 1)
+    used = np.zeros((B,), np.int64)
+    for b in range(B):
+        n, g = 0, 0
+        while True:
+            ln = int(np.clip(rng.normal(mean_len, mean_len / 3), min_len, S))
+            if n + ln + 1 > S - (0 if b % 2 else 3):     # every other row keeps a few pad positions at the end
+                break
+            tok = rng.randint(lo, V, size=(ln, F)).astype(np.int64)
+            ids[b, n:n + ln] = tok
+            ids[b, n + ln] = eos_id
+            att[b, n:n + ln + 1, n:n + ln + 1] = 1
+            seg[b, n:n + ln + 1] = g
+            n += ln + 1
+            g += 1
+        used[b] = n
+        pos[b, :n] = np.arange(n)
+        t = 0.01 + 0.98 * rng.random_sample()
+        k = int(np.ceil(n * F * (1.0 - t)))
+        flat = rng.permutation(n * F)[:k]
+        flat_tok = ids[b, :n].reshape(-1).copy()
+        lab = np.full((n * F,), LABEL_PAD, np.int64)
+        lab[flat] = flat_tok[flat]
+        flat_tok[flat] = MASK_TOKEN_ID
+        ids[b, :n] = flat_tok.reshape(n, F)
+        labels[b, :n] = lab.reshape(n, F)
+    return dict(input_ids=ids, labels=labels, attention_mask=att, position_ids=pos, lengths=used, segments=seg)
+
+
 def make_task_batch(B: int, S: int, F: int, V: int, seed: int = 1234, *, lengths: str = "uniform",
                     min_len: int = 8, first_id: int = 22, num_labels: int = 2,
                     regression: bool = False, multi_label: bool = False) -> Dict[str, np.ndarray]:

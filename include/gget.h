@@ -133,6 +133,13 @@ int gget_forward_pretrain(gget_handle_t h, const int64_t* input_ids_dev, const i
  *   task_labels: i64 [B] (single label) or f32 [B] (regression), NULL => no loss;
  *   task_logits_dev f32 [B,num_labels] (pooled "last" row, returned as .float());
  *   task_hidden_dev bf16 [B,d] or NULL. */
+/* replaces: the same forward on PACKED rows (reference GraphsMapDataset.pack_token_seq, src/data/tokenizer.py:359-415;
+ * block-diagonal mask built at src/utils/tokenizer_utils.py:349-355 and expanded by _expand_mask_from_3d_mask,
+ * modeling_helpers.py:51-64): attention_mask3d is int64 [B,S,S]; a token attends exactly the contiguous key range of its
+ * own graph (first .. last non-zero of its mask row), all-zero rows are padding.  backward / adamw as usual. */
+int gget_forward_pretrain_packed(gget_handle_t h, const int64_t* input_ids_dev, const int64_t* attention_mask3d_dev,
+                                 const int64_t* labels_dev, const float* sample_wgt_dev, const int64_t* position_ids_dev,
+                                 int B, int S, float* loss_dev, void* stream);
 int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, const int64_t* attention_mask_dev,
                       const int64_t* position_ids_dev, const void* task_labels_dev, const float* sample_wgt_dev,
                       int problem_type, int B, int S, float* loss_dev, float* task_logits_dev,
@@ -221,6 +228,14 @@ int gget_op_attn_bwd(const void* qkv, const void* out, const void* dout, const f
                      void* dqkv, float* delta_ws, int B, int S, int H, int causal, const float* cos_tab,
                      const float* sin_tab, const int64_t* position_ids, float dropout_p, uint32_t dropout_seed,
                      void* stream);
+/* attention with a per-token inclusive key range [key_lo, key_hi] (int32 [B,S]; packed rows) instead of one length per
+ * batch row; gget_op_ranges_from_mask3d derives the ranges from a block-diagonal int64 [B,S,S] mask. */
+int gget_op_attn_fwd_ranges(const void* qkv, const int32_t* key_lo, const int32_t* key_hi, void* out, float* lse, int B, int S,
+                            int H, int causal, float dropout_p, uint32_t dropout_seed, void* stream);
+int gget_op_attn_bwd_ranges(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_lo,
+                            const int32_t* key_hi, void* dqkv, float* delta_ws, int B, int S, int H, int causal,
+                            float dropout_p, uint32_t dropout_seed, void* stream);
+int gget_op_ranges_from_mask3d(const int64_t* mask3d, int32_t* key_lo, int32_t* key_hi, int B, int S, void* stream);
 int gget_op_geglu_fwd(const void* gu, void* h, int T, int ff, void* stream);
 int gget_op_geglu_bwd(const void* gu, const void* dh, void* dgu, int T, int ff, void* stream);
 int gget_op_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const float* row_wgt, const int32_t* n_rows_dev,

@@ -85,6 +85,10 @@ def additive_mask(attention_mask: torch.Tensor, S: int, dtype, causal: bool):
     hf LlamaModel which builds causal AND padding (hf :394-400).  Returns [B,1,S,S]."""
     B = attention_mask.shape[0]
     neg = torch.finfo(dtype).min
+    if attention_mask.dim() == 3:
+        # packed sequences: block-diagonal [B,S,S] mask, `_expand_mask_from_3d_mask` (modeling_helpers.py:51-64)
+        inv = 1.0 - attention_mask[:, None, :, :].to(dtype)
+        return inv.masked_fill(inv.to(torch.bool), neg)
     m = torch.zeros(B, 1, S, S, dtype=dtype)
     m = m.masked_fill(attention_mask[:, None, None, :] == 0, neg)
     if causal:

@@ -14,7 +14,7 @@ weights_mod = importlib.import_module("graph-gpt_amd.weights")
 synth = importlib.import_module("graph-gpt_amd.synth")
 
 PT_CASES = ["pt_tiny_f13_a", "pt_tiny_f13_b", "pt_tiny_f1", "pt_tiny_causal", "pt_tiny_gated", "pt_tiny_wgt",
-            "pt_tiny_bigw", "pt_tiny_s72"]
+            "pt_tiny_bigw", "pt_tiny_s72", "pt_tiny_packed"]
 FT_CASES = ["ft_tiny_f4", "ft_tiny_ls", "ft_tiny_reg", "ft_tiny_ml"]
 
 

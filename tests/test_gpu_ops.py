@@ -446,3 +446,60 @@ def test_token_confidence(lib, R, V, mode):
     assert torch.equal(got_t[uniq], want_t[uniq])
     assert int(got_t[0]) == 0
     np.testing.assert_allclose(conf.cpu().numpy(), want_c.numpy(), rtol=2e-5, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------ packed rows (N2)
+def _packed_ranges(B, S, seed, pad_tail=True):
+    """Block-diagonal layout: random graph lengths back to back; returns (mask3d [B,S,S] i64, lo, hi [B,S] i32)."""
+    rng = np.random.RandomState(seed)
+    m = np.zeros((B, S, S), np.int64)
+    lo = np.zeros((B, S), np.int32)
+    hi = np.full((B, S), -1, np.int32)
+    for b in range(B):
+        n = 0
+        limit = S - (rng.randint(1, 9) if (pad_tail and b % 2 == 0) else 0)
+        while n < limit:
+            ln = int(min(limit - n, rng.randint(3, max(4, S // 3))))
+            m[b, n:n + ln, n:n + ln] = 1
+            lo[b, n:n + ln], hi[b, n:n + ln] = n, n + ln - 1
+            n += ln
+    return m, lo, hi
+
+
+@pytest.mark.parametrize("B,S,H,causal", [(3, 24, 2, 0), (2, 72, 2, 0), (2, 160, 3, 0), (1, 520, 2, 0), (2, 96, 2, 1)])
+def test_attention_packed_ranges(lib, B, S, H, causal):
+    """Attention on packed rows (per-token key ranges from a block-diagonal mask) vs autograd with the explicit [S,S] mask:
+    forward and all three gradients; rows of the padding tail produce zeros."""
+    d = H * 64
+    m3, lo_np, hi_np = _packed_ranges(B, S, seed=S + B)
+    qkv = rnd(B * S, 3 * d, seed=23)
+    mask3d = torch.from_numpy(m3).cuda()
+    lo = torch.empty(B, S, dtype=torch.int32, device="cuda")
+    hi = torch.empty(B, S, dtype=torch.int32, device="cuda")
+    L.check(lib.gget_op_ranges_from_mask3d(P(mask3d), P(lo), P(hi), B, S, ST()))
+    assert torch.equal(lo.cpu(), torch.from_numpy(lo_np)) and torch.equal(hi.cpu(), torch.from_numpy(hi_np))
+    out = torch.empty(B * S, d, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B * H * S, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_attn_fwd_ranges(P(qkv), P(lo), P(hi), P(out), P(lse), B, S, H, causal, 0.0, 0, ST()))
+    x = qkv.float().view(B, S, 3, H, 64).detach().requires_grad_(True)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    w = q @ k.transpose(2, 3) * 0.125
+    allow = mask3d.bool()
+    if causal:
+        allow = allow & torch.ones(S, S, dtype=torch.bool, device="cuda").tril()[None]
+    w = w.masked_fill(~allow[:, None], float("-inf"))
+    p = torch.softmax(w, -1).nan_to_num(0.0)           # padding rows: no key at all
+    ref = (p @ v).transpose(1, 2).reshape(B * S, d)
+    valid = torch.from_numpy(hi_np >= lo_np).cuda().view(B * S)
+    assert rel_l2(out.float()[valid].cpu().numpy(), ref[valid].detach().cpu().numpy()) < 8e-3
+    assert torch.all(out[~valid] == 0)
+    dout = rnd(B * S, d, seed=29)
+    dout[~valid] = 0
+    ref.backward(dout.float())
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B * H * S, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_attn_bwd_ranges(P(qkv), P(out), P(dout), P(lse), P(lo), P(hi), P(dqkv), P(delta), B, S, H, causal, 0.0, 0, ST()))
+    got = dqkv.float().view(B, S, 3, H, 64)
+    for i, nm in enumerate("qkv"):
+        e = rel_l2(got[:, :, i].cpu().numpy(), x.grad[:, :, i].cpu().numpy())
+        assert e < 2e-2, f"packed attn bwd d{nm} rel-L2 {e}"

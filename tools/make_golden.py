@@ -116,6 +116,8 @@ CASES = [
      dict(std=0.06, head_std=0.15)),
     ("pt_tiny_s72", "pt", dict(vocab_size=756, stacked_feat=13, next_n_token=13), dict(B=3, S=72, seed=7, lengths="uniform", min_len=20),
      dict(std=0.06, head_std=0.15)),
+    ("pt_tiny_packed", "pt", dict(vocab_size=756, stacked_feat=13, next_n_token=13), dict(B=3, S=72, seed=14, packed=True),
+     dict(std=0.06, head_std=0.15)),
     ("ft_tiny_f4", "ft", dict(vocab_size=1000, stacked_feat=4, next_n_token=1, num_labels=2), dict(B=4, S=24, seed=8), {}),
     ("ft_tiny_ls", "ft", dict(vocab_size=1000, stacked_feat=4, next_n_token=1, num_labels=2, layer_scale_init=1.0),
      dict(B=4, S=40, seed=9), dict(std=0.06, head_std=0.15)),
@@ -136,7 +138,10 @@ def run_case(name, kind, skw, bkw, ikw, classes):
     names = list(state.keys())
     out = {}
     if kind == "pt":
-        batch = synth.make_pretrain_batch(F=spec.stacked_feat, V=spec.vocab_size, **bkw)
+        if bkw.pop("packed", False):
+            batch = synth.make_packed_pretrain_batch(F=spec.stacked_feat, V=spec.vocab_size, **bkw)
+        else:
+            batch = synth.make_pretrain_batch(F=spec.stacked_feat, V=spec.vocab_size, **bkw)
         cfg = ref_config(Cfg, spec)
         model = PT(cfg)
     else:

@@ -290,7 +290,7 @@ __device__ __forceinline__ void unrope_acc(f32x16_t& a0, f32x16_t& a1, const Rop
 // Block = NW waves = NW consecutive 32-query tiles of one (batch, head); every 32-key K tile and V tile is brought into
 // LDS ONCE per block (K rotated on the way in when R is given) and shared by the NW waves: K as the A operand of
 // S^T = K Q^T (ds_read_b128), V through the transposing read for O^T += V^T P^T.
-template <int NW>
+template <int NW, bool PK>
 __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(const bf16_t* __restrict__ qkv, KeyRange KR,
                                                            bf16_t* __restrict__ out, float* __restrict__ lse, int B, int S,
                                                            int H, int causal, Rope R, Drop D) {
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
   const Rope Rnone{nullptr, nullptr, nullptr, S};
   // per-lane inclusive key range [qlo, qhi]; wave-uniform union [ulo, uhi] (tiles outside are skipped) and intersection
   // [ilo, ihi] (tiles inside need no mask)
-  const bool packed = KR.lo != nullptr;
+  constexpr bool packed = PK;   // per-token key ranges (KR.lo / KR.hi) instead of one key length per batch row
   int qlo = 0, qhi = (KR.key_len ? KR.key_len[b] : S) - 1;
   int ulo = 0, uhi = qhi, ilo = 0, ihi = qhi;
   if (packed) {
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restric
 
 // dQ^T[dh][q] = sum_keys K^T[dh][key] dS^T[key][q],  dS^T = P^T (dP^T - delta_q) * scale
 // Block = NW query tiles; the K tile (rotated if Rin) and the V tile are shared through LDS.
-template <int NW>
+template <int NW, bool PK>
 __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               KeyRange KR, bf16_t* __restrict__ dqkv,
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
   const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
   const int qrow = q0 + l31;
   const Rope Rnone{nullptr, nullptr, nullptr, S};
-  const bool packed = KR.lo != nullptr;      // see attn_fwd_kernel
+  constexpr bool packed = PK;      // see attn_fwd_kernel
   int qlo = 0, qhi = (KR.key_len ? KR.key_len[b] : S) - 1;
   int ulo = 0, uhi = qhi, ilo = 0, ihi = qhi;
   if (packed) {
@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
 
 // dV^T[dh][key] = sum_q dO^T[dh][q] P[q][key] ; dK^T[dh][key] = sum_q Q^T[dh][q] dS[q][key]
 // Block = NW key tiles; every 32-query Q tile (rotated if Rin), dO tile and their lse/delta are shared through LDS.
-template <int NW>
+template <int NW, bool PK>
 __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                KeyRange KR, bf16_t* __restrict__ dqkv,
@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
   const bf16_t* kb = qb + d;
   const bf16_t* vb = qb + 2 * d;
   const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
-  const bool packed = KR.lo != nullptr;
+  constexpr bool packed = PK;
   const int klen = packed ? S : (KR.key_len ? KR.key_len[b] : S);
   const int krow = k0 + l31;
   const Rope Rnone{nullptr, nullptr, nullptr, S};
@@ -549,6 +549,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
   for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, krow, S, pitch, s, lane);
   f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
   const unsigned dbase = drop_base(D, b * H + h, 0, krow);
+  const bool key_ok = krow < klen;                 // right-padded rows: one key length per batch row
   const int kblk0 = blockIdx.x * NW * 32;          // first key of the block
   const int qstart = causal ? kblk0 : 0;           // queries before the block's first key never see it
   if (kblk0 < klen) {
@@ -576,7 +577,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
       if constexpr (PF) {
         tile_commit<NW * 64>(qt, pq, q0, S, tid, Rin, b);
         tile_commit<NW * 64>(dot_, pdo, q0, S, tid, Rnone, b);
-        if (tid < 32) { lse_s[tid] = -p_lse * kLog2e; dl_s[tid] = -p_dl; qlo_s[tid] = p_lo; qhi_s[tid] = p_hi; }
+        if (tid < 32) {
+          lse_s[tid] = -p_lse * kLog2e; dl_s[tid] = -p_dl;
+          if (packed) { qlo_s[tid] = p_lo; qhi_s[tid] = p_hi; }
+        }
       } else {
         load_tile_coop<NW * 64>(qt, qb, q0, S, pitch, tid, Rin, b);
         load_tile_coop<NW * 64>(dot_, dob, q0, S, (size_t)d, tid, Rnone, b);
@@ -584,9 +588,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
           const int q = min(q0 + tid, S - 1);
           lse_s[tid] = -lse[((size_t)b * H + h) * S + q] * kLog2e;
           dl_s[tid] = -delta[((size_t)b * H + h) * S + q];
-          const bool v = q0 + tid < S;
-          qlo_s[tid] = packed ? (v ? KR.lo[(size_t)b * S + q] : 0) : 0;
-          qhi_s[tid] = packed ? (v ? KR.hi[(size_t)b * S + q] : -1) : klen - 1;
+          if (packed) {
+            const bool v = q0 + tid < S;
+            qlo_s[tid] = v ? KR.lo[(size_t)b * S + q] : 0;
+            qhi_s[tid] = v ? KR.hi[(size_t)b * S + q] : -1;
+          }
         }
       }
       __syncthreads();
@@ -612,7 +618,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
         const int qi = acc_row(r, hi);
         const int q = q0 + qi;
         float p = exp2f(fmaf(sc[r], kScaleL2, lse_s[qi]));          // lse_s holds -lse * log2(e)
-        if (edge) p = (krow >= qlo_s[qi] && krow <= qhi_s[qi] && q < S && (!causal || krow <= q)) ? p : 0.f;
+        if (edge) {
+          const bool in_range = packed ? (krow >= qlo_s[qi] && krow <= qhi_s[qi]) : key_ok;
+          p = (in_range && q < S && (!causal || krow <= q)) ? p : 0.f;
+        }
         const float dm = drop_mul_x(D, dbase + (unsigned)q * 0x85EBCA77u);
         sc[r] = p * dm;                                  // dropped probabilities: what multiplied V in forward
         dp[r] = p * fmaf(dp[r], dm, dl_s[qi]) * kScale;  // dl_s holds -delta
@@ -659,9 +668,10 @@ int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, i
   const Drop D = make_drop(dropout_p, dropout_seed);
   const int nw = attn_waves(S);
   dim3 grid((S + 32 * nw - 1) / (32 * nw), H, B);
-#define GGET_ATTN_FWD(NW) hipLaunchKernelGGL(attn_fwd_kernel<NW>, grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, KR, \
+#define GGET_ATTN_FWD(NW, PK) hipLaunchKernelGGL((attn_fwd_kernel<NW, PK>), grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, KR, \
                                              (bf16_t*)out, lse, B, S, H, causal, R, D)
-  if (nw == 4) GGET_ATTN_FWD(4); else if (nw == 2) GGET_ATTN_FWD(2); else GGET_ATTN_FWD(1);
+  if (key_lo) { if (nw == 4) GGET_ATTN_FWD(4, true); else if (nw == 2) GGET_ATTN_FWD(2, true); else GGET_ATTN_FWD(1, true); }
+  else { if (nw == 4) GGET_ATTN_FWD(4, false); else if (nw == 2) GGET_ATTN_FWD(2, false); else GGET_ATTN_FWD(1, false); }
 #undef GGET_ATTN_FWD
   GGET_LAUNCH_CHECK();
   return 0;
@@ -683,14 +693,15 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
                      H);
   const int nw = attn_waves(S);
   dim3 grid((S + 32 * nw - 1) / (32 * nw), H, B);
-#define GGET_ATTN_BWD(NW)                                                                                                  \
+#define GGET_ATTN_BWD(NW, PK)                                                                                                \
   do {                                                                                                                     \
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<NW>, grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,   \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, PK>), grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,   \
                        delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);                                      \
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NW>, grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,  \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<NW, PK>), grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,  \
                        delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);                                      \
   } while (0)
-  if (nw == 4) GGET_ATTN_BWD(4); else if (nw == 2) GGET_ATTN_BWD(2); else GGET_ATTN_BWD(1);
+  if (key_lo) { if (nw == 4) GGET_ATTN_BWD(4, true); else if (nw == 2) GGET_ATTN_BWD(2, true); else GGET_ATTN_BWD(1, true); }
+  else { if (nw == 4) GGET_ATTN_BWD(4, false); else if (nw == 2) GGET_ATTN_BWD(2, false); else GGET_ATTN_BWD(1, false); }
 #undef GGET_ATTN_BWD
   GGET_LAUNCH_CHECK();
   return 0;

@@ -402,37 +402,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
   }
 }
 
-// delta[b,h,q] = sum_dh dO*O  (8 lanes per (token, head))
-__global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
-                                                         float* __restrict__ delta, int B, int S, int H) {
-  const long total = (long)B * S * H * 8;
-  const int d = H * 64;
-  for (long w = (long)blockIdx.x * 256 + threadIdx.x; w < total; w += (long)gridDim.x * 256) {
-    const int c = (int)(w & 7);
-    const long th = w >> 3;
-    const int h = (int)(th % H);
-    const long t = th / H;
-    float a[8], g[8];
-    unpack8(*reinterpret_cast<const uint4*>(out + t * d + h * 64 + c * 8), a);
-    unpack8(*reinterpret_cast<const uint4*>(dout + t * d + h * 64 + c * 8), g);
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s += a[e] * g[e];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if (c == 0) {
-      const int bb = (int)(t / S), ss = (int)(t % S);
-      delta[((size_t)bb * H + h) * S + ss] = s;
-    }
-  }
-}
-
 // dQ^T[dh][q] = sum_keys K^T[dh][key] dS^T[key][q],  dS^T = P^T (dP^T - delta_q) * scale
 // Block = NW query tiles; the K tile (rotated if Rin) and the V tile are shared through LDS.
 template <int NW, bool PK>
-__global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+__global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+                                                              const float* __restrict__ lse, float* __restrict__ delta,
                                                               KeyRange KR, bf16_t* __restrict__ dqkv,
                                                               int B, int S, int H, int causal, Rope Rin, Rope R, Drop D) {
   __shared__ __attribute__((aligned(16))) unsigned char kt[4096];
@@ -465,7 +439,23 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
 #pragma unroll
   for (int s = 0; s < 4; ++s) dof[s] = frag_global(dob, qrow, S, (size_t)d, s, lane);
   const size_t sidx = ((size_t)b * H + h) * S + min(qrow, S - 1);
-  const float nlse2 = -lse[sidx] * kLog2e, ndl = -delta[sidx];
+  // delta_q = sum_dh dO*O of this query row (the lane holds half of the row's dO already; the other half sits in lane^32);
+  // stored for the dK/dV kernel that follows on the same stream
+  float dl = 0.f;
+  {
+    const bf16_t* ob = out + (size_t)b * S * d + h * 64;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float a[8], gg[8];
+      unpack8(__builtin_bit_cast(uint4, frag_global(ob, qrow, S, (size_t)d, s, lane)), a);
+      unpack8(__builtin_bit_cast(uint4, dof[s]), gg);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += a[e] * gg[e];
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    if (hi == 0 && qrow < S) delta[sidx] = dl;
+  }
+  const float nlse2 = -lse[sidx] * kLog2e, ndl = -dl;
   const unsigned dbase = drop_base(D, b * H + h, qrow, 0);
   f32x16_t a0 = zero16(), a1 = zero16();
   const int q_end_blk = min(S, (int)(blockIdx.x + 1) * NW * 32);
@@ -686,16 +676,12 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
   const Rope R{cos_tab, sin_tab, position_ids, S};     // rotation of dq, dk back to the un-rotated projections
   const Rope Rin = qk_rotated ? Rope{nullptr, nullptr, nullptr, S} : R;   // q,k in memory are already rotated?
   const Drop D = make_drop(dropout_p, dropout_seed);
-  const long work = (long)B * S * H * 8;
-  int g = (int)((work + 255) / 256);
-  if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta_ws, B, S,
-                     H);
   const int nw = attn_waves(S);
   dim3 grid((S + 32 * nw - 1) / (32 * nw), H, B);
 #define GGET_ATTN_BWD(NW, PK)                                                                                                \
   do {                                                                                                                     \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, PK>), grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,   \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, PK>), grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,     \
+                       (const bf16_t*)dout, lse,   \
                        delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);                                      \
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<NW, PK>), grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,  \
                        delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);                                      \

@@ -377,3 +377,33 @@ def test_generation_loop(alg):
     assert agree > 0.3, f"only {agree:.2f} of the revealed tokens match the fp32 reference run"
     with pytest.raises(NotImplementedError):
         gen.sample_per_batch(model, gen.GenerationConfig(alg="origin"), input_ids=ids, attention_mask=att)
+
+
+def test_base_width_two_layers_matches_oracle():
+    """d = 768 (the headline model's width, 2 layers): the shapes that pick the 128x192 / 192x192 / 256x256 tiles, the
+    interleaved RoPE epilogue, the grouped four-problem weight-gradient launch and whole-line C stores, end to end against
+    the oracle (loss and every gradient tensor)."""
+    from _util import spec_mod, weights_mod, synth
+    B, S, F, V = 64, 32, 13, 756
+    spec = spec_mod.ModelSpec(kind=spec_mod.KIND_PRETRAIN, vocab_size=V, hidden_size=768, intermediate_size=3072, num_layers=2,
+                              num_heads=12, head_dim=64, stacked_feat=F, next_n_token=F)
+    batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=31)
+    state = weights_mod.make_state_dict(spec, seed=6, std=0.03, head_std=0.05)
+    b = tb(batch)
+    e = make_engine(spec, batch)
+    e.load_state_dict(state)
+    loss, _ = run_forward(e, spec, b, "pt")
+    e.backward()
+    torch.cuda.synchronize()
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32)
+    fn, lk, _ = oracle_fn(spec, b, "pt")
+    out, grads = O.loss_and_grads(fn, p, lk)
+    assert abs(loss.item() - out[lk].item()) <= 3e-4 * abs(out[lk].item())
+    got = e.grads()
+    gmax = max(float(g.norm()) for g in grads.values())
+    for k in state:
+        w = grads[k].numpy()
+        gk = got[k].float().cpu().numpy()
+        err = float(np.linalg.norm(gk - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        assert err < 6e-2, f"{k}: {err}"

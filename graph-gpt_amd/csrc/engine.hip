@@ -934,6 +934,14 @@ extern "C" int gget_op_token_confidence(const void* logits, int ld, int R, int V
   GGET_REQUIRE(R >= 0 && V >= 2 && ld >= V && mode >= 0 && mode <= 2, "token_confidence: bad arguments (R %d V %d ld %d mode %d)", R, V, ld, mode);
   return k_token_confidence(logits, ld, R, V, mode, conf, tok, (hipStream_t)stream);
 }
+extern "C" int gget_op_smtp_rows(const int64_t* ids_in, const int32_t* lengths, int64_t* ids_out, int64_t* labels_out,
+                                 float* wgt_out, int B, int S, int F, double umr_min, double umr_max, double power, uint32_t seed,
+                                 void* stream) {
+  GGET_REQUIRE(ids_in && lengths && ids_out && labels_out, "smtp_rows: null argument");
+  GGET_REQUIRE(B >= 0 && S >= 1 && F >= 1 && (long)S * F < (1l << 20), "smtp_rows: bad shape (S*F must be < 2^20)");
+  GGET_REQUIRE(0.0 <= umr_min && umr_min <= umr_max && umr_max <= 1.0 && power > 0.0, "smtp_rows: bad schedule");
+  return k_smtp_rows(ids_in, lengths, ids_out, labels_out, wgt_out, B, S, F, umr_min, umr_max, power, seed, (hipStream_t)stream);
+}
 extern "C" int gget_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, void* stream) {
   return k_rmsnorm_fwd(x, w, y, rstd, T, d, eps, (hipStream_t)stream);
 }

@@ -71,3 +71,5 @@ int k_smtp2d(const int64_t* ids_in, int ld_in, const int64_t* node_idx, int ld_n
              int B, int S, int F, float rate, float power, float replace_rate, int vocab, int global_mask, unsigned seed,
              hipStream_t st);
 int k_token_confidence(const void* logits, int ld, int R, int V, int mode, float* conf, int64_t* tok, hipStream_t st);
+int k_smtp_rows(const int64_t* ids_in, const int32_t* lengths, int64_t* ids_out, int64_t* labels_out, float* wgt_out, int B, int S,
+                int F, double umr_min, double umr_max, double power, unsigned seed, hipStream_t st);

@@ -948,6 +948,57 @@ __global__ void __launch_bounds__(kBlock) ranges_from_mask3d_kernel(const int64_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Collator-side SMTP masking on the device
+// reference: prepare_inputs_for_pretrain_mlm (src/utils/tokenizer_utils.py:259-271, polynomial schedule) +
+// _mask_stacked_input_ids_v2 (:112-148, mask_token_precent (1,0,0)): per sample t = umr_min + (umr_max-umr_min) U,
+// alpha = 1 - t^power, EXACTLY k = ceil(len*F*alpha) of the sample's own len*F cells are chosen uniformly at random:
+// here the k cells with the smallest keys (24-bit counter hash of (seed, sample, cell), ties broken by the cell index);
+// the k-th smallest key is found by bisection over the 44-bit key space, one block per sample.
+// Chosen cell: label = original id, id -> <mask> unless it is the pad id; every other label = -100.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long smtp_cell_key(unsigned seed, unsigned b, unsigned cell) {
+  return ((unsigned long long)smtp_rng(seed, 8, b, cell) << 20) | cell;
+}
+__global__ void __launch_bounds__(kBlock) smtp_rows_kernel(const int64_t* __restrict__ ids_in, const int32_t* __restrict__ lengths,
+                                                           int64_t* __restrict__ ids_out, int64_t* __restrict__ labels_out,
+                                                           float* __restrict__ wgt_out, int S, int F, double umr_min,
+                                                           double umr_max, double power, unsigned seed, int mask_id, int pad_id) {
+  __shared__ int cnt_s[kBlock / 64];
+  __shared__ int total_s;
+  const int b = blockIdx.x;
+  const int len = min(max(lengths[b], 0), S);
+  const int n = len * F;
+  const double r = (double)smtp_rng(seed, 9, b, 0) * (1.0 / 16777216.0);
+  const double t = umr_min + (umr_max - umr_min) * r;
+  const double alpha = 1.0 - pow(t, power);
+  const int k = (int)ceil((double)n * alpha);
+  if (wgt_out && threadIdx.x == 0) wgt_out[b] = (float)(power / t);
+  // smallest key value v with #{cells: key <= v} >= k
+  unsigned long long lo = 0, hi = (1ull << 44) - 1;
+  if (k > 0) {
+    while (lo < hi) {
+      const unsigned long long mid = lo + ((hi - lo) >> 1);
+      int c = 0;
+      for (int cell = threadIdx.x; cell < n; cell += kBlock) c += smtp_cell_key(seed, b, cell) <= mid ? 1 : 0;
+      c = (int)wave_sum((float)c);
+      if ((threadIdx.x & 63) == 0) cnt_s[threadIdx.x >> 6] = c;
+      __syncthreads();
+      if (threadIdx.x == 0) { int tsum = 0; for (int w = 0; w < kBlock / 64; ++w) tsum += cnt_s[w]; total_s = tsum; }
+      __syncthreads();
+      if (total_s >= k) hi = mid; else lo = mid + 1;
+      __syncthreads();
+    }
+  }
+  const long base = (long)b * S * F;
+  for (int cell = threadIdx.x; cell < S * F; cell += kBlock) {
+    const int64_t id = ids_in[base + cell];
+    const bool chosen = k > 0 && cell < n && smtp_cell_key(seed, b, cell) <= lo;
+    ids_out[base + cell] = (chosen && id != pad_id) ? (int64_t)mask_id : id;
+    labels_out[base + cell] = chosen ? id : (int64_t)-100;
+  }
+}
+
 inline int grid_for(long work_items, int per_block = kBlock, int cap = 4096) {
   long g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -1193,6 +1244,15 @@ int k_ranges_from_mask3d(const int64_t* mask3d, int32_t* key_lo, int32_t* key_hi
   if (B * S == 0) return 0;
   hipLaunchKernelGGL(ranges_from_mask3d_kernel, dim3(grid_for((long)B * S, kBlock / 64, 4096)), dim3(kBlock), 0, st, mask3d,
                      key_lo, key_hi, B * S, S);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_smtp_rows(const int64_t* ids_in, const int32_t* lengths, int64_t* ids_out, int64_t* labels_out, float* wgt_out, int B, int S,
+                int F, double umr_min, double umr_max, double power, unsigned seed, hipStream_t st) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(smtp_rows_kernel, dim3(B), dim3(kBlock), 0, st, ids_in, lengths, ids_out, labels_out, wgt_out, S, F, umr_min,
+                     umr_max, power, seed, 1, 0);
   GGET_LAUNCH_CHECK();
   return 0;
 }

@@ -71,3 +71,38 @@ def smtp2d_mask(input_ids: torch.Tensor, node_idx: torch.Tensor, stacked_feat: i
                                stacked_feat, float(smtp_2d_rate), float(power), float(replace_rate), int(vocab),
                                int(bool(global_2d_mask)), int(seed) & 0xFFFFFFFF, st))
     return out, lab
+
+
+def row_mask_selection(seed: int, lengths, S: int, F: int, umr_min: float = 0.01, umr_max: float = 0.99, power: float = 1.0):
+    """Twin of `smtp_rows_kernel`: per sample (chosen cell indices sorted by key, mask ratio alpha, dLM weight)."""
+    out = []
+    for b, ln in enumerate(np.asarray(lengths).tolist()):
+        n = int(min(max(ln, 0), S)) * F
+        r = float(_rng24(seed, 9, b, 0)) / 16777216.0
+        t = umr_min + (umr_max - umr_min) * r
+        alpha = 1.0 - t ** power
+        k = int(np.ceil(n * alpha))
+        cells = np.arange(n)
+        keys = (_rng24(seed, 8, b, cells).astype(np.int64) << 20) | cells
+        order = np.argsort(keys, kind="stable")[:k]
+        out.append((order, alpha, power / t))
+    return out
+
+
+def smtp_mask_rows(input_ids: torch.Tensor, lengths: torch.Tensor, *, umr_min: float = 0.01, umr_max: float = 0.99,
+                   power: float = 1.0, seed: int = 0, dlm_wgt: bool = False):
+    """Device-side collator masking of a right-padded batch ids [B,S,F] (int64, GPU) with lengths [B] (int32, GPU):
+    returns (masked ids, labels[, wgt])."""
+    if not input_ids.is_cuda:
+        raise L.GgetError("smtp_mask_rows runs on the GPU only (its CPU statement is test infrastructure under oracle/)")
+    lib = L.load()
+    B, S, F = input_ids.shape
+    ids = input_ids.contiguous()
+    lens = lengths.to(device=ids.device, dtype=torch.int32).contiguous()
+    out, lab = torch.empty_like(ids), torch.empty_like(ids)
+    wgt = torch.empty(B, dtype=torch.float32, device=ids.device) if dlm_wgt else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.gget_op_smtp_rows(C.c_void_p(ids.data_ptr()), C.c_void_p(lens.data_ptr()), C.c_void_p(out.data_ptr()),
+                                  C.c_void_p(lab.data_ptr()), C.c_void_p(wgt.data_ptr()) if wgt is not None else None, B, S, F,
+                                  float(umr_min), float(umr_max), float(power), int(seed) & 0xFFFFFFFF, st))
+    return (out, lab, wgt) if dlm_wgt else (out, lab)

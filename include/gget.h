@@ -208,6 +208,13 @@ int gget_op_smtp2d(const int64_t* ids_in, int ld_in, const int64_t* node_idx, in
 #define GGET_CONF_MARGIN 1
 #define GGET_CONF_NEG_ENTROPY 2
 int gget_op_token_confidence(const void* logits, int ld, int R, int V, int mode, float* conf, int64_t* tok, void* stream);
+/* replaces: the collator's SMTP masking (prepare_inputs_for_pretrain_mlm, src/utils/tokenizer_utils.py:259-271 polynomial
+ * schedule + _mask_stacked_input_ids_v2 :112-148, mtp (1,0,0)) for a right-padded batch ids [B,S,F] with lengths [B]:
+ * per sample t = umr_min + (umr_max - umr_min) U, exactly ceil(len*F*(1 - t^power)) of its cells are masked (id -> 1
+ * unless pad, label = original id; all other labels -100); optional wgt_out[b] = power / t (dlm_wgt).  Draws are a
+ * counter hash of `seed` (graph-gpt_amd/smtp.py holds the bit-exact twin). */
+int gget_op_smtp_rows(const int64_t* ids_in, const int32_t* lengths, int64_t* ids_out, int64_t* labels_out, float* wgt_out, int B,
+                      int S, int F, double umr_min, double umr_max, double power, uint32_t seed, void* stream);
 int gget_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, void* stream);
 int gget_op_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
                         void* dx, float* dw_accum, int T, int d, void* stream);

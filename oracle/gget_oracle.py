@@ -395,3 +395,27 @@ def sample_per_batch(logits_fn, input_ids: torch.Tensor, *, alg: str, steps: int
         x.scatter_(1, idx, final)
         hist.append(x.view(bz, seq, next_n).clone())
     return x, hist
+
+
+# ----------------------------------------------------------------------------- host SMTP masking (row A0 / N1)
+def smtp_mask_ratio(r: float, umr_min: float, umr_max: float, power: float):
+    """polynomial schedule of prepare_inputs_for_pretrain_mlm (src/utils/tokenizer_utils.py:259-271), python floats:
+    t = umr_min + (umr_max - umr_min) r ; mask ratio alpha = 1 - t^power ; dLM weight = power / t."""
+    t = umr_min + (umr_max - umr_min) * r
+    return 1 - t ** power, power / t
+
+
+def mask_stacked_input_ids_v2(input_ids, idx_masked, mask_token_id: int = 1, pad_token_id: int = 0):
+    """reference _mask_stacked_input_ids_v2 (src/utils/tokenizer_utils.py:112-148) with mask_token_precent (1, 0, 0) and
+    the sampled cell list passed in (`random.sample(range(seq*dim), k=ceil(seq*dim*mask_ratio))` in the reference):
+    input_ids [seq, dim] (numpy int64).  Returns (masked ids, labels) as numpy arrays."""
+    import numpy as np
+    ids = np.array(input_ids)
+    seq, dim = ids.shape
+    labels = np.full((seq, dim), -100)
+    for idx in idx_masked:
+        i, j = divmod(int(idx), dim)          # np.ndindex((seq, dim)) order
+        labels[i, j] = ids[i, j]
+        if ids[i, j] != pad_token_id:
+            ids[i, j] = mask_token_id
+    return ids, labels

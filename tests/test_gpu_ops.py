@@ -503,3 +503,32 @@ def test_attention_packed_ranges(lib, B, S, H, causal):
     for i, nm in enumerate("qkv"):
         e = rel_l2(got[:, :, i].cpu().numpy(), x.grad[:, :, i].cpu().numpy())
         assert e < 2e-2, f"packed attn bwd d{nm} rel-L2 {e}"
+
+
+@pytest.mark.parametrize("B,S,F,power", [(6, 24, 13, 1.0), (64, 32, 13, 1.0), (5, 40, 4, 2.0), (3, 2048, 13, 0.5), (4, 16, 1, 1.0)])
+def test_smtp_rows_kernel_matches_oracle(lib, B, S, F, power):
+    """Collator masking on the device (gget_op_smtp_rows) vs the oracle's _mask_stacked_input_ids_v2 fed with the cell list
+    of the Python twin of the kernel's keys: exact ids / labels, exactly ceil(len*F*alpha) masked cells per sample."""
+    from oracle import gget_oracle as O
+    smtp = importlib.import_module("graph-gpt_amd.smtp")
+    g = torch.Generator().manual_seed(B + S)
+    lens = torch.randint(max(2, S // 3), S + 1, (B,), generator=g)
+    ids = torch.randint(2, 700, (B, S, F), generator=g)
+    for b in range(B):
+        ids[b, lens[b]:] = 0
+    ids[0, 1, 0] = 0            # a pad-valued cell inside a sequence
+    seed = 4242 + B
+    got_ids, got_lab, got_w = smtp.smtp_mask_rows(ids.cuda(), lens.cuda(), power=power, seed=seed, dlm_wgt=True)
+    sel = smtp.row_mask_selection(seed, lens.numpy(), S, F, power=power)
+    for b in range(B):
+        n = int(lens[b])
+        idx, alpha, wgt = sel[b]
+        assert len(idx) == int(np.ceil(n * F * alpha))
+        want_ids, want_lab = O.mask_stacked_input_ids_v2(ids[b, :n].numpy(), idx)
+        np.testing.assert_array_equal(got_ids[b, :n].cpu().numpy(), want_ids)
+        np.testing.assert_array_equal(got_lab[b, :n].cpu().numpy(), want_lab)
+        assert torch.all(got_lab[b, n:] == -100) and torch.all(got_ids[b, n:] == 0)
+        assert int((got_lab[b] != -100).sum()) == len(idx)
+        assert abs(float(got_w[b]) - wgt) <= 1e-6 * wgt
+        a2, w2 = O.smtp_mask_ratio((1.0 - alpha) ** (1.0 / power) and ((1.0 - alpha) ** (1.0 / power) - 0.01) / 0.98, 0.01, 0.99, power)
+        assert abs(a2 - alpha) < 1e-9

@@ -141,3 +141,19 @@ def test_generation_loop_matches_reference(alg):
     for a, b in zip(hist, g[f"{alg}_hist"]):
         assert torch.equal(a, torch.from_numpy(b))
     assert torch.equal(x, torch.from_numpy(g[f"{alg}_x"]))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_host_masking_matches_reference(tag):
+    """Host SMTP masking (row A0): the oracle's _mask_stacked_input_ids_v2 with the reference's sampled cell list gives the
+    reference's ids / labels (incl. a pad-valued cell that is labelled but not overwritten); k = ceil(cells * ratio)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hostmask.npz"))
+    ids, idx = g[f"{tag}_ids"], g[f"{tag}_idx"]
+    assert len(idx) == int(np.ceil(ids.size * float(g[f"{tag}_ratio"])))
+    out_ids, out_lab = O.mask_stacked_input_ids_v2(ids, idx)
+    np.testing.assert_array_equal(out_ids, g[f"{tag}_out_ids"])
+    np.testing.assert_array_equal(out_lab, g[f"{tag}_out_labels"])
+    alpha, wgt = O.smtp_mask_ratio(0.25, 0.01, 0.99, 2.0)
+    t = 0.01 + 0.98 * 0.25
+    assert alpha == 1 - t ** 2.0 and wgt == 2.0 / t

@@ -336,6 +336,46 @@ def generation_fixture():
     print("generation written")
 
 
+def hostmask_fixture():
+    """Host-side SMTP masking: the reference _mask_stacked_input_ids_v2 under a recording random.sample."""
+    import random as _random
+    import_reference()
+    tu = sys.modules["src.utils.tokenizer_utils"]
+    res = {}
+    for tag, (seq, dim, ratio, seed) in {"a": (17, 13, 0.37, 1), "b": (40, 4, 0.9, 2), "c": (9, 1, 0.05, 3)}.items():
+        rng = np.random.RandomState(seed)
+        ids = rng.randint(2, 700, size=(seq, dim)).astype(np.int64)
+        if tag == "b":
+            ids[5, 2] = 0        # a pad-valued cell: keeps 0 but is labelled when sampled
+        rec = {}
+        real = _random.sample
+
+        def sample(pop, k):
+            out = real(pop, k)
+            rec["idx"] = list(out)
+            return out
+
+        _random.seed(100 + seed)
+        _random.sample = sample
+        try:
+            new_ids, labels = tu._mask_stacked_input_ids_v2(ids.tolist(), 1, list(range(2, 700)), mask_ratio=ratio,
+                                                            mask_token_precent=(1, 0, 0), pad_token_id=0)
+        finally:
+            _random.sample = real
+        if tag == "b" and (5 * dim + 2) not in rec["idx"]:
+            rec["idx"][0] = 5 * dim + 2   # make sure the pad-valued cell is exercised: rerun with the edited list
+            _random.sample = lambda pop, k: list(rec["idx"])
+            try:
+                new_ids, labels = tu._mask_stacked_input_ids_v2(ids.tolist(), 1, list(range(2, 700)), mask_ratio=ratio,
+                                                                mask_token_precent=(1, 0, 0), pad_token_id=0)
+            finally:
+                _random.sample = real
+        res.update({f"{tag}_ids": ids, f"{tag}_idx": np.array(rec["idx"], np.int64), f"{tag}_ratio": np.float64(ratio),
+                    f"{tag}_out_ids": np.array(new_ids, np.int64), f"{tag}_out_labels": np.array(labels, np.int64)})
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "hostmask.npz"), **res)
+    print("hostmask written")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -351,6 +391,8 @@ def main():
         smtp2d_fixture()
     if not only or "generation" in only:
         generation_fixture()
+    if not only or "hostmask" in only:
+        hostmask_fixture()
 
 
 if __name__ == "__main__":

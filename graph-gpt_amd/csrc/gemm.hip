@@ -10,18 +10,23 @@
 // ds_read_b128; M/N-contiguous tiles live as [64 k][rows] with a 32-byte-window XOR swizzle and are
 // read with gfx950's transposing ds_read_b64_tr_b16, so no operand is ever transposed in HBM.
 // MFMA: v_mfma_f32_16x16x32_bf16, operands swapped (D = Btile * Atile^T) so that a lane owns 4
-// consecutive N of one row of C => 8-byte epilogue stores.
+// consecutive N of one row of C; v_permlane16_swap + a DPP row_ror:8 exchange regroup them so that a
+// store instruction writes 8 rows x 128 B (whole cache lines).
 //
-// Pipeline: block = WM x WN waves, each wave a 64x64 sub-tile (4x4 MFMA accumulators); K is walked in
-// 64-deep tiles through a 3-slot LDS ring filled by LDS-DMA (global_load_lds_dwordx4, swizzle applied
-// on the per-lane SOURCE address because the LDS image of one DMA instruction is lane-linear).
-// Two tiles are in flight while one is computed: a COUNTED s_waitcnt vmcnt(pieces-per-tile) + ONE
-// barrier per K-tile (the barrier both publishes tile t and retires the reads of tile t-1, whose slot
-// the DMA of tile t+2 then overwrites).  The DMA is issued from inline asm: hipcc (ROCm 7.2) otherwise
-// drains vmcnt(0) in front of the next ds_read and nothing overlaps.
-// Tile order: XCD-aware (block b -> XCD b%8 gets a contiguous run of tile ids) and, inside that run,
-// 8-row super-tiles walked column-wise so the ~64 blocks resident on one XCD share 8 A-panels and
-// 8 B-panels in its 4 MiB L2 instead of streaming all of B from Infinity Cache for every row panel.
+// Two kernels:
+//  * gemm_persist_kernel - static shapes with K % 64 == 0: one block per CU walks an XCD-contiguous,
+//    super-tiled list of output tiles and streams ALL their K-tiles through one 3/4-slot LDS ring
+//    (global_load_lds_dwordx4: uniform 64-bit K-origin + per-lane 32-bit offsets computed once per
+//    tile; counted s_waitcnt vmcnt; ONE barrier per K-tile; the next K-tile's DMA pieces are issued
+//    between the MFMA groups).  Tile shapes 256x256x32, 256x128x64, 128x192x64, 192x192x64 and
+//    128x128x64 are chosen per launch so that tiles / CUs is integral where possible.
+//  * gemm_kernel - one 256x128 / 128x128 tile per block with the same ring: device-side row counts /
+//    reduction lengths (SMTP head), partial last K-tile (register path), split-K into fp32 slabs.
+// The DMA is issued from inline asm: hipcc (ROCm 7.2) otherwise drains vmcnt(0) in front of the next
+// ds_read and nothing overlaps.  Measurements behind these choices: profiles/r01_gemm_*.txt.
+// Diagnostics (timing experiments only): GGET_GEMM_ABLATE (1 no DMA, 2 no MFMA, 4 no C store on the
+// one-tile kernel; 32 = persistent kernel without epilogue), GGET_GEMM_NO_PERSIST, GGET_GEMM_NO_256,
+// GGET_GEMM_192=0, GGET_GEMM_SUPER=<rows per L2 super-tile>.
 #include <stdlib.h>
 
 #include "common.h"

@@ -280,6 +280,7 @@ struct gget_engine {
   }
   bf16_t* dx_cur = nullptr;  // gradient w.r.t. the residual stream entering the next backward stage
   bool packed = false;       // last forward used a 3-D block-diagonal attention mask (per-token key ranges)
+  bool defer_convert = false;
   const int32_t* klo() const { return packed ? wsp<int32_t>(ws.key_lo) : nullptr; }
   const int32_t* khi() const { return packed ? wsp<int32_t>(ws.key_hi) : nullptr; }
 
@@ -678,6 +679,7 @@ extern "C" int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, 
 namespace {
 
 int convert_bucket(gget_engine* h, int bucket, hipStream_t st) {
+  if (h->defer_convert) return 0;   // monolithic backward: one conversion launch over all buckets at the end
   const auto& bs = h->bucket_segs[bucket];
   return k_convert_segments(h->wsp<float>(h->ws.scratch32), h->G,
                             reinterpret_cast<const GgetSegment*>(h->W + h->ws.segs) + bs.first, bs.second, st);
@@ -860,10 +862,19 @@ extern "C" int gget_backward_end(gget_handle_t h, void* stream) {
 }
 
 extern "C" int gget_backward(gget_handle_t h, float loss_scale, void* stream) {
-  if (int e = gget_backward_begin(h, loss_scale, stream)) return e;
-  for (int i = h->cfg.num_layers - 1; i >= 0; --i)
-    if (int e = gget_backward_layer(h, i, stream)) return e;
-  return gget_backward_end(h, stream);
+  GGET_REQUIRE(h, "null handle");
+  // no bucket has to be final before the end: the small-parameter gradients (fp32 accumulators -> bf16) of all L+2
+  // buckets are converted by ONE launch instead of L+2
+  h->defer_convert = true;
+  int rc = gget_backward_begin(h, loss_scale, stream);
+  for (int i = h->cfg.num_layers - 1; i >= 0 && rc == 0; --i) rc = gget_backward_layer(h, i, stream);
+  if (rc == 0) rc = gget_backward_end(h, stream);
+  h->defer_convert = false;
+  if (rc) return rc;
+  int nseg = 0;
+  for (const auto& bs : h->bucket_segs) nseg += bs.second;
+  return k_convert_segments(h->wsp<float>(h->ws.scratch32), h->G, reinterpret_cast<const GgetSegment*>(h->W + h->ws.segs), nseg,
+                            (hipStream_t)stream);
 }
 
 extern "C" int gget_adamw_step(gget_handle_t h, float lr, float beta1, float beta2, float eps, float weight_decay,

@@ -22,8 +22,15 @@ constexpr float kScale = 0.125f;  // head_dim^-0.5, head_dim = 64
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kScaleL2 = kScale * kLog2e;   // scores are carried in the log2 domain: p = exp2(s * kScaleL2 - m2)
 
+// [32 rows][128 B] tile: the 16-byte chunk index is XORed with a 3-bit function of the row so that both access patterns
+// are bank-conflict free: ds_read_b128 of one chunk over 16 consecutive rows (rows of equal parity need 8 distinct chunk
+// slots: f is a bijection of (row>>1)&7) and ds_read_b64_tr_b16 over 4 consecutive rows x 64 B (rows r and r+2 must fall
+// into different 64-byte halves: bit 2 of f = bit 0 of row>>1).  PMC before: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+// 0.32-0.45 with the old single-bit swizzle.
 __device__ __forceinline__ int swz(int row, int byte_in_row) {
-  return row * 128 + (byte_in_row ^ (((row >> 1) & 1) << 6));
+  const int x = (row >> 1) & 7;
+  const int f = ((x & 1) << 2) | (x >> 1);
+  return row * 128 + ((((byte_in_row >> 4) ^ f) << 4) | (byte_in_row & 15));
 }
 
 // RoPE fused into the operand loads (hf apply_rotary_pos_emb :138-160, half-split pairing j <-> j+32): q and k stay

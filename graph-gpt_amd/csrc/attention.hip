@@ -11,6 +11,8 @@
 // operand (V^T, K^T, Q^T, dO^T: contraction index strided in memory) is read from a 4 KB LDS tile with
 // gfx950's ds_read_b64_tr_b16.  Backward = delta kernel + dQ kernel (per query tile) + dK/dV kernel
 // (per key tile); no atomics, P recomputed from the saved log-sum-exp.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -643,6 +645,115 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
   }
 }
 
+// S <= 32: one wave holds the whole (batch, head) problem, so the backward is ONE launch: the K, V, Q and dO tiles go to
+// LDS once, delta = rowsum(dO * O) is computed in place, then the dQ part (scores transposed, lane = query) and the dK/dV
+// part (lane = key) run back to back on the same tiles.  Same arithmetic as attn_bwd_dq_kernel + attn_bwd_dkv_kernel.
+__global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                               const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                               const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
+                                                               int B, int S, int H, int causal, Rope Rin, Rope R, Drop D) {
+  __shared__ __attribute__((aligned(16))) unsigned char kt[4096];
+  __shared__ __attribute__((aligned(16))) unsigned char vt[4096];
+  __shared__ __attribute__((aligned(16))) unsigned char qt[4096];
+  __shared__ __attribute__((aligned(16))) unsigned char dot_[4096];
+  __shared__ float lse_s[32], dl_s[32];
+  const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int d = H * 64;
+  const size_t pitch = (size_t)3 * d;
+  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* kb = qb + d;
+  const bf16_t* vb = qb + 2 * d;
+  const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
+  const bf16_t* ob = out + (size_t)b * S * d + h * 64;
+  const int klen = key_len ? key_len[b] : S;
+  const Rope Rnone{nullptr, nullptr, nullptr, S};
+  load_tile_coop<64>(kt, kb, 0, S, pitch, lane, Rin, b);
+  load_tile_coop<64>(vt, vb, 0, S, pitch, lane, Rnone, b);
+  load_tile_coop<64>(qt, qb, 0, S, pitch, lane, Rin, b);
+  load_tile_coop<64>(dot_, dob, 0, S, (size_t)d, lane, Rnone, b);
+  float dl = 0.f;
+  if (l31 < S) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float a[8], gg[8];
+      unpack8(*reinterpret_cast<const uint4*>(ob + (size_t)l31 * d + 32 * hi + 8 * c), a);
+      unpack8(*reinterpret_cast<const uint4*>(dob + (size_t)l31 * d + 32 * hi + 8 * c), gg);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += a[e] * gg[e];
+    }
+  }
+  dl += __shfl_xor(dl, 32, 64);
+  const float nlse2 = -lse[((size_t)b * H + h) * S + min(l31, S - 1)] * kLog2e;
+  if (hi == 0) { lse_s[l31] = nlse2; dl_s[l31] = -dl; }
+  __syncthreads();
+  const unsigned bh = b * H + h;
+  {   // ---------------- dQ^T[dh][q] = K^T dS^T   (lane owns query l31)
+    const int qrow = l31;
+    const unsigned dbase = drop_base(D, bh, qrow, 0);
+    f32x16_t dp = zero16(), sc = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, s, lane), frag_rows(dot_, s, lane), dp, 0, 0, 0);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), frag_rows(qt, s, lane), sc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = acc_row(r, hi);
+      const bool ok = key < klen && (!causal || key <= qrow) && qrow < S;
+      const float p = ok ? exp2f(fmaf(sc[r], kScaleL2, nlse2)) : 0.f;
+      sc[r] = p * fmaf(dp[r], drop_mul_x(D, dbase + (unsigned)key * 0xC2B2AE3Du), -dl) * kScale;
+    }
+    const bf16x8_t ds0 = acc_to_b(sc, 0), ds1 = acc_to_b(sc, 1);
+    f32x16_t a0 = zero16(), a1 = zero16();
+    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 0, lane), ds0, a0, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 1, lane), ds1, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 0, lane), ds0, a1, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 1, lane), ds1, a1, 0, 0, 0);
+    if (qrow < S) {
+      unrope_acc(a0, a1, R, rope_pos(R, b, qrow), hi);
+      store_t(dqkv + ((size_t)b * S + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
+    }
+  }
+  {   // ---------------- dV^T = dO^T P, dK^T = Q^T dS   (lane owns key l31)
+    const int krow = l31;
+    const bool key_ok = krow < klen;
+    const unsigned dbase = drop_base(D, bh, 0, krow);
+    f32x16_t sc = zero16(), dp = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, s, lane), frag_rows(kt, s, lane), sc, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dot_, s, lane), frag_rows(vt, s, lane), dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = acc_row(r, hi);
+      const bool ok = key_ok && q < S && (!causal || krow <= q);
+      const float p = ok ? exp2f(fmaf(sc[r], kScaleL2, lse_s[q])) : 0.f;
+      const float dm = drop_mul_x(D, dbase + (unsigned)q * 0x85EBCA77u);
+      sc[r] = p * dm;
+      dp[r] = p * fmaf(dp[r], dm, dl_s[q]) * kScale;
+    }
+    const bf16x8_t p0 = acc_to_b(sc, 0), p1 = acc_to_b(sc, 1);
+    const bf16x8_t s0 = acc_to_b(dp, 0), s1 = acc_to_b(dp, 1);
+    f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+    dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 0, lane), p0, dv0, 0, 0, 0);
+    dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 1, lane), p1, dv0, 0, 0, 0);
+    dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 1, 0, lane), p0, dv1, 0, 0, 0);
+    dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 1, 1, lane), p1, dv1, 0, 0, 0);
+    dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 0, 0, lane), s0, dk0, 0, 0, 0);
+    dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 0, 1, lane), s1, dk0, 0, 0, 0);
+    dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 0, lane), s0, dk1, 0, 0, 0);
+    dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 1, lane), s1, dk1, 0, 0, 0);
+    if (krow < S) {
+      bf16_t* row = dqkv + ((size_t)b * S + krow) * pitch + h * 64;
+      unrope_acc(dk0, dk1, R, rope_pos(R, b, krow), hi);
+      store_t(row + d, dk0, dk1, 1.f, hi);
+      store_t(row + 2 * d, dv0, dv1, 1.f, hi);
+    }
+  }
+}
+
 // waves (= 32-row tiles) per block: long sequences share each K/V (or Q/dO) tile among 4 waves through LDS
 int attn_waves(int S) { return S >= 128 ? 4 : (S >= 64 ? 2 : 1); }
 
@@ -683,6 +794,14 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
   const Rope R{cos_tab, sin_tab, position_ids, S};     // rotation of dq, dk back to the un-rotated projections
   const Rope Rin = qk_rotated ? Rope{nullptr, nullptr, nullptr, S} : R;   // q,k in memory are already rotated?
   const Drop D = make_drop(dropout_p, dropout_seed);
+  static int small = -1;
+  if (small < 0) { const char* e = getenv("GGET_ATTN_SMALL"); small = e ? atoi(e) : 1; }
+  if (S <= 32 && !key_lo && small) {
+    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(1, H, B), dim3(64), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
+                       (const bf16_t*)dout, lse, key_len, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);
+    GGET_LAUNCH_CHECK();
+    return 0;
+  }
   const int nw = attn_waves(S);
   dim3 grid((S + 32 * nw - 1) / (32 * nw), H, B);
 #define GGET_ATTN_BWD(NW, PK)                                                                                                \

@@ -319,15 +319,17 @@ def _drop_mask(seed, B, H, S, p):
     return torch.from_numpy((keep.astype(np.float32) / (1.0 - p)).reshape(B, H, S, S))
 
 
-def test_attention_dropout(lib):
+@pytest.mark.parametrize("S,short", [(72, 50), (32, 21), (256, 130)])
+def test_attention_dropout(lib, S, short):
     """Dropout on the softmax output (hf eager_attention_forward :210): the kernels regenerate the same counter-based
-    mask in forward, dQ and dK/dV; checked against autograd with the identical mask, and the drop rate is ~p."""
-    B, S, H, p, seed = 2, 72, 3, 0.1, 12345
+    mask in forward, dQ and dK/dV (S <= 32: the fused single-launch backward); checked against autograd with the
+    identical mask, and the drop rate is ~p."""
+    B, H, p, seed = 2, 3, 0.1, 12345
     d = H * 64
     qkv = rnd(B * S, 3 * d, seed=17)
-    lens = torch.tensor([S, 50], dtype=torch.int32).cuda()
+    lens = torch.tensor([S, short], dtype=torch.int32).cuda()
     mask = _drop_mask(seed, B, H, S, p).cuda()
-    assert abs(float((mask == 0).float().mean()) - p) < 0.01
+    assert abs(float((mask == 0).float().mean()) - p) < 0.015
     out = torch.zeros(B * S, d, dtype=torch.bfloat16, device="cuda")
     lse = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
     L.check(lib.gget_op_attn_fwd(P(qkv), P(lens), P(out), P(lse), B, S, H, 0, None, None, None, p, seed, ST()))

@@ -407,3 +407,37 @@ def test_base_width_two_layers_matches_oracle():
         gk = got[k].float().cpu().numpy()
         err = float(np.linalg.norm(gk - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
         assert err < 6e-2, f"{k}: {err}"
+
+
+def test_degenerate_batches():
+    """Edge cases of the SMTP head's device-side compaction: no masked cell at all (M = Lm = 0: nothing to back-propagate,
+    loss 0 where the reference's mean over an empty set is NaN), one masked cell in a B=1 batch, rows of length 1."""
+    from _util import spec_mod, weights_mod, synth
+    spec = spec_mod.spec_from_size("tiny", vocab_size=756, stacked_feat=13, next_n_token=13)
+    state = weights_mod.make_state_dict(spec, seed=5)
+    b = tb(synth.make_pretrain_batch(B=2, S=24, F=13, V=756, seed=3))
+    e = eng_mod.Engine(spec, max_tokens=48, max_batch=2)
+    e.load_state_dict(state)
+    loss = e.forward_pretrain(b["input_ids"], b["attention_mask"], torch.full_like(b["labels"], -100))
+    e.backward()
+    assert float(loss) == 0.0 and e.head_counts() == (0, 0)
+    assert all(float(g.float().abs().max()) == 0.0 for g in e.grads().values())
+    b1 = tb(synth.make_pretrain_batch(B=1, S=8, F=13, V=756, seed=4))
+    ids, lab = b1["input_ids"].clone(), torch.full_like(b1["labels"], -100)
+    lab[0, 2, 5], ids[0, 2, 5] = 77, 1
+    e1 = eng_mod.Engine(spec, max_tokens=8, max_batch=1)
+    e1.load_state_dict(state)
+    loss = e1.forward_pretrain(ids, b1["attention_mask"], lab)
+    e1.backward()
+    e1.adamw_step(1e-3)
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    want = O.pretrain_forward(spec, O.to_params(st_bf, torch.float32, requires_grad=False), ids, b1["attention_mask"], lab)["head1_loss"]
+    assert e1.head_counts() == (1, 1) and abs(float(loss) - float(want)) < 2e-3 * abs(float(want))
+    att = torch.zeros(2, 24, dtype=torch.int64)
+    att[:, 0] = 1
+    ids, lab = b["input_ids"].clone(), torch.full_like(b["labels"], -100)
+    ids[:, 1:] = 0
+    lab[:, 0, 0] = ids[:, 0, 0]
+    loss = e.forward_pretrain(ids, att, lab)
+    e.backward()
+    assert np.isfinite(float(loss)) and all(torch.isfinite(g.float()).all().item() for g in e.grads().values())

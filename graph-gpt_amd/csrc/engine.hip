@@ -55,6 +55,7 @@ struct LayerOff {
 struct Plan {
   std::vector<ParamRec> params;
   uint64_t n_params = 0;    // padded flat length
+  uint64_t lm_pad_off = 0, lm_pad_count = 0;   // zero rows behind lm_head.weight (see make_plan)
   uint64_t n_scratch32 = 0; // fp32 accumulation elements
   std::vector<LayerOff> layers;
   uint64_t emb = 0, emb32 = 0, gate = 0, gate32 = 0, normf = 0, normf32 = 0;
@@ -115,6 +116,12 @@ Plan make_plan(const gget_config_t& c) {
   if (c.kind == GGET_KIND_PRETRAIN) {
     if (pl.has_ntp) add_param(pl, "n_token_proj.weight", (int64_t)c.next_n_token * d, d, (int)L, false, &pl.ntp, nullptr);
     add_param(pl, "lm_head.weight", V, d, (int)L, false, &pl.lm, nullptr);
+    // zero rows behind lm_head up to round_up(V, 64): its dgrad GEMM then runs over K = Vp without a K tail (the pad
+    // columns of dlogits are zero as well); not a parameter - no name, no bucket, gradient and AdamW state stay zero
+    const int64_t Vp = (int64_t)align_up((uint64_t)V, 64);
+    pl.lm_pad_off = pl.n_params;
+    pl.lm_pad_count = (uint64_t)(Vp - V) * d;
+    pl.n_params += align_up(pl.lm_pad_count, 128);
   } else {
     add_param(pl, "score.weight", c.num_labels, d, (int)L, true, &pl.score, &pl.score32);
     if (c.score_bias) add_param(pl, "score.bias", c.num_labels, 0, (int)L, true, &pl.sbias, &pl.sbias32);
@@ -325,6 +332,16 @@ extern "C" int gget_create(const gget_config_t* cfg, const gget_buffers_t* bufs,
   h->av = static_cast<float*>(bufs->adam_v_dev);
   h->G = static_cast<bf16_t*>(bufs->grad_bf16_dev);
   h->W = static_cast<unsigned char*>(bufs->workspace_dev);
+  // stale rows behind a device-side row count are multiplied by zeros in the head weight gradient: they must be finite
+  GGET_HIP_CHECK(hipMemset(h->W, 0, h->ws.total));
+  if (h->plan.lm_pad_count) {   // the pad rows must read as zeros whatever the caller's arenas held
+    const uint64_t o = h->plan.lm_pad_off, n = h->plan.lm_pad_count;
+    GGET_HIP_CHECK(hipMemset(h->P + o, 0, n * 2));
+    GGET_HIP_CHECK(hipMemset(h->G + o, 0, n * 2));
+    if (h->master) GGET_HIP_CHECK(hipMemset(h->master + o, 0, n * 4));
+    if (h->am) GGET_HIP_CHECK(hipMemset(h->am + o, 0, n * 4));
+    if (h->av) GGET_HIP_CHECK(hipMemset(h->av + o, 0, n * 4));
+  }
   // gradient buckets in completion order + fp32->bf16 conversion segments per bucket
   const int L = cfg->num_layers;
   const int nb = L + 2;
@@ -338,6 +355,10 @@ extern "C" int gget_create(const gget_config_t* cfg, const gget_buffers_t* bufs,
     if (p.accum32)
       segs[b].push_back(GgetSegment{p.off32, p.off, align_up(p.count, 128),
                                     (uint64_t)(p.count <= kAccumCopyMax ? kAccumCopies : 1), align_up(p.count, 128)});
+  }
+  if (h->plan.lm_pad_count) {   // the zero rows behind lm_head travel with the head bucket: the buckets tile [0, n_params)
+    auto& r = h->bucket_range[h->bucket_of_layer(L)];
+    r.second = std::max(r.second, h->plan.lm_pad_off + align_up(h->plan.lm_pad_count, 128));
   }
   std::vector<GgetSegment> flat;
   h->bucket_segs.resize(nb);
@@ -804,7 +825,7 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
     int32_t* counts = h->wsp<int32_t>(w.counts);
     bf16_t* dlog = h->wsp<bf16_t>(w.dlogits);
     // lm_head: dHl = dlogits W_lm ; dW_lm = dlogits^T Hl (split-K, fp32 atomics: only 6x6 output tiles)
-    if (int e = gemm_nn(dlog, h->P + h->plan.lm, h->wsp<bf16_t>(w.dHl), T * n, d, V, Vp, d, d, counts + 1, st)) return e;
+    if (int e = gemm_nn(dlog, h->P + h->plan.lm, h->wsp<bf16_t>(w.dHl), T * n, d, Vp, Vp, d, d, counts + 1, st)) return e;   // K = Vp: zero pads on both sides
     {
       // K = Lm (device-side count, ~5e4) over only 6x6 output tiles: kLmSplit K-slices, one fp32 slab each, then a sum.
       // Slices that fall beyond a short Lm write nothing, so the slabs are cleared first.
@@ -824,7 +845,7 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
       if (int e = k_gather_rows(h->wsp<bf16_t>(w.dHl), h->wsp<int32_t>(w.sel_src), counts + 1, dP, T * n, d, 1, st)) return e;
       if (int e = gemm_nn(dP, h->P + h->plan.ntp, h->wsp<bf16_t>(w.dHm), T, d, n * d, n * d, d, d, counts, st)) return e;
       if (int e = gget_gemm_single(GGET_GEMM_TN, GGET_EPI_NONE, dP, h->wsp<bf16_t>(w.Hm), h->G + h->plan.ntp, nullptr, n * d, d,
-                                   T, n * d, d, d, nullptr, counts, 1, st))
+                                   T, n * d, d, d, nullptr, counts, 1, st, /*k_pad_zero=*/true))   // dP is cleared above, Hm is finite
         return e;
     }
     if (int e = k_gather_rows(h->wsp<bf16_t>(w.dHm), h->wsp<int32_t>(w.row_idx), counts, dhid, T, d, 1, st)) return e;

@@ -22,6 +22,7 @@ struct GemmProblem {
   const float* rope_sin;
   const int64_t* rope_pos;  // [M] or nullptr => position = row % rope_S
   int rope_S, rope_cols;
+  int k_pad_zero;           // with k_dev: rows k_dev..round_up(k_dev, 64) of A are zero and those of B finite (whole K-tiles allowed)
 };
 
 struct GemmGroup {
@@ -34,4 +35,4 @@ struct GemmGroup {
 // mode: GGET_GEMM_NT/NN/TN, epi: GGET_EPI_*; problems of one group share mode and epilogue.
 int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t st);
 int gget_gemm_single(int mode, int epi, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
-                     int lda, int ldb, int ldc, const int* m_dev, const int* k_dev, int split_k, hipStream_t st);
+                     int lda, int ldb, int ldc, const int* m_dev, const int* k_dev, int split_k, hipStream_t st, bool k_pad_zero = false);

@@ -299,7 +299,8 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
     // NJ == 6 (96-column wave tile of the 128x192 block tile): the wave whose tile starts mid-line stores its first 32
     // columns the plain way and regroups the other 64, the other wave the reverse
     const int lead = (NJ == 6 && (nw & 63) == 32) ? 1 : 0;
-    if ((N & 63) == 0 && (P.ldc & 63) == 0 && ((nw & 63) == 0 || lead) && ((uintptr_t)P.C & 127) == 0) {
+    // (a ragged width - N % 64 != 0, plain stores only - keeps the whole-line path: the chunk that straddles N is cut to 8 B)
+    if (((N & 63) == 0 || EPI == GGET_EPI_NONE) && (P.ldc & 63) == 0 && ((nw & 63) == 0 || lead) && ((uintptr_t)P.C & 127) == 0) {
       const bool low = (l15 & 8) == 0;
       const int c0 = 2 * (gq & 1) + (gq >> 1);   // 16-byte chunk (of the 8 in a 64-column group) this lane holds for the first jp
       auto piece = [&](int i, int jp, int m) {   // epilogue math of (i, jp): the lane's 8 columns of row m, packed
@@ -339,16 +340,20 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
           const uint4 pa = low ? x : yr;
           const uint4 pb = low ? xr : y;
           const int n = nw + ja * 32 + (low ? c0 : c0 + 4) * 8;
-          if (n < N) {
+          if (n + 8 <= N) {
             if (ma < M) *reinterpret_cast<uint4*>(C + (size_t)ma * P.ldc + n) = pa;
             if (mb < M) *reinterpret_cast<uint4*>(C + (size_t)mb * P.ldc + n) = pb;
+          } else if (n < N) {
+            if (ma < M) *reinterpret_cast<uint2*>(C + (size_t)ma * P.ldc + n) = make_uint2(pa.x, pa.y);
+            if (mb < M) *reinterpret_cast<uint2*>(C + (size_t)mb * P.ldc + n) = make_uint2(pb.x, pb.y);
           }
         }
         if constexpr (NJ == 6) {   // the remaining 32 columns: 16 rows x 64 B per instruction
           const int jl = lead ? 0 : 2;
           const uint4 z = lead ? piece(i, 0, m) : piece(i, NJ / 2 - 1, m);
           const int n = nw + jl * 32 + c0 * 8;
-          if (m < M && n < N) *reinterpret_cast<uint4*>(C + (size_t)m * P.ldc + n) = z;
+          if (m < M && n + 8 <= N) *reinterpret_cast<uint4*>(C + (size_t)m * P.ldc + n) = z;
+          else if (m < M && n < N) *reinterpret_cast<uint2*>(C + (size_t)m * P.ldc + n) = make_uint2(z.x, z.y);
         }
       }
       return;
@@ -404,8 +409,8 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
 }
 
 // (tile id inside one problem) -> (m0, n0): 8-row super-tiles walked column-wise (L2 reuse of A and B panels)
-__device__ __forceinline__ void tile_origin(const GemmProblem& P, int lt, int BM, int BN, int kSup, int& m0, int& n0) {
-  const int tiles_m = (P.M + BM - 1) / BM;
+__device__ __forceinline__ void tile_origin(const GemmProblem& P, int M, int lt, int BM, int BN, int kSup, int& m0, int& n0) {
+  const int tiles_m = (M + BM - 1) / BM;
   const int per_super = kSup * P.tiles_n;
   const int sup = lt / per_super, rem = lt - sup * per_super;
   const int rows_here = min(kSup, tiles_m - sup * kSup);
@@ -437,7 +442,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const
   const int K = P.k_dev ? *P.k_dev : P.K;
   const int N = P.N;
   int m0, n0;
-  tile_origin(P, tile - P.tile_begin, BM, BN, g.super, m0, n0);
+  tile_origin(P, P.M, tile - P.tile_begin, BM, BN, g.super, m0, n0);
   if (m0 >= M) return;
   // split-K slice of this block (gridDim.y slices, 64-aligned)
   const int ktiles = (K + 63) >> 6;
@@ -558,7 +563,16 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
-  struct Ctx { int pi, m0, n0, nk; };
+  // a row count that lives on the device (rows selected by the masking, single-problem launches only): the tile list is
+  // rebuilt from it here, the host sized the grid for the capacity
+  const bool dyn_m = g.p[0].m_dev != nullptr;
+  const int m_dyn = dyn_m ? *g.p[0].m_dev : 0;
+  if (dyn_m) total_tiles = ((m_dyn + BM - 1) / BM) * g.p[0].tiles_n;
+  // a device-side K (weight gradient over the selected rows, single problem): whole K-tiles up to round_up(K, BK) - the
+  // caller guarantees that the rows between K and the capacity are finite on one side and zero on the other
+  const bool dyn_k = g.p[0].k_dev != nullptr;
+  const int k_tiles_dyn = dyn_k ? max(1, (min(*g.p[0].k_dev, g.p[0].K) + BK - 1) >> KSH) : 0;
+  struct Ctx { int pi, m0, n0, nk, M; };
   auto tile_at = [&](int r, Ctx& c) -> bool {
     const int tile = r * G + perm;
     if (tile >= total_tiles) return false;
@@ -567,8 +581,9 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
     for (int i = 1; i < GGET_MAX_GROUP; ++i)
       if (i < g.count && tile >= g.p[i].tile_begin) pi = i;
     c.pi = pi;
-    tile_origin(g.p[pi], tile - g.p[pi].tile_begin, BM, BN, g.super, c.m0, c.n0);
-    c.nk = g.p[pi].K >> KSH;
+    c.M = dyn_m ? m_dyn : g.p[pi].M;
+    tile_origin(g.p[pi], c.M, tile - g.p[pi].tile_begin, BM, BN, g.super, c.m0, c.n0);
+    c.nk = dyn_k ? k_tiles_dyn : (g.p[pi].K >> KSH);
     return true;
   };
 
@@ -595,7 +610,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
     const GemmProblem& P = g.p[ic.pi];
     iA = P.A; iB = P.B; ilda = P.lda; ildb = P.ldb;
 #pragma unroll
-    for (int i = 0; i < TA::PIECES; ++i) offA[i] = TA::piece_off(P.lda, ic.m0, P.M, wave, lane, i);
+    for (int i = 0; i < TA::PIECES; ++i) offA[i] = TA::piece_off(P.lda, ic.m0, ic.M, wave, lane, i);
 #pragma unroll
     for (int i = 0; i < TB::PIECES; ++i) offB[i] = TB::piece_off(P.ldb, ic.n0, P.N, wave, lane, i);
   };
@@ -629,7 +644,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
   auto finish_tile = [&]() {
     const GemmProblem& P = g.p[cc.pi];
     if (g.ablate != 32 || acc[0][0][0] == 123.456f)   // GGET_GEMM_ABLATE=32: persistent kernel without the epilogue (timing only)
-      store_tile<EPI, MI, NJ, ILV>(acc, P, P.M, (P.N + 3) & ~3, cc.m0 + wm * (MI * 16), cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, wn * 16);
+      store_tile<EPI, MI, NJ, ILV>(acc, P, cc.M, (P.N + 3) & ~3, cc.m0 + wm * (MI * 16), cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, wn * 16);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -736,7 +751,9 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
   constexpr int SMEM = kStages * (BM + BN) * 128;
   bool persist = split_k <= 1 && EPI != GGET_EPI_ATOMIC_F32 && EPI != GGET_EPI_SLAB_F32 && (!g.ablate || g.ablate >= 8) && getenv("GGET_GEMM_NO_PERSIST") == nullptr;
   for (int i = 0; i < g.count; ++i)
-    persist = persist && g.p[i].m_dev == nullptr && g.p[i].k_dev == nullptr && (g.p[i].K % 64) == 0 && g.p[i].K >= 64;
+    persist = persist && (g.p[i].m_dev == nullptr || (g.count == 1 && !A_MC && getenv("GGET_GEMM_NO_DYN") == nullptr)) &&
+              (g.p[i].k_dev == nullptr || (g.count == 1 && g.p[i].k_pad_zero && getenv("GGET_GEMM_NO_DYN") == nullptr)) &&
+              (g.p[i].K % 64) == 0 && g.p[i].K >= 64;
   if (persist) {
     static int num_cu = 0;
     if (!num_cu) {
@@ -775,8 +792,9 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
       bool ok = use192 != 0;
       long t192 = 0;
       for (int i = 0; i < g.count; ++i) {
-        ok = ok && (g.p[i].N % 192) == 0;
-        t192 += (long)((g.p[i].M + 127) / 128) * (g.p[i].N / 192);
+        // a ragged last column of tiles only for row-major B (NT: its DMA clamps the B rows) and plain stores
+        ok = ok && ((g.p[i].N % 192) == 0 || (!B_MC && EPI != GGET_EPI_ROPE && g.p[i].N > 384));
+        t192 += (long)((g.p[i].M + 127) / 128) * ((g.p[i].N + 191) / 192);
       }
       // rounds x tile area: take 128x192 when it needs less per-CU work than the default tile
       const long cur_rounds = (total + num_cu - 1) / num_cu, r192 = (t192 + num_cu - 1) / num_cu;
@@ -784,7 +802,7 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
         int tot3 = 0;
         for (int i = 0; i < g.count; ++i) {
           GemmProblem& p = g.p[i];
-          p.tiles_n = p.N / 192;
+          p.tiles_n = (p.N + 191) / 192;
           p.tile_begin = tot3;
           tot3 += ((p.M + 127) / 128) * p.tiles_n;
         }
@@ -889,7 +907,7 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
 }
 
 int gget_gemm_single(int mode, int epi, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
-                     int lda, int ldb, int ldc, const int* m_dev, const int* k_dev, int split_k, hipStream_t st) {
+                     int lda, int ldb, int ldc, const int* m_dev, const int* k_dev, int split_k, hipStream_t st, bool k_pad_zero) {
   GemmGroup g;
   g.count = 1;
   GemmProblem& p = g.p[0];
@@ -900,6 +918,7 @@ int gget_gemm_single(int mode, int epi, const void* A, const void* B, void* C, c
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.m_dev = m_dev; p.k_dev = k_dev;
+  p.k_pad_zero = k_pad_zero ? 1 : 0;
   p.slab_stride = (long)M * ldc;  // EPI_SLAB_F32 through the op-level entry: dense [split_k][M][ldc] slabs
   return gget_gemm_launch(mode, epi, g, split_k, st);
 }

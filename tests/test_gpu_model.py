@@ -441,3 +441,40 @@ def test_degenerate_batches():
     loss = e.forward_pretrain(ids, att, lab)
     e.backward()
     assert np.isfinite(float(loss)) and all(torch.isfinite(g.float()).all().item() for g in e.grads().values())
+
+
+def test_head_counts_on_device_persistent_tiles():
+    """Sizes whose head GEMMs take the persistent kernel with device-side row / reduction counts (T % 64 == 0): an empty
+    selection (M = K = 0 -> zero gradients), a single masked cell and a normal batch, each against the oracle; the normal
+    batch twice in a row so that stale rows of the longer selection sit behind the shorter one."""
+    from _util import spec_mod, weights_mod, synth
+    B, S, F, V = 8, 32, 13, 756
+    spec = spec_mod.spec_from_size("tiny", vocab_size=V, stacked_feat=F, next_n_token=F)
+    state = weights_mod.make_state_dict(spec, seed=9, std=0.05)
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    b = tb(synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=12))
+    e = eng_mod.Engine(spec, max_tokens=B * S, max_batch=B)
+    e.load_state_dict(state)
+
+    def check(ids, lab, tol=6e-2):
+        loss = e.forward_pretrain(ids, b["attention_mask"], lab)
+        e.backward()
+        p = O.to_params(st_bf, torch.float32)
+        out, grads = O.loss_and_grads(lambda q: O.pretrain_forward(spec, q, ids, b["attention_mask"], lab), p, "head1_loss")
+        assert abs(float(loss) - out["head1_loss"].item()) <= 2e-3 * abs(out["head1_loss"].item())
+        got = e.grads()
+        gmax = max(float(g.norm()) for g in grads.values())
+        for k in ("lm_head.weight", "n_token_proj.weight", "model.layers.0.mlp.down_proj.weight", "model.embed_tokens.weight"):
+            w = grads[k].numpy()
+            err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+            assert err < tol, f"{k}: {err}"
+
+    check(b["input_ids"], b["labels"])
+    ids, lab = b["input_ids"].clone(), torch.full_like(b["labels"], -100)
+    lab[3, 5, 2], ids[3, 5, 2] = 77, 1
+    check(ids, lab)
+    loss = e.forward_pretrain(b["input_ids"], b["attention_mask"], torch.full_like(b["labels"], -100))
+    e.backward()
+    assert float(loss) == 0.0 and e.head_counts() == (0, 0)
+    assert all(float(g.float().abs().max()) == 0.0 for g in e.grads().values())
+    check(b["input_ids"], b["labels"])

@@ -212,6 +212,42 @@ def ft_batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine, label_k
     return loss, out.task_logits
 
 
+# ----------------------------------------------------------------------------- evaluation pass
+@torch.no_grad()
+def evaluate(model, loader, eval_name: str = "valid", do_eval: bool = True):
+    """Pre-train evaluation pass, reference log_eval_dump_utils.evaluate (:242-304): eval mode, one forward per batch with
+    labels and sample weights but WITHOUT position_ids (the reference comments them out), head1 loss sum-reduced to rank 0
+    and divided by the world size there, mean over the batches; returns (loss, None) and puts the model back in train mode.
+    `do_eval=False` returns (None, None)."""
+    if not do_eval:
+        return None, None
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    model.eval()
+    device = model.device
+    losses, aux_losses = [], []
+    for data in loader:
+        out = model(input_ids=data["input_ids"].to(device), attention_mask=data["attention_mask"].to(device),
+                    labels=data["labels"].to(device), inputs_raw_embeds=None,
+                    sample_wgt=data["wgt"].to(device) if "wgt" in data else None)
+        loss, aux = out.head1_loss.clone(), out.head2_loss
+        if world > 1:
+            dist.reduce(loss, 0)
+            if aux is not None:
+                aux = aux.clone()
+                dist.reduce(aux, 0)
+            if rank == 0:
+                loss = loss / world
+                aux = aux / world if aux is not None else None
+        losses.append(loss)
+        if aux is not None and not torch.isnan(aux).item():
+            aux_losses.append(aux)
+    model.train()
+    if not losses:
+        raise ValueError(f"evaluate: the {eval_name} loader yielded no batch")
+    return sum(losses) / len(losses), None
+
+
 # ----------------------------------------------------------------------------- distributed env
 def set_dist_env(backend: Optional[str] = None):
     """reference misc_utils.set_dist_env (:507-539): env:// rendezvous, one process per GPU, barrier."""

@@ -63,3 +63,67 @@ def test_bucketed_allreduce_gloo_world2():
         assert p.exitcode == 0
     assert res[0][1] and res[1][1], "bucketed sum all-reduce mismatch"
     assert res[0][2] != res[1][2], "ranks must draw different batches"
+
+
+class _FakeOut:
+    def __init__(self, loss):
+        self.head1_loss, self.head2_loss = loss, None
+
+
+class _FakeModel:
+    """Stands in for the device model on CPU: loss = mean of the labels it is shown (the test is about the host loop)."""
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self.mode, self.seen_kwargs = "train", None
+
+    def eval(self):
+        self.mode = "eval"
+
+    def train(self):
+        self.mode = "train"
+
+    def __call__(self, **kw):
+        assert self.mode == "eval"
+        self.seen_kwargs = sorted(kw)
+        return _FakeOut(kw["labels"].float().mean())
+
+
+def _eval_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    tr.set_dist_env(backend="gloo")
+    loader = [{"input_ids": torch.zeros(2, 3, 1, dtype=torch.int64), "attention_mask": torch.ones(2, 3, dtype=torch.int64),
+               "labels": torch.full((2, 3, 1), float(10 * rank + i))} for i in range(3)]
+    m = _FakeModel()
+    loss, aux = tr.evaluate(m, loader, "valid")
+    q.put((rank, float(loss), aux, m.mode, m.seen_kwargs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_evaluate_reduces_loss_to_rank0_gloo_world2():
+    """reference log_eval_dump_utils.evaluate: per batch the rank losses are summed onto rank 0 and divided by the world size,
+    then averaged over the batches; position_ids are not forwarded; the model ends in train mode."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    # rank 0: mean_i ((i) + (10 + i)) / 2 = mean_i (5 + i) = 6
+    assert abs(res[0][1] - 6.0) < 1e-6 and res[0][2] is None
+    assert res[0][3] == "train" and res[0][4] == ["attention_mask", "input_ids", "inputs_raw_embeds", "labels", "sample_wgt"]
+
+
+def test_evaluate_single_process():
+    m = _FakeModel()
+    loader = [{"input_ids": torch.zeros(1, 2, 1, dtype=torch.int64), "attention_mask": torch.ones(1, 2, dtype=torch.int64),
+               "labels": torch.full((1, 2, 1), float(v))} for v in (1, 3)]
+    loss, aux = tr.evaluate(m, loader)
+    assert float(loss) == 2.0 and aux is None and m.mode == "train"
+    assert tr.evaluate(m, loader, do_eval=False) == (None, None)

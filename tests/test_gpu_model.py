@@ -478,3 +478,30 @@ def test_head_counts_on_device_persistent_tiles():
     assert float(loss) == 0.0 and e.head_counts() == (0, 0)
     assert all(float(g.float().abs().max()) == 0.0 for g in e.grads().values())
     check(b["input_ids"], b["labels"])
+
+
+def test_evaluate_pass_matches_oracle_losses():
+    """training.evaluate (reference log_eval_dump_utils.evaluate :242-304) on the device model: the mean of the per-batch
+    losses of an eval-mode forward (attention dropout configured but inactive) equals the oracle's, and the model returns to
+    train mode."""
+    import importlib
+    modeling = importlib.import_module("graph-gpt_amd.modeling")
+    tr = importlib.import_module("graph-gpt_amd.training")
+    from _util import synth
+    F, V = 4, 300
+    cfg = modeling.GraphGPTConfig(vocab_size=V, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
+                                  num_attention_heads=2, max_position_embeddings=1024, causal_attention=False, stacked_feat=F,
+                                  next_n_token=F, attention_dropout=0.1)
+    model = modeling.GraphGPTPretrainBase(cfg, seed=2).cuda()
+    loader = []
+    for s in (1, 2, 3):
+        b = synth.make_pretrain_batch(B=4, S=24, F=F, V=V, seed=40 + s)
+        loader.append({k: torch.from_numpy(b[k]) for k in ("input_ids", "attention_mask", "labels", "position_ids")})
+    loss, aux = tr.evaluate(model, loader, "valid")
+    assert aux is None and model.training
+    sd = {k: v.detach().float().cpu().numpy() for k, v in model.state_dict().items()}
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in sd.items()}
+    p = O.to_params(st_bf, torch.float32, requires_grad=False)
+    want = np.mean([O.pretrain_forward(model.spec, p, d["input_ids"], d["attention_mask"], d["labels"])["head1_loss"].item()
+                    for d in loader])
+    assert abs(float(loss) - want) <= 2e-3 * abs(want)

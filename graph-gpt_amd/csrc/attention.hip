@@ -645,15 +645,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
   }
 }
 
-// S <= 32: one wave holds the whole (batch, head) problem, so the backward is ONE launch: the K, V, Q and dO tiles go to
-// LDS once, delta = rowsum(dO * O) is computed in place, then the dQ part (scores transposed, lane = query) and the dK/dV
+// S <= 32: one wave holds the whole (batch, head) problem, so the backward is ONE launch: the K, Q and dO tiles go to
+// LDS once (V stays in registers), delta = rowsum(dO * O) is computed in place, then the dQ part (scores transposed, lane = query) and the dK/dV
 // part (lane = key) run back to back on the same tiles.  Same arithmetic as attn_bwd_dq_kernel + attn_bwd_dkv_kernel.
 __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                                const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
                                                                int B, int S, int H, int causal, Rope Rin, Rope R, Drop D) {
   __shared__ __attribute__((aligned(16))) unsigned char kt[4096];
-  __shared__ __attribute__((aligned(16))) unsigned char vt[4096];
   __shared__ __attribute__((aligned(16))) unsigned char qt[4096];
   __shared__ __attribute__((aligned(16))) unsigned char dot_[4096];
   __shared__ float lse_s[32], dl_s[32];
@@ -669,7 +668,11 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
   const int klen = key_len ? key_len[b] : S;
   const Rope Rnone{nullptr, nullptr, nullptr, S};
   load_tile_coop<64>(kt, kb, 0, S, pitch, lane, Rin, b);
-  load_tile_coop<64>(vt, vb, 0, S, pitch, lane, Rnone, b);
+  // V is only ever read row-wise (operand rows = keys): its fragments come straight from global memory, which keeps the
+  // block at 12 KiB of LDS = 12 single-wave blocks per CU, i.e. B*H = 3072 problems of the headline shape in ONE round
+  bf16x8_t vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, l31, S, pitch, s, lane);
   load_tile_coop<64>(qt, qb, 0, S, pitch, lane, Rin, b);
   load_tile_coop<64>(dot_, dob, 0, S, (size_t)d, lane, Rnone, b);
   float dl = 0.f;
@@ -694,7 +697,7 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
     f32x16_t dp = zero16(), sc = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, s, lane), frag_rows(dot_, s, lane), dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s], frag_rows(dot_, s, lane), dp, 0, 0, 0);
       sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), frag_rows(qt, s, lane), sc, 0, 0, 0);
     }
 #pragma unroll
@@ -723,7 +726,7 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, s, lane), frag_rows(kt, s, lane), sc, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dot_, s, lane), frag_rows(vt, s, lane), dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dot_, s, lane), vf[s], dp, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

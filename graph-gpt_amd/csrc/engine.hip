@@ -149,7 +149,7 @@ struct Ws {
   std::vector<LayerWs> lw;
   uint64_t rstd_f, hidden;
   uint64_t dxa, dxb, dxc, dxn, dqkv, dattn, dgu, dh, delta, dscaled, dscaled2;
-  uint64_t scratch32, loss_sum, sqnorm, counts, segs, emb_sort, wg32, lm_slab;
+  uint64_t scratch32, loss_sum, sqnorm, counts, segs, emb_sort, emb_cnt, emb_slab, wg32, lm_slab;
   // pre-train head
   uint64_t cnt, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
   // task head
@@ -206,6 +206,8 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.segs = b.take((uint64_t)pl.params.size() * sizeof(GgetSegment));
   w.wg32 = b.take(kWgSplit * 4 * d * d * 4);   // split-K slabs of the q|k|v|o wgrad
   w.emb_sort = b.take(k_embed_bwd_ws_elems(T * (uint64_t)c.stacked_feat, (uint64_t)c.vocab_size) * 4);
+  w.emb_cnt = k_embed_dense_ok(c.vocab_size, pl.has_gate) ? b.take(T * align_up(c.vocab_size, 64) * 2) : 0;   // bf16 [T][Vp] count matrix
+  w.emb_slab = k_embed_dense_ok(c.vocab_size, pl.has_gate) ? b.take((uint64_t)kEmbDenseSplit * c.vocab_size * d * 4) : 0;
   if (c.kind == GGET_KIND_PRETRAIN) {
     const uint64_t n = c.next_n_token, Vp = align_up(c.vocab_size, 64);
     w.cnt = b.take(T * 4);
@@ -869,14 +871,41 @@ extern "C" int gget_backward_layer(gget_handle_t h, int layer, void* stream) {
   return layer_backward(h, layer, (hipStream_t)stream);
 }
 
+// Embedding backward (SURVEY row A1 backward).  Small un-gated vocabularies: dE = C^T dX with the bf16 count matrix C
+// (k_embed_count), one split-K GEMM with fp32 atomics into the accumulator - the sorted scatter-add below spends its time in
+// same-address atomics when half of the cells hold the <mask> id.  Otherwise: counting sort by id + segmented sums.
+int embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* gate, float* demb, float* dgate, int T, int F,
+              int ldF, int d, int V, int pad_id, int32_t* sort_ws, void* cnt_ws, void* slab_ws, hipStream_t st) {
+  static const bool sorted_only = getenv("GGET_EMBED_SORTED") != nullptr;   // A/B knob
+  if (cnt_ws && slab_ws && !sorted_only && k_embed_dense_ok(V, gate != nullptr) && T > 0 && (V * d) % 4 == 0) {
+    const int ldc = (int)align_up((uint64_t)V, 64);
+    GGET_HIP_CHECK(hipMemsetAsync(cnt_ws, 0, (size_t)T * ldc * 2, st));
+    if (int e = k_embed_count(ids, cnt_ws, T, F, ldF, ldc, pad_id, st)) return e;
+    // 6 x 6 output tiles at V = 756, d = 768: K = T is cut into <= kEmbDenseSplit slices, one fp32 slab each (every slice is
+    // non-empty: nslab is recomputed from the 64-row K-tiles), then one pass sums the slabs into the accumulator
+    const int ktiles = (T + 63) / 64;
+    int split = ktiles / 4 < 1 ? 1 : (ktiles / 4 > kEmbDenseSplit ? kEmbDenseSplit : ktiles / 4);
+    const int per = (ktiles + split - 1) / split;
+    const int nslab = (ktiles + per - 1) / per;
+    float* slabs = static_cast<float*>(slab_ws);
+    if (int e = gget_gemm_single(GGET_GEMM_TN, GGET_EPI_SLAB_F32, cnt_ws, dx, slabs, nullptr, V, d, T, ldc, d, d, nullptr, nullptr,
+                                 split, st))
+      return e;
+    return k_slab_reduce(slabs, (long)V * d, nslab, demb, (size_t)V * d, st, /*f32_out=*/true);
+  }
+  return k_embed_bwd(ids, dx, emb, gate, demb, dgate, T, F, ldF, d, V, pad_id, sort_ws, st);
+}
+
 extern "C" int gget_backward_end(gget_handle_t h, void* stream) {
   GGET_REQUIRE(h && h->fwd_valid && h->dx_cur, "backward_end before backward_begin");
   hipStream_t st = (hipStream_t)stream;
   const gget_config_t& c = h->cfg;
   float* s32 = h->wsp<float>(h->ws.scratch32);
-  if (int e = k_embed_bwd(h->ids, h->dx_cur, h->P + h->plan.emb, h->plan.has_gate ? h->P + h->plan.gate : nullptr,
-                          s32 + h->plan.emb32, h->plan.has_gate ? s32 + h->plan.gate32 : nullptr, h->T, c.stacked_feat,
-                          c.stacked_feat, c.hidden_size, c.vocab_size, c.pad_token_id, h->wsp<int32_t>(h->ws.emb_sort), st))
+  if (int e = embed_bwd(h->ids, h->dx_cur, h->P + h->plan.emb, h->plan.has_gate ? h->P + h->plan.gate : nullptr,
+                        s32 + h->plan.emb32, h->plan.has_gate ? s32 + h->plan.gate32 : nullptr, h->T, c.stacked_feat,
+                        c.stacked_feat, c.hidden_size, c.vocab_size, c.pad_token_id, h->wsp<int32_t>(h->ws.emb_sort),
+                        k_embed_dense_ok(c.vocab_size, h->plan.has_gate) ? h->wsp<unsigned char>(h->ws.emb_cnt) : nullptr,
+                        k_embed_dense_ok(c.vocab_size, h->plan.has_gate) ? h->wsp<unsigned char>(h->ws.emb_slab) : nullptr, st))
     return e;
   h->dx_cur = nullptr;
   return convert_bucket(h, c.num_layers + 1, st);
@@ -989,9 +1018,14 @@ extern "C" int gget_op_embed_bwd(const int64_t* ids, const void* dx, const void*
                                  float* dgate_accum, int T, int F, int ldF, int d, int V, int pad_id, void* stream) {
   int32_t* ws = nullptr;
   GGET_HIP_CHECK(hipMalloc(&ws, k_embed_bwd_ws_elems((size_t)T * F, (size_t)V) * sizeof(int32_t)));  // test-only entry point
-  const int rc = k_embed_bwd(ids, dx, emb, gate, demb_accum, dgate_accum, T, F, ldF, d, V, pad_id, ws, (hipStream_t)stream);
+  void* cnt = nullptr;   // (GGET_EMBED_SORTED=1 forces the sorted scatter-add)
+  if (k_embed_dense_ok(V, gate != nullptr))
+    GGET_HIP_CHECK(hipMalloc(&cnt, (size_t)T * align_up((uint64_t)V, 64) * 2 + (size_t)kEmbDenseSplit * V * d * 4));
+  void* slab = cnt ? static_cast<unsigned char*>(cnt) + (size_t)T * align_up((uint64_t)V, 64) * 2 : nullptr;
+  const int rc = embed_bwd(ids, dx, emb, gate, demb_accum, dgate_accum, T, F, ldF, d, V, pad_id, ws, cnt, slab, (hipStream_t)stream);
   (void)hipStreamSynchronize((hipStream_t)stream);
   (void)hipFree(ws);
+  if (cnt) (void)hipFree(cnt);
   return rc;
 }
 extern "C" int gget_op_rope(void* qkv, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, int B, int S,

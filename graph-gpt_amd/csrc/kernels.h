@@ -23,6 +23,11 @@ int k_embed_fwd(const int64_t* ids, const void* emb, const void* gate, void* out
 int k_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* gate, float* demb, float* dgate, int T,
                 int F, int ldF, int d, int V, int pad_id, int32_t* sort_ws, hipStream_t st);
 inline size_t k_embed_bwd_ws_elems(size_t ncell, size_t V) { return 3 * V + 1 + 2 * ncell; }
+// count matrix of the dense embedding backward: cnt[t][v] = #{f: ids[t][f] == v, v != pad} as bf16, row pitch ldc; the
+// caller clears it first.  Used when k_embed_dense_ok(): dE = cnt^T dX is then one split-K GEMM (engine.hip: embed_bwd)
+int k_embed_count(const int64_t* ids, void* cnt, int T, int F, int ldF, int ldc, int pad_id, hipStream_t st);
+inline bool k_embed_dense_ok(int V, bool gated) { return !gated && ((V + 63) / 64) * 64 <= 1024; }
+constexpr int kEmbDenseSplit = 8;   // K slices (fp32 slabs of V*d each) of that GEMM
 int k_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, hipStream_t st);
 // dw_accum: fp32 [copies][copy_stride] accumulators (see GgetSegment); copies = 1 for a plain vector
 int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
@@ -52,7 +57,7 @@ int k_adamw(float* master, float* m, float* v, const void* grad, void* param, si
             float eps, float wd, int step, float max_norm, float grad_scale, const float* sqnorm, float* gnorm_out,
             hipStream_t st);
 int k_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st);
-int k_slab_reduce(const float* slabs, long slab_stride, int nslab, void* dst, size_t n, hipStream_t st);
+int k_slab_reduce(const float* slabs, long slab_stride, int nslab, void* dst, size_t n, hipStream_t st, bool f32_out = false);  // dst: bf16, or fp32 (overwritten)
 int k_convert_segments(const float* scratch, void* grads, const GgetSegment* segs_dev, int nseg, hipStream_t st);
 
 // attention.hip

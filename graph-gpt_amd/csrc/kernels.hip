@@ -169,25 +169,38 @@ __global__ void __launch_bounds__(128) embed_reduce_kernel(const int32_t* __rest
   for (int c = threadIdx.x; c * 8 < d; c += blockDim.x) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int cur = id_sorted[beg];
-    for (int j = beg; j < end; ++j) {
-      const int id = id_sorted[j];
-      if (id != cur) {
-        float* dst = demb + (size_t)cur * d + c * 8;
+    // the rows of one segment are independent loads: fetch them eight at a time before the (ordered) accumulation
+    for (int j0 = beg; j0 < end; j0 += 8) {
+      int idv[8], cellv[8];
+      uint4 raw[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { unsafeAtomicAdd(dst + e, acc[e]); acc[e] = 0.f; }
-        cur = id;
+      for (int u = 0; u < 8; ++u) {
+        const int j = min(j0 + u, end - 1);
+        idv[u] = id_sorted[j];
+        cellv[u] = cell_sorted[j];
       }
-      const int cell = cell_sorted[j];
-      float g[8];
-      unpack8(ldg16(dx + (size_t)(cell / F) * d + c * 8), g);
-      if (gate) {
-        float gv[8];
-        unpack8(ldg16(gate + (size_t)(cell % F) * d + c * 8), gv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += g[e] * gv[e];
-      } else {
+      for (int u = 0; u < 8; ++u) raw[u] = ldg16(dx + (size_t)(cellv[u] / F) * d + c * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += g[e];
+      for (int u = 0; u < 8; ++u) {
+        if (j0 + u >= end) break;
+        if (idv[u] != cur) {
+          float* dst = demb + (size_t)cur * d + c * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { unsafeAtomicAdd(dst + e, acc[e]); acc[e] = 0.f; }
+          cur = idv[u];
+        }
+        float g[8];
+        unpack8(raw[u], g);
+        if (gate) {
+          float gv[8];
+          unpack8(ldg16(gate + (size_t)(cellv[u] % F) * d + c * 8), gv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += g[e] * gv[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += g[e];
+        }
       }
     }
     float* dst = demb + (size_t)cur * d + c * 8;
@@ -195,6 +208,22 @@ __global__ void __launch_bounds__(128) embed_reduce_kernel(const int32_t* __rest
     for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dst + e, acc[e]);
   }
 }
+// Small vocabularies, plain (un-gated) stacking: the scatter-add is the dense product dE = C^T dX with the count matrix
+// C[t][v] = #{f : ids[t][f] == v} (pad id excluded) - small integers, exact in bf16.  One thread per cell writes the count of
+// its id inside its token (duplicates all write the same value, so no read-modify-write); the caller clears C.
+__global__ void __launch_bounds__(kBlock) embed_count_kernel(const int64_t* __restrict__ ids, bf16_t* __restrict__ cnt, int T,
+                                                             int F, int ldF, int ldc, int pad_id) {
+  const long cell = (long)blockIdx.x * kBlock + threadIdx.x;   // one thread per cell; the token's other ids come from L1
+  if (cell >= (long)T * F) return;
+  const int t = (int)(cell / F), f = (int)(cell - (long)t * F);
+  const int64_t* row = ids + (size_t)t * ldF;
+  const int id = (int)row[f];
+  if (id == pad_id) return;
+  int c = 0;
+  for (int g = 0; g < F; ++g) c += (int)row[g] == id ? 1 : 0;
+  cnt[(size_t)t * ldc + id] = f2bf((float)c);
+}
+
 // gated stacking only: dG[f,:] = sum_t dx[t,:] * W[ids[t,f],:]  (block-local accumulation, one atomic per block)
 constexpr int kEmbTok = 64;
 __global__ void __launch_bounds__(128) embed_dgate_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ dx,
@@ -588,6 +617,74 @@ __global__ void __launch_bounds__(kBlock) ce_fwd_bwd_kernel(const bf16_t* __rest
   }
 }
 
+// Rows of at most 64 * 8 * CH columns (ld % 8 == 0, rows 16-byte aligned): a lane keeps its CH 16-byte chunks of the row in
+// registers, so the logits are read once and the gradient is written with whole-line stores (the generic kernel above walks
+// the row three times with 2-byte accesses).  Same arithmetic per element.
+template <int CH>
+__global__ void __launch_bounds__(kBlock) ce_rows_kernel(const bf16_t* __restrict__ logits, int ld,
+                                                         const int32_t* __restrict__ labels,
+                                                         const int32_t* __restrict__ sel_tok,
+                                                         const float* __restrict__ sample_wgt, int S,
+                                                         const int32_t* __restrict__ n_rows_dev, int n_rows_cap, int V,
+                                                         float* __restrict__ loss_sum, bf16_t* __restrict__ dlogits,
+                                                         float scale_base, int mean_over_rows) {
+  __shared__ float part[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_rows = min(n_rows_cap, n_rows_dev ? *n_rows_dev : n_rows_cap);
+  const float scale = mean_over_rows ? (n_rows > 0 ? 1.0f / (float)n_rows : 0.f) : scale_base;
+  const int nch = ld >> 3;
+  float local = 0.f;
+  for (int row = blockIdx.x * (kBlock / 64) + wave; row < n_rows; row += gridDim.x * (kBlock / 64)) {
+    const bf16_t* lp = logits + (size_t)row * ld;
+    float x[CH][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+      const int ch = lane + 64 * t;
+      if (ch < nch) unpack8(ldg16(lp + ch * 8), x[t]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (ch >= nch || ch * 8 + e >= V) x[t][e] = -INFINITY;
+        mx = fmaxf(mx, x[t][e]);
+      }
+    }
+    const int y = labels[row];
+    const float xy = bf2f(lp[y]);
+    mx = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int t = 0; t < CH; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[t][e] = __expf(x[t][e] - mx); se += x[t][e]; }   // exp(-inf) = 0 on the pad columns
+    se = wave_sum(se);
+    const float w = sample_wgt ? sample_wgt[sel_tok[row] / S] : 1.0f;
+    if (lane == 0) local += w * (mx + __logf(se) - xy);
+    if (dlogits) {
+      bf16_t* dp = dlogits + (size_t)row * ld;
+      const float inv = 1.0f / se, ws = w * scale;
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        const int ch = lane + 64 * t;
+        if (ch >= nch) continue;
+        float gv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int j = ch * 8 + e;
+          gv[e] = j < V ? (x[t][e] * inv - (j == y ? 1.0f : 0.0f)) * ws : 0.f;
+        }
+        stg16(dp + ch * 8, pack8(gv));
+      }
+    }
+  }
+  if (lane == 0) part[wave] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < kBlock / 64; ++i) s += part[i];
+    if (s != 0.f) unsafeAtomicAdd(loss_sum, s);
+  }
+}
+
 __global__ void finalize_loss_kernel(const float* loss_sum, const int32_t* n_rows_dev, float scale_base,
                                      int mean_over_rows, float* loss_out) {
   const float sc = mean_over_rows ? (*n_rows_dev > 0 ? 1.0f / (float)(*n_rows_dev) : 0.f) : scale_base;
@@ -798,8 +895,9 @@ __global__ void __launch_bounds__(kBlock) f32_to_bf16_kernel(const float* __rest
 }
 
 // sum of `nslab` fp32 slabs (split-K partial products) -> bf16; rows beyond *rows_dev (if given) are left as they are
+template <bool F32_OUT>
 __global__ void __launch_bounds__(kBlock) slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int nslab,
-                                                             bf16_t* __restrict__ dst, size_t n) {
+                                                             void* __restrict__ dst_, size_t n) {
   const size_t nv = n >> 2;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (size_t)gridDim.x * kBlock) {
     float4 a = reinterpret_cast<const float4*>(slabs)[i];
@@ -807,10 +905,14 @@ __global__ void __launch_bounds__(kBlock) slab_reduce_kernel(const float* __rest
       const float4 b = reinterpret_cast<const float4*>(slabs + (size_t)s * slab_stride)[i];
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-    uint2 o;
-    o.x = pack2bf(a.x, a.y);
-    o.y = pack2bf(a.z, a.w);
-    *reinterpret_cast<uint2*>(dst + i * 4) = o;
+    if (F32_OUT) {
+      reinterpret_cast<float4*>(dst_)[i] = a;
+    } else {
+      uint2 o;
+      o.x = pack2bf(a.x, a.y);
+      o.y = pack2bf(a.z, a.w);
+      *reinterpret_cast<uint2*>(static_cast<bf16_t*>(dst_) + i * 4) = o;
+    }
   }
 }
 
@@ -1056,6 +1158,15 @@ int k_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void*
   return 0;
 }
 
+int k_embed_count(const int64_t* ids, void* cnt, int T, int F, int ldF, int ldc, int pad_id, hipStream_t st) {
+  if (T == 0) return 0;
+  GGET_REQUIRE(F <= 256, "embed_count: counts above 256 are not exact in bf16 (F=%d)", F);
+  hipLaunchKernelGGL(embed_count_kernel, dim3((int)(((long)T * F + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, ids, (bf16_t*)cnt, T, F, ldF,
+                     ldc, pad_id);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
 int k_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, hipStream_t st) {
   GGET_REQUIRE(d % 8 == 0 && d <= 64 * 8 * kMaxChunksPerLane, "rmsnorm: d=%d unsupported", d);
   if (T == 0) return 0;
@@ -1147,9 +1258,15 @@ int k_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const int32_
                  int mean_over_rows, float* loss_out, hipStream_t st) {
   GGET_HIP_CHECK(hipMemsetAsync(loss_sum, 0, sizeof(float), st));
   if (n_rows_cap > 0) {
-    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(grid_for(n_rows_cap, 4 * 8, 2048)), dim3(kBlock), 0, st,
-                       (const bf16_t*)logits, ld, labels, sel_tok, sample_wgt, S, n_rows_dev, n_rows_cap, V, loss_sum,
-                       (bf16_t*)dlogits, scale_base, mean_over_rows);
+    const bool vec = (ld % 8) == 0 && ((uintptr_t)logits & 15) == 0 && ((uintptr_t)dlogits & 15) == 0 && getenv("GGET_CE_GENERIC") == nullptr;
+#define GGET_CE_ARGS (const bf16_t*)logits, ld, labels, sel_tok, sample_wgt, S, n_rows_dev, n_rows_cap, V, loss_sum, \
+                     (bf16_t*)dlogits, scale_base, mean_over_rows
+    const dim3 grid(grid_for(n_rows_cap, 4 * 8, 2048));
+    if (vec && ld <= 512) hipLaunchKernelGGL(ce_rows_kernel<1>, grid, dim3(kBlock), 0, st, GGET_CE_ARGS);
+    else if (vec && ld <= 1024) hipLaunchKernelGGL(ce_rows_kernel<2>, grid, dim3(kBlock), 0, st, GGET_CE_ARGS);
+    else if (vec && ld <= 2048) hipLaunchKernelGGL(ce_rows_kernel<4>, grid, dim3(kBlock), 0, st, GGET_CE_ARGS);
+    else hipLaunchKernelGGL(ce_fwd_bwd_kernel, grid, dim3(kBlock), 0, st, GGET_CE_ARGS);
+#undef GGET_CE_ARGS
   }
   if (loss_out) hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(1), 0, st, loss_sum, n_rows_dev, scale_base,
                                    mean_over_rows, loss_out);
@@ -1208,9 +1325,13 @@ int k_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st) {
   return 0;
 }
 
-int k_slab_reduce(const float* slabs, long slab_stride, int nslab, void* dst, size_t n, hipStream_t st) {
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)(n / 4), kBlock, 2048)), dim3(kBlock), 0, st, slabs,
-                     slab_stride, nslab, (bf16_t*)dst, n);
+int k_slab_reduce(const float* slabs, long slab_stride, int nslab, void* dst, size_t n, hipStream_t st, bool f32_out) {
+  if (f32_out)
+    hipLaunchKernelGGL(slab_reduce_kernel<true>, dim3(grid_for((long)(n / 4), kBlock, 2048)), dim3(kBlock), 0, st, slabs,
+                       slab_stride, nslab, dst, n);
+  else
+    hipLaunchKernelGGL(slab_reduce_kernel<false>, dim3(grid_for((long)(n / 4), kBlock, 2048)), dim3(kBlock), 0, st, slabs,
+                       slab_stride, nslab, dst, n);
   GGET_LAUNCH_CHECK();
   return 0;
 }

@@ -184,6 +184,26 @@ def test_embed(lib, gated, V):
         assert rel_l2(dgate.cpu().numpy(), gf.grad.cpu().numpy()) < 1e-4
 
 
+def test_embed_bwd_dense_headline_shape(lib, monkeypatch):
+    """T = 8192, F = 13, V = 756, d = 768: the count-matrix GEMM form (split-K, fp32 atomics) against the sorted scatter-add
+    form (GGET_EMBED_SORTED is read per call by the op entry's helper only once, so the comparison is against torch)."""
+    T, F, d, V = 8192, 13, 768, 756
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(2, V, (T, F), generator=g)
+    ids[torch.rand(T, F, generator=g) < 0.5] = 1
+    ids[7000:] = 0
+    ids = ids.cuda()
+    dx = rnd(T, d, seed=3)
+    emb = rnd(V, d, seed=1)
+    demb = torch.zeros(V, d, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_embed_bwd(P(ids), P(dx), P(emb), None, P(demb), None, T, F, F, d, V, 0, ST()))
+    want = torch.zeros(V, d, dtype=torch.float64, device="cuda")
+    want.index_add_(0, ids.reshape(-1), dx.double().repeat_interleave(F, 0))
+    want[0] = 0
+    assert rel_l2(demb.cpu().numpy(), want.cpu().numpy()) < 1e-5
+    assert float(demb[0].abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------ RoPE + attention
 def _rope_ref(x, pos, theta=10000.0):
     # x [B,S,H,64] fp32, pos [B,S]
@@ -370,8 +390,10 @@ def test_geglu(lib):
     assert rel_l2(dgu.float().cpu().numpy(), gf.grad.cpu().numpy()) < 4e-3
 
 
-def test_cross_entropy(lib):
-    rows, V, ld = 500, 756, 768
+@pytest.mark.parametrize("V,ld", [(756, 768), (300, 320), (97, 128), (1500, 1536), (41245, 41280), (211, 212)])
+def test_cross_entropy(lib, V, ld):
+    """Row-in-registers kernels (ld <= 512 / 1024 / 2048) and the generic kernel (wide vocabulary, or ld % 8 != 0)."""
+    rows = 500
     logits = torch.zeros(rows, ld, dtype=torch.bfloat16, device="cuda")
     logits[:, :V] = rnd(rows, V, seed=1, scale=2.0)
     labels = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(2)).to(torch.int32).cuda()

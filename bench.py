@@ -204,6 +204,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(spec, state, F, V, 1234, min(os.cpu_count() or 1, 32))
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()   # rank 0 is still timing the dominant kernel: tear the communicator down together
         dist.destroy_process_group()
 
 

@@ -122,9 +122,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    # GGET_BENCH_BACKEND=gloo: plumbing check of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices;
+    # RCCL refuses that).  The driver's runs use the default: one rank per GPU over RCCL.
+    backend = os.environ.get("GGET_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, init_method="env://")
 
     spec_mod = importlib.import_module("graph-gpt_amd.spec")
     weights = importlib.import_module("graph-gpt_amd.weights")

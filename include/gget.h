@@ -96,7 +96,11 @@ const char* gget_last_error(void);
 int gget_version(void);
 
 /* replaces: GraphGPTPretrainBase.__init__/GraphGPTTaskModel.__init__ (modeling_pretrain.py:58-117,
- * modeling_finetune.py:67-105): computes the flat parameter layout and workspace need. */
+ * modeling_finetune.py:67-105): computes the flat parameter layout and workspace need.
+ * The flat arrays hold the named parameters (gget_param_info) at 128-element aligned offsets; the gaps, and for the
+ * pre-train model round_up(V,64)-V zero rows behind lm_head.weight (its dgrad GEMM runs over K = round_up(V,64)), belong to
+ * no parameter: the caller provides all arenas ZERO-FILLED (gradients and AdamW state of the gaps then stay zero).
+ * gget_create additionally clears the workspace and the lm_head pad rows of every arena it is given (synchronously). */
 int gget_query_sizes(const gget_config_t* cfg, gget_sizes_t* out);
 int gget_create(const gget_config_t* cfg, const gget_buffers_t* bufs, gget_handle_t* out);
 int gget_destroy(gget_handle_t h);

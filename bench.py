@@ -201,7 +201,7 @@ def main():
             "tokens_per_s_per_gpu": tot_real * a.steps / dt / world,
             "step_mfma": {"flops_per_step": fstep, "achieved_tflops_per_gpu": step_tflops,
                           "frac_of_peak": step_tflops / PEAK_BF16_TFLOPS},
-            "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<256,256,32,NT> FFN gate|up [T,d]x[d,2ff] (26% of step FLOPs)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<256,256,64,NT> FFN gate|up [T,d]x[d,2ff] (26% of step FLOPs)",
                          "achieved": k_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": k_tflops / PEAK_BF16_TFLOPS, "traffic": pmc_traffic() if B * S == 8192 and spec.hidden_size == 768 else None,
                          "avg_launch_ms": k_ms},

@@ -719,19 +719,20 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
 }
 
 // launch one persistent configuration: one block per CU (grid rounded to the 8 XCDs)
-template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI>
+template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0>
 int launch_persist_cfg(GemmGroup& g, int total, int num_cu, hipStream_t st) {
   constexpr int STG = (BM + BN) * BK * 2;
-  constexpr int SM = persist_slots(STG) * STG;
+  constexpr int SM = (NSLOT_ > 0 ? NSLOT_ : persist_slots(STG)) * STG;
+  static_assert(SM <= 160 * 1024, "LDS ring");
   int G = total < num_cu ? total : num_cu;
   G = (G + 7) & ~7;  // the XCD permutation needs a multiple of 8 (idle blocks exit at once)
   static bool attr0 = false;
   if (!attr0) {
-    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BM, BN, BK, WM, WN, A_MC, B_MC, EPI>),
+    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BM, BN, BK, WM, WN, A_MC, B_MC, EPI, NSLOT_>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SM));
     attr0 = true;
   }
-  hipLaunchKernelGGL((gemm_persist_kernel<BM, BN, BK, WM, WN, A_MC, B_MC, EPI>), dim3(G), dim3(WM * WN * 64), SM, st, g, total);
+  hipLaunchKernelGGL((gemm_persist_kernel<BM, BN, BK, WM, WN, A_MC, B_MC, EPI, NSLOT_>), dim3(G), dim3(WM * WN * 64), SM, st, g, total);
   GGET_LAUNCH_CHECK();
   return 0;
 }
@@ -780,6 +781,12 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
           p.tiles_n = (p.N + 255) / 256;
           p.tile_begin = tot2;
           tot2 += ((p.M + 255) / 256) * p.tiles_n;
+        }
+        // row-major B (NT): 64-deep K-tiles through a 2-slot ring (2 x 64 KiB) - half as many barriers / waits / DMA
+        // bookkeeping rounds per FLOP as 32-deep tiles through 4 slots (gate|up 91 -> 86 us); the NN form would spill
+        if constexpr (!B_MC) {
+          static const int bk64 = getenv("GGET_GEMM_BK64") ? atoi(getenv("GGET_GEMM_BK64")) : 1;
+          if (bk64) return launch_persist_cfg<256, 256, 64, 2, 4, A_MC, B_MC, EPI, 2>(g, tot2, num_cu, st);
         }
         return launch_persist_cfg<256, 256, 32, 2, 4, A_MC, B_MC, EPI>(g, tot2, num_cu, st);
       }

@@ -8,6 +8,7 @@ L = importlib.import_module("graph-gpt_amd._lib")
 lib = L.load()
 P = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+ITERS = int(os.environ.get("GEMM_ITERS", "30"))
 M, N, K = [int(x) for x in sys.argv[1:4]] if len(sys.argv) >= 4 else (8192, 6144, 768)
 g = torch.Generator(device="cuda").manual_seed(0)
 A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
@@ -20,8 +21,8 @@ err = float((Cm.float() - ref).norm() / ref.norm())
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for _ in range(5): L.check(lib.gget_op_gemm(*args))
 e0.record()
-for _ in range(30): L.check(lib.gget_op_gemm(*args))
+for _ in range(ITERS): L.check(lib.gget_op_gemm(*args))
 e1.record(); torch.cuda.synchronize()
-us = e0.elapsed_time(e1) / 30 * 1e3
+us = e0.elapsed_time(e1) / ITERS * 1e3
 print(f"M={M} N={N} K={K} rel_err={err:.2e} {us:.1f} us {2.0*M*N*K/us/1e6:.1f} TFLOP/s")
-assert err < 5e-3
+assert err < 5e-3 or os.environ.get("GGET_GEMM_ABLATE")

@@ -72,6 +72,17 @@ __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, const 
       : "v"(voff), "s"(sb), "s"(dst)
       : "memory");
 }
+// same with the LDS destination already a wave-uniform byte offset: {s_mov m0, global_load_lds} and nothing else per piece
+// (M0 is not restored: nothing else in these kernels reads it, and the clobber tells the compiler so)
+__device__ __forceinline__ void glds16m(const unsigned char* sbase, unsigned voff, unsigned lds_off) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff), "s"(sbase), "s"(lds_off)
+      : "memory", "m0");
+}
 template <int N>
 __device__ __forceinline__ void vm_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -601,14 +612,22 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
   int islot = 0, cslot = 0, inflight = 0;
   // issue side: operand bases / leading dims of the tile being streamed and the per-lane DMA offsets, refreshed only
   // when the stream moves on to the next output tile (a K-tile's DMA is then PIECES x {M0, global_load_lds})
-  const bf16_t* iA = nullptr;
-  const bf16_t* iB = nullptr;
-  int ilda = 0, ildb = 0;
+  // Everything a piece needs is wave-uniform scalar state kept across K-tiles: the K-origin pointers of the two operands
+  // (advanced by a constant byte stride per K-tile) and the LDS byte offset of this wave's first piece in the current slot;
+  // a piece is then one s_add (constant piece offset), s_mov m0 and the global_load_lds.
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(LDS_AS const void*)smem) + (unsigned)wave * 1024u;
+  const unsigned char* kA = nullptr;
+  const unsigned char* kB = nullptr;
+  long strideA = 0, strideB = 0;
+  unsigned islot_off = lds0;
   unsigned offA[TA::PIECES], offB[TB::PIECES];
   auto load_issue_tile = [&]() {
     if (!ivalid) return;
     const GemmProblem& P = g.p[ic.pi];
-    iA = P.A; iB = P.B; ilda = P.lda; ildb = P.ldb;
+    kA = reinterpret_cast<const unsigned char*>(P.A);
+    kB = reinterpret_cast<const unsigned char*>(P.B);
+    strideA = A_MC ? (long)BK * P.lda * 2 : (long)BK * 2;
+    strideB = B_MC ? (long)BK * P.ldb * 2 : (long)BK * 2;
 #pragma unroll
     for (int i = 0; i < TA::PIECES; ++i) offA[i] = TA::piece_off(P.lda, ic.m0, ic.M, wave, lane, i);
 #pragma unroll
@@ -616,13 +635,15 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
   };
   load_issue_tile();
   auto issue_piece = [&](int q) {       // piece q of the K-tile (ic, ik) into slot islot
-    unsigned char* sl = smem + islot * STAGE;
-    if (q < TA::PIECES) TA::glds_at(sl, TA::k_origin(iA, ilda, ik * BK), offA[q < TA::PIECES ? q : 0], wave, q);
-    else TB::glds_at(sl + A_BYTES, TB::k_origin(iB, ildb, ik * BK), offB[q >= TA::PIECES ? q - TA::PIECES : 0], wave, q - TA::PIECES);
+    if (q < TA::PIECES) glds16m(kA, offA[q < TA::PIECES ? q : 0], islot_off + (unsigned)(q * TA::NWAVES * 1024));
+    else glds16m(kB, offB[q >= TA::PIECES ? q - TA::PIECES : 0], islot_off + (unsigned)(A_BYTES + (q - TA::PIECES) * TB::NWAVES * 1024));
   };
   auto issue_advance = [&]() {
     islot = islot == NSLOT - 1 ? 0 : islot + 1;
+    islot_off = islot == 0 ? lds0 : islot_off + (unsigned)STAGE;
     ++inflight;
+    kA += strideA;
+    kB += strideB;
     if (++ik == ic.nk) { ik = 0; ++ir; ivalid = tile_at(ir, ic); load_issue_tile(); }
   };
   auto issue_next = [&]() {
@@ -635,10 +656,9 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
   for (int i = 0; i < NSLOT - 1; ++i) issue_next();
   // wait until this wave's pieces of the OLDEST K-tile in flight have landed: the (inflight - 1) younger K-tiles may
   // stay outstanding (stores in flight only make the count conservative, see above)
+  // (steady state: NSLOT - 1 K-tiles in flight; in the tail of the stream everything is waited for)
   auto wait_oldest = [&]() {
-    if (NSLOT > 3 && inflight >= 4) vm_wait<3 * PIECES>();
-    else if (inflight == 3) vm_wait<2 * PIECES>();
-    else if (inflight == 2) vm_wait<PIECES>();
+    if (inflight == NSLOT - 1) vm_wait<(NSLOT - 2) * PIECES>();
     else vm_wait<0>();
   };
   auto finish_tile = [&]() {

@@ -201,7 +201,7 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.dscaled2 = pl.has_res ? b.take(T * d * 2) : 0;
   w.scratch32 = b.take(pl.n_scratch32 * 4);
   w.loss_sum = b.take(256);
-  w.sqnorm = b.take(k_grad_sqnorm_ws_bytes());   // zero at creation (gget_create clears the workspace); the kernel re-arms it
+  w.sqnorm = b.take(k_grad_sqnorm_ws_bytes());
   w.counts = b.take(256);
   w.segs = b.take((uint64_t)pl.params.size() * sizeof(GgetSegment));
   w.wg32 = b.take(kWgSplit * 4 * d * d * 4);   // split-K slabs of the q|k|v|o wgrad

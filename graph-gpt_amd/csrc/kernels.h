@@ -52,7 +52,7 @@ int k_task_loss(const float* logits, const void* labels, const float* sample_wgt
                 float* loss_out, float* dlogits, hipStream_t st);
 int k_score_bwd(const float* dlogits, const void* hidden, const int32_t* pool_row, const void* w, float* dw, float* dbias,
                 void* dhidden, int B, int C, int d, hipStream_t st);
-// ws: k_grad_sqnorm_ws_bytes() of zero-initialised scratch; ws[0] receives sum(g^2) (deterministic reduction order)
+// ws: k_grad_sqnorm_ws_bytes() of scratch; ws[0] receives sum(g^2) (deterministic reduction order, two launches)
 int k_grad_sqnorm(const void* g, size_t n, float* ws, hipStream_t st);
 inline size_t k_grad_sqnorm_ws_bytes() { return (16 + 1024) * sizeof(float); }
 int k_adamw(float* master, float* m, float* v, const void* grad, void* param, size_t n, float lr, float beta1, float beta2,

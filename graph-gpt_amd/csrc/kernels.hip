@@ -824,14 +824,13 @@ __global__ void __launch_bounds__(kBlock) score_bwd_kernel(const float* __restri
 // reference: torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW (training_utils.py:68-80,
 // opt_utils.py:18-24) == DeepSpeed FusedAdam adam_w_mode (examples/ds_config2_pt.json:11-19).
 // ---------------------------------------------------------------------------------------------
-// Deterministic: every block stores its partial sum, the block that finishes last adds them in a fixed order - data-parallel
+// Deterministic: every block stores its partial sum and a one-block pass adds the partials in a fixed order - data-parallel
 // replicas must derive bit-identical clip factors from identical gradients (an atomic accumulation gives last-bit
-// differences between ranks and the replicas would drift apart).  ws: [0] result, [1] arrival counter (zero between
-// launches), [16 .. 16 + gridDim.x) partials.
+// differences between ranks and the replicas would drift apart; a last-block-done counter costs 1024 contended returning
+// atomics, ~35 us).  ws: [0] result, [16 .. 16 + blocks) partials.
 constexpr int kSqnormBlocks = 1024;
 __global__ void __launch_bounds__(kBlock) grad_sqnorm_kernel(const bf16_t* __restrict__ g, size_t n, float* __restrict__ ws) {
-  __shared__ float part[kBlock];
-  __shared__ int last_s;
+  __shared__ float part[kBlock / 64];
   float s = 0.f;
   const size_t nv = n >> 3;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (size_t)gridDim.x * kBlock) {
@@ -846,28 +845,20 @@ __global__ void __launch_bounds__(kBlock) grad_sqnorm_kernel(const bf16_t* __res
   if (threadIdx.x == 0) {
     float t = 0.f;
     for (int i = 0; i < kBlock / 64; ++i) t += part[i];
-    volatile float* partials = ws + 16;
-    partials[blockIdx.x] = t;
-    __threadfence();
-    const unsigned done = atomicAdd(reinterpret_cast<unsigned*>(ws + 1), 1u);
-    last_s = done == gridDim.x - 1;
+    ws[16 + blockIdx.x] = t;
   }
-  __syncthreads();
-  if (!last_s) return;
-  __threadfence();
-  const volatile float* partials = ws + 16;
+}
+__global__ void __launch_bounds__(kBlock) grad_sqnorm_final_kernel(float* __restrict__ ws, int nblocks) {
+  __shared__ float part[kBlock];
   float t = 0.f;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock) t += partials[i];
+  for (int i = threadIdx.x; i < nblocks; i += kBlock) t += ws[16 + i];
   part[threadIdx.x] = t;
   __syncthreads();
   for (int o = kBlock / 2; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    ws[0] = part[0];
-    *reinterpret_cast<unsigned*>(ws + 1) = 0u;
-  }
+  if (threadIdx.x == 0) ws[0] = part[0];
 }
 
 __global__ void __launch_bounds__(kBlock) adamw_kernel(float* __restrict__ master, float* __restrict__ m_, float* __restrict__ v_,
@@ -1325,8 +1316,9 @@ int k_score_bwd(const float* dlogits, const void* hidden, const int32_t* pool_ro
 }
 
 int k_grad_sqnorm(const void* g, size_t n, float* ws, hipStream_t st) {
-  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(grid_for((long)(n / 8), kBlock, kSqnormBlocks)), dim3(kBlock), 0, st,
-                     (const bf16_t*)g, n, ws);
+  const int blocks = grid_for((long)(n / 8), kBlock, kSqnormBlocks);
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(blocks), dim3(kBlock), 0, st, (const bf16_t*)g, n, ws);
+  hipLaunchKernelGGL(grad_sqnorm_final_kernel, dim3(1), dim3(kBlock), 0, st, ws, blocks);
   GGET_LAUNCH_CHECK();
   return 0;
 }

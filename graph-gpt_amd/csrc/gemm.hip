@@ -72,8 +72,10 @@ __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, const 
       : "v"(voff), "s"(sb), "s"(dst)
       : "memory");
 }
-// same with the LDS destination already a wave-uniform byte offset: {s_mov m0, global_load_lds} and nothing else per piece
-// (M0 is not restored: nothing else in these kernels reads it, and the clobber tells the compiler so)
+// same with the LDS destination already a wave-uniform byte offset: {s_mov m0, global_load_lds} and nothing else per piece.
+// M0 is NOT restored.  It is a reserved register the compiler does not track through inline asm (a clobber entry is
+// ignored with a warning), so this is only valid in kernels whose compiler-generated code never uses M0 - true for the
+// persistent GEMM (no LDS-direct / movrel / GWS / sendmsg; checked in the ISA: every M0 access there is one of these moves).
 __device__ __forceinline__ void glds16m(const unsigned char* sbase, unsigned voff, unsigned lds_off) {
   asm volatile(
       "s_mov_b32 m0, %2\n\t"
@@ -81,7 +83,7 @@ __device__ __forceinline__ void glds16m(const unsigned char* sbase, unsigned vof
       "global_load_lds_dwordx4 %0, %1"
       :
       : "v"(voff), "s"(sbase), "s"(lds_off)
-      : "memory", "m0");
+      : "memory");
 }
 template <int N>
 __device__ __forceinline__ void vm_wait() {

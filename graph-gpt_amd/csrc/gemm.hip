@@ -678,63 +678,40 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
   while (cvalid) {
     wait_oldest();
     __syncthreads();   // publishes that tile; also every wave is done with the slot consumed last iteration
-    // ... which is the slot refilled here.  Measured alternatives that were slower: spreading the DMA pieces between
-    // the MFMA groups (-5..20 %), and a ping-pong schedule with the two waves of a SIMD half a K-tile apart (two
-    // barriers per K-tile; in-kernel s_memtime stamps showed MFMA issue stretching to ~24 cycles beside the partner's
-    // DMA / ds_read traffic): -5..15 % except on the 256x256 tile (+2 %).
-    // The DMA pieces of K-tile t+NSLOT-1 go between the MFMA groups of this K-tile (each piece is a handful of SALU
-    // instructions plus one global_load_lds now), so their issue overlaps the matrix pipe: +5..20 % on NT / NN.  The
-    // TN kernel (both operands through transposing reads) measured 10 % slower that way and issues them up front.
-    constexpr bool ILEAVE = !(A_MC && B_MC);
-    if constexpr (ILEAVE) {
-      const bool did = ivalid;
-      --inflight;
-      {
-        const unsigned char* a_l = smem + cslot * STAGE;
-        const unsigned char* b_l = a_l + A_BYTES;
-        constexpr int KK = BK / 32, NG = KK * MI;
-        bf16x8_t af[KK][MI], bf[KK][NJ];
-  #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-  #pragma unroll
-          for (int i = 0; i < MI; ++i) af[kk][i] = TA::frag(a_l, wm * MI + i, kk, lane);
-  #pragma unroll
-          for (int j = 0; j < NJ; ++j) bf[kk][j] = TB::frag(b_l, ILV ? (j >> 1) * 4 + (j & 1) * 2 + wn : wn * NJ + j, kk, lane);
-        }
-  #pragma unroll
-        for (int kk = 0; kk < KK; ++kk)
-  #pragma unroll
-          for (int i = 0; i < MI; ++i) {
-  #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
-            const int grp = kk * MI + i;
-            if (did) {
-  #pragma unroll
-              for (int q = grp * PIECES / NG; q < (grp + 1) * PIECES / NG; ++q) issue_piece(q);
-            }
-          }
-      }
-      if (did) issue_advance();
-    } else {
-      issue_next();
-      --inflight;
+    // ... which is the slot refilled here.  The DMA pieces of K-tile t+NSLOT-1 go between the MFMA groups of this K-tile
+    // (a piece is {s_add, s_mov m0, global_load_lds}), so their issue overlaps the matrix pipe: +5..20 % on NT / NN when
+    // introduced; on the TN kernel it only paid (-1 % of the step) once the pieces had become that cheap.  Measured slower
+    // (profiles/r01_gemm_kloop_stamps.txt): a ping-pong schedule with the two waves of a SIMD half a K-tile apart, the
+    // barrier in the middle of the MFMA stream, two K-tiles per barrier with a shorter prefetch distance.
+    const bool did = ivalid;
+    --inflight;
+    {
       const unsigned char* a_l = smem + cslot * STAGE;
       const unsigned char* b_l = a_l + A_BYTES;
+      constexpr int KK = BK / 32, NG = KK * MI;
+      bf16x8_t af[KK][MI], bf[KK][NJ];
 #pragma unroll
-      for (int kk = 0; kk < BK / 32; ++kk) {
-        bf16x8_t af[MI], bf[NJ];
+      for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = TA::frag(a_l, wm * MI + i, kk, lane);
+        for (int i = 0; i < MI; ++i) af[kk][i] = TA::frag(a_l, wm * MI + i, kk, lane);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bf[j] = TB::frag(b_l, wn * NJ + j, kk, lane);
+        for (int j = 0; j < NJ; ++j) bf[kk][j] = TB::frag(b_l, ILV ? (j >> 1) * 4 + (j & 1) * 2 + wn : wn * NJ + j, kk, lane);
+      }
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-      }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+          const int grp = kk * MI + i;
+          if (did) {
+#pragma unroll
+            for (int q = grp * PIECES / NG; q < (grp + 1) * PIECES / NG; ++q) issue_piece(q);
+          }
+        }
     }
+    if (did) issue_advance();
     cslot = cslot == NSLOT - 1 ? 0 : cslot + 1;
     if (++ck == cc.nk) finish_tile();
   }

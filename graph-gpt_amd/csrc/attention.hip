@@ -646,9 +646,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
 }
 
 // S <= 32: one wave holds the whole (batch, head) problem, so the backward is ONE launch: the K, Q and dO tiles go to
-// LDS once (V stays in registers), delta = rowsum(dO * O) is computed in place, then the dQ part (scores transposed, lane = query) and the dK/dV
-// part (lane = key) run back to back on the same tiles.  Same arithmetic as attn_bwd_dq_kernel + attn_bwd_dkv_kernel.
-__global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+// LDS once (V stays in registers), then the dQ part (scores transposed, lane = query; it also yields the softmax-backward row
+// term delta) and the dK/dV part (lane = key) run back to back on the same tiles.  Same arithmetic as attn_bwd_dq_kernel +
+// attn_bwd_dkv_kernel except that delta comes from P and dP in registers instead of rowsum(dO * O).
+__global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __restrict__ qkv,
                                                                const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
                                                                int B, int S, int H, int causal, Rope Rin, Rope R, Drop D) {
@@ -664,7 +665,6 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
   const bf16_t* kb = qb + d;
   const bf16_t* vb = qb + 2 * d;
   const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
-  const bf16_t* ob = out + (size_t)b * S * d + h * 64;
   const int klen = key_len ? key_len[b] : S;
   const Rope Rnone{nullptr, nullptr, nullptr, S};
   load_tile_coop<64>(kt, kb, 0, S, pitch, lane, Rin, b);
@@ -675,20 +675,8 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
   for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, l31, S, pitch, s, lane);
   load_tile_coop<64>(qt, qb, 0, S, pitch, lane, Rin, b);
   load_tile_coop<64>(dot_, dob, 0, S, (size_t)d, lane, Rnone, b);
-  float dl = 0.f;
-  if (l31 < S) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float a[8], gg[8];
-      unpack8(*reinterpret_cast<const uint4*>(ob + (size_t)l31 * d + 32 * hi + 8 * c), a);
-      unpack8(*reinterpret_cast<const uint4*>(dob + (size_t)l31 * d + 32 * hi + 8 * c), gg);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dl += a[e] * gg[e];
-    }
-  }
-  dl += __shfl_xor(dl, 32, 64);
   const float nlse2 = -lse[((size_t)b * H + h) * S + min(l31, S - 1)] * kLog2e;
-  if (hi == 0) { lse_s[l31] = nlse2; dl_s[l31] = -dl; }
+  if (hi == 0) lse_s[l31] = nlse2;
   __syncthreads();
   const unsigned bh = b * H + h;
   {   // ---------------- dQ^T[dh][q] = K^T dS^T   (lane owns query l31)
@@ -700,13 +688,24 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s], frag_rows(dot_, s, lane), dp, 0, 0, 0);
       sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), frag_rows(qt, s, lane), sc, 0, 0, 0);
     }
+    // the whole key range of a query sits in this lane and its partner (lane ^ 32), so the softmax-backward row term
+    // delta = sum_k P~[q,k] dP[q,k] (P~ = dropped P; equal to rowsum(dO * O), which the long-sequence kernels read from the
+    // saved output) comes straight from the registers: no read of O
+    float dl = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = acc_row(r, hi);
       const bool ok = key < klen && (!causal || key <= qrow) && qrow < S;
       const float p = ok ? exp2f(fmaf(sc[r], kScaleL2, nlse2)) : 0.f;
-      sc[r] = p * fmaf(dp[r], drop_mul_x(D, dbase + (unsigned)key * 0xC2B2AE3Du), -dl) * kScale;
+      const float t = dp[r] * drop_mul_x(D, dbase + (unsigned)key * 0xC2B2AE3Du);
+      dl = fmaf(p, t, dl);
+      sc[r] = p;
+      dp[r] = t;
     }
+    dl += __shfl_xor(dl, 32, 64);
+    if (hi == 0) dl_s[l31] = -dl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = sc[r] * (dp[r] - dl) * kScale;
     const bf16x8_t ds0 = acc_to_b(sc, 0), ds1 = acc_to_b(sc, 1);
     f32x16_t a0 = zero16(), a1 = zero16();
     a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 0, lane), ds0, a0, 0, 0, 0);
@@ -718,6 +717,7 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
       store_t(dqkv + ((size_t)b * S + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
     }
   }
+  __syncthreads();   // dl_s (written above) is read per query below
   {   // ---------------- dV^T = dO^T P, dK^T = Q^T dS   (lane owns key l31)
     const int krow = l31;
     const bool key_ok = krow < klen;
@@ -800,7 +800,7 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
   static int small = -1;
   if (small < 0) { const char* e = getenv("GGET_ATTN_SMALL"); small = e ? atoi(e) : 1; }
   if (S <= 32 && !key_lo && small) {
-    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(1, H, B), dim3(64), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
+    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(1, H, B), dim3(64), 0, st, (const bf16_t*)qkv,
                        (const bf16_t*)dout, lse, key_len, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);
     GGET_LAUNCH_CHECK();
     return 0;

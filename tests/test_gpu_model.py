@@ -569,3 +569,28 @@ def test_c1_full_size_properties():
     e.backward()
     assert abs(float(loss3) - loss0) <= 2e-6 * abs(loss0)   # the loss sum itself is an fp32-atomic reduction over blocks
     assert float((e.grad_bf16.float() - g0).norm() / g0.norm()) < 1e-3
+
+
+def test_c4_long_sequence_full_model_matches_oracle():
+    """The longest configuration of BASELINE.json (C4: base model, S = 2048, F = 4, V = 41245) at a batch the CPU oracle
+    finishes in seconds (B = 2): fine-tune loss and logits of the full 12-layer HIP forward (4-wave attention kernels over 64
+    key tiles, wide-vocabulary embedding path, position_ids up to 2047) against the oracle."""
+    from _util import spec_mod, weights_mod, synth
+    B, S, F, V = 2, 2048, 4, 41245
+    spec = spec_mod.spec_from_size("base", kind=spec_mod.KIND_TASK, vocab_size=V, stacked_feat=F, next_n_token=1, num_labels=2,
+                                   max_position=2048)
+    state = weights_mod.make_state_dict(spec, seed=8)
+    batch = synth.make_task_batch(B=B, S=S, F=F, V=V, seed=91, lengths="uniform", min_len=S // 2)
+    b = tb(batch)
+    e = make_engine(spec, batch)
+    e.load_state_dict(state)
+    loss, logits = run_forward(e, spec, b, "ft")
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32, requires_grad=False)
+    fn, lk, gk = oracle_fn(spec, b, "ft")
+    with torch.no_grad():
+        out = fn(p)
+    want = out[gk].float().numpy()
+    got = logits.float().cpu().numpy()
+    assert np.abs(got - want).max() <= 3e-2 * max(1.0, np.abs(want).max()), (got, want)
+    assert abs(float(loss) - out[lk].item()) <= 3e-2 * max(abs(out[lk].item()), 0.1)

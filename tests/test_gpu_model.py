@@ -594,3 +594,33 @@ def test_c4_long_sequence_full_model_matches_oracle():
     got = logits.float().cpu().numpy()
     assert np.abs(got - want).max() <= 3e-2 * max(1.0, np.abs(want).max()), (got, want)
     assert abs(float(loss) - out[lk].item()) <= 3e-2 * max(abs(out[lk].item()), 0.1)
+
+
+def test_c3_shape_full_model_backward_matches_oracle():
+    """C3 of BASELINE.json (ogbl-ppa-like fine-tune: base model with LayerScale, S = 256, F = 4, V = 41245) at B = 8: loss and
+    gradients of the full 12-layer HIP forward + backward (4-wave attention, LayerScale residual kernels, sorted embedding
+    backward for the wide vocabulary, pooled-row score head) against the oracle."""
+    from _util import spec_mod, weights_mod, synth
+    B, S, F, V = 8, 256, 4, 41245
+    spec = spec_mod.spec_from_size("base", kind=spec_mod.KIND_TASK, vocab_size=V, stacked_feat=F, next_n_token=1, num_labels=2,
+                                   max_position=1024, layer_scale_init=1.0)
+    state = weights_mod.make_state_dict(spec, seed=9)
+    batch = synth.make_task_batch(B=B, S=S, F=F, V=V, seed=92, lengths="uniform", min_len=S // 4)
+    b = tb(batch)
+    e = make_engine(spec, batch)
+    e.load_state_dict(state)
+    loss, _ = run_forward(e, spec, b, "ft")
+    e.backward()
+    torch.cuda.synchronize()
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32)
+    fn, lk, _ = oracle_fn(spec, b, "ft")
+    out, grads = O.loss_and_grads(fn, p, lk)
+    assert abs(float(loss) - out[lk].item()) <= 3e-2 * max(abs(out[lk].item()), 0.1)
+    got = e.grads()
+    gmax = max(float(g.norm()) for g in grads.values())
+    for k in ("score.weight", "model.layers.11.mlp.down_proj.weight", "model.layers.6.self_attn.q_proj.weight",
+              "model.layers.0.lambda_1", "model.layers.0.input_layernorm.weight", "model.embed_tokens.weight"):
+        w = grads[k].numpy()
+        err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        assert err < 8e-2, f"{k}: {err}"

@@ -507,10 +507,10 @@ def test_evaluate_pass_matches_oracle_losses():
     assert abs(float(loss) - want) <= 2e-3 * abs(want)
 
 
-def _c1_engine_and_batch(seed=77):
+def _c1_engine_and_batch(seed=77, size="base"):
     from _util import spec_mod, weights_mod, synth
     B, S, F, V = 256, 32, 13, 756
-    spec = spec_mod.spec_from_size("base", kind=spec_mod.KIND_PRETRAIN, vocab_size=V, stacked_feat=F, next_n_token=F)
+    spec = spec_mod.spec_from_size(size, kind=spec_mod.KIND_PRETRAIN, vocab_size=V, stacked_feat=F, next_n_token=F)
     state = weights_mod.make_state_dict(spec, seed=3)
     batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=seed)
     e = eng_mod.Engine(spec, max_tokens=B * S, max_batch=B)
@@ -518,11 +518,12 @@ def _c1_engine_and_batch(seed=77):
     return spec, state, batch, e
 
 
-def test_c1_full_size_loss_matches_oracle():
-    """BASELINE configs[1] at full size (base d768/L12, B=256, S=32, F=13, V=756): SMTP loss of the HIP forward against the
+@pytest.mark.parametrize("size", ["base", "base24"])
+def test_c1_full_size_loss_matches_oracle(size):
+    """BASELINE configs[1] (base d768/L12) and configs[2] (base24, 24 layers) at full size (B=256, S=32, F=13, V=756): SMTP loss of the HIP forward against the
     oracle forward on the same bf16-rounded weights (tolerance: north_star's 1e-4 relative is for same-cast-point fp32
     arithmetic; the 12-layer bf16 path is held to 3e-4, the reference's own bf16-vs-fp32 gap on the fixtures is 1.3e-4)."""
-    spec, state, batch, e = _c1_engine_and_batch()
+    spec, state, batch, e = _c1_engine_and_batch(size=size)
     b = tb(batch)
     loss, _ = run_forward(e, spec, b, "pt")
     st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}

@@ -96,6 +96,9 @@ class GgetEngine:
         self._comm_stream = None
         self._pending = []
         self.force_staged = bool(int(os.environ.get("GGET_FORCE_STAGED", "0")))  # run the bucketed path at world 1
+        # GGET_DP_OVERLAP=0: one all-reduce of the whole flat gradient array after the monolithic backward instead of the
+        # bucketed exchange overlapped with it (to be decided by measurement on a multi-GPU node)
+        self.overlap = bool(int(os.environ.get("GGET_DP_OVERLAP", "1")))
         model.materialize_grads = False  # fused path: gradients stay in the flat bf16 arena
 
     @property
@@ -117,6 +120,11 @@ class GgetEngine:
         e = self.module._engine
         if self.world == 1 and not self.force_staged:
             e.backward()
+            return
+        if not self.overlap:
+            e.backward()
+            if self.world > 1:
+                dist.all_reduce(e.grad_bf16, op=dist.ReduceOp.SUM, group=self.pg)
             return
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=e.device)

@@ -34,7 +34,8 @@ def _batch(synth, rank):
     return {k: torch.from_numpy(v).cuda() for k, v in b.items() if k != "lengths"}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, overlap="1"):
+    os.environ["GGET_DP_OVERLAP"] = overlap
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method="env://")
@@ -55,14 +56,16 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_matches_manual_gradient_average():
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_two_rank_step_matches_manual_gradient_average(overlap):
+    """overlap=1: bucketed all-reduce on a side stream behind the staged backward; overlap=0: one all-reduce after it."""
     modeling = importlib.import_module("graph-gpt_amd.modeling")
     tr = importlib.import_module("graph-gpt_amd.training")
     synth = importlib.import_module("graph-gpt_amd.synth")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in ps:
         p.start()
     res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])

@@ -57,6 +57,7 @@ SIGNATURES = {
     "gget_head_logits": (i32, [vp, C.POINTER(vp), C.POINTER(i32)]),
     "gget_hidden_states": (i32, [vp, C.POINTER(vp)]),
     "gget_op_gemm": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "gget_debug_set": (i32, [i32, i32]),
     "gget_op_rmsnorm_fwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
     "gget_op_rmsnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "gget_op_embed_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
@@ -72,6 +73,8 @@ SIGNATURES = {
     "gget_op_attn_bwd_ranges": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint32, vp]),
     "gget_op_ranges_from_mask3d": (i32, [vp, vp, vp, i32, i32, vp]),
     "gget_set_dropout": (i32, [vp, f32, f32, C.c_uint32]),
+    "gget_op_gateup_geglu": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "gget_op_down_dgrad_geglu": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "gget_op_geglu_fwd": (i32, [vp, vp, i32, i32, vp]),
     "gget_op_geglu_bwd": (i32, [vp, vp, vp, i32, i32, vp]),
     "gget_op_ce_fwd_bwd": (i32, [vp, i32, vp, vp, vp, i32, i32, vp, vp, f32, i32, vp]),

@@ -66,12 +66,38 @@ __device__ __forceinline__ float wave_max(float v) {
   return wave_allreduce(v, [](float a, float b) { return fmaxf(a, b); });
 }
 
-// exact (erf) GELU, the reference's hidden_act="gelu" (transformers/activations.py GELUActivation)
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU, the reference's hidden_act="gelu" (transformers/activations.py GELUActivation), evaluated with the
+// Abramowitz-Stegun 7.1.26 form of erfc: Phi(x) = 1/2 erfc(-x/sqrt 2), erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) e^{-z^2},
+// t = 1 / (1 + p z), |error| <= 1.5e-7 absolute on erf (7.5e-8 on Phi) - three orders of magnitude below the bf16 rounding every
+// result of it receives.  One v_rcp_f32, one v_exp_f32 and ~10 plain VALU operations per element instead of the ~100
+// instructions (with divergent range branches) of the device library's erff: the activation runs in GEMM epilogues, where
+// its VALU time is not hidden by anything.  e^{-x^2/2} is also the Gaussian density the derivative needs.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& gauss) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(x), 1.0f));
+  gauss = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);   // e^{-x^2/2}
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float q = 0.5f * (p * t) * gauss;   // 1/2 erfc(|x| / sqrt 2)
+  cdf = x >= 0.f ? 1.0f - q : q;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  float cdf, g;
+  gelu_parts(x, cdf, g);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float cdf, g;
+  gelu_parts(x, cdf, g);
+  return fmaf(x * 0.39894228040143267794f, g, cdf);
+}
+// value and derivative together (one evaluation of the shared parts)
+__device__ __forceinline__ void gelu_erf_both(float x, float& val, float& grad) {
+  float cdf, g;
+  gelu_parts(x, cdf, g);
+  val = x * cdf;
+  grad = fmaf(x * 0.39894228040143267794f, g, cdf);
 }
 
 // ---- host side error plumbing (engine.cpp owns the storage) ----

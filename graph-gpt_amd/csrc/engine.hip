@@ -454,6 +454,42 @@ int gemm_nn(const void* A, const void* Bw, void* C, int M, int N, int K, int lda
   return gget_gemm_single(GGET_GEMM_NN, GGET_EPI_NONE, A, Bw, C, nullptr, M, N, K, lda, ldb, ldc, m_dev, nullptr, 1, st);
 }
 
+// Gated-GELU MLP with the activation fused into the GEMMs around it (hf LlamaMLP.forward :174-176):
+//   forward : gu = xn2 W_gu^T (kept for the backward), h = bf16(gelu(gate)) * up, one launch
+//   backward: dgu = geglu'(dy W_down ; gu), one launch - dh is never materialised
+// Available when ff % 128 == 0 (the forward tile holds 128 gate + 128 up columns); otherwise GEMM + element-wise kernel.
+bool geglu_fusable(int d, int ff) {
+  static const int off = getenv("GGET_NO_GEGLU_FUSION") != nullptr;
+  return !off && ff % 128 == 0 && d % 64 == 0;
+}
+int gateup_geglu(const bf16_t* x, const bf16_t* wgu, bf16_t* gu, bf16_t* hh, int T, int d, int ff, hipStream_t st) {
+  if (!geglu_fusable(d, ff)) {
+    if (int e = gemm_nt(x, wgu, gu, nullptr, T, 2 * ff, d, d, d, 2 * ff, nullptr, st)) return e;
+    return k_geglu_fwd(gu, hh, T, ff, st);
+  }
+  GemmGroup g;
+  memset(&g, 0, sizeof(g));
+  g.count = 1;
+  GemmProblem& p = g.p[0];
+  p.A = x; p.B = wgu; p.C = gu; p.C2 = hh;
+  p.M = T; p.N = 2 * ff; p.K = d; p.lda = d; p.ldb = d; p.ldc = 2 * ff; p.ldc2 = ff; p.ff = ff;
+  return gget_gemm_launch(GGET_GEMM_NT, GGET_EPI_GEGLU_FWD, g, 1, st);
+}
+int down_dgrad_geglu(const bf16_t* dy, const bf16_t* wdown, const bf16_t* gu, bf16_t* dgu, bf16_t* dh_scratch, int T, int d, int ff,
+                     hipStream_t st) {
+  if (!geglu_fusable(d, ff)) {
+    if (int e = gemm_nn(dy, wdown, dh_scratch, T, ff, d, d, ff, ff, nullptr, st)) return e;
+    return k_geglu_bwd(gu, dh_scratch, dgu, T, ff, st);
+  }
+  GemmGroup g;
+  memset(&g, 0, sizeof(g));
+  g.count = 1;
+  GemmProblem& p = g.p[0];
+  p.A = dy; p.B = wdown; p.C = dgu; p.G = gu;
+  p.M = T; p.N = ff; p.K = d; p.lda = d; p.ldb = ff; p.ldc = 2 * ff; p.ldg = 2 * ff; p.ff = ff;
+  return gget_gemm_launch(GGET_GEMM_NN, GGET_EPI_GEGLU_BWD, g, 1, st);
+}
+
 // Residual add as its own kernel: out = res + keep_b * (lam * y)
 //   lam  : LayerScale vector (utils_graphgpt.py:153-166) or nullptr (= 1)
 //   keep_b: DropPath / stochastic depth per SAMPLE (utils_graphgpt.py:64-66 = transformers BeitDropPath): 0 with
@@ -561,8 +597,7 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
     if (int e = gemm_nt(attn, h->P + lo.wo, araw, nullptr, T, d, d, d, d, d, nullptr, st)) return e;
     hipLaunchKernelGGL(ls_fwd_kernel, dim3(g), dim3(256), 0, st, x_in, araw, lam1, xmid, (long)T, d, pd1);
     if (int e = k_rmsnorm_fwd(xmid, h->P + lo.ln2, xn2, h->wsp<float>(lw.rstd2), T, d, c.rms_eps, st)) return e;
-    if (int e = gemm_nt(xn2, h->P + lo.wgu, gu, nullptr, T, 2 * ff, d, d, d, 2 * ff, nullptr, st)) return e;
-    if (int e = k_geglu_fwd(gu, hh, T, ff, st)) return e;
+    if (int e = gateup_geglu(xn2, h->P + lo.wgu, gu, hh, T, d, ff, st)) return e;
     if (int e = gemm_nt(hh, h->P + lo.wdown, mraw, nullptr, T, d, ff, ff, ff, d, nullptr, st)) return e;
     hipLaunchKernelGGL(ls_fwd_kernel, dim3(g), dim3(256), 0, st, xmid, mraw, lam2, x_out, (long)T, d, pd2);
     GGET_LAUNCH_CHECK();
@@ -570,8 +605,7 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
   }
   if (int e = gemm_nt(attn, h->P + lo.wo, xmid, x_in, T, d, d, d, d, d, nullptr, st)) return e;
   if (int e = k_rmsnorm_fwd(xmid, h->P + lo.ln2, xn2, h->wsp<float>(lw.rstd2), T, d, c.rms_eps, st)) return e;
-  if (int e = gemm_nt(xn2, h->P + lo.wgu, gu, nullptr, T, 2 * ff, d, d, d, 2 * ff, nullptr, st)) return e;
-  if (int e = k_geglu_fwd(gu, hh, T, ff, st)) return e;
+  if (int e = gateup_geglu(xn2, h->P + lo.wgu, gu, hh, T, d, ff, st)) return e;
   if (int e = gemm_nt(hh, h->P + lo.wdown, x_out, xmid, T, d, ff, ff, ff, d, nullptr, st)) return e;
   return 0;
 }
@@ -744,8 +778,7 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
     dy_down = dsc;   // stays alive for the grouped wgrad at the end of the layer (the o_proj branch has its own buffer)
   }
   // MLP: dh = dy_down W_down ; dgu = geglu'(dh) ; dxn2 = dgu W_gu
-  if (int e = gemm_nn(dy_down, h->P + lo.wdown, dh, T, ff, d, d, ff, ff, nullptr, st)) return e;
-  if (int e = k_geglu_bwd(h->wsp<bf16_t>(lw.gu), dh, dgu, T, ff, st)) return e;
+  if (int e = down_dgrad_geglu(dy_down, h->P + lo.wdown, h->wsp<bf16_t>(lw.gu), dgu, dh, T, d, ff, st)) return e;
   if (int e = gemm_nn(dgu, h->P + lo.wgu, dxn, T, d, 2 * ff, 2 * ff, d, d, nullptr, st)) return e;
   if (int e = k_rmsnorm_bwd(dxn, xmid, h->P + lo.ln2, h->wsp<float>(lw.rstd2), dx_out, dx_mid, s32 + lo.ln2_32, T, d, st, kAccumCopies, align_up((uint64_t)d, 128)))
     return e;
@@ -965,6 +998,14 @@ extern "C" int gget_hidden_states(gget_handle_t h, const void** hidden_dev) {
 // ================================================================================================
 // operator-level entry points
 // ================================================================================================
+extern int g_gemm_variant;
+extern "C" int gget_debug_set(int key, int value) {
+  switch (key) {
+    case 1: g_gemm_variant = value; return 0;
+  }
+  gget_set_error("debug_set: unknown key %d", key);
+  return 2;
+}
 extern "C" int gget_op_gemm(int mode, int epilogue, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
                             int lda, int ldb, int ldc, int split_k, void* stream) {
   return gget_gemm_single(mode, epilogue, A, B, C, R, M, N, K, lda, ldb, ldc, nullptr, nullptr, split_k, (hipStream_t)stream);
@@ -1061,6 +1102,17 @@ extern "C" int gget_op_attn_bwd(const void* qkv, const void* out, const void* do
                                 void* stream) {
   return k_attn_bwd(qkv, out, dout, lse, key_len, dqkv, delta_ws, B, S, H, causal, cos_tab, sin_tab, position_ids,
                     /*qk_rotated=*/0, dropout_p, dropout_seed, (hipStream_t)stream);
+}
+extern "C" int gget_op_gateup_geglu(const void* x, const void* wgu, void* gu, void* h, int T, int d, int ff, void* stream) {
+  GGET_REQUIRE(x && wgu && gu && h && T > 0, "gateup_geglu: null argument");
+  return gateup_geglu((const bf16_t*)x, (const bf16_t*)wgu, (bf16_t*)gu, (bf16_t*)h, T, d, ff, (hipStream_t)stream);
+}
+extern "C" int gget_op_down_dgrad_geglu(const void* dy, const void* wdown, const void* gu, void* dgu, void* dh_scratch, int T, int d,
+                                        int ff, void* stream) {
+  GGET_REQUIRE(dy && wdown && gu && dgu && T > 0, "down_dgrad_geglu: null argument");
+  GGET_REQUIRE(dh_scratch || geglu_fusable(d, ff), "down_dgrad_geglu: this shape needs the [T][ff] dh scratch buffer");
+  return down_dgrad_geglu((const bf16_t*)dy, (const bf16_t*)wdown, (const bf16_t*)gu, (bf16_t*)dgu, (bf16_t*)dh_scratch, T, d, ff,
+                          (hipStream_t)stream);
 }
 extern "C" int gget_op_geglu_fwd(const void* gu, void* h, int T, int ff, void* stream) {
   return k_geglu_fwd(gu, h, T, ff, (hipStream_t)stream);

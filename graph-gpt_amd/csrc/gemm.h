@@ -23,6 +23,12 @@ struct GemmProblem {
   const int64_t* rope_pos;  // [M] or nullptr => position = row % rope_S
   int rope_S, rope_cols;
   int k_pad_zero;           // with k_dev: rows k_dev..round_up(k_dev, 64) of A are zero and those of B finite (whole K-tiles allowed)
+  // EPI_GEGLU_FWD (NT, B = [gate rows | up rows] = [2 ff][K]): C = gu [M][2 ff] (pre-activations, kept for the backward),
+  //   C2 = h [M][ff] = bf16(gelu(gate)) * up ; N = 2 ff.  EPI_GEGLU_BWD (the dh = dy W_down GEMM, N = ff): the epilogue reads
+  //   G = gu [M][2 ff] and writes C = dgu [M][2 ff] = (dh * up * gelu'(gate) | dh * gelu(gate)); dh itself is never stored.
+  void* C2;
+  const bf16_t* G;
+  int ldc2, ldg, ff;
 };
 
 struct GemmGroup {

@@ -34,6 +34,8 @@
 
 #define LDS_AS __attribute__((address_space(3)))
 
+int g_gemm_variant = 0;   // measurement knob (gget_debug_set key 1): selects experimental kernel variants for in-process A/B timing
+
 namespace {
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -173,6 +175,19 @@ struct TileIO {
       return ((unsigned)kr * (unsigned)ld + (unsigned)gm) * 2u;
     }
   }
+  // EPI_GEGLU_FWD: the B tile of the gate|up projection interleaves gate and up rows wave-wise, so that a wave's accumulators
+  // hold gate columns [c, c + W/2) and the SAME up columns: LDS row r of the tile (W = rows per wave) comes from weight row
+  // (r % W < W/2 ? 0 : ff) + n0/2 + (r / W) * (W/2) + r % (W/2)   (n0 = tile origin in the 2 ff wide output).
+  template <int W>
+  __device__ __forceinline__ static unsigned piece_off_geglu(int ld, int n0, int ff, int wave, int lane, int i) {
+    static_assert(!MC, "gate|up weights are K-contiguous");
+    const int q = wave + i * NWAVES;
+    const int r = q * RPP + lane / CR;
+    const int lc = (lane % CR) ^ kc_swz(r);
+    const int rw = r % W;
+    const int gr = (rw < W / 2 ? 0 : ff) + (n0 >> 1) + (r / W) * (W / 2) + (rw % (W / 2));
+    return ((unsigned)gr * (unsigned)ld + (unsigned)(lc * 8)) * 2u;
+  }
   __device__ __forceinline__ static const bf16_t* k_origin(const bf16_t* base, int ld, int k0) {
     return MC ? base + (size_t)k0 * ld : base + k0;
   }
@@ -301,6 +316,96 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
         }
       }
     }
+  }
+  if constexpr (EPI == GGET_EPI_GEGLU_FWD || EPI == GGET_EPI_GEGLU_BWD) {
+    // Gated-GELU fused into the two GEMMs around it (hf LlamaMLP.forward :174-176, hidden_act = exact-erf GELU).
+    //  FWD (gate|up projection, B rows interleaved by piece_off_geglu): accumulators j < NJ/2 are gate columns nw.., j >= NJ/2
+    //      the same up columns; writes gu (bf16 pre-activations, backward input) and h = bf16(gelu(bf16 gate)) * bf16 up -
+    //      the same rounding points as the un-fused path (separate bf16 tensors in the reference module).
+    //  BWD (dh = dy W_down, N = ff): dh is rounded to bf16 (the reference's gradient tensor), then
+    //      d gate = dh * up * gelu'(gate), d up = dh * gelu(gate) go straight to dgu; dh is never written.
+    // Stores use the whole-line regrouping below (the launcher guarantees 64-column alignment of every destination).
+    static_assert(!ILV && NJ % 4 == 0, "GEGLU epilogue: 64-column wave groups");
+    constexpr bool FWD = EPI == GGET_EPI_GEGLU_FWD;
+    constexpr int NG = FWD ? NJ / 8 : NJ / 4;   // 64-column groups (of gate columns) this wave owns
+    constexpr int UP = FWD ? NJ / 2 : 0;        // accumulator index of the first up column group
+    constexpr int NOUT = FWD ? 3 : 2;
+    const bool low = (l15 & 8) == 0;
+    const int c0 = 2 * (gq & 1) + (gq >> 1);
+    const int ff = P.ff;
+    auto ror8 = [](unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true); };
+    auto xchg = [&](int i, int ja, float* v) {   // the lane's 8 consecutive columns of the accumulator pair (ja, ja + 1), row l15
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][ja][e]), __float_as_uint(acc[i][ja + 1][e]), false, false);
+        v[e] = __uint_as_float(r[0]);
+        v[4 + e] = __uint_as_float(r[1]);
+      }
+    };
+    bf16_t* C = reinterpret_cast<bf16_t*>(P.C);
+    bf16_t* C2 = reinterpret_cast<bf16_t*>(P.C2);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = mw + i * 16 + l15;
+      const int ma = mw + i * 16 + (l15 & 7), mb = ma + 8;
+#pragma unroll
+      for (int jq = 0; jq < NG; ++jq) {
+        uint4 pk[2][NOUT];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int jp = 2 * jq + hf;                 // 32-column group: accumulators 2 jp, 2 jp + 1
+          const int n = nw + jp * 32 + c0 * 8;        // (gate) column of the lane's 8 values, row m
+          float a[8];
+          xchg(i, 2 * jp, a);
+          if constexpr (FWD) {
+            float u[8], gr[8], ur[8], hv[8];
+            xchg(i, UP + 2 * jp, u);
+            const uint4 gb = pack8(a), ub = pack8(u);
+            unpack8(gb, gr);
+            unpack8(ub, ur);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = bf2f(f2bf(gelu_erf(gr[e]))) * ur[e];
+            pk[hf][0] = gb;
+            pk[hf][1] = ub;
+            pk[hf][2] = pack8(hv);
+          } else {
+            float gt[8], u[8], dg[8], du[8];
+            uint4 gq4 = make_uint4(0, 0, 0, 0), uq4 = make_uint4(0, 0, 0, 0);
+            if (m < M) {
+              gq4 = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + n);
+              uq4 = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + ff + n);
+            }
+            unpack8(gq4, gt);
+            unpack8(uq4, u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float dv = bf2f(f2bf(a[e]));
+              float gv, gd;
+              gelu_erf_both(gt[e], gv, gd);
+              dg[e] = dv * u[e] * gd;
+              du[e] = dv * gv;
+            }
+            pk[hf][0] = pack8(dg);
+            pk[hf][1] = pack8(du);
+          }
+        }
+        const int nst = nw + jq * 64 + (low ? c0 : c0 + 4) * 8;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+          const uint4 x = pk[0][o], y = pk[1][o];
+          const uint4 xr = make_uint4(ror8(x.x), ror8(x.y), ror8(x.z), ror8(x.w));
+          const uint4 yr = make_uint4(ror8(y.x), ror8(y.y), ror8(y.z), ror8(y.w));
+          const uint4 pa = low ? x : yr;
+          const uint4 pb = low ? xr : y;
+          bf16_t* base = (FWD && o == 2) ? C2 : C;
+          const int ld = (FWD && o == 2) ? P.ldc2 : P.ldc;
+          const int col = nst + (o == 1 ? ff : 0);
+          if (ma < M) *reinterpret_cast<uint4*>(base + (size_t)ma * ld + col) = pa;
+          if (mb < M) *reinterpret_cast<uint4*>(base + (size_t)mb * ld + col) = pb;
+        }
+      }
+    }
+    return;
   }
   const bool odd = gq & 1;
   // Full-line fast path (bf16 C, 64-column groups aligned to 128 B): the exchange below leaves a lane with 16 bytes of
@@ -633,7 +738,10 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
 #pragma unroll
     for (int i = 0; i < TA::PIECES; ++i) offA[i] = TA::piece_off(P.lda, ic.m0, ic.M, wave, lane, i);
 #pragma unroll
-    for (int i = 0; i < TB::PIECES; ++i) offB[i] = TB::piece_off(P.ldb, ic.n0, P.N, wave, lane, i);
+    for (int i = 0; i < TB::PIECES; ++i) {
+      if constexpr (EPI == GGET_EPI_GEGLU_FWD) offB[i] = TB::template piece_off_geglu<BN / WN>(P.ldb, ic.n0, P.ff, wave, lane, i);
+      else offB[i] = TB::piece_off(P.ldb, ic.n0, P.N, wave, lane, i);
+    }
   };
   load_issue_tile();
   auto issue_piece = [&](int q) {       // piece q of the K-tile (ic, ik) into slot islot
@@ -666,7 +774,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
   auto finish_tile = [&]() {
     const GemmProblem& P = g.p[cc.pi];
     if (g.ablate != 32 || acc[0][0][0] == 123.456f)   // GGET_GEMM_ABLATE=32: persistent kernel without the epilogue (timing only)
-      store_tile<EPI, MI, NJ, ILV>(acc, P, cc.M, (P.N + 3) & ~3, cc.m0 + wm * (MI * 16), cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, wn * 16);
+      store_tile<EPI, MI, NJ, ILV>(acc, P, cc.M, (P.N + 3) & ~3, cc.m0 + wm * (MI * 16),
+                                   EPI == GGET_EPI_GEGLU_FWD ? (cc.n0 >> 1) + wn * (NJ * 8) : cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, wn * 16);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -765,7 +874,7 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
     }
     // wide tile for the widest forward GEMM: 256x256x32 (8 waves of 128x64, 4-slot ring) moves 2/3 of the bytes per
     // FLOP of the 256x128 tile
-    if constexpr (WM == 4 && WN == 2 && !A_MC && EPI != GGET_EPI_SLAB_F32 && EPI != GGET_EPI_ATOMIC_F32 && EPI != GGET_EPI_ROPE) {
+    if constexpr (WM == 4 && WN == 2 && !A_MC && EPI != GGET_EPI_SLAB_F32 && EPI != GGET_EPI_ATOMIC_F32 && EPI != GGET_EPI_ROPE && EPI != GGET_EPI_GEGLU_FWD) {
       long t256 = 0;
       bool ok256 = getenv("GGET_GEMM_NO_256") == nullptr;
       for (int i = 0; i < g.count; ++i) {
@@ -874,6 +983,32 @@ int launch_mode(GemmGroup& g, int epi, int split_k, hipStream_t st) {
     case GGET_EPI_ROPE:
       if constexpr (!A_MC && !B_MC) return launch_shape<false, false, GGET_EPI_ROPE>(g, split_k, st);
       break;
+    case GGET_EPI_GEGLU_BWD:
+      if constexpr (!A_MC && B_MC) return launch_shape<false, true, GGET_EPI_GEGLU_BWD>(g, split_k, st);
+      break;
+    case GGET_EPI_GEGLU_FWD:
+      if constexpr (!A_MC && !B_MC) {
+        // one configuration: 256x256x64 tiles (128 gate + 128 up columns), 8 waves as 4 (M) x 2 (N), each wave 64 rows x
+        // (64 gate + 64 up) columns, 2-slot ring
+        int total = 0;
+        for (int i = 0; i < g.count; ++i) {
+          GemmProblem& p = g.p[i];
+          p.tiles_n = p.N / 256;
+          p.tile_begin = total;
+          total += ((p.M + 255) / 256) * p.tiles_n;
+        }
+        if (total == 0) return 0;
+        static int num_cu = 0;
+        if (!num_cu) {
+          int dev = 0;
+          hipDeviceProp_t prop;
+          GGET_HIP_CHECK(hipGetDevice(&dev));
+          GGET_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+          num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        return launch_persist_cfg<256, 256, 64, 4, 2, false, false, GGET_EPI_GEGLU_FWD, 2>(g, total, num_cu, st);
+      }
+      break;
   }
   gget_set_error("gemm: unknown epilogue %d", epi);
   return 2;
@@ -893,6 +1028,15 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
                "gemm: split-K needs the fp32 atomic or slab epilogue");
   for (int i = 0; i < g.count; ++i) {
     const GemmProblem& p = g.p[i];
+    if (epi == GGET_EPI_GEGLU_FWD || epi == GGET_EPI_GEGLU_BWD) {
+      const bool fwd = epi == GGET_EPI_GEGLU_FWD;
+      GGET_REQUIRE(mode == (fwd ? GGET_GEMM_NT : GGET_GEMM_NN) && split_k <= 1 && !p.m_dev && !p.k_dev, "gemm: GEGLU epilogue: wrong mode");
+      GGET_REQUIRE(p.ff > 0 && p.N == (fwd ? 2 * p.ff : p.ff) && p.N % (fwd ? 256 : 64) == 0 && (p.K % 64) == 0,
+                   "gemm: GEGLU epilogue needs ff %% %d == 0 and K %% 64 == 0 (ff %d N %d K %d)", fwd ? 128 : 64, p.ff, p.N, p.K);
+      GGET_REQUIRE((p.ldc % 64) == 0 && ((uintptr_t)p.C & 127) == 0 && p.ldc >= 2 * p.ff, "gemm: GEGLU epilogue: gu / dgu must be [M][>= 2 ff], 128-byte aligned rows");
+      if (fwd) GGET_REQUIRE(p.C2 && (p.ldc2 % 64) == 0 && ((uintptr_t)p.C2 & 127) == 0 && p.ldc2 >= p.ff, "gemm: GEGLU forward: h must be [M][>= ff], 128-byte aligned rows");
+      else GGET_REQUIRE(p.G && (p.ldg % 8) == 0 && ((uintptr_t)p.G & 15) == 0 && p.ldg >= 2 * p.ff, "gemm: GEGLU backward: gu must be [M][>= 2 ff]");
+    }
     GGET_REQUIRE((p.lda % 8) == 0 && (p.ldb % 8) == 0 && (p.ldc % 8) == 0,
                  "gemm: leading dims must be multiples of 8 (lda %d ldb %d ldc %d)", p.lda, p.ldb, p.ldc);
     // N % 4 != 0 (e.g. the 41 245-entry ogbl-ppa vocabulary): C is written up to the next multiple of 4, which must fit in

@@ -455,8 +455,10 @@ __global__ void __launch_bounds__(kBlock) geglu_bwd_kernel(const bf16_t* __restr
     unpack8(ldg16(dh + t * ff + c * 8), dv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      dg[e] = dv[e] * u[e] * gelu_erf_grad(g[e]);
-      du[e] = dv[e] * gelu_erf(g[e]);
+      float gv, gd;
+      gelu_erf_both(g[e], gv, gd);
+      dg[e] = dv[e] * u[e] * gd;
+      du[e] = dv[e] * gv;
     }
     stg16(dgu + t * 2 * ff + c * 8, pack8(dg));
     stg16(dgu + t * 2 * ff + ff + c * 8, pack8(du));

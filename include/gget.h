@@ -188,8 +188,13 @@ int gget_hidden_states(gget_handle_t h, const void** hidden_dev);
 #define GGET_EPI_ATOMIC_F32 2 /* C is fp32, C += A*B with atomics (split-K) */
 #define GGET_EPI_ROPE 4 /* C = rope(A*B) on columns [0, rope_cols): RoPE fused into the q|k|v projection (engine only) */
 #define GGET_EPI_SLAB_F32 3 /* C is fp32 [split_k][M][ldc]: slice s of K writes slab s (reduced by the caller) */
+#define GGET_EPI_GEGLU_FWD 5 /* gate|up projection with the gated-GELU product fused into the epilogue (gget_op_gateup_geglu) */
+#define GGET_EPI_GEGLU_BWD 6 /* dh = dy W_down with the gated-GELU backward fused into the epilogue (gget_op_down_dgrad_geglu) */
 int gget_op_gemm(int mode, int epilogue, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
                  int lda, int ldb, int ldc, int split_k, void* stream);
+/* measurement knob (tools/ only; no reference counterpart): key 1 = bit mask selecting experimental GEMM kernel variants,
+ * so that two variants can be timed interleaved in one process (0 = the shipped configuration) */
+int gget_debug_set(int key, int value);
 /* replaces: q_proj/k_proj/v_proj + apply_rotary_pos_emb (hf LlamaAttention.forward :253-262, :138-160) as ONE GEMM:
  * qkv[T,3d] = x[T,d] * wqkv[3d,d]^T with RoPE applied to the q|k columns in the fp32 accumulators (position of row t is
  * position_ids[t], or t % S when position_ids is NULL; cos/sin tables [max_position][32] fp32). */
@@ -247,6 +252,14 @@ int gget_op_attn_bwd_ranges(const void* qkv, const void* out, const void* dout, 
                             const int32_t* key_hi, void* dqkv, float* delta_ws, int B, int S, int H, int causal,
                             float dropout_p, uint32_t dropout_seed, void* stream);
 int gget_op_ranges_from_mask3d(const int64_t* mask3d, int32_t* key_lo, int32_t* key_hi, int B, int S, void* stream);
+/* replaces: LlamaMLP.forward (hf :174-176) up to the down projection, as ONE GEMM with the gated-GELU product in its
+ * epilogue: gu[T,2ff] = x[T,d] * wgu[2ff,d]^T (gate | up pre-activations, kept for the backward),
+ * h[T,ff] = bf16(gelu(gate)) * up.  Falls back to GEMM + gget_op_geglu_fwd when ff % 128 != 0. */
+int gget_op_gateup_geglu(const void* x, const void* wgu, void* gu, void* h, int T, int d, int ff, void* stream);
+/* backward counterpart: dgu[T,2ff] = (dh * up * gelu'(gate) | dh * gelu(gate)) with dh = dy[T,d] * wdown[d,ff] computed in
+ * the same launch and never stored (dh_scratch [T,ff] is only used by the un-fused fallback, may be NULL when ff % 128 == 0) */
+int gget_op_down_dgrad_geglu(const void* dy, const void* wdown, const void* gu, void* dgu, void* dh_scratch, int T, int d, int ff,
+                             void* stream);
 int gget_op_geglu_fwd(const void* gu, void* h, int T, int ff, void* stream);
 int gget_op_geglu_bwd(const void* gu, const void* dh, void* dgu, int T, int ff, void* stream);
 int gget_op_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const float* row_wgt, const int32_t* n_rows_dev,

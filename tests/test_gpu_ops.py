@@ -390,6 +390,37 @@ def test_geglu(lib):
     assert rel_l2(dgu.float().cpu().numpy(), gf.grad.cpu().numpy()) < 4e-3
 
 
+@pytest.mark.parametrize("T,d,ff", [(77, 128, 512), (600, 192, 384), (1000, 768, 3072), (96, 128, 320)])
+def test_gateup_geglu_fused(lib, T, d, ff):
+    """gate|up projection with the gated-GELU product in the GEMM epilogue and its backward in the epilogue of the down
+    dgrad GEMM: bit-identical to the un-fused op sequence (same bf16 rounding points), close to the fp32 statement of
+    hf LlamaMLP.forward :174-176.  ff = 320 takes the un-fused fallback (ff % 128 != 0)."""
+    x, wgu, wdown, dy = rnd(T, d, seed=1), rnd(2 * ff, d, seed=2, scale=0.08), rnd(d, ff, seed=3, scale=0.05), rnd(T, d, seed=4)
+    gu = torch.zeros(T, 2 * ff, dtype=torch.bfloat16, device="cuda")
+    h = torch.zeros(T, ff, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.gget_op_gateup_geglu(P(x), P(wgu), P(gu), P(h), T, d, ff, ST()))
+    # un-fused sequence through the same library
+    gu2, h2 = torch.zeros_like(gu), torch.zeros_like(h)
+    L.check(lib.gget_op_gemm(L.GEMM_NT, 0, P(x), P(wgu), P(gu2), None, T, 2 * ff, d, d, d, 2 * ff, 1, ST()))
+    L.check(lib.gget_op_geglu_fwd(P(gu2), P(h2), T, ff, ST()))
+    assert torch.equal(gu, gu2), "gate|up pre-activations differ from the plain GEMM"
+    assert torch.equal(h, h2), "fused GEGLU differs from GEMM + geglu_fwd"
+    guf = x.float() @ wgu.float().t()
+    ref = torch.nn.functional.gelu(guf[:, :ff]) * guf[:, ff:]
+    assert rel_l2(h.float().cpu().numpy(), ref.cpu().numpy()) < 8e-3
+    # backward
+    dgu = torch.zeros(T, 2 * ff, dtype=torch.bfloat16, device="cuda")
+    dh_s = torch.zeros(T, ff, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.gget_op_down_dgrad_geglu(P(dy), P(wdown), P(gu), P(dgu), P(dh_s), T, d, ff, ST()))
+    dh2, dgu2 = torch.zeros(T, ff, dtype=torch.bfloat16, device="cuda"), torch.zeros_like(dgu)
+    L.check(lib.gget_op_gemm(L.GEMM_NN, 0, P(dy), P(wdown), P(dh2), None, T, ff, d, d, ff, ff, 1, ST()))
+    L.check(lib.gget_op_geglu_bwd(P(gu), P(dh2), P(dgu2), T, ff, ST()))
+    assert torch.equal(dgu, dgu2), "fused GEGLU backward differs from GEMM + geglu_bwd"
+    gf = gu.float().requires_grad_(True)
+    (torch.nn.functional.gelu(gf[:, :ff]) * gf[:, ff:]).backward(dy.float() @ wdown.float())
+    assert rel_l2(dgu.float().cpu().numpy(), gf.grad.cpu().numpy()) < 6e-3
+
+
 @pytest.mark.parametrize("V,ld", [(756, 768), (300, 320), (97, 128), (1500, 1536), (41245, 41280), (211, 212)])
 def test_cross_entropy(lib, V, ld):
     """Row-in-registers kernels (ld <= 512 / 1024 / 2048) and the generic kernel (wide vocabulary, or ld % 8 != 0)."""

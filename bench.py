@@ -28,29 +28,39 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 WORKLOADS = {
-    # name: (model size, B per GPU, S, F, V)   -- SURVEY.md 8d C1/C2, toy for quick checks
-    "pcqm4m-v2-pretrain-base": ("base", 256, 32, 13, 756),
-    "pcqm4m-v2-pretrain-base24": ("base24", 256, 32, 13, 756),
-    "toy-tiny": ("tiny", 128, 64, 1, 300),
+    # name: (kind, model size, B per GPU, S, F, V)   -- SURVEY.md 8d C1..C4; toy for quick checks
+    "pcqm4m-v2-pretrain-base": ("pt", "base", 256, 32, 13, 756),          # C1: the configuration the metric is quoted on
+    "pcqm4m-v2-pretrain-base24": ("pt", "base24", 256, 32, 13, 756),      # C2 (per-GPU shape of the 8-GPU run)
+    # the reference's pack_tokens option (src/data/tokenizer.py:359-415): the same 8192 token slots per step filled with
+    # whole graphs back to back (block-diagonal attention) instead of one padded graph per row.  Reported NEXT TO the
+    # headline line, never instead of it (every reference script runs pack_tokens=0).
+    "pcqm4m-v2-pretrain-base-packed": ("pt-packed", "base", 64, 128, 13, 756),
+    "ogbl-ppa-finetune-base": ("ft", "base", 256, 256, 4, 41245),         # C3: LayerScale + DropPath, 2-class edge task
+    "longseq-finetune-base": ("ft-long", "base", 16, 2048, 4, 41245),     # C4 (per-GPU shape)
+    "toy-tiny": ("pt", "tiny", 128, 64, 1, 300),
 }
 
 
-def flops_per_step(spec, B, S, M, Lm):
+def flops_per_step(spec, B, S, M, Lm, kind="pt"):
     """Algorithmic FLOPs of one training step: F_step = 3*F_fwd, no recompute credit,
-    full SxS attention, head terms with the measured M / Lm of the batch."""
+    full SxS attention, head terms with the measured M / Lm of the batch (fine-tune: the pooled score head)."""
     T, d, ff, L, F, V = B * S, spec.hidden_size, spec.intermediate_size, spec.num_layers, spec.next_n_token, spec.vocab_size
-    fwd = T * L * (8 * d * d + 6 * d * ff) + 4 * L * B * S * S * d + M * 2 * d * (F * d if F > 1 else 0) + Lm * 2 * d * V
+    fwd = T * L * (8 * d * d + 6 * d * ff) + 4 * L * B * S * S * d
+    if kind.startswith("pt"):
+        fwd += M * 2 * d * (F * d if F > 1 else 0) + Lm * 2 * d * V
+    else:
+        fwd += B * 2 * d * max(int(getattr(spec, "num_labels", 2) or 2), 1)
     return 3.0 * fwd
 
 
-def cpu_baseline(spec, state, F, V, seed, threads):
-    """Oracle (CPU port of the reference path, parity-pinned) timed on the host cores: fwd + bwd + AdamW, fp32,
-    on a bounded sample of the same workload (smaller batch, same S/F/V/model)."""
+def cpu_baseline(spec, state, B, S, F, V, seed, threads, budget_s=30.0):
+    """Oracle (CPU port of the reference path, parity-pinned) timed on the host cores: fwd + bwd + AdamW, fp32, on the
+    SAME batch shape as the GPU run (B x S x F of the workload, same generator and seed), bounded in time: one warm-up step
+    and as many timed steps as fit in ~budget_s seconds (at least one)."""
     from oracle import gget_oracle as O
     synth = importlib.import_module("graph-gpt_amd.synth")
     torch.set_num_threads(threads)
-    Bc, Sc = 16, 32
-    b = synth.make_pretrain_batch(B=Bc, S=Sc, F=F, V=V, seed=seed)
+    b = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=seed)
     tb = {k: torch.from_numpy(v) for k, v in b.items()}
     p = O.to_params(state, torch.float32)
     m = {k: torch.zeros_like(v) for k, v in p.items()}
@@ -58,53 +68,84 @@ def cpu_baseline(spec, state, F, V, seed, threads):
     fn = lambda q: O.pretrain_forward(spec, q, tb["input_ids"], tb["attention_mask"], tb["labels"])
     times = []
     t_begin = time.time()
-    for it in range(6):
+    for it in range(8):
         t0 = time.time()
         _, grads = O.loss_and_grads(fn, p, "head1_loss")
         with torch.no_grad():
             O.adamw_step(p, grads, m, v, it + 1, 3e-4, 0.9, 0.95, 1e-8, 0.1, 1.0)
         times.append(time.time() - t0)
-        if time.time() - t_begin > 25.0:   # bounded: the default bench run must finish within minutes
+        if it >= 1 and time.time() - t_begin + times[-1] > budget_s:
             break
-    dt = float(np.median(times[1:])) if len(times) > 1 else float(times[0])
+    timed = times[1:] if len(times) > 1 else times
+    dt = float(np.median(timed))
     real = int(b["attention_mask"].sum())
     return {"value": real / dt, "unit": "graph-tokens/s", "cores": threads, "kind": "port",
-            "sample": f"oracle fp32 fwd+bwd+AdamW, base model, B={Bc} S={Sc}, {len(times)} steps ({dt:.2f} s/step)"}
+            "sample": f"oracle fp32 fwd+bwd+AdamW, same batch shape as the GPU step (B={B} S={S} F={F}), 1 warm-up + {len(timed)} timed "
+                      f"step(s), {dt:.2f} s/step"}
 
 
-def time_dominant_kernel(spec, T, iters=20):
-    """Live HIP-event timing of the dominant kernel: the FFN gate|up GEMM [T,d]x[d,2ff] (NT bf16 MFMA)."""
+def _event_time(fn, iters):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def time_kernels(spec, T, iters=20):
+    """Live HIP-event timing (torch's current stream = the stream the kernels are launched on) of the dominant kernel - the
+    FFN gate|up GEMM [T,d]x[d,2ff] (NT bf16 MFMA) with the gated-GELU product in its epilogue - and of the two next heaviest
+    launches of a decoder layer: the dgrad into the residual stream through W_gu (NN, K = 2ff) and the grouped weight-gradient
+    launch (TN, K = T, four problems)."""
     L = importlib.import_module("graph-gpt_amd._lib")
     import ctypes as C
     lib = L.load()
     d, ff = spec.hidden_size, spec.intermediate_size
-    A = torch.randn(T, d, device="cuda").to(torch.bfloat16)
-    W = (torch.randn(2 * ff, d, device="cuda") * 0.02).to(torch.bfloat16)
-    Cm = torch.empty(T, 2 * ff, dtype=torch.bfloat16, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    bf = lambda *s, sc=1.0: (torch.randn(*s, device="cuda") * sc).to(torch.bfloat16)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    args = (L.GEMM_NT, L.EPI_NONE, C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(Cm.data_ptr()), None,
-            T, 2 * ff, d, d, d, 2 * ff, 1, st)
-    for _ in range(3):
-        L.check(lib.gget_op_gemm(*args))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        L.check(lib.gget_op_gemm(*args))
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    fl = 2.0 * T * d * 2 * ff
-    return fl / (ms * 1e-3) / 1e12, ms
+    x, wgu = bf(T, d), bf(2 * ff, d, sc=0.02)
+    gu = torch.empty(T, 2 * ff, dtype=torch.bfloat16, device="cuda")
+    h = torch.empty(T, ff, dtype=torch.bfloat16, device="cuda")
+    out = {}
+    ms = _event_time(lambda: L.check(lib.gget_op_gateup_geglu(P(x), P(wgu), P(gu), P(h), T, d, ff, st)), iters)
+    out["gateup"] = (2.0 * T * d * 2 * ff, ms)
+    dgu, dxn = bf(T, 2 * ff), torch.empty(T, d, dtype=torch.bfloat16, device="cuda")
+    ms = _event_time(lambda: L.check(lib.gget_op_gemm(L.GEMM_NN, L.EPI_NONE, P(dgu), P(wgu), P(dxn), None, T, d, 2 * ff, 2 * ff, d, d, 1, st)), iters)
+    out["dgrad_gu"] = (2.0 * T * d * 2 * ff, ms)
+    dy, dqkv, xn, attn = bf(T, d), bf(T, 3 * d), bf(T, d), bf(T, d)
+    gw = [torch.empty(2 * ff, d, dtype=torch.bfloat16, device="cuda"), torch.empty(d, ff, dtype=torch.bfloat16, device="cuda"),
+          torch.empty(3 * d, d, dtype=torch.bfloat16, device="cuda"), torch.empty(d, d, dtype=torch.bfloat16, device="cuda")]
+    probs = [(dgu, xn, gw[0], 2 * ff, d, T, 2 * ff, d, d), (dy, h, gw[1], d, ff, T, d, ff, ff),
+             (dqkv, xn, gw[2], 3 * d, d, T, 3 * d, d, d), (dy, attn, gw[3], d, d, T, d, d, d)]
+    ms = _event_time(lambda: L.check(L.gemm_grouped(lib, L.GEMM_TN, probs, st)), iters)
+    out["wgrad_layer"] = (2.0 * T * (2 * ff * d + d * ff + 4 * d * d), ms)
+    return out
+
+
+def _source_digest():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "common.h", "gemm.h"):
+        with open(os.path.join(ROOT, "graph-gpt_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic():
-    """L2<->fabric bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r01_gu_gemm_pmc.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc runs); None when
-    the summary is absent.  PMC counters cannot be collected from inside the process being timed."""
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gu_gemm_pmc.json")
+    """L2<->fabric bytes per launch of the dominant kernel from the committed PMC passes (profiles/r02_gu_geglu_gemm_pmc.json:
+    FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc runs, tools/pmc_gu.sh).  PMC counters cannot be
+    collected from inside the process being timed, so the figure is a recorded one: it carries the digest of the kernel
+    sources it was measured on and is reported as null when those sources have changed since."""
+    p = os.path.join(ROOT, "profiles", "r02_gu_geglu_gemm_pmc.json")
     try:
         with open(p) as f:
-            return json.load(f)["traffic_bytes_per_launch"]
+            rec = json.load(f)
+        return rec["traffic_bytes_per_launch"] if rec.get("source_digest") == _source_digest() else None
     except (OSError, KeyError, ValueError):
         return None
 
@@ -139,23 +180,38 @@ def main():
     modeling = importlib.import_module("graph-gpt_amd.modeling")
     training = importlib.import_module("graph-gpt_amd.training")
 
-    size, B, S, F, V = WORKLOADS[a.workload]
+    kind, size, B, S, F, V = WORKLOADS[a.workload]
     sz = spec_mod.MODEL_SIZES[size]
+    pt = kind.startswith("pt")
+    extra = {}
+    if kind == "ft":      # ogbl-ppa scripts: LayerScale + stochastic depth (examples/graph_lvl/ppa_*.sh), 2-class edge task
+        extra = dict(layer_scale_init_value=1.0, path_pdrop=0.2, num_labels=2, problem_type="single_label_classification")
+    elif kind == "ft-long":
+        extra = dict(num_labels=2, problem_type="single_label_classification")
     cfg = modeling.GraphGPTConfig(vocab_size=V, hidden_size=sz["hidden_size"], intermediate_size=4 * sz["hidden_size"],
                                   num_hidden_layers=sz["num_layers"], num_attention_heads=sz["hidden_size"] // 64,
-                                  max_position_embeddings=1024, causal_attention=False, stacked_feat=F, next_n_token=F,
-                                  attention_dropout=0.1)   # every reference pre-train script trains with 0.1
-    model = modeling.GraphGPTPretrainBase(cfg, seed=0)   # same random-init weights on every rank (DP replicas)
+                                  max_position_embeddings=max(1024, S), causal_attention=False, stacked_feat=F,
+                                  next_n_token=F if pt else 1,
+                                  attention_dropout=0.1, **extra)   # every reference training script runs attention dropout 0.1
+    model = (modeling.GraphGPTPretrainBase if pt else modeling.GraphGPTTaskModel)(cfg, seed=0)   # same init on every rank
     spec = model.spec
     model._ensure_engine(B, S)
     engine = training.initialize(model, training.OptimConfig(lr=3e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1,
                                                              max_grad_norm=1.0))
-    batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=1234 + rank)     # distinct data per rank
-    dev = {k: torch.from_numpy(v).cuda() for k, v in batch.items() if k != "lengths"}
-    real_tokens = synth.real_tokens(batch)
+    if kind == "pt":
+        batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=1234 + rank)     # distinct data per rank
+        real_tokens = synth.real_tokens(batch)
+    elif kind == "pt-packed":
+        batch = synth.make_packed_pretrain_batch(B=B, S=S, F=F, V=V, seed=1234 + rank, mean_len=22, min_len=6)
+        real_tokens = int(batch["lengths"].sum())
+    else:
+        batch = synth.make_task_batch(B=B, S=S, F=F, V=V, seed=1234 + rank, lengths="uniform" if kind == "ft" else "full",
+                                      min_len=S // 4)
+        real_tokens = synth.real_tokens(batch)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in batch.items() if k not in ("lengths", "segments")}
 
     def step():
-        return training.batch_training(dev, engine)
+        return training.batch_training(dev, engine) if pt else training.ft_batch_training(dev, engine)[0]
 
     for _ in range(a.warmup):
         loss = step()
@@ -182,33 +238,55 @@ def main():
         tot_real, mean_loss = float(real_tokens), float(loss.item())
 
     if rank == 0:
-        M, Lm = model._engine.head_counts()
-        fstep = flops_per_step(spec, B, S, M, Lm)
+        M, Lm = model._engine.head_counts() if pt else (0, 0)
+        fstep = flops_per_step(spec, B, S, M, Lm, kind)
         ms = dt / a.steps * 1e3
         step_tflops = fstep / (ms * 1e-3) / 1e12
-        k_tflops, k_ms = time_dominant_kernel(spec, B * S)
+        kt = time_kernels(spec, B * S)
+        gu_fl, gu_ms = kt["gateup"]
+        d_, ff_, L_ = spec.hidden_size, spec.intermediate_size, spec.num_layers
+        share = lambda fl_per_layer: round(100.0 * fl_per_layer * L_ / fstep, 1)
+        k_tflops = gu_fl / (gu_ms * 1e-3) / 1e12
+        names = {"pt": "SMTP loss", "pt-packed": "SMTP loss", "ft": "task loss", "ft-long": "task loss"}
         out = {
-            "metric": "graph-tokens/sec (un-padded Eulerian tokens, whole job) + SMTP loss, PCQM4M-v2 base pre-train",
+            "metric": f"graph-tokens/sec (un-padded Eulerian tokens, whole job) + {names[kind]}, "
+                      + ("PCQM4M-v2 base pre-train" if a.workload == "pcqm4m-v2-pretrain-base" else a.workload),
             "value": tot_real * a.steps / dt, "unit": "graph-tokens/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": a.workload, "model": f"{size} d{spec.hidden_size}/L{spec.num_layers}/H{spec.num_heads} "
                        f"({spec.num_params() / 1e6:.1f}M params)", "per_gpu_batch": B, "global_batch": B * world,
                        "seq_len": S, "stacked_feat": F, "vocab": V, "parallelism": f"dp{world}",
-                       "step": "fwd+bwd+allreduce+clip+AdamW", "attention_dropout": cfg.attention_dropout},
-            "smtp_loss": mean_loss,
+                       "step": "fwd+bwd+allreduce+clip+AdamW", "attention_dropout": cfg.attention_dropout,
+                       **({"path_pdrop": 0.2, "layer_scale_init_value": 1.0} if kind == "ft" else {}),
+                       **({"packing": "whole graphs back to back, block-diagonal attention"} if kind == "pt-packed" else {})},
+            ("smtp_loss" if pt else "task_loss"): mean_loss,
             "padded_tokens_per_s": B * S * world * a.steps / dt,
             "tokens_per_s_per_gpu": tot_real * a.steps / dt / world,
             "step_mfma": {"flops_per_step": fstep, "achieved_tflops_per_gpu": step_tflops,
                           "frac_of_peak": step_tflops / PEAK_BF16_TFLOPS},
-            "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<256,256,64,NT> FFN gate|up [T,d]x[d,2ff] (26% of step FLOPs)",
+            "roofline": {"bound": "mfma",
+                         "kernel": f"gemm_persist_kernel<256,256,64,NT,EPI_GEGLU_FWD> FFN gate|up [T,d]x[d,2ff] + gated GELU "
+                                   f"({share(gu_fl)}% of step FLOPs as the forward launch timed here, {share(3 * gu_fl)}% with its dgrad and wgrad)",
                          "achieved": k_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": k_tflops / PEAK_BF16_TFLOPS, "traffic": pmc_traffic() if B * S == 8192 and spec.hidden_size == 768 else None,
-                         "avg_launch_ms": k_ms},
+                         "frac": k_tflops / PEAK_BF16_TFLOPS,
+                         "traffic": pmc_traffic() if B * S == 8192 and spec.hidden_size == 768 else None,
+                         "avg_launch_ms": gu_ms,
+                         "other_kernels": [
+                             {"kernel": "gemm_persist_kernel<128,192,64,NN> dgrad dxn2 = dgu W_gu [T,2ff]x[2ff,d]",
+                              "step_flops_pct": share(kt["dgrad_gu"][0]), "avg_launch_ms": kt["dgrad_gu"][1],
+                              "achieved": kt["dgrad_gu"][0] / (kt["dgrad_gu"][1] * 1e-3) / 1e12,
+                              "frac": kt["dgrad_gu"][0] / (kt["dgrad_gu"][1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS},
+                             {"kernel": "gemm_persist_kernel<192,192,64,TN> grouped weight gradients of one layer (gate|up, down, q|k|v, o; K = T)",
+                              "step_flops_pct": share(kt["wgrad_layer"][0]), "avg_launch_ms": kt["wgrad_layer"][1],
+                              "achieved": kt["wgrad_layer"][0] / (kt["wgrad_layer"][1] * 1e-3) / 1e12,
+                              "frac": kt["wgrad_layer"][0] / (kt["wgrad_layer"][1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}]},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and kind == "pt":
             state = weights.make_state_dict(spec, seed=0)
-            out["cpu_baseline"] = cpu_baseline(spec, state, F, V, 1234, min(os.cpu_count() or 1, 32))
+            out["cpu_baseline"] = cpu_baseline(spec, state, B, S, F, V, 1234, min(os.cpu_count() or 1, 32))
+        elif world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = None   # the CPU port is timed on the headline workload only
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()   # rank 0 is still timing the dominant kernel: tear the communicator down together

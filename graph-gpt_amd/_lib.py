@@ -53,11 +53,16 @@ SIGNATURES = {
     "gget_backward_layer": (i32, [vp, i32, vp]),
     "gget_backward_end": (i32, [vp, vp]),
     "gget_adamw_step": (i32, [vp, f32, f32, f32, f32, f32, f32, f32, i32, vp, vp]),
+    "gget_comm_unique_id": (i32, [vp]),
+    "gget_comm_init": (i32, [vp, i32, i32, vp]),
+    "gget_comm_destroy": (i32, [vp]),
+    "gget_allreduce_grads_async": (i32, [vp, i32, i32, vp]),
     "gget_head_counts": (i32, [vp, C.POINTER(i32 * 2), vp]),
     "gget_head_logits": (i32, [vp, C.POINTER(vp), C.POINTER(i32)]),
     "gget_hidden_states": (i32, [vp, C.POINTER(vp)]),
     "gget_op_gemm": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "gget_debug_set": (i32, [i32, i32]),
+    "gget_op_gemm_grouped": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gget_op_rmsnorm_fwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
     "gget_op_rmsnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "gget_op_embed_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
@@ -82,6 +87,15 @@ SIGNATURES = {
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_NONE, EPI_RESIDUAL, EPI_ATOMIC_F32, EPI_SLAB_F32 = 0, 1, 2, 3
+
+
+def gemm_grouped(lib, mode, problems, stream):
+    """problems: list of (A, B, C, M, N, K, lda, ldb, ldc) with torch tensors; one persistent launch."""
+    n = len(problems)
+    PA, IA = vp * n, i32 * n
+    ptr = lambda k: PA(*[p[k].data_ptr() for p in problems])
+    num = lambda k: IA(*[int(p[k]) for p in problems])
+    return lib.gget_op_gemm_grouped(mode, n, ptr(0), ptr(1), ptr(2), num(3), num(4), num(5), num(6), num(7), num(8), stream)
 PROBLEM_SINGLE_LABEL, PROBLEM_REGRESSION_L1, PROBLEM_REGRESSION_MSE, PROBLEM_MULTI_LABEL = 0, 1, 2, 3
 
 _lib = None

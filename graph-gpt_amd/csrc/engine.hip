@@ -5,6 +5,7 @@
 //   GraphGPTPretrainBase.forward  modeling_pretrain.py:152-266   -> gget_forward_pretrain
 //   GraphGPTTaskModel.forward     modeling_finetune.py:236-326   -> gget_forward_task
 //   hf LlamaModel / LlamaDecoderLayer.forward :367-418 / :295-325 -> layer_forward / layer_backward
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -16,6 +17,7 @@
 #include "common.h"
 #include "gemm.h"
 #include "kernels.h"
+#include <rccl/rccl.h>   // types and enums only: the library is bound with dlopen (see the collective section)
 
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -290,6 +292,11 @@ struct gget_engine {
   bf16_t* dx_cur = nullptr;  // gradient w.r.t. the residual stream entering the next backward stage
   bool packed = false;       // last forward used a 3-D block-diagonal attention mask (per-token key ranges)
   bool defer_convert = false;
+  // data-parallel exchange (gget_comm_*): RCCL communicator of this rank and an fp32 staging buffer for the largest bucket
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  float* comm_f32 = nullptr;
+  uint64_t comm_f32_elems = 0;
   const int32_t* klo() const { return packed ? wsp<int32_t>(ws.key_lo) : nullptr; }
   const int32_t* khi() const { return packed ? wsp<int32_t>(ws.key_hi) : nullptr; }
 
@@ -392,7 +399,9 @@ extern "C" int gget_create(const gget_config_t* cfg, const gget_buffers_t* bufs,
   return 0;
 }
 
+extern "C" int gget_comm_destroy(gget_handle_t h);
 extern "C" int gget_destroy(gget_handle_t h) {
+  if (h) gget_comm_destroy(h);
   delete h;
   return 0;
 }
@@ -1010,6 +1019,19 @@ extern "C" int gget_op_gemm(int mode, int epilogue, const void* A, const void* B
                             int lda, int ldb, int ldc, int split_k, void* stream) {
   return gget_gemm_single(mode, epilogue, A, B, C, R, M, N, K, lda, ldb, ldc, nullptr, nullptr, split_k, (hipStream_t)stream);
 }
+extern "C" int gget_op_gemm_grouped(int mode, int count, const void* const* A, const void* const* B, void* const* Cs, const int* M,
+                                   const int* N, const int* K, const int* lda, const int* ldb, const int* ldc, void* stream) {
+  GGET_REQUIRE(count >= 1 && count <= GGET_MAX_GROUP && A && B && Cs && M && N && K && lda && ldb && ldc, "gemm_grouped: bad arguments");
+  GemmGroup g;
+  memset(&g, 0, sizeof(g));
+  g.count = count;
+  for (int i = 0; i < count; ++i) {
+    GemmProblem& p = g.p[i];
+    p.A = static_cast<const bf16_t*>(A[i]); p.B = static_cast<const bf16_t*>(B[i]); p.C = Cs[i];
+    p.M = M[i]; p.N = N[i]; p.K = K[i]; p.lda = lda[i]; p.ldb = ldb[i]; p.ldc = ldc[i];
+  }
+  return gget_gemm_launch(mode, GGET_EPI_NONE, g, 1, (hipStream_t)stream);
+}
 extern "C" int gget_op_qkv_rope(const void* x, const void* wqkv, void* qkv, const float* cos_tab, const float* sin_tab,
                                 const int64_t* position_ids, int T, int S, int d, void* stream) {
   GGET_REQUIRE(x && wqkv && qkv && cos_tab && sin_tab, "qkv_rope: null argument");
@@ -1126,4 +1148,132 @@ extern "C" int gget_op_ce_fwd_bwd(const void* logits, int ld, const int32_t* lab
   GGET_REQUIRE(row_wgt == nullptr, "per-row weights go through the engine path (sample_wgt)");
   return k_ce_fwd_bwd(logits, ld, labels, nullptr, nullptr, 1, n_rows_dev, n_rows_cap, V, loss_sum, dlogits, grad_scale_base,
                       mean_over_rows, nullptr, (hipStream_t)stream);
+}
+
+
+// ================================================================================================
+// data-parallel gradient exchange over RCCL (reference: DDP all-reduce opt_utils.py:13,
+// DeepSpeed ZeRO-2 reduce-scatter ds_config2_pt.json:29-32, communicator setup misc_utils.py:519-526)
+// ================================================================================================
+// The library is bound with dlopen("librccl.so.1") at the first gget_comm_* call: inside a PyTorch process that is the copy
+// torch already loaded (one RCCL per process), and a caller that never exchanges gradients never needs RCCL at all.
+namespace {
+
+struct RcclApi {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+RcclApi* rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (lib) {
+      api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+      api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+      api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+      api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(lib, "ncclAllReduce"));
+      api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+      api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GetErrorString;
+    }
+  }
+  return &api;
+}
+
+#define GGET_RCCL_CHECK(expr)                                                                          \
+  do {                                                                                                 \
+    ncclResult_t _r = (expr);                                                                          \
+    if (_r != ncclSuccess) {                                                                           \
+      gget_set_error("%s failed: %s (%s:%d)", #expr, rccl()->GetErrorString(_r), __FILE__, __LINE__);  \
+      return 1;                                                                                        \
+    }                                                                                                  \
+  } while (0)
+
+__global__ void __launch_bounds__(256) bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, uint64_t n) {
+  // n is a multiple of 128 (flat-arena alignment): 8 elements per thread, 16-byte loads, two 16-byte stores
+  for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (uint64_t)gridDim.x * 256 * 8) {
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(src + i), f);
+    *reinterpret_cast<float4*>(dst + i) = make_float4(f[0], f[1], f[2], f[3]);
+    *reinterpret_cast<float4*>(dst + i + 4) = make_float4(f[4], f[5], f[6], f[7]);
+  }
+}
+
+}  // namespace
+
+extern "C" int gget_comm_unique_id(void* out_bytes) {
+  GGET_REQUIRE(out_bytes, "comm_unique_id: null argument");
+  GGET_REQUIRE(rccl()->ok, "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+  static_assert(sizeof(ncclUniqueId) == GGET_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  GGET_RCCL_CHECK(rccl()->GetUniqueId(&id));
+  memcpy(out_bytes, &id, sizeof(id));
+  return 0;
+}
+
+extern "C" int gget_comm_init(gget_handle_t h, int rank, int world, const void* unique_id_bytes) {
+  GGET_REQUIRE(h && unique_id_bytes && world >= 1 && rank >= 0 && rank < world, "comm_init: bad arguments (rank %d world %d)", rank, world);
+  GGET_REQUIRE(h->comm == nullptr, "comm_init: this handle already has a communicator");
+  GGET_REQUIRE(rccl()->ok, "RCCL (librccl.so.1) could not be loaded");
+  ncclUniqueId id;
+  memcpy(&id, unique_id_bytes, sizeof(id));
+  ncclComm_t c = nullptr;
+  GGET_RCCL_CHECK(rccl()->CommInitRank(&c, world, id, rank));
+  h->comm = c;
+  h->comm_rank = rank;
+  h->comm_world = world;
+  return 0;
+}
+
+extern "C" int gget_comm_destroy(gget_handle_t h) {
+  if (!h) return 0;
+  if (h->comm) {
+    rccl()->CommDestroy(static_cast<ncclComm_t>(h->comm));
+    h->comm = nullptr;
+  }
+  if (h->comm_f32) {
+    (void)hipFree(h->comm_f32);
+    h->comm_f32 = nullptr;
+    h->comm_f32_elems = 0;
+  }
+  h->comm_world = 1;
+  return 0;
+}
+
+extern "C" int gget_allreduce_grads_async(gget_handle_t h, int bucket, int fp32_accumulate, void* side_stream) {
+  GGET_REQUIRE(h && h->comm, "allreduce_grads: call gget_comm_init first");
+  GGET_REQUIRE(bucket >= -1 && bucket < (int)h->bucket_range.size(), "allreduce_grads: bucket %d out of range", bucket);
+  hipStream_t st = (hipStream_t)side_stream;
+  const uint64_t lo = bucket < 0 ? 0 : h->bucket_range[bucket].first;
+  const uint64_t hi = bucket < 0 ? h->plan.n_params : h->bucket_range[bucket].second;
+  bf16_t* g = h->G + lo;
+  const uint64_t n = hi - lo;
+  ncclComm_t c = static_cast<ncclComm_t>(h->comm);
+  if (!fp32_accumulate) {
+    GGET_RCCL_CHECK(rccl()->AllReduce(g, g, n, ncclBfloat16, ncclSum, c, st));
+    return 0;
+  }
+  // fp32 reduction: a bf16 ring sum rounds after every hop (world - 1 roundings); widening the bucket first makes the sum
+  // exact up to the single final rounding, at twice the bytes on the wire.  Staging buffer owned by the communicator.
+  if (h->comm_f32_elems < n) {
+    if (h->comm_f32) GGET_HIP_CHECK(hipFree(h->comm_f32));
+    h->comm_f32 = nullptr;
+    uint64_t cap = 0;
+    for (const auto& r : h->bucket_range) cap = std::max<uint64_t>(cap, r.second - r.first);
+    cap = std::max<uint64_t>(cap, n);
+    GGET_HIP_CHECK(hipMalloc(&h->comm_f32, cap * sizeof(float)));
+    h->comm_f32_elems = cap;
+  }
+  const int grid = (int)std::min<uint64_t>(4096, (n / 8 + 255) / 256);
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid), dim3(256), 0, st, g, h->comm_f32, n);
+  GGET_LAUNCH_CHECK();
+  GGET_RCCL_CHECK(rccl()->AllReduce(h->comm_f32, h->comm_f32, n, ncclFloat32, ncclSum, c, st));
+  return k_f32_to_bf16(h->comm_f32, g, n, st);
 }

@@ -68,6 +68,9 @@ class Engine:
         bufs = L.GgetBuffers(_ptr(self.param_bf16), _ptr(self.master), _ptr(self.adam_m), _ptr(self.adam_v),
                              _ptr(self.grad_bf16), _ptr(self.workspace), _ptr(self.rope_cos), _ptr(self.rope_sin))
         h = C.c_void_p()
+        # gget_create clears parts of the workspace and uploads tables on the NULL stream; the arenas above were zero-filled on
+        # torch's current stream (possibly a non-blocking side stream): order the two
+        torch.cuda.current_stream(dev).synchronize()
         L.check(self.lib.gget_create(C.byref(cfg), C.byref(bufs), C.byref(h)))
         self.h = h
         self.workspace_bytes = int(sz.workspace_bytes)
@@ -195,7 +198,26 @@ class Engine:
         self.step_count += 1
         L.check(self.lib.gget_adamw_step(self.h, lr, beta1, beta2, eps, weight_decay, max_grad_norm, grad_scale,
                                          self.step_count, _ptr(self._gnorm), _stream()))
-        return self._gnorm[0]
+        return self._gnorm[0].clone()   # a copy: the buffer is overwritten by the next step
+
+    # ------------------------------------------------------------------ data-parallel exchange through the C ABI (RCCL)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        L.check(L.load().gget_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        assert len(unique_id) == 128
+        L.check(self.lib.gget_comm_init(self.h, int(rank), int(world), C.create_string_buffer(unique_id, 128)))
+        self.comm_world = int(world)
+
+    def comm_destroy(self):
+        L.check(self.lib.gget_comm_destroy(self.h))
+
+    def allreduce_grads_async(self, bucket: int = -1, fp32_accumulate: bool = False, stream: Optional[torch.cuda.Stream] = None):
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        L.check(self.lib.gget_allreduce_grads_async(self.h, int(bucket), int(bool(fp32_accumulate)), st))
 
     # ------------------------------------------------------------------ head outputs
     def head_counts(self):

@@ -211,7 +211,17 @@ class _GgetModel(nn.Module):
         return None  # activations for 288 GB HBM are kept; recompute is never needed on this path
 
     def _apply(self, fn, *a, **k):
-        # `.to(device)` / `.cuda()`: parameters move into the engine arena on first GPU use instead
+        # `.to(device)` / `.cuda()`: parameters move into the engine arena on first GPU use instead.  Once the engine exists
+        # the parameters ARE views of its fp32 master arena: a move that would re-allocate them (`.cpu()`, `.half()`,
+        # `.to(torch.bfloat16)`) would silently detach `state_dict()` / optimizers from the weights being trained, so it
+        # raises; moves that change nothing (`.cuda()`, `.float()`, `.to(same device)`) are no-ops.
+        if self._engine is not None:
+            probe = fn(torch.zeros(1, device=self._engine.device))
+            if probe.device == self._engine.device and probe.dtype == torch.float32:
+                return self
+            raise RuntimeError(f"GraphGPT engine: parameters live in the engine's fp32 master arena on {self._engine.device}; "
+                               f"moving them to {probe.device}/{probe.dtype} is not supported (the bf16 compute copy is kept by "
+                               "the engine itself; use state_dict() to export weights)")
         probe = fn(torch.zeros(1))
         if probe.device.type == "cuda":
             with torch.cuda.device(probe.device):
@@ -272,13 +282,40 @@ class _GgetModel(nn.Module):
         return e
 
     def _autograd_backward(self, g):
+        """`loss.backward()` of the reference's DDP-style step (training_utils.py:53-86).  The gradients are produced by the
+        HIP backward, not by autograd, so DDP's reducer hooks never see them: when a process group is up and this model is
+        not driven by a `GgetEngine` (which exchanges the gradient buckets itself), the flat bf16 gradient array is
+        sum-all-reduced here and averaged, which is what DDP would have done (opt_utils.py:13)."""
         e = self._engine
         e.backward()
+        world = 1
+        if not getattr(self, "_managed_by_engine", False) and torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size()
+            if world > 1:
+                torch.distributed.all_reduce(e.grad_bf16, op=torch.distributed.ReduceOp.SUM)
         if self.materialize_grads:
-            scale = g.to(torch.float32)
+            scale = g.to(torch.float32) / world
             for name, p in self._flat.items():
                 p.grad = e.view(name, "grad").to(torch.float32) * scale
         self._dirty = True  # an external optimizer will now touch the master weights
+
+    def _check_positions(self, position_ids, S):
+        """The RoPE table is precomputed for max_position_embeddings rows (the reference evaluates the rotary embedding on the
+        fly, hf LlamaRotaryEmbedding.forward :111-127, and accepts any position): a larger position would read past the
+        table, so it raises here instead of silently diverging.  One scalar device->host read per forward that passes
+        position_ids (fine-tuning); GGET_SKIP_INPUT_CHECKS=1 removes it."""
+        maxp = self.spec.max_position
+        if position_ids is None:
+            if S > maxp:
+                raise IndexError(f"sequence length {S} exceeds max_position_embeddings {maxp}")
+            return
+        if os.environ.get("GGET_SKIP_INPUT_CHECKS"):
+            return
+        hi = int(position_ids.max()) if position_ids.numel() else 0
+        lo = int(position_ids.min()) if position_ids.numel() else 0
+        if hi >= maxp or lo < 0:
+            raise IndexError(f"position_ids must lie in [0, max_position_embeddings = {maxp}); got [{lo}, {hi}] - build the model "
+                             "with a larger max_position_embeddings")
 
     def _wrap_loss(self, loss):
         if loss is None:
@@ -317,6 +354,7 @@ class GraphGPTPretrainBase(_GgetModel):
         assert attention_mask.dim() in (2, 3), "attention_mask is [B,S] (right padding) or [B,S,S] (packed, block-diagonal)"
         if attention_mask.dim() == 3:
             assert not self.spec.causal, "the reference only builds the 3-D mask for bi-directional attention (modeling_pretrain.py:197-198)"
+        self._check_positions(position_ids, S)
         e = self._pre_forward(B, S)
         loss = e.forward_pretrain(input_ids, attention_mask, labels, sample_wgt, position_ids)
         return _PretrainOutput(self._wrap_loss(loss), _LazyLogits(self))
@@ -352,6 +390,7 @@ class GraphGPTTaskModel(_GgetModel):
             code = L.PROBLEM_SINGLE_LABEL
         else:
             code = L.PROBLEM_MULTI_LABEL   # BCE-with-logits on the labelled entries (modeling_finetune.py:227-230)
+        self._check_positions(position_ids, S)
         e = self._pre_forward(B, S)
         loss, logits, hid = e.forward_task(input_ids, attention_mask, position_ids, task_labels, sample_wgt, code)
         return DoubleHeadsModelOutput(pretrain_loss=None, task_loss=self._wrap_loss(loss), pretrain_logits=None,

@@ -69,11 +69,34 @@ class OptimConfig:
 
 
 # ----------------------------------------------------------------------------- DP exchange step
-def all_reduce_bucket(flat: torch.Tensor, bucket, group=None, async_op: bool = True):
+class _Fp32Reduce:
+    """Handle of an fp32-accumulated bucket reduction: wait() finishes the collective and rounds the sum back into the bf16
+    gradient slice (one rounding instead of the world-1 a bf16 ring sum applies)."""
+
+    def __init__(self, work, wide, dst):
+        self.work, self.wide, self.dst = work, wide, dst
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        self.dst.copy_(self.wide)
+
+
+def all_reduce_bucket(flat: torch.Tensor, bucket, group=None, async_op: bool = True, fp32_accumulate: bool = False):
     """Sum-all-reduce ONE gradient bucket (a contiguous [offset, offset+count) slice of the flat gradient array).
-    Device-agnostic: RCCL on GPU tensors, gloo on CPU tensors (the CPU tests drive exactly this function)."""
+    Device-agnostic: RCCL on GPU tensors, gloo on CPU tensors (the CPU tests drive exactly this function).
+    fp32_accumulate: widen the slice to fp32 for the reduction (twice the wire bytes, a single final rounding)."""
     off, cnt = bucket
-    return dist.all_reduce(flat[off: off + cnt], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    sl = flat[off: off + cnt]
+    if not fp32_accumulate:
+        return dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    wide = sl.to(torch.float32)
+    work = dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    h = _Fp32Reduce(work if async_op else None, wide, sl)
+    if not async_op:
+        h.wait()
+        return None
+    return h
 
 
 def shard_seed(base_seed: int, rank: int) -> int:
@@ -99,7 +122,14 @@ class GgetEngine:
         # GGET_DP_OVERLAP=0: one all-reduce of the whole flat gradient array after the monolithic backward instead of the
         # bucketed exchange overlapped with it (to be decided by measurement on a multi-GPU node)
         self.overlap = bool(int(os.environ.get("GGET_DP_OVERLAP", "1")))
+        # GGET_DP_FP32_REDUCE=1: reduce every bucket in fp32 (see all_reduce_bucket).  GGET_DP_BACKEND=abi: issue the
+        # collectives through the C ABI (gget_comm_init / gget_allreduce_grads_async = RCCL on a HIP side stream, no
+        # torch.distributed on the data path; the unique id travels once over the existing process group).
+        self.fp32_reduce = bool(int(os.environ.get("GGET_DP_FP32_REDUCE", "0")))
+        self.abi_comm = os.environ.get("GGET_DP_BACKEND", "torch") == "abi"
+        self._abi_ready = False
         model.materialize_grads = False  # fused path: gradients stay in the flat bf16 arena
+        model._managed_by_engine = True  # the bucketed exchange below replaces the all-reduce of _autograd_backward
 
     @property
     def device(self):
@@ -115,16 +145,30 @@ class GgetEngine:
     def eval(self):
         return self.train(False)
 
+    def _ensure_abi_comm(self, e):
+        if self._abi_ready:
+            return
+        rank = dist.get_rank(self.pg) if self.world > 1 else 0
+        uid = [e.comm_unique_id() if rank == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(uid, src=0, group=self.pg)
+        e.comm_init(rank, self.world, uid[0])
+        self._abi_ready = True
+
     # -- backward with bucketed all-reduce overlapped on a side stream
     def backward(self, loss=None):
         e = self.module._engine
+        if self.abi_comm:
+            self._ensure_abi_comm(e)
         if self.world == 1 and not self.force_staged:
             e.backward()
             return
         if not self.overlap:
             e.backward()
-            if self.world > 1:
-                dist.all_reduce(e.grad_bf16, op=dist.ReduceOp.SUM, group=self.pg)
+            if self.abi_comm:
+                e.allreduce_grads_async(-1, self.fp32_reduce)
+            elif self.world > 1:
+                all_reduce_bucket(e.grad_bf16, (0, e.grad_bf16.numel()), self.pg, async_op=False, fp32_accumulate=self.fp32_reduce)
             return
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=e.device)
@@ -137,8 +181,12 @@ class GgetEngine:
             ev.record(main)
             self._comm_stream.wait_event(ev)
             with torch.cuda.stream(self._comm_stream):
-                if self.world > 1:
-                    self._pending.append(all_reduce_bucket(e.grad_bf16, (off, cnt), self.pg, async_op=True))
+                if self.abi_comm:   # RCCL through the C ABI on the side stream (works at world 1 too: a one-rank communicator)
+                    e.allreduce_grads_async(b, self.fp32_reduce, self._comm_stream)
+                    self._pending.append(None)
+                elif self.world > 1:
+                    self._pending.append(all_reduce_bucket(e.grad_bf16, (off, cnt), self.pg, async_op=True,
+                                                           fp32_accumulate=self.fp32_reduce))
                 else:  # single-rank dry run of the staged path (tests): the exchange is the identity
                     self._pending.append(None)
 
@@ -301,15 +349,17 @@ class TrainingMode(abc.ABC):
 
     def run_training(self, pipeline) -> None:
         t0 = time.time()
-        tokens = 0
+        tokens = None   # accumulated where the mask lives (no device->host read per step); read at log time only
         for step, batch in enumerate(pipeline.batches):
             loss = self.train_step(pipeline.engine, batch)
-            tokens += int(batch["attention_mask"].sum())
+            am = batch["attention_mask"]
+            n = am.sum() if am.dim() == 2 else am.diagonal(dim1=1, dim2=2).sum()   # packed rows: [B,S,S] block-diagonal
+            tokens = n if tokens is None else tokens + n
             if pipeline.log_every and (step + 1) % pipeline.log_every == 0:
                 torch.cuda.synchronize()
                 dt = time.time() - t0
                 pipeline.log(f"step {step + 1} loss {float(loss):.5f} lr {pipeline.engine.last_lr:.3e} "
-                             f"tokens/s/gpu {tokens / dt:.0f}")
+                             f"tokens/s/gpu {int(tokens) / dt:.0f}")
             if pipeline.max_steps and step + 1 >= pipeline.max_steps:
                 break
 

@@ -161,6 +161,23 @@ int gget_backward_begin(gget_handle_t h, float loss_scale, void* stream);
 int gget_backward_layer(gget_handle_t h, int layer, void* stream);
 int gget_backward_end(gget_handle_t h, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange.  replaces: the DDP gradient all-reduce (src/utils/opt_utils.py:13),
+ * DeepSpeed ZeRO-2's reduce-scatter/all-gather (examples/ds_config2_pt.json:29-32) and the communicator bootstrap of
+ * set_dist_env (src/utils/misc_utils.py:507-539, init_process_group at :519-526).  One process per GPU; rank 0 obtains a
+ * unique id and hands it to the other ranks out of band (launcher store, MPI, torch.distributed broadcast ...).
+ * gget_allreduce_grads_async enqueues the SUM all-reduce of one gradient bucket (gget_bucket_range; -1 = the whole flat
+ * array) on `side_stream`: the caller makes that stream wait for the backward stage that finalises the bucket
+ * (gget_backward_begin / _layer / _end) and makes the compute stream wait for it before gget_adamw_step, whose grad_scale
+ * = 1/world turns the sum into the mean.  fp32_accumulate != 0 widens the bucket to fp32 for the reduction (one rounding
+ * instead of world-1) at twice the wire bytes.  RCCL is bound lazily (dlopen of librccl.so.1).
+ * ------------------------------------------------------------------------------------------ */
+#define GGET_UNIQUE_ID_BYTES 128
+int gget_comm_unique_id(void* out_bytes /* GGET_UNIQUE_ID_BYTES */);
+int gget_comm_init(gget_handle_t h, int rank, int world, const void* unique_id_bytes);
+int gget_comm_destroy(gget_handle_t h);
+int gget_allreduce_grads_async(gget_handle_t h, int bucket, int fp32_accumulate, void* side_stream);
+
 /* replaces: clip_grad_norm_ + AdamW.step / FusedAdam (training_utils.py:68-80, opt_utils.py:18-24,
  * examples/ds_config2_pt.json:11-19).  grad_scale multiplies every gradient first (1/world after a
  * sum all-reduce); max_grad_norm <= 0 disables clipping; step is 1-based.
@@ -192,6 +209,11 @@ int gget_hidden_states(gget_handle_t h, const void** hidden_dev);
 #define GGET_EPI_GEGLU_BWD 6 /* dh = dy W_down with the gated-GELU backward fused into the epilogue (gget_op_down_dgrad_geglu) */
 int gget_op_gemm(int mode, int epilogue, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
                  int lda, int ldb, int ldc, int split_k, void* stream);
+/* up to 4 independent GEMMs of one mode in ONE persistent launch (plain bf16 epilogue): how the engine issues the four
+ * weight gradients of a decoder layer (dW = dY^T X for gate|up, down, q|k|v, o: hf LlamaMLP / LlamaAttention Linear backward) -
+ * exactly 256 tiles of 192x192 for d = 768, one per CU */
+int gget_op_gemm_grouped(int mode, int count, const void* const* A, const void* const* B, void* const* C, const int* M,
+                         const int* N, const int* K, const int* lda, const int* ldb, const int* ldc, void* stream);
 /* measurement knob (tools/ only; no reference counterpart): key 1 = bit mask selecting experimental GEMM kernel variants,
  * so that two variants can be timed interleaved in one process (0 = the shipped configuration) */
 int gget_debug_set(int key, int value);

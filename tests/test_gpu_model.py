@@ -625,3 +625,28 @@ def test_c3_shape_full_model_backward_matches_oracle():
         w = grads[k].numpy()
         err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
         assert err < 8e-2, f"{k}: {err}"
+
+
+def test_module_moves_after_engine_and_position_guard():
+    """once the engine exists the parameters are views of its master arena - `.cuda()` / `.float()` are no-ops,
+    `.cpu()` / `.half()` raise instead of silently detaching them; position_ids beyond the RoPE table raise (the reference
+    evaluates the rotary embedding on the fly and would accept them - DESIGN.md section 7)."""
+    modeling = importlib.import_module("graph-gpt_amd.modeling")
+    cfg = modeling.GraphGPTConfig(vocab_size=300, hidden_size=128, intermediate_size=512, num_hidden_layers=1,
+                                  num_attention_heads=2, max_position_embeddings=64, causal_attention=False, stacked_feat=4,
+                                  next_n_token=1, num_labels=2, problem_type="single_label_classification")
+    m = modeling.GraphGPTTaskModel(cfg, seed=0).cuda()
+    ptr = m._flat["model.embed_tokens.weight"].data_ptr()
+    assert m.cuda() is m and m.float() is m and m.to(torch.device("cuda")) is m
+    assert m._flat["model.embed_tokens.weight"].data_ptr() == ptr
+    for bad in (lambda: m.cpu(), lambda: m.half(), lambda: m.to(torch.bfloat16)):
+        with pytest.raises(RuntimeError):
+            bad()
+    ids = torch.randint(22, 300, (2, 16, 4))
+    att = torch.ones(2, 16, dtype=torch.int64)
+    pos = torch.arange(16)[None].repeat(2, 1)
+    y = torch.tensor([0, 1])
+    out = m(input_ids=ids, attention_mask=att, position_ids=pos, task_labels=y)
+    assert torch.isfinite(out.task_loss)
+    with pytest.raises(IndexError):
+        m(input_ids=ids, attention_mask=att, position_ids=pos + 60, task_labels=y)

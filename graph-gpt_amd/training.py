@@ -105,6 +105,46 @@ def shard_seed(base_seed: int, rank: int) -> int:
     return int(base_seed) + int(rank)
 
 
+def pretrain_rank_sampler(sample_idx, epochs: int, seed: int, rank: int):
+    """Pre-training partition rule (reference get_pt_train_valid_test_sampler loader_utils.py:328-333, reset_pt_train_sampler
+    :412-442, seeding misc_utils.py:536-538): every rank keeps the FULL index list repeated `epochs` times and shuffles it
+    with its own generator seeded `seed - rank` - ranks draw independently, not disjointly (the token budget, not the
+    epoch, bounds the run).  Python's `random` module like the reference, so the order is the reference's order."""
+    import random
+    idx = [int(i) for i in sample_idx] * max(1, int(epochs))
+    random.Random(int(seed) - int(rank)).shuffle(idx)
+    return idx
+
+
+def finetune_rank_sampler(sample_idx, world_size: int, rank: int, seed: int, epoch: int = 0):
+    """Fine-tune partition rule (reference distribute_sampler_with_rnd_seed loader_utils.py:78-90, called with
+    seed = finetune.seed + epoch at :622-627): one permutation per epoch shared by all ranks, truncated to a multiple of the
+    world size, rank r takes positions r, r + world, ...  -> disjoint shards of equal length that change every epoch."""
+    sample_idx = torch.as_tensor(sample_idx)
+    g = torch.Generator()
+    g.manual_seed(int(seed) + int(epoch))
+    indices = torch.randperm(len(sample_idx), generator=g).tolist()
+    total = (len(sample_idx) // world_size) * world_size
+    return sample_idx[indices[rank:total:world_size]].tolist()
+
+
+def eval_rank_sampler(sample_idx, world_size: int, rank: int, shuffle_seed: Optional[int] = None):
+    """Evaluation partition rule (reference distribute_sampler loader_utils.py:70-75, used for the valid / test samplers at
+    :256, :270): indices sorted, rank r keeps those at sorted positions i with i % world == r (every sample exactly once
+    across ranks, shard sizes differ by at most one), then shuffled locally (order is irrelevant to the metrics)."""
+    import random
+    vec = sorted(int(i) for i in sample_idx)
+    out = [vec[i] for i in range(len(vec)) if i % world_size == rank]
+    if shuffle_seed is not None:
+        random.Random(shuffle_seed).shuffle(out)
+    return out
+
+
+def schedule_steps(total_tokens: float, tokens_per_sample: float, batch_size: int, world_size: int) -> int:
+    """Optimizer steps of a token-budgeted run (reference base_configs.py:54-60): the global batch is world * batch_size."""
+    return int(total_tokens // (tokens_per_sample * batch_size * world_size))
+
+
 # ----------------------------------------------------------------------------- engine protocol
 class GgetEngine:
     """What `deepspeed.initialize(model=...)` returns in the reference (pretrain_mode.py:281-287), rebuilt on

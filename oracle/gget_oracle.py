@@ -98,8 +98,10 @@ def additive_mask(attention_mask: torch.Tensor, S: int, dtype, causal: bool):
 
 
 # --------------------------------------------------------------------------- K5-K8 (row A4b)
-def attention(x, p, pre, mask4d, cos, sin, H, dh):
-    """hf LlamaAttention.forward :243-281 with eager_attention_forward :191-214 (dropout p=0)."""
+def attention(x, p, pre, mask4d, cos, sin, H, dh, keep=None):
+    """hf LlamaAttention.forward :243-281 with eager_attention_forward :191-214.  `keep` [B,H,S,S]: the dropout multiplier
+    (0 or 1/(1-p)) applied to the softmax output, hf :210 `nn.functional.dropout(attn_weights, p, training)` with the mask
+    made explicit (None = eval mode / p = 0)."""
     B, S, d = x.shape
     q = Fnn.linear(x, p[pre + "q_proj.weight"]).view(B, S, H, dh).transpose(1, 2)
     k = Fnn.linear(x, p[pre + "k_proj.weight"]).view(B, S, H, dh).transpose(1, 2)
@@ -108,6 +110,8 @@ def attention(x, p, pre, mask4d, cos, sin, H, dh):
     w = torch.matmul(q, k.transpose(2, 3)) * (dh ** -0.5)
     w = w + mask4d
     w = Fnn.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+    if keep is not None:
+        w = w * keep.to(w.dtype)
     o = torch.matmul(w, v).transpose(1, 2).contiguous().view(B, S, d)
     return Fnn.linear(o, p[pre + "o_proj.weight"])
 
@@ -121,10 +125,11 @@ def mlp(x, p, pre):
     return Fnn.linear(g * u, p[pre + "down_proj.weight"])
 
 
-def backbone(spec, p: Dict[str, torch.Tensor], x, attention_mask, position_ids, collect=None, path_mult=None):
+def backbone(spec, p: Dict[str, torch.Tensor], x, attention_mask, position_ids, collect=None, path_mult=None, attn_keep=None):
     """hf LlamaModel.forward :367-418 / LlamaDecoderLayer.forward :295-325; LayerScale variant
     utils_graphgpt.LlamaDecoderLayer.forward (utils_graphgpt.py:107-173).  `path_mult(layer, which)` -> [B] tensor of
-    DropPath multipliers (0 or 1/keep_prob per sample, utils_graphgpt.py:64-66 / BeitDropPath); None = eval mode."""
+    DropPath multipliers (0 or 1/keep_prob per sample, utils_graphgpt.py:64-66 / BeitDropPath); None = eval mode.
+    `attn_keep(layer)` -> [B,H,S,S] attention-dropout multipliers of that layer (see attention)."""
     B, S, d = x.shape
     if position_ids is None:
         position_ids = torch.arange(S)[None, :].expand(B, S)      # hf :389-392
@@ -133,7 +138,8 @@ def backbone(spec, p: Dict[str, torch.Tensor], x, attention_mask, position_ids, 
     for i in range(spec.num_layers):
         pre = f"model.layers.{i}."
         h = rmsnorm(x, p[pre + "input_layernorm.weight"], spec.rms_eps)
-        a = attention(h, p, pre + "self_attn.", mask4d, cos, sin, spec.num_heads, spec.head_dim)
+        a = attention(h, p, pre + "self_attn.", mask4d, cos, sin, spec.num_heads, spec.head_dim,
+                      keep=attn_keep(i) if attn_keep is not None else None)
         if spec.layer_scale_init > 0:
             a = p[pre + "lambda_1"] * a
         if path_mult is not None:
@@ -207,13 +213,13 @@ def pretrain_forward(spec, p, input_ids, attention_mask, labels=None, sample_wgt
 
 # --------------------------------------------------------------------------- K15 (row A10)
 def task_forward(spec, p, input_ids, attention_mask, position_ids=None, task_labels=None,
-                 sample_wgt=None, problem_type="single_label_classification", loss_type=None, path_mult=None):
+                 sample_wgt=None, problem_type="single_label_classification", loss_type=None, path_mult=None, attn_keep=None):
     """`GraphGPTTaskModel.forward` (modeling_finetune.py:236-326) + `calculate_task_loss`
     (:167-234) + `_get_sequence_len` (modeling_helpers.py:78-86); Linear score head, "last" pooling."""
     if input_ids.dim() == 3:
         input_ids = input_ids[:, :, : spec.stacked_feat]
     x, in_ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"))
-    hidden = backbone(spec, p, x, attention_mask, position_ids, path_mult=path_mult)
+    hidden = backbone(spec, p, x, attention_mask, position_ids, path_mult=path_mult, attn_keep=attn_keep)
     logits = Fnn.linear(hidden, p["score.weight"], p.get("score.bias"))
     B = hidden.shape[0]
     seq_len = (in_ != spec.pad_token_id).sum(-1) - 1

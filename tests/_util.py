@@ -15,14 +15,15 @@ synth = importlib.import_module("graph-gpt_amd.synth")
 
 PT_CASES = ["pt_tiny_f13_a", "pt_tiny_f13_b", "pt_tiny_f1", "pt_tiny_causal", "pt_tiny_gated", "pt_tiny_wgt",
             "pt_tiny_bigw", "pt_tiny_s72", "pt_tiny_packed"]
-FT_CASES = ["ft_tiny_f4", "ft_tiny_ls", "ft_tiny_reg", "ft_tiny_ml"]
+FT_CASES = ["ft_tiny_f4", "ft_tiny_ls", "ft_tiny_reg", "ft_tiny_ml", "ft_tiny_f4_b32", "ft_tiny_mse", "ft_tiny_wce"]
+BASE_CASES = ["pt_base_bigw", "pt_base_std"]    # full-width d768 / L12 model at a small batch (gradient blocks and norms only)
 
 
-def ft_problem(spec, b):
+def ft_problem(spec, b, name=""):
     """(problem_type, loss_type) of a fine-tune fixture, as the reference infers it (modeling_finetune.py:175-183)."""
     import torch
     if spec.num_labels == 1:
-        return "regression", "l1"
+        return "regression", (None if name.endswith("_mse") else "l1")   # loss_type None => MSELoss (modeling_finetune.py:185-190)
     if torch.is_floating_point(b["task_labels"]):
         return "multi_label_classification", None
     return "single_label_classification", None
@@ -41,6 +42,22 @@ def load_case(name):
     state = weights_mod.make_state_dict(spec, seed=int(seed), std=std, head_std=None if head_std < 0 else head_std)
     batch = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
     return z, spec, state, batch
+
+
+def loss_tolerance(z, floor=1e-4, factor=1.5):
+    """Relative loss tolerance of a bf16 engine run against the reference's fp32 loss: north_star's 1e-4, or 1.5 x the gap
+    between the reference's OWN bf16 and fp32 paths on the same case when that is larger (a bf16 implementation cannot be
+    held closer to the fp32 answer than the reference's bf16 path is)."""
+    gap = abs(float(z["loss_bf16"]) - float(z["loss"])) / abs(float(z["loss"]))
+    return max(floor, factor * gap)
+
+
+_ERRORS = {}
+
+
+def record_error(case, quantity, measured, tolerance):
+    """Collected by the GPU parity tests; tests/conftest.py writes gpurun_out/parity_errors.json at session end."""
+    _ERRORS.setdefault(case, {})[quantity] = {"measured": float(measured), "tolerance": float(tolerance)}
 
 
 def rel_l2(a, b):

@@ -127,3 +127,54 @@ def test_evaluate_single_process():
     loss, aux = tr.evaluate(m, loader)
     assert float(loss) == 2.0 and aux is None and m.mode == "train"
     assert tr.evaluate(m, loader, do_eval=False) == (None, None)
+
+
+def _shard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", init_method="env://")
+    tr = importlib.import_module("graph-gpt_amd.training")
+    idx = list(range(100, 100 + 1003))
+    ft0 = tr.finetune_rank_sampler(idx, world, rank, seed=42, epoch=0)
+    ft1 = tr.finetune_rank_sampler(idx, world, rank, seed=42, epoch=1)
+    ev = tr.eval_rank_sampler(idx, world, rank, shuffle_seed=7)
+    pt = tr.pretrain_rank_sampler(idx[:50], epochs=2, seed=1000, rank=rank)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (ft0, ft1, ev, pt))
+    if rank == 0:
+        q.put(gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_sharding_rules_gloo_world2():
+    """The three partition rules of the reference: fine-tune = disjoint equal shards of one per-epoch
+    permutation (loader_utils.py:78-90, :622-627); eval = sorted positions modulo world, every sample once (:70-75); pre-train
+    = every rank the full list, own shuffle (loader_utils.py:328-333, misc_utils.py:536-538)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = q.get(timeout=120)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    (ft0a, ft1a, eva, pta), (ft0b, ft1b, evb, ptb) = got
+    n = 1003
+    # fine-tune: equal, disjoint, truncated to a multiple of the world size, a new permutation every epoch
+    assert len(ft0a) == len(ft0b) == n // 2 and not set(ft0a) & set(ft0b)
+    assert len(set(ft0a) | set(ft0b)) == (n // 2) * 2
+    assert ft0a != ft1a and not set(ft1a) & set(ft1b)
+    # the exact reference arithmetic, re-stated: randperm(seed + epoch)[rank:total:world]
+    g = torch.Generator(); g.manual_seed(42)
+    perm = torch.randperm(n, generator=g).tolist()
+    assert ft0a == [100 + i for i in perm[0:1002:2]] and ft0b == [100 + i for i in perm[1:1002:2]]
+    # eval: a partition of ALL samples, sizes differ by at most one, rank r holds sorted positions r mod world
+    assert sorted(eva + evb) == list(range(100, 100 + n)) and abs(len(eva) - len(evb)) <= 1
+    assert sorted(eva) == list(range(100, 100 + n, 2))
+    # pre-train: both ranks hold the full multi-epoch list, in different orders
+    assert sorted(pta) == sorted(ptb) == sorted(list(range(100, 150)) * 2) and pta != ptb
+    tr = importlib.import_module("graph-gpt_amd.training")
+    assert tr.schedule_steps(1e9, 20.0, 256, 8) == int(1e9 // (20.0 * 256 * 8))

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import ADAM, CLIP, FT_CASES, PT_CASES, ft_problem, load_case, rel_l2, tb
+from _util import ADAM, BASE_CASES, CLIP, FT_CASES, PT_CASES, ft_problem, load_case, loss_tolerance, record_error, rel_l2, tb
 from oracle import gget_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -24,28 +24,39 @@ def make_engine(spec, batch):
     return e
 
 
-def run_forward(e, spec, b, kind):
+def run_forward(e, spec, b, kind, name=""):
     if kind == "pt":
         loss = e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], b.get("wgt"))
         return loss, None
-    problem = {"regression": L.PROBLEM_REGRESSION_L1, "multi_label_classification": L.PROBLEM_MULTI_LABEL,
-               "single_label_classification": L.PROBLEM_SINGLE_LABEL}[ft_problem(spec, b)[0]]
-    loss, logits, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], None, problem)
+    pt_, lt_ = ft_problem(spec, b, name)
+    problem = {"regression": L.PROBLEM_REGRESSION_L1 if lt_ == "l1" else L.PROBLEM_REGRESSION_MSE,
+               "multi_label_classification": L.PROBLEM_MULTI_LABEL, "single_label_classification": L.PROBLEM_SINGLE_LABEL}[pt_]
+    loss, logits, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], b.get("wgt"), problem)
     return loss, logits
 
 
-def oracle_fn(spec, b, kind):
+def oracle_fn(spec, b, kind, name=""):
     if kind == "pt":
         return (lambda p: O.pretrain_forward(spec, p, b["input_ids"], b["attention_mask"], b["labels"], b.get("wgt"))), \
             "head1_loss", "head1_logits"
-    problem, loss_type = ft_problem(spec, b)
+    problem, loss_type = ft_problem(spec, b, name)
     return (lambda p: O.task_forward(spec, p, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"],
-                                     problem_type=problem, loss_type=loss_type)), "task_loss", "task_logits"
+                                     sample_wgt=b.get("wgt"), problem_type=problem, loss_type=loss_type)), "task_loss", "task_logits"
 
 
-# loss tolerance: north_star asks 1e-4 relative on bf16; the reference's OWN bf16 path is 1.3e-4 away from its fp32
-# path on the big-weight S=72 case, so big-weight cases get 6e-4.
-LOSS_TOL = {"pt_tiny_bigw": 6e-4, "pt_tiny_s72": 6e-4, "pt_tiny_packed": 6e-4, "ft_tiny_f4": 3e-3, "ft_tiny_ls": 3e-2, "ft_tiny_reg": 8e-3, "ft_tiny_ml": 3e-3}
+# Loss tolerance (tests/_util.py:loss_tolerance): north_star's 1e-4 relative, or 1.5 x the gap between the reference's OWN
+# bf16 and fp32 losses on the case when that is larger.  Two cases get an explicit floor on top of that rule, each with its
+# reason; every measured error is recorded next to its tolerance (gpurun_out/parity_errors.json -> profiles/).
+LOSS_FLOOR = {
+    # 4-sample CE / L1 losses whose reference bf16 path happens to land within 1e-5 of fp32 by cancellation: the rule's
+    # tolerance collapses to 1e-4 although every pooled logit carries bf16 noise of ~4e-3 relative
+    "ft_tiny_ls": 4e-3, "ft_tiny_reg": 4e-3, "ft_tiny_f4": 2e-3, "ft_tiny_ml": 2e-3,
+    # MSE over 32 pooled rows: (pred - y)^2 doubles the relative error of pred (measured max-abs logit error 8e-3, like the
+    # other heads), while the reference's bf16 loss lands 5.6e-4 from fp32 by cancellation across the rows
+    "ft_tiny_mse": 4e-3,
+}
+# fine-tune losses are means over B pooled rows only (no averaging over thousands of masked cells): factor 2 instead of 1.5
+FT_FACTOR = 2.0
 
 
 @pytest.mark.parametrize("name", PT_CASES + FT_CASES)
@@ -55,11 +66,13 @@ def test_forward_matches_reference(name):
     b = tb(batch)
     e = make_engine(spec, batch)
     e.load_state_dict(state)
-    loss, tlogits = run_forward(e, spec, b, kind)
+    loss, tlogits = run_forward(e, spec, b, kind, name)
     torch.cuda.synchronize()
     got = float(loss.item())
     want = float(z["loss"])
-    tol = LOSS_TOL.get(name, 1e-4)
+    tol = max(loss_tolerance(z, factor=1.5 if kind == "pt" else FT_FACTOR), LOSS_FLOOR.get(name, 0.0))
+    record_error(name, "loss_rel_vs_reference_fp32", abs(got - want) / abs(want), tol)
+    record_error(name, "reference_bf16_vs_fp32_loss_gap", abs(float(z["loss_bf16"]) - want) / abs(want), float("nan"))
     assert abs(got - want) <= tol * abs(want) + 1e-6, f"{name}: loss {got} vs reference fp32 {want} (bf16 ref {float(z['loss_bf16'])})"
     if kind == "pt":
         M, Lm = e.head_counts()
@@ -68,30 +81,32 @@ def test_forward_matches_reference(name):
         assert lg.shape == tuple(int(x) for x in z["logits_shape"])
         err = rel_l2(lg[:64], z["logits"])
         ref_err = rel_l2(z["logits_bf16"], z["logits"])
+        record_error(name, "logits_rel_l2_vs_reference_fp32", err, max(2.5 * ref_err, 1.5e-2))
         assert err < max(2.5 * ref_err, 1.5e-2), f"{name}: logits rel-L2 {err} (reference bf16-vs-fp32 {ref_err})"
     else:
-        err = np.abs(tlogits.cpu().numpy() - z["logits"]).max()
+        err = np.abs(tlogits.cpu().numpy()[:64] - z["logits"]).max()
         ref_err = np.abs(z["logits_bf16"] - z["logits"]).max()
+        record_error(name, "task_logits_max_abs_vs_reference_fp32", err, max(3 * ref_err, 2e-2))
         assert err < max(3 * ref_err, 2e-2), f"{name}: task logits max-abs {err} (reference bf16-vs-fp32 {ref_err})"
 
 
 @pytest.mark.parametrize("name", ["pt_tiny_f13_a", "pt_tiny_f1", "pt_tiny_causal", "pt_tiny_gated", "pt_tiny_wgt",
                                   "pt_tiny_bigw", "pt_tiny_s72", "pt_tiny_packed", "ft_tiny_f4", "ft_tiny_ls", "ft_tiny_reg",
-                                  "ft_tiny_ml"])
+                                  "ft_tiny_ml", "ft_tiny_f4_b32", "ft_tiny_mse", "ft_tiny_wce"])
 def test_backward_matches_oracle(name):
     z, spec, state, batch = load_case(name)
     kind = "pt" if name.startswith("pt") else "ft"
     b = tb(batch)
     e = make_engine(spec, batch)
     e.load_state_dict(state)
-    run_forward(e, spec, b, kind)
+    run_forward(e, spec, b, kind, name)
     e.backward()
     torch.cuda.synchronize()
     got = {k: v.float().cpu().numpy() for k, v in e.grads().items()}
     # oracle on the bf16-rounded weights (what the engine computes with), fp32 arithmetic
     st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
     p = O.to_params(st_bf, torch.float32)
-    fn, lk, _ = oracle_fn(spec, b, kind)
+    fn, lk, _ = oracle_fn(spec, b, kind, name)
     _, grads = O.loss_and_grads(fn, p, lk)
     worst = []
     gmax = max(float(np.linalg.norm(grads[k].numpy())) for k in state)
@@ -108,15 +123,25 @@ def test_backward_matches_oracle(name):
         worst.append((err, k))
     worst.sort(reverse=True)
     # bf16 activations/gradients through L layers: a few 1e-2 relative per tensor
+    record_error(name, "worst_gradient_rel_l2_vs_oracle (" + worst[0][1] + ")", worst[0][0], 6e-2)
     assert worst[0][0] < 6e-2, f"{name}: worst gradient rel-L2 {worst[:4]}"
+    # q / k projections judged on their OWN norm wherever it is not negligible (big-weight cases: attention far from uniform)
+    for k in ("model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.k_proj.weight",
+              "model.layers.1.self_attn.q_proj.weight", "model.layers.1.self_attn.k_proj.weight"):
+        w = grads[k].numpy()
+        if np.linalg.norm(w) >= 2e-3 * gmax:
+            err = rel_l2(got[k], w)
+            record_error(name, "grad_rel_l2_own_norm " + k, err, 6e-2)
+            assert err < 6e-2, f"{name}: {k} rel-L2 {err} on its own norm ({np.linalg.norm(w) / gmax:.1e} of the largest)"
     # the three tensors the fixtures keep from the REAL reference
     for key, arr in (("model.embed_tokens.weight", "grad_embed"), ("model.layers.0.self_attn.q_proj.weight", "grad_l0_q"),
                      ("model.layers.1.mlp.down_proj.weight", "grad_l1_down")):
         err = rel_l2(got[key], z[arr])
+        record_error(name, "grad_rel_l2_vs_reference " + key, err, 6e-2)
         assert err < 6e-2, f"{name}: {key} vs reference gradient rel-L2 {err}"
 
 
-@pytest.mark.parametrize("name", ["pt_tiny_f13_a", "pt_tiny_bigw", "pt_tiny_wgt", "ft_tiny_f4"])
+@pytest.mark.parametrize("name", ["pt_tiny_f13_a", "pt_tiny_bigw", "pt_tiny_wgt", "ft_tiny_f4", "ft_tiny_mse", "ft_tiny_wce"])
 def test_adamw_trajectory(name):
     z, spec, state, batch = load_case(name)
     kind = "pt" if name.startswith("pt") else "ft"
@@ -125,15 +150,17 @@ def test_adamw_trajectory(name):
     e.load_state_dict(state)
     losses, gns = [], []
     for _ in range(3):
-        loss, _ = run_forward(e, spec, b, kind)
+        loss, _ = run_forward(e, spec, b, kind, name)
         losses.append(float(loss.item()))
         e.backward()
         gns.append(float(e.adamw_step(ADAM["lr"], ADAM["beta1"], ADAM["beta2"], ADAM["eps"], ADAM["wd"], CLIP).item()))
-    loss, _ = run_forward(e, spec, b, kind)
+    loss, _ = run_forward(e, spec, b, kind, name)
     losses.append(float(loss.item()))
     # clip-then-AdamW (training_utils.py:68-80): same loss curve as the reference within bf16 noise
+    record_error(name, "adamw_3step_losses_max_rel", float(np.max(np.abs(np.array(losses) - z["adamw_losses"]) / np.maximum(np.abs(z["adamw_losses"]), 2e-3 / (4e-3 if kind == "pt" else 6e-2)))), 4e-3 if kind == "pt" else 6e-2)
     np.testing.assert_allclose(losses, z["adamw_losses"], rtol=4e-3 if kind == "pt" else 6e-2, atol=2e-3)
-    np.testing.assert_allclose(gns, z["adamw_gnorms"], rtol=3e-2)
+    # (fine-tune cases overfit the one batch within a step: the later norms belong to losses of 1e-3 and move with bf16 noise)
+    np.testing.assert_allclose(gns, z["adamw_gnorms"], rtol=3e-2 if kind == "pt" else 6e-2)
     fin = np.array([float(e.view(k, "master").float().norm()) for k in state])
     np.testing.assert_allclose(fin, z["adamw_final_norms"], rtol=2e-3)
 
@@ -650,3 +677,153 @@ def test_module_moves_after_engine_and_position_guard():
     assert torch.isfinite(out.task_loss)
     with pytest.raises(IndexError):
         m(input_ids=ids, attention_mask=att, position_ids=pos + 60, task_labels=y)
+
+
+@pytest.mark.parametrize("name", BASE_CASES)
+def test_full_width_base_model_matches_reference(name):
+    """The architecture of the headline run (base: d768 / L12 / ff3072, F=13, V=756) against outputs of the REAL reference at a
+    small batch (tools/make_golden.py pt_base_*): standard init, and big weights (std 0.06 / heads 0.15: loss far from ln V,
+    attention far from uniform, q/k gradients of ordinary size).  Loss held to max(1e-4, 1.5 x the reference's own bf16-vs-fp32
+    gap); every per-parameter gradient norm and 64x64 gradient blocks of q / k / gate / down projections against the
+    reference's; then three clip + AdamW steps against the reference's loss trajectory."""
+    z, spec, state, batch = load_case(name)
+    b = tb(batch)
+    e = make_engine(spec, batch)
+    e.load_state_dict(state)
+    loss, _ = run_forward(e, spec, b, "pt")
+    e.backward()
+    torch.cuda.synchronize()
+    got, want = float(loss.item()), float(z["loss"])
+    tol = loss_tolerance(z)
+    record_error(name, "loss_rel_vs_reference_fp32", abs(got - want) / abs(want), tol)
+    record_error(name, "reference_bf16_vs_fp32_loss_gap", abs(float(z["loss_bf16"]) - want) / abs(want), float("nan"))
+    assert abs(got - want) <= tol * abs(want), f"{name}: loss {got} vs reference fp32 {want} (reference bf16 {float(z['loss_bf16'])})"
+    lg = e.head_logits().float().cpu().numpy()
+    err, ref_err = rel_l2(lg[:64], z["logits"]), rel_l2(z["logits_bf16"], z["logits"])
+    record_error(name, "logits_rel_l2_vs_reference_fp32", err, max(2.5 * ref_err, 1.5e-2))
+    assert err < max(2.5 * ref_err, 1.5e-2), (err, ref_err)
+    grads = e.grads()
+    names = list(state.keys())
+    gn = np.array([float(grads[n].float().norm()) for n in names])
+    ref = z["grad_norms"]
+    big = ref >= 1e-3 * ref.max()
+    worst = float(np.max(np.abs(gn[big] - ref[big]) / ref[big]))
+    record_error(name, "per_parameter_grad_norm_max_rel (norm >= 1e-3 of the largest)", worst, 5e-2)
+    assert worst < 5e-2, [(names[i], gn[i], ref[i]) for i in np.argsort(-np.abs(gn - ref) / np.maximum(ref, 1e-3 * ref.max()))[:4]]
+    for tag, pn in (("l0_q", "model.layers.0.self_attn.q_proj.weight"), ("l0_k", "model.layers.0.self_attn.k_proj.weight"),
+                    ("l11_q", "model.layers.11.self_attn.q_proj.weight"), ("l11_k", "model.layers.11.self_attn.k_proj.weight"),
+                    ("l5_down", "model.layers.5.mlp.down_proj.weight"), ("l5_gate", "model.layers.5.mlp.gate_proj.weight")):
+        blk = grads[pn].float().cpu().numpy()[:64, :64]
+        ref_blk = z["gradblk_" + tag]
+        err = rel_l2(blk, ref_blk)
+        ref_err = rel_l2(z["gradblk_bf16_" + tag], ref_blk)      # the reference's own bf16 backward on the same block
+        tolb = max(6e-2, 1.5 * ref_err)
+        record_error(name, f"grad_block_rel_l2_own_norm {pn}[:64,:64]", err, tolb)
+        record_error(name, f"reference_bf16_vs_fp32 grad_block {pn}[:64,:64]", ref_err, float("nan"))
+        assert err < tolb, f"{name}: {pn} block rel-L2 {err}"
+    # three optimiser steps on the same batch: loss after each step against the reference trajectory
+    losses = [got]
+    e.adamw_step(ADAM["lr"], ADAM["beta1"], ADAM["beta2"], ADAM["eps"], ADAM["wd"], CLIP)
+    for _ in range(2):
+        l_, _ = run_forward(e, spec, b, "pt")
+        losses.append(float(l_.item()))
+        e.backward()
+        e.adamw_step(ADAM["lr"], ADAM["beta1"], ADAM["beta2"], ADAM["eps"], ADAM["wd"], CLIP)
+    l_, _ = run_forward(e, spec, b, "pt")
+    losses.append(float(l_.item()))
+    rel = np.abs(np.array(losses) - z["adamw_losses"]) / np.abs(z["adamw_losses"])
+    # standard init: 5e-3.  The big-weight model sits at a loss of 55 where Adam's sign-like first steps (lr 1e-3 on every
+    # weight) move the loss by 3-5 per step: gradient noise of a few % on near-zero entries flips update signs -> 2e-2
+    ttol = 5e-3 if name == "pt_base_std" else 2e-2
+    record_error(name, "loss_after_3_adamw_steps_rel_vs_reference", float(rel[-1]), ttol)
+    record_error(name, "adamw_trajectory_losses_max_rel", float(rel.max()), ttol)
+    assert rel.max() < ttol, (losses, z["adamw_losses"])
+
+
+def test_c4_long_sequence_full_model_backward_matches_oracle():
+    """Full 12-layer forward + BACKWARD at S = 2048 (C4 / C5 of BASELINE.json: base model, F = 4, V = 41245), B = 1, against the
+    oracle: loss, pooled logits and the gradients of representative tensors of the first / middle / last layer, the score
+    head and the embedding (multi-wave attention backward over 64 key tiles inside the full model, not only at op level)."""
+    from _util import spec_mod, weights_mod, synth
+    B, S, F, V = 1, 2048, 4, 41245
+    spec = spec_mod.spec_from_size("base", kind=spec_mod.KIND_TASK, vocab_size=V, stacked_feat=F, next_n_token=1, num_labels=2,
+                                   max_position=2048)
+    state = weights_mod.make_state_dict(spec, seed=8, std=0.04, head_std=0.1)
+    batch = synth.make_task_batch(B=B, S=S, F=F, V=V, seed=93, lengths="full")
+    batch["task_labels"][:] = 1
+    b = tb(batch)
+    e = make_engine(spec, batch)
+    e.load_state_dict(state)
+    loss, logits = run_forward(e, spec, b, "ft")
+    e.backward()
+    torch.cuda.synchronize()
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32)
+    fn, lk, gk = oracle_fn(spec, b, "ft")
+    out, grads = O.loss_and_grads(fn, p, lk)
+    want = out[lk].item()
+    record_error("c4_S2048_B1_backward", "loss_rel_vs_oracle", abs(float(loss) - want) / max(abs(want), 0.1), 3e-2)
+    assert abs(float(loss) - want) <= 3e-2 * max(abs(want), 0.1), (float(loss), want)
+    got = e.grads()
+    gmax = max(float(g.norm()) for g in grads.values())
+    for k in ("score.weight", "model.layers.11.mlp.down_proj.weight", "model.layers.11.self_attn.q_proj.weight",
+              "model.layers.6.self_attn.k_proj.weight", "model.layers.6.self_attn.v_proj.weight",
+              "model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.o_proj.weight",
+              "model.layers.0.mlp.gate_proj.weight", "model.layers.0.input_layernorm.weight", "model.embed_tokens.weight"):
+        w = grads[k].numpy()
+        err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        record_error("c4_S2048_B1_backward", "grad_rel_l2 " + k, err, 8e-2)
+        assert err < 8e-2, f"{k}: {err}"
+
+
+def _attn_drop_keep(seed, B, H, S, p):
+    """Python twin of drop_mul() in csrc/attention.hip (same as tests/test_gpu_ops.py:_drop_mask)."""
+    bh = np.arange(B * H, dtype=np.uint64)[:, None, None]
+    q = np.arange(S, dtype=np.uint64)[None, :, None]
+    k = np.arange(S, dtype=np.uint64)[None, None, :]
+    M32 = np.uint64(0xFFFFFFFF)
+    x = (np.uint64(seed) ^ ((bh * np.uint64(0x9E3779B1)) & M32)) & M32
+    x = (x + q * np.uint64(0x85EBCA77) + k * np.uint64(0xC2B2AE3D)) & M32
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x045D9F3B)) & M32
+    x ^= x >> np.uint64(16)
+    thresh = np.uint64(int(np.float32(p) * np.float32(16777216.0)))
+    keep = (x >> np.uint64(8)) >= thresh
+    return torch.from_numpy((keep.astype(np.float32) / (1.0 - p)).reshape(B, H, S, S))
+
+
+def test_c3_training_mode_dropouts_exact_mask():
+    """C3 as the ogbl-ppa scripts train it: base model with LayerScale, stochastic depth path_pdrop = 0.2 AND attention dropout
+    0.1, S = 256 (B = 4 so the CPU oracle finishes quickly).  Both masks are counter hashes; their Python twins feed the oracle
+    the exact masks the kernels used, so loss and gradients must agree like in eval mode."""
+    from _util import spec_mod, weights_mod, synth
+    B, S, F, V, seed, p_attn, p_path = 4, 256, 4, 41245, 4242, 0.1, 0.2
+    spec = spec_mod.spec_from_size("base", kind=spec_mod.KIND_TASK, vocab_size=V, stacked_feat=F, next_n_token=1, num_labels=2,
+                                   max_position=1024, layer_scale_init=1.0, path_pdrop=p_path)
+    state = weights_mod.make_state_dict(spec, seed=9, std=0.04, head_std=0.1)
+    batch = synth.make_task_batch(B=B, S=S, F=F, V=V, seed=94, lengths="uniform", min_len=S // 2)
+    b = tb(batch)
+    e = make_engine(spec, batch)
+    e.load_state_dict(state)
+    e.set_dropout(p_attn, p_path, seed)
+    loss, _, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], None, L.PROBLEM_SINGLE_LABEL)
+    e.backward()
+    torch.cuda.synchronize()
+    L_, H = spec.num_layers, spec.num_heads
+    pm = lambda l, w: _path_keep(seed, l, w, B, p_path * l / (L_ - 1))
+    ak = lambda l: _attn_drop_keep((seed + 0x9E37 * l) & 0xFFFFFFFF, B, H, S, p_attn)
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32)
+    out, grads = O.loss_and_grads(lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"],
+                                                           b["task_labels"], path_mult=pm, attn_keep=ak), p, "task_loss")
+    want = out["task_loss"].item()
+    record_error("c3_train_mode_dropouts", "loss_rel_vs_oracle_same_masks", abs(float(loss) - want) / max(abs(want), 0.1), 3e-2)
+    assert abs(float(loss) - want) <= 3e-2 * max(abs(want), 0.1), (float(loss), want)
+    got = e.grads()
+    gmax = max(float(g.norm()) for g in grads.values())
+    for k in ("score.weight", "model.layers.11.mlp.down_proj.weight", "model.layers.6.self_attn.q_proj.weight",
+              "model.layers.6.self_attn.v_proj.weight", "model.layers.0.lambda_1", "model.layers.11.lambda_2",
+              "model.layers.0.input_layernorm.weight", "model.embed_tokens.weight"):
+        w = grads[k].numpy()
+        err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        record_error("c3_train_mode_dropouts", "grad_rel_l2 " + k, err, 8e-2)
+        assert err < 8e-2, f"{k}: {err}"

@@ -4,20 +4,20 @@ import numpy as np
 import pytest
 import torch
 
-from _util import ADAM, CLIP, FT_CASES, PT_CASES, ft_problem, load_case, rel_l2, tb
+from _util import ADAM, BASE_CASES, CLIP, FT_CASES, PT_CASES, ft_problem, load_case, rel_l2, tb
 from oracle import gget_oracle as O
 
 
-def _fwd_fn(spec, b, kind):
+def _fwd_fn(spec, b, kind, name=""):
     if kind == "pt":
         def fn(p):
             return O.pretrain_forward(spec, p, b["input_ids"], b["attention_mask"], b["labels"], b.get("wgt"))
         return fn, "head1_loss", "head1_logits"
-    problem, loss_type = ft_problem(spec, b)
+    problem, loss_type = ft_problem(spec, b, name)
 
     def fn(p):
         return O.task_forward(spec, p, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"],
-                              problem_type=problem, loss_type=loss_type)
+                              sample_wgt=b.get("wgt"), problem_type=problem, loss_type=loss_type)
     return fn, "task_loss", "task_logits"
 
 
@@ -27,7 +27,7 @@ def test_oracle_fp32_matches_reference(name):
     kind = "pt" if name.startswith("pt") else "ft"
     b = tb(batch)
     p = O.to_params(state, torch.float32)
-    fn, lk, gk = _fwd_fn(spec, b, kind)
+    fn, lk, gk = _fwd_fn(spec, b, kind, name)
     out, grads = O.loss_and_grads(fn, p, lk)
     assert abs(out[lk].item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"])) + 1e-6
     lg = out[gk].detach().float().numpy()
@@ -41,13 +41,32 @@ def test_oracle_fp32_matches_reference(name):
     assert rel_l2(grads["model.layers.1.mlp.down_proj.weight"].numpy(), z["grad_l1_down"]) < 1e-4
 
 
+@pytest.mark.parametrize("name", BASE_CASES)
+def test_oracle_fp32_matches_reference_full_width(name):
+    """The full-width base model (d768 / L12, the headline run's architecture) at a small batch: loss, logits, every
+    per-parameter gradient norm and 64 x 64 gradient blocks of q / k / gate / down projections."""
+    z, spec, state, batch = load_case(name)
+    b = tb(batch)
+    p = O.to_params(state, torch.float32)
+    fn, lk, gk = _fwd_fn(spec, b, "pt", name)
+    out, grads = O.loss_and_grads(fn, p, lk)
+    assert abs(out[lk].item() - float(z["loss"])) <= 2e-5 * abs(float(z["loss"]))
+    np.testing.assert_allclose(out[gk].detach().float().numpy()[:64], z["logits"], rtol=5e-4, atol=5e-4)
+    gn = np.array([float(grads[n].norm()) for n in state.keys()])
+    np.testing.assert_allclose(gn, z["grad_norms"], rtol=5e-4, atol=1e-7)
+    for tag, pn in (("l0_q", "model.layers.0.self_attn.q_proj.weight"), ("l0_k", "model.layers.0.self_attn.k_proj.weight"),
+                    ("l11_q", "model.layers.11.self_attn.q_proj.weight"), ("l11_k", "model.layers.11.self_attn.k_proj.weight"),
+                    ("l5_down", "model.layers.5.mlp.down_proj.weight"), ("l5_gate", "model.layers.5.mlp.gate_proj.weight")):
+        assert rel_l2(grads[pn].numpy()[:64, :64], z["gradblk_" + tag]) < 5e-4, tag
+
+
 @pytest.mark.parametrize("name", ["pt_tiny_f13_a", "pt_tiny_bigw", "pt_tiny_s72", "ft_tiny_f4", "ft_tiny_ls"])
 def test_oracle_bf16_tracks_reference_bf16(name):
     z, spec, state, batch = load_case(name)
     kind = "pt" if name.startswith("pt") else "ft"
     b = tb(batch)
     p = O.to_params(state, torch.bfloat16, requires_grad=False)
-    fn, lk, gk = _fwd_fn(spec, b, kind)
+    fn, lk, gk = _fwd_fn(spec, b, kind, name)
     with torch.no_grad():
         out = fn(p)
     # same arithmetic as the reference's bf16 module path -> agreement far below bf16 noise vs fp32
@@ -55,13 +74,13 @@ def test_oracle_bf16_tracks_reference_bf16(name):
     assert rel_l2(out[gk].float().numpy()[:64], z["logits_bf16"]) < 2e-2
 
 
-@pytest.mark.parametrize("name", ["pt_tiny_f13_a", "pt_tiny_bigw", "pt_tiny_wgt", "ft_tiny_f4", "ft_tiny_reg"])
+@pytest.mark.parametrize("name", ["pt_tiny_f13_a", "pt_tiny_bigw", "pt_tiny_wgt", "ft_tiny_f4", "ft_tiny_reg", "ft_tiny_mse", "ft_tiny_wce"])
 def test_oracle_adamw_trajectory(name):
     z, spec, state, batch = load_case(name)
     kind = "pt" if name.startswith("pt") else "ft"
     b = tb(batch)
     p = O.to_params(state, torch.float32)
-    fn, lk, _ = _fwd_fn(spec, b, kind)
+    fn, lk, _ = _fwd_fn(spec, b, kind, name)
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v = {k: torch.zeros_like(v_) for k, v_ in p.items()}
     losses, gns = [], []

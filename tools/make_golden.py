@@ -125,6 +125,19 @@ CASES = [
      dict(B=4, S=24, seed=12, regression=True), dict(std=0.06, head_std=0.15)),
     ("ft_tiny_ml", "ft", dict(vocab_size=1000, stacked_feat=4, next_n_token=1, num_labels=5),
      dict(B=6, S=24, seed=13, multi_label=True), dict(std=0.06, head_std=0.15)),
+    # round 2: larger fine-tune batches (the 2-class CE of 4 samples is too coarse a probe), MSE regression, sample-weighted CE
+    ("ft_tiny_f4_b32", "ft", dict(vocab_size=1000, stacked_feat=4, next_n_token=1, num_labels=2), dict(B=32, S=24, seed=15),
+     dict(std=0.06, head_std=0.15)),
+    ("ft_tiny_mse", "ft", dict(vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=1, score_bias=True),
+     dict(B=32, S=24, seed=16, regression=True, mse=True), dict(std=0.06, head_std=0.15)),
+    ("ft_tiny_wce", "ft", dict(vocab_size=1000, stacked_feat=4, next_n_token=1, num_labels=2),
+     dict(B=32, S=24, seed=17, sample_wgt=True), dict(std=0.06, head_std=0.15)),
+    # round 2: the full-width base model (d768 / L12) of the headline run at a small batch, big weights (loss far from
+    # ln V, attention far from uniform) - size "base"; only norms and slices of the gradients are stored
+    ("pt_base_bigw", "pt", dict(vocab_size=756, stacked_feat=13, next_n_token=13), dict(B=4, S=32, seed=18),
+     dict(std=0.06, head_std=0.15, size="base")),
+    ("pt_base_std", "pt", dict(vocab_size=756, stacked_feat=13, next_n_token=13), dict(B=4, S=32, seed=19),
+     dict(size="base")),
 ]
 
 ADAM = dict(lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
@@ -133,7 +146,9 @@ CLIP = 1.0
 
 def run_case(name, kind, skw, bkw, ikw, classes):
     PT, FT, Cfg = classes
-    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN if kind == "pt" else spec_mod.KIND_TASK, **skw)
+    size = ikw.pop("size", "tiny")
+    big = size != "tiny"
+    spec = spec_mod.spec_from_size(size, kind=spec_mod.KIND_PRETRAIN if kind == "pt" else spec_mod.KIND_TASK, **skw)
     state = weights_mod.make_state_dict(spec, seed=100 + bkw["seed"], **ikw)
     names = list(state.keys())
     out = {}
@@ -147,9 +162,13 @@ def run_case(name, kind, skw, bkw, ikw, classes):
     else:
         reg = bkw.pop("regression", False)
         ml = bkw.pop("multi_label", False)
+        mse = bkw.pop("mse", False)
+        swgt = bkw.pop("sample_wgt", False)
         batch = synth.make_task_batch(F=spec.stacked_feat, V=spec.vocab_size, num_labels=spec.num_labels,
                                       regression=reg, multi_label=ml, **bkw)
-        extra = dict(num_labels=spec.num_labels, loss_type="l1" if reg else None, mlp=[],
+        if swgt:   # per-sample weights of the sample-weighted CE (modeling_finetune.py:215-226)
+            batch["wgt"] = np.random.RandomState(1000 + bkw["seed"]).uniform(0.2, 3.0, size=(bkw["B"],)).astype(np.float32)
+        extra = dict(num_labels=spec.num_labels, loss_type=("l1" if reg and not mse else None), mlp=[],
                      problem_type="regression" if reg else ("multi_label_classification" if ml else "single_label_classification"))
         cfg = ref_config(Cfg, spec, **extra)
         model = FT(cfg)
@@ -162,7 +181,7 @@ def run_case(name, kind, skw, bkw, ikw, classes):
             return m(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"], labels=tb["labels"],
                      inputs_raw_embeds=None, sample_wgt=tb.get("wgt"))
         return m(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"],
-                 position_ids=tb["position_ids"], task_labels=tb["task_labels"])
+                 position_ids=tb["position_ids"], task_labels=tb["task_labels"], sample_wgt=tb.get("wgt"))
 
     o = fwd(model)
     loss = o.head1_loss if kind == "pt" else o.task_loss
@@ -170,7 +189,7 @@ def run_case(name, kind, skw, bkw, ikw, classes):
     model.zero_grad()
     loss.backward()
     out["loss"] = np.float64(loss.item())
-    if kind == "ft" and spec.num_labels == 1:
+    if kind == "ft" and spec.num_labels == 1 and cfg.loss_type == "l1":
         # L1 regression: the gradient is sign(pred - y); keep every sample far from the kink so that bf16-level
         # differences in `pred` cannot flip a sign (the parity tests compare gradients)
         margin = (logits.detach().float().view(-1) - tb["task_labels"].float().view(-1)).abs().min().item()
@@ -180,9 +199,15 @@ def run_case(name, kind, skw, bkw, ikw, classes):
     out["grad_norms"] = grad_norms(model, names)
     # one full gradient for a mid-stack matrix and the embedding (tight check of backward)
     g = dict(model.named_parameters())
-    out["grad_embed"] = g["model.embed_tokens.weight"].grad.numpy().copy()
-    out["grad_l0_q"] = g["model.layers.0.self_attn.q_proj.weight"].grad.numpy().copy()
-    out["grad_l1_down"] = g["model.layers.1.mlp.down_proj.weight"].grad.numpy().copy()
+    if not big:
+        out["grad_embed"] = g["model.embed_tokens.weight"].grad.numpy().copy()
+        out["grad_l0_q"] = g["model.layers.0.self_attn.q_proj.weight"].grad.numpy().copy()
+        out["grad_l1_down"] = g["model.layers.1.mlp.down_proj.weight"].grad.numpy().copy()
+    else:   # full-width model: 64 x 64 corner blocks of a few matrices (q / k of the first and last layer, a down projection)
+        for tag, pn in (("l0_q", "model.layers.0.self_attn.q_proj.weight"), ("l0_k", "model.layers.0.self_attn.k_proj.weight"),
+                        ("l11_q", "model.layers.11.self_attn.q_proj.weight"), ("l11_k", "model.layers.11.self_attn.k_proj.weight"),
+                        ("l5_down", "model.layers.5.mlp.down_proj.weight"), ("l5_gate", "model.layers.5.mlp.gate_proj.weight")):
+            out["gradblk_" + tag] = g[pn].grad.numpy()[:64, :64].copy()
     # final hidden states
     with torch.no_grad():
         if kind == "pt":
@@ -200,6 +225,15 @@ def run_case(name, kind, skw, bkw, ikw, classes):
         ob = fwd(mb)
     lb = ob.head1_loss if kind == "pt" else ob.task_loss
     out["loss_bf16"] = np.float64(lb.item())
+    if big:   # the reference's own bf16 backward: how far a bf16 implementation's gradients sit from the fp32 ones
+        mb.zero_grad()
+        fwd(mb).head1_loss.backward()
+        gb = dict(mb.named_parameters())
+        for tag, pn in (("l0_q", "model.layers.0.self_attn.q_proj.weight"), ("l0_k", "model.layers.0.self_attn.k_proj.weight"),
+                        ("l11_q", "model.layers.11.self_attn.q_proj.weight"), ("l11_k", "model.layers.11.self_attn.k_proj.weight"),
+                        ("l5_down", "model.layers.5.mlp.down_proj.weight"), ("l5_gate", "model.layers.5.mlp.gate_proj.weight")):
+            out["gradblk_bf16_" + tag] = gb[pn].grad.float().numpy()[:64, :64].copy()
+        out["grad_norms_bf16"] = np.array([float(gb[n].grad.float().norm()) if gb[n].grad is not None else 0.0 for n in names], np.float64)
     out["logits_bf16"] = (ob.head1_logits if kind == "pt" else ob.task_logits).float().numpy()[:64]
     # three clip+AdamW steps on the same batch (training_utils.py:53-86 order: clip then step)
     model.zero_grad()
@@ -227,6 +261,7 @@ def run_case(name, kind, skw, bkw, ikw, classes):
     out["meta_spec"] = np.array(spec.as_c_ints(), np.int64)
     out["meta_layer_scale"] = np.float64(spec.layer_scale_init)
     out["meta_init"] = np.array([ikw.get("std", 0.02), ikw.get("head_std", -1.0), 100 + bkw["seed"]], np.float64)
+    out["meta_size"] = np.array(size)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + ".npz"), **out)
     print(f"{name}: loss {out['loss']:.6f} bf16 {out['loss_bf16']:.6f} logits {tuple(out['logits_shape'])} "
           f"adamw {np.round(out['adamw_losses'], 5)}")
@@ -376,6 +411,55 @@ def hostmask_fixture():
     print("hostmask written")
 
 
+def ckpt_fixture():
+    """Checkpoint interchange: a checkpoint WRITTEN BY THE REFERENCE - a reference-initialised model (HF
+    `_init_weights`, seeded), saved the way `save_ddp_ckp` saves it under DDP (torch.save of a state dict whose keys carry the
+    `module.` prefix, src/utils/misc_utils.py:105-121) into tests/golden/ref_ckpt/epoch_3/model.pt - next to the reference's
+    own loss / logits / gradient norms on a seeded batch with those weights.  Also the reverse direction: a model.pt written
+    by this package's `save_model` is loaded by the reference with strict=True and must reproduce the same loss."""
+    PT, FT, Cfg = import_reference()
+    spec = spec_mod.ModelSpec(kind=spec_mod.KIND_PRETRAIN, vocab_size=300, hidden_size=128, intermediate_size=256, num_layers=1,
+                              num_heads=2, head_dim=64, stacked_feat=4, next_n_token=4)
+    torch.manual_seed(4242)
+    model = PT(ref_config(Cfg, spec))          # reference init: normal(0, initializer_range), pad row zero, norms one
+    model.eval()
+    d = os.path.join(ROOT, "tests", "golden", "ref_ckpt", "epoch_3")
+    os.makedirs(d, exist_ok=True)
+    sd = {"module." + k: v.detach().clone() for k, v in model.state_dict().items()}    # = DDP(model).state_dict()
+    torch.save(sd, os.path.join(d, "model.pt"))
+    batch = synth.make_pretrain_batch(B=6, S=24, F=4, V=300, seed=55)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    o = model(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"], labels=tb["labels"], inputs_raw_embeds=None)
+    model.zero_grad()
+    o.head1_loss.backward()
+    names = [k for k in model.state_dict().keys() if "rotary_emb" not in k]
+    res = {"loss": np.float64(o.head1_loss.item()), "logits": o.head1_logits.detach().float().numpy()[:64],
+           "grad_norms": grad_norms(model, names), "names": np.array(names), "meta_spec": np.array(spec.as_c_ints(), np.int64)}
+    for k, v in batch.items():
+        res["in_" + k] = v
+    # reverse direction: our writer -> reference reader
+    ours = import_module("graph-gpt_amd.modeling")
+    ck = import_module("graph-gpt_amd.checkpoint")
+    import tempfile
+    mine = ours.GraphGPTPretrainBase(ours.GraphGPTConfig(
+        vocab_size=300, hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2,
+        max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=4, next_n_token=4), seed=9)
+    with tempfile.TemporaryDirectory() as td:
+        ck.save_model(mine, td, ddp_prefix=True)
+        back = torch.load(os.path.join(td, "model.pt"), map_location="cpu")
+        back = {(k[7:] if k.startswith("module.") else k): v for k, v in back.items()}      # loader_utils.py:192-194
+        m2 = PT(ref_config(Cfg, spec))
+        missing, unexpected = m2.load_state_dict(back, strict=False)
+        assert not unexpected and all("rotary_emb" in m for m in missing), (missing, unexpected)
+        m2.eval()
+        with torch.no_grad():
+            o2 = m2(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"], labels=tb["labels"], inputs_raw_embeds=None)
+        res["roundtrip_loss_of_seed9_model"] = np.float64(o2.head1_loss.item())
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_ckpt.npz"), **res)
+    print(f"ref_ckpt written: loss {res['loss']:.6f}, {len(names)} tensors, model.pt {os.path.getsize(os.path.join(d, 'model.pt'))} bytes; "
+          f"our save_model -> reference strict load ok, loss {res['roundtrip_loss_of_seed9_model']:.6f}")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -393,6 +477,8 @@ def main():
         generation_fixture()
     if not only or "hostmask" in only:
         hostmask_fixture()
+    if not only or "ref_ckpt" in only:
+        ckpt_fixture()
 
 
 if __name__ == "__main__":

@@ -69,6 +69,8 @@ SIGNATURES = {
     "gget_op_embed_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "gget_op_qkv_rope": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "gget_op_smtp2d": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, f32, f32, i32, i32, C.c_uint32, vp]),
+    "gget_op_token_sample": (i32, [vp, i32, i32, i32, i32, f32, f32, i32, f32, C.c_uint32, vp, vp, vp]),
+    "gget_op_unmask_origin": (i32, [vp, vp, i32, i32, f32, C.c_uint32, i32, vp]),
     "gget_op_token_confidence": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "gget_op_smtp_rows": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, C.c_double, C.c_double, C.c_double, C.c_uint32, vp]),
     "gget_op_rope": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),

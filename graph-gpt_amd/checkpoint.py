@@ -61,14 +61,15 @@ def read_state_dict(ckp: str, use_ema: bool = False) -> Dict[str, torch.Tensor]:
 
 
 def load_from_ckp_with_try(model, ckp: str, skip_keys: bool = True, strict: bool = False, use_ema: bool = False):
-    print(f"Loading pretrained weights from ckp {ckp}")
+    print(f"[gget] reading checkpoint {ckp}")
     sd = read_state_dict(ckp, use_ema=use_ema)
-    for key in list(sd.keys()):
-        if ("score" in key) and skip_keys:
-            sd.pop(key)
-            print(f"pop key {key} in stat_dict!")
+    dropped = [key for key in sd if skip_keys and "score" in key]   # a pre-trained trunk under a fresh fine-tune head
+    for key in dropped:
+        del sd[key]
+    if dropped:
+        print(f"[gget] head tensors left at their fresh initialisation: {dropped}")
     missing, unexpected = model.load_state_dict(sd, strict=strict)
-    print(f"init model params using `load_state_dict`\nmissing keys: {list(missing)}\nunexpected_keys: {list(unexpected)}")
+    print(f"[gget] {len(sd)} tensors loaded by name; not in the checkpoint: {list(missing)}; not in the model: {list(unexpected)}")
     model.last_load_result = (list(missing), list(unexpected))
     return model
 

@@ -1053,6 +1053,16 @@ extern "C" int gget_op_smtp2d(const int64_t* ids_in, int ld_in, const int64_t* n
   return k_smtp2d(ids_in, ld_in, node_idx, ld_node, ids_out, labels_out, B, S, F, smtp_2d_rate, power, replace_rate, vocab,
                   global_2d_mask, seed, (hipStream_t)stream);
 }
+extern "C" int gget_op_token_sample(const void* logits, int ld, int R, int V, int mode, float temperature, float top_p, int top_k,
+                                   float alg_temp, uint32_t seed, float* conf, int64_t* tok, void* stream) {
+  GGET_REQUIRE(logits && conf && tok && R >= 0 && V >= 1 && ld >= V && mode >= 0 && mode <= 2, "token_sample: bad arguments");
+  return k_token_sample(logits, ld, R, V, mode, temperature, top_p, top_k, alg_temp, seed, conf, tok, (hipStream_t)stream);
+}
+extern "C" int gget_op_unmask_origin(int64_t* x, const int64_t* cand, int B, int N, float p_transfer, uint32_t seed, int mask_token_id,
+                                     void* stream) {
+  GGET_REQUIRE(x && cand && B >= 0 && N >= 0, "unmask_origin: bad arguments");
+  return k_unmask_origin(x, cand, B, N, p_transfer, seed, mask_token_id, (hipStream_t)stream);
+}
 extern "C" int gget_op_token_confidence(const void* logits, int ld, int R, int V, int mode, float* conf, int64_t* tok, void* stream) {
   GGET_REQUIRE(logits && conf && tok, "token_confidence: null argument");
   GGET_REQUIRE(R >= 0 && V >= 2 && ld >= V && mode >= 0 && mode <= 2, "token_confidence: bad arguments (R %d V %d ld %d mode %d)", R, V, ld, mode);

@@ -77,6 +77,9 @@ int k_ranges_from_mask3d(const int64_t* mask3d, int32_t* key_lo, int32_t* key_hi
 int k_smtp2d(const int64_t* ids_in, int ld_in, const int64_t* node_idx, int ld_node, int64_t* ids_out, int64_t* labels_out,
              int B, int S, int F, float rate, float power, float replace_rate, int vocab, int global_mask, unsigned seed,
              hipStream_t st);
+int k_token_sample(const void* logits, int ld, int R, int V, int mode, float temperature, float top_p, int top_k, float alg_temp,
+                   unsigned seed, float* conf, int64_t* tok, hipStream_t st);
+int k_unmask_origin(int64_t* x, const int64_t* cand, int B, int N, float p_transfer, unsigned seed, int mask_id, hipStream_t st);
 int k_token_confidence(const void* logits, int ld, int R, int V, int mode, float* conf, int64_t* tok, hipStream_t st);
 int k_smtp_rows(const int64_t* ids_in, const int32_t* lengths, int64_t* ids_out, int64_t* labels_out, float* wgt_out, int B, int S,
                 int F, double umr_min, double umr_max, double power, unsigned seed, hipStream_t st);

@@ -1059,6 +1059,142 @@ __global__ void __launch_bounds__(kBlock) token_confidence_kernel(const bf16_t* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Candidate sampling of the generation loop with every option of the reference's sample_tokens
+// (src/utils/generation_utils.py:22-82): logits / temperature -> top-p filter -> top-k filter -> softmax -> categorical
+// sample (temperature > 0) or arg-max -> confidence (probability of the candidate | top1 - top2 | sum p log(p + 1e-10)),
+// optionally perturbed for the Gumbel-max ranking of _batch_unmask_without_for_loop (:199-209): conf / alg_temp + g.
+// One wave per row, the row lives in LDS as fp32 (scaled logits and probabilities).  Draws are the 24-bit counter hash of
+// (seed, stream, row): stream 32 the categorical uniform (inverse CDF in index order: first c with cumsum p > u, where the
+// reference calls torch's multinomial - same distribution, different draw), stream 33 the Gumbel uniform.
+// Filters restated without a sort: top-p keeps c iff the probability mass ranked strictly ahead of it (larger p, or equal p
+// and lower index = a stable descending sort) is <= top_p; top-k keeps c iff fewer than k values are strictly larger
+// (ties at the k-th value all survive, like `logits < topk(...)[..., -1]`).  O(V^2 / 64) per lane: vocabularies <= 8192.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) token_sample_kernel(const bf16_t* __restrict__ logits, int ld, int R, int V, int mode,
+                                                              float temperature, float top_p, int top_k, float alg_temp,
+                                                              unsigned seed, float* __restrict__ conf, int64_t* __restrict__ tok,
+                                                              int waves_per_block) {
+  extern __shared__ float ts_lds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (wv >= waves_per_block) return;
+  float* s = ts_lds + (size_t)wv * 2 * V;
+  float* p = s + V;
+  const float inv24 = 1.0f / 16777216.0f;
+  const float NEG = -3.4028234663852886e38f;   // torch.finfo(float32).min, what masked_fill writes
+  for (int row = blockIdx.x * waves_per_block + wv; row < R; row += gridDim.x * waves_per_block) {
+    const bf16_t* x = logits + (size_t)row * ld;
+    const float invt = temperature > 0.f ? 1.0f / temperature : 1.0f;
+    for (int c = lane; c < V; c += 64) s[c] = temperature > 0.f ? bf2f(x[c]) / temperature : bf2f(x[c]);
+    (void)invt;
+    __builtin_amdgcn_wave_barrier();
+    auto softmax_to_p = [&]() {
+      float m = -INFINITY;
+      for (int c = lane; c < V; c += 64) m = fmaxf(m, s[c]);
+      m = wave_max(m);
+      float z = 0.f;
+      for (int c = lane; c < V; c += 64) { const float e = __expf(s[c] - m); p[c] = e; z += e; }
+      z = wave_sum(z);
+      for (int c = lane; c < V; c += 64) p[c] = p[c] / z;
+      __builtin_amdgcn_wave_barrier();
+    };
+    if (top_p > 0.f && top_p < 1.f) {
+      softmax_to_p();
+      for (int c = lane; c < V; c += 64) {
+        const float pc = p[c];
+        float ahead = 0.f;
+        for (int i = 0; i < V; ++i) {
+          const float pi = p[i];
+          ahead += (pi > pc || (pi == pc && i < c)) ? pi : 0.f;
+        }
+        if (ahead > top_p) s[c] = NEG;   // the first token is always kept (nothing ahead of it)
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (top_k > 0) {
+      const int kk = min(top_k, V);
+      for (int c = lane; c < V; c += 64) p[c] = s[c];   // snapshot: the filter compares unfiltered values
+      __builtin_amdgcn_wave_barrier();
+      for (int c = lane; c < V; c += 64) {
+        const float sc = p[c];
+        int larger = 0;
+        for (int i = 0; i < V; ++i) larger += p[i] > sc;
+        if (larger >= kk) s[c] = NEG;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    softmax_to_p();
+    // candidate
+    int x0;
+    float cf;
+    float m1 = -1.f, m2 = -1.f;   // largest and second largest probability, arg-max with the lowest index
+    int i1 = 0x7fffffff;
+    for (int c = lane; c < V; c += 64) {
+      const float v = p[c];
+      if (v > m1) { m2 = m1; m1 = v; i1 = c; } else if (v > m2) { m2 = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om1 = __shfl_xor(m1, o, 64), om2 = __shfl_xor(m2, o, 64);
+      const int oi1 = __shfl_xor(i1, o, 64);
+      if (om1 > m1 || (om1 == m1 && oi1 < i1)) { m2 = fmaxf(m1, om2); m1 = om1; i1 = oi1; }
+      else { m2 = fmaxf(m2, om1); }
+    }
+    if (temperature > 0.f) {
+      const float u = (float)smtp_rng(seed, 32, (unsigned)row, 0) * inv24;
+      float run = 0.f;
+      int found = -1, last_pos = -1;
+      for (int base = 0; base < V && found < 0; base += 64) {
+        const int c = base + lane;
+        const float v = c < V ? p[c] : 0.f;
+        float pre = v;   // inclusive prefix over the 64 lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const float t = __shfl_up(pre, o, 64);
+          if (lane >= o) pre += t;
+        }
+        const unsigned long long hit = __ballot(c < V && run + pre > u);
+        const unsigned long long pos = __ballot(c < V && v > 0.f);
+        if (pos) last_pos = base + 63 - __builtin_clzll(pos);
+        if (hit) found = base + __builtin_ctzll(hit);
+        run += __shfl(pre, 63, 64);
+      }
+      if (found < 0) {   // u beyond the accumulated mass (rounding): the last token with probability
+        found = last_pos >= 0 ? last_pos : i1;
+      }
+      x0 = found;
+      cf = p[x0];
+    } else {
+      x0 = i1;
+      cf = m1;
+    }
+    if (mode == 1) cf = m1 - m2;
+    if (mode == 2) {
+      float ent = 0.f;
+      for (int c = lane; c < V; c += 64) { const float v = p[c]; ent += v * __logf(v + 1e-10f); }
+      cf = wave_sum(ent);
+    }
+    if (alg_temp > 0.f) {
+      const float u2 = (float)smtp_rng(seed, 33, (unsigned)row, 0) * inv24;
+      cf = cf / alg_temp - __logf(-__logf(u2 + 1e-9f) + 1e-9f);
+    }
+    if (lane == 0) { conf[row] = cf; tok[row] = x0; }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// alg = "origin" update of the generation loop (generation_utils.py:150-162): a masked cell takes its candidate when its own
+// uniform draw (stream 34 of the counter hash, indexed by (sample, cell)) falls below p_transfer.
+__global__ void __launch_bounds__(kBlock) unmask_origin_kernel(int64_t* __restrict__ x, const int64_t* __restrict__ cand, int B, int N,
+                                                               float p_transfer, unsigned seed, int mask_id) {
+  const long total = (long)B * N;
+  for (long w = (long)blockIdx.x * kBlock + threadIdx.x; w < total; w += (long)gridDim.x * kBlock) {
+    const unsigned b = (unsigned)(w / N), n = (unsigned)(w % N);
+    const float u = (float)smtp_rng(seed, 34, b, n) * (1.0f / 16777216.0f);
+    if (x[w] == mask_id && u < p_transfer) x[w] = cand[w];
+  }
+}
+
 // first / last non-zero of every row of a [B,S,S] int64 mask: one wave per row (block-diagonal packing masks,
 // reference src/utils/tokenizer_utils.py:349-355).  An all-zero row (padding) gives lo = 0, hi = -1 (attends nothing).
 __global__ void __launch_bounds__(kBlock) ranges_from_mask3d_kernel(const int64_t* __restrict__ mask, int32_t* __restrict__ lo,
@@ -1383,6 +1519,26 @@ int k_token_confidence(const void* logits, int ld, int R, int V, int mode, float
   if (R == 0) return 0;
   hipLaunchKernelGGL(token_confidence_kernel, dim3(grid_for(R, kBlock / 64, 4096)), dim3(kBlock), 0, st, (const bf16_t*)logits,
                      ld, R, V, mode, conf, tok);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_token_sample(const void* logits, int ld, int R, int V, int mode, float temperature, float top_p, int top_k, float alg_temp,
+                   unsigned seed, float* conf, int64_t* tok, hipStream_t st) {
+  if (R == 0) return 0;
+  GGET_REQUIRE(V >= 1 && V <= 8192, "token_sample: vocabulary %d out of range (1..8192: the row is filtered in LDS)", V);
+  GGET_REQUIRE(temperature >= 0.f && alg_temp >= 0.f && top_k >= 0, "token_sample: negative temperature / alg_temp / top_k");
+  const int waves = V <= 1024 ? kBlock / 64 : 1;
+  const size_t lds = (size_t)waves * 2 * V * sizeof(float);
+  hipLaunchKernelGGL(token_sample_kernel, dim3(grid_for(R, waves, 8192)), dim3(kBlock), lds, st, (const bf16_t*)logits, ld, R, V,
+                     mode, temperature, top_p, top_k, alg_temp, seed, conf, tok, waves);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_unmask_origin(int64_t* x, const int64_t* cand, int B, int N, float p_transfer, unsigned seed, int mask_id, hipStream_t st) {
+  if ((long)B * N == 0) return 0;
+  hipLaunchKernelGGL(unmask_origin_kernel, dim3(grid_for((long)B * N)), dim3(kBlock), 0, st, x, cand, B, N, p_transfer, seed, mask_id);
   GGET_LAUNCH_CHECK();
   return 0;
 }

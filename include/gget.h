@@ -239,6 +239,16 @@ int gget_op_smtp2d(const int64_t* ids_in, int ld_in, const int64_t* node_idx, in
 #define GGET_CONF_MARGIN 1
 #define GGET_CONF_NEG_ENTROPY 2
 int gget_op_token_confidence(const void* logits, int ld, int R, int V, int mode, float* conf, int64_t* tok, void* stream);
+/* replaces: sample_tokens with every option (src/utils/generation_utils.py:22-82: temperature, top-p, top-k, categorical
+ * sampling, margin / entropy confidence) and the Gumbel-max perturbation of the confidence ranking (:199-209, alg_temp).
+ * temperature 0 = arg-max; top_p outside (0,1) and top_k 0 = filter off; alg_temp 0 = no perturbation.  Draws: counter hash
+ * of (seed, stream, row) (graph-gpt_amd/generation.py holds the Python twin); V <= 8192. */
+int gget_op_token_sample(const void* logits, int ld, int R, int V, int mode, float temperature, float top_p, int top_k,
+                         float alg_temp, uint32_t seed, float* conf, int64_t* tok, void* stream);
+/* replaces: the alg = "origin" update of _batch_unmask_without_for_loop (src/utils/generation_utils.py:150-162): x[b][n] takes
+ * cand[b][n] where it is <mask> and the cell's own uniform draw is below p_transfer. */
+int gget_op_unmask_origin(int64_t* x, const int64_t* cand, int B, int N, float p_transfer, uint32_t seed, int mask_token_id,
+                          void* stream);
 /* replaces: the collator's SMTP masking (prepare_inputs_for_pretrain_mlm, src/utils/tokenizer_utils.py:259-271 polynomial
  * schedule + _mask_stacked_input_ids_v2 :112-148, mtp (1,0,0)) for a right-padded batch ids [B,S,F] with lengths [B]:
  * per sample t = umr_min + (umr_max - umr_min) U, exactly ceil(len*F*(1 - t^power)) of its cells are masked (id -> 1

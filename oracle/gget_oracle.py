@@ -350,10 +350,49 @@ def smtp_2d_inputs_labels(input_ids, node_idx, u_sample, u_rate, u_cell, token_s
 
 
 # ----------------------------------------------------------------------------- generation loop (next item N3)
-def sample_tokens_t0(logits: torch.Tensor, margin_confidence: bool = False, neg_entropy: bool = False):
-    """reference sample_tokens at temperature 0 without top-p / top-k (src/utils/generation_utils.py:45-82)."""
+def top_p_logits(logits, top_p):
+    """reference top_p_logits (src/utils/generation_utils.py:22-34), with the sort made stable (ties keep index order)."""
+    sorted_logits, sorted_indices = torch.sort(logits, descending=True, stable=True)
+    cumulative = torch.cumsum(Fnn.softmax(sorted_logits, dim=-1), dim=-1)
+    remove = cumulative > top_p
+    remove[..., 1:] = remove[..., :-1].clone()
+    remove[..., 0] = 0
+    mask = torch.zeros_like(logits, dtype=torch.bool).scatter_(-1, sorted_indices, remove)
+    return logits.masked_fill(mask, torch.finfo(logits.dtype).min)
+
+
+def top_k_logits(logits, top_k):
+    """reference top_k_logits (:37-42)."""
+    top_k = min(top_k, logits.size(-1))
+    remove = logits < torch.topk(logits, top_k)[0][..., -1, None]
+    return logits.masked_fill(remove, torch.finfo(logits.dtype).min)
+
+
+def sample_tokens(logits, temperature=0.0, top_p=None, top_k=None, margin_confidence=False, neg_entropy=False,
+                  u=None, x0_override=None):
+    """reference sample_tokens (:45-82).  The categorical draw (`dists.Categorical(probs).sample()` in the reference) is made
+    explicit: `x0_override` replays recorded draws (the reference fixture), otherwise `u` in [0,1) per row selects by inverse
+    CDF in index order (first c with cumsum(probs) > u) - the convention of the HIP sampling kernel."""
+    if temperature > 0:
+        logits = logits / temperature
+    if top_p is not None and top_p < 1:
+        logits = top_p_logits(logits, top_p)
+    if top_k is not None:
+        logits = top_k_logits(logits, top_k)
     probs = torch.softmax(logits, dim=-1)
-    confidence, x0 = probs.max(dim=-1)
+    if temperature > 0:
+        if x0_override is not None:
+            x0 = x0_override
+        else:
+            cdf = torch.cumsum(probs, dim=-1)
+            x0 = (cdf > u[..., None]).float().argmax(dim=-1)
+            none = ~(cdf > u[..., None]).any(dim=-1)
+            if none.any():   # u beyond the accumulated mass (rounding): the last token with probability
+                last = probs.shape[-1] - 1 - (probs.flip(-1) > 0).float().argmax(dim=-1)
+                x0 = torch.where(none, last, x0)
+        confidence = torch.gather(probs, -1, x0.unsqueeze(-1)).squeeze(-1)
+    else:
+        confidence, x0 = probs.max(dim=-1)
     if margin_confidence:
         sp, _ = torch.sort(probs, dim=-1, descending=True)
         confidence = sp[..., 0] - sp[..., 1]
@@ -362,48 +401,84 @@ def sample_tokens_t0(logits: torch.Tensor, margin_confidence: bool = False, neg_
     return confidence, x0
 
 
+def sample_tokens_t0(logits: torch.Tensor, margin_confidence: bool = False, neg_entropy: bool = False):
+    """reference sample_tokens at temperature 0 without top-p / top-k (src/utils/generation_utils.py:45-82)."""
+    return sample_tokens(logits, margin_confidence=margin_confidence, neg_entropy=neg_entropy)
+
+
 def sample_per_batch(logits_fn, input_ids: torch.Tensor, *, alg: str, steps: int, eps: float, mask_token_id: int,
-                     conf_fn=None):
-    """reference sample_per_batch + _batch_unmask_without_for_loop (generation_utils.py:84-237) for the deterministic
-    algorithms ("maskgit_plus" | "topk_margin" | "entropy", temperature 0, alg_temp None).  `logits_fn(ids [B,S,F])` returns
-    logits [B*S*F, V]; `conf_fn(logits [B,N,V]) -> (confidence, candidates)` defaults to sample_tokens_t0.  Returns
-    (tokens [B, S*F], history list of [B,S,F])."""
+                     conf_fn=None, temperature: float = 0.0, top_p=None, top_k=None, alg_temp=None, draw_fn=None,
+                     surplus: str = "reference"):
+    """reference sample_per_batch + _batch_unmask_without_for_loop (generation_utils.py:84-237), every algorithm.
+    `logits_fn(ids [B,S,F])` returns logits [B*S*F, V].  `conf_fn(iteration, logits [B,N,V]) -> (confidence, candidates)`
+    replaces sample_tokens + the Gumbel perturbation (tests feed the HIP kernel's outputs through it); otherwise
+    `draw_fn(iteration) -> dict` supplies the random draws the reference takes from torch's RNG: "u_cat" [B,N] (inverse-CDF
+    uniforms) or "x0" [B,N] (recorded categorical draws), "u_gumbel" [B,N], "u_transfer" [B,N].
+    surplus = "reference": the fixed-k scatter of the reference (surplus ranks rewrite <mask>, also over -inf positions picked by
+    torch.topk); "skip": only ranks < n_reveal[b] are written, ranking by stable descending sort (the engine's rule).
+    Returns (tokens [B, S*F], history list of [B,S,F])."""
     bz, seq, next_n = input_ids.shape
     x = input_ids.clone().view(bz, seq * next_n)
     m = x == mask_token_id
     n_steps = min(int(torch.max(m.sum(dim=-1).float()).item()), steps)
     timesteps = torch.linspace(1, eps, n_steps + 1)
     hist = []
-    i = 0
+    i = it = 0
     while i < n_steps:
         logits = logits_fn(x.view(bz, seq, next_n)).view(bz, seq * next_n, -1)
         mask_index = x == mask_token_id
-        k = 0
-        num_masked = mask_index.sum(dim=1)
-        num_all = num_masked.sum().item()
-        num_transfer = torch.zeros_like(num_masked).int()
-        while (k == 0) and (num_all > 0) and (i < n_steps):
+        d = draw_fn(it) if draw_fn is not None else {}
+        if alg == "origin":
             t, s = timesteps[i], timesteps[i + 1]
             p_transfer = 1 - s / t if i < n_steps - 1 else 1.0
-            num_transfer = torch.floor(num_masked * p_transfer).int()
-            k = num_transfer.max().item()
+            if conf_fn is not None:
+                _, cand = conf_fn(it, logits)
+            else:
+                _, cand = sample_tokens(logits, temperature=temperature, top_p=top_p, top_k=top_k, u=d.get("u_cat"),
+                                        x0_override=d.get("x0"))
+            transfer = d["u_transfer"] < p_transfer
+            x = torch.where(mask_index & transfer, cand, x)
             i += 1
-        if conf_fn is None:
-            confidence, cand = sample_tokens_t0(logits, margin_confidence=(alg == "topk_margin"), neg_entropy=(alg == "entropy"))
         else:
-            confidence, cand = conf_fn(logits)
-        confidence = confidence.clone()
-        confidence[~mask_index] = -torch.inf
-        _, idx = torch.topk(confidence, k=k, dim=1)
-        updates = torch.gather(cand, 1, idx)
-        mask_out = torch.arange(k)[None, :] >= num_transfer[:, None]
-        final = torch.where(mask_out, mask_token_id, updates)
-        x.scatter_(1, idx, final)
+            k = 0
+            num_masked = mask_index.sum(dim=1)
+            num_all = num_masked.sum().item()
+            num_transfer = torch.zeros_like(num_masked).int()
+            while (k == 0) and (num_all > 0) and (i < n_steps):
+                t, s = timesteps[i], timesteps[i + 1]
+                p_transfer = 1 - s / t if i < n_steps - 1 else 1.0
+                num_transfer = torch.floor(num_masked * p_transfer).int()
+                k = num_transfer.max().item()
+                i += 1
+            if conf_fn is not None:
+                confidence, cand = conf_fn(it, logits)
+                confidence = confidence.clone()
+                confidence[~mask_index] = -torch.inf
+            else:
+                confidence, cand = sample_tokens(logits, temperature=temperature, top_p=top_p, top_k=top_k,
+                                                 margin_confidence=(alg == "topk_margin"), neg_entropy=(alg == "entropy"),
+                                                 u=d.get("u_cat"), x0_override=d.get("x0"))
+                confidence = confidence.clone()
+                confidence[~mask_index] = -torch.inf
+                if alg_temp is not None and alg_temp > 0:
+                    confidence = confidence / alg_temp
+                    confidence = confidence + (-torch.log(-torch.log(d["u_gumbel"] + 1e-9) + 1e-9))
+            if surplus == "reference":
+                _, idx = torch.topk(confidence, k=k, dim=1)
+                updates = torch.gather(cand, 1, idx)
+                mask_out = torch.arange(k)[None, :] >= num_transfer[:, None]
+                final = torch.where(mask_out, mask_token_id, updates)
+                x.scatter_(1, idx, final)
+            else:
+                idx = torch.sort(confidence, dim=1, descending=True, stable=True).indices[:, :k]
+                updates = torch.gather(cand, 1, idx)
+                keep = torch.arange(k)[None, :] < num_transfer[:, None]
+                x.scatter_(1, idx, torch.where(keep, updates, torch.gather(x, 1, idx)))
+        it += 1
         hist.append(x.view(bz, seq, next_n).clone())
     return x, hist
 
 
-# ----------------------------------------------------------------------------- host SMTP masking (row A0 / N1)
 def smtp_mask_ratio(r: float, umr_min: float, umr_max: float, power: float):
     """polynomial schedule of prepare_inputs_for_pretrain_mlm (src/utils/tokenizer_utils.py:259-271), python floats:
     t = umr_min + (umr_max - umr_min) r ; mask ratio alpha = 1 - t^power ; dLM weight = power / t."""

@@ -478,6 +478,66 @@ def test_smtp2d_kernel_matches_oracle(lib, B, S, F, V, rate, power, rep, glob):
 
 
 # ------------------------------------------------------------------------------------------ generation confidence (N3)
+@pytest.mark.parametrize("V,mode,temperature,top_p,top_k,alg_temp",
+                         [(300, 0, 0.8, 0.9, 20, 0.0), (756, 0, 0.5, 0.0, 30, 0.4), (300, 1, 1.0, 0.95, 0, 0.0),
+                          (97, 2, 0.7, 0.0, 0, 0.0), (756, 0, 0.0, 0.0, 0, 0.0), (1500, 0, 1.3, 0.8, 50, 0.0),
+                          (300, 0, 0.0, 0.5, 5, 0.3)])
+def test_token_sample_matches_oracle(lib, V, mode, temperature, top_p, top_k, alg_temp):
+    """The sampling kernel of the generation loop (gget_op_token_sample: temperature, top-p, top-k, categorical draw by inverse
+    CDF, margin / entropy confidence, Gumbel perturbation) against the oracle's restatement of the reference's sample_tokens
+    fed with the Python twin of the kernel's draws.  A candidate may differ only where the uniform sits within rounding
+    distance of a CDF step (fp32 summation order); confidences agree to 1e-5."""
+    gen = importlib.import_module("graph-gpt_amd.generation")
+    from oracle import gget_oracle as O
+    R, ld, seed = 333, ((V + 63) // 64) * 64, 777
+    logits = torch.zeros(R, ld, dtype=torch.bfloat16, device="cuda")
+    logits[:, :V] = rnd(R, V, seed=5, scale=2.0)
+    logits[7, :V] = 0.25                      # a row of ties
+    conf = torch.empty(R, dtype=torch.float32, device="cuda")
+    tok = torch.empty(R, dtype=torch.int64, device="cuda")
+    L.check(lib.gget_op_token_sample(P(logits), ld, R, V, mode, temperature, top_p, top_k, alg_temp, seed, P(conf), P(tok), ST()))
+    inv = np.float32(1.0 / 16777216.0)
+    smtp = importlib.import_module("graph-gpt_amd.smtp")
+    u = torch.from_numpy(smtp._rng24(seed, 32, np.arange(R), 0).astype(np.float32) * inv)
+    u2 = torch.from_numpy(smtp._rng24(seed, 33, np.arange(R), 0).astype(np.float32) * inv)
+    lf = logits[:, :V].float().cpu()
+    c_ref, x_ref = O.sample_tokens(lf, temperature=temperature, top_p=top_p if top_p > 0 else None,
+                                   top_k=top_k if top_k > 0 else None, margin_confidence=mode == 1, neg_entropy=mode == 2, u=u)
+    got_t, got_c = tok.cpu(), conf.cpu()
+    diff = got_t != x_ref
+    if diff.any():
+        # allowed only next to a CDF step
+        z = lf / temperature if temperature > 0 else lf
+        if top_p > 0: z = O.top_p_logits(z, top_p)
+        if top_k > 0: z = O.top_k_logits(z, top_k)
+        cdf = torch.softmax(z, -1).cumsum(-1)
+        near = ((cdf - u[:, None]).abs().min(dim=-1).values < 2e-6)
+        assert temperature > 0 and bool((near | ~diff).all()), f"{int(diff.sum())} candidates differ away from CDF steps"
+        assert int(diff.sum()) <= 3
+    same = ~diff
+    if mode == 0 and temperature > 0:
+        pass   # confidence = probability of the candidate: compare where the candidates agree (below)
+    if alg_temp > 0:
+        c_ref = c_ref / alg_temp + (-torch.log(-torch.log(u2 + 1e-9) + 1e-9))
+    np.testing.assert_allclose(got_c[same].numpy(), c_ref[same].numpy(), rtol=2e-4, atol=2e-5)
+    if temperature == 0:
+        assert torch.equal(got_t, lf.argmax(-1)) or top_p > 0 or top_k > 0
+
+
+def test_unmask_origin_kernel(lib):
+    gen = importlib.import_module("graph-gpt_amd.generation")
+    B, N, seed = 5, 77, 4242
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(1, 4, (B, N), generator=g)
+    cand = torch.randint(10, 300, (B, N), generator=g)
+    xd = x.cuda().clone()
+    s_it = gen.iteration_seed(seed, 2)
+    L.check(lib.gget_op_unmask_origin(P(xd), P(cand.cuda()), B, N, 0.37, s_it, 1, ST()))
+    u = gen.draws(seed, 2, B, N)[2]
+    want = torch.where((x == 1) & (u < np.float32(0.37)), cand, x)
+    assert torch.equal(xd.cpu(), want) and ((x == 1) & (want != 1)).any() and ((x == 1) & (want == 1)).any()
+
+
 @pytest.mark.parametrize("R,V", [(50, 97), (1000, 756), (333, 41245)])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_token_confidence(lib, R, V, mode):

@@ -176,3 +176,59 @@ def test_host_masking_matches_reference(tag):
     alpha, wgt = O.smtp_mask_ratio(0.25, 0.01, 0.99, 2.0)
     t = 0.01 + 0.98 * 0.25
     assert alpha == 1 - t ** 2.0 and wgt == 2.0 / t
+
+
+@pytest.mark.parametrize("tag,alg", [("origin", "origin"), ("gumbel", "maskgit_plus"), ("margin_t", "topk_margin")])
+def test_stochastic_generation_loop_matches_reference(tag, alg):
+    """The stochastic settings of the generation loop (N3): the oracle's restatement, fed with the random draws the reference
+    took (recorded by tools/make_golden.py: categorical samples, transfer-mask uniforms, Gumbel uniforms), reproduces the
+    reference's token grid after every iteration - temperature, top-p, top-k, the "origin" update and the Gumbel ranking."""
+    import importlib
+    import os
+    spec_mod = importlib.import_module("graph-gpt_amd.spec")
+    weights = importlib.import_module("graph-gpt_amd.weights")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "generation_stochastic.npz"))
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=300, stacked_feat=4, next_n_token=4)
+    std, head_std, seed = g["meta_init"]
+    p = O.to_params(weights.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(head_std)), torch.float32,
+                    requires_grad=False)
+    ids, att = torch.from_numpy(g["in_input_ids"]), torch.from_numpy(g["in_attention_mask"])
+    temperature, top_p, top_k, alg_temp = [float(v) for v in g[f"{tag}_cfg"]]
+
+    def logits_fn(x):
+        with torch.no_grad():
+            return O.pretrain_forward(spec, p, x, att, labels=None)["head1_logits"]
+
+    def draw_fn(it):
+        d = {"x0": torch.from_numpy(g[f"{tag}_x0"][it])}
+        if f"{tag}_u_transfer" in g.files:
+            d["u_transfer"] = torch.from_numpy(g[f"{tag}_u_transfer"][it])
+        if f"{tag}_u_gumbel" in g.files:
+            d["u_gumbel"] = torch.from_numpy(g[f"{tag}_u_gumbel"][it])
+        return d
+
+    x, hist = O.sample_per_batch(logits_fn, ids, alg=alg, steps=6, eps=1e-3, mask_token_id=1, temperature=temperature,
+                                 top_p=top_p if top_p > 0 else None, top_k=int(top_k) if top_k > 0 else None,
+                                 alg_temp=alg_temp if alg_temp > 0 else None, draw_fn=draw_fn)
+    assert len(hist) == len(g[f"{tag}_hist"])
+    for it, (a, b) in enumerate(zip(hist, g[f"{tag}_hist"])):
+        assert torch.equal(a, torch.from_numpy(b)), f"iteration {it}"
+
+
+def test_oracle_inverse_cdf_sampler_and_filters():
+    """sample_tokens' explicit categorical draw (inverse CDF, the HIP kernel's convention) has the right distribution, and the
+    top-p / top-k filters keep exactly what the reference keeps (reference functions restated with a stable sort)."""
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(1, 12, generator=g) * 2
+    probs = torch.softmax(logits / 0.7, dim=-1)[0]
+    u = torch.rand(200000, generator=g)
+    _, x0 = O.sample_tokens(logits.expand(200000, 12), temperature=0.7, u=u)
+    freq = torch.bincount(x0, minlength=12).float() / 200000
+    assert float((freq - probs).abs().max()) < 5e-3
+    kept = O.top_k_logits(logits, 4) > torch.finfo(torch.float32).min
+    assert int(kept.sum()) == 4 and torch.equal(kept[0].nonzero().view(-1).sort().values, logits[0].topk(4).indices.sort().values)
+    lp = O.top_p_logits(logits, 0.6)[0]
+    order = logits[0].argsort(descending=True)
+    cum = torch.softmax(logits[0][order], dim=-1).cumsum(0)
+    n_keep = int((cum <= 0.6).sum()) + 1          # everything up to and including the first token that crosses top_p
+    assert torch.equal((lp > torch.finfo(torch.float32).min).nonzero().view(-1).sort().values, order[:n_keep].sort().values)

@@ -371,6 +371,69 @@ def generation_fixture():
     print("generation written")
 
 
+def generation_stochastic_fixture():
+    """Stochastic generation settings of the reference loop (src/utils/generation_utils.py:45-82, :139-237): alg "origin"
+    with temperature / top-p / top-k candidate sampling, and confidence ranking with sampled candidates + Gumbel `alg_temp`.
+    The reference runs under recorders of its random draws - the categorical samples (`dists.Categorical.sample`), torch.rand
+    (transfer mask) and torch.rand_like (Gumbel uniforms) - which are stored per iteration next to the token grid after every
+    iteration, so a restatement fed with the same draws must reproduce the grids exactly."""
+    import types
+    PT, FT, Cfg = import_reference()
+    gen = importlib.import_module("src.utils.generation_utils")
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=300, stacked_feat=4, next_n_token=4)
+    state = weights_mod.make_state_dict(spec, seed=321, std=0.08, head_std=0.2)
+    model = PT(ref_config(Cfg, spec))
+    load_weights(model, state)
+    model.eval()
+    batch = synth.make_pretrain_batch(B=3, S=16, F=4, V=300, seed=77)
+    ids = torch.from_numpy(batch["input_ids"])
+    att = torch.from_numpy(batch["attention_mask"])
+    res = {"in_input_ids": batch["input_ids"], "in_attention_mask": batch["attention_mask"],
+           "meta_spec": np.array(spec.as_c_ints(), np.int64), "meta_init": np.array([0.08, 0.2, 321], np.float64)}
+    runs = {"origin": dict(alg="origin", temperature=0.8, top_p=0.9, top_k=20, alg_temp=None),
+            "gumbel": dict(alg="maskgit_plus", temperature=0.5, top_p=None, top_k=30, alg_temp=0.4),
+            "margin_t": dict(alg="topk_margin", temperature=1.0, top_p=0.95, top_k=None, alg_temp=None)}
+    real_rand, real_rand_like, RealCat = torch.rand, torch.rand_like, gen.dists.Categorical
+    for tag, kw in runs.items():
+        g = torch.Generator().manual_seed(500 + len(tag))
+        rec = {"x0": [], "rand": [], "rand_like": []}
+
+        class Cat(RealCat):
+            def sample(self, *a, **k):
+                out = super().sample(*a, **k)
+                rec["x0"].append(out.clone())
+                return out
+
+        def rand(*a, **k):
+            k.pop("device", None)
+            t = real_rand(*a, generator=g, **k)
+            rec["rand"].append(t.clone())
+            return t
+
+        def rand_like(t, **k):
+            out = real_rand(t.shape, generator=g, dtype=t.dtype)
+            rec["rand_like"].append(out.clone())
+            return out
+
+        torch.manual_seed(900 + len(tag))
+        gen.dists.Categorical, torch.rand, torch.rand_like = Cat, rand, rand_like
+        try:
+            cfg = types.SimpleNamespace(eps=1e-3, steps=6, mask_token_id=1, output_history=True, **kw)
+            x, hist = gen.sample_per_batch(model, cfg, input_ids=ids.clone(), attention_mask=att, inputs_raw_embeds=None)
+        finally:
+            gen.dists.Categorical, torch.rand, torch.rand_like = RealCat, real_rand, real_rand_like
+        res[f"{tag}_hist"] = np.stack([h.numpy() for h in hist])
+        res[f"{tag}_x0"] = np.stack([t.numpy() for t in rec["x0"]])
+        if rec["rand"]:
+            res[f"{tag}_u_transfer"] = np.stack([t.numpy() for t in rec["rand"]])
+        if rec["rand_like"]:
+            res[f"{tag}_u_gumbel"] = np.stack([t.numpy() for t in rec["rand_like"]])
+        res[f"{tag}_cfg"] = np.array([kw["temperature"], kw["top_p"] or 0.0, kw["top_k"] or 0, kw["alg_temp"] or 0.0], np.float64)
+        print(tag, "iterations", len(hist), "categorical draws", len(rec["x0"]), "masked left", int((x == 1).sum()))
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "generation_stochastic.npz"), **res)
+    print("generation_stochastic written")
+
+
 def hostmask_fixture():
     """Host-side SMTP masking: the reference _mask_stacked_input_ids_v2 under a recording random.sample."""
     import random as _random
@@ -475,6 +538,8 @@ def main():
         smtp2d_fixture()
     if not only or "generation" in only:
         generation_fixture()
+    if not only or "generation_stochastic" in only:
+        generation_stochastic_fixture()
     if not only or "hostmask" in only:
         hostmask_fixture()
     if not only or "ref_ckpt" in only:

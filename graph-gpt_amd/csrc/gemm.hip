@@ -826,6 +826,144 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
   }
 }
 
+// In-block K split for the launches with ONE output tile per CU (every N = d GEMM of the step at T = 8192: o / down projections,
+// the dgrads into the residual stream, and the grouped weight gradients): the 8 waves are 2 (M) x 2 (N) x 2 (K) instead of
+// 4 x 2, so a wave owns a sub-tile twice as large (64x96 of 128x192, 96x96 of 192x192) but only one 32-deep half of every
+// 64-deep K-tile.  Same MFMA count per wave, 10 instead of 16 (12 instead of 18) fragment reads per K-tile: the 128x192 tile
+// is bound by LDS fragment traffic (profiles/r02_gemm_structure_experiments.txt: +17 % / +8 % in the pipe micro-benchmark).
+// At the end the two K halves of a sub-tile (waves w and w ^ 4, same SIMD) are added through LDS - the ring is free by
+// then, one tile per block - each wave keeps one row half, and the usual epilogue stores it.
+template <int BM, int BN, bool A_MC, bool B_MC, int EPI>
+__global__ void __launch_bounds__(512, 2) gemm_ks_kernel(const GemmGroup g, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BK = 64, NT = 512;
+  using TA = TileIO<BM, A_MC, NT, BK>;
+  using TB = TileIO<BN, B_MC, NT, BK>;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int NSLOT = persist_slots(STAGE);
+  constexpr int PIECES = TA::PIECES + TB::PIECES;
+  constexpr int MI = BM / 2 / 16, NJ = BN / 2 / 16, HI = MI / 2, HT = HI * NJ;
+  static_assert(MI % 2 == 0 || MI == 3 * 2 / 2 * 2 || true, "row halves");
+  static_assert(8 * HT * 64 * 16 <= NSLOT * STAGE, "accumulator exchange fits in the ring");
+
+  const int G = gridDim.x;
+  const int tile = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);   // XCD-contiguous
+  if (tile >= total_tiles) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GGET_MAX_GROUP; ++i)
+    if (i < g.count && tile >= g.p[i].tile_begin) pi = i;
+  const GemmProblem& P = g.p[pi];
+  int m0, n0;
+  tile_origin(P, P.M, tile - P.tile_begin, BM, BN, g.super, m0, n0);
+  const int nk = P.K >> 6;
+
+  f32x4_t acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(LDS_AS const void*)smem) + (unsigned)wave * 1024u;
+  const unsigned char* kA = reinterpret_cast<const unsigned char*>(P.A);
+  const unsigned char* kB = reinterpret_cast<const unsigned char*>(P.B);
+  const long strideA = A_MC ? (long)BK * P.lda * 2 : (long)BK * 2;
+  const long strideB = B_MC ? (long)BK * P.ldb * 2 : (long)BK * 2;
+  unsigned offA[TA::PIECES], offB[TB::PIECES];
+#pragma unroll
+  for (int i = 0; i < TA::PIECES; ++i) offA[i] = TA::piece_off(P.lda, m0, P.M, wave, lane, i);
+#pragma unroll
+  for (int i = 0; i < TB::PIECES; ++i) offB[i] = TB::piece_off(P.ldb, n0, P.N, wave, lane, i);
+  int islot = 0, cslot = 0, issued = 0;
+  unsigned islot_off = lds0;
+  auto issue_piece = [&](int q) {
+    if (q < TA::PIECES) glds16m(kA, offA[q < TA::PIECES ? q : 0], islot_off + (unsigned)(q * TA::NWAVES * 1024));
+    else glds16m(kB, offB[q >= TA::PIECES ? q - TA::PIECES : 0], islot_off + (unsigned)(A_BYTES + (q - TA::PIECES) * TB::NWAVES * 1024));
+  };
+  auto issue_advance = [&]() {
+    islot = islot == NSLOT - 1 ? 0 : islot + 1;
+    islot_off = islot == 0 ? lds0 : islot_off + (unsigned)STAGE;
+    kA += strideA;
+    kB += strideB;
+    ++issued;
+  };
+#pragma unroll
+  for (int i = 0; i < NSLOT - 1; ++i) {
+    if (issued < nk) {
+#pragma unroll
+      for (int q = 0; q < PIECES; ++q) issue_piece(q);
+      issue_advance();
+    }
+  }
+  for (int t = 0; t < nk; ++t) {
+    // this wave's pieces of K-tile t have landed (issued - t - 1 younger K-tiles may stay in flight)
+    if (issued - t == NSLOT - 1) vm_wait<(NSLOT - 2) * PIECES>();
+    else vm_wait<0>();
+    __syncthreads();
+    const bool did = issued < nk;
+    const unsigned char* a_l = smem + cslot * STAGE;
+    const unsigned char* b_l = a_l + A_BYTES;
+    bf16x8_t af[MI], bf[NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af[i] = TA::frag(a_l, wm * MI + i, wk, lane);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bf[j] = TB::frag(b_l, wn * NJ + j, wk, lane);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+      if (did) {
+#pragma unroll
+        for (int q = i * PIECES / MI; q < (i + 1) * PIECES / MI; ++q) issue_piece(q);
+      }
+    }
+    if (did) issue_advance();
+    cslot = cslot == NSLOT - 1 ? 0 : cslot + 1;
+  }
+  // ---- add the two K halves: wave w keeps row half (wk) of the sub-tile, gives the other half to wave w ^ 4
+  __syncthreads();
+  float4* xch = reinterpret_cast<float4*>(smem);
+#pragma unroll
+  for (int ii = 0; ii < HI; ++ii)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const f32x4_t v = wk == 0 ? acc[HI + ii][j] : acc[ii][j];
+      xch[(size_t)(wave * HT + ii * NJ + j) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  __syncthreads();
+  f32x4_t own[HI][NJ];
+  const int partner = wave ^ 4;
+#pragma unroll
+  for (int ii = 0; ii < HI; ++ii)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float4 o = xch[(size_t)(partner * HT + ii * NJ + j) * 64 + lane];
+      const f32x4_t mine = wk == 0 ? acc[ii][j] : acc[HI + ii][j];
+      own[ii][j] = f32x4_t{mine[0] + o.x, mine[1] + o.y, mine[2] + o.z, mine[3] + o.w};
+    }
+  store_tile<EPI, HI, NJ>(own, P, P.M, (P.N + 3) & ~3, m0 + wm * (MI * 16) + wk * (HI * 16), n0 + wn * (NJ * 16), lane);
+}
+
+template <int BM, int BN, bool A_MC, bool B_MC, int EPI>
+int launch_ks_cfg(GemmGroup& g, int total, hipStream_t st) {
+  constexpr int STG = (BM + BN) * 64 * 2;
+  constexpr int SM = persist_slots(STG) * STG;
+  const int G = (total + 7) & ~7;
+  static bool attr0 = false;
+  if (!attr0) {
+    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ks_kernel<BM, BN, A_MC, B_MC, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SM));
+    attr0 = true;
+  }
+  hipLaunchKernelGGL((gemm_ks_kernel<BM, BN, A_MC, B_MC, EPI>), dim3(G), dim3(512), SM, st, g, total);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
 // launch one persistent configuration: one block per CU (grid rounded to the 8 XCDs)
 template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0>
 int launch_persist_cfg(GemmGroup& g, int total, int num_cu, hipStream_t st) {
@@ -921,6 +1059,14 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
           p.tile_begin = tot3;
           tot3 += ((p.M + 127) / 128) * p.tiles_n;
         }
+        if constexpr (EPI != GGET_EPI_ROPE) {
+          // one tile per CU, nothing device-sized: the K-split arrangement of the same tile (g_gemm_variant bit 0 turns it off)
+          bool ks = tot3 <= num_cu && !(g_gemm_variant & 1);
+          // (K >= 1536: with only 12 K-tiles the accumulator exchange costs what the lighter fragment traffic saves)
+          for (int i = 0; i < g.count; ++i)
+            ks = ks && !g.p[i].m_dev && !g.p[i].k_dev && (g.p[i].N % 192) == 0 && (g.p[i].M % 128) == 0 && g.p[i].K >= 1536;
+          if (ks) return launch_ks_cfg<128, 192, A_MC, B_MC, EPI>(g, tot3, st);
+        }
         return launch_persist_cfg<128, 192, 64, 4, 2, A_MC, B_MC, EPI>(g, tot3, num_cu, st);
       }
     }
@@ -944,6 +1090,11 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
           p.tiles_n = p.N / 192;
           p.tile_begin = tot4;
           tot4 += (p.M / 192) * p.tiles_n;
+        }
+        if (tot4 <= num_cu && !(g_gemm_variant & 2)) {
+          bool ks = true;
+          for (int i = 0; i < g.count; ++i) ks = ks && !g.p[i].m_dev && !g.p[i].k_dev;
+          if (ks) return launch_ks_cfg<192, 192, true, true, EPI>(g, tot4, st);
         }
         return launch_persist_cfg<192, 192, 64, 4, 2, true, true, EPI>(g, tot4, num_cu, st);
       }
@@ -1019,7 +1170,11 @@ int launch_mode(GemmGroup& g, int epi, int split_k, hipStream_t st) {
 int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t st) {
   GGET_REQUIRE(g.count >= 1 && g.count <= GGET_MAX_GROUP, "gemm: bad group size %d", g.count);
   static int ablate = -1;
-  if (ablate < 0) { const char* e = getenv("GGET_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
+  if (ablate < 0) {
+    const char* e = getenv("GGET_GEMM_ABLATE");
+    ablate = e ? atoi(e) : 0;
+    if (const char* v = getenv("GGET_GEMM_VARIANT")) g_gemm_variant = atoi(v);   // same knob as gget_debug_set(1, .), for whole-step A/B
+  }
   g.ablate = ablate;
   static int super = -1;
   if (super < 0) { const char* e = getenv("GGET_GEMM_SUPER"); super = e ? atoi(e) : 0; }

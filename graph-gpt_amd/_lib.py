@@ -62,6 +62,7 @@ SIGNATURES = {
     "gget_hidden_states": (i32, [vp, C.POINTER(vp)]),
     "gget_op_gemm": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "gget_debug_set": (i32, [i32, i32]),
+    "gget_debug_occupy": (i32, [vp, u64, i32, i32, i32, vp]),
     "gget_op_gemm_grouped": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gget_op_rmsnorm_fwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
     "gget_op_rmsnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),

@@ -1007,10 +1007,40 @@ extern "C" int gget_hidden_states(gget_handle_t h, const void** hidden_dev) {
 // ================================================================================================
 // operator-level entry points
 // ================================================================================================
+// Stand-in for a collective's kernel in co-residency measurements (tools/coresidency.py): `blocks` workgroups of 256 threads
+// with `lds_bytes` of LDS each stay resident for ~`microseconds`, streaming a little memory (a ring step's copy / reduce
+// traffic) while they wait.  No reference counterpart: a measurement aid like gget_debug_set.
+__global__ void __launch_bounds__(256) occupy_kernel(float* buf, size_t n, long long ticks) {
+  extern __shared__ float occ_lds[];
+  const long long t0 = wall_clock64();
+  float acc = 0.f;
+  size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) % n;
+  while (wall_clock64() - t0 < ticks) {
+    acc += buf[i];
+    i = (i + 65536) % n;
+    if (threadIdx.x == 0) occ_lds[0] = acc;
+  }
+  if (acc == 1.2345e-30f) buf[0] = acc;
+}
+extern "C" int gget_debug_occupy(void* scratch, uint64_t scratch_bytes, int blocks, int lds_bytes, int microseconds, void* stream) {
+  GGET_REQUIRE(scratch && scratch_bytes >= 4096 && blocks > 0 && lds_bytes >= 4 && lds_bytes <= 160 * 1024, "debug_occupy: bad arguments");
+  static bool attr = false;
+  if (!attr) {
+    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, (float*)scratch, scratch_bytes / 4,
+                     (long long)microseconds * 100);   // wall_clock64 ticks at 100 MHz
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
 extern int g_gemm_variant;
+extern int g_gemm_lds_headroom;
 extern "C" int gget_debug_set(int key, int value) {
   switch (key) {
     case 1: g_gemm_variant = value; return 0;
+    case 2: g_gemm_lds_headroom = value; return 0;
   }
   gget_set_error("debug_set: unknown key %d", key);
   return 2;

@@ -34,6 +34,8 @@
 
 #define LDS_AS __attribute__((address_space(3)))
 
+int g_gemm_lds_headroom = 1;   // 1 (default): the 128x192 tile kernels run a 3-slot ring and leave 40 KiB of LDS free, 0: 4 slots = all 160 KiB
+                               // (gget_debug_set key 2, env GGET_GEMM_LDS_HEADROOM; measured in profiles/r02_coresidency.txt)
 int g_gemm_variant = 0;   // measurement knob (gget_debug_set key 1): selects experimental kernel variants for in-process A/B timing
 
 namespace {
@@ -833,7 +835,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
 // is bound by LDS fragment traffic (profiles/r02_gemm_structure_experiments.txt: +17 % / +8 % in the pipe micro-benchmark).
 // At the end the two K halves of a sub-tile (waves w and w ^ 4, same SIMD) are added through LDS - the ring is free by
 // then, one tile per block - each wave keeps one row half, and the usual epilogue stores it.
-template <int BM, int BN, bool A_MC, bool B_MC, int EPI>
+template <int BM, int BN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0>
 __global__ void __launch_bounds__(512, 2) gemm_ks_kernel(const GemmGroup g, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BK = 64, NT = 512;
@@ -841,7 +843,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ks_kernel(const GemmGroup g, int 
   using TB = TileIO<BN, B_MC, NT, BK>;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int NSLOT = persist_slots(STAGE);
+  constexpr int NSLOT = NSLOT_ > 0 ? NSLOT_ : persist_slots(STAGE);
   constexpr int PIECES = TA::PIECES + TB::PIECES;
   constexpr int MI = BM / 2 / 16, NJ = BN / 2 / 16, HI = MI / 2, HT = HI * NJ;
   static_assert(MI % 2 == 0 || MI == 3 * 2 / 2 * 2 || true, "row halves");
@@ -948,18 +950,18 @@ __global__ void __launch_bounds__(512, 2) gemm_ks_kernel(const GemmGroup g, int 
   store_tile<EPI, HI, NJ>(own, P, P.M, (P.N + 3) & ~3, m0 + wm * (MI * 16) + wk * (HI * 16), n0 + wn * (NJ * 16), lane);
 }
 
-template <int BM, int BN, bool A_MC, bool B_MC, int EPI>
+template <int BM, int BN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0>
 int launch_ks_cfg(GemmGroup& g, int total, hipStream_t st) {
   constexpr int STG = (BM + BN) * 64 * 2;
-  constexpr int SM = persist_slots(STG) * STG;
+  constexpr int SM = (NSLOT_ > 0 ? NSLOT_ : persist_slots(STG)) * STG;
   const int G = (total + 7) & ~7;
   static bool attr0 = false;
   if (!attr0) {
-    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ks_kernel<BM, BN, A_MC, B_MC, EPI>),
+    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ks_kernel<BM, BN, A_MC, B_MC, EPI, NSLOT_>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SM));
     attr0 = true;
   }
-  hipLaunchKernelGGL((gemm_ks_kernel<BM, BN, A_MC, B_MC, EPI>), dim3(G), dim3(512), SM, st, g, total);
+  hipLaunchKernelGGL((gemm_ks_kernel<BM, BN, A_MC, B_MC, EPI, NSLOT_>), dim3(G), dim3(512), SM, st, g, total);
   GGET_LAUNCH_CHECK();
   return 0;
 }
@@ -1065,8 +1067,12 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
           // (K >= 1536: with only 12 K-tiles the accumulator exchange costs what the lighter fragment traffic saves)
           for (int i = 0; i < g.count; ++i)
             ks = ks && !g.p[i].m_dev && !g.p[i].k_dev && (g.p[i].N % 192) == 0 && (g.p[i].M % 128) == 0 && g.p[i].K >= 1536;
+          // g_gemm_lds_headroom (gget_debug_set key 2 / GGET_GEMM_LDS_HEADROOM): 3 ring slots (120 KiB) instead of 4, so that a
+          // collective's workgroup (a few KiB of LDS) can share the CU with the GEMM block
+          if (ks && g_gemm_lds_headroom) return launch_ks_cfg<128, 192, A_MC, B_MC, EPI, 3>(g, tot3, st);
           if (ks) return launch_ks_cfg<128, 192, A_MC, B_MC, EPI>(g, tot3, st);
         }
+        if (g_gemm_lds_headroom) return launch_persist_cfg<128, 192, 64, 4, 2, A_MC, B_MC, EPI, 3>(g, tot3, num_cu, st);
         return launch_persist_cfg<128, 192, 64, 4, 2, A_MC, B_MC, EPI>(g, tot3, num_cu, st);
       }
     }
@@ -1173,7 +1179,8 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
   if (ablate < 0) {
     const char* e = getenv("GGET_GEMM_ABLATE");
     ablate = e ? atoi(e) : 0;
-    if (const char* v = getenv("GGET_GEMM_VARIANT")) g_gemm_variant = atoi(v);   // same knob as gget_debug_set(1, .), for whole-step A/B
+    if (const char* v = getenv("GGET_GEMM_VARIANT")) g_gemm_variant = atoi(v);
+    if (const char* v = getenv("GGET_GEMM_LDS_HEADROOM")) g_gemm_lds_headroom = atoi(v);   // same knob as gget_debug_set(1, .), for whole-step A/B
   }
   g.ablate = ablate;
   static int super = -1;

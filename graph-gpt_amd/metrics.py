@@ -63,3 +63,99 @@ def mrr(pos_scores: np.ndarray, neg_scores: np.ndarray) -> float:
 
 def mae(pred: np.ndarray, target: np.ndarray) -> float:
     return float(np.abs(np.asarray(pred, np.float64).reshape(-1) - np.asarray(target, np.float64).reshape(-1)).mean())
+
+
+# ----------------------------------------------------------------------------- accumulating metric objects of the fine-tune evaluation pass
+class SingleLabelClassificationMetrics:
+    """Counterpart of the reference class of the same name (src/utils/metrics_utils.py:17-80): per batch `update(logits,
+    labels, idx)`; two classes: probability of class 1 feeds AUROC / accuracy, the edge score logit1 - logit0 (fp32) is what
+    is kept for the OGB evaluators; more classes: arg-max accuracy.  torchmetrics is replaced by the NumPy statements above."""
+
+    def __init__(self, device=None, num_labels: int = 2, **kwargs):
+        self.device, self.num_labels = device, num_labels
+        self.auroc = self.acc = None
+        self.ls_prob, self.ls_pred, self.ls_labels, self.ls_idx = [], [], [], []
+
+    def update(self, logits, labels, idx):
+        import torch
+        lg = logits.detach().float()
+        if self.num_labels == 2:
+            self.ls_prob.append(lg.softmax(dim=-1)[:, 1].cpu())
+            y_pred = lg[:, 1] - lg[:, 0]
+        else:
+            y_pred = torch.argmax(lg, dim=-1)
+            labels, idx = labels.reshape(y_pred.shape), idx.reshape(y_pred.shape)
+        self.ls_pred.append(y_pred.cpu())
+        self.ls_labels.append(labels.detach().cpu())
+        self.ls_idx.append(idx.detach().cpu())
+
+    def compute(self):
+        import torch
+        y = torch.hstack(self.ls_labels).numpy()
+        if self.num_labels == 2:
+            prob = torch.hstack(self.ls_prob).numpy()
+            self.auroc = auroc(prob, y)
+            self.acc = float(((prob > 0.5).astype(np.int64) == y).mean())
+        else:
+            self.auroc = -1
+            self.acc = float((torch.hstack(self.ls_pred).numpy() == y).mean())
+
+    def to_dict(self):
+        import torch
+        return {"y_true": torch.hstack(self.ls_labels), "y_pred": torch.hstack(self.ls_pred), "idx": torch.hstack(self.ls_idx)}
+
+    def results_in_tuple(self):
+        return self.auroc, self.acc
+
+    def results_in_dict(self):
+        return {"auroc": self.auroc, "acc": self.acc}
+
+
+class RegressionMetrics:
+    """Counterpart of the reference RegressionMetrics (src/utils/metrics_utils.py:143-189): mean absolute / squared error."""
+
+    def __init__(self, device=None, num_labels: int = 1, **kwargs):
+        self.device = device
+        self.mae = self.mse = None
+        self.ls_pred, self.ls_labels, self.ls_idx = [], [], []
+
+    def update(self, logits, labels, idx):
+        self.ls_pred.append(logits.detach().float().reshape(-1).cpu())
+        self.ls_labels.append(labels.detach().float().reshape(-1).cpu())
+        self.ls_idx.append(idx.detach().reshape(-1).cpu())
+
+    def compute(self):
+        import torch
+        p, y = torch.hstack(self.ls_pred).numpy(), torch.hstack(self.ls_labels).numpy()
+        self.mae = mae(p, y)
+        self.mse = float(((p.astype(np.float64) - y) ** 2).mean())
+
+    def to_dict(self):
+        import torch
+        return {"y_true": torch.hstack(self.ls_labels), "y_pred": torch.hstack(self.ls_pred), "idx": torch.hstack(self.ls_idx)}
+
+    def results_in_tuple(self):
+        return self.mae, self.mse
+
+    def results_in_dict(self):
+        return {"mae": self.mae, "mse": self.mse}
+
+
+def get_metrics(metric_type: str, device=None, num_labels: int = 2):
+    """reference `get_metrics` registry (metrics_utils.py:11-13) for the two problem types of the BASELINE configs."""
+    if metric_type == "single_label_classification":
+        return SingleLabelClassificationMetrics(device, num_labels=num_labels)
+    if metric_type == "regression":
+        return RegressionMetrics(device, num_labels=num_labels)
+    raise NotImplementedError(f"metric_type={metric_type!r} (multi-label / sequence metrics are outside the hot-path scope)")
+
+
+def evaluate_ogb(dataset_name: str, input_dict):
+    """reference `evaluate_ogb` for the datasets of the BASELINE configs (src/utils/ogb_utils.py:83-90 ogbl-ppa Hits@100 over
+    positive / negative edges split by label; :199-204 PCQM4Mv2 MAE).  None for a dataset this package has no evaluator for."""
+    y_true, y_pred = np.asarray(input_dict["y_true"]), np.asarray(input_dict["y_pred"], np.float64)
+    if dataset_name == "ogbl-ppa":
+        return {"hits@100": hits_at_k(y_pred[y_true == 1], y_pred[y_true == 0], 100)}
+    if dataset_name == "PCQM4Mv2":
+        return {"mae": mae(y_pred, y_true)}
+    return None

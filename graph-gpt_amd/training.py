@@ -344,6 +344,60 @@ def evaluate(model, loader, eval_name: str = "valid", do_eval: bool = True):
     return sum(losses) / len(losses), None
 
 
+def all_gather_varlen(q: torch.Tensor) -> torch.Tensor:
+    """reference misc_utils.all_gather (:472-504): concatenates per-rank tensors of different lengths along dim 0."""
+    ws = dist.get_world_size()
+    local = torch.tensor(q.shape[0], device=q.device)
+    sizes = [torch.zeros_like(local) for _ in range(ws)]
+    dist.all_gather(sizes, local)
+    mx = int(max(sizes).item())
+    if mx > q.shape[0]:
+        q = torch.cat([q, torch.zeros([mx - q.shape[0]] + list(q.shape[1:]), device=q.device, dtype=q.dtype)], dim=0)
+    out = [torch.zeros_like(q) for _ in range(ws)]
+    dist.all_gather(out, q)
+    return torch.cat([o[: int(n)] for o, n in zip(out, sizes)])
+
+
+@torch.no_grad()
+def ft_evaluate(model, loader, *, problem_type: str = "single_label_classification", num_labels: int = 2,
+                task_level: str = "task", metric_type: Optional[str] = None, dataset_name: str = "", eval_name: str = "valid"):
+    """Fine-tune evaluation pass, reference log_eval_dump_utils.ft_evaluate (:77-163): eval mode; per batch one forward WITH
+    task labels, sample weights and position_ids; the task loss is averaged over the batches, logits feed the metric object
+    (`update(task_logits, labels, idx)`); with several ranks every entry of the metric's tensor dict is gathered from all
+    ranks (variable length); the dataset's OGB-style evaluator runs on the gathered dict when there is one, otherwise the
+    metric object's own results are returned.  Returns (loss, metrics, eval_result, input_dict) like the reference; the
+    keyword arguments replace the fields the reference reads from its Hydra config."""
+    from . import metrics as M
+    model.eval()
+    device = model.device
+    cls_metrics = M.get_metrics(metric_type or problem_type, device, num_labels=num_labels)
+    test_loss, j = 0, 0
+    for j, data in enumerate(loader, 1):
+        labels = data[f"{task_level}_labels"].to(device)
+        labels = labels.float() if problem_type == "multi_label_classification" else labels
+        res = model(input_ids=data["input_ids"].to(device), attention_mask=data["attention_mask"].to(device),
+                    task_labels=labels, cls_idx=data["cls_idx"].to(device) if "cls_idx" in data else None,
+                    sample_wgt=data["wgt"].to(device) if "wgt" in data else None,
+                    position_ids=data["position_ids"].to(device) if "position_ids" in data else None)
+        test_loss = test_loss + res.task_loss.detach()
+        idx = data["idx"].to(device) if "idx" in data else torch.arange(labels.shape[0], device=device) + (j - 1) * labels.shape[0]
+        cls_metrics.update(res.task_logits, labels, idx)
+    model.train()
+    if j == 0:
+        raise ValueError(f"ft_evaluate: the {eval_name} loader yielded no batch")
+    test_loss = test_loss / j
+    input_dict = cls_metrics.to_dict()
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world > 1:
+        gdev = device if dist.get_backend() == "nccl" else torch.device("cpu")
+        input_dict = {k: all_gather_varlen(v.to(gdev)).cpu() for k, v in input_dict.items()}
+    cls_metrics.compute()
+    res = M.evaluate_ogb(dataset_name, {k: v.numpy() for k, v in input_dict.items()})
+    if res is None:
+        res = cls_metrics.results_in_dict()
+    return test_loss, cls_metrics, res, input_dict
+
+
 # ----------------------------------------------------------------------------- distributed env
 def set_dist_env(backend: Optional[str] = None):
     """reference misc_utils.set_dist_env (:507-539): env:// rendezvous, one process per GPU, barrier."""

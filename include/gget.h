@@ -217,6 +217,9 @@ int gget_op_gemm_grouped(int mode, int count, const void* const* A, const void* 
 /* measurement knob (tools/ only; no reference counterpart): key 1 = bit mask selecting experimental GEMM kernel variants,
  * so that two variants can be timed interleaved in one process (0 = the shipped configuration) */
 int gget_debug_set(int key, int value);
+/* measurement aid (tools/coresidency.py; no reference counterpart): occupies `blocks` CU slots (256 threads, lds_bytes of LDS
+ * each) for ~microseconds on `stream`, as a stand-in for a collective's kernel running beside the compute stream */
+int gget_debug_occupy(void* scratch, uint64_t scratch_bytes, int blocks, int lds_bytes, int microseconds, void* stream);
 /* replaces: q_proj/k_proj/v_proj + apply_rotary_pos_emb (hf LlamaAttention.forward :253-262, :138-160) as ONE GEMM:
  * qkv[T,3d] = x[T,d] * wqkv[3d,d]^T with RoPE applied to the q|k columns in the fp32 accumulators (position of row t is
  * position_ids[t], or t % S when position_ids is NULL; cos/sin tables [max_position][32] fp32). */

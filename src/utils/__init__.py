@@ -9,6 +9,7 @@ _m = _il.import_module("graph-gpt_amd.metrics")
 loader_utils = _types.SimpleNamespace(load_from_ckp=_c.load_from_ckp, load_from_ckp_with_try=_c.load_from_ckp_with_try)
 misc_utils = _types.SimpleNamespace(get_latest_ckp=_c.get_latest_ckp, MODEL_NAME=_c.MODEL_NAME, save_model=_c.save_model)
 metrics_utils = _m
-log_eval_dump_utils = _types.SimpleNamespace(evaluate=_il.import_module("graph-gpt_amd.training").evaluate)
+_t = _il.import_module("graph-gpt_amd.training")
+log_eval_dump_utils = _types.SimpleNamespace(evaluate=_t.evaluate, ft_evaluate=_t.ft_evaluate)
 
 __all__ = ["loader_utils", "misc_utils", "metrics_utils", "log_eval_dump_utils"]

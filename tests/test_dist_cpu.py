@@ -3,6 +3,7 @@ bucketed gradient exchange in the order backward completes the buckets, followed
 import importlib
 import os
 import socket
+import types
 
 import numpy as np
 import torch
@@ -178,3 +179,64 @@ def test_rank_sharding_rules_gloo_world2():
     assert sorted(pta) == sorted(ptb) == sorted(list(range(100, 150)) * 2) and pta != ptb
     tr = importlib.import_module("graph-gpt_amd.training")
     assert tr.schedule_steps(1e9, 20.0, 256, 8) == int(1e9 // (20.0 * 256 * 8))
+
+
+class _FakeTaskModel:
+    """Stands in for GraphGPTTaskModel in the fine-tune evaluation pass: logits are a fixed function of the sample index."""
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self.mode = "train"
+
+    def eval(self):
+        self.mode = "eval"
+
+    def train(self):
+        self.mode = "train"
+
+    def __call__(self, **kw):
+        assert self.mode == "eval" and kw["position_ids"] is not None and kw["task_labels"] is not None
+        s = kw["input_ids"][:, 0, 0].float()                      # the sample's id doubles as its score
+        lg = torch.stack([torch.zeros_like(s), s], dim=1)
+        out = types.SimpleNamespace(task_loss=s.mean(), task_logits=lg)
+        return out
+
+
+def _ft_eval_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    tr.set_dist_env(backend="gloo")
+    # eval sharding rule: sorted positions modulo world; rank 0 gets 6 samples, rank 1 gets 5 (variable-length gather)
+    mine = tr.eval_rank_sampler(list(range(11)), world, rank)
+    loader = []
+    for a in range(0, len(mine), 4):
+        ids = torch.tensor(mine[a:a + 4])
+        loader.append({"input_ids": ids.view(-1, 1, 1).repeat(1, 3, 2), "attention_mask": torch.ones(len(ids), 3, dtype=torch.int64),
+                       "position_ids": torch.arange(3)[None].repeat(len(ids), 1), "task_labels": (ids % 2), "idx": ids})
+    m = _FakeTaskModel()
+    loss, met, res, d = tr.ft_evaluate(m, loader, problem_type="single_label_classification", num_labels=2, dataset_name="ogbl-ppa")
+    q.put((rank, float(loss), res, {k: v.tolist() for k, v in d.items()}, m.mode))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ft_evaluate_gathers_all_ranks_gloo_world2():
+    """reference log_eval_dump_utils.ft_evaluate (:77-163): every rank evaluates its eval shard, the metric tensors of all ranks
+    are gathered (different lengths), the dataset evaluator sees every sample exactly once."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_ft_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, loss, ogb, d, mode in res:
+        assert mode == "train"
+        assert sorted(d["idx"]) == list(range(11)) and len(d["y_pred"]) == 11          # gathered: every sample once
+        assert sorted(zip(d["idx"], d["y_pred"])) == [(i, float(i)) for i in range(11)]
+        # positives = odd ids {1,3,5,7,9}, negatives = even ids: fewer than 100 negatives -> Hits@100 = 1 (OGB convention)
+        assert ogb == {"hits@100": 1.0}
+    # per-rank mean of per-batch mean scores
+    assert abs(res[0][1] - np.mean([np.mean([0, 2, 4, 6]), np.mean([8, 10])])) < 1e-6

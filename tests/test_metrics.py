@@ -41,3 +41,31 @@ def test_mae_on_reference_regression_logits():
     assert abs(M.mae(z["logits"], batch["task_labels"]) - mean_absolute_error(batch["task_labels"], z["logits"].reshape(-1))) < 1e-6
     # the reference's L1 task loss IS the MAE of the pooled logits (modeling_finetune.py:183-197)
     assert abs(M.mae(z["logits"], batch["task_labels"]) - float(z["loss"])) < 1e-5
+
+
+def test_metric_objects_and_ogb_evaluators():
+    """The accumulating metric objects of the fine-tune evaluation pass (reference metrics_utils.py:17-80, :143-189) and the
+    dataset evaluators (ogb_utils.py:83-90, :199-204) on batches fed piecewise."""
+    import torch
+    rng = np.random.RandomState(1)
+    lg = torch.from_numpy(rng.randn(300, 2).astype(np.float32))
+    y = torch.from_numpy(rng.randint(0, 2, 300))
+    m = M.get_metrics("single_label_classification", None, num_labels=2)
+    for a in range(0, 300, 64):
+        m.update(lg[a:a + 64], y[a:a + 64], torch.arange(a, min(a + 64, 300)))
+    m.compute()
+    score = (lg[:, 1] - lg[:, 0]).numpy()
+    assert abs(m.auroc - roc_auc_score(y.numpy(), score)) < 1e-9          # AUROC is invariant under softmax vs score
+    assert m.acc == float(((score > 0).astype(int) == y.numpy()).mean())
+    d = m.to_dict()
+    np.testing.assert_allclose(d["y_pred"].numpy(), score, rtol=1e-6)
+    assert list(d["idx"].numpy()) == list(range(300))
+    res = M.evaluate_ogb("ogbl-ppa", {k: v.numpy() for k, v in d.items()})
+    assert res == {"hits@100": M.hits_at_k(score[y.numpy() == 1], score[y.numpy() == 0], 100)}
+    r = M.get_metrics("regression", None, num_labels=1)
+    pred, tgt = torch.from_numpy(rng.randn(50, 1).astype(np.float32)), torch.from_numpy(rng.randn(50).astype(np.float32))
+    r.update(pred, tgt, torch.arange(50))
+    r.compute()
+    assert abs(r.mae - mean_absolute_error(tgt.numpy(), pred.numpy().reshape(-1))) < 1e-7
+    assert M.evaluate_ogb("PCQM4Mv2", {k: v.numpy() for k, v in r.to_dict().items()})["mae"] == r.mae
+    assert M.evaluate_ogb("some-other-dataset", {"y_true": [0], "y_pred": [0.0]}) is None

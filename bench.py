@@ -273,11 +273,11 @@ def main():
                          "traffic": pmc_traffic() if B * S == 8192 and spec.hidden_size == 768 else None,
                          "avg_launch_ms": gu_ms,
                          "other_kernels": [
-                             {"kernel": "gemm_persist_kernel<128,192,64,NN> dgrad dxn2 = dgu W_gu [T,2ff]x[2ff,d]",
+                             {"kernel": "gemm_ks_kernel<128,192,NN> (in-block K split) dgrad dxn2 = dgu W_gu [T,2ff]x[2ff,d]",
                               "step_flops_pct": share(kt["dgrad_gu"][0]), "avg_launch_ms": kt["dgrad_gu"][1],
                               "achieved": kt["dgrad_gu"][0] / (kt["dgrad_gu"][1] * 1e-3) / 1e12,
                               "frac": kt["dgrad_gu"][0] / (kt["dgrad_gu"][1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS},
-                             {"kernel": "gemm_persist_kernel<192,192,64,TN> grouped weight gradients of one layer (gate|up, down, q|k|v, o; K = T)",
+                             {"kernel": "gemm_ks_kernel<192,192,TN> (in-block K split) grouped weight gradients of one layer (gate|up, down, q|k|v, o; K = T)",
                               "step_flops_pct": share(kt["wgrad_layer"][0]), "avg_launch_ms": kt["wgrad_layer"][1],
                               "achieved": kt["wgrad_layer"][0] / (kt["wgrad_layer"][1] * 1e-3) / 1e12,
                               "frac": kt["wgrad_layer"][0] / (kt["wgrad_layer"][1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}]},

@@ -16,6 +16,8 @@ LIB = os.path.join(LIBDIR, "libgget_hip.so")
 SOURCES = ["engine.hip", "gemm.hip", "kernels.hip", "attention.hip"]
 HEADERS = ["common.h", "gemm.h", "kernels.h", os.path.join("..", "..", "include", "gget.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# per-file extra flags (none at present; -fno-slp-vectorize on attention.hip was tried: forward unchanged, backward 2x slower)
+EXTRA_FLAGS = {}
 
 
 def _hipcc() -> str:
@@ -31,6 +33,7 @@ def _digest() -> str:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -47,7 +50,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

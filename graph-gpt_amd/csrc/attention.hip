@@ -15,6 +15,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 #define LDS_AS __attribute__((address_space(3)))
 
@@ -22,7 +23,10 @@ namespace {
 
 constexpr float kScale = 0.125f;  // head_dim^-0.5, head_dim = 64
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kScaleL2 = kScale * kLog2e;   // scores are carried in the log2 domain: p = exp2(s * kScaleL2 - m2)
+constexpr float kScaleL2 = kScale * kLog2e;
+// v_exp_f32 alone: the library exp2f wraps it in a range check + scaling (6 instructions) to keep denormal results, which a
+// probability never needs - the softmax loops are VALU-bound (PMC: 225 VALU instructions per 32x32 score tile before, 62 % VALU busy)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // scores are carried in the log2 domain: p = exp2(s * kScaleL2 - m2)
 
 // [32 rows][128 B] tile: the 16-byte chunk index is XORed with a 3-bit function of the row so that both access patterns
 // are bank-conflict free: ds_read_b128 of one chunk over 16 consecutive rows (rows of equal parity need 8 distinct chunk
@@ -184,23 +188,35 @@ __device__ __forceinline__ bf16x8_t frag_global(const bf16_t* __restrict__ base,
 // launch script sets attention_dropout=0.1).  Counter-based: the keep decision of element (batch*head, query, key) is a
 // hash of (seed, coordinates), so forward and the two backward kernels regenerate the same mask without storing it.
 struct Drop {
-  unsigned thresh;   // drop when hash24 < thresh  (thresh = p * 2^24); 0 => no dropout
+  unsigned thresh;   // drop when the 16-bit field < thresh  (thresh = p * 2^16); 0 => no dropout
   float inv_keep;    // 1 / (1 - p)
   unsigned seed;
 };
-// hash(seed, bh, q, k) = mix((seed ^ bh*C0) + q*C1 + k*C2), mix = one multiply between two xor-shifts: the softmax loop is
-// VALU-bound (head_dim 64) and integer multiplies are quarter rate, so the per-element cost is kept to 2 adds + 1 multiply:
-// callers pass the partial sum of everything that is fixed for the lane (drop_base) and add the moving coordinate's term.
-__device__ __forceinline__ unsigned drop_base(const Drop& D, unsigned bh, unsigned q_or_0, unsigned k_or_0) {
-  return (D.seed ^ (bh * 0x9E3779B1u)) + q_or_0 * 0x85EBCA77u + k_or_0 * 0xC2B2AE3Du;
+// One hash serves TWO scores: w(seed, bh, q, k >> 1) = mix((seed ^ bh*C0) + q*C1 + (k>>1)*C2), mix = one multiply between two
+// xor-shifts; key k uses the low (k even) or high (k odd) 16 bits of w (measured on 3 M scores: drop rates 0.1000 / 0.2998
+// for p = 0.1 / 0.3 in both fields, correlations between the fields of a pair, neighbouring keys, queries and heads <= 2e-3).
+// The softmax loops are VALU-bound at head_dim 64 and a 32-bit multiply is quarter rate: in the kernels whose lanes walk
+// along keys (forward, dQ) a lane's accumulator registers come in (k, k+1) pairs, so the hash costs one multiply per two
+// scores.  Callers pass the partial sum of everything fixed for the lane (drop_base) and add the moving term.
+// tests/test_gpu_ops.py:_drop_mask is the Python twin.
+__device__ __forceinline__ unsigned drop_base(const Drop& D, unsigned bh, unsigned q_or_0, unsigned khalf_or_0) {
+  return (D.seed ^ (bh * 0x9E3779B1u)) + q_or_0 * 0x85EBCA77u + khalf_or_0 * 0xC2B2AE3Du;
 }
-__device__ __forceinline__ float drop_mul_x(const Drop& D, unsigned x) {
+__device__ __forceinline__ unsigned drop_word(unsigned x) {
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  return x;
+}
+// keep-multiplier of key parity `odd` from the pair's hash word
+__device__ __forceinline__ float drop_mul_w(const Drop& D, unsigned w, int odd) {
+  const unsigned f = odd ? (w >> 16) : (w & 0xffffu);
+  return f < D.thresh ? 0.f : D.inv_keep;
+}
+// single score: x = drop_base(D, bh, q, 0) + (k >> 1) * C2 already summed by the caller
+__device__ __forceinline__ float drop_mul_x(const Drop& D, unsigned x, int odd) {
   if (D.thresh == 0) return 1.f;
-  x ^= x >> 16; x *= 0x045D9F3Bu; x ^= x >> 16;
-  return (x >> 8) < D.thresh ? 0.f : D.inv_keep;
-}
-__device__ __forceinline__ float drop_mul(const Drop& D, unsigned bh, unsigned q, unsigned k) {
-  return drop_mul_x(D, drop_base(D, bh, q, k));
+  return drop_mul_w(D, drop_word(x), odd);
 }
 
 // Which keys a query may attend: right padding gives one length per batch row (key_len[b], keys [0, len)); packed rows
@@ -382,14 +398,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m, mx * kScaleL2);     // kScaleL2 > 0: max commutes with the scaling
     const bool dead = m_new == -INFINITY;
-    const float alpha = dead ? 1.f : exp2f(m - m_new);
+    const float alpha = dead ? 1.f : fast_exp2(m - m_new);
     const float nm = dead ? 0.f : -m_new;
     float rs = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = dead ? 0.f : exp2f(fmaf(sc[r], kScaleL2, nm));
+      const float p = fast_exp2(fmaf(sc[r], kScaleL2, nm));   // masked scores are -inf -> 0
       rs += p;                                                                    // softmax normaliser: before dropout
-      sc[r] = p * drop_mul_x(D, dbase + (unsigned)(k0 + acc_row(r, hi)) * 0xC2B2AE3Du);   // what multiplies V
+      sc[r] = p * drop_mul_x(D, dbase + (unsigned)((k0 + acc_row(r, hi)) >> 1) * 0xC2B2AE3Du, r & 1);   // what multiplies V (acc_row parity = r & 1)
     }
     rs += __shfl_xor(rs, 32, 64);
     l = l * alpha + rs;
@@ -501,9 +517,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + acc_row(r, hi);
-      float p = exp2f(fmaf(sc[r], kScaleL2, nlse2));
+      float p = fast_exp2(fmaf(sc[r], kScaleL2, nlse2));
       if (edge) p = (key >= qlo && key <= qhi && (!causal || key <= qrow) && qrow < S) ? p : 0.f;
-      sc[r] = p * fmaf(dp[r], drop_mul_x(D, dbase + (unsigned)key * 0xC2B2AE3Du), ndl) * kScale;
+      sc[r] = p * fmaf(dp[r], drop_mul_x(D, dbase + (unsigned)(key >> 1) * 0xC2B2AE3Du, key & 1), ndl) * kScale;
     }
     const bf16x8_t ds0 = acc_to_b(sc, 0), ds1 = acc_to_b(sc, 1);
     a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 0, lane), ds0, a0, 0, 0, 0);
@@ -547,7 +563,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
 #pragma unroll
   for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, krow, S, pitch, s, lane);
   f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
-  const unsigned dbase = drop_base(D, b * H + h, 0, krow);
+  const unsigned dbase = drop_base(D, b * H + h, 0, (unsigned)krow >> 1);
   const bool key_ok = krow < klen;                 // right-padded rows: one key length per batch row
   const int kblk0 = blockIdx.x * NW * 32;          // first key of the block
   const int qstart = causal ? kblk0 : 0;           // queries before the block's first key never see it
@@ -616,12 +632,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
       for (int r = 0; r < 16; ++r) {
         const int qi = acc_row(r, hi);
         const int q = q0 + qi;
-        float p = exp2f(fmaf(sc[r], kScaleL2, lse_s[qi]));          // lse_s holds -lse * log2(e)
+        float p = fast_exp2(fmaf(sc[r], kScaleL2, lse_s[qi]));          // lse_s holds -lse * log2(e)
         if (edge) {
           const bool in_range = packed ? (krow >= qlo_s[qi] && krow <= qhi_s[qi]) : key_ok;
           p = (in_range && q < S && (!causal || krow <= q)) ? p : 0.f;
         }
-        const float dm = drop_mul_x(D, dbase + (unsigned)q * 0x85EBCA77u);
+        const float dm = drop_mul_x(D, dbase + (unsigned)q * 0x85EBCA77u, krow & 1);
         sc[r] = p * dm;                                  // dropped probabilities: what multiplied V in forward
         dp[r] = p * fmaf(dp[r], dm, dl_s[qi]) * kScale;  // dl_s holds -delta
       }
@@ -696,8 +712,8 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
     for (int r = 0; r < 16; ++r) {
       const int key = acc_row(r, hi);
       const bool ok = key < klen && (!causal || key <= qrow) && qrow < S;
-      const float p = ok ? exp2f(fmaf(sc[r], kScaleL2, nlse2)) : 0.f;
-      const float t = dp[r] * drop_mul_x(D, dbase + (unsigned)key * 0xC2B2AE3Du);
+      const float p = ok ? fast_exp2(fmaf(sc[r], kScaleL2, nlse2)) : 0.f;
+      const float t = dp[r] * drop_mul_x(D, dbase + (unsigned)(key >> 1) * 0xC2B2AE3Du, key & 1);
       dl = fmaf(p, t, dl);
       sc[r] = p;
       dp[r] = t;
@@ -721,7 +737,7 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
   {   // ---------------- dV^T = dO^T P, dK^T = Q^T dS   (lane owns key l31)
     const int krow = l31;
     const bool key_ok = krow < klen;
-    const unsigned dbase = drop_base(D, bh, 0, krow);
+    const unsigned dbase = drop_base(D, bh, 0, (unsigned)krow >> 1);
     f32x16_t sc = zero16(), dp = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -732,8 +748,8 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
     for (int r = 0; r < 16; ++r) {
       const int q = acc_row(r, hi);
       const bool ok = key_ok && q < S && (!causal || krow <= q);
-      const float p = ok ? exp2f(fmaf(sc[r], kScaleL2, lse_s[q])) : 0.f;
-      const float dm = drop_mul_x(D, dbase + (unsigned)q * 0x85EBCA77u);
+      const float p = ok ? fast_exp2(fmaf(sc[r], kScaleL2, lse_s[q])) : 0.f;
+      const float dm = drop_mul_x(D, dbase + (unsigned)q * 0x85EBCA77u, krow & 1);
       sc[r] = p * dm;
       dp[r] = p * fmaf(dp[r], dm, dl_s[q]) * kScale;
     }
@@ -757,12 +773,779 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
   }
 }
 
+// ================================================================================================
+// Long-sequence kernels (S >= 256, q / k already rotated in memory - the engine's layout): 8 waves per block = 256 rows
+// of one (batch, head); the operand that is streamed (K and V, or Q and dO) arrives by LDS-DMA in stages of 64 rows
+// (2 arrays x 8 KiB, two [32][128 B] swizzled tiles each) through a double buffer: ONE barrier per 64 rows, the next stage's
+// DMA is issued right behind it and flies under the 16-32 MFMAs + softmax of the current one; no VALU work for loading
+// (the swizzle is a permutation of the per-lane source chunk, the LDS image of a piece is lane-linear).  The per-32x32 math
+// is the one of the kernels above (transposed scores, lane-local statistics, P^T feeds the next MFMA from registers), with
+// the paired dropout hash (one multiply per two scores where the lane walks along keys).  Rows beyond the sequence are
+// clamped (finite) and masked.  Packed rows: the block's union of key ranges bounds the stage loop, so whole stages are
+// neither loaded nor computed.
+// ================================================================================================
+__device__ __forceinline__ void attn_glds16(const void* gsrc, const unsigned char* lds_dst) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(LDS_AS const void*)lds_dst);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(dst)
+      : "memory");
+}
+// piece p (0..7) of a 64-row stage array: rows [8p, 8p+8) x 128 B; lane -> (row, LDS slot), source chunk = slot ^ f(row)
+__device__ __forceinline__ void stage_piece(unsigned char* arr, const bf16_t* __restrict__ base, size_t pitch, int r0, int row_lim,
+                                            int p, int lane) {
+  const int row = p * 8 + (lane >> 3), slot = lane & 7;
+  const int x = (row >> 1) & 7;
+  const int f = ((x & 1) << 2) | (x >> 1);
+  const int gr = min(r0 + row, row_lim - 1);
+  attn_glds16(base + (size_t)gr * pitch + ((slot ^ f) << 3), arr + p * 1024);
+}
+// the block's 8 waves load one stage (two arrays): wave w issues pieces w and w + 8
+__device__ __forceinline__ void stage_issue(unsigned char* buf /* [2][8192] */, const bf16_t* __restrict__ a0, size_t pitch0,
+                                            const bf16_t* __restrict__ a1, size_t pitch1, int r0, int row_lim, int wave, int lane) {
+  stage_piece(buf, a0, pitch0, r0, row_lim, wave, lane);
+  stage_piece(buf + 8192, a1, pitch1, r0, row_lim, wave, lane);
+}
+__device__ __forceinline__ void attn_vm_wait0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// block-wide min / max of two small ints through LDS (packed rows: union of the waves' key ranges)
+__device__ __forceinline__ void block_range(int& lo, int& hi, int* red /* [16] */, int wave, int lane) {
+  if (lane == 0) { red[wave] = lo; red[8 + wave] = hi; }
+  __syncthreads();
+  int l = red[0], h = red[8];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) { l = min(l, red[i]); h = max(h, red[8 + i]); }
+  lo = l; hi = h;
+  __syncthreads();
+}
+
+// Forward: a wave owns QT = 2 consecutive 32-query tiles, so every K fragment (ds_read_b128) and every transposed V fragment
+// (ds_read_b64_tr_b16 pair) read from LDS feeds two MFMAs (the 32-query version spends one LDS KiB per MFMA: half of the CU's LDS
+// bandwidth at full matrix rate) and the two score accumulators are independent MFMA chains.  Block = NWB waves.
+template <bool PK, int QT, int NWB>
+__global__ void __launch_bounds__(NWB * 64, QT == 1 ? 4 : 2) attn_fwd64_kernel(const bf16_t* __restrict__ qkv, KeyRange KR, bf16_t* __restrict__ out,
+                                                                 float* __restrict__ lse, int B, int S, int H, int causal, Drop D) {
+  __shared__ __attribute__((aligned(16))) unsigned char st[2][2 * 8192];
+  __shared__ int red[16];
+  constexpr int QB = NWB * QT * 32;   // queries per block
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * QB + wave * (QT * 32);      // first query of this wave
+  const int d = H * 64;
+  const size_t pitch = (size_t)3 * d;
+  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* kb = qb + d;
+  const bf16_t* vb = qb + 2 * d;
+  int qlo[QT], qhi[QT];
+  int ulo = S, uhi = -1, ilo = 0, ihi = S - 1;            // union / intersection over the wave's QT * 32 queries
+  const int len = KR.key_len ? KR.key_len[b] : S;
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int qrow = q0 + 32 * t + l31;
+    qlo[t] = 0; qhi[t] = len - 1;
+    if (PK) {
+      const bool v = qrow < S;
+      qlo[t] = v ? KR.lo[(size_t)b * S + qrow] : 0;
+      qhi[t] = v ? KR.hi[(size_t)b * S + qrow] : -1;
+      ulo = min(ulo, wave_imin(qhi[t] >= qlo[t] ? qlo[t] : S)); uhi = max(uhi, wave_imax(qhi[t] >= qlo[t] ? qhi[t] + 1 : 0) - 1);
+      ilo = max(ilo, wave_imax(v ? qlo[t] : 0)); ihi = min(ihi, wave_imin(v ? qhi[t] + 1 : S) - 1);
+    }
+  }
+  if (!PK) { ulo = 0; uhi = len - 1; ilo = 0; ihi = len - 1; }
+  const int klen = PK ? S : len;
+  const int q_end_blk = min(S, (int)(blockIdx.x + 1) * QB);
+  int kbeg_blk = 0, kend_blk = causal ? min(klen, q_end_blk) : klen;
+  if (PK) {
+    int blo = ulo, bhi = uhi;
+    block_range(blo, bhi, red, wave, lane);
+    kbeg_blk = min(max(blo, 0), S) & ~63;
+    kend_blk = min(kend_blk, bhi + 1);
+  }
+  const int kend = (q0 < S) ? min(uhi + 1, causal ? q0 + QT * 32 : S) : 0;   // this wave's own key range
+
+  bf16x8_t qf[QT][4];
+  f32x16_t o0[QT], o1[QT];
+  float m[QT], l[QT];
+  unsigned dbase[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int qrow = q0 + 32 * t + l31;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[t][s] = frag_global(qb, qrow, S, pitch, s, lane);
+    o0[t] = zero16(); o1[t] = zero16();
+    m[t] = -INFINITY; l[t] = 0.f;
+    dbase[t] = drop_base(D, b * H + h, qrow, 0);
+  }
+  constexpr int PPW = 16 / NWB;     // DMA pieces per wave per stage (16 pieces of 1 KiB: K 8, V 8)
+  auto issue = [&](int buf, int r0) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave * PPW + i;   // 0..15
+      if (pc < 8) stage_piece(st[buf], kb, pitch, r0, S, pc, lane);
+      else stage_piece(st[buf] + 8192, vb, pitch, r0, S, pc - 8, lane);
+    }
+  };
+  const int nst = kend_blk > kbeg_blk ? (kend_blk - kbeg_blk + 63) >> 6 : 0;
+  if (nst > 0) issue(0, kbeg_blk);
+  for (int t = 0; t < nst; ++t) {
+    const int ks = kbeg_blk + t * 64;
+    attn_vm_wait0();          // this wave's pieces of stage t have landed
+    __syncthreads();          // everyone's have; everyone is done with stage t-1 (the buffer refilled next)
+    if (t + 1 < nst) issue((t + 1) & 1, ks + 64);
+    const unsigned char* kst = st[t & 1];
+    const unsigned char* vst = kst + 8192;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k0 = ks + 32 * j;
+      if (k0 >= kend || k0 + 31 < ulo) continue;
+      const unsigned char* kt = kst + 4096 * j;
+      const unsigned char* vt = vst + 4096 * j;
+      f32x16_t sc[QT];
+#pragma unroll
+      for (int t2 = 0; t2 < QT; ++t2) sc[t2] = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8_t kf = frag_rows(kt, s, lane);
+#pragma unroll
+        for (int t2 = 0; t2 < QT; ++t2) sc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t2][s], sc[t2], 0, 0, 0);
+      }
+      const bool edge = (k0 < ilo) || (k0 + 31 > ihi) || (causal && k0 + 31 > q0) || (q0 + QT * 32 > S);
+      bf16x8_t pb[QT][2];
+#pragma unroll
+      for (int t2 = 0; t2 < QT; ++t2) {
+        const int qrow = q0 + 32 * t2 + l31;
+        float mx = -INFINITY;
+        if (edge) {
+          // (the opaque copy keeps the 31 index / compare instructions of the mask INSIDE this rarely taken branch: hipcc
+          // otherwise hoists them above it and every tile pays for them)
+          int k0v = k0;
+          asm volatile("" : "+v"(k0v));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = k0v + acc_row(r, hi);
+            const bool ok = key >= qlo[t2] && key <= qhi[t2] && (!causal || key <= qrow);
+            sc[t2][r] = ok ? sc[t2][r] : -INFINITY;
+            mx = fmaxf(mx, sc[t2][r]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[t2][r]);
+        }
+        {
+          const hw_u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+          mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float m_new = fmaxf(m[t2], mx * kScaleL2);
+        const bool dead = m_new == -INFINITY;
+        const float alpha = dead ? 1.f : fast_exp2(m[t2] - m_new);
+        const float nm = dead ? 0.f : -m_new;
+        float rs = 0.f;
+        if (D.thresh == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = fast_exp2(fmaf(sc[t2][r], kScaleL2, nm));   // masked scores are -inf -> 0
+            rs += p;
+            sc[t2][r] = p;
+          }
+        } else {
+          // registers (2 rp, 2 rp + 1) are keys (k, k + 1) = one hash word; (k >> 1) = (k0 >> 1) + 2 hi + (rp & 1) + 4 (rp >> 1): the
+          // lane's part is one multiply per tile, the register's part a literal.  The keep scale 1 / (1 - p) is applied once to
+          // O at the end (l sums the un-dropped probabilities), so a dropped score costs one select.
+          const unsigned xb = dbase[t2] + (unsigned)((k0 >> 1) + 2 * hi) * 0xC2B2AE3Du;
+#pragma unroll
+          for (int rp = 0; rp < 8; ++rp) {
+            const unsigned w = drop_word(xb + (unsigned)((rp & 1) + 4 * (rp >> 1)) * 0xC2B2AE3Du);
+            const float p0 = fast_exp2(fmaf(sc[t2][2 * rp], kScaleL2, nm));
+            const float p1 = fast_exp2(fmaf(sc[t2][2 * rp + 1], kScaleL2, nm));
+            rs += p0 + p1;                                      // softmax normaliser: before dropout
+            sc[t2][2 * rp] = (w & 0xffffu) < D.thresh ? 0.f : p0;      // what multiplies V (x 1 / (1 - p) at the end)
+            sc[t2][2 * rp + 1] = (w >> 16) < D.thresh ? 0.f : p1;
+          }
+        }
+        {
+          const hw_u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rs), __float_as_uint(rs), false, false);
+          rs = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        l[t2] = l[t2] * alpha + rs;
+        m[t2] = m_new;
+        if (__any(alpha != 1.f)) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { o0[t2][r] *= alpha; o1[t2][r] *= alpha; }
+        }
+        pb[t2][0] = acc_to_b(sc[t2], 0);
+        pb[t2][1] = acc_to_b(sc[t2], 1);
+      }
+#pragma unroll
+      for (int dhb = 0; dhb < 2; ++dhb)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const bf16x8_t vf = frag_tr(vt, dhb, jj, lane);
+#pragma unroll
+          for (int t2 = 0; t2 < QT; ++t2) {
+            if (dhb == 0) o0[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[t2][jj], o0[t2], 0, 0, 0);
+            else o1[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[t2][jj], o1[t2], 0, 0, 0);
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int qrow = q0 + 32 * t + l31;
+    if (qrow < S) {
+      const float inv = l[t] > 0.f ? D.inv_keep / l[t] : 0.f;   // (D.inv_keep = 1 without dropout)
+      store_t(out + ((size_t)b * S + qrow) * d + h * 64, o0[t], o1[t], inv, hi);
+      if (hi == 0 && lse) lse[((size_t)b * H + h) * S + qrow] = l[t] > 0.f ? (m[t] + log2f(l[t])) * (1.0f / kLog2e) : 0.f;
+    }
+  }
+}
+
+// Forward for the dense case (one key length per batch row, not causal: fine-tuning batches), software-pipelined inside the
+// wave.  Measured on gfx950 (tools/ubench/valu_mfma.hip, profiles/r02_valu_mfma_overlap.txt): a SIMD overlaps MFMA and VALU
+// work only when they alternate in ONE wave's instruction stream - "all MFMAs, then all VALU" runs at ~86 % of the SUM of the
+// two even with four waves per SIMD, and attn_fwd64_kernel sits exactly there (VALU 67 % + MFMA 30 % busy) - while the softmax
+// of a 32x32 tile is more VALU time than its 8 MFMAs.  So step j issues the P.V MFMAs of tile j-1 and the score MFMAs of tile
+// j+1 between the softmax instructions of tile j: eight chunks of {one MFMA, one LDS fragment fetch two chunks ahead, an eighth
+// of the softmax}, pinned by scheduling fences (the compiler otherwise bunches the MFMAs, and a burst of MFMAs blocks the
+// SIMD's vector issue of the other waves).  K stages are needed one tile early and V stages one tile late: two rings of
+// three 8 KiB slots (K(t), K(t+1) resident + K(t+2) in flight; V(t-1), V(t) resident + V(t+1) in flight), one barrier per 64
+// keys, the stage loop unrolled by three so every LDS address is lane offset + immediate.  All waves of a block see the same
+// keys, so the loop is branch-free (the lazy rescale of the running output aside); the last one or two tiles (key_len not
+// a multiple of 64) take the sequential masked path.
+#define GGET_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <bool DROP, int NWB>
+__global__ void __launch_bounds__(NWB * 64, NWB == 8 ? 4 : 3) attn_fwd_dense_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
+                                                                                    bf16_t* __restrict__ out, float* __restrict__ lse, int B, int S,
+                                                                                    int H, Drop D) {
+  __shared__ __attribute__((aligned(16))) unsigned char kr[3][8192];
+  __shared__ __attribute__((aligned(16))) unsigned char vr[3][8192];
+  constexpr int QB = NWB * 32;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * QB + wave * 32;
+  const int d = H * 64;
+  const size_t pitch = (size_t)3 * d;
+  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* kb = qb + d;
+  const bf16_t* vb = qb + 2 * d;
+  const int qrow = q0 + l31;
+  const int len = key_len ? min(key_len[b], S) : S;
+  const int nfull = len >> 5;                        // tiles whose 32 keys are all visible
+  const int ntile = (len + 31) >> 5;
+  const int nst = (ntile + 1) >> 1;
+  const int nfs = nfull >> 1;                        // stages the pipelined loop covers (both tiles full)
+
+  bf16x8_t qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = frag_global(qb, qrow, S, pitch, s, lane);
+  f32x16_t o0 = zero16(), o1 = zero16();
+  float m = -INFINITY, l = 0.f;
+  const unsigned dbase = drop_base(D, b * H + h, qrow, 0);
+
+  constexpr int PPW = 16 / NWB;
+  auto issue = [&](int t, unsigned char* kdst, unsigned char* vdst) {   // at the top of stage t: K(t+2) and V(t+1)
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave * PPW + i;
+      if (pc < 8) { if (t + 2 < nst) stage_piece(kdst, kb, pitch, (t + 2) * 64, S, pc, lane); }
+      else { if (t + 1 < nst) stage_piece(vdst, vb, pitch, (t + 1) * 64, S, pc - 8, lane); }
+    }
+  };
+  auto qk = [&](const unsigned char* kt, f32x16_t& sc) {
+    sc = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), qf[s], sc, 0, 0, 0);
+  };
+  auto pv = [&](const unsigned char* vt, const bf16x8_t (&pb)[2]) {
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 0, lane), pb[0], o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 0, lane), pb[0], o1, 0, 0, 0);
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 1, lane), pb[1], o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 1, lane), pb[1], o1, 0, 0, 0);
+  };
+  auto rescale = [&](float alpha) {
+    if (__any(alpha != 1.f)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    }
+  };
+  // pieces of the softmax of one tile (sc -> probabilities in place)
+  const hw_f32x2_t sc2 = {kScaleL2, kScaleL2};
+  auto drop_pair = [&](unsigned xb, int rp, hw_f32x2_t& pp2) {
+    // registers (2 rp, 2 rp + 1) are keys (k, k + 1) = one hash word (see attn_fwd64_kernel); 1 / (1 - p) is applied at the end
+    const unsigned w = drop_word(xb + (unsigned)((rp & 1) + 4 * (rp >> 1)) * 0xC2B2AE3Du);
+    pp2[0] = (w & 0xffffu) < D.thresh ? 0.f : pp2[0];
+    pp2[1] = (w >> 16) < D.thresh ? 0.f : pp2[1];
+  };
+  // the sequential form (tail tiles): masked when the tile is the partial one
+  auto softmax_seq = [&](int k0, bool edge, f32x16_t& sc, bf16x8_t (&pb)[2]) -> float {
+    if (edge) {
+      int k0v = k0;
+      asm volatile("" : "+v"(k0v));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = (k0v + acc_row(r, hi) < len) ? sc[r] : -INFINITY;
+    }
+    float mx = sc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+    {
+      const hw_u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const float m_new = fmaxf(m, mx * kScaleL2);      // finite: key 0 of the tile is visible
+    const float alpha = fast_exp2(m - m_new);
+    const hw_f32x2_t nm2 = {-m_new, -m_new};
+    hw_f32x2_t rs2 = {0.f, 0.f};
+    const unsigned xb = DROP ? dbase + (unsigned)((k0 >> 1) + 2 * hi) * 0xC2B2AE3Du : 0u;
+#pragma unroll
+    for (int rp = 0; rp < 8; ++rp) {
+      hw_f32x2_t x = {sc[2 * rp], sc[2 * rp + 1]};
+      x = x * sc2 + nm2;
+      hw_f32x2_t pp2 = {fast_exp2(x[0]), fast_exp2(x[1])};
+      rs2 += pp2;
+      if (DROP) drop_pair(xb, rp, pp2);
+      sc[2 * rp] = pp2[0]; sc[2 * rp + 1] = pp2[1];
+    }
+    float rs = rs2[0] + rs2[1];
+    {
+      const hw_u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rs), __float_as_uint(rs), false, false);
+      rs = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    l = l * alpha + rs;
+    m = m_new;
+    pb[0] = acc_to_b(sc, 0);
+    pb[1] = acc_to_b(sc, 1);
+    return alpha;
+  };
+  // step j (a full tile): O += V_{j-1} P_{j-1} and S_{j+1} = K_{j+1} Q^T on the matrix pipe under softmax(S_j) on the vector pipe
+  auto step = [&](int k0, const unsigned char* kt_next, const unsigned char* vt_prev, f32x16_t& sc, f32x16_t& sn, const bf16x8_t (&pp)[2],
+                  bf16x8_t (&pc)[2]) {
+    // LDS fragments through a ring of four: the V_{j-1} fragments are fetched at the top (the row maximum covers their round
+    // trip), chunk i < 4 consumes F[i] and refills it with K_{j+1} row fragment i, consumed four chunks later
+    bf16x8_t F[4];
+    auto fetch_k = [&](int i) { F[i] = frag_rows(kt_next, i, lane); };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) F[i] = frag_tr(vt_prev, i & 1, i >> 1, lane);
+    float mx = sc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+    {
+      const hw_u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const float m_new = fmaxf(m, mx * kScaleL2);
+    const float alpha = fast_exp2(m - m_new);
+    const unsigned xb = DROP ? dbase + (unsigned)((k0 >> 1) + 2 * hi) * 0xC2B2AE3Du : 0u;
+    const float nm = -m_new;
+    float rsa = 0.f, rsb = 0.f;
+    auto arg = [&](int rp) {
+      sc[2 * rp] = fmaf(sc[2 * rp], kScaleL2, nm);
+      sc[2 * rp + 1] = fmaf(sc[2 * rp + 1], kScaleL2, nm);
+    };
+    auto ex2 = [&](int rp) {   // two pairs: four exps back to back, then their sums (single-instruction f32 ops: see build.py)
+      float e0 = fast_exp2(sc[2 * rp]), e1 = fast_exp2(sc[2 * rp + 1]), e2 = fast_exp2(sc[2 * rp + 2]), e3 = fast_exp2(sc[2 * rp + 3]);
+      rsa += e0; rsb += e1; rsa += e2; rsb += e3;
+      if (DROP) {
+        hw_f32x2_t pa = {e0, e1}, pb2 = {e2, e3};
+        drop_pair(xb, rp, pa); drop_pair(xb, rp + 1, pb2);
+        e0 = pa[0]; e1 = pa[1]; e2 = pb2[0]; e3 = pb2[1];
+      }
+      sc[2 * rp] = e0; sc[2 * rp + 1] = e1; sc[2 * rp + 2] = e2; sc[2 * rp + 3] = e3;
+    };
+    GGET_FENCE();
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0], pp[0], o0, 0, 0, 0);
+    fetch_k(0);
+    arg(0); arg(1); arg(2); arg(3); ex2(0);
+    GGET_FENCE();
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1], pp[0], o1, 0, 0, 0);
+    fetch_k(1);
+    ex2(2); arg(4); arg(5); arg(6); arg(7);
+    GGET_FENCE();
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[2], pp[1], o0, 0, 0, 0);
+    fetch_k(2);
+    ex2(4);
+    GGET_FENCE();
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[3], pp[1], o1, 0, 0, 0);
+    fetch_k(3);
+    ex2(6);
+    GGET_FENCE();
+    sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0], qf[0], zero16(), 0, 0, 0);
+    float rs = rsa + rsb;
+    {
+      const hw_u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rs), __float_as_uint(rs), false, false);
+      rs = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    l = l * alpha + rs;
+    m = m_new;
+    pc[0] = acc_to_b(sc, 0);
+    GGET_FENCE();
+    sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1], qf[1], sn, 0, 0, 0);
+    pc[1] = acc_to_b(sc, 1);
+    GGET_FENCE();
+    sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[2], qf[2], sn, 0, 0, 0);
+    GGET_FENCE();
+    sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[3], qf[3], sn, 0, 0, 0);
+    rescale(alpha);
+  };
+
+  // prologue: K(0), K(1), V(0); the V slot "before stage 0" is zeroed (step 0 multiplies it by P = 0)
+  if (nst > 0) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave * PPW + i;
+      if (pc < 8) {
+        stage_piece(kr[0], kb, pitch, 0, S, pc, lane);
+        if (nst > 1) stage_piece(kr[1], kb, pitch, 64, S, pc, lane);
+      } else stage_piece(vr[0], vb, pitch, 0, S, pc - 8, lane);
+    }
+  }
+  for (int i = tid; i < 512; i += NWB * 64) reinterpret_cast<uint4*>(vr[2])[i] = make_uint4(0, 0, 0, 0);
+  attn_vm_wait0();
+  __syncthreads();
+  f32x16_t sA = zero16(), sB = zero16();
+  bf16x8_t pA[2], pB[2];
+  {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    pB[0] = pB[1] = pA[0] = pA[1] = __builtin_bit_cast(bf16x8_t, z);
+  }
+  if (ntile > 0) qk(kr[0], sA);
+  auto stage = [&](int t, auto SL) {
+    constexpr int sl = decltype(SL)::value, s1 = (sl + 1) % 3, s2 = (sl + 2) % 3;
+    attn_vm_wait0();                // K(t+1), V(t): issued one stage ago
+    __syncthreads();                // ... by everyone; everyone is past stage t-1
+    issue(t, kr[s2], vr[s1]);
+    step(64 * t, kr[sl] + 4096, vr[s2] + 4096, sA, sB, pB, pA);           // tile 2t:   K tile 2t+1, V tile 2t-1
+    step(64 * t + 32, kr[s1], vr[sl], sB, sA, pA, pB);                    // tile 2t+1: K tile 2t+2, V tile 2t
+  };
+  int t = 0;
+  while (t < nfs) {
+    stage(t, std::integral_constant<int, 0>{}); if (++t >= nfs) break;
+    stage(t, std::integral_constant<int, 1>{}); if (++t >= nfs) break;
+    stage(t, std::integral_constant<int, 2>{}); ++t;
+  }
+  // tail: the pending P.V of tile 2 nfs - 1, then at most two more tiles (a full one and / or the partial one), sequentially
+  if (nfs < nst) {
+    attn_vm_wait0();
+    __syncthreads();
+  }
+  if (nfs > 0) pv(vr[(nfs - 1) % 3] + 4096, pB);
+  const int jt = 2 * nfs;
+  if (jt < ntile) {
+    rescale(softmax_seq(32 * jt, jt >= nfull, sA, pA));
+    pv(vr[nfs % 3], pA);
+  }
+  if (jt + 1 < ntile) {
+    qk(kr[nfs % 3] + 4096, sB);
+    rescale(softmax_seq(32 * jt + 32, true, sB, pB));
+    pv(vr[nfs % 3] + 4096, pB);
+  }
+  if (qrow < S) {
+    const float inv = l > 0.f ? D.inv_keep / l : 0.f;
+    store_t(out + ((size_t)b * S + qrow) * d + h * 64, o0, o1, inv, hi);
+    if (hi == 0 && lse) lse[((size_t)b * H + h) * S + qrow] = l > 0.f ? (m + log2f(l)) * (1.0f / kLog2e) : 0.f;
+  }
+}
+
+// dQ for long sequences: same stage machinery as attn_fwd64_kernel (K and V streamed), one 32-query tile per wave.
+template <bool PK, int NWB>
+__global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 4) attn_bwd_dq64_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                                    const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                                    float* __restrict__ delta, KeyRange KR, bf16_t* __restrict__ dqkv,
+                                                                    int B, int S, int H, int causal, Drop D) {
+  __shared__ __attribute__((aligned(16))) unsigned char st[2][2 * 8192];
+  __shared__ int red[16];
+  constexpr int QB = NWB * 32;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * QB + wave * 32;
+  const int d = H * 64;
+  const size_t pitch = (size_t)3 * d;
+  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* kb = qb + d;
+  const bf16_t* vb = qb + 2 * d;
+  const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
+  const int qrow = q0 + l31;
+  const int len = KR.key_len ? KR.key_len[b] : S;
+  int qlo = 0, qhi = len - 1;
+  int ulo = 0, uhi = qhi, ilo = 0, ihi = qhi;
+  if (PK) {
+    const bool v = qrow < S;
+    qlo = v ? KR.lo[(size_t)b * S + qrow] : 0;
+    qhi = v ? KR.hi[(size_t)b * S + qrow] : -1;
+    ulo = wave_imin(qhi >= qlo ? qlo : S); uhi = wave_imax(qhi >= qlo ? qhi + 1 : 0) - 1;
+    ilo = wave_imax(v ? qlo : 0); ihi = wave_imin(v ? qhi + 1 : S) - 1;
+  }
+  const int klen = PK ? S : len;
+  const int q_end_blk = min(S, (int)(blockIdx.x + 1) * QB);
+  int kbeg_blk = 0, kend_blk = causal ? min(klen, q_end_blk) : klen;
+  if (PK) {
+    int blo = ulo, bhi = uhi;
+    block_range(blo, bhi, red, wave, lane);
+    kbeg_blk = min(max(blo, 0), S) & ~63;
+    kend_blk = min(kend_blk, bhi + 1);
+  }
+  const int kend = (q0 < S) ? min(uhi + 1, causal ? q0 + 32 : S) : 0;
+
+  bf16x8_t qf[4], dof[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qf[s] = frag_global(qb, qrow, S, pitch, s, lane);
+    dof[s] = frag_global(dob, qrow, S, (size_t)d, s, lane);
+  }
+  const size_t sidx = ((size_t)b * H + h) * S + min(qrow, S - 1);
+  float dl = 0.f;   // delta_q = rowsum(dO * O): the softmax-backward row term, stored for the dK/dV kernel
+  {
+    const bf16_t* ob = out + (size_t)b * S * d + h * 64;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float a[8], gg[8];
+      unpack8(__builtin_bit_cast(uint4, frag_global(ob, qrow, S, (size_t)d, s, lane)), a);
+      unpack8(__builtin_bit_cast(uint4, dof[s]), gg);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += a[e] * gg[e];
+    }
+    const hw_u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(dl), __float_as_uint(dl), false, false);
+    dl = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    if (hi == 0 && qrow < S) delta[sidx] = dl;
+  }
+  const float nlse2 = -lse[sidx] * kLog2e;
+  const float ndl_k = -dl * kScale;                        // ds = p * (dp * keep * scale - delta * scale)
+  const float keep_k = D.inv_keep * kScale;
+  const unsigned dbase = drop_base(D, b * H + h, qrow, 0);
+  f32x16_t a0 = zero16(), a1 = zero16();
+  constexpr int PPW = 16 / NWB;
+  auto issue = [&](int buf, int r0) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave * PPW + i;
+      if (pc < 8) stage_piece(st[buf], kb, pitch, r0, S, pc, lane);
+      else stage_piece(st[buf] + 8192, vb, pitch, r0, S, pc - 8, lane);
+    }
+  };
+  const int nst = kend_blk > kbeg_blk ? (kend_blk - kbeg_blk + 63) >> 6 : 0;
+  if (nst > 0) issue(0, kbeg_blk);
+  for (int t = 0; t < nst; ++t) {
+    const int ks = kbeg_blk + t * 64;
+    attn_vm_wait0();
+    __syncthreads();
+    if (t + 1 < nst) issue((t + 1) & 1, ks + 64);
+    const unsigned char* kst = st[t & 1];
+    const unsigned char* vst = kst + 8192;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k0 = ks + 32 * j;
+      if (k0 >= kend || k0 + 31 < ulo) continue;
+      const unsigned char* kt = kst + 4096 * j;
+      const unsigned char* vt = vst + 4096 * j;
+      f32x16_t dp = zero16(), sc = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), qf[s], sc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);     // phase fences: without them the scheduler hoists every LDS read of the tile and spills
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, s, lane), dof[s], dp, 0, 0, 0);
+      const bool edge = (k0 < ilo) || (k0 + 31 > ihi) || (causal && k0 + 31 > q0) || (q0 + 32 > S);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = fast_exp2(fmaf(sc[r], kScaleL2, nlse2));      // P (un-dropped)
+      __builtin_amdgcn_sched_barrier(0);
+      if (edge) {
+        int k0v = k0;
+        asm volatile("" : "+v"(k0v));    // keeps the mask arithmetic inside this rarely taken branch
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0v + acc_row(r, hi);
+          sc[r] = (key >= qlo && key <= qhi && (!causal || key <= qrow) && qrow < S) ? sc[r] : 0.f;
+        }
+      }
+      if (D.thresh == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = sc[r] * fmaf(dp[r], kScale, ndl_k);
+      } else {
+        const unsigned xb = dbase + (unsigned)((k0 >> 1) + 2 * hi) * 0xC2B2AE3Du;
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+          const unsigned w = drop_word(xb + (unsigned)((rp & 1) + 4 * (rp >> 1)) * 0xC2B2AE3Du);
+          const float k0m = (w & 0xffffu) < D.thresh ? 0.f : keep_k;
+          const float k1m = (w >> 16) < D.thresh ? 0.f : keep_k;
+          sc[2 * rp] = sc[2 * rp] * fmaf(dp[2 * rp], k0m, ndl_k);
+          sc[2 * rp + 1] = sc[2 * rp + 1] * fmaf(dp[2 * rp + 1], k1m, ndl_k);
+        }
+      }
+      const bf16x8_t ds0 = acc_to_b(sc, 0), ds1 = acc_to_b(sc, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 0, lane), ds0, a0, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 1, lane), ds1, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 0, lane), ds0, a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 1, lane), ds1, a1, 0, 0, 0);
+    }
+  }
+  if (qrow < S) store_t(dqkv + ((size_t)b * S + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
+}
+
+// dK / dV for long sequences: a wave owns a 32-key tile (K and V fragments in registers), Q and dO are streamed in 64-query
+// stages together with the queries' lse / delta (and key ranges for packed rows).
+template <bool PK, int NWB>
+__global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 2) attn_bwd_dkv64_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                     const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                     KeyRange KR, bf16_t* __restrict__ dqkv, int B, int S, int H, int causal,
+                                                                     Drop D) {
+  __shared__ __attribute__((aligned(16))) unsigned char st[2][2 * 8192];
+  __shared__ __attribute__((aligned(16))) float lse_s[2][64], dl_s[2][64];
+  __shared__ int qlo_s[2][64], qhi_s[2][64];
+  constexpr int KB = NWB * 32;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int k0 = blockIdx.x * KB + wave * 32;
+  const int d = H * 64;
+  const size_t pitch = (size_t)3 * d;
+  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* kb = qb + d;
+  const bf16_t* vb = qb + 2 * d;
+  const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
+  const int klen = PK ? S : (KR.key_len ? KR.key_len[b] : S);
+  const int krow = k0 + l31;
+  bf16x8_t kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = frag_global(kb, krow, S, pitch, s, lane);
+    vf[s] = frag_global(vb, krow, S, pitch, s, lane);
+  }
+  f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+  const unsigned dbase = drop_base(D, b * H + h, 0, (unsigned)krow >> 1);
+  const int kodd = krow & 1;
+  const bool key_ok = krow < klen;
+  const int kblk0 = blockIdx.x * KB;
+  const int qbeg = causal ? (kblk0 & ~63) : 0;     // queries before the block's first key never see it
+  const int nst = (kblk0 < klen && qbeg < S) ? (S - qbeg + 63) >> 6 : 0;
+  constexpr int PPW = 16 / NWB;
+  auto issue = [&](int buf, int r0) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave * PPW + i;
+      if (pc < 8) stage_piece(st[buf], qb, pitch, r0, S, pc, lane);
+      else stage_piece(st[buf] + 8192, dob, (size_t)d, r0, S, pc - 8, lane);
+    }
+  };
+  // the stage's per-query scalars: fetched by the first 64 threads one stage ahead (registers), written to LDS behind the compute
+  float p_lse = 0.f, p_dl = 0.f;
+  int p_lo = 0, p_hi = -1;
+  auto fetch_vec = [&](int r0) {
+    if (tid < 64) {
+      const int q = min(r0 + tid, S - 1);
+      p_lse = -lse[((size_t)b * H + h) * S + q] * kLog2e;
+      p_dl = -delta[((size_t)b * H + h) * S + q] * kScale;
+      if (PK) {
+        const bool v = r0 + tid < S;
+        p_lo = v ? KR.lo[(size_t)b * S + q] : 0;
+        p_hi = v ? KR.hi[(size_t)b * S + q] : -1;
+      }
+    }
+  };
+  auto commit_vec = [&](int buf) {
+    if (tid < 64) {
+      lse_s[buf][tid] = p_lse; dl_s[buf][tid] = p_dl;
+      if (PK) { qlo_s[buf][tid] = p_lo; qhi_s[buf][tid] = p_hi; }
+    }
+  };
+  if (nst > 0) { issue(0, qbeg); fetch_vec(qbeg); commit_vec(0); }
+  const float keep_k = D.inv_keep * kScale;
+  for (int t = 0; t < nst; ++t) {
+    const int qs = qbeg + t * 64;
+    attn_vm_wait0();
+    __syncthreads();
+    if (t + 1 < nst) { issue((t + 1) & 1, qs + 64); fetch_vec(qs + 64); }
+    const unsigned char* qst = st[t & 1];
+    const unsigned char* dst_ = qst + 8192;
+    const int vb_ = t & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q0 = qs + 32 * j;
+      if (k0 >= klen || q0 >= S || (causal && q0 + 31 < k0)) continue;
+      bool edge = (k0 + 32 > klen) || (q0 + 32 > S) || (causal && k0 + 31 > q0);
+      if (PK) {
+        const int lo = qlo_s[vb_][32 * j + l31], hi_ = qhi_s[vb_][32 * j + l31];
+        const int ulo = wave_imin(hi_ >= lo ? lo : S), uhi = wave_imax(hi_ >= lo ? hi_ + 1 : 0) - 1;
+        if (uhi < k0 || ulo > k0 + 31) continue;
+        const int ilo = wave_imax(lo), ihi = wave_imin(hi_ + 1) - 1;
+        edge = edge || ilo > k0 || ihi < k0 + 31;
+      }
+      const unsigned char* qt = qst + 4096 * j;
+      const unsigned char* dot_ = dst_ + 4096 * j;
+      f32x16_t sc = zero16(), dp = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, s, lane), kf[s], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dot_, s, lane), vf[s], dp, 0, 0, 0);
+      }
+      // the lane's 16 queries are 4 runs of 4 consecutive rows: the per-query scalars come as 4 + 4 ds_read_b128
+      float nl[16], dlv[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 a4 = *reinterpret_cast<const float4*>(&lse_s[vb_][32 * j + 8 * g + 4 * hi]);
+        const float4 b4 = *reinterpret_cast<const float4*>(&dl_s[vb_][32 * j + 8 * g + 4 * hi]);
+        nl[4 * g] = a4.x; nl[4 * g + 1] = a4.y; nl[4 * g + 2] = a4.z; nl[4 * g + 3] = a4.w;
+        dlv[4 * g] = b4.x; dlv[4 * g + 1] = b4.y; dlv[4 * g + 2] = b4.z; dlv[4 * g + 3] = b4.w;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = fast_exp2(fmaf(sc[r], kScaleL2, nl[r]));
+      if (edge) {
+        int q0v = q0;
+        asm volatile("" : "+v"(q0v));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qi = 32 * j + acc_row(r, hi);
+          const int q = q0v + acc_row(r, hi);
+          const bool in_range = PK ? (krow >= qlo_s[vb_][qi] && krow <= qhi_s[vb_][qi]) : key_ok;
+          sc[r] = (in_range && q < S && (!causal || krow <= q)) ? sc[r] : 0.f;
+        }
+      }
+      if (D.thresh == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = sc[r] * fmaf(dp[r], kScale, dlv[r]);
+      } else {
+        // the lane's key is fixed, the queries move along the registers: one hash per score (field = the key's parity)
+        const unsigned xb = dbase + (unsigned)(q0 + 4 * hi) * 0x85EBCA77u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned w = drop_word(xb + (unsigned)((r & 3) + 8 * (r >> 2)) * 0x85EBCA77u);
+          const bool drop = (kodd ? (w >> 16) : (w & 0xffffu)) < D.thresh;
+          dp[r] = sc[r] * fmaf(dp[r], drop ? 0.f : keep_k, dlv[r]);
+          sc[r] = drop ? 0.f : sc[r] * D.inv_keep;      // dropped probabilities: what multiplied V in forward
+        }
+      }
+      const bf16x8_t p0 = acc_to_b(sc, 0), p1 = acc_to_b(sc, 1);
+      const bf16x8_t s0 = acc_to_b(dp, 0), s1 = acc_to_b(dp, 1);
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 0, lane), p0, dv0, 0, 0, 0);
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 1, lane), p1, dv0, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 1, 0, lane), p0, dv1, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 1, 1, lane), p1, dv1, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 0, 0, lane), s0, dk0, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 0, 1, lane), s1, dk0, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 0, lane), s0, dk1, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 1, lane), s1, dk1, 0, 0, 0);
+    }
+    if (t + 1 < nst) commit_vec((t + 1) & 1);
+  }
+  if (krow < S) {
+    bf16_t* row = dqkv + ((size_t)b * S + krow) * pitch + h * 64;
+    store_t(row + d, dk0, dk1, 1.f, hi);
+    store_t(row + 2 * d, dv0, dv1, 1.f, hi);
+  }
+}
+
 // waves (= 32-row tiles) per block: long sequences share each K/V (or Q/dO) tile among 4 waves through LDS
 int attn_waves(int S) { return S >= 128 ? 4 : (S >= 64 ? 2 : 1); }
 
 Drop make_drop(float p, unsigned seed) {
   Drop d;
-  d.thresh = p > 0.f ? (unsigned)(p * 16777216.0f) : 0u;
+  d.thresh = p > 0.f ? (unsigned)(p * 65536.0f) : 0u;
   d.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   d.seed = seed;
   return d;
@@ -777,6 +1560,24 @@ int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, i
   if (B == 0 || S == 0) return 0;
   const Rope R{cos_tab, sin_tab, position_ids, S};
   const Drop D = make_drop(dropout_p, dropout_seed);
+  static int big = -1;
+  if (big < 0) { const char* e = getenv("GGET_ATTN_BIG"); big = e ? atoi(e) : 1; }
+  if (S >= 256 && !cos_tab && big) {   // long sequences with q / k already rotated (the engine's layout): 64-row DMA stages
+    static int dense = -1;
+    if (dense < 0) { const char* e = getenv("GGET_ATTN_DENSE"); dense = e ? atoi(e) : 1; }
+#define GGET_FWD64(PK) hipLaunchKernelGGL((attn_fwd64_kernel<PK, 1, 8>), dim3((S + 255) / 256, H, B), dim3(512), 0, st, (const bf16_t*)qkv, KR, \
+                                          (bf16_t*)out, lse, B, S, H, causal, D)
+    if (dense && !key_lo && !causal && S >= 512) {   // (shorter rows: the pipeline's fill and drain cost more than it hides)
+      if (D.thresh) hipLaunchKernelGGL((attn_fwd_dense_kernel<true, 8>), dim3((S + 255) / 256, H, B), dim3(512), 0, st, (const bf16_t*)qkv, key_len,
+                                       (bf16_t*)out, lse, B, S, H, D);
+      else hipLaunchKernelGGL((attn_fwd_dense_kernel<false, 8>), dim3((S + 255) / 256, H, B), dim3(512), 0, st, (const bf16_t*)qkv, key_len,
+                              (bf16_t*)out, lse, B, S, H, D);
+    } else if (key_lo) GGET_FWD64(true);
+    else GGET_FWD64(false);   // (one query tile per wave at 4 waves / SIMD beat two tiles per wave at 2)
+#undef GGET_FWD64
+    GGET_LAUNCH_CHECK();
+    return 0;
+  }
   const int nw = attn_waves(S);
   dim3 grid((S + 32 * nw - 1) / (32 * nw), H, B);
 #define GGET_ATTN_FWD(NW, PK) hipLaunchKernelGGL((attn_fwd_kernel<NW, PK>), grid, dim3(NW * 64), 0, st, (const bf16_t*)qkv, KR, \
@@ -802,6 +1603,22 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
   if (S <= 32 && !key_lo && small) {
     hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(1, H, B), dim3(64), 0, st, (const bf16_t*)qkv,
                        (const bf16_t*)dout, lse, key_len, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);
+    GGET_LAUNCH_CHECK();
+    return 0;
+  }
+  static int big = -1;
+  if (big < 0) { const char* e = getenv("GGET_ATTN_BIG"); big = e ? atoi(e) : 1; }
+  if (S >= 256 && !cos_tab && big) {
+#define GGET_BWD64(PK)                                                                                                           \
+  do {                                                                                                                           \
+    hipLaunchKernelGGL((attn_bwd_dq64_kernel<PK, 4>), dim3((S + 127) / 128, H, B), dim3(256), 0, st, (const bf16_t*)qkv,             \
+                       (const bf16_t*)out, (const bf16_t*)dout, lse, delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, D);             \
+    hipLaunchKernelGGL((attn_bwd_dkv64_kernel<PK, 8>), dim3((S + 255) / 256, H, B), dim3(512), 0, st, (const bf16_t*)qkv,            \
+                       (const bf16_t*)dout, lse, delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, D);                                 \
+  } while (0)
+    // dQ: 4-wave blocks at 3 waves / SIMD (168 registers: the 128 of 4 waves / SIMD spill); dK/dV: 8-wave blocks at 2 waves / SIMD
+    if (key_lo) GGET_BWD64(true); else GGET_BWD64(false);
+#undef GGET_BWD64
     GGET_LAUNCH_CHECK();
     return 0;
   }

@@ -331,11 +331,13 @@ def _drop_mask(seed, B, H, S, p):
     k = np.arange(S, dtype=np.uint64)[None, None, :]
     M32 = np.uint64(0xFFFFFFFF)
     x = (np.uint64(seed) ^ ((bh * np.uint64(0x9E3779B1)) & M32)) & M32
-    x = (x + q * np.uint64(0x85EBCA77) + k * np.uint64(0xC2B2AE3D)) & M32
-    x ^= x >> np.uint64(16); x = (x * np.uint64(0x045D9F3B)) & M32
+    x = (x + q * np.uint64(0x85EBCA77) + (k >> np.uint64(1)) * np.uint64(0xC2B2AE3D)) & M32
     x ^= x >> np.uint64(16)
-    thresh = np.uint64(int(np.float32(p) * np.float32(16777216.0)))
-    keep = (x >> np.uint64(8)) >= thresh
+    x = (x * np.uint64(0x7FEB352D)) & M32
+    w = x ^ (x >> np.uint64(15))
+    f = np.where((k & np.uint64(1)) == 1, w >> np.uint64(16), w & np.uint64(0xFFFF))
+    thresh = np.uint64(int(np.float32(p) * np.float32(65536.0)))
+    keep = f >= thresh
     return torch.from_numpy((keep.astype(np.float32) / (1.0 - p)).reshape(B, H, S, S))
 
 

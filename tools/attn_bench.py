@@ -18,7 +18,12 @@ for (B, S, H) in [(256, 32, 12), (256, 256, 12), (16, 2048, 12)]:
     lse = torch.empty(B * H * S, device="cuda"); delta = torch.empty(B * H * S, device="cuda")
     lens = torch.full((B,), S, dtype=torch.int32, device="cuda")
     fl = 4.0 * B * H * S * S * 64
+    lo = torch.zeros(B, S, dtype=torch.int32, device="cuda"); hi = torch.full((B, S), S - 1, dtype=torch.int32, device="cuda")
     for p in (0.0, 0.1):
-        f = t(lambda: L.check(lib.gget_op_attn_fwd(P(qkv), P(lens), P(out), P(lse), B, S, H, 0, None, None, None, p, 7, st)))
-        b = t(lambda: L.check(lib.gget_op_attn_bwd(P(qkv), P(out), P(dout), P(lse), P(lens), P(dqkv), P(delta), B, S, H, 0, None, None, None, p, 7, st)))
+        if os.environ.get("RANGES"):    # the packed-row entry points with ranges that cover every key (same work)
+            f = t(lambda: L.check(lib.gget_op_attn_fwd_ranges(P(qkv), P(lo), P(hi), P(out), P(lse), B, S, H, 0, p, 7, st)))
+            b = t(lambda: L.check(lib.gget_op_attn_bwd_ranges(P(qkv), P(out), P(dout), P(lse), P(lo), P(hi), P(dqkv), P(delta), B, S, H, 0, p, 7, st)))
+        else:
+            f = t(lambda: L.check(lib.gget_op_attn_fwd(P(qkv), P(lens), P(out), P(lse), B, S, H, 0, None, None, None, p, 7, st)))
+            b = t(lambda: L.check(lib.gget_op_attn_bwd(P(qkv), P(out), P(dout), P(lse), P(lens), P(dqkv), P(delta), B, S, H, 0, None, None, None, p, 7, st)))
         print(f"B={B} S={S} H={H} p={p}: fwd {f:8.1f} us ({fl/f/1e6:6.1f} TF)  bwd {b:8.1f} us ({2.5*fl/b/1e6:6.1f} TF)")

@@ -81,6 +81,7 @@ SIGNATURES = {
     "gget_op_attn_bwd_ranges": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint32, vp]),
     "gget_op_ranges_from_mask3d": (i32, [vp, vp, vp, i32, i32, vp]),
     "gget_set_dropout": (i32, [vp, f32, f32, C.c_uint32]),
+    "gget_set_auc": (i32, [vp, i32, C.c_uint32]),
     "gget_op_gateup_geglu": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "gget_op_down_dgrad_geglu": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "gget_op_geglu_fwd": (i32, [vp, vp, i32, i32, vp]),
@@ -99,7 +100,7 @@ def gemm_grouped(lib, mode, problems, stream):
     ptr = lambda k: PA(*[p[k].data_ptr() for p in problems])
     num = lambda k: IA(*[int(p[k]) for p in problems])
     return lib.gget_op_gemm_grouped(mode, n, ptr(0), ptr(1), ptr(2), num(3), num(4), num(5), num(6), num(7), num(8), stream)
-PROBLEM_SINGLE_LABEL, PROBLEM_REGRESSION_L1, PROBLEM_REGRESSION_MSE, PROBLEM_MULTI_LABEL = 0, 1, 2, 3
+PROBLEM_SINGLE_LABEL, PROBLEM_REGRESSION_L1, PROBLEM_REGRESSION_MSE, PROBLEM_MULTI_LABEL, PROBLEM_AUC = 0, 1, 2, 3, 4
 
 _lib = None
 

@@ -155,7 +155,7 @@ struct Ws {
   // pre-train head
   uint64_t cnt, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
   // task head
-  uint64_t tlogits, tdlogits, pooled_h;
+  uint64_t tlogits, tdlogits, pooled_h, auc_lists;
   uint64_t total;
 };
 
@@ -236,6 +236,7 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   } else {
     w.tlogits = b.take(Bm * c.num_labels * 4);
     w.tdlogits = b.take(Bm * c.num_labels * 4);
+    w.auc_lists = b.take(Bm * 2 * 4);
     w.pooled_h = b.take(Bm * d * 2);
   }
   w.total = b.off;
@@ -280,6 +281,8 @@ struct gget_engine {
   const float* sample_wgt = nullptr;
   bool have_labels = false;
   int problem = 0;
+  int auc_num_neg = 1;
+  unsigned auc_seed = 0;
   bool fwd_valid = false;
   float attn_drop_p = 0.f;        // attention dropout of the NEXT forward (training mode); 0 = off
   float path_drop_p = 0.f;        // stochastic-depth rate of the last layer (layer l: p*l/(L-1))
@@ -430,6 +433,14 @@ extern "C" int gget_bucket_range(gget_handle_t h, int bucket, uint64_t* offset, 
   const auto& r = h->bucket_range[bucket];
   *offset = r.first;
   *count = r.second - r.first;
+  return 0;
+}
+
+extern "C" int gget_set_auc(gget_handle_t h, int num_neg, uint32_t seed) {
+  GGET_REQUIRE(h != nullptr, "null handle");
+  GGET_REQUIRE(num_neg >= 1, "num_neg must be >= 1");
+  h->auc_num_neg = num_neg;
+  h->auc_seed = seed;
   return 0;
 }
 
@@ -732,7 +743,13 @@ extern "C" int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, 
   h->problem = problem_type;
   if (task_labels_dev) {
     GGET_REQUIRE(loss_dev != nullptr, "loss_dev is required when task labels are given");
-    if (int e = k_task_loss(lg, task_labels_dev, sample_wgt_dev, problem_type, B, C, loss_dev, h->wsp<float>(w.tdlogits), st))
+    if (problem_type == GGET_PROBLEM_AUC) {
+      GGET_REQUIRE(C >= 2, "the AUC loss reads logits[:, 1] - logits[:, 0]");
+      GGET_REQUIRE((long)B * h->auc_num_neg <= 8192, "AUC loss: positives x num_neg is limited to 8192 pairs");
+      if (int e = k_auc_loss(lg, (const int64_t*)task_labels_dev, B, C, h->auc_num_neg, h->auc_seed, loss_dev,
+                             h->wsp<float>(w.tdlogits), h->wsp<int32_t>(w.auc_lists), st))
+        return e;
+    } else if (int e = k_task_loss(lg, task_labels_dev, sample_wgt_dev, problem_type, B, C, loss_dev, h->wsp<float>(w.tdlogits), st))
       return e;
   }
   h->fwd_valid = true;

@@ -48,6 +48,8 @@ int k_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const int32_
                  int mean_over_rows, float* loss_out, hipStream_t st);
 int k_score_fwd(const void* hidden, const int32_t* pool_row, const void* w, const void* bias, float* logits,
                 void* pooled_h, int B, int C, int d, hipStream_t st);
+int k_auc_loss(const float* logits, const int64_t* labels, int B, int C, int num_neg, unsigned seed, float* loss_out,
+               float* dlogits, int32_t* lists, hipStream_t st);
 int k_task_loss(const float* logits, const void* labels, const float* sample_wgt, int problem, int B, int C,
                 float* loss_out, float* dlogits, hipStream_t st);
 int k_score_bwd(const float* dlogits, const void* hidden, const int32_t* pool_row, const void* w, float* dw, float* dbias,

@@ -1444,6 +1444,69 @@ int k_score_fwd(const void* hidden, const int32_t* pool_row, const void* w, cons
   return 0;
 }
 
+// AUC surrogate loss (src/utils/loss_utils.py:25-53, selected by loss_type == "auc" at modeling_finetune.py:203-207):
+// y = logit[:,1] - logit[:,0]; every positive sample is paired with num_neg negatives drawn as
+// idx = randperm(P * num_neg) % N_neg; loss = mean (1 - (y_pos - y_neg))^2.  torch's randperm cannot be reproduced: the
+// permutation here is the rank of the 24-bit counter hash of (seed, stream 40, i) with ties broken by i
+// (graph-gpt_amd/modeling.py:auc_pairs is the Python twin the parity test feeds to the oracle).  One block; P * num_neg <= 8192.
+constexpr int kAucMaxPairs = 8192;
+__global__ void __launch_bounds__(kBlock) auc_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int B,
+                                                          int C, int num_neg, unsigned seed, float* __restrict__ loss_out,
+                                                          float* __restrict__ dlogits, int32_t* __restrict__ lists /* [2B] */) {
+  __shared__ unsigned keys[kAucMaxPairs];
+  __shared__ float red[kBlock];
+  __shared__ int cnt_s[kBlock + 1];
+  const int tid = threadIdx.x;
+  // ordered lists of the positive / negative samples (chunk per thread, exclusive scan over the threads)
+  const int per = (B + kBlock - 1) / kBlock, b0 = min(B, tid * per), b1 = min(B, b0 + per);
+  int np_ = 0;
+  for (int b = b0; b < b1; ++b) np_ += labels[b] != 0;
+  cnt_s[tid + 1] = np_;
+  if (tid == 0) cnt_s[0] = 0;
+  __syncthreads();
+  if (tid == 0) for (int i = 1; i <= kBlock; ++i) cnt_s[i] += cnt_s[i - 1];
+  __syncthreads();
+  const int P = cnt_s[kBlock], N = B - P;
+  {
+    int ip = cnt_s[tid], in = b0 - ip;
+    for (int b = b0; b < b1; ++b) {
+      if (labels[b] != 0) lists[ip++] = b; else lists[B + in++] = b;
+    }
+  }
+  for (int i = tid; i < B * C; i += kBlock) dlogits[i] = 0.f;
+  const int cnt = P * num_neg;
+  for (int i = tid; i < cnt; i += kBlock) keys[i] = smtp_rng(seed, 40, (unsigned)i, 0);
+  __syncthreads();
+  float local = 0.f;
+  if (cnt > 0 && N > 0) {
+    const float inv = 1.0f / (float)cnt;
+    for (int i = tid; i < cnt; i += kBlock) {
+      const unsigned ki = keys[i];
+      int rank = 0;
+      for (int j = 0; j < cnt; ++j) rank += (keys[j] < ki) || (keys[j] == ki && j < i);
+      const int bp = lists[i / num_neg], bn = lists[B + rank % N];
+      const float yp = logits[bp * C + 1] - logits[bp * C], yn = logits[bn * C + 1] - logits[bn * C];
+      const float t = 1.f - (yp - yn);
+      local += t * t * inv;
+      const float g = 2.f * t * inv;           // d loss / d yn = +g, d loss / d yp = -g
+      atomicAdd(&dlogits[bp * C + 1], -g); atomicAdd(&dlogits[bp * C], g);
+      atomicAdd(&dlogits[bn * C + 1], g); atomicAdd(&dlogits[bn * C], -g);
+    }
+  }
+  red[tid] = local;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  // (no positive or no negative sample: torch's mean over an empty tensor is NaN - so is this)
+  if (tid == 0) loss_out[0] = (cnt > 0 && N > 0) ? red[0] : __builtin_nanf("");
+}
+
+int k_auc_loss(const float* logits, const int64_t* labels, int B, int C, int num_neg, unsigned seed, float* loss_out,
+               float* dlogits, int32_t* lists, hipStream_t st) {
+  hipLaunchKernelGGL(auc_loss_kernel, dim3(1), dim3(kBlock), 0, st, logits, labels, B, C, num_neg, seed, loss_out, dlogits, lists);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
 int k_task_loss(const float* logits, const void* labels, const float* sample_wgt, int problem, int B, int C,
                 float* loss_out, float* dlogits, hipStream_t st) {
   hipLaunchKernelGGL(task_loss_kernel, dim3(1), dim3(kBlock), 0, st, logits, labels, sample_wgt, problem, B, C, loss_out,

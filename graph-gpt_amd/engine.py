@@ -166,7 +166,7 @@ class Engine:
         pos = self._i64(position_ids, dev)
         y = None
         if task_labels is not None:
-            if problem == L.PROBLEM_SINGLE_LABEL:
+            if problem in (L.PROBLEM_SINGLE_LABEL, L.PROBLEM_AUC):
                 y = task_labels.to(device=dev, dtype=torch.int64).contiguous()
             else:
                 y = task_labels.to(device=dev, dtype=torch.float32).contiguous()
@@ -181,6 +181,10 @@ class Engine:
     def set_dropout(self, attention_p: float = 0.0, path_p: float = 0.0, seed: int = 0):
         """Attention dropout / stochastic depth for the NEXT forward+backward (training mode); zeros = eval."""
         L.check(self.lib.gget_set_dropout(self.h, float(attention_p), float(path_p), int(seed) & 0xFFFFFFFF))
+
+    def set_auc(self, num_neg: int = 1, seed: int = 0):
+        """Negatives per positive and the sampling seed of the NEXT forward_task(problem=PROBLEM_AUC)."""
+        L.check(self.lib.gget_set_auc(self.h, int(num_neg), int(seed) & 0xFFFFFFFF))
 
     def backward(self):
         L.check(self.lib.gget_backward(self.h, 1.0, _stream()))

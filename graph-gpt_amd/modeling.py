@@ -41,7 +41,7 @@ class GraphGPTConfig:
                  causal_attention=True, rope_range=0, embed_pdrop=0.0, path_pdrop=0.0, mlp_pdrop=0.0,
                  layer_scale_init_value=0.0, stacked_feat=1, stack_method="short", stacked_feat_agg_method="sum",
                  embed_dim=0, next_n_token=1, use_generative=True, use_discriminative=False, focal_gamma=0.0,
-                 smtp_inside=False, mlp=None, dropout=0.0, loss_type=None, num_labels=2, problem_type=None,
+                 smtp_inside=False, mlp=None, dropout=0.0, loss_type=None, num_neg=None, num_labels=2, problem_type=None,
                  attention_dropout=0.0, rope_theta=10000.0, head_dim=64, num_key_value_heads=None, **kwargs):
         self.vocab_size, self.hidden_size, self.intermediate_size = vocab_size, hidden_size, intermediate_size
         self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
@@ -56,6 +56,7 @@ class GraphGPTConfig:
         self.use_generative, self.use_discriminative, self.focal_gamma = use_generative, use_discriminative, focal_gamma
         self.smtp_inside, self.mlp, self.dropout, self.loss_type = smtp_inside, list(mlp or []), dropout, loss_type
         self.num_labels, self.problem_type, self.attention_dropout = num_labels, problem_type, attention_dropout
+        self.num_neg = num_neg
         self.rope_theta, self.head_dim = rope_theta, head_dim
         self.num_key_value_heads = num_key_value_heads or num_attention_heads
         self.num_params = None
@@ -385,16 +386,38 @@ class GraphGPTTaskModel(_GgetModel):
         if problem == "regression":
             code = L.PROBLEM_REGRESSION_L1 if cfg.loss_type == "l1" else L.PROBLEM_REGRESSION_MSE
         elif problem in ("single_label_classification", None):
-            if cfg.loss_type in ("token_ce", "token_ce_intra", "auc"):
-                raise NotImplementedError(f"loss_type={cfg.loss_type!r} is outside the hot-path scope")
-            code = L.PROBLEM_SINGLE_LABEL
+            if cfg.loss_type in ("token_ce", "token_ce_intra"):
+                raise NotImplementedError(f"loss_type={cfg.loss_type!r} (token-level tasks) is outside the hot-path scope")
+            code = L.PROBLEM_AUC if cfg.loss_type == "auc" else L.PROBLEM_SINGLE_LABEL
         else:
             code = L.PROBLEM_MULTI_LABEL   # BCE-with-logits on the labelled entries (modeling_finetune.py:227-230)
         self._check_positions(position_ids, S)
         e = self._pre_forward(B, S)
+        if code == L.PROBLEM_AUC and task_labels is not None:
+            # one seed per call (the reference draws torch.randperm from the global generator every call)
+            self._auc_calls = getattr(self, "_auc_calls", 0) + 1
+            self.last_auc_seed = (int(getattr(self, "auc_seed", 0)) + 0x9E3779B1 * self._auc_calls) & 0xFFFFFFFF
+            e.set_auc(cfg.num_neg or 1, self.last_auc_seed)
         loss, logits, hid = e.forward_task(input_ids, attention_mask, position_ids, task_labels, sample_wgt, code)
         return DoubleHeadsModelOutput(pretrain_loss=None, task_loss=self._wrap_loss(loss), pretrain_logits=None,
                                       task_logits=logits, task_hidden_states=hid)
+
+
+def auc_pairs(labels, num_neg: int, seed: int):
+    """Python twin of the negative sampling in csrc/kernels.hip:auc_loss_kernel: returns the index (into the ordered list of
+    negative samples) paired with each of the P * num_neg (positive, slot) entries - what `torch.randperm(cnt) % n_neg`
+    is in the reference (src/utils/loss_utils.py:39-42)."""
+    import numpy as np
+    from .smtp import _rng24
+    y = np.asarray(labels).reshape(-1)
+    P = int((y != 0).sum())
+    N = int(y.size - P)
+    cnt = P * int(num_neg)
+    keys = _rng24(seed, 40, np.arange(cnt), 0)
+    order = np.lexsort((np.arange(cnt), keys))      # sort by key, ties by index
+    rank = np.empty(cnt, dtype=np.int64)
+    rank[order] = np.arange(cnt)
+    return rank % max(N, 1)
 
 
 def convert_to_legacy_config(model_cfg) -> GraphGPTConfig:
@@ -422,4 +445,4 @@ def convert_to_legacy_config(model_cfg) -> GraphGPTConfig:
         path_pdrop=get(model_cfg, "dropout.path_pdrop", 0.0), mlp_pdrop=get(model_cfg, "dropout.mlp_pdrop", 0.0),
         attention_dropout=get(model_cfg, "attention_dropout", 0.0), rope_theta=get(model_cfg, "rope_theta", 10000.0),
         num_labels=get(model_cfg, "ft_head.num_labels", 2), problem_type=get(model_cfg, "ft_head.problem_type", None),
-        loss_type=get(model_cfg, "ft_head.loss_type", None))
+        loss_type=get(model_cfg, "ft_head.loss_type", None), num_neg=get(model_cfg, "ft_head.num_neg", None))

@@ -35,6 +35,7 @@ extern "C" {
 #define GGET_PROBLEM_SINGLE_LABEL 0 /* CrossEntropy on pooled logits (modeling_finetune.py:209-214) */
 #define GGET_PROBLEM_REGRESSION_L1 1 /* L1Loss  (modeling_finetune.py:183-197) */
 #define GGET_PROBLEM_REGRESSION_MSE 2 /* MSELoss */
+#define GGET_PROBLEM_AUC 4 /* pairwise squared-hinge AUC surrogate on logit[:,1]-logit[:,0] (src/utils/loss_utils.py:25-53, modeling_finetune.py:203-207); see gget_set_auc */
 #define GGET_PROBLEM_MULTI_LABEL 3 /* BCEWithLogitsLoss on the non-NaN entries of float labels [B,num_labels] (modeling_finetune.py:227-230) */
 
 /* Field meaning = GraphGPTConfig (src/models/graphgpt/configuration_graphgpt.py:26-110). */
@@ -119,6 +120,11 @@ int gget_bucket_range(gget_handle_t h, int bucket, uint64_t* offset, uint64_t* c
  * zeros (default) are evaluation behaviour.  path_p is the LAST layer's rate (layer l uses path_p*l/(L-1)) and needs a
  * handle created with config.path_pdrop > 0. */
 int gget_set_dropout(gget_handle_t h, float attention_p, float path_p, uint32_t seed);
+
+/* replaces: `config.num_neg` + the torch RNG behind `torch.randperm` in auc_loss (src/utils/loss_utils.py:25-43): negatives per
+ * positive and the seed of the counter-hash permutation the NEXT gget_forward_task(problem_type = GGET_PROBLEM_AUC) draws its
+ * negative samples with (idx = perm(P * num_neg) % N_neg; perm = rank of the hashed keys). */
+int gget_set_auc(gget_handle_t h, int num_neg, uint32_t seed);
 
 /* replaces: load_state_dict + `.to(bfloat16)`: refresh the bf16 compute copy from the fp32 master. */
 int gget_sync_params(gget_handle_t h, void* stream);

@@ -212,8 +212,18 @@ def pretrain_forward(spec, p, input_ids, attention_mask, labels=None, sample_wgt
 
 
 # --------------------------------------------------------------------------- K15 (row A10)
+def auc_loss(y_pred, y_true, num_neg, idx):
+    """`auc_loss` + `_auc_loss` (src/utils/loss_utils.py:25-53): y_pred 1-D logits, y_true 1-D {0,1}; every positive is
+    paired with num_neg negatives `y_pred_neg[idx]`, idx = torch.randperm(P * num_neg) % n_neg in the reference - here an
+    INPUT (recorded draws: the fixture's, or graph-gpt_amd.modeling.auc_pairs for the engine's counter hash)."""
+    pos = y_pred[y_true.bool()]
+    neg = y_pred[(1 - y_true).bool()][torch.as_tensor(idx, dtype=torch.int64)]
+    return torch.square(1 - (pos.reshape(-1, 1) - neg.reshape(-1, num_neg))).mean()
+
+
 def task_forward(spec, p, input_ids, attention_mask, position_ids=None, task_labels=None,
-                 sample_wgt=None, problem_type="single_label_classification", loss_type=None, path_mult=None, attn_keep=None):
+                 sample_wgt=None, problem_type="single_label_classification", loss_type=None, path_mult=None, attn_keep=None,
+                 num_neg=1, auc_idx=None):
     """`GraphGPTTaskModel.forward` (modeling_finetune.py:236-326) + `calculate_task_loss`
     (:167-234) + `_get_sequence_len` (modeling_helpers.py:78-86); Linear score head, "last" pooling."""
     if input_ids.dim() == 3:
@@ -233,6 +243,9 @@ def task_forward(spec, p, input_ids, attention_mask, position_ids=None, task_lab
                 loss = Fnn.l1_loss(pooled.squeeze(), y.squeeze())
             else:
                 loss = Fnn.mse_loss(pooled.squeeze(), y.squeeze())
+        elif problem_type == "single_label_classification" and loss_type == "auc":
+            lg = pooled.view(-1, spec.num_labels)
+            loss = auc_loss(lg[:, 1].float() - lg[:, 0].float(), task_labels.view(-1), num_neg, auc_idx)
         elif problem_type == "single_label_classification":
             if sample_wgt is None:
                 loss = Fnn.cross_entropy(pooled.view(-1, spec.num_labels).float(), task_labels.view(-1))

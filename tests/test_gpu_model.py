@@ -783,14 +783,32 @@ def test_c4_long_sequence_full_model_backward_matches_oracle():
     assert abs(float(loss) - want) <= 3e-2 * max(abs(want), 0.1), (float(loss), want)
     got = e.grads()
     gmax = max(float(g.norm()) for g in grads.values())
+    # ONE sample, two classes: d loss / d logits = (-p0, p0), so every gradient of the model carries the factor p0 - and p0 comes
+    # from the bf16 forward of 12 layers at S = 2048 (logit error ~1e-2 on a difference of ~3 moves p0 by several %).  That
+    # common factor is the forward's rounding, not a backward error: it is measured from the two logit vectors and divided out,
+    # the backward is then held to 4e-2; the raw error is recorded beside it (and bounded by the factor's own deviation).
+    lg_e = logits.float().cpu().numpy().reshape(-1)[:2]
+    lg_o = out[gk].detach().float().numpy().reshape(-1)[:2]
+
+    def p0(lg):
+        z = np.exp(lg - lg.max())
+        return float(z[0] / z.sum())
+    scale = p0(lg_e) / p0(lg_o)
+    record_error("c4_S2048_B1_backward", "dlogit_scale_minus_1 (forward rounding through p0)", abs(scale - 1.0), 0.15)
+    assert abs(scale - 1.0) < 0.15, (lg_e, lg_o)
     for k in ("score.weight", "model.layers.11.mlp.down_proj.weight", "model.layers.11.self_attn.q_proj.weight",
               "model.layers.6.self_attn.k_proj.weight", "model.layers.6.self_attn.v_proj.weight",
               "model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.o_proj.weight",
               "model.layers.0.mlp.gate_proj.weight", "model.layers.0.input_layernorm.weight", "model.embed_tokens.weight"):
         w = grads[k].numpy()
-        err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
-        record_error("c4_S2048_B1_backward", "grad_rel_l2 " + k, err, 8e-2)
-        assert err < 8e-2, f"{k}: {err}"
+        g = got[k].float().cpu().numpy()
+        den = max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        raw = float(np.linalg.norm(g - w)) / den
+        err = float(np.linalg.norm(g / scale - w)) / den
+        record_error("c4_S2048_B1_backward", "grad_rel_l2_raw " + k, raw, 4e-2 + 1.2 * abs(scale - 1.0))
+        record_error("c4_S2048_B1_backward", "grad_rel_l2 " + k, err, 4e-2)
+        assert err < 4e-2, f"{k}: {err} (raw {raw}, scale {scale})"
+        assert raw < 4e-2 + 1.2 * abs(scale - 1.0), f"{k}: raw {raw}, scale {scale}"
 
 
 def _attn_drop_keep(seed, B, H, S, p):
@@ -846,3 +864,56 @@ def test_c3_training_mode_dropouts_exact_mask():
         err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
         record_error("c3_train_mode_dropouts", "grad_rel_l2 " + k, err, 8e-2)
         assert err < 8e-2, f"{k}: {err}"
+
+
+@pytest.mark.gpu
+def test_auc_loss_matches_oracle_with_the_same_pairs():
+    """loss_type "auc" (modeling_finetune.py:203-207, src/utils/loss_utils.py:25-53) through the drop-in model class: the
+    engine's counter-hash negative sampling is reproduced by its Python twin, the oracle (pinned to the reference by
+    tests/golden/ft_tiny_auc.npz) evaluates the same pairs - loss on the engine's own logits exact to fp32 rounding, loss and
+    gradients of the whole model within the fine-tune tolerances."""
+    import os
+    from _util import GOLDEN, spec_mod, weights_mod
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    z = np.load(os.path.join(GOLDEN, "ft_tiny_auc.npz"))
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=1000, stacked_feat=4, next_n_token=1, num_labels=2)
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    num_neg = int(z["num_neg"])
+    cfg = M.GraphGPTConfig(vocab_size=1000, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+                           num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
+                           max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=4, num_labels=2,
+                           loss_type="auc", num_neg=num_neg, problem_type="single_label_classification")
+    model = M.GraphGPTTaskModel(cfg, seed=1)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model.auc_seed = 77
+    out = model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], position_ids=b["position_ids"],
+                task_labels=b["task_labels"])
+    loss = float(out.task_loss.item())
+    out.task_loss.backward()
+    idx = M.auc_pairs(b["task_labels"].numpy(), num_neg, model.last_auc_seed)
+    lg = out.task_logits.float().cpu()
+    on_own_logits = O.auc_loss(lg[:, 1] - lg[:, 0], b["task_labels"].view(-1), num_neg, idx).item()
+    record_error("ft_tiny_auc", "loss_rel_vs_oracle_on_engine_logits", abs(loss - on_own_logits) / abs(on_own_logits), 2e-6)
+    assert abs(loss - on_own_logits) <= 2e-6 * abs(on_own_logits), (loss, on_own_logits)
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32)
+    fn = lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"],
+                                  problem_type="single_label_classification", loss_type="auc", num_neg=num_neg, auc_idx=idx)
+    o, grads = O.loss_and_grads(fn, p, "task_loss")
+    want = o["task_loss"].item()
+    record_error("ft_tiny_auc", "loss_rel_vs_oracle", abs(loss - want) / abs(want), 2e-2)
+    assert abs(loss - want) <= 2e-2 * abs(want), (loss, want)
+    got = model._engine.grads()
+    gmax = max(float(g.norm()) for g in grads.values())
+    for k in ("score.weight", "model.layers.1.mlp.down_proj.weight", "model.layers.0.self_attn.q_proj.weight",
+              "model.embed_tokens.weight"):
+        w = grads[k].numpy()
+        err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        record_error("ft_tiny_auc", "grad_rel_l2 " + k, err, 6e-2)
+        assert err < 6e-2, f"{k}: {err}"
+    # another call draws other pairs (the reference draws a fresh randperm every call)
+    out2 = model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], position_ids=b["position_ids"],
+                 task_labels=b["task_labels"])
+    assert float(out2.task_loss.item()) != loss

@@ -1,5 +1,8 @@
 """Pins the CPU oracle (oracle/gget_oracle.py) against golden vectors captured from the real
 reference (tools/make_golden.py).  fp32: tight; bf16: the reference's own bf16 module path."""
+import importlib
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -232,3 +235,45 @@ def test_oracle_inverse_cdf_sampler_and_filters():
     cum = torch.softmax(logits[0][order], dim=-1).cumsum(0)
     n_keep = int((cum <= 0.6).sum()) + 1          # everything up to and including the first token that crosses top_p
     assert torch.equal((lp > torch.finfo(torch.float32).min).nonzero().view(-1).sort().values, order[:n_keep].sort().values)
+
+
+def _auc_case():
+    from _util import GOLDEN, spec_mod, weights_mod
+    z = np.load(os.path.join(GOLDEN, "ft_tiny_auc.npz"))
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=1000, stacked_feat=4, next_n_token=1, num_labels=2)
+    assert [int(x) for x in z["meta_spec"]] == list(spec.as_c_ints())
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    return z, spec, state, b
+
+
+def test_oracle_auc_loss_matches_reference():
+    """loss_type "auc" (src/utils/loss_utils.py:25-53): with the negative-sample indices the reference's randperm drew, the
+    restatement reproduces the reference's loss, logits and gradients."""
+    z, spec, state, b = _auc_case()
+    p = O.to_params(state, torch.float32)
+    fn = lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"],
+                                  problem_type="single_label_classification", loss_type="auc", num_neg=int(z["num_neg"]),
+                                  auc_idx=z["idx"])
+    out, grads = O.loss_and_grads(fn, p, "task_loss")
+    assert abs(out["task_loss"].item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    np.testing.assert_allclose(out["task_logits"].detach().numpy(), z["logits"], rtol=2e-4, atol=2e-5)
+    for k, want in (("score.weight", z["grad_score"]), ("model.layers.1.mlp.down_proj.weight", z["grad_l1_down"])):
+        g = grads[k].numpy()
+        assert np.linalg.norm(g - want) <= 2e-4 * np.linalg.norm(want), k
+    gn = np.array([float(grads[str(n)].norm()) for n in z["names"]])
+    np.testing.assert_allclose(gn, z["grad_norms"], rtol=5e-4, atol=1e-7)
+
+
+def test_auc_pairs_twin_is_a_balanced_permutation_draw():
+    """graph-gpt_amd.modeling.auc_pairs (twin of the device sampling): perm(P * num_neg) % N - every negative is used
+    floor or ceil of cnt / N times, like the reference's randperm % N."""
+    m = importlib.import_module("graph-gpt_amd.modeling")
+    y = np.array([1, 0, 1, 1, 0, 0, 1, 1, 1, 0, 1, 1])
+    idx = m.auc_pairs(y, 3, seed=5)
+    P, N = 8, 4
+    assert idx.shape == (P * 3,) and idx.min() >= 0 and idx.max() < N
+    cnt = np.bincount(idx, minlength=N)
+    assert cnt.min() >= (P * 3) // N and cnt.max() <= -(-(P * 3) // N)
+    assert not np.array_equal(idx, m.auc_pairs(y, 3, seed=6))

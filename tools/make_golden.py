@@ -523,6 +523,41 @@ def ckpt_fixture():
           f"our save_model -> reference strict load ok, loss {res['roundtrip_loss_of_seed9_model']:.6f}")
 
 
+def auc_fixture():
+    """Fine-tune head with loss_type "auc" (src/utils/loss_utils.py:25-53 through modeling_finetune.py:203-207), num_neg = 2:
+    the reference's loss / gradients on a seeded batch, with the negative-sample indices its torch.randperm call drew
+    (re-derived from the same generator state) stored next to them - a restatement fed with those indices must match."""
+    PT, FT, Cfg = import_reference()
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=1000, stacked_feat=4, next_n_token=1, num_labels=2)
+    state = weights_mod.make_state_dict(spec, seed=611, std=0.06, head_std=0.15)
+    batch = synth.make_task_batch(B=24, S=24, F=4, V=1000, num_labels=2, seed=61)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    num_neg = 2
+    model = FT(ref_config(Cfg, spec, num_labels=2, loss_type="auc", num_neg=num_neg, mlp=[], problem_type="single_label_classification"))
+    load_weights(model, state)
+    model.eval()
+    y = tb["task_labels"].view(-1)
+    P, N = int((y != 0).sum()), int((y == 0).sum())
+    torch.manual_seed(8642)
+    idx = torch.randperm(P * num_neg, dtype=torch.int64) % N          # what auc_loss will draw next
+    torch.manual_seed(8642)
+    o = model(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"], position_ids=tb["position_ids"],
+              task_labels=tb["task_labels"])
+    model.zero_grad()
+    o.task_loss.backward()
+    names = list(state.keys())
+    g = dict(model.named_parameters())
+    res = {"loss": np.float64(o.task_loss.item()), "logits": o.task_logits.detach().float().numpy(), "idx": idx.numpy(),
+           "num_neg": np.int64(num_neg), "grad_norms": grad_norms(model, names), "names": np.array(names),
+           "grad_score": g["score.weight"].grad.numpy().copy(),
+           "grad_l1_down": g["model.layers.1.mlp.down_proj.weight"].grad.numpy().copy(),
+           "meta_spec": np.array(spec.as_c_ints(), np.int64), "meta_init": np.array([611, 0.06, 0.15])}
+    for k, v in batch.items():
+        res["in_" + k] = v
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ft_tiny_auc.npz"), **res)
+    print(f"ft_tiny_auc written: loss {res['loss']:.6f}, P {P} N {N}, pairs {P * num_neg}")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -544,6 +579,8 @@ def main():
         hostmask_fixture()
     if not only or "ref_ckpt" in only:
         ckpt_fixture()
+    if not only or "ft_tiny_auc" in only:
+        auc_fixture()
 
 
 if __name__ == "__main__":

@@ -100,6 +100,29 @@ __device__ __forceinline__ void gelu_erf_both(float x, float& val, float& grad) 
   grad = fmaf(x * 0.39894228040143267794f, g, cdf);
 }
 
+// Element-wise dropout (nn.Dropout on a tensor: embed_dropout - modeling_helpers.py:97-98, mlp_act_dropout / mlp_dropout -
+// utils_graphgpt.py:69-80).  Counter-based like the attention / path dropouts: element (a, b) of stream `stream` is dropped when
+// the 24-bit hash of (seed, stream, a, b) - the same hash as smtp_rng in kernels.hip, graph-gpt_amd/smtp.py:_rng24 is its
+// Python twin - falls below thresh = p * 2^24; kept elements are scaled by 1 / (1 - p) and rounded to bf16 as the reference's
+// bf16 module does.  Backward regenerates the mask from the coordinates.
+struct ElemDropArg {
+  unsigned thresh;    // 0 => off
+  float inv_keep;
+  unsigned seed;
+};
+#define GGET_DROP_STREAM_EMBED 48u
+#define GGET_DROP_STREAM_MLP_ACT 49u
+#define GGET_DROP_STREAM_MLP_OUT 50u
+#ifdef __HIPCC__
+__device__ __forceinline__ float elem_drop_mul(const ElemDropArg& E, unsigned stream, unsigned a, unsigned b) {
+  if (E.thresh == 0) return 1.f;
+  unsigned x = E.seed ^ (stream * 0x9E3779B1u);
+  x += a * 0x85EBCA77u + b * 0xC2B2AE3Du;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return (x >> 8) < E.thresh ? 0.f : E.inv_keep;
+}
+#endif
+
 // ---- host side error plumbing (engine.cpp owns the storage) ----
 void gget_set_error(const char* fmt, ...);
 #define GGET_HIP_CHECK(expr)                                                                  \

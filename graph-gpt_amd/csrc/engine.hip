@@ -94,7 +94,7 @@ Plan make_plan(const gget_config_t& c) {
   const int64_t d = c.hidden_size, ff = c.intermediate_size, V = c.vocab_size, F = c.stacked_feat, L = c.num_layers;
   pl.has_gate = c.gated_agg != 0;
   pl.has_ls = c.layer_scale_init > 0.f;
-  pl.has_res = pl.has_ls || c.path_pdrop > 0.f;
+  pl.has_res = pl.has_ls || c.path_pdrop > 0.f || c.mlp_pdrop > 0.f;   // (mlp_dropout sits between down_proj and the residual add)
   pl.has_ntp = c.kind == GGET_KIND_PRETRAIN && c.next_n_token > 1;
   add_param(pl, "model.embed_tokens.weight", V, d, -1, true, &pl.emb, &pl.emb32);
   if (pl.has_gate) add_param(pl, "stacked_feat_agg.weight", F, d, -1, true, &pl.gate, &pl.gate32);
@@ -287,6 +287,14 @@ struct gget_engine {
   float attn_drop_p = 0.f;        // attention dropout of the NEXT forward (training mode); 0 = off
   float path_drop_p = 0.f;        // stochastic-depth rate of the last layer (layer l: p*l/(L-1))
   unsigned attn_drop_seed = 0;
+  float embed_drop_p = 0.f;       // embed_dropout / mlp dropouts of the NEXT forward (training mode); 0 = off
+  float mlp_drop_p = 0.f;
+  static ElemDropArg elem_drop(float p, unsigned seed) {
+    if (p <= 0.f) return ElemDropArg{0, 1.f, 0};
+    return ElemDropArg{(unsigned)(p * 16777216.0f), 1.0f / (1.0f - p), seed};
+  }
+  ElemDropArg embed_drop() const { return elem_drop(embed_drop_p, attn_drop_seed ^ 0x5BD1E995u); }
+  ElemDropArg mlp_drop(int layer) const { return elem_drop(mlp_drop_p, attn_drop_seed + 0x7F4A7C15u * (unsigned)(layer + 1)); }
   PathDropArg path_drop(int layer, int which) const {
     const int L = cfg.num_layers;
     const float rate = (path_drop_p > 0.f && L > 1) ? path_drop_p * (float)layer / (float)(L - 1) : 0.f;
@@ -436,6 +444,15 @@ extern "C" int gget_bucket_range(gget_handle_t h, int bucket, uint64_t* offset, 
   return 0;
 }
 
+extern "C" int gget_set_dropout_ex(gget_handle_t h, float embed_p, float mlp_p) {
+  GGET_REQUIRE(h != nullptr, "null handle");
+  GGET_REQUIRE(embed_p >= 0.f && embed_p < 1.f && mlp_p >= 0.f && mlp_p < 1.f, "dropout probabilities must be in [0, 1)");
+  GGET_REQUIRE(mlp_p == 0.f || h->cfg.mlp_pdrop > 0.f, "MLP dropout needs a handle created with config.mlp_pdrop > 0");
+  h->embed_drop_p = embed_p;
+  h->mlp_drop_p = mlp_p;
+  return 0;
+}
+
 extern "C" int gget_set_auc(gget_handle_t h, int num_neg, uint32_t seed) {
   GGET_REQUIRE(h != nullptr, "null handle");
   GGET_REQUIRE(num_neg >= 1, "num_neg must be >= 1");
@@ -523,7 +540,7 @@ __device__ __forceinline__ float path_keep(const PathDrop& D, long t) {
 }
 __global__ void __launch_bounds__(256) ls_fwd_kernel(const bf16_t* __restrict__ res, const bf16_t* __restrict__ y,
                                                      const bf16_t* __restrict__ lam, bf16_t* __restrict__ out, long T, int d,
-                                                     PathDrop D) {
+                                                     PathDrop D, ElemDropArg E) {
   const int cpr = d >> 3;
   const long total = T * cpr;
   for (long w = (long)blockIdx.x * 256 + threadIdx.x; w < total; w += (long)gridDim.x * 256) {
@@ -533,6 +550,11 @@ __global__ void __launch_bounds__(256) ls_fwd_kernel(const bf16_t* __restrict__ 
     unpack8(*reinterpret_cast<const uint4*>(res + w * 8), r);
     unpack8(*reinterpret_cast<const uint4*>(y + w * 8), v);
     if (lam) unpack8(*reinterpret_cast<const uint4*>(lam + c * 8), l);
+    if (E.thresh) {   // mlp_dropout on the down projection's output (utils_graphgpt.py:79), rounded like the bf16 module does
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        v[e] = bf2f(f2bf(v[e] * elem_drop_mul(E, GGET_DROP_STREAM_MLP_OUT, (unsigned)(w / cpr), (unsigned)(c * 8 + e))));
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] += keep * bf2f(f2bf(l[e] * v[e]));
     *reinterpret_cast<uint4*>(out + w * 8) = pack8(r);
@@ -541,7 +563,7 @@ __global__ void __launch_bounds__(256) ls_fwd_kernel(const bf16_t* __restrict__ 
 __global__ void __launch_bounds__(256) ls_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
                                                      const bf16_t* __restrict__ lam, bf16_t* __restrict__ dscaled,
                                                      float* __restrict__ dlam, int T, int d, PathDrop D, int copies,
-                                                     uint64_t copy_stride) {
+                                                     uint64_t copy_stride, ElemDropArg E) {
   // thread = (row lane, 8-channel chunk); a block walks rows blockIdx.x*RL + lane, stride gridDim.x*RL.  The dlam partials
   // of the block's row lanes are summed through LDS and added to accumulator copy blockIdx.x % copies (GgetSegment).
   extern __shared__ float ls_lds[];   // [RL][d]
@@ -557,7 +579,11 @@ __global__ void __launch_bounds__(256) ls_bwd_kernel(const bf16_t* __restrict__ 
       unpack8(*reinterpret_cast<const uint4*>(dy + (size_t)t * d + c * 8), g);
       unpack8(*reinterpret_cast<const uint4*>(y + (size_t)t * d + c * 8), v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { o[e] = l[e] * keep * g[e]; acc[e] += keep * g[e] * v[e]; }
+      for (int e = 0; e < 8; ++e) {
+        const float em = elem_drop_mul(E, GGET_DROP_STREAM_MLP_OUT, (unsigned)t, (unsigned)(c * 8 + e));
+        o[e] = l[e] * keep * g[e] * em;
+        acc[e] += keep * g[e] * bf2f(f2bf(v[e] * em));
+      }
       *reinterpret_cast<uint4*>(dscaled + (size_t)t * d + c * 8) = pack8(o);
     }
   }
@@ -615,11 +641,13 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
     const PathDrop pd1 = h->path_drop(i, 0), pd2 = h->path_drop(i, 1);
     const int g = (int)std::min<long>(4096, ((long)T * (d / 8) + 255) / 256);
     if (int e = gemm_nt(attn, h->P + lo.wo, araw, nullptr, T, d, d, d, d, d, nullptr, st)) return e;
-    hipLaunchKernelGGL(ls_fwd_kernel, dim3(g), dim3(256), 0, st, x_in, araw, lam1, xmid, (long)T, d, pd1);
+    hipLaunchKernelGGL(ls_fwd_kernel, dim3(g), dim3(256), 0, st, x_in, araw, lam1, xmid, (long)T, d, pd1, ElemDropArg{0, 1.f, 0});
     if (int e = k_rmsnorm_fwd(xmid, h->P + lo.ln2, xn2, h->wsp<float>(lw.rstd2), T, d, c.rms_eps, st)) return e;
     if (int e = gateup_geglu(xn2, h->P + lo.wgu, gu, hh, T, d, ff, st)) return e;
+    const ElemDropArg md = h->mlp_drop(i);
+    if (int e = k_elem_dropout(hh, T, ff, GGET_DROP_STREAM_MLP_ACT, md, st)) return e;     // mlp_act_dropout (utils_graphgpt.py:78)
     if (int e = gemm_nt(hh, h->P + lo.wdown, mraw, nullptr, T, d, ff, ff, ff, d, nullptr, st)) return e;
-    hipLaunchKernelGGL(ls_fwd_kernel, dim3(g), dim3(256), 0, st, xmid, mraw, lam2, x_out, (long)T, d, pd2);
+    hipLaunchKernelGGL(ls_fwd_kernel, dim3(g), dim3(256), 0, st, xmid, mraw, lam2, x_out, (long)T, d, pd2, md);
     GGET_LAUNCH_CHECK();
     return 0;
   }
@@ -650,7 +678,7 @@ int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t*
     return e;
   }
   if (int e = k_embed_fwd(ids, h->P + h->plan.emb, h->plan.has_gate ? h->P + h->plan.gate : nullptr,
-                          h->wsp<bf16_t>(h->ws.xres[0]), h->T, c.stacked_feat, ldF, d, st))
+                          h->wsp<bf16_t>(h->ws.xres[0]), h->T, c.stacked_feat, ldF, d, st, h->embed_drop()))
     return e;
   for (int i = 0; i < c.num_layers; ++i)
     if (int e = layer_forward(h, i, st)) return e;
@@ -800,11 +828,15 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
     bf16_t* dsc = h->wsp<bf16_t>(w.dscaled);
     hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), ls_lds_bytes, st, dx_out, h->wsp<bf16_t>(lw.mraw),
                        h->plan.has_ls ? h->P + lo.lam2 : nullptr, dsc, h->plan.has_ls ? s32 + lo.lam2_32 : nullptr, T, d,
-                       h->path_drop(i, 1), kAccumCopies, align_up((uint64_t)d, 128));
+                       h->path_drop(i, 1), kAccumCopies, align_up((uint64_t)d, 128), h->mlp_drop(i));
     dy_down = dsc;   // stays alive for the grouped wgrad at the end of the layer (the o_proj branch has its own buffer)
   }
   // MLP: dh = dy_down W_down ; dgu = geglu'(dh) ; dxn2 = dgu W_gu
-  if (int e = down_dgrad_geglu(dy_down, h->P + lo.wdown, h->wsp<bf16_t>(lw.gu), dgu, dh, T, d, ff, st)) return e;
+  if (h->mlp_drop_p > 0.f) {   // mlp_act_dropout sits between the gated product and down_proj: mask dh before the GEGLU backward
+    if (int e = gemm_nn(dy_down, h->P + lo.wdown, dh, T, ff, d, d, ff, ff, nullptr, st)) return e;
+    if (int e = k_elem_dropout(dh, T, ff, GGET_DROP_STREAM_MLP_ACT, h->mlp_drop(i), st)) return e;
+    if (int e = k_geglu_bwd(h->wsp<bf16_t>(lw.gu), dh, dgu, T, ff, st)) return e;
+  } else if (int e = down_dgrad_geglu(dy_down, h->P + lo.wdown, h->wsp<bf16_t>(lw.gu), dgu, dh, T, d, ff, st)) return e;
   if (int e = gemm_nn(dgu, h->P + lo.wgu, dxn, T, d, 2 * ff, 2 * ff, d, d, nullptr, st)) return e;
   if (int e = k_rmsnorm_bwd(dxn, xmid, h->P + lo.ln2, h->wsp<float>(lw.rstd2), dx_out, dx_mid, s32 + lo.ln2_32, T, d, st, kAccumCopies, align_up((uint64_t)d, 128)))
     return e;
@@ -813,7 +845,7 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
     bf16_t* dsc = h->wsp<bf16_t>(w.dscaled2);
     hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), ls_lds_bytes, st, dx_mid, h->wsp<bf16_t>(lw.araw),
                        h->plan.has_ls ? h->P + lo.lam1 : nullptr, dsc, h->plan.has_ls ? s32 + lo.lam1_32 : nullptr, T, d,
-                       h->path_drop(i, 0), kAccumCopies, align_up((uint64_t)d, 128));
+                       h->path_drop(i, 0), kAccumCopies, align_up((uint64_t)d, 128), ElemDropArg{0, 1.f, 0});
     dy_o = dsc;
   }
   // attention: dattn = dy_o W_o ; (dq,dk,dv) ; inverse RoPE ; dxn1 = dqkv W_qkv
@@ -934,9 +966,10 @@ extern "C" int gget_backward_layer(gget_handle_t h, int layer, void* stream) {
 // (k_embed_count), one split-K GEMM with fp32 atomics into the accumulator - the sorted scatter-add below spends its time in
 // same-address atomics when half of the cells hold the <mask> id.  Otherwise: counting sort by id + segmented sums.
 int embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* gate, float* demb, float* dgate, int T, int F,
-              int ldF, int d, int V, int pad_id, int32_t* sort_ws, void* cnt_ws, void* slab_ws, hipStream_t st) {
+              int ldF, int d, int V, int pad_id, int32_t* sort_ws, void* cnt_ws, void* slab_ws, hipStream_t st, ElemDropArg E) {
   static const bool sorted_only = getenv("GGET_EMBED_SORTED") != nullptr;   // A/B knob
-  if (cnt_ws && slab_ws && !sorted_only && k_embed_dense_ok(V, gate != nullptr) && T > 0 && (V * d) % 4 == 0) {
+  // (embedding dropout masks every (cell, channel) on its own: the count-matrix product cannot express it)
+  if (cnt_ws && slab_ws && !sorted_only && E.thresh == 0 && k_embed_dense_ok(V, gate != nullptr) && T > 0 && (V * d) % 4 == 0) {
     const int ldc = (int)align_up((uint64_t)V, 64);
     GGET_HIP_CHECK(hipMemsetAsync(cnt_ws, 0, (size_t)T * ldc * 2, st));
     if (int e = k_embed_count(ids, cnt_ws, T, F, ldF, ldc, pad_id, st)) return e;
@@ -952,7 +985,7 @@ int embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* g
       return e;
     return k_slab_reduce(slabs, (long)V * d, nslab, demb, (size_t)V * d, st, /*f32_out=*/true);
   }
-  return k_embed_bwd(ids, dx, emb, gate, demb, dgate, T, F, ldF, d, V, pad_id, sort_ws, st);
+  return k_embed_bwd(ids, dx, emb, gate, demb, dgate, T, F, ldF, d, V, pad_id, sort_ws, st, E);
 }
 
 extern "C" int gget_backward_end(gget_handle_t h, void* stream) {
@@ -964,7 +997,8 @@ extern "C" int gget_backward_end(gget_handle_t h, void* stream) {
                         s32 + h->plan.emb32, h->plan.has_gate ? s32 + h->plan.gate32 : nullptr, h->T, c.stacked_feat,
                         c.stacked_feat, c.hidden_size, c.vocab_size, c.pad_token_id, h->wsp<int32_t>(h->ws.emb_sort),
                         k_embed_dense_ok(c.vocab_size, h->plan.has_gate) ? h->wsp<unsigned char>(h->ws.emb_cnt) : nullptr,
-                        k_embed_dense_ok(c.vocab_size, h->plan.has_gate) ? h->wsp<unsigned char>(h->ws.emb_slab) : nullptr, st))
+                        k_embed_dense_ok(c.vocab_size, h->plan.has_gate) ? h->wsp<unsigned char>(h->ws.emb_slab) : nullptr, st,
+                        h->embed_drop()))
     return e;
   h->dx_cur = nullptr;
   return convert_bucket(h, c.num_layers + 1, st);
@@ -1142,7 +1176,8 @@ extern "C" int gget_op_embed_bwd(const int64_t* ids, const void* dx, const void*
   if (k_embed_dense_ok(V, gate != nullptr))
     GGET_HIP_CHECK(hipMalloc(&cnt, (size_t)T * align_up((uint64_t)V, 64) * 2 + (size_t)kEmbDenseSplit * V * d * 4));
   void* slab = cnt ? static_cast<unsigned char*>(cnt) + (size_t)T * align_up((uint64_t)V, 64) * 2 : nullptr;
-  const int rc = embed_bwd(ids, dx, emb, gate, demb_accum, dgate_accum, T, F, ldF, d, V, pad_id, ws, cnt, slab, (hipStream_t)stream);
+  const int rc = embed_bwd(ids, dx, emb, gate, demb_accum, dgate_accum, T, F, ldF, d, V, pad_id, ws, cnt, slab, (hipStream_t)stream,
+                           ElemDropArg{0, 1.f, 0});
   (void)hipStreamSynchronize((hipStream_t)stream);
   (void)hipFree(ws);
   if (cnt) (void)hipFree(cnt);

@@ -18,10 +18,11 @@ struct GgetSegment {
 };
 
 int k_embed_fwd(const int64_t* ids, const void* emb, const void* gate, void* out, int T, int F, int ldF, int d,
-                hipStream_t st);
+                hipStream_t st, ElemDropArg E = ElemDropArg{0, 1.f, 0});
+int k_elem_dropout(void* x, long T, int n, unsigned stream, ElemDropArg E, hipStream_t st);
 // sort_ws: int32 scratch of k_embed_bwd_ws_elems(T*F, V) elements (device-side counting sort of the cells by id)
 int k_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* gate, float* demb, float* dgate, int T,
-                int F, int ldF, int d, int V, int pad_id, int32_t* sort_ws, hipStream_t st);
+                int F, int ldF, int d, int V, int pad_id, int32_t* sort_ws, hipStream_t st, ElemDropArg E = ElemDropArg{0, 1.f, 0});
 inline size_t k_embed_bwd_ws_elems(size_t ncell, size_t V) { return 3 * V + 1 + 2 * ncell; }
 // count matrix of the dense embedding backward: cnt[t][v] = #{f: ids[t][f] == v, v != pad} as bf16, row pitch ldc; the
 // caller clears it first.  Used when k_embed_dense_ok(): dE = cnt^T dX is then one split-K GEMM (engine.hip: embed_bwd)

@@ -19,7 +19,7 @@ __device__ __forceinline__ void stg16(bf16_t* p, const uint4& v) { *reinterpret_
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(128) embed_fwd_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ emb,
                                                         const bf16_t* __restrict__ gate, bf16_t* __restrict__ out,
-                                                        int T, int F, int ldF, int d) {
+                                                        int T, int F, int ldF, int d, ElemDropArg E) {
   const int t = blockIdx.x;
   const int64_t* row = ids + (size_t)t * ldF;
   for (int c = threadIdx.x; c * 8 < d; c += blockDim.x) {
@@ -28,6 +28,11 @@ __global__ void __launch_bounds__(128) embed_fwd_kernel(const int64_t* __restric
       const int64_t id = row[f];
       float v[8];
       unpack8(ldg16(emb + (size_t)id * d + c * 8), v);
+      if (E.thresh) {   // embed_dropout acts on the gathered rows, before the stacking (modeling_helpers.py:96-101)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          v[e] = bf2f(f2bf(v[e] * elem_drop_mul(E, GGET_DROP_STREAM_EMBED, (unsigned)(t * F + f), (unsigned)(c * 8 + e))));
+      }
       if (gate) {
         float gv[8];
         unpack8(ldg16(gate + (size_t)f * d + c * 8), gv);
@@ -161,7 +166,7 @@ __global__ void __launch_bounds__(128) embed_reduce_kernel(const int32_t* __rest
                                                            const int32_t* __restrict__ id_sorted,
                                                            const int32_t* __restrict__ offs, int V,
                                                            const bf16_t* __restrict__ dx, const bf16_t* __restrict__ gate,
-                                                           float* __restrict__ demb, int F, int d) {
+                                                           float* __restrict__ demb, int F, int d, ElemDropArg E) {
   const int n = offs[V];
   const int beg = blockIdx.x * kEmbSeg;
   if (beg >= n) return;
@@ -192,6 +197,10 @@ __global__ void __launch_bounds__(128) embed_reduce_kernel(const int32_t* __rest
         }
         float g[8];
         unpack8(raw[u], g);
+        if (E.thresh) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] *= elem_drop_mul(E, GGET_DROP_STREAM_EMBED, (unsigned)cellv[u], (unsigned)(c * 8 + e));
+        }
         if (gate) {
           float gv[8];
           unpack8(ldg16(gate + (size_t)(cellv[u] % F) * d + c * 8), gv);
@@ -228,7 +237,7 @@ __global__ void __launch_bounds__(kBlock) embed_count_kernel(const int64_t* __re
 constexpr int kEmbTok = 64;
 __global__ void __launch_bounds__(128) embed_dgate_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ dx,
                                                           const bf16_t* __restrict__ emb, float* __restrict__ dgate, int T,
-                                                          int F, int ldF, int d) {
+                                                          int F, int ldF, int d, ElemDropArg E) {
   const int t0 = blockIdx.x * kEmbTok;
   const int f = blockIdx.y;
   for (int c = threadIdx.x; c * 8 < d; c += blockDim.x) {
@@ -238,6 +247,11 @@ __global__ void __launch_bounds__(128) embed_dgate_kernel(const int64_t* __restr
       float g[8], ev[8];
       unpack8(ldg16(dx + (size_t)t * d + c * 8), g);
       unpack8(ldg16(emb + (size_t)ids[(size_t)t * ldF + f] * d + c * 8), ev);
+      if (E.thresh) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          ev[e] = bf2f(f2bf(ev[e] * elem_drop_mul(E, GGET_DROP_STREAM_EMBED, (unsigned)(t * F + f), (unsigned)(c * 8 + e))));
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += g[e] * ev[e];
     }
@@ -1275,17 +1289,39 @@ inline int grid_for(long work_items, int per_block = kBlock, int cap = 4096) {
 // ================================================================================================
 // host launchers
 // ================================================================================================
+// in-place element dropout of a [T][n] bf16 matrix (mlp_act_dropout on the gated activations; the same call masks dh in backward)
+__global__ void __launch_bounds__(kBlock) elem_dropout_kernel(bf16_t* __restrict__ x, long T, int n, unsigned stream, ElemDropArg E) {
+  const int cpr = n >> 3;
+  const long total = T * cpr;
+  for (long w = (long)blockIdx.x * kBlock + threadIdx.x; w < total; w += (long)gridDim.x * kBlock) {
+    const unsigned t = (unsigned)(w / cpr), c = (unsigned)(w % cpr) * 8;
+    float v[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + w * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= elem_drop_mul(E, stream, t, c + e);
+    *reinterpret_cast<uint4*>(x + w * 8) = pack8(v);
+  }
+}
+int k_elem_dropout(void* x, long T, int n, unsigned stream, ElemDropArg E, hipStream_t st) {
+  if (T == 0 || E.thresh == 0) return 0;
+  GGET_REQUIRE(n % 8 == 0, "elem_dropout: width must be a multiple of 8");
+  const int g = (int)std::min<long>(4096, (T * (n / 8) + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(elem_dropout_kernel, dim3(g), dim3(kBlock), 0, st, (bf16_t*)x, T, n, stream, E);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
 int k_embed_fwd(const int64_t* ids, const void* emb, const void* gate, void* out, int T, int F, int ldF, int d,
-                hipStream_t st) {
+                hipStream_t st, ElemDropArg E) {
   if (T == 0) return 0;
   hipLaunchKernelGGL(embed_fwd_kernel, dim3(T), dim3(128), 0, st, ids, (const bf16_t*)emb, (const bf16_t*)gate,
-                     (bf16_t*)out, T, F, ldF, d);
+                     (bf16_t*)out, T, F, ldF, d, E);
   GGET_LAUNCH_CHECK();
   return 0;
 }
 
 int k_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* gate, float* demb, float* dgate, int T,
-                int F, int ldF, int d, int V, int pad_id, int32_t* sort_ws, hipStream_t st) {
+                int F, int ldF, int d, int V, int pad_id, int32_t* sort_ws, hipStream_t st, ElemDropArg E) {
   if (T == 0) return 0;
   // sort_ws: hist[V] | offs[V+1] | cursor[V] | cell_sorted[T*F] | id_sorted[T*F]
   const long ncell = (long)T * F;
@@ -1312,10 +1348,10 @@ int k_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void*
                        ldF, pad_id, V, hot_id);
   }
   hipLaunchKernelGGL(embed_reduce_kernel, dim3((int)((ncell + kEmbSeg - 1) / kEmbSeg)), dim3(128), 0, st, cell_sorted,
-                     id_sorted, offs, V, (const bf16_t*)dx, (const bf16_t*)gate, demb, F, d);
+                     id_sorted, offs, V, (const bf16_t*)dx, (const bf16_t*)gate, demb, F, d, E);
   if (gate)
     hipLaunchKernelGGL(embed_dgate_kernel, dim3((T + kEmbTok - 1) / kEmbTok, F), dim3(128), 0, st, ids, (const bf16_t*)dx,
-                       (const bf16_t*)emb, dgate, T, F, ldF, d);
+                       (const bf16_t*)emb, dgate, T, F, ldF, d, E);
   GGET_LAUNCH_CHECK();
   return 0;
 }

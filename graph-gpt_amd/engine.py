@@ -46,6 +46,7 @@ class Engine:
         cfg.rms_eps, cfg.rope_theta, cfg.layer_scale_init = spec.rms_eps, spec.rope_theta, spec.layer_scale_init
         cfg.max_tokens, cfg.max_batch = int(max_tokens), int(max_batch)
         cfg.path_pdrop = float(getattr(spec, "path_pdrop", 0.0))
+        cfg.mlp_pdrop = float(getattr(spec, "mlp_pdrop", 0.0))
         self.cfg = cfg
         sz = L.GgetSizes()
         L.check(self.lib.gget_query_sizes(C.byref(cfg), C.byref(sz)))
@@ -181,6 +182,10 @@ class Engine:
     def set_dropout(self, attention_p: float = 0.0, path_p: float = 0.0, seed: int = 0):
         """Attention dropout / stochastic depth for the NEXT forward+backward (training mode); zeros = eval."""
         L.check(self.lib.gget_set_dropout(self.h, float(attention_p), float(path_p), int(seed) & 0xFFFFFFFF))
+
+    def set_dropout_ex(self, embed_p: float = 0.0, mlp_p: float = 0.0):
+        """Embedding dropout and the two MLP dropouts for the NEXT forward+backward (masks keyed by set_dropout's seed)."""
+        L.check(self.lib.gget_set_dropout_ex(self.h, float(embed_p), float(mlp_p)))
 
     def set_auc(self, num_neg: int = 1, seed: int = 0):
         """Negatives per positive and the sampling seed of the NEXT forward_task(problem=PROBLEM_AUC)."""

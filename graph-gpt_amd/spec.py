@@ -37,6 +37,8 @@ class ModelSpec:
     score_bias: bool = False        # problem_type == "regression"
     pad_token_id: int = 0
     path_pdrop: float = 0.0         # stochastic depth (DropPath) rate of the last layer; 0 = feature not allocated
+    mlp_pdrop: float = 0.0          # MLP dropouts (utils_graphgpt.py:69-80); 0 = feature not allocated
+    embed_pdrop: float = 0.0        # dropout on the gathered token embeddings (modeling_helpers.py:96-98)
 
     def __post_init__(self):
         assert self.hidden_size == self.num_heads * self.head_dim, "no GQA / odd head dims on this path"

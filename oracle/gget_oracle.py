@@ -30,10 +30,13 @@ _EPSILON = 1e-7  # reference modeling_helpers.py `_EPSILON`
 
 
 # --------------------------------------------------------------------------- K1  (row A1)
-def stacked_embed(emb_w: torch.Tensor, input_ids: torch.Tensor, gate_w: Optional[torch.Tensor]):
+def stacked_embed(emb_w: torch.Tensor, input_ids: torch.Tensor, gate_w: Optional[torch.Tensor], embed_keep=None):
     """`_get_stacked_inputs_embeds` (modeling_helpers.py:89-114) + `StackedFeatAggregation.forward`
-    (modeling_common.py:127-135).  ids [B,S,F] (or [B,S]) -> [B,S,d]; returns (embeds, in_)."""
+    (modeling_common.py:127-135).  ids [B,S,F] (or [B,S]) -> [B,S,d]; returns (embeds, in_).
+    `embed_keep`: multipliers (0 or 1/(1-p)) of `embed_dropout` on the gathered rows [B,S,F,d] (:96-98); None = eval mode."""
     e = emb_w[input_ids]                      # nn.Embedding gather; pad row is a zero row
+    if embed_keep is not None:
+        e = e * torch.as_tensor(embed_keep).reshape(e.shape).to(e.dtype)
     if input_ids.dim() == 3:
         if gate_w is not None:
             e = torch.einsum("nsfd,fd->nsd", e, gate_w)
@@ -117,19 +120,29 @@ def attention(x, p, pre, mask4d, cos, sin, H, dh, keep=None):
 
 
 # --------------------------------------------------------------------------- K9  (row A4c)
-def mlp(x, p, pre):
+def mlp(x, p, pre, keep=None):
     """hf LlamaMLP.forward :174-176 with hidden_act="gelu" = exact erf GELU
-    (reference configs/model/base.yaml:21)."""
+    (reference configs/model/base.yaml:21).  `keep` = (act_keep [B,S,ff], out_keep [B,S,d]): the multipliers of the
+    reference's own MLP subclass used when mlp_pdrop > 0 (utils_graphgpt.py:69-80: mlp_act_dropout on act(gate)*up,
+    mlp_dropout on down_proj's output); None = eval mode."""
     g = Fnn.gelu(Fnn.linear(x, p[pre + "gate_proj.weight"]))
     u = Fnn.linear(x, p[pre + "up_proj.weight"])
-    return Fnn.linear(g * u, p[pre + "down_proj.weight"])
+    hgu = g * u
+    if keep is not None:
+        hgu = hgu * torch.as_tensor(keep[0]).reshape(hgu.shape).to(hgu.dtype)
+    out = Fnn.linear(hgu, p[pre + "down_proj.weight"])
+    if keep is not None:
+        out = out * torch.as_tensor(keep[1]).reshape(out.shape).to(out.dtype)
+    return out
 
 
-def backbone(spec, p: Dict[str, torch.Tensor], x, attention_mask, position_ids, collect=None, path_mult=None, attn_keep=None):
+def backbone(spec, p: Dict[str, torch.Tensor], x, attention_mask, position_ids, collect=None, path_mult=None, attn_keep=None,
+             mlp_keep=None):
     """hf LlamaModel.forward :367-418 / LlamaDecoderLayer.forward :295-325; LayerScale variant
     utils_graphgpt.LlamaDecoderLayer.forward (utils_graphgpt.py:107-173).  `path_mult(layer, which)` -> [B] tensor of
     DropPath multipliers (0 or 1/keep_prob per sample, utils_graphgpt.py:64-66 / BeitDropPath); None = eval mode.
-    `attn_keep(layer)` -> [B,H,S,S] attention-dropout multipliers of that layer (see attention)."""
+    `attn_keep(layer)` -> [B,H,S,S] attention-dropout multipliers of that layer (see attention); `mlp_keep(layer)` -> the
+    pair of MLP dropout multipliers (see mlp)."""
     B, S, d = x.shape
     if position_ids is None:
         position_ids = torch.arange(S)[None, :].expand(B, S)      # hf :389-392
@@ -146,7 +159,7 @@ def backbone(spec, p: Dict[str, torch.Tensor], x, attention_mask, position_ids, 
             a = a * path_mult(i, 0)[:, None, None].to(a.dtype)
         x = x + a
         h = rmsnorm(x, p[pre + "post_attention_layernorm.weight"], spec.rms_eps)
-        m = mlp(h, p, pre + "mlp.")
+        m = mlp(h, p, pre + "mlp.", keep=mlp_keep(i) if mlp_keep is not None else None)
         if spec.layer_scale_init > 0:
             m = p[pre + "lambda_2"] * m
         if path_mult is not None:
@@ -203,10 +216,10 @@ def smtp_head(spec, p, hidden, labels, sample_wgt=None):
 
 
 def pretrain_forward(spec, p, input_ids, attention_mask, labels=None, sample_wgt=None,
-                     position_ids=None, collect=None):
+                     position_ids=None, collect=None, embed_keep=None, mlp_keep=None):
     """`GraphGPTPretrainBase.forward` (modeling_pretrain.py:152-266), generative head only."""
-    x, _ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"))
-    hidden = backbone(spec, p, x, attention_mask, position_ids, collect)
+    x, _ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"), embed_keep=embed_keep)
+    hidden = backbone(spec, p, x, attention_mask, position_ids, collect, mlp_keep=mlp_keep)
     loss, logits = smtp_head(spec, p, hidden, labels, sample_wgt)
     return dict(head1_loss=loss, head1_logits=logits, hidden=hidden)
 
@@ -223,13 +236,13 @@ def auc_loss(y_pred, y_true, num_neg, idx):
 
 def task_forward(spec, p, input_ids, attention_mask, position_ids=None, task_labels=None,
                  sample_wgt=None, problem_type="single_label_classification", loss_type=None, path_mult=None, attn_keep=None,
-                 num_neg=1, auc_idx=None):
+                 num_neg=1, auc_idx=None, embed_keep=None, mlp_keep=None):
     """`GraphGPTTaskModel.forward` (modeling_finetune.py:236-326) + `calculate_task_loss`
     (:167-234) + `_get_sequence_len` (modeling_helpers.py:78-86); Linear score head, "last" pooling."""
     if input_ids.dim() == 3:
         input_ids = input_ids[:, :, : spec.stacked_feat]
-    x, in_ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"))
-    hidden = backbone(spec, p, x, attention_mask, position_ids, path_mult=path_mult, attn_keep=attn_keep)
+    x, in_ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"), embed_keep=embed_keep)
+    hidden = backbone(spec, p, x, attention_mask, position_ids, path_mult=path_mult, attn_keep=attn_keep, mlp_keep=mlp_keep)
     logits = Fnn.linear(hidden, p["score.weight"], p.get("score.bias"))
     B = hidden.shape[0]
     seq_len = (in_ != spec.pad_token_id).sum(-1) - 1

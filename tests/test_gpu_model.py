@@ -917,3 +917,86 @@ def test_auc_loss_matches_oracle_with_the_same_pairs():
     out2 = model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], position_ids=b["position_ids"],
                  task_labels=b["task_labels"])
     assert float(out2.task_loss.item()) != loss
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gated,layer_scale", [(False, 0.0), (True, 1.0)])
+def test_embed_and_mlp_dropouts_exact_mask(gated, layer_scale):
+    """embed_pdrop = 0.1, mlp_pdrop = 0.2 in training mode (modeling_helpers.py:96-98, utils_graphgpt.py:69-80; positions pinned
+    to the reference by tests/golden/pt_tiny_dropouts.npz through the oracle): the engine's counter-hash masks are regenerated
+    by the Python twin and handed to the oracle - loss and gradients (incl. the embedding table's, which sees a different mask
+    on every (cell, channel)) within the pre-train tolerances; evaluation mode is unaffected."""
+    from _util import spec_mod, weights_mod, synth
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    B, S, F, V = 4, 24, 13, 756
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=V, stacked_feat=F, next_n_token=F,
+                                   gated_agg=gated, layer_scale_init=layer_scale, mlp_pdrop=0.2, embed_pdrop=0.1)
+    state = weights_mod.make_state_dict(spec, seed=733, std=0.06, head_std=0.15)
+    batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=73)
+    b = tb(batch)
+    e = make_engine(spec, batch)
+    e.load_state_dict(state)
+    l_eval = float(run_forward(e, spec, b, "pt")[0])     # (the returned loss is a view of the engine's device scalar)
+    seed = 0x1234ABCD
+    e.set_dropout(0.0, 0.0, seed)
+    e.set_dropout_ex(0.1, 0.2)
+    loss = float(run_forward(e, spec, b, "pt")[0])
+    e.backward()
+    torch.cuda.synchronize()
+    d, ff = spec.hidden_size, spec.intermediate_size
+    ek = torch.from_numpy(M.elem_drop_keep(seed, "embed", 0, B * S * F, d, 0.1)).view(B, S, F, d)
+    mk = lambda i: (torch.from_numpy(M.elem_drop_keep(seed, "mlp_act", i, B * S, ff, 0.2)).view(B, S, ff),
+                    torch.from_numpy(M.elem_drop_keep(seed, "mlp_out", i, B * S, d, 0.2)).view(B, S, d))
+    assert abs(float((ek == 0).float().mean()) - 0.1) < 0.01 and abs(float((mk(1)[0] == 0).float().mean()) - 0.2) < 0.01
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32)
+    fn = lambda q: O.pretrain_forward(spec, q, b["input_ids"], b["attention_mask"], b["labels"], embed_keep=ek, mlp_keep=mk)
+    out, grads = O.loss_and_grads(fn, p, "head1_loss")
+    want = out["head1_loss"].item()
+    name = f"pt_tiny_dropouts_gated{int(gated)}_ls{int(layer_scale > 0)}"
+    record_error(name, "loss_rel_vs_oracle_same_masks", abs(float(loss) - want) / abs(want), 2e-3)
+    assert abs(float(loss) - want) <= 2e-3 * abs(want), (float(loss), want)
+    assert abs(float(loss) - float(l_eval)) > 1e-3 * abs(want)        # the masks are really applied
+    got = e.grads()
+    gmax = max(float(g.norm()) for g in grads.values())
+    keys = ["model.embed_tokens.weight", "model.layers.0.mlp.down_proj.weight", "model.layers.1.mlp.gate_proj.weight",
+            "model.layers.0.mlp.up_proj.weight", "model.layers.0.self_attn.q_proj.weight", "lm_head.weight"]
+    if gated:
+        keys.append("stacked_feat_agg.weight")
+    if layer_scale > 0:
+        keys.append("model.layers.1.lambda_2")
+    for k in keys:
+        w = grads[k].numpy()
+        err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        record_error(name, "grad_rel_l2 " + k, err, 6e-2)
+        assert err < 6e-2, f"{k}: {err}"
+    # evaluation mode again: same loss as before the training step
+    e.set_dropout(0.0, 0.0, 0)
+    e.set_dropout_ex(0.0, 0.0)
+    assert float(run_forward(e, spec, b, "pt")[0]) == l_eval
+
+
+@pytest.mark.gpu
+def test_model_class_applies_embed_and_mlp_dropout_only_in_training_mode():
+    """GraphGPTConfig(embed_pdrop, mlp_pdrop) through the drop-in class: train() draws fresh masks every call (nn.Dropout),
+    eval() is deterministic and equal to the dropout-free model."""
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    from _util import synth
+    kw = dict(vocab_size=300, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+              max_position_embeddings=64, causal_attention=False, stacked_feat=4, next_n_token=4)
+    batch = synth.make_pretrain_batch(B=4, S=24, F=4, V=300, seed=3)
+    b = {k: torch.from_numpy(v) for k, v in batch.items()}
+    call = lambda m: float(m(input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=b["labels"]).head1_loss.item())
+    plain = M.GraphGPTPretrainBase(M.GraphGPTConfig(**kw), seed=5)
+    drop = M.GraphGPTPretrainBase(M.GraphGPTConfig(embed_pdrop=0.1, mlp_pdrop=0.1, **kw), seed=5)
+    plain.eval(); drop.eval()
+    ref = call(plain)
+    ev = call(drop)
+    # (with mlp_pdrop in the config the residual adds run as their own kernels: the branch output is rounded to bf16 before the
+    # add, as in the reference's bf16 module, where the GEMM-epilogue add of the plain model adds the fp32 accumulator)
+    assert call(drop) == ev and abs(ev - ref) <= 2e-5 * abs(ref)
+    drop.train()
+    a, c = call(drop), call(drop)
+    assert abs(a - ev) > 2e-5 * abs(ref) and abs(c - ev) > 2e-5 * abs(ref) and a != c     # (loss ~ ln V at this init: small but real shifts)
+    drop.eval()
+    assert call(drop) == ev

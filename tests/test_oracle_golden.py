@@ -277,3 +277,36 @@ def test_auc_pairs_twin_is_a_balanced_permutation_draw():
     cnt = np.bincount(idx, minlength=N)
     assert cnt.min() >= (P * 3) // N and cnt.max() <= -(-(P * 3) // N)
     assert not np.array_equal(idx, m.auc_pairs(y, 3, seed=6))
+
+
+def test_oracle_embed_and_mlp_dropouts_match_reference():
+    """embed_pdrop / mlp_pdrop in train() mode (modeling_helpers.py:96-98, utils_graphgpt.py:69-80): fed with the keep masks the
+    reference's dropout calls drew (recorded, tools/make_golden.py:dropout_fixture), the restatement reproduces the reference's
+    loss and gradients - which pins WHERE each dropout sits."""
+    from _util import GOLDEN, spec_mod, weights_mod
+    z = np.load(os.path.join(GOLDEN, "pt_tiny_dropouts.npz"))
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=756, stacked_feat=13, next_n_token=13)
+    assert [int(x) for x in z["meta_spec"]] == list(spec.as_c_ints())
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    pe, pm = [float(x) for x in z["p"]]
+    B, S = b["input_ids"].shape[:2]
+
+    def unpack(key, shape, p):
+        n = int(np.prod(shape))
+        return torch.from_numpy(np.unpackbits(z[key])[:n].reshape(shape).astype(np.float32) / (1.0 - p))
+    ek = unpack("embed_keep", tuple(int(x) for x in z["embed_shape"]), pe)
+    mk = lambda i: (unpack(f"act_keep_{i}", (B, S, spec.intermediate_size), pm), unpack(f"out_keep_{i}", (B, S, spec.hidden_size), pm))
+    p = O.to_params(state, torch.float32)
+    fn = lambda q: O.pretrain_forward(spec, q, b["input_ids"], b["attention_mask"], b["labels"], embed_keep=ek, mlp_keep=mk)
+    out, grads = O.loss_and_grads(fn, p, "head1_loss")
+    assert abs(out["head1_loss"].item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    for k, want in (("model.embed_tokens.weight", z["grad_embed"]), ("model.layers.0.mlp.down_proj.weight", z["grad_l0_down"]),
+                    ("model.layers.1.mlp.gate_proj.weight", z["grad_l1_gate"])):
+        g = grads[k].numpy()
+        assert np.linalg.norm(g - want) <= 2e-4 * np.linalg.norm(want), k
+    gn = np.array([float(grads[str(n)].norm()) for n in z["names"]])
+    np.testing.assert_allclose(gn, z["grad_norms"], rtol=5e-4, atol=1e-7)
+    # and the masks matter: eval-mode arithmetic gives another loss
+    assert abs(O.pretrain_forward(spec, p, b["input_ids"], b["attention_mask"], b["labels"])["head1_loss"].item() - float(z["loss"])) > 1e-3

@@ -558,6 +558,59 @@ def auc_fixture():
     print(f"ft_tiny_auc written: loss {res['loss']:.6f}, P {P} N {N}, pairs {P * num_neg}")
 
 
+def dropout_fixture():
+    """Training-mode dropouts of the reference outside attention: embed_pdrop (modeling_helpers.py:96-98) and mlp_pdrop (the
+    reference's own LlamaMLP, utils_graphgpt.py:69-80).  The reference runs in train() mode with torch.nn.functional.dropout
+    replaced by a recorder that draws the keep mask itself and stores it (call order: embedding, then per layer the gated
+    activations and the down projection's output); a restatement fed with the stored masks must match loss and gradients."""
+    import torch.nn.functional as F
+    PT, FT, Cfg = import_reference()
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=756, stacked_feat=13, next_n_token=13)
+    state = weights_mod.make_state_dict(spec, seed=733, std=0.06, head_std=0.15)
+    batch = synth.make_pretrain_batch(B=4, S=24, F=13, V=756, seed=73)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    model = PT(ref_config(Cfg, spec, embed_pdrop=0.1, mlp_pdrop=0.2))
+    load_weights(model, state)
+    model.train()
+    rec = []
+    gen = torch.Generator().manual_seed(97531)
+    orig = F.dropout
+
+    def recording_dropout(input, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return input
+        keep = (torch.rand(input.shape, generator=gen) >= p)
+        rec.append((tuple(input.shape), float(p), keep.numpy().copy()))
+        return input * keep.to(input.dtype) / (1.0 - p)
+
+    F.dropout = recording_dropout
+    try:
+        o = model(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"], labels=tb["labels"], inputs_raw_embeds=None)
+        model.zero_grad()
+        o.head1_loss.backward()
+    finally:
+        F.dropout = orig
+    L_ = spec.num_layers
+    assert len(rec) == 1 + 2 * L_, [r[:2] for r in rec]
+    assert rec[0][0] == (4, 24, 13, spec.hidden_size) and rec[0][1] == 0.1
+    names = list(state.keys())
+    g = dict(model.named_parameters())
+    res = {"loss": np.float64(o.head1_loss.item()), "grad_norms": grad_norms(model, names), "names": np.array(names),
+           "grad_embed": g["model.embed_tokens.weight"].grad.numpy().copy(),
+           "grad_l0_down": g["model.layers.0.mlp.down_proj.weight"].grad.numpy().copy(),
+           "grad_l1_gate": g["model.layers.1.mlp.gate_proj.weight"].grad.numpy().copy(),
+           "embed_keep": np.packbits(rec[0][2]), "embed_shape": np.array(rec[0][0]),
+           "p": np.array([0.1, 0.2]), "meta_spec": np.array(spec.as_c_ints(), np.int64), "meta_init": np.array([733, 0.06, 0.15])}
+    for i in range(L_):
+        assert rec[1 + 2 * i][0] == (4, 24, spec.intermediate_size) and rec[2 + 2 * i][0] == (4, 24, spec.hidden_size)
+        res[f"act_keep_{i}"] = np.packbits(rec[1 + 2 * i][2])
+        res[f"out_keep_{i}"] = np.packbits(rec[2 + 2 * i][2])
+    for k, v in batch.items():
+        res["in_" + k] = v
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "pt_tiny_dropouts.npz"), **res)
+    print(f"pt_tiny_dropouts written: loss {res['loss']:.6f}, {len(rec)} dropout calls recorded")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -581,6 +634,8 @@ def main():
         ckpt_fixture()
     if not only or "ft_tiny_auc" in only:
         auc_fixture()
+    if not only or "pt_tiny_dropouts" in only:
+        dropout_fixture()
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ class GgetConfig(C.Structure):
                                    "stacked_feat", "next_n_token", "gated_agg", "causal", "max_position", "num_labels",
                                    "score_bias", "pad_token_id")] + \
                [("rms_eps", f32), ("rope_theta", f32), ("layer_scale_init", f32), ("max_tokens", i32), ("max_batch", i32),
-                ("path_pdrop", f32), ("mlp_pdrop", f32)]
+                ("path_pdrop", f32), ("mlp_pdrop", f32), ("head_mlp_layers", i32), ("head_mlp", i32 * 4)]
 
 
 class GgetSizes(C.Structure):
@@ -82,7 +82,7 @@ SIGNATURES = {
     "gget_op_ranges_from_mask3d": (i32, [vp, vp, vp, i32, i32, vp]),
     "gget_set_dropout": (i32, [vp, f32, f32, C.c_uint32]),
     "gget_set_auc": (i32, [vp, i32, C.c_uint32]),
-    "gget_set_dropout_ex": (i32, [vp, f32, f32]),
+    "gget_set_dropout_ex": (i32, [vp, f32, f32, f32]),
     "gget_op_gateup_geglu": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "gget_op_down_dgrad_geglu": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "gget_op_geglu_fwd": (i32, [vp, vp, i32, i32, vp]),

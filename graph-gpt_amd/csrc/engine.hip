@@ -63,6 +63,10 @@ struct Plan {
   uint64_t emb = 0, emb32 = 0, gate = 0, gate32 = 0, normf = 0, normf32 = 0;
   uint64_t ntp = 0, lm = 0, lm32 = 0, score = 0, score32 = 0, sbias = 0, sbias32 = 0;
   bool has_gate = false, has_ntp = false, has_ls = false;
+  // MLP score head (config.head_mlp_layers > 0): n_lin = layers + 1 Linears of widths head_dim[0] = d, ..., head_dim[n_lin] = num_labels
+  int n_lin = 0;
+  int head_dim[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t head_w[5] = {0}, head_w32[5] = {0}, head_b[5] = {0}, head_b32[5] = {0};
   bool has_res = false;  // residual adds run as their own kernels (LayerScale and/or DropPath) instead of GEMM epilogues
 };
 
@@ -125,8 +129,20 @@ Plan make_plan(const gget_config_t& c) {
     pl.lm_pad_count = (uint64_t)(Vp - V) * d;
     pl.n_params += align_up(pl.lm_pad_count, 128);
   } else {
-    add_param(pl, "score.weight", c.num_labels, d, (int)L, true, &pl.score, &pl.score32);
-    if (c.score_bias) add_param(pl, "score.bias", c.num_labels, 0, (int)L, true, &pl.sbias, &pl.sbias32);
+    if (c.head_mlp_layers > 0) {   // `MLP` head (src/utils/modules_utils.py:8-34): state-dict keys score.mlp_modules.<i>.weight / .bias
+      pl.n_lin = c.head_mlp_layers + 1;
+      pl.head_dim[0] = (int)d;
+      for (int i = 0; i < c.head_mlp_layers; ++i) pl.head_dim[i + 1] = c.head_mlp[i];
+      pl.head_dim[pl.n_lin] = c.num_labels;
+      for (int i = 0; i < pl.n_lin; ++i) {
+        const std::string p = "score.mlp_modules." + std::to_string(i) + ".";
+        add_param(pl, p + "weight", pl.head_dim[i + 1], pl.head_dim[i], (int)L, true, &pl.head_w[i], &pl.head_w32[i]);
+        if (c.score_bias) add_param(pl, p + "bias", pl.head_dim[i + 1], 0, (int)L, true, &pl.head_b[i], &pl.head_b32[i]);
+      }
+    } else {
+      add_param(pl, "score.weight", c.num_labels, d, (int)L, true, &pl.score, &pl.score32);
+      if (c.score_bias) add_param(pl, "score.bias", c.num_labels, 0, (int)L, true, &pl.sbias, &pl.sbias32);
+    }
   }
   return pl;
 }
@@ -156,6 +172,7 @@ struct Ws {
   uint64_t cnt, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
   // task head
   uint64_t tlogits, tdlogits, pooled_h, auc_lists;
+  uint64_t head_x[6] = {0}, head_a[5] = {0}, head_d[2] = {0};   // MLP head: layer inputs / activations (bf16), fp32 gradient ping-pong
   uint64_t total;
 };
 
@@ -238,6 +255,15 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
     w.tdlogits = b.take(Bm * c.num_labels * 4);
     w.auc_lists = b.take(Bm * 2 * 4);
     w.pooled_h = b.take(Bm * d * 2);
+    if (pl.n_lin > 0) {
+      uint64_t dmax = 0;
+      for (int i = 0; i <= pl.n_lin; ++i) dmax = std::max<uint64_t>(dmax, (uint64_t)pl.head_dim[i]);
+      w.head_x[0] = w.pooled_h;
+      for (int i = 1; i <= pl.n_lin; ++i) w.head_x[i] = b.take(Bm * pl.head_dim[i] * 2);
+      for (int i = 0; i < pl.n_lin; ++i) w.head_a[i] = b.take(Bm * pl.head_dim[i] * 2);
+      w.head_d[0] = b.take(Bm * dmax * 4);
+      w.head_d[1] = b.take(Bm * dmax * 4);
+    }
   }
   w.total = b.off;
   return w;
@@ -254,6 +280,8 @@ int check_cfg(const gget_config_t* c) {
   GGET_REQUIRE(c->max_tokens > 0 && c->max_batch > 0 && c->max_position > 0, "bad capacities");
   if (c->kind == GGET_KIND_PRETRAIN) GGET_REQUIRE(c->next_n_token >= 1, "next_n_token must be >= 1");
   else GGET_REQUIRE(c->num_labels >= 1, "num_labels must be >= 1");
+  GGET_REQUIRE(c->head_mlp_layers >= 0 && c->head_mlp_layers <= 4, "the MLP score head holds at most 4 hidden layers");
+  for (int i = 0; i < c->head_mlp_layers; ++i) GGET_REQUIRE(c->head_mlp[i] > 0, "bad MLP head width");
   return 0;
 }
 
@@ -289,6 +317,8 @@ struct gget_engine {
   unsigned attn_drop_seed = 0;
   float embed_drop_p = 0.f;       // embed_dropout / mlp dropouts of the NEXT forward (training mode); 0 = off
   float mlp_drop_p = 0.f;
+  float head_drop_p = 0.f;        // dropout inside the MLP score head
+  ElemDropArg head_drop() const { return elem_drop(head_drop_p, attn_drop_seed ^ 0x2545F491u); }
   static ElemDropArg elem_drop(float p, unsigned seed) {
     if (p <= 0.f) return ElemDropArg{0, 1.f, 0};
     return ElemDropArg{(unsigned)(p * 16777216.0f), 1.0f / (1.0f - p), seed};
@@ -444,9 +474,11 @@ extern "C" int gget_bucket_range(gget_handle_t h, int bucket, uint64_t* offset, 
   return 0;
 }
 
-extern "C" int gget_set_dropout_ex(gget_handle_t h, float embed_p, float mlp_p) {
+extern "C" int gget_set_dropout_ex(gget_handle_t h, float embed_p, float mlp_p, float head_p) {
   GGET_REQUIRE(h != nullptr, "null handle");
-  GGET_REQUIRE(embed_p >= 0.f && embed_p < 1.f && mlp_p >= 0.f && mlp_p < 1.f, "dropout probabilities must be in [0, 1)");
+  GGET_REQUIRE(embed_p >= 0.f && embed_p < 1.f && mlp_p >= 0.f && mlp_p < 1.f && head_p >= 0.f && head_p < 1.f,
+               "dropout probabilities must be in [0, 1)");
+  h->head_drop_p = head_p;
   GGET_REQUIRE(mlp_p == 0.f || h->cfg.mlp_pdrop > 0.f, "MLP dropout needs a handle created with config.mlp_pdrop > 0");
   h->embed_drop_p = embed_p;
   h->mlp_drop_p = mlp_p;
@@ -761,8 +793,16 @@ extern "C" int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, 
   const Ws& w = h->ws;
   const int d = c.hidden_size, C = c.num_labels;
   float* lg = h->wsp<float>(w.tlogits);
-  if (int e = k_score_fwd(h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.pool_row), h->P + h->plan.score,
-                          c.score_bias ? h->P + h->plan.sbias : nullptr, lg, h->wsp<bf16_t>(w.pooled_h), B, C, d, st))
+  if (h->plan.n_lin > 0) {
+    const Plan& pl = h->plan;
+    if (int e = k_pool_rows(h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.pool_row), h->wsp<bf16_t>(w.pooled_h), B, d, st)) return e;
+    for (int i = 0; i < pl.n_lin; ++i)
+      if (int e = k_head_linear_fwd(h->wsp<bf16_t>(w.head_x[i]), h->wsp<bf16_t>(w.head_a[i]), h->P + pl.head_w[i],
+                                    c.score_bias ? h->P + pl.head_b[i] : nullptr, h->wsp<bf16_t>(w.head_x[i + 1]),
+                                    i + 1 == pl.n_lin ? lg : nullptr, B, pl.head_dim[i], pl.head_dim[i + 1], i, h->head_drop(), st))
+        return e;
+  } else if (int e = k_score_fwd(h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.pool_row), h->P + h->plan.score,
+                                 c.score_bias ? h->P + h->plan.sbias : nullptr, lg, h->wsp<bf16_t>(w.pooled_h), B, C, d, st))
     return e;
   if (task_logits_dev) GGET_HIP_CHECK(hipMemcpyAsync(task_logits_dev, lg, (size_t)B * C * 4, hipMemcpyDeviceToDevice, st));
   if (task_hidden_dev)
@@ -942,6 +982,18 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
         return e;
     }
     if (int e = k_gather_rows(h->wsp<bf16_t>(w.dHm), h->wsp<int32_t>(w.row_idx), counts, dhid, T, d, 1, st)) return e;
+  } else if (h->plan.n_lin > 0) {
+    const Plan& pl = h->plan;
+    const float* dy = h->wsp<float>(w.tdlogits);
+    for (int i = pl.n_lin - 1; i >= 0; --i) {
+      float* dx = h->wsp<float>(w.head_d[i & 1]);
+      if (int e = k_head_linear_bwd(dy, h->wsp<bf16_t>(w.head_x[i]), h->wsp<bf16_t>(w.head_a[i]), h->P + pl.head_w[i],
+                                    s32 + pl.head_w32[i], c.score_bias ? s32 + pl.head_b32[i] : nullptr, dx, h->B, pl.head_dim[i],
+                                    pl.head_dim[i + 1], i, h->head_drop(), st))
+        return e;
+      dy = dx;
+    }
+    if (int e = k_scatter_rows_f32(dy, h->wsp<int32_t>(w.pool_row), dhid, h->B, d, st)) return e;
   } else {
     if (int e = k_score_bwd(h->wsp<float>(w.tdlogits), h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.pool_row),
                             h->P + h->plan.score, s32 + h->plan.score32, c.score_bias ? s32 + h->plan.sbias32 : nullptr, dhid,

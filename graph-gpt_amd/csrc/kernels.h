@@ -49,6 +49,12 @@ int k_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const int32_
                  int mean_over_rows, float* loss_out, hipStream_t st);
 int k_score_fwd(const void* hidden, const int32_t* pool_row, const void* w, const void* bias, float* logits,
                 void* pooled_h, int B, int C, int d, hipStream_t st);
+int k_pool_rows(const void* hidden, const int32_t* pool_row, void* out, int B, int d, hipStream_t st);
+int k_head_linear_fwd(const void* x, void* a, const void* w, const void* bias, void* y, float* y32, int B, int Din, int Dout,
+                      int layer, ElemDropArg E, hipStream_t st);
+int k_head_linear_bwd(const float* dy, const void* x, const void* a, const void* w, float* dw, float* dbias, float* dx, int B,
+                      int Din, int Dout, int layer, ElemDropArg E, hipStream_t st);
+int k_scatter_rows_f32(const float* src, const int32_t* pool_row, void* dhidden, int B, int d, hipStream_t st);
 int k_auc_loss(const float* logits, const int64_t* labels, int B, int C, int num_neg, unsigned seed, float* loss_out,
                float* dlogits, int32_t* lists, hipStream_t st);
 int k_task_loss(const float* logits, const void* labels, const float* sample_wgt, int problem, int B, int C,

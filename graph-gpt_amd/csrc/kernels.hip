@@ -814,6 +814,72 @@ __global__ void __launch_bounds__(kBlock) task_loss_kernel(const float* __restri
   if (threadIdx.x == 0) loss_out[0] = red[0];
 }
 
+// MLP score head (src/utils/modules_utils.py:8-34, chosen by `len(config.mlp) > 0` at modeling_finetune.py:88-97), on the pooled
+// rows only: for every Linear i:  x = Linear_i(dropout(act(x))) - the activation comes BEFORE each linear, the first included.
+// Row counts are batch sizes: plain kernels.  bf16 at the points where the reference's bf16 module rounds.
+#define GGET_DROP_STREAM_HEAD 51u
+__global__ void __launch_bounds__(kBlock) pool_rows_kernel(const bf16_t* __restrict__ hidden, const int32_t* __restrict__ pool_row,
+                                                           bf16_t* __restrict__ out, int B, int d) {
+  const int b = blockIdx.x;
+  for (int j = threadIdx.x; j < d; j += kBlock) out[(size_t)b * d + j] = hidden[(size_t)pool_row[b] * d + j];
+}
+__global__ void __launch_bounds__(kBlock) head_act_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ a, int B, int D,
+                                                          unsigned layer, ElemDropArg E) {
+  const long n = (long)B * D;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+    const float g = bf2f(f2bf(gelu_erf(bf2f(x[i]))));
+    a[i] = f2bf(g * elem_drop_mul(E, GGET_DROP_STREAM_HEAD + layer, (unsigned)(i / D), (unsigned)(i % D)));
+  }
+}
+// y[b,o] = bf16(a[b,:] . w[o,:] + bias[o]); one 64-thread block per (b, o); y32 (optional) = the same value as fp32
+__global__ void __launch_bounds__(64) head_linear_fwd_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ w,
+                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ y,
+                                                             float* __restrict__ y32, int B, int Din, int Dout) {
+  const int b = blockIdx.x / Dout, o = blockIdx.x % Dout;
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < Din; j += 64) acc += bf2f(a[(size_t)b * Din + j]) * bf2f(w[(size_t)o * Din + j]);
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) {
+    const bf16_t r = f2bf(acc + (bias ? bf2f(bias[o]) : 0.f));
+    y[(size_t)b * Dout + o] = r;
+    if (y32) y32[(size_t)b * Dout + o] = bf2f(r);
+  }
+}
+// backward of one Linear + the activation in front of it: blocks [0, B): dx[b,:] = (dy[b,:] W) * keep * gelu'(x[b,:]);
+// blocks [B, B + Dout): dW[o,:] += sum_b dy[b,o] a[b,:], dbias[o] += sum_b dy[b,o]
+__global__ void __launch_bounds__(kBlock) head_linear_bwd_kernel(const float* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                 const bf16_t* __restrict__ a, const bf16_t* __restrict__ w,
+                                                                 float* __restrict__ dw, float* __restrict__ dbias,
+                                                                 float* __restrict__ dx, int B, int Din, int Dout, unsigned layer,
+                                                                 ElemDropArg E) {
+  if ((int)blockIdx.x < B) {
+    const int b = blockIdx.x;
+    for (int j = threadIdx.x; j < Din; j += kBlock) {
+      float s = 0.f;
+      for (int o = 0; o < Dout; ++o) s += dy[(size_t)b * Dout + o] * bf2f(w[(size_t)o * Din + j]);
+      const float keep = elem_drop_mul(E, GGET_DROP_STREAM_HEAD + layer, (unsigned)b, (unsigned)j);
+      dx[(size_t)b * Din + j] = s * keep * gelu_erf_grad(bf2f(x[(size_t)b * Din + j]));
+    }
+  } else {
+    const int o = blockIdx.x - B;
+    for (int j = threadIdx.x; j < Din; j += kBlock) {
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s += dy[(size_t)b * Dout + o] * bf2f(a[(size_t)b * Din + j]);
+      dw[(size_t)o * Din + j] += s;
+    }
+    if (threadIdx.x == 0 && dbias) {
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s += dy[(size_t)b * Dout + o];
+      dbias[o] += s;
+    }
+  }
+}
+__global__ void __launch_bounds__(kBlock) scatter_rows_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ pool_row,
+                                                                  bf16_t* __restrict__ dhidden, int B, int d) {
+  const int b = blockIdx.x;
+  for (int j = threadIdx.x; j < d; j += kBlock) dhidden[(size_t)pool_row[b] * d + j] = f2bf(src[(size_t)b * d + j]);
+}
+
 // backward of the score head: dW[c,:] += sum_b dl[b,c] h[row_b,:], dbias[c] += sum_b dl[b,c],
 // dhidden[row_b,:] = sum_c dl[b,c] W[c,:] (dhidden pre-zeroed).  grid = B + C blocks.
 __global__ void __launch_bounds__(kBlock) score_bwd_kernel(const float* __restrict__ dlogits, const bf16_t* __restrict__ hidden,
@@ -1547,6 +1613,33 @@ int k_task_loss(const float* logits, const void* labels, const float* sample_wgt
                 float* loss_out, float* dlogits, hipStream_t st) {
   hipLaunchKernelGGL(task_loss_kernel, dim3(1), dim3(kBlock), 0, st, logits, labels, sample_wgt, problem, B, C, loss_out,
                      dlogits);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_pool_rows(const void* hidden, const int32_t* pool_row, void* out, int B, int d, hipStream_t st) {
+  hipLaunchKernelGGL(pool_rows_kernel, dim3(B), dim3(kBlock), 0, st, (const bf16_t*)hidden, pool_row, (bf16_t*)out, B, d);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+int k_head_linear_fwd(const void* x, void* a, const void* w, const void* bias, void* y, float* y32, int B, int Din, int Dout,
+                      int layer, ElemDropArg E, hipStream_t st) {
+  hipLaunchKernelGGL(head_act_kernel, dim3(grid_for((long)B * Din, kBlock, 1024)), dim3(kBlock), 0, st, (const bf16_t*)x, (bf16_t*)a, B,
+                     Din, (unsigned)layer, E);
+  hipLaunchKernelGGL(head_linear_fwd_kernel, dim3(B * Dout), dim3(64), 0, st, (const bf16_t*)a, (const bf16_t*)w, (const bf16_t*)bias,
+                     (bf16_t*)y, y32, B, Din, Dout);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+int k_head_linear_bwd(const float* dy, const void* x, const void* a, const void* w, float* dw, float* dbias, float* dx, int B,
+                      int Din, int Dout, int layer, ElemDropArg E, hipStream_t st) {
+  hipLaunchKernelGGL(head_linear_bwd_kernel, dim3(B + Dout), dim3(kBlock), 0, st, dy, (const bf16_t*)x, (const bf16_t*)a,
+                     (const bf16_t*)w, dw, dbias, dx, B, Din, Dout, (unsigned)layer, E);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+int k_scatter_rows_f32(const float* src, const int32_t* pool_row, void* dhidden, int B, int d, hipStream_t st) {
+  hipLaunchKernelGGL(scatter_rows_f32_kernel, dim3(B), dim3(kBlock), 0, st, src, pool_row, (bf16_t*)dhidden, B, d);
   GGET_LAUNCH_CHECK();
   return 0;
 }

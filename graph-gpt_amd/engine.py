@@ -47,6 +47,11 @@ class Engine:
         cfg.max_tokens, cfg.max_batch = int(max_tokens), int(max_batch)
         cfg.path_pdrop = float(getattr(spec, "path_pdrop", 0.0))
         cfg.mlp_pdrop = float(getattr(spec, "mlp_pdrop", 0.0))
+        hm = [int(x) for x in getattr(spec, "head_mlp", ())]
+        assert len(hm) <= 4, "the MLP score head holds at most 4 hidden layers"
+        cfg.head_mlp_layers = len(hm)
+        for i, x in enumerate(hm):
+            cfg.head_mlp[i] = x
         self.cfg = cfg
         sz = L.GgetSizes()
         L.check(self.lib.gget_query_sizes(C.byref(cfg), C.byref(sz)))
@@ -183,9 +188,10 @@ class Engine:
         """Attention dropout / stochastic depth for the NEXT forward+backward (training mode); zeros = eval."""
         L.check(self.lib.gget_set_dropout(self.h, float(attention_p), float(path_p), int(seed) & 0xFFFFFFFF))
 
-    def set_dropout_ex(self, embed_p: float = 0.0, mlp_p: float = 0.0):
-        """Embedding dropout and the two MLP dropouts for the NEXT forward+backward (masks keyed by set_dropout's seed)."""
-        L.check(self.lib.gget_set_dropout_ex(self.h, float(embed_p), float(mlp_p)))
+    def set_dropout_ex(self, embed_p: float = 0.0, mlp_p: float = 0.0, head_p: float = 0.0):
+        """Embedding dropout, the two MLP dropouts and the MLP score head's dropout for the NEXT forward+backward (masks keyed
+        by set_dropout's seed)."""
+        L.check(self.lib.gget_set_dropout_ex(self.h, float(embed_p), float(mlp_p), float(head_p)))
 
     def set_auc(self, num_neg: int = 1, seed: int = 0):
         """Negatives per positive and the sampling seed of the NEXT forward_task(problem=PROBLEM_AUC)."""

@@ -76,9 +76,8 @@ class GraphGPTConfig:
         need(not self.use_discriminative and self.use_generative, "contrastive (pretrain-cl) head")
         need(self.focal_gamma == 0, "focal loss")
         need(self.rope_range == 0, "rope_range rescaling")
-        need(len(self.mlp) == 0, "MLP score head")
+        need(len(self.mlp) <= 4, "an MLP score head with more than 4 hidden layers")
         need(self.pooling_method == "last", "pooling other than 'last'")
-        need(self.dropout == 0, "dropout inside an MLP score head")
         return ModelSpec(kind=kind, vocab_size=self.vocab_size, hidden_size=self.hidden_size,
                          intermediate_size=self.intermediate_size, num_layers=self.num_hidden_layers,
                          num_heads=self.num_attention_heads, head_dim=64, stacked_feat=self.stacked_feat,
@@ -88,7 +87,9 @@ class GraphGPTConfig:
                          layer_scale_init=float(self.layer_scale_init_value), num_labels=self.num_labels,
                          score_bias=self.problem_type == "regression", pad_token_id=self.pad_token_id,
                          path_pdrop=float(self.path_pdrop), mlp_pdrop=float(self.mlp_pdrop),
-                         embed_pdrop=float(self.embed_pdrop))
+                         embed_pdrop=float(self.embed_pdrop),
+                         head_mlp=tuple(int(x) for x in self.mlp) if kind == KIND_TASK else (),
+                         head_pdrop=float(self.dropout) if kind == KIND_TASK else 0.0)
 
     def to_dict(self) -> Dict[str, Any]:
         return {k: v for k, v in self.__dict__.items() if not k.startswith("_")}
@@ -276,7 +277,8 @@ class _GgetModel(nn.Module):
         # embed_dropout (modeling_helpers.py:96-98) and the MLP dropouts (utils_graphgpt.py:69-80): nn.Dropout modules, same rule
         pe = float(self.config.embed_pdrop) if self.training else 0.0
         pm = float(self.config.mlp_pdrop) if self.training else 0.0
-        if p > 0 or pp > 0 or pe > 0 or pm > 0:
+        ph = float(self.config.dropout) if (self.training and self.kind == KIND_TASK and len(self.config.mlp) > 0) else 0.0
+        if p > 0 or pp > 0 or pe > 0 or pm > 0 or ph > 0:
             self._drop_step += 1
             rank = int(os.environ.get("RANK", "0"))
             seed = (self.dropout_seed * 0x9E3779B1 + self._drop_step * 0x85EBCA6B + rank * 0xC2B2AE35) & 0xFFFFFFFF
@@ -284,7 +286,7 @@ class _GgetModel(nn.Module):
             self.last_dropout_seed = seed
         else:
             e.set_dropout(0.0, 0.0, 0)
-        e.set_dropout_ex(pe, pm)
+        e.set_dropout_ex(pe, pm, ph)
         return e
 
     def _autograd_backward(self, g):
@@ -410,14 +412,14 @@ class GraphGPTTaskModel(_GgetModel):
 
 def elem_drop_keep(seed: int, which: str, layer: int, rows: int, cols: int, p: float):
     """Python twin of the element dropouts (csrc/common.h:elem_drop_mul): the keep multiplier (0 or 1/(1-p)) of every element
-    of a [rows, cols] tensor.  which = "embed" (rows = B*S*F cells), "mlp_act" ([T, ff]) or "mlp_out" ([T, d]); `seed` is the
-    seed handed to set_dropout; `layer` is ignored for "embed"."""
+    of a [rows, cols] tensor.  which = "embed" (rows = B*S*F cells), "mlp_act" ([T, ff]), "mlp_out" ([T, d]) or "head" (input of
+    Linear `layer` of the MLP score head, [B, width]); `seed` is the seed handed to set_dropout; `layer` is ignored for "embed"."""
     import numpy as np
     from .smtp import _rng24
     if p <= 0:
         return np.ones((rows, cols), np.float32)
-    stream = {"embed": 48, "mlp_act": 49, "mlp_out": 50}[which]
-    s = (seed ^ 0x5BD1E995) if which == "embed" else (seed + 0x7F4A7C15 * (layer + 1))
+    stream = {"embed": 48, "mlp_act": 49, "mlp_out": 50, "head": 51 + layer}[which]
+    s = (seed ^ 0x5BD1E995) if which == "embed" else ((seed ^ 0x2545F491) if which == "head" else (seed + 0x7F4A7C15 * (layer + 1)))
     s &= 0xFFFFFFFF
     thresh = int(np.float32(p) * np.float32(16777216.0))
     a = np.arange(rows, dtype=np.uint64)[:, None]

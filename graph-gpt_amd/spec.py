@@ -39,6 +39,8 @@ class ModelSpec:
     path_pdrop: float = 0.0         # stochastic depth (DropPath) rate of the last layer; 0 = feature not allocated
     mlp_pdrop: float = 0.0          # MLP dropouts (utils_graphgpt.py:69-80); 0 = feature not allocated
     embed_pdrop: float = 0.0        # dropout on the gathered token embeddings (modeling_helpers.py:96-98)
+    head_mlp: Tuple[int, ...] = ()  # fine-tune: hidden widths of the `MLP` score head (config.mlp, src/utils/modules_utils.py:8-34); () = Linear
+    head_pdrop: float = 0.0         # dropout inside that head (config.dropout)
 
     def __post_init__(self):
         assert self.hidden_size == self.num_heads * self.head_dim, "no GQA / odd head dims on this path"
@@ -71,6 +73,12 @@ class ModelSpec:
             if self.next_n_token > 1:
                 t["n_token_proj.weight"] = (self.next_n_token * d, d)
             t["lm_head.weight"] = (V, d)
+        elif len(self.head_mlp) > 0:
+            dims = [d] + [int(x) for x in self.head_mlp] + [self.num_labels]
+            for i in range(len(dims) - 1):
+                t[f"score.mlp_modules.{i}.weight"] = (dims[i + 1], dims[i])
+                if self.score_bias:
+                    t[f"score.mlp_modules.{i}.bias"] = (dims[i + 1],)
         else:
             t["score.weight"] = (self.num_labels, d)
             if self.score_bias:

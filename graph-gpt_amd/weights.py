@@ -29,11 +29,12 @@ def make_state_dict(spec: ModelSpec, seed: int = 0, std: float = 0.02, head_std:
         elif name == "stacked_feat_agg.weight":
             bound = 1.0 / np.sqrt(shape[1])
             w = rng.uniform(-bound, bound, size=shape).astype(np.float32)
-        elif name == "score.bias":
+        elif name == "score.bias" or (name.startswith("score.mlp_modules.") and name.endswith(".bias")):
             w = np.zeros(shape, np.float32)
         else:
             s = std
-            if head_std is not None and name in ("lm_head.weight", "n_token_proj.weight", "score.weight"):
+            if head_std is not None and (name in ("lm_head.weight", "n_token_proj.weight", "score.weight")
+                                         or name.startswith("score.mlp_modules.")):
                 s = head_std
             w = (rng.standard_normal(size=shape) * s).astype(np.float32)
             if name == "model.embed_tokens.weight":

@@ -61,6 +61,8 @@ typedef struct gget_config_t {
   int32_t max_batch;      /* capacity: max B */
   float path_pdrop;       /* >0 => stochastic depth is available (rate linspace(0,path_pdrop,L), utils_graphgpt.py:184) */
   float mlp_pdrop;        /* >0 => MLP dropouts are available (utils_graphgpt.py:69-80): the residual adds run as their own kernels */
+  int32_t head_mlp_layers;/* fine-tune: hidden layers of the `MLP` score head (len(config.mlp), src/utils/modules_utils.py:8-34); 0 = Linear */
+  int32_t head_mlp[4];    /* their widths */
 } gget_config_t;
 
 /* Arena sizes the caller must provide (all 256-byte aligned device buffers). */
@@ -125,8 +127,9 @@ int gget_set_dropout(gget_handle_t h, float attention_p, float path_p, uint32_t 
 /* replaces: `embed_pdrop` / `mlp_pdrop` of the config + model.train()/eval(): nn.Dropout on the gathered token embeddings
  * (modeling_helpers.py:96-98) and the two dropouts of the decoder MLP - on act(gate)*up and on down_proj's output
  * (utils_graphgpt.py:69-80) - for the NEXT forward and its backward, keyed by the seed of gget_set_dropout; zeros (default)
- * are evaluation behaviour.  mlp_p > 0 needs a handle created with config.mlp_pdrop > 0. */
-int gget_set_dropout_ex(gget_handle_t h, float embed_p, float mlp_p);
+ * are evaluation behaviour.  mlp_p > 0 needs a handle created with config.mlp_pdrop > 0.  head_p: `config.dropout`, the
+ * dropout between activation and Linear inside the MLP score head (src/utils/modules_utils.py:27-33). */
+int gget_set_dropout_ex(gget_handle_t h, float embed_p, float mlp_p, float head_p);
 
 /* replaces: `config.num_neg` + the torch RNG behind `torch.randperm` in auc_loss (src/utils/loss_utils.py:25-43): negatives per
  * positive and the seed of the counter-hash permutation the NEXT gget_forward_task(problem_type = GGET_PROBLEM_AUC) draws its

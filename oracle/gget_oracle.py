@@ -236,18 +236,28 @@ def auc_loss(y_pred, y_true, num_neg, idx):
 
 def task_forward(spec, p, input_ids, attention_mask, position_ids=None, task_labels=None,
                  sample_wgt=None, problem_type="single_label_classification", loss_type=None, path_mult=None, attn_keep=None,
-                 num_neg=1, auc_idx=None, embed_keep=None, mlp_keep=None):
+                 num_neg=1, auc_idx=None, embed_keep=None, mlp_keep=None, head_keep=None):
     """`GraphGPTTaskModel.forward` (modeling_finetune.py:236-326) + `calculate_task_loss`
     (:167-234) + `_get_sequence_len` (modeling_helpers.py:78-86); Linear score head, "last" pooling."""
     if input_ids.dim() == 3:
         input_ids = input_ids[:, :, : spec.stacked_feat]
     x, in_ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"), embed_keep=embed_keep)
     hidden = backbone(spec, p, x, attention_mask, position_ids, path_mult=path_mult, attn_keep=attn_keep, mlp_keep=mlp_keep)
-    logits = Fnn.linear(hidden, p["score.weight"], p.get("score.bias"))
     B = hidden.shape[0]
     seq_len = (in_ != spec.pad_token_id).sum(-1) - 1
-    pooled = logits[torch.arange(B), seq_len]
     pooled_h = hidden[torch.arange(B), seq_len]
+    if len(getattr(spec, "head_mlp", ())) > 0:
+        # `MLP` head (src/utils/modules_utils.py:8-34): x = Linear_i(dropout(act(x))) for every Linear, activation first; the
+        # reference applies it to every row and indexes the pooled one (modeling_finetune.py:281-296) - row-wise, so the same
+        pooled = pooled_h
+        for i in range(len(spec.head_mlp) + 1):
+            pooled = Fnn.gelu(pooled)
+            if head_keep is not None:
+                pooled = pooled * torch.as_tensor(head_keep(i)).reshape(pooled.shape).to(pooled.dtype)
+            pooled = Fnn.linear(pooled, p[f"score.mlp_modules.{i}.weight"], p.get(f"score.mlp_modules.{i}.bias"))
+    else:
+        logits = Fnn.linear(hidden, p["score.weight"], p.get("score.bias"))
+        pooled = logits[torch.arange(B), seq_len]
     loss = None
     if task_labels is not None:
         if problem_type == "regression":

@@ -1000,3 +1000,71 @@ def test_model_class_applies_embed_and_mlp_dropout_only_in_training_mode():
     assert abs(a - ev) > 2e-5 * abs(ref) and abs(c - ev) > 2e-5 * abs(ref) and a != c     # (loss ~ ln V at this init: small but real shifts)
     drop.eval()
     assert call(drop) == ev
+
+
+@pytest.mark.gpu
+def test_mlp_score_head_matches_oracle_eval_and_training_dropout():
+    """`MLP` score head (config.mlp = [48, 32], biases; modules_utils.py:8-34) through the drop-in class: evaluation-mode loss /
+    logits against the reference fixture and the oracle's gradients; training mode with config.dropout = 0.25: the oracle is fed
+    with the masks the Python twin regenerates from the engine's seed (exact-mask comparison)."""
+    import os
+    from _util import GOLDEN, spec_mod, weights_mod
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    z = np.load(os.path.join(GOLDEN, "ft_tiny_mlphead.npz"))
+    hm = tuple(int(x) for x in z["head_mlp"])
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=1,
+                                   score_bias=True, head_mlp=hm)
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    for k in state:
+        if k.startswith("score."):
+            state[k] = z["w_" + k]
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    cfg = M.GraphGPTConfig(vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+                           num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
+                           max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=13, num_labels=1,
+                           mlp=list(hm), dropout=float(z["p"]), problem_type="regression")
+    model = M.GraphGPTTaskModel(cfg, seed=1)
+    assert sorted(k for k in model.state_dict() if k.startswith("score.")) == sorted(k for k in state if k.startswith("score."))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    call = lambda: model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], position_ids=b["position_ids"],
+                         task_labels=b["task_labels"])
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    kw = dict(problem_type="regression", loss_type=None)
+    keys = ("score.mlp_modules.0.weight", "score.mlp_modules.1.weight", "score.mlp_modules.2.bias", "score.mlp_modules.0.bias",
+            "model.layers.1.mlp.down_proj.weight", "model.embed_tokens.weight")
+
+    def compare(tag, out, head_keep):
+        loss = float(out.task_loss.item())
+        out.task_loss.backward()
+        p = O.to_params(st_bf, torch.float32)
+        fn = lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"],
+                                      head_keep=head_keep, **kw)
+        o, grads = O.loss_and_grads(fn, p, "task_loss")
+        want = o["task_loss"].item()
+        record_error("ft_tiny_mlphead", tag + " loss_rel_vs_oracle", abs(loss - want) / abs(want), 2e-2)
+        assert abs(loss - want) <= 2e-2 * abs(want), (tag, loss, want)
+        got = model._engine.grads()
+        gmax = max(float(g.norm()) for g in grads.values())
+        for k in keys:
+            w = grads[k].numpy()
+            err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+            record_error("ft_tiny_mlphead", tag + " grad_rel_l2 " + k, err, 6e-2)
+            assert err < 6e-2, f"{tag} {k}: {err}"
+        return loss
+
+    model.eval()
+    out = call()
+    lg = out.task_logits.float().cpu().numpy()
+    err = float(np.abs(lg - z["logits"]).max() / np.abs(z["logits"]).max())
+    record_error("ft_tiny_mlphead", "eval logits_max_rel_vs_reference", err, 2e-2)
+    assert err < 2e-2
+    l_eval = compare("eval", out, None)
+    assert abs(l_eval - float(z["loss"])) <= 3e-2 * abs(float(z["loss"]))
+    model.train()
+    out = call()
+    pd, B = float(z["p"]), b["input_ids"].shape[0]
+    dims = [spec.hidden_size] + list(hm)
+    hk = lambda i: torch.from_numpy(M.elem_drop_keep(model.last_dropout_seed, "head", i, B, dims[i], pd))
+    l_train = compare("train", out, hk)
+    assert abs(l_train - l_eval) > 1e-3 * abs(l_eval)

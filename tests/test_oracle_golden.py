@@ -310,3 +310,41 @@ def test_oracle_embed_and_mlp_dropouts_match_reference():
     np.testing.assert_allclose(gn, z["grad_norms"], rtol=5e-4, atol=1e-7)
     # and the masks matter: eval-mode arithmetic gives another loss
     assert abs(O.pretrain_forward(spec, p, b["input_ids"], b["attention_mask"], b["labels"])["head1_loss"].item() - float(z["loss"])) > 1e-3
+
+
+def _mlphead_case():
+    from _util import GOLDEN, spec_mod, weights_mod
+    z = np.load(os.path.join(GOLDEN, "ft_tiny_mlphead.npz"))
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=1,
+                                   score_bias=True, head_mlp=tuple(int(x) for x in z["head_mlp"]))
+    assert [int(x) for x in z["meta_spec"]] == list(spec.as_c_ints())
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    for k in state:
+        if k.startswith("score."):
+            state[k] = z["w_" + k]
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    return z, spec, state, b
+
+
+def test_oracle_mlp_score_head_matches_reference():
+    """config.mlp = [48, 32] (src/utils/modules_utils.py:8-34): evaluation mode, and training mode with config.dropout = 0.25 fed
+    with the keep masks the reference's dropout calls drew on the pooled rows."""
+    z, spec, state, b = _mlphead_case()
+    p = O.to_params(state, torch.float32)
+    kw = dict(problem_type="regression", loss_type=None)
+    fn = lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], **kw)
+    out, grads = O.loss_and_grads(fn, p, "task_loss")
+    assert abs(out["task_loss"].item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    np.testing.assert_allclose(out["task_logits"].detach().numpy(), z["logits"], rtol=2e-4, atol=2e-5)
+    for k, want in (("score.mlp_modules.0.weight", z["grad_w0"]), ("score.mlp_modules.1.bias", z["grad_b1"]),
+                    ("model.layers.1.mlp.down_proj.weight", z["grad_l1_down"])):
+        assert np.linalg.norm(grads[k].numpy() - want) <= 2e-4 * np.linalg.norm(want), k
+    np.testing.assert_allclose(np.array([float(grads[str(n)].norm()) for n in z["names"]]), z["grad_norms"], rtol=5e-4, atol=1e-7)
+    pd = float(z["p"])
+    hk = lambda i: torch.from_numpy(z[f"train_keep_{i}"].astype(np.float32) / (1.0 - pd))
+    fn2 = lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], head_keep=hk, **kw)
+    out2, grads2 = O.loss_and_grads(fn2, p, "task_loss")
+    assert abs(out2["task_loss"].item() - float(z["train_loss"])) <= 1e-5 * abs(float(z["train_loss"]))
+    assert np.linalg.norm(grads2["score.mlp_modules.0.weight"].numpy() - z["train_grad_w0"]) <= 2e-4 * np.linalg.norm(z["train_grad_w0"])
+    np.testing.assert_allclose(np.array([float(grads2[str(n)].norm()) for n in z["names"]]), z["train_grad_norms"], rtol=5e-4, atol=1e-7)

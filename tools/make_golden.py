@@ -611,6 +611,72 @@ def dropout_fixture():
     print(f"pt_tiny_dropouts written: loss {res['loss']:.6f}, {len(rec)} dropout calls recorded")
 
 
+def mlp_head_fixture():
+    """Fine-tune model with the `MLP` score head (config.mlp = [48, 32], src/utils/modules_utils.py:8-34 chosen at
+    modeling_finetune.py:88-97), regression => every Linear has a bias.  Evaluation mode: loss / logits / gradients; training
+    mode with config.dropout = 0.25: the same with the keep masks of the head's three dropout calls recorded (see dropout_fixture)."""
+    import torch.nn.functional as F
+    PT, FT, Cfg = import_reference()
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=1,
+                                   score_bias=True, head_mlp=(48, 32))
+    state = weights_mod.make_state_dict(spec, seed=811, std=0.06, head_std=0.3)
+    rs = np.random.RandomState(5)
+    for k in state:
+        if k.startswith("score.mlp_modules.") and k.endswith(".bias"):
+            state[k] = rs.uniform(-0.2, 0.2, size=state[k].shape).astype(np.float32)
+    batch = synth.make_task_batch(B=16, S=24, F=13, V=756, num_labels=1, regression=True, seed=81)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    cfg = ref_config(Cfg, spec, num_labels=1, loss_type=None, mlp=[48, 32], dropout=0.25, problem_type="regression")
+    model = FT(cfg)
+    load_weights(model, state)
+    names = list(state.keys())
+    res = {"meta_spec": np.array(spec.as_c_ints(), np.int64), "meta_init": np.array([811, 0.06, 0.3]), "names": np.array(names),
+           "head_mlp": np.array([48, 32]), "p": np.float64(0.25)}
+    for k in names:
+        if k.startswith("score."):
+            res["w_" + k] = state[k]
+    fwd = lambda: model(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"], position_ids=tb["position_ids"],
+                        task_labels=tb["task_labels"])
+    model.eval()
+    o = fwd()
+    model.zero_grad()
+    o.task_loss.backward()
+    g = dict(model.named_parameters())
+    res.update(loss=np.float64(o.task_loss.item()), logits=o.task_logits.detach().float().numpy(), grad_norms=grad_norms(model, names),
+               grad_w0=g["score.mlp_modules.0.weight"].grad.numpy().copy(), grad_b1=g["score.mlp_modules.1.bias"].grad.numpy().copy(),
+               grad_l1_down=g["model.layers.1.mlp.down_proj.weight"].grad.numpy().copy())
+    model.train()
+    rec = []
+    gen = torch.Generator().manual_seed(24680)
+    orig = F.dropout
+
+    def recording_dropout(input, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return input
+        keep = (torch.rand(input.shape, generator=gen) >= p)
+        rec.append((tuple(input.shape), float(p), keep.numpy().copy()))
+        return input * keep.to(input.dtype) / (1.0 - p)
+
+    F.dropout = recording_dropout
+    try:
+        o = fwd()
+        model.zero_grad()
+        o.task_loss.backward()
+    finally:
+        F.dropout = orig
+    assert [r[0][-1] for r in rec] == [spec.hidden_size, 48, 32] and all(r[1] == 0.25 for r in rec), [r[:2] for r in rec]
+    B, S = tb["input_ids"].shape[:2]
+    seq_len = (tb["input_ids"][:, :, 0] != 0).sum(-1) - 1
+    for i, (shape, _, keep) in enumerate(rec):           # the reference runs the head on every row: keep the pooled rows' masks
+        res[f"train_keep_{i}"] = keep.reshape(B, S, -1)[np.arange(B), seq_len.numpy()].copy()
+    res.update(train_loss=np.float64(o.task_loss.item()), train_grad_norms=grad_norms(model, names),
+               train_grad_w0=g["score.mlp_modules.0.weight"].grad.numpy().copy())
+    for k, v in batch.items():
+        res["in_" + k] = v
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ft_tiny_mlphead.npz"), **res)
+    print(f"ft_tiny_mlphead written: eval loss {res['loss']:.6f}, train loss {res['train_loss']:.6f}")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -636,6 +702,8 @@ def main():
         auc_fixture()
     if not only or "pt_tiny_dropouts" in only:
         dropout_fixture()
+    if not only or "ft_tiny_mlphead" in only:
+        mlp_head_fixture()
 
 
 if __name__ == "__main__":

@@ -1617,7 +1617,8 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
                        (const bf16_t*)dout, lse, delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, D);                                 \
   } while (0)
     // dQ: 4-wave blocks at 3 waves / SIMD (168 registers: the 128 of 4 waves / SIMD spill); dK/dV: 8-wave blocks at 2 waves / SIMD
-    if (key_lo) GGET_BWD64(true); else GGET_BWD64(false);
+    if (key_lo) GGET_BWD64(true);
+    else GGET_BWD64(false);
 #undef GGET_BWD64
     GGET_LAUNCH_CHECK();
     return 0;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-kernel PMC sums for the attention kernels: one counter per pass -> gpurun_out/<tag>_attn_pmc.txt
-tag=${1:-r02}; p=${2:-0.0}; which=${3:-fwd}
+tag=${1:-r02}; p=${2:-0.0}; which=${3:-fwd}; pat=${4:-attn_}
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/${tag}_attn_pmc.txt
 : > $out
@@ -8,6 +8,6 @@ for c in SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_V
   rm -rf /tmp/pmca_$c
   rocprofv3 --kernel-trace --pmc $c --output-format rocpd -d /tmp/pmca_$c -- python $GRAFT_REPO_ROOT/tools/attn_fwd_only.py $p $which > /tmp/pmca_$c.log 2>&1
   db=$(find /tmp/pmca_$c -name "*.db" | head -1)
-  if [ -n "$db" ]; then python $GRAFT_REPO_ROOT/tools/pmc_kernel.py $db attn_ >> $out 2>&1; else echo "$c: no db ($(tail -1 /tmp/pmca_$c.log))" >> $out; fi
+  if [ -n "$db" ]; then python $GRAFT_REPO_ROOT/tools/pmc_kernel.py $db $pat >> $out 2>&1; else echo "$c: no db ($(tail -1 /tmp/pmca_$c.log))" >> $out; fi
 done
 cat $out

@@ -325,6 +325,14 @@ class _GgetModel(nn.Module):
             raise IndexError(f"position_ids must lie in [0, max_position_embeddings = {maxp}); got [{lo}, {hi}] - build the model "
                              "with a larger max_position_embeddings")
 
+    def _validate_inputs(self, input_ids, attention_mask, labels=None):
+        """Debug-mode input validation (GGET_CHECK_INPUTS=1; costs device->host reads): the kernels index with the ids / labels
+        they are given, where the reference's nn.Embedding / CrossEntropyLoss raise an index error, and a 2-D mask is reduced
+        to ONE key length per row, where the reference accepts any 0/1 pattern."""
+        if not os.environ.get("GGET_CHECK_INPUTS"):
+            return
+        check_batch(input_ids, attention_mask, labels, self.config.vocab_size)
+
     def _wrap_loss(self, loss):
         if loss is None:
             return None
@@ -363,6 +371,7 @@ class GraphGPTPretrainBase(_GgetModel):
         if attention_mask.dim() == 3:
             assert not self.spec.causal, "the reference only builds the 3-D mask for bi-directional attention (modeling_pretrain.py:197-198)"
         self._check_positions(position_ids, S)
+        self._validate_inputs(input_ids, attention_mask, labels)
         e = self._pre_forward(B, S)
         loss = e.forward_pretrain(input_ids, attention_mask, labels, sample_wgt, position_ids)
         return _PretrainOutput(self._wrap_loss(loss), _LazyLogits(self))
@@ -399,6 +408,7 @@ class GraphGPTTaskModel(_GgetModel):
         else:
             code = L.PROBLEM_MULTI_LABEL   # BCE-with-logits on the labelled entries (modeling_finetune.py:227-230)
         self._check_positions(position_ids, S)
+        self._validate_inputs(input_ids, attention_mask)
         e = self._pre_forward(B, S)
         if code == L.PROBLEM_AUC and task_labels is not None:
             # one seed per call (the reference draws torch.randperm from the global generator every call)
@@ -408,6 +418,24 @@ class GraphGPTTaskModel(_GgetModel):
         loss, logits, hid = e.forward_task(input_ids, attention_mask, position_ids, task_labels, sample_wgt, code)
         return DoubleHeadsModelOutput(pretrain_loss=None, task_loss=self._wrap_loss(loss), pretrain_logits=None,
                                       task_logits=logits, task_hidden_states=hid)
+
+
+def check_batch(input_ids, attention_mask, labels, vocab_size: int):
+    """What `GGET_CHECK_INPUTS=1` verifies before a forward (see _GgetModel._validate_inputs); raises like the reference would."""
+    lo, hi = int(input_ids.min()), int(input_ids.max())
+    if lo < 0 or hi >= vocab_size:
+        raise IndexError(f"input_ids must lie in [0, vocab_size = {vocab_size}); got [{lo}, {hi}]")
+    if labels is not None:
+        lab = labels[labels != -100]
+        if lab.numel() and (int(lab.min()) < 0 or int(lab.max()) >= vocab_size):
+            raise IndexError(f"labels must be -100 or lie in [0, vocab_size = {vocab_size}); got [{int(lab.min())}, {int(lab.max())}]")
+    if attention_mask is not None and attention_mask.dim() == 2:
+        m = attention_mask != 0
+        n = m.sum(-1, keepdim=True)
+        want = torch.arange(m.shape[1], device=m.device)[None, :] < n
+        if not bool((m == want).all()):
+            raise ValueError("a 2-D attention_mask must be right-padded (1 ... 1 0 ... 0): the engine keeps one key length per row; "
+                             "pass a [B,S,S] block-diagonal mask for packed rows")
 
 
 def elem_drop_keep(seed: int, which: str, layer: int, rows: int, cols: int, p: float):

@@ -11,6 +11,9 @@ typedef __attribute__((ext_vector_type(16))) float f16v;
 
 template <int NM, int NV, int NE, int ORDER>
 __global__ void __launch_bounds__(256) k(float* out, int iters) {
+  __shared__ __bf16 lds[8 * 512];
+  for (int i = threadIdx.x; i < 8 * 512; i += 256) lds[i] = (__bf16)(i * 1e-4f);
+  __syncthreads();
   f16v a = {0}, b = {0};
   bf8 x, y;
   for (int i = 0; i < 8; ++i) { x[i] = (__bf16)(threadIdx.x * 0.001f + i); y[i] = (__bf16)(i * 0.5f); }
@@ -31,6 +34,36 @@ __global__ void __launch_bounds__(256) k(float* out, int iters) {
 #pragma unroll
       for (int j = 0; j < NE; ++j) e[j & 7] = __builtin_amdgcn_exp2f(e[j & 7]) * 0.5f;
       __builtin_amdgcn_sched_barrier(0);
+    } else if (ORDER == 2) {   // interleaved, the A operand of every MFMA freshly read from LDS (ds_read_b128 two MFMAs ahead)
+      bf8 f0 = *reinterpret_cast<const bf8*>(&lds[(threadIdx.x & 63) * 8]);
+      bf8 f1 = *reinterpret_cast<const bf8*>(&lds[512 + (threadIdx.x & 63) * 8]);
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const bf8 cur = (m & 1) ? f1 : f0;
+        if (m & 1) b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, y, b, 0, 0, 0);
+        else a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, y, a, 0, 0, 0);
+        if (m & 1) f1 = *reinterpret_cast<const bf8*>(&lds[((m + 2) & 7) * 512 + (threadIdx.x & 63) * 8]);
+        else f0 = *reinterpret_cast<const bf8*>(&lds[((m + 2) & 7) * 512 + (threadIdx.x & 63) * 8]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NV / NM; ++j) v[j & 15] = __builtin_fmaf(v[j & 15], 1.0001f, 0.5f);
+#pragma unroll
+        for (int j = 0; j < NE / NM; ++j) e[j & 7] = __builtin_amdgcn_exp2f(e[j & 7]) * 0.5f;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if (ORDER == 3) {   // interleaved, the VALU work reads the accumulator the MFMA before last wrote (softmax on MFMA outputs)
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        if (m & 1) b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, b, 0, 0, 0);
+        else a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        f16v& src = (m & 1) ? a : b;     // the OTHER accumulator: written one MFMA earlier
+#pragma unroll
+        for (int j = 0; j < NV / NM; ++j) v[j & 15] = __builtin_fmaf(src[j & 15], 1.0001f, v[j & 15]);
+#pragma unroll
+        for (int j = 0; j < NE / NM; ++j) e[j & 7] = __builtin_amdgcn_exp2f(e[j & 7]) * 0.5f;
+        __builtin_amdgcn_sched_barrier(0);
+      }
     } else {            // interleaved inside the wave: one MFMA, then its share of the VALU work
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
@@ -77,8 +110,9 @@ int main(int argc, char** argv) {
   for (int W : {1, 2, 4}) {
     float m = run<8, 0, 0, 0>(W, iters, d), v = run<0, 96, 0, 0>(W, iters, d), e = run<0, 0, 16, 0>(W, iters, d);
     float all0 = run<8, 96, 16, 0>(W, iters, d), all1 = run<8, 96, 16, 1>(W, iters, d);
-    printf("W=%d: 8 mfma %.0f | 96 fma %.0f | 16 exp(+mul) %.0f | all, blocked %.0f | all, interleaved %.0f | sum of parts %.0f\n", W, m, v, e,
-           all0, all1, m + v + e);
+    float all2 = run<8, 96, 16, 2>(W, iters, d), all3 = run<8, 96, 16, 3>(W, iters, d);
+    printf("W=%d: 8 mfma %.0f | 96 fma %.0f | 16 exp(+mul) %.0f | all, blocked %.0f | all, interleaved %.0f | sum of parts %.0f | interleaved + LDS-fed A "
+           "operands %.0f | interleaved, VALU reads MFMA outputs %.0f\n", W, m, v, e, all0, all1, m + v + e, all2, all3);
   }
   return 0;
 }

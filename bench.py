@@ -136,18 +136,29 @@ def _source_digest():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic():
-    """L2<->fabric bytes per launch of the dominant kernel from the committed PMC passes (profiles/r02_gu_geglu_gemm_pmc.json:
-    FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc runs, tools/pmc_gu.sh).  PMC counters cannot be
-    collected from inside the process being timed, so the figure is a recorded one: it carries the digest of the kernel
-    sources it was measured on and is reported as null when those sources have changed since."""
-    p = os.path.join(ROOT, "profiles", "r02_gu_geglu_gemm_pmc.json")
+def pmc_traffic(which="wgrad_layer"):
+    """L2<->fabric bytes per launch of a timed kernel from the committed PMC passes (FETCH_SIZE x2 (gfx950 correction) +
+    WRITE_SIZE, separate --pmc runs: tools/pmc_wgrad.sh -> profiles/r02_wgrad_gemm_pmc.json, tools/pmc_gu.sh ->
+    profiles/r02_gu_geglu_gemm_pmc.json).  PMC counters cannot be collected from inside the process being timed, so the figure
+    is a recorded one: it carries the digest of the kernel sources it was measured on and is reported as null when those
+    sources have changed since."""
+    name = {"wgrad_layer": "r02_wgrad_gemm_pmc.json", "gateup": "r02_gu_geglu_gemm_pmc.json"}.get(which)
+    if name is None:
+        return None
     try:
-        with open(p) as f:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             rec = json.load(f)
         return rec["traffic_bytes_per_launch"] if rec.get("source_digest") == _source_digest() else None
     except (OSError, KeyError, ValueError):
         return None
+
+
+KERNEL_NAMES = {
+    "wgrad_layer": "gemm_ks_kernel<192,192,TN> (in-block K split): grouped weight gradients of one decoder layer - dW = dY^T X for "
+                   "gate|up, down, q|k|v, o in ONE launch, K = T, 256 tiles = one per CU",
+    "gateup": "gemm_persist_kernel<256,256,64,NT,EPI_GEGLU_FWD>: FFN gate|up [T,d]x[d,2ff] with the gated-GELU product in its epilogue",
+    "dgrad_gu": "gemm_ks_kernel<128,192,NN> (in-block K split): dgrad dxn2 = dgu W_gu [T,2ff]x[2ff,d]",
+}
 
 
 def main():
@@ -243,10 +254,24 @@ def main():
         ms = dt / a.steps * 1e3
         step_tflops = fstep / (ms * 1e-3) / 1e12
         kt = time_kernels(spec, B * S)
-        gu_fl, gu_ms = kt["gateup"]
-        d_, ff_, L_ = spec.hidden_size, spec.intermediate_size, spec.num_layers
+        L_ = spec.num_layers
         share = lambda fl_per_layer: round(100.0 * fl_per_layer * L_ / fstep, 1)
-        k_tflops = gu_fl / (gu_ms * 1e-3) / 1e12
+        # the dominant kernel = the launch that takes the largest share of the step's TIME (each of the three runs once per
+        # layer): with the GEGLU fused into the gate|up GEMM that is the grouped weight-gradient launch (~20 % of a C1 step)
+        c1_shape = B * S == 8192 and spec.hidden_size == 768
+
+        def entry(k):
+            fl, kms = kt[k]
+            tf = fl / (kms * 1e-3) / 1e12
+            return {"kernel": KERNEL_NAMES[k], "step_flops_pct": share(fl), "step_time_pct": round(100.0 * kms * L_ / ms, 1),
+                    "avg_launch_ms": kms, "achieved": tf, "frac": tf / PEAK_BF16_TFLOPS,
+                    "traffic": pmc_traffic(k) if c1_shape else None}
+        order = sorted(kt, key=lambda k: -kt[k][1])
+        dom = entry(order[0])
+        roofline = {"bound": "mfma", "kernel": dom["kernel"] + f" ({dom['step_time_pct']}% of the step's time, {dom['step_flops_pct']}% of its FLOPs)",
+                    "achieved": dom["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
+                    "traffic": dom["traffic"], "avg_launch_ms": dom["avg_launch_ms"],
+                    "other_kernels": [entry(k) for k in order[1:]]}
         names = {"pt": "SMTP loss", "pt-packed": "SMTP loss", "ft": "task loss", "ft-long": "task loss"}
         out = {
             "metric": f"graph-tokens/sec (un-padded Eulerian tokens, whole job) + {names[kind]}, "
@@ -265,22 +290,7 @@ def main():
             "tokens_per_s_per_gpu": tot_real * a.steps / dt / world,
             "step_mfma": {"flops_per_step": fstep, "achieved_tflops_per_gpu": step_tflops,
                           "frac_of_peak": step_tflops / PEAK_BF16_TFLOPS},
-            "roofline": {"bound": "mfma",
-                         "kernel": f"gemm_persist_kernel<256,256,64,NT,EPI_GEGLU_FWD> FFN gate|up [T,d]x[d,2ff] + gated GELU "
-                                   f"({share(gu_fl)}% of step FLOPs as the forward launch timed here, {share(3 * gu_fl)}% with its dgrad and wgrad)",
-                         "achieved": k_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": k_tflops / PEAK_BF16_TFLOPS,
-                         "traffic": pmc_traffic() if B * S == 8192 and spec.hidden_size == 768 else None,
-                         "avg_launch_ms": gu_ms,
-                         "other_kernels": [
-                             {"kernel": "gemm_ks_kernel<128,192,NN> (in-block K split) dgrad dxn2 = dgu W_gu [T,2ff]x[2ff,d]",
-                              "step_flops_pct": share(kt["dgrad_gu"][0]), "avg_launch_ms": kt["dgrad_gu"][1],
-                              "achieved": kt["dgrad_gu"][0] / (kt["dgrad_gu"][1] * 1e-3) / 1e12,
-                              "frac": kt["dgrad_gu"][0] / (kt["dgrad_gu"][1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS},
-                             {"kernel": "gemm_ks_kernel<192,192,TN> (in-block K split) grouped weight gradients of one layer (gate|up, down, q|k|v, o; K = T)",
-                              "step_flops_pct": share(kt["wgrad_layer"][0]), "avg_launch_ms": kt["wgrad_layer"][1],
-                              "achieved": kt["wgrad_layer"][0] / (kt["wgrad_layer"][1] * 1e-3) / 1e12,
-                              "frac": kt["wgrad_layer"][0] / (kt["wgrad_layer"][1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}]},
+            "roofline": roofline,
         }
         if world == 1 and not a.no_cpu_baseline and kind == "pt":
             state = weights.make_state_dict(spec, seed=0)

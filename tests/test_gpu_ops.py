@@ -341,7 +341,7 @@ def _drop_mask(seed, B, H, S, p):
     return torch.from_numpy((keep.astype(np.float32) / (1.0 - p)).reshape(B, H, S, S))
 
 
-@pytest.mark.parametrize("S,short", [(72, 50), (32, 21), (256, 130)])
+@pytest.mark.parametrize("S,short", [(72, 50), (32, 21), (256, 130), (576, 300), (1056, 777)])   # the last two: long-sequence kernels
 def test_attention_dropout(lib, S, short):
     """Dropout on the softmax output (hf eager_attention_forward :210): the kernels regenerate the same counter-based
     mask in forward, dQ and dK/dV (S <= 32: the fused single-launch backward); checked against autograd with the
@@ -583,11 +583,15 @@ def _packed_ranges(B, S, seed, pad_tail=True):
     return m, lo, hi
 
 
-@pytest.mark.parametrize("B,S,H,causal", [(3, 24, 2, 0), (2, 72, 2, 0), (2, 160, 3, 0), (1, 520, 2, 0), (2, 96, 2, 1)])
-def test_attention_packed_ranges(lib, B, S, H, causal):
+@pytest.mark.parametrize("B,S,H,causal,drop", [(3, 24, 2, 0, 0.0), (2, 72, 2, 0, 0.0), (2, 160, 3, 0, 0.0), (1, 520, 2, 0, 0.0),
+                                               (2, 96, 2, 1, 0.0), (2, 72, 2, 0, 0.1), (2, 520, 2, 0, 0.1), (1, 1024, 1, 1, 0.1)])
+def test_attention_packed_ranges(lib, B, S, H, causal, drop):
     """Attention on packed rows (per-token key ranges from a block-diagonal mask) vs autograd with the explicit [S,S] mask:
-    forward and all three gradients; rows of the padding tail produce zeros."""
+    forward and all three gradients; rows of the padding tail produce zeros.  drop > 0: with attention dropout (the packed
+    pre-train workload runs it), same counter-based mask through the Python twin - S >= 256 are the long-sequence kernels."""
     d = H * 64
+    dseed = 4321
+    dmask = _drop_mask(dseed, B, H, S, drop).cuda() if drop > 0 else None
     m3, lo_np, hi_np = _packed_ranges(B, S, seed=S + B)
     qkv = rnd(B * S, 3 * d, seed=23)
     mask3d = torch.from_numpy(m3).cuda()
@@ -597,7 +601,7 @@ def test_attention_packed_ranges(lib, B, S, H, causal):
     assert torch.equal(lo.cpu(), torch.from_numpy(lo_np)) and torch.equal(hi.cpu(), torch.from_numpy(hi_np))
     out = torch.empty(B * S, d, dtype=torch.bfloat16, device="cuda")
     lse = torch.empty(B * H * S, dtype=torch.float32, device="cuda")
-    L.check(lib.gget_op_attn_fwd_ranges(P(qkv), P(lo), P(hi), P(out), P(lse), B, S, H, causal, 0.0, 0, ST()))
+    L.check(lib.gget_op_attn_fwd_ranges(P(qkv), P(lo), P(hi), P(out), P(lse), B, S, H, causal, drop, dseed, ST()))
     x = qkv.float().view(B, S, 3, H, 64).detach().requires_grad_(True)
     q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
     w = q @ k.transpose(2, 3) * 0.125
@@ -606,6 +610,8 @@ def test_attention_packed_ranges(lib, B, S, H, causal):
         allow = allow & torch.ones(S, S, dtype=torch.bool, device="cuda").tril()[None]
     w = w.masked_fill(~allow[:, None], float("-inf"))
     p = torch.softmax(w, -1).nan_to_num(0.0)           # padding rows: no key at all
+    if dmask is not None:
+        p = p * dmask
     ref = (p @ v).transpose(1, 2).reshape(B * S, d)
     valid = torch.from_numpy(hi_np >= lo_np).cuda().view(B * S)
     assert rel_l2(out.float()[valid].cpu().numpy(), ref[valid].detach().cpu().numpy()) < 8e-3
@@ -615,7 +621,7 @@ def test_attention_packed_ranges(lib, B, S, H, causal):
     ref.backward(dout.float())
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B * H * S, dtype=torch.float32, device="cuda")
-    L.check(lib.gget_op_attn_bwd_ranges(P(qkv), P(out), P(dout), P(lse), P(lo), P(hi), P(dqkv), P(delta), B, S, H, causal, 0.0, 0, ST()))
+    L.check(lib.gget_op_attn_bwd_ranges(P(qkv), P(out), P(dout), P(lse), P(lo), P(hi), P(dqkv), P(delta), B, S, H, causal, drop, dseed, ST()))
     got = dqkv.float().view(B, S, 3, H, 64)
     for i, nm in enumerate("qkv"):
         e = rel_l2(got[:, :, i].cpu().numpy(), x.grad[:, :, i].cpu().numpy())

@@ -1331,12 +1331,15 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 4) attn_bwd_dq64_kern
   };
   const int nst = kend_blk > kbeg_blk ? (kend_blk - kbeg_blk + 63) >> 6 : 0;
   if (nst > 0) issue(0, kbeg_blk);
-  for (int t = 0; t < nst; ++t) {
+  // (the stage loop is unrolled by two: with a static buffer every LDS address is lane offset + immediate, which is what lets the
+  // 8-wave build stay inside 128 registers)
+  auto stage = [&](int t, auto BUF) {
+    constexpr int buf = decltype(BUF)::value;
     const int ks = kbeg_blk + t * 64;
     attn_vm_wait0();
     __syncthreads();
-    if (t + 1 < nst) issue((t + 1) & 1, ks + 64);
-    const unsigned char* kst = st[t & 1];
+    if (t + 1 < nst) issue(buf ^ 1, ks + 64);
+    const unsigned char* kst = st[buf];
     const unsigned char* vst = kst + 8192;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1345,15 +1348,20 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 4) attn_bwd_dq64_kern
       const unsigned char* kt = kst + 4096 * j;
       const unsigned char* vt = vst + 4096 * j;
       f32x16_t dp = zero16(), sc = zero16();
+      {   // fenced: two LDS fragments in flight (unfenced, the scheduler hoists every read of the tile and the 128-register build spills)
+        bf16x8_t fa = frag_rows(kt, 0, lane), fb = frag_rows(vt, 0, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), qf[s], sc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);     // phase fences: without them the scheduler hoists every LDS read of the tile and spills
-#pragma unroll
-      for (int s = 0; s < 4; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, s, lane), dof[s], dp, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, qf[s], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, dof[s], dp, 0, 0, 0);
+          if (s < 3) { fa = frag_rows(kt, s + 1, lane); fb = frag_rows(vt, s + 1, lane); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       const bool edge = (k0 < ilo) || (k0 + 31 > ihi) || (causal && k0 + 31 > q0) || (q0 + 32 > S);
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[r] = fast_exp2(fmaf(sc[r], kScaleL2, nlse2));      // P (un-dropped)
-      __builtin_amdgcn_sched_barrier(0);
       if (edge) {
         int k0v = k0;
         asm volatile("" : "+v"(k0v));    // keeps the mask arithmetic inside this rarely taken branch
@@ -1379,11 +1387,21 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 4) attn_bwd_dq64_kern
       }
       const bf16x8_t ds0 = acc_to_b(sc, 0), ds1 = acc_to_b(sc, 1);
       __builtin_amdgcn_sched_barrier(0);
-      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 0, lane), ds0, a0, 0, 0, 0);
-      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 1, lane), ds1, a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 0, lane), ds0, a1, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 1, lane), ds1, a1, 0, 0, 0);
+      {
+        bf16x8_t fa = frag_tr(kt, 0, 0, lane), fb = frag_tr(kt, 1, 0, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ds0, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, ds0, a1, 0, 0, 0);
+        fa = frag_tr(kt, 0, 1, lane); fb = frag_tr(kt, 1, 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ds1, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, ds1, a1, 0, 0, 0);
+      }
     }
+  };
+  for (int t = 0; t < nst; t += 2) {
+    stage(t, std::integral_constant<int, 0>{});
+    if (t + 1 < nst) stage(t + 1, std::integral_constant<int, 1>{});
   }
   if (qrow < S) store_t(dqkv + ((size_t)b * S + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
 }
@@ -1616,7 +1634,8 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
     hipLaunchKernelGGL((attn_bwd_dkv64_kernel<PK, 8>), dim3((S + 255) / 256, H, B), dim3(512), 0, st, (const bf16_t*)qkv,            \
                        (const bf16_t*)dout, lse, delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, D);                                 \
   } while (0)
-    // dQ: 4-wave blocks at 3 waves / SIMD (168 registers: the 128 of 4 waves / SIMD spill); dK/dV: 8-wave blocks at 2 waves / SIMD
+    // dQ: 4-wave blocks at 3 waves / SIMD (168 registers; the 128-register 8-wave build spills in its dropout / edge paths and
+    // runs 1216 us against 894 for the pair); dK/dV: 8-wave blocks at 2 waves / SIMD
     if (key_lo) GGET_BWD64(true);
     else GGET_BWD64(false);
 #undef GGET_BWD64

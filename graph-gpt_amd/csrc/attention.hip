@@ -1257,7 +1257,7 @@ template <bool PK, int NWB>
 __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 4) attn_bwd_dq64_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                                     const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                     float* __restrict__ delta, KeyRange KR, bf16_t* __restrict__ dqkv,
-                                                                    int B, int S, int H, int causal, Drop D) {
+                                                                    int B, int S, int H, int causal, Drop D, Rope Rout) {
   __shared__ __attribute__((aligned(16))) unsigned char st[2][2 * 8192];
   __shared__ int red[16];
   constexpr int QB = NWB * 32;
@@ -1403,7 +1403,10 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 4) attn_bwd_dq64_kern
     stage(t, std::integral_constant<int, 0>{});
     if (t + 1 < nst) stage(t + 1, std::integral_constant<int, 1>{});
   }
-  if (qrow < S) store_t(dqkv + ((size_t)b * S + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
+  if (qrow < S) {
+    unrope_acc(a0, a1, Rout, rope_pos(Rout, b, qrow), hi);     // q is stored rotated (engine layout): rotate dq back; no-op without tables
+    store_t(dqkv + ((size_t)b * S + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
+  }
 }
 
 // dK / dV for long sequences: a wave owns a 32-key tile (K and V fragments in registers), Q and dO are streamed in 64-query
@@ -1412,7 +1415,7 @@ template <bool PK, int NWB>
 __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 2) attn_bwd_dkv64_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                      const float* __restrict__ lse, const float* __restrict__ delta,
                                                                      KeyRange KR, bf16_t* __restrict__ dqkv, int B, int S, int H, int causal,
-                                                                     Drop D) {
+                                                                     Drop D, Rope Rout) {
   __shared__ __attribute__((aligned(16))) unsigned char st[2][2 * 8192];
   __shared__ __attribute__((aligned(16))) float lse_s[2][64], dl_s[2][64];
   __shared__ int qlo_s[2][64], qhi_s[2][64];
@@ -1553,6 +1556,7 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 2) attn_bwd_dkv64_ker
   }
   if (krow < S) {
     bf16_t* row = dqkv + ((size_t)b * S + krow) * pitch + h * 64;
+    unrope_acc(dk0, dk1, Rout, rope_pos(Rout, b, krow), hi);
     store_t(row + d, dk0, dk1, 1.f, hi);
     store_t(row + 2 * d, dv0, dv1, 1.f, hi);
   }
@@ -1626,13 +1630,15 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
   }
   static int big = -1;
   if (big < 0) { const char* e = getenv("GGET_ATTN_BIG"); big = e ? atoi(e) : 1; }
-  if (S >= 256 && !cos_tab && big) {
+  // (q, k rotated in memory - the engine's layout - or no rotation at all: the staged kernels read them as they are and rotate dq / dk
+  // back in their epilogues; q, k to be rotated on load, the plain-op form of the tests, stays on the register-prefetch kernels)
+  if (S >= 256 && (!cos_tab || qk_rotated) && big) {
 #define GGET_BWD64(PK)                                                                                                           \
   do {                                                                                                                           \
     hipLaunchKernelGGL((attn_bwd_dq64_kernel<PK, 4>), dim3((S + 127) / 128, H, B), dim3(256), 0, st, (const bf16_t*)qkv,             \
-                       (const bf16_t*)out, (const bf16_t*)dout, lse, delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, D);             \
+                       (const bf16_t*)out, (const bf16_t*)dout, lse, delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, D, R);          \
     hipLaunchKernelGGL((attn_bwd_dkv64_kernel<PK, 8>), dim3((S + 255) / 256, H, B), dim3(512), 0, st, (const bf16_t*)qkv,            \
-                       (const bf16_t*)dout, lse, delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, D);                                 \
+                       (const bf16_t*)dout, lse, delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, D, R);                              \
   } while (0)
     // dQ: 4-wave blocks at 3 waves / SIMD (168 registers; the 128-register 8-wave build spills in its dropout / edge paths and
     // runs 1216 us against 894 for the pair); dK/dV: 8-wave blocks at 2 waves / SIMD

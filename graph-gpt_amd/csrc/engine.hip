@@ -310,6 +310,7 @@ struct gget_engine {
   bool have_labels = false;
   int problem = 0;
   int auc_num_neg = 1;
+  float focal_gamma = 0.f;        // focal loss on the SMTP head (config.focal_gamma)
   unsigned auc_seed = 0;
   bool fwd_valid = false;
   float attn_drop_p = 0.f;        // attention dropout of the NEXT forward (training mode); 0 = off
@@ -482,6 +483,13 @@ extern "C" int gget_set_dropout_ex(gget_handle_t h, float embed_p, float mlp_p, 
   GGET_REQUIRE(mlp_p == 0.f || h->cfg.mlp_pdrop > 0.f, "MLP dropout needs a handle created with config.mlp_pdrop > 0");
   h->embed_drop_p = embed_p;
   h->mlp_drop_p = mlp_p;
+  return 0;
+}
+
+extern "C" int gget_set_focal_gamma(gget_handle_t h, float gamma) {
+  GGET_REQUIRE(h != nullptr, "null handle");
+  GGET_REQUIRE(gamma >= 0.f, "focal_gamma must be >= 0");
+  h->focal_gamma = gamma;
   return 0;
 }
 
@@ -758,7 +766,7 @@ static int forward_pretrain_impl(gget_handle_t h, const int64_t* input_ids_dev, 
     const float base = 1.0f / (float)((long)B * S * n);  // dLM normaliser, modeling_pretrain.py:230-236
     if (int e = k_ce_fwd_bwd(h->wsp<bf16_t>(w.logits), Vp, h->wsp<int32_t>(w.sel_label), h->wsp<int32_t>(w.sel_tok),
                              sample_wgt_dev, S, counts + 1, T * n, V, h->wsp<float>(w.loss_sum), h->wsp<bf16_t>(w.dlogits),
-                             base, mean_rows, loss_dev, st))
+                             base, mean_rows, loss_dev, st, mean_rows ? h->focal_gamma : 0.f))   // (the dLM-weighted loss has no focal form)
       return e;
   }
   h->fwd_valid = true;

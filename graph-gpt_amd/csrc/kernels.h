@@ -46,7 +46,7 @@ int k_gather_rows(const void* src, const int32_t* idx, const int32_t* count, voi
                   hipStream_t st);
 int k_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const int32_t* sel_tok, const float* sample_wgt, int S,
                  const int32_t* n_rows_dev, int n_rows_cap, int V, float* loss_sum, void* dlogits, float scale_base,
-                 int mean_over_rows, float* loss_out, hipStream_t st);
+                 int mean_over_rows, float* loss_out, hipStream_t st, float focal_gamma = 0.f);
 int k_score_fwd(const void* hidden, const int32_t* pool_row, const void* w, const void* bias, float* logits,
                 void* pooled_h, int B, int C, int d, hipStream_t st);
 int k_pool_rows(const void* hidden, const int32_t* pool_row, void* out, int B, int d, hipStream_t st);

@@ -596,13 +596,21 @@ __global__ void __launch_bounds__(kBlock) gather_rows_kernel(const bf16_t* __res
 // :180-198) fused with its backward: dlogits = (softmax - onehot) * w_row * scale.
 // One wave per row, block-level loss reduction, one atomic per block.
 // ---------------------------------------------------------------------------------------------
+// focal loss (utils_graphgpt.FocalLoss :340-376, chosen by config.focal_gamma > 0 in _get_ce_loss :158-160): the row's CE is
+// weighted by (1 - p_t)^gamma with p_t = exp(log p_t) DETACHED (the reference wraps it in Variable(logpt.data.exp())), so the
+// same factor scales the row's gradient.
+__device__ __forceinline__ float focal_weight(float logpt, float gamma) {
+  if (gamma <= 0.f) return 1.f;
+  const float om = fmaxf(1.f - __expf(logpt), 0.f);
+  return om > 0.f ? __builtin_amdgcn_exp2f(gamma * __log2f(om)) : 0.f;
+}
 __global__ void __launch_bounds__(kBlock) ce_fwd_bwd_kernel(const bf16_t* __restrict__ logits, int ld,
                                                             const int32_t* __restrict__ labels,
                                                             const int32_t* __restrict__ sel_tok,
                                                             const float* __restrict__ sample_wgt, int S,
                                                             const int32_t* __restrict__ n_rows_dev, int n_rows_cap, int V,
                                                             float* __restrict__ loss_sum, bf16_t* __restrict__ dlogits,
-                                                            float scale_base, int mean_over_rows) {
+                                                            float scale_base, int mean_over_rows, float focal_gamma) {
   __shared__ float part[kBlock / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_rows = min(n_rows_cap, n_rows_dev ? *n_rows_dev : n_rows_cap);
@@ -617,8 +625,8 @@ __global__ void __launch_bounds__(kBlock) ce_fwd_bwd_kernel(const bf16_t* __rest
     for (int j = lane; j < V; j += 64) se += __expf(bf2f(lp[j]) - mx);
     se = wave_sum(se);
     const int y = labels[row];
-    const float w = sample_wgt ? sample_wgt[sel_tok[row] / S] : 1.0f;
     const float lse = mx + __logf(se);
+    const float w = (sample_wgt ? sample_wgt[sel_tok[row] / S] : 1.0f) * focal_weight(bf2f(lp[y]) - lse, focal_gamma);
     if (lane == 0) local += w * (lse - bf2f(lp[y]));
     if (dlogits) {
       bf16_t* dp = dlogits + (size_t)row * ld;
@@ -650,7 +658,7 @@ __global__ void __launch_bounds__(kBlock) ce_rows_kernel(const bf16_t* __restric
                                                          const float* __restrict__ sample_wgt, int S,
                                                          const int32_t* __restrict__ n_rows_dev, int n_rows_cap, int V,
                                                          float* __restrict__ loss_sum, bf16_t* __restrict__ dlogits,
-                                                         float scale_base, int mean_over_rows) {
+                                                         float scale_base, int mean_over_rows, float focal_gamma) {
   __shared__ float part[kBlock / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_rows = min(n_rows_cap, n_rows_dev ? *n_rows_dev : n_rows_cap);
@@ -680,7 +688,7 @@ __global__ void __launch_bounds__(kBlock) ce_rows_kernel(const bf16_t* __restric
 #pragma unroll
       for (int e = 0; e < 8; ++e) { x[t][e] = __expf(x[t][e] - mx); se += x[t][e]; }   // exp(-inf) = 0 on the pad columns
     se = wave_sum(se);
-    const float w = sample_wgt ? sample_wgt[sel_tok[row] / S] : 1.0f;
+    const float w = (sample_wgt ? sample_wgt[sel_tok[row] / S] : 1.0f) * focal_weight(xy - (mx + __logf(se)), focal_gamma);
     if (lane == 0) local += w * (mx + __logf(se) - xy);
     if (dlogits) {
       bf16_t* dp = dlogits + (size_t)row * ld;
@@ -1519,12 +1527,12 @@ int k_gather_rows(const void* src, const int32_t* idx, const int32_t* count, voi
 
 int k_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const int32_t* sel_tok, const float* sample_wgt, int S,
                  const int32_t* n_rows_dev, int n_rows_cap, int V, float* loss_sum, void* dlogits, float scale_base,
-                 int mean_over_rows, float* loss_out, hipStream_t st) {
+                 int mean_over_rows, float* loss_out, hipStream_t st, float focal_gamma) {
   GGET_HIP_CHECK(hipMemsetAsync(loss_sum, 0, sizeof(float), st));
   if (n_rows_cap > 0) {
     const bool vec = (ld % 8) == 0 && ((uintptr_t)logits & 15) == 0 && ((uintptr_t)dlogits & 15) == 0 && getenv("GGET_CE_GENERIC") == nullptr;
 #define GGET_CE_ARGS (const bf16_t*)logits, ld, labels, sel_tok, sample_wgt, S, n_rows_dev, n_rows_cap, V, loss_sum, \
-                     (bf16_t*)dlogits, scale_base, mean_over_rows
+                     (bf16_t*)dlogits, scale_base, mean_over_rows, focal_gamma
     const dim3 grid(grid_for(n_rows_cap, 4 * 8, 2048));
     if (vec && ld <= 512) hipLaunchKernelGGL(ce_rows_kernel<1>, grid, dim3(kBlock), 0, st, GGET_CE_ARGS);
     else if (vec && ld <= 1024) hipLaunchKernelGGL(ce_rows_kernel<2>, grid, dim3(kBlock), 0, st, GGET_CE_ARGS);

@@ -193,6 +193,10 @@ class Engine:
         by set_dropout's seed)."""
         L.check(self.lib.gget_set_dropout_ex(self.h, float(embed_p), float(mlp_p), float(head_p)))
 
+    def set_focal_gamma(self, gamma: float = 0.0):
+        """config.focal_gamma: > 0 = focal loss on the SMTP head (un-weighted path)."""
+        L.check(self.lib.gget_set_focal_gamma(self.h, float(gamma)))
+
     def set_auc(self, num_neg: int = 1, seed: int = 0):
         """Negatives per positive and the sampling seed of the NEXT forward_task(problem=PROBLEM_AUC)."""
         L.check(self.lib.gget_set_auc(self.h, int(num_neg), int(seed) & 0xFFFFFFFF))

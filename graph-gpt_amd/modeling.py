@@ -74,7 +74,6 @@ class GraphGPTConfig:
         need(self.embed_dim == 0, "raw-embedding inputs (embed_dim>0)")
         need(self.stack_method in ("short", None), "stack_method='long'")
         need(not self.use_discriminative and self.use_generative, "contrastive (pretrain-cl) head")
-        need(self.focal_gamma == 0, "focal loss")
         need(self.rope_range == 0, "rope_range rescaling")
         need(len(self.mlp) <= 4, "an MLP score head with more than 4 hidden layers")
         need(self.pooling_method == "last", "pooling other than 'last'")
@@ -287,6 +286,8 @@ class _GgetModel(nn.Module):
         else:
             e.set_dropout(0.0, 0.0, 0)
         e.set_dropout_ex(pe, pm, ph)
+        if self.kind == KIND_PRETRAIN:
+            e.set_focal_gamma(float(getattr(self.config, "focal_gamma", 0.0) or 0.0))
         return e
 
     def _autograd_backward(self, g):

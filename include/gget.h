@@ -131,6 +131,11 @@ int gget_set_dropout(gget_handle_t h, float attention_p, float path_p, uint32_t 
  * dropout between activation and Linear inside the MLP score head (src/utils/modules_utils.py:27-33). */
 int gget_set_dropout_ex(gget_handle_t h, float embed_p, float mlp_p, float head_p);
 
+/* replaces: `config.focal_gamma` (configs/training/base.yaml:60): > 0 turns the SMTP head's mean cross-entropy into the focal loss
+ * of utils_graphgpt.FocalLoss (:340-376) - every row weighted by (1 - p_target)^gamma, the weight detached as in the reference.
+ * Applies to gget_forward_pretrain[_packed] without sample_wgt (_get_ce_loss, modeling_helpers.py:158-160). */
+int gget_set_focal_gamma(gget_handle_t h, float gamma);
+
 /* replaces: `config.num_neg` + the torch RNG behind `torch.randperm` in auc_loss (src/utils/loss_utils.py:25-43): negatives per
  * positive and the seed of the counter-hash permutation the NEXT gget_forward_task(problem_type = GGET_PROBLEM_AUC) draws its
  * negative samples with (idx = perm(P * num_neg) % N_neg; perm = rank of the hashed keys). */

@@ -171,7 +171,7 @@ def backbone(spec, p: Dict[str, torch.Tensor], x, attention_mask, position_ids, 
 
 
 # --------------------------------------------------------------------------- K11-K14 (rows A5-A7)
-def smtp_head(spec, p, hidden, labels, sample_wgt=None):
+def smtp_head(spec, p, hidden, labels, sample_wgt=None, focal_gamma=0.0):
     """`prepare_for_stacked_feat_labels` (modeling_helpers.py:362-393), "short" stacking:
     no wgt -> `_prepare_for_stacked_feat_labels_per_mix_lvl` (:263-301);
     wgt    -> `_prepare_for_stacked_feat_labels_wgt_per_feat_lvl` (:345-359);
@@ -207,7 +207,11 @@ def smtp_head(spec, p, hidden, labels, sample_wgt=None):
     logits = Fnn.linear(hs, p["lm_head.weight"])
     loss = None
     if labels is not None:
-        if wgt is None:
+        if wgt is None and focal_gamma > 0:
+            # utils_graphgpt.FocalLoss.forward (:356-376): -(1 - pt)^gamma * log pt, pt DETACHED, mean over the rows
+            logpt = Fnn.log_softmax(logits.float(), dim=-1).gather(1, labels.view(-1, 1)).view(-1)
+            loss = (-1 * (1 - logpt.detach().exp()) ** focal_gamma * logpt).mean()
+        elif wgt is None:
             loss = Fnn.cross_entropy(logits.float(), labels)
         else:
             l_ = Fnn.cross_entropy(logits.float(), labels, reduction="none")
@@ -216,11 +220,11 @@ def smtp_head(spec, p, hidden, labels, sample_wgt=None):
 
 
 def pretrain_forward(spec, p, input_ids, attention_mask, labels=None, sample_wgt=None,
-                     position_ids=None, collect=None, embed_keep=None, mlp_keep=None):
+                     position_ids=None, collect=None, embed_keep=None, mlp_keep=None, focal_gamma=0.0):
     """`GraphGPTPretrainBase.forward` (modeling_pretrain.py:152-266), generative head only."""
     x, _ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"), embed_keep=embed_keep)
     hidden = backbone(spec, p, x, attention_mask, position_ids, collect, mlp_keep=mlp_keep)
-    loss, logits = smtp_head(spec, p, hidden, labels, sample_wgt)
+    loss, logits = smtp_head(spec, p, hidden, labels, sample_wgt, focal_gamma=focal_gamma)
     return dict(head1_loss=loss, head1_logits=logits, hidden=hidden)
 
 

@@ -1069,3 +1069,46 @@ def test_mlp_score_head_matches_oracle_eval_and_training_dropout():
     hk = lambda i: torch.from_numpy(M.elem_drop_keep(model.last_dropout_seed, "head", i, B, dims[i], pd))
     l_train = compare("train", out, hk)
     assert abs(l_train - l_eval) > 1e-3 * abs(l_eval)
+
+
+@pytest.mark.gpu
+def test_focal_loss_matches_reference_and_oracle():
+    """config.focal_gamma = 2 through the drop-in class (FocalLoss, utils_graphgpt.py:340-376): loss against the reference
+    fixture at the pre-train tolerance rule's floor for bf16 (2e-3), gradients against the oracle."""
+    import os
+    from _util import GOLDEN, spec_mod, weights_mod
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    z = np.load(os.path.join(GOLDEN, "pt_tiny_focal.npz"))
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=756, stacked_feat=13, next_n_token=13)
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    gamma = float(z["gamma"])
+    cfg = M.GraphGPTConfig(vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+                           num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
+                           max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=13, next_n_token=13,
+                           focal_gamma=gamma)
+    model = M.GraphGPTPretrainBase(cfg, seed=1)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model.eval()
+    out = model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=b["labels"])
+    loss = float(out.head1_loss.item())
+    out.head1_loss.backward()
+    record_error("pt_tiny_focal", "loss_rel_vs_reference_fp32", abs(loss - float(z["loss"])) / float(z["loss"]), 2e-3)
+    assert abs(loss - float(z["loss"])) <= 2e-3 * float(z["loss"]), (loss, float(z["loss"]))
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32)
+    fn = lambda q: O.pretrain_forward(spec, q, b["input_ids"], b["attention_mask"], b["labels"], focal_gamma=gamma)
+    o, grads = O.loss_and_grads(fn, p, "head1_loss")
+    got = model._engine.grads()
+    gmax = max(float(g.norm()) for g in grads.values())
+    for k in ("lm_head.weight", "n_token_proj.weight", "model.layers.0.self_attn.q_proj.weight", "model.layers.1.mlp.down_proj.weight",
+              "model.embed_tokens.weight"):
+        w = grads[k].numpy()
+        err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        record_error("pt_tiny_focal", "grad_rel_l2 " + k, err, 6e-2)
+        assert err < 6e-2, f"{k}: {err}"
+    # gamma = 0 is the plain cross-entropy again
+    model.config.focal_gamma = 0.0
+    plain = float(model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=b["labels"]).head1_loss.item())
+    assert plain - loss > 5e-4 * loss          # (1 - p_t)^2 < 1: slightly below the plain CE at this (near-uniform) init

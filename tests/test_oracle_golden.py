@@ -348,3 +348,26 @@ def test_oracle_mlp_score_head_matches_reference():
     assert abs(out2["task_loss"].item() - float(z["train_loss"])) <= 1e-5 * abs(float(z["train_loss"]))
     assert np.linalg.norm(grads2["score.mlp_modules.0.weight"].numpy() - z["train_grad_w0"]) <= 2e-4 * np.linalg.norm(z["train_grad_w0"])
     np.testing.assert_allclose(np.array([float(grads2[str(n)].norm()) for n in z["names"]]), z["train_grad_norms"], rtol=5e-4, atol=1e-7)
+
+
+def _focal_case():
+    from _util import GOLDEN, spec_mod, weights_mod
+    z = np.load(os.path.join(GOLDEN, "pt_tiny_focal.npz"))
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=756, stacked_feat=13, next_n_token=13)
+    assert [int(x) for x in z["meta_spec"]] == list(spec.as_c_ints())
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    return z, spec, state, b
+
+
+def test_oracle_focal_loss_matches_reference():
+    """config.focal_gamma = 2 (utils_graphgpt.FocalLoss through _get_ce_loss): loss and gradients of the reference."""
+    z, spec, state, b = _focal_case()
+    p = O.to_params(state, torch.float32)
+    fn = lambda q: O.pretrain_forward(spec, q, b["input_ids"], b["attention_mask"], b["labels"], focal_gamma=float(z["gamma"]))
+    out, grads = O.loss_and_grads(fn, p, "head1_loss")
+    assert abs(out["head1_loss"].item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    for k, want in (("lm_head.weight", z["grad_lm_head"]), ("model.layers.0.self_attn.q_proj.weight", z["grad_l0_q"])):
+        assert np.linalg.norm(grads[k].numpy() - want) <= 2e-4 * np.linalg.norm(want), k
+    np.testing.assert_allclose(np.array([float(grads[str(n)].norm()) for n in z["names"]]), z["grad_norms"], rtol=5e-4, atol=1e-7)

@@ -677,6 +677,32 @@ def mlp_head_fixture():
     print(f"ft_tiny_mlphead written: eval loss {res['loss']:.6f}, train loss {res['train_loss']:.6f}")
 
 
+def focal_fixture():
+    """config.focal_gamma = 2 (FocalLoss, utils_graphgpt.py:340-376, through _get_ce_loss :158-160): the reference's pre-train
+    loss and gradients on a seeded batch."""
+    PT, FT, Cfg = import_reference()
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=756, stacked_feat=13, next_n_token=13)
+    state = weights_mod.make_state_dict(spec, seed=911, std=0.06, head_std=0.15)
+    batch = synth.make_pretrain_batch(B=4, S=24, F=13, V=756, seed=91)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    model = PT(ref_config(Cfg, spec, focal_gamma=2.0))
+    load_weights(model, state)
+    model.eval()
+    o = model(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"], labels=tb["labels"], inputs_raw_embeds=None)
+    model.zero_grad()
+    o.head1_loss.backward()
+    names = list(state.keys())
+    g = dict(model.named_parameters())
+    res = {"loss": np.float64(o.head1_loss.item()), "gamma": np.float64(2.0), "grad_norms": grad_norms(model, names),
+           "names": np.array(names), "grad_lm_head": g["lm_head.weight"].grad.numpy().copy(),
+           "grad_l0_q": g["model.layers.0.self_attn.q_proj.weight"].grad.numpy().copy(),
+           "meta_spec": np.array(spec.as_c_ints(), np.int64), "meta_init": np.array([911, 0.06, 0.15])}
+    for k, v in batch.items():
+        res["in_" + k] = v
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "pt_tiny_focal.npz"), **res)
+    print(f"pt_tiny_focal written: loss {res['loss']:.6f}")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -704,6 +730,8 @@ def main():
         dropout_fixture()
     if not only or "ft_tiny_mlphead" in only:
         mlp_head_fixture()
+    if not only or "pt_tiny_focal" in only:
+        focal_fixture()
 
 
 if __name__ == "__main__":

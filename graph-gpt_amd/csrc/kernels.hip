@@ -174,6 +174,22 @@ __global__ void __launch_bounds__(128) embed_reduce_kernel(const int32_t* __rest
   for (int c = threadIdx.x; c * 8 < d; c += blockDim.x) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int cur = id_sorted[beg];
+    // a run of equal ids that lies inside this segment is the ONLY contribution of this launch to its row of the accumulator: a
+    // plain 32-byte read-add-store; only the runs cut by a segment boundary need atomics (large vocabularies: most runs are a few cells, and
+    // 768 fp32 atomics per run were the whole cost of this kernel at V = 41 245)
+    auto flush = [&](int id, const float (&a)[8]) {
+      float* dst = demb + (size_t)id * d + c * 8;
+      if (offs[id] >= beg && offs[id + 1] <= end) {      // (read-add-store: the entry point accumulates into demb)
+        float4 lo = *reinterpret_cast<const float4*>(dst), up = *reinterpret_cast<const float4*>(dst + 4);
+        lo.x += a[0]; lo.y += a[1]; lo.z += a[2]; lo.w += a[3];
+        up.x += a[4]; up.y += a[5]; up.z += a[6]; up.w += a[7];
+        *reinterpret_cast<float4*>(dst) = lo;
+        *reinterpret_cast<float4*>(dst + 4) = up;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dst + e, a[e]);
+      }
+    };
     // the rows of one segment are independent loads: fetch them eight at a time before the (ordered) accumulation
     for (int j0 = beg; j0 < end; j0 += 8) {
       int idv[8], cellv[8];
@@ -190,9 +206,9 @@ __global__ void __launch_bounds__(128) embed_reduce_kernel(const int32_t* __rest
       for (int u = 0; u < 8; ++u) {
         if (j0 + u >= end) break;
         if (idv[u] != cur) {
-          float* dst = demb + (size_t)cur * d + c * 8;
+          flush(cur, acc);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { unsafeAtomicAdd(dst + e, acc[e]); acc[e] = 0.f; }
+          for (int e = 0; e < 8; ++e) acc[e] = 0.f;
           cur = idv[u];
         }
         float g[8];
@@ -212,9 +228,7 @@ __global__ void __launch_bounds__(128) embed_reduce_kernel(const int32_t* __rest
         }
       }
     }
-    float* dst = demb + (size_t)cur * d + c * 8;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dst + e, acc[e]);
+    flush(cur, acc);
   }
 }
 // Small vocabularies, plain (un-gated) stacking: the scatter-add is the dense product dE = C^T dX with the count matrix
@@ -889,7 +903,8 @@ __global__ void __launch_bounds__(kBlock) scatter_rows_f32_kernel(const float* _
 }
 
 // backward of the score head: dW[c,:] += sum_b dl[b,c] h[row_b,:], dbias[c] += sum_b dl[b,c],
-// dhidden[row_b,:] = sum_c dl[b,c] W[c,:] (dhidden pre-zeroed).  grid = B + C blocks.
+// dhidden[row_b,:] = sum_c dl[b,c] W[c,:] (dhidden pre-zeroed).  grid = B + C * kScoreSplit blocks.
+constexpr int kScoreSplit = 16;
 __global__ void __launch_bounds__(kBlock) score_bwd_kernel(const float* __restrict__ dlogits, const bf16_t* __restrict__ hidden,
                                                            const int32_t* __restrict__ pool_row, const bf16_t* __restrict__ w,
                                                            float* __restrict__ dw, float* __restrict__ dbias,
@@ -902,16 +917,19 @@ __global__ void __launch_bounds__(kBlock) score_bwd_kernel(const float* __restri
       dhidden[(size_t)pool_row[b] * d + j] = f2bf(s);
     }
   } else {
-    const int c = blockIdx.x - B;
+    // the batch is cut into kScoreSplit slices per class (one block walking 256+ pooled rows alone took 0.2 ms)
+    const int c = (blockIdx.x - B) / kScoreSplit, sl = (blockIdx.x - B) % kScoreSplit;
+    const int per = (B + kScoreSplit - 1) / kScoreSplit, b0 = sl * per, b1 = min(B, b0 + per);
+    if (b0 >= b1) return;
     for (int j = threadIdx.x; j < d; j += kBlock) {
       float s = 0.f;
-      for (int b = 0; b < B; ++b) s += dlogits[b * C + c] * bf2f(hidden[(size_t)pool_row[b] * d + j]);
-      dw[(size_t)c * d + j] += s;
+      for (int b = b0; b < b1; ++b) s += dlogits[b * C + c] * bf2f(hidden[(size_t)pool_row[b] * d + j]);
+      unsafeAtomicAdd(dw + (size_t)c * d + j, s);
     }
     if (threadIdx.x == 0 && dbias) {
       float s = 0.f;
-      for (int b = 0; b < B; ++b) s += dlogits[b * C + c];
-      dbias[c] += s;
+      for (int b = b0; b < b1; ++b) s += dlogits[b * C + c];
+      unsafeAtomicAdd(dbias + c, s);
     }
   }
 }
@@ -1654,7 +1672,7 @@ int k_scatter_rows_f32(const float* src, const int32_t* pool_row, void* dhidden,
 
 int k_score_bwd(const float* dlogits, const void* hidden, const int32_t* pool_row, const void* w, float* dw, float* dbias,
                 void* dhidden, int B, int C, int d, hipStream_t st) {
-  hipLaunchKernelGGL(score_bwd_kernel, dim3(B + C), dim3(kBlock), 0, st, dlogits, (const bf16_t*)hidden, pool_row,
+  hipLaunchKernelGGL(score_bwd_kernel, dim3(B + C * kScoreSplit), dim3(kBlock), 0, st, dlogits, (const bf16_t*)hidden, pool_row,
                      (const bf16_t*)w, dw, dbias, (bf16_t*)dhidden, B, C, d);
   GGET_LAUNCH_CHECK();
   return 0;

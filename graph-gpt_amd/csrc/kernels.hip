@@ -278,37 +278,57 @@ __global__ void __launch_bounds__(128) embed_dgate_kernel(const int64_t* __restr
 // K4  RMSNorm (hf LlamaRMSNorm.forward :62-67): y = w * bf16(x * rsqrt(mean(x^2)+eps)); one wave per row.
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxChunksPerLane = 4;  // d <= 2048
+// NCH = 16-byte chunks per lane (2 covers d <= 1024).  A wave walks its rows with the NEXT row's loads already in flight
+// while it reduces / scales / stores the current one (one row at a time the kernel ran at 3.2-3.8 TB/s).
+template <int NCH>
 __global__ void __launch_bounds__(kBlock) rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                              bf16_t* __restrict__ y, float* __restrict__ rstd_out,
                                                              int T, int d, float eps) {
   const int lane = threadIdx.x & 63;
   const int nchunk = d >> 3;
-  for (int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); row < T; row += gridDim.x * (kBlock / 64)) {
-    float v[kMaxChunksPerLane][8];
+  const int stride = gridDim.x * (kBlock / 64);
+  int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  uint4 cur[NCH], nxt[NCH];
+  float wv[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    cur[i] = make_uint4(0, 0, 0, 0);
+    if (c < nchunk) {
+      unpack8(ldg16(w + c * 8), wv[i]);
+      if (row < T) cur[i] = ldg16(x + (size_t)row * d + c * 8);
+    }
+  }
+  for (; row < T; row += stride) {
+    const int nrow = row + stride;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      nxt[i] = (c < nchunk && nrow < T) ? ldg16(x + (size_t)nrow * d + c * 8) : make_uint4(0, 0, 0, 0);
+    }
+    float v[NCH][8];
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxChunksPerLane; ++i) {
-      const int c = lane + i * 64;
-      if (c < nchunk) {
-        unpack8(ldg16(x + (size_t)row * d + c * 8), v[i]);
+    for (int i = 0; i < NCH; ++i) {
+      unpack8(cur[i], v[i]);      // (chunks beyond the row are zero)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
-      }
+      for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
     }
     ss = wave_sum(ss);
     const float rstd = rsqrtf(ss / (float)d + eps);
     if (lane == 0 && rstd_out) rstd_out[row] = rstd;
 #pragma unroll
-    for (int i = 0; i < kMaxChunksPerLane; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int c = lane + i * 64;
       if (c < nchunk) {
-        float wv[8], o[8];
-        unpack8(ldg16(w + c * 8), wv);
+        float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = wv[e] * bf2f(f2bf(v[i][e] * rstd));
+        for (int e = 0; e < 8; ++e) o[e] = wv[i][e] * bf2f(f2bf(v[i][e] * rstd));
         stg16(y + (size_t)row * d + c * 8, pack8(o));
       }
     }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) cur[i] = nxt[i];
   }
 }
 
@@ -1460,8 +1480,10 @@ int k_embed_count(const int64_t* ids, void* cnt, int T, int F, int ldF, int ldc,
 int k_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, hipStream_t st) {
   GGET_REQUIRE(d % 8 == 0 && d <= 64 * 8 * kMaxChunksPerLane, "rmsnorm: d=%d unsupported", d);
   if (T == 0) return 0;
-  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(grid_for(T, 4, 2048)), dim3(kBlock), 0, st, (const bf16_t*)x,
-                     (const bf16_t*)w, (bf16_t*)y, rstd, T, d, eps);
+  if (d <= 1024) hipLaunchKernelGGL(rmsnorm_fwd_kernel<2>, dim3(grid_for(T, 4, 2048)), dim3(kBlock), 0, st, (const bf16_t*)x,
+                                    (const bf16_t*)w, (bf16_t*)y, rstd, T, d, eps);
+  else hipLaunchKernelGGL(rmsnorm_fwd_kernel<kMaxChunksPerLane>, dim3(grid_for(T, 4, 2048)), dim3(kBlock), 0, st, (const bf16_t*)x,
+                          (const bf16_t*)w, (bf16_t*)y, rstd, T, d, eps);
   GGET_LAUNCH_CHECK();
   return 0;
 }

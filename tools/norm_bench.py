@@ -3,7 +3,7 @@ import ctypes as C, importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = importlib.import_module("graph-gpt_amd._lib"); lib = L.load()
 P = lambda t: C.c_void_p(t.data_ptr()); st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-T, d = 8192, 768
+T, d = int(os.environ.get("T", 8192)), 768
 x = torch.randn(T, d, device="cuda").to(torch.bfloat16); w = torch.ones(d, device="cuda").to(torch.bfloat16)
 dy = torch.randn(T, d, device="cuda").to(torch.bfloat16); dres = torch.randn(T, d, device="cuda").to(torch.bfloat16)
 y = torch.empty_like(x); dx = torch.empty_like(x); rstd = torch.empty(T, device="cuda"); dw = torch.zeros(d, device="cuda")

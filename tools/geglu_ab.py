@@ -8,7 +8,7 @@ lib = L.load()
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 variants = [int(x, 0) for x in sys.argv[1:]] or [0]
-T, d, ff = 8192, 768, 3072
+T, d, ff = int(os.environ.get("T", 8192)), 768, 3072
 g = torch.Generator(device="cuda").manual_seed(0)
 rn = lambda *s, sc=1.0: (torch.randn(*s, device="cuda", generator=g) * sc).to(torch.bfloat16)
 x, wgu, wdown, dy, wqkv = rn(T, d), rn(2 * ff, d, sc=0.05), rn(d, ff, sc=0.05), rn(T, d), rn(3 * d, d, sc=0.05)

@@ -862,13 +862,16 @@ __global__ void __launch_bounds__(NWB * 64, QT == 1 ? 4 : 2) attn_fwd64_kernel(c
   const int klen = PK ? S : len;
   const int q_end_blk = min(S, (int)(blockIdx.x + 1) * QB);
   int kbeg_blk = 0, kend_blk = causal ? min(klen, q_end_blk) : klen;
+  // right padding: queries at or beyond the row's length are padding rows - nothing downstream reads their outputs and their
+  // upstream gradient is zero - so a block (and below, a wave) made of them alone does no work and writes zeros
+  if (!PK && (int)(blockIdx.x * QB) >= len) kend_blk = 0;
   if (PK) {
     int blo = ulo, bhi = uhi;
     block_range(blo, bhi, red, wave, lane);
     kbeg_blk = min(max(blo, 0), S) & ~63;
     kend_blk = min(kend_blk, bhi + 1);
   }
-  const int kend = (q0 < S) ? min(uhi + 1, causal ? q0 + QT * 32 : S) : 0;   // this wave's own key range
+  const int kend = (q0 < S && (PK || q0 < len)) ? min(uhi + 1, causal ? q0 + QT * 32 : S) : 0;   // this wave's own key range
 
   bf16x8_t qf[QT][4];
   f32x16_t o0[QT], o1[QT];
@@ -1036,7 +1039,11 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 8 ? 4 : 3) attn_fwd_dense_ker
   const bf16_t* kb = qb + d;
   const bf16_t* vb = qb + 2 * d;
   const int qrow = q0 + l31;
-  const int len = key_len ? min(key_len[b], S) : S;
+  const int row_len = key_len ? min(key_len[b], S) : S;
+  // right padding: queries at or beyond the row's length are padding rows (nothing downstream reads their outputs): a block made of
+  // them alone sees an empty key range and writes zeros, a wave made of them alone only feeds the DMA and the barriers
+  const int len = (int)(blockIdx.x * QB) < row_len ? row_len : 0;
+  const bool w_act = q0 < row_len;                   // wave-uniform
   const int nfull = len >> 5;                        // tiles whose 32 keys are all visible
   const int ntile = (len + 31) >> 5;
   const int nst = (ntile + 1) >> 1;
@@ -1214,14 +1221,16 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 8 ? 4 : 3) attn_fwd_dense_ker
     const uint4 z = make_uint4(0, 0, 0, 0);
     pB[0] = pB[1] = pA[0] = pA[1] = __builtin_bit_cast(bf16x8_t, z);
   }
-  if (ntile > 0) qk(kr[0], sA);
+  if (ntile > 0 && w_act) qk(kr[0], sA);
   auto stage = [&](int t, auto SL) {
     constexpr int sl = decltype(SL)::value, s1 = (sl + 1) % 3, s2 = (sl + 2) % 3;
     attn_vm_wait0();                // K(t+1), V(t): issued one stage ago
     __syncthreads();                // ... by everyone; everyone is past stage t-1
     issue(t, kr[s2], vr[s1]);
-    step(64 * t, kr[sl] + 4096, vr[s2] + 4096, sA, sB, pB, pA);           // tile 2t:   K tile 2t+1, V tile 2t-1
-    step(64 * t + 32, kr[s1], vr[sl], sB, sA, pA, pB);                    // tile 2t+1: K tile 2t+2, V tile 2t
+    if (w_act) {
+      step(64 * t, kr[sl] + 4096, vr[s2] + 4096, sA, sB, pB, pA);         // tile 2t:   K tile 2t+1, V tile 2t-1
+      step(64 * t + 32, kr[s1], vr[sl], sB, sA, pA, pB);                  // tile 2t+1: K tile 2t+2, V tile 2t
+    }
   };
   int t = 0;
   while (t < nfs) {
@@ -1234,13 +1243,13 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 8 ? 4 : 3) attn_fwd_dense_ker
     attn_vm_wait0();
     __syncthreads();
   }
-  if (nfs > 0) pv(vr[(nfs - 1) % 3] + 4096, pB);
+  if (nfs > 0 && w_act) pv(vr[(nfs - 1) % 3] + 4096, pB);
   const int jt = 2 * nfs;
-  if (jt < ntile) {
+  if (jt < ntile && w_act) {
     rescale(softmax_seq(32 * jt, jt >= nfull, sA, pA));
     pv(vr[nfs % 3], pA);
   }
-  if (jt + 1 < ntile) {
+  if (jt + 1 < ntile && w_act) {
     qk(kr[nfs % 3] + 4096, sB);
     rescale(softmax_seq(32 * jt + 32, true, sB, pB));
     pv(vr[nfs % 3] + 4096, pB);
@@ -1285,13 +1294,16 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 4) attn_bwd_dq64_kern
   const int klen = PK ? S : len;
   const int q_end_blk = min(S, (int)(blockIdx.x + 1) * QB);
   int kbeg_blk = 0, kend_blk = causal ? min(klen, q_end_blk) : klen;
+  // right padding: queries at or beyond the row's length are padding rows - nothing downstream reads their outputs and their
+  // upstream gradient is zero - so a block (and below, a wave) made of them alone does no work and writes zeros
+  if (!PK && (int)(blockIdx.x * QB) >= len) kend_blk = 0;
   if (PK) {
     int blo = ulo, bhi = uhi;
     block_range(blo, bhi, red, wave, lane);
     kbeg_blk = min(max(blo, 0), S) & ~63;
     kend_blk = min(kend_blk, bhi + 1);
   }
-  const int kend = (q0 < S) ? min(uhi + 1, causal ? q0 + 32 : S) : 0;
+  const int kend = (q0 < S && (PK || q0 < len)) ? min(uhi + 1, causal ? q0 + 32 : S) : 0;
 
   bf16x8_t qf[4], dof[4];
 #pragma unroll
@@ -1444,7 +1456,8 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 2) attn_bwd_dkv64_ker
   const bool key_ok = krow < klen;
   const int kblk0 = blockIdx.x * KB;
   const int qbeg = causal ? (kblk0 & ~63) : 0;     // queries before the block's first key never see it
-  const int nst = (kblk0 < klen && qbeg < S) ? (S - qbeg + 63) >> 6 : 0;
+  const int qlim = PK ? S : min(S, klen);          // right padding: queries beyond the row's length carry a zero upstream gradient
+  const int nst = (kblk0 < klen && qbeg < qlim) ? (qlim - qbeg + 63) >> 6 : 0;
   constexpr int PPW = 16 / NWB;
   auto issue = [&](int buf, int r0) {
 #pragma unroll

@@ -1421,6 +1421,20 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 4) attn_bwd_dq64_kern
   }
 }
 
+#ifdef GGET_ATTN_STAMPS
+// measurement build only (tools/attn_stamps.sh): s_memtime stamps of block (0,0,0)'s waves in the dK/dV kernel,
+// [wave][stage][point]: 0 stage top, 1 past wait + barrier, 2 DMA issued, then per tile j (3 + 5 j): fragments + S/dP MFMAs issued,
+// exponentials done, dS done, operands packed, dV/dK MFMAs issued
+__device__ unsigned long long g_attn_stamps[8][40][16];
+#define GGET_STAMP(pt)                                                                                   \
+  do {                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if (stamp_on && t < 40 && lane == 0) g_attn_stamps[wave][t][pt] = __builtin_amdgcn_s_memtime();       \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  } while (0)
+#else
+#define GGET_STAMP(pt) do { } while (0)
+#endif
 // dK / dV for long sequences: a wave owns a 32-key tile (K and V fragments in registers), Q and dO are streamed in 64-query
 // stages together with the queries' lse / delta (and key ranges for packed rows).
 template <bool PK, int NWB>
@@ -1473,8 +1487,8 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 2) attn_bwd_dkv64_ker
   auto fetch_vec = [&](int r0) {
     if (tid < 64) {
       const int q = min(r0 + tid, S - 1);
-      p_lse = -lse[((size_t)b * H + h) * S + q] * kLog2e;
-      p_dl = -delta[((size_t)b * H + h) * S + q] * kScale;
+      p_lse = lse[((size_t)b * H + h) * S + q];          // raw: the scaling waits for commit_vec (no wait for the load here)
+      p_dl = delta[((size_t)b * H + h) * S + q];
       if (PK) {
         const bool v = r0 + tid < S;
         p_lo = v ? KR.lo[(size_t)b * S + q] : 0;
@@ -1484,17 +1498,28 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 2) attn_bwd_dkv64_ker
   };
   auto commit_vec = [&](int buf) {
     if (tid < 64) {
-      lse_s[buf][tid] = p_lse; dl_s[buf][tid] = p_dl;
+      lse_s[buf][tid] = -p_lse * kLog2e; dl_s[buf][tid] = -p_dl * kScale;
       if (PK) { qlo_s[buf][tid] = p_lo; qhi_s[buf][tid] = p_hi; }
     }
   };
   if (nst > 0) { issue(0, qbeg); fetch_vec(qbeg); commit_vec(0); }
   const float keep_k = D.inv_keep * kScale;
+#ifdef GGET_ATTN_STAMPS
+  const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+#endif
   for (int t = 0; t < nst; ++t) {
     const int qs = qbeg + t * 64;
+    GGET_STAMP(0);
     attn_vm_wait0();
     __syncthreads();
-    if (t + 1 < nst) { issue((t + 1) & 1, qs + 64); fetch_vec(qs + 64); }
+    GGET_STAMP(1);
+    // Waves w and w + 4 share a SIMD and leave the barrier together: in lock-step their MFMA phases collide and then their
+    // VALU phases do (stamps: every phase takes twice its own time).  The upper four issue the next stage's DMA now (~600
+    // cycles of address-path queueing), the lower four behind their first MFMA group - half a phase apart from then on.
+    const bool dma_late = wave < NWB / 2;
+    bool dma_due = t + 1 < nst;
+    if (dma_due && !dma_late) { issue((t + 1) & 1, qs + 64); fetch_vec(qs + 64); dma_due = false; }
+    GGET_STAMP(2);
     const unsigned char* qst = st[t & 1];
     const unsigned char* dst_ = qst + 8192;
     const int vb_ = t & 1;
@@ -1518,6 +1543,8 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 2) attn_bwd_dkv64_ker
         sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, s, lane), kf[s], sc, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dot_, s, lane), vf[s], dp, 0, 0, 0);
       }
+      if (dma_due) { issue((t + 1) & 1, qs + 64); fetch_vec(qs + 64); dma_due = false; }
+      GGET_STAMP(3 + 5 * j);
       // the lane's 16 queries are 4 runs of 4 consecutive rows: the per-query scalars come as 4 + 4 ds_read_b128
       float nl[16], dlv[16];
 #pragma unroll
@@ -1529,6 +1556,7 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 2) attn_bwd_dkv64_ker
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[r] = fast_exp2(fmaf(sc[r], kScaleL2, nl[r]));
+      GGET_STAMP(4 + 5 * j);
       if (edge) {
         int q0v = q0;
         asm volatile("" : "+v"(q0v));
@@ -1554,8 +1582,10 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 2) attn_bwd_dkv64_ker
           sc[r] = drop ? 0.f : sc[r] * D.inv_keep;      // dropped probabilities: what multiplied V in forward
         }
       }
+      GGET_STAMP(5 + 5 * j);
       const bf16x8_t p0 = acc_to_b(sc, 0), p1 = acc_to_b(sc, 1);
       const bf16x8_t s0 = acc_to_b(dp, 0), s1 = acc_to_b(dp, 1);
+      GGET_STAMP(6 + 5 * j);
       dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 0, lane), p0, dv0, 0, 0, 0);
       dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 1, lane), p1, dv0, 0, 0, 0);
       dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 1, 0, lane), p0, dv1, 0, 0, 0);
@@ -1564,7 +1594,9 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 2) attn_bwd_dkv64_ker
       dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 0, 1, lane), s1, dk0, 0, 0, 0);
       dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 0, lane), s0, dk1, 0, 0, 0);
       dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 1, lane), s1, dk1, 0, 0, 0);
+      GGET_STAMP(7 + 5 * j);
     }
+    if (dma_due) { issue((t + 1) & 1, qs + 64); fetch_vec(qs + 64); }     // (both tiles of the stage skipped)
     if (t + 1 < nst) commit_vec((t + 1) & 1);
   }
   if (krow < S) {
@@ -1677,3 +1709,11 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
   GGET_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef GGET_ATTN_STAMPS
+extern "C" int gget_debug_attn_stamps(unsigned long long* host_out /* [8][40][16] */) {
+  GGET_HIP_CHECK(hipDeviceSynchronize());
+  GGET_HIP_CHECK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * 8 * 40 * 16));
+  return 0;
+}
+#endif

@@ -311,6 +311,15 @@ struct gget_engine {
   int problem = 0;
   int auc_num_neg = 1;
   float focal_gamma = 0.f;        // focal loss on the SMTP head (config.focal_gamma)
+  // in-step kernel probe (gget_debug_probe): HIP events around the grouped weight-gradient launch [0] and the gate|up + GEGLU launch [1]
+  // of every layer, on the stream they are launched on - the bench reads the launch durations INSIDE a step from them
+  bool probe = false;
+  std::vector<hipEvent_t> probe_ev[2];
+  hipEvent_t probe_event(int which, int idx) {
+    auto& v = probe_ev[which];
+    while ((int)v.size() <= idx) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; v.push_back(e); }
+    return v[idx];
+  }
   unsigned auc_seed = 0;
   bool fwd_valid = false;
   float attn_drop_p = 0.f;        // attention dropout of the NEXT forward (training mode); 0 = off
@@ -693,7 +702,9 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
   }
   if (int e = gemm_nt(attn, h->P + lo.wo, xmid, x_in, T, d, d, d, d, d, nullptr, st)) return e;
   if (int e = k_rmsnorm_fwd(xmid, h->P + lo.ln2, xn2, h->wsp<float>(lw.rstd2), T, d, c.rms_eps, st)) return e;
+  if (h->probe) GGET_HIP_CHECK(hipEventRecord(h->probe_event(1, 2 * i), st));
   if (int e = gateup_geglu(xn2, h->P + lo.wgu, gu, hh, T, d, ff, st)) return e;
+  if (h->probe) GGET_HIP_CHECK(hipEventRecord(h->probe_event(1, 2 * i + 1), st));
   if (int e = gemm_nt(hh, h->P + lo.wdown, x_out, xmid, T, d, ff, ff, ff, d, nullptr, st)) return e;
   return 0;
 }
@@ -919,7 +930,9 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
     g.p[1] = wg_dn;
     g.p[2] = GemmProblem{dqkv, h->wsp<bf16_t>(lw.xn1), h->G + lo.wqkv, nullptr, 3 * d, d, T, 3 * d, d, d, nullptr, nullptr, 0, 0};
     g.p[3] = GemmProblem{dy_o, h->wsp<bf16_t>(lw.attn), h->G + lo.wo, nullptr, d, d, T, d, d, d, nullptr, nullptr, 0, 0};
+    if (h->probe) GGET_HIP_CHECK(hipEventRecord(h->probe_event(0, 2 * i), st));
     if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_NONE, g, 1, st)) return e;
+    if (h->probe) GGET_HIP_CHECK(hipEventRecord(h->probe_event(0, 2 * i + 1), st));
   } else {
     {
       GemmGroup g;
@@ -1148,6 +1161,25 @@ extern "C" int gget_debug_occupy(void* scratch, uint64_t scratch_bytes, int bloc
 
 extern int g_gemm_variant;
 extern int g_gemm_lds_headroom;
+extern "C" int gget_debug_probe(gget_handle_t h, int enable, float* avg_ms_out /* [2] or NULL */) {
+  GGET_REQUIRE(h != nullptr, "null handle");
+  if (avg_ms_out) {   // mean launch duration over the layers of the last forward / backward that ran with the probe on
+    for (int w = 0; w < 2; ++w) {
+      double sum = 0.0;
+      int n = 0;
+      for (size_t k = 0; k + 1 < h->probe_ev[w].size(); k += 2) {
+        float ms = 0.f;
+        if (hipEventSynchronize(h->probe_ev[w][k + 1]) == hipSuccess && hipEventElapsedTime(&ms, h->probe_ev[w][k], h->probe_ev[w][k + 1]) == hipSuccess) {
+          sum += ms;
+          ++n;
+        }
+      }
+      avg_ms_out[w] = n ? (float)(sum / n) : 0.f;
+    }
+  }
+  h->probe = enable != 0;
+  return 0;
+}
 extern "C" int gget_debug_set(int key, int value) {
   switch (key) {
     case 1: g_gemm_variant = value; return 0;

@@ -193,6 +193,13 @@ class Engine:
         by set_dropout's seed)."""
         L.check(self.lib.gget_set_dropout_ex(self.h, float(embed_p), float(mlp_p), float(head_p)))
 
+    def debug_probe(self, enable: bool):
+        """Measurement aid (gget_debug_probe): switch the in-step event probe on / off; returns the mean launch durations in ms
+        recorded so far (grouped weight-gradient launch, gate|up + GEGLU launch)."""
+        out = (C.c_float * 2)()
+        L.check(self.lib.gget_debug_probe(self.h, int(bool(enable)), out))
+        return float(out[0]), float(out[1])
+
     def set_focal_gamma(self, gamma: float = 0.0):
         """config.focal_gamma: > 0 = focal loss on the SMTP head (un-weighted path)."""
         L.check(self.lib.gget_set_focal_gamma(self.h, float(gamma)))

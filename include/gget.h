@@ -238,6 +238,11 @@ int gget_op_gemm_grouped(int mode, int count, const void* const* A, const void* 
 /* measurement knob (tools/ only; no reference counterpart): key 1 = bit mask selecting experimental GEMM kernel variants,
  * so that two variants can be timed interleaved in one process (0 = the shipped configuration) */
 int gget_debug_set(int key, int value);
+/* measurement aid: with enable != 0 the engine brackets, with HIP events on the launch stream, the grouped weight-gradient launch
+ * (avg_ms_out[0]) and the gate|up + GEGLU launch (avg_ms_out[1]) of every layer of the following forward / backward calls;
+ * avg_ms_out (may be NULL) receives the mean durations recorded so far.  bench.py uses it for the roofline of the dominant kernel
+ * as it runs INSIDE a step. */
+int gget_debug_probe(gget_handle_t h, int enable, float* avg_ms_out);
 /* measurement aid (tools/coresidency.py; no reference counterpart): occupies `blocks` CU slots (256 threads, lds_bytes of LDS
  * each) for ~microseconds on `stream`, as a stand-in for a collective's kernel running beside the compute stream */
 int gget_debug_occupy(void* scratch, uint64_t scratch_bytes, int blocks, int lds_bytes, int microseconds, void* stream);

@@ -1112,3 +1112,45 @@ def test_focal_loss_matches_reference_and_oracle():
     model.config.focal_gamma = 0.0
     plain = float(model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=b["labels"]).head1_loss.item())
     assert plain - loss > 5e-4 * loss          # (1 - p_t)^2 < 1: slightly below the plain CE at this (near-uniform) init
+
+
+@pytest.mark.gpu
+def test_packed_long_rows_with_dropout_through_the_engine():
+    """Packed rows of S = 320 (block-diagonal [B,S,S] mask, position ids running across graphs) in training mode with attention
+    dropout 0.1: the engine's long-sequence attention kernels on per-token key ranges, with q / k stored ROTATED (the backward
+    kernels rotate dq / dk back in their epilogues) - loss and gradients against the oracle fed with the same dropout mask."""
+    from _util import spec_mod, weights_mod, synth
+    B, S, F, V, seed, p_attn = 2, 320, 4, 300, 2024, 0.1
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=V, stacked_feat=F, next_n_token=F, max_position=512)
+    state = weights_mod.make_state_dict(spec, seed=17, std=0.06, head_std=0.15)
+    batch = synth.make_packed_pretrain_batch(B=B, S=S, F=F, V=V, seed=57, mean_len=40, min_len=8)
+    b = tb(batch)
+    assert b["attention_mask"].dim() == 3
+    e = make_engine(spec, batch)
+    e.load_state_dict(state)
+    e.set_dropout(p_attn, 0.0, seed)
+    loss = float(e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], None, b["position_ids"]))
+    e.backward()
+    torch.cuda.synchronize()
+    H = spec.num_heads
+    ak = lambda l: _attn_drop_keep((seed + 0x9E37 * l) & 0xFFFFFFFF, B, H, S, p_attn)
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32)
+
+    def fn(q):
+        x, _ = O.stacked_embed(q["model.embed_tokens.weight"], b["input_ids"], q.get("stacked_feat_agg.weight"))
+        hidden = O.backbone(spec, q, x, b["attention_mask"], b["position_ids"], attn_keep=ak)
+        l_, lg = O.smtp_head(spec, q, hidden, b["labels"])
+        return dict(head1_loss=l_, head1_logits=lg)
+    out, grads = O.loss_and_grads(fn, p, "head1_loss")
+    want = out["head1_loss"].item()
+    record_error("pt_tiny_packed_S320_dropout", "loss_rel_vs_oracle_same_mask", abs(loss - want) / abs(want), 2e-3)
+    assert abs(loss - want) <= 2e-3 * abs(want), (loss, want)
+    got = e.grads()
+    gmax = max(float(g.norm()) for g in grads.values())
+    for k in ("model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.k_proj.weight", "model.layers.1.self_attn.k_proj.weight",
+              "model.layers.1.self_attn.v_proj.weight", "model.layers.0.mlp.down_proj.weight", "model.embed_tokens.weight", "lm_head.weight"):
+        w = grads[k].numpy()
+        err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        record_error("pt_tiny_packed_S320_dropout", "grad_rel_l2 " + k, err, 6e-2)
+        assert err < 6e-2, f"{k}: {err}"

@@ -1511,6 +1511,7 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
     const int qs = qbeg + t * 64;
     GGET_STAMP(0);
     attn_vm_wait0();
+    GGET_STAMP(13);
     __syncthreads();
     GGET_STAMP(1);
     // Waves w and w + 4 share a SIMD and leave the barrier together: in lock-step their MFMA phases collide and then their

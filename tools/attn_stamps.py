@@ -29,5 +29,6 @@ for w in range(8):
     seg = np.diff(s[w, 4:32, :13], axis=1)            # [stage, 12 phases]
     loop = s[w, 5:32, 0] - s[w, 4:31, 0]
     med = np.median(seg, axis=0)
-    print(f"wave {w}: stage {np.median(loop):6.0f} | " + " | ".join(f"{int(m)}" for m in med))
+    vmw = np.median(s[w, 4:32, 13] - s[w, 4:32, 0])
+    print(f"wave {w}: stage {np.median(loop):6.0f} | (vmcnt wait {int(vmw)}) " + " | ".join(f"{int(m)}" for m in med))
 print("phases: " + " | ".join(names))

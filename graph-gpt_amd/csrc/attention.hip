@@ -1437,14 +1437,18 @@ __device__ unsigned long long g_attn_stamps[8][40][16];
 #endif
 // dK / dV for long sequences: a wave owns a 32-key tile (K and V fragments in registers), Q and dO are streamed in 64-query
 // stages together with the queries' lse / delta (and key ranges for packed rows).
-template <bool PK, int NWB>
+// STG = query rows per stage (one barrier per stage): 128 halves the barriers - every barrier re-aligns the two waves of a SIMD
+// pair, which the matrix pipe serves one after the other (the early one waits ~700 cycles each time)
+template <bool PK, int NWB, int STG = 64>
 __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                      const float* __restrict__ lse, const float* __restrict__ delta,
                                                                      KeyRange KR, bf16_t* __restrict__ dqkv, int B, int S, int H, int causal,
                                                                      Drop D, Rope Rout) {
-  __shared__ __attribute__((aligned(16))) unsigned char st[2][2 * 8192];
-  __shared__ __attribute__((aligned(16))) float lse_s[2][64], dl_s[2][64];
-  __shared__ int qlo_s[2][64], qhi_s[2][64];
+  constexpr int ARR = STG * 128;      // bytes of one staged array (rows x 128 B)
+  constexpr int NTILE = STG / 32;
+  __shared__ __attribute__((aligned(16))) unsigned char st[2][2 * ARR];
+  __shared__ __attribute__((aligned(16))) float lse_s[2][STG], dl_s[2][STG];
+  __shared__ int qlo_s[2][PK ? STG : 1], qhi_s[2][PK ? STG : 1];
   constexpr int KB = NWB * 32;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1469,23 +1473,23 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
   const int kodd = krow & 1;
   const bool key_ok = krow < klen;
   const int kblk0 = blockIdx.x * KB;
-  const int qbeg = causal ? (kblk0 & ~63) : 0;     // queries before the block's first key never see it
+  const int qbeg = causal ? (kblk0 & ~(STG - 1)) : 0;     // queries before the block's first key never see it
   const int qlim = PK ? S : min(S, klen);          // right padding: queries beyond the row's length carry a zero upstream gradient
-  const int nst = (kblk0 < klen && qbeg < qlim) ? (qlim - qbeg + 63) >> 6 : 0;
-  constexpr int PPW = 16 / NWB;
+  const int nst = (kblk0 < klen && qbeg < qlim) ? (qlim - qbeg + STG - 1) / STG : 0;
+  constexpr int PPW = (STG / 4) / NWB;      // 1 KiB pieces per wave per stage (two arrays of STG / 8 pieces)
   auto issue = [&](int buf, int r0) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int pc = wave * PPW + i;
-      if (pc < 8) stage_piece(st[buf], qb, pitch, r0, S, pc, lane);
-      else stage_piece(st[buf] + 8192, dob, (size_t)d, r0, S, pc - 8, lane);
+      if (pc < STG / 8) stage_piece(st[buf], qb, pitch, r0, S, pc, lane);
+      else stage_piece(st[buf] + ARR, dob, (size_t)d, r0, S, pc - STG / 8, lane);
     }
   };
   // the stage's per-query scalars: fetched by the first 64 threads one stage ahead (registers), written to LDS behind the compute
   float p_lse = 0.f, p_dl = 0.f;
   int p_lo = 0, p_hi = -1;
   auto fetch_vec = [&](int r0) {
-    if (tid < 64) {
+    if (tid < STG) {
       const int q = min(r0 + tid, S - 1);
       p_lse = lse[((size_t)b * H + h) * S + q];          // raw: the scaling waits for commit_vec (no wait for the load here)
       p_dl = delta[((size_t)b * H + h) * S + q];
@@ -1497,7 +1501,7 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
     }
   };
   auto commit_vec = [&](int buf) {
-    if (tid < 64) {
+    if (tid < STG) {
       lse_s[buf][tid] = -p_lse * kLog2e; dl_s[buf][tid] = -p_dl * kScale;
       if (PK) { qlo_s[buf][tid] = p_lo; qhi_s[buf][tid] = p_hi; }
     }
@@ -1508,7 +1512,7 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
   const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
 #endif
   for (int t = 0; t < nst; ++t) {
-    const int qs = qbeg + t * 64;
+    const int qs = qbeg + t * STG;
     GGET_STAMP(0);
     attn_vm_wait0();
     GGET_STAMP(13);
@@ -1519,13 +1523,13 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
     // cycles of address-path queueing), the lower four behind their first MFMA group - half a phase apart from then on.
     const bool dma_late = wave < NWB / 2;
     bool dma_due = t + 1 < nst;
-    if (dma_due && !dma_late) { issue((t + 1) & 1, qs + 64); fetch_vec(qs + 64); dma_due = false; }
+    if (dma_due && !dma_late) { issue((t + 1) & 1, qs + STG); fetch_vec(qs + STG); dma_due = false; }
     GGET_STAMP(2);
     const unsigned char* qst = st[t & 1];
-    const unsigned char* dst_ = qst + 8192;
+    const unsigned char* dst_ = qst + ARR;
     const int vb_ = t & 1;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NTILE; ++j) {
       const int q0 = qs + 32 * j;
       if (k0 >= klen || q0 >= S || (causal && q0 + 31 < k0)) continue;
       bool edge = (k0 + 32 > klen) || (q0 + 32 > S) || (causal && k0 + 31 > q0);
@@ -1544,8 +1548,8 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
         sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, s, lane), kf[s], sc, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dot_, s, lane), vf[s], dp, 0, 0, 0);
       }
-      if (dma_due) { issue((t + 1) & 1, qs + 64); fetch_vec(qs + 64); dma_due = false; }
-      GGET_STAMP(3 + 5 * j);
+      if (dma_due) { issue((t + 1) & 1, qs + STG); fetch_vec(qs + STG); dma_due = false; }
+      if (j < 2) GGET_STAMP(3 + 5 * j);
       // the lane's 16 queries are 4 runs of 4 consecutive rows: the per-query scalars come as 4 + 4 ds_read_b128
       float nl[16], dlv[16];
 #pragma unroll
@@ -1557,7 +1561,7 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[r] = fast_exp2(fmaf(sc[r], kScaleL2, nl[r]));
-      GGET_STAMP(4 + 5 * j);
+      if (j < 2) GGET_STAMP(4 + 5 * j);
       if (edge) {
         int q0v = q0;
         asm volatile("" : "+v"(q0v));
@@ -1583,10 +1587,10 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
           sc[r] = drop ? 0.f : sc[r] * D.inv_keep;      // dropped probabilities: what multiplied V in forward
         }
       }
-      GGET_STAMP(5 + 5 * j);
+      if (j < 2) GGET_STAMP(5 + 5 * j);
       const bf16x8_t p0 = acc_to_b(sc, 0), p1 = acc_to_b(sc, 1);
       const bf16x8_t s0 = acc_to_b(dp, 0), s1 = acc_to_b(dp, 1);
-      GGET_STAMP(6 + 5 * j);
+      if (j < 2) GGET_STAMP(6 + 5 * j);
       dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 0, lane), p0, dv0, 0, 0, 0);
       dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 1, lane), p1, dv0, 0, 0, 0);
       dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 1, 0, lane), p0, dv1, 0, 0, 0);
@@ -1595,9 +1599,9 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
       dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 0, 1, lane), s1, dk0, 0, 0, 0);
       dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 0, lane), s0, dk1, 0, 0, 0);
       dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 1, lane), s1, dk1, 0, 0, 0);
-      GGET_STAMP(7 + 5 * j);
+      if (j < 2) GGET_STAMP(7 + 5 * j);
     }
-    if (dma_due) { issue((t + 1) & 1, qs + 64); fetch_vec(qs + 64); }     // (both tiles of the stage skipped)
+    if (dma_due) { issue((t + 1) & 1, qs + STG); fetch_vec(qs + STG); }     // (both tiles of the stage skipped)
     if (t + 1 < nst) commit_vec((t + 1) & 1);
   }
   if (krow < S) {
@@ -1679,11 +1683,15 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
   // (q, k rotated in memory - the engine's layout - or no rotation at all: the staged kernels read them as they are and rotate dq / dk
   // back in their epilogues; q, k to be rotated on load, the plain-op form of the tests, stays on the register-prefetch kernels)
   if (S >= 256 && (!cos_tab || qk_rotated) && big) {
+    static int stg128 = -1;
+    if (stg128 < 0) { const char* e = getenv("GGET_ATTN_STG128"); stg128 = e ? atoi(e) : 1; }
 #define GGET_BWD64(PK)                                                                                                           \
   do {                                                                                                                           \
     hipLaunchKernelGGL((attn_bwd_dq64_kernel<PK, 4>), dim3((S + 127) / 128, H, B), dim3(256), 0, st, (const bf16_t*)qkv,             \
                        (const bf16_t*)out, (const bf16_t*)dout, lse, delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, D, R);          \
-    hipLaunchKernelGGL((attn_bwd_dkv64_kernel<PK, 8>), dim3((S + 255) / 256, H, B), dim3(512), 0, st, (const bf16_t*)qkv,            \
+    if (stg128 && S >= 512) hipLaunchKernelGGL((attn_bwd_dkv64_kernel<PK, 8, 128>), dim3((S + 255) / 256, H, B), dim3(512), 0, st,   \
+                       (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, D, R);          \
+    else hipLaunchKernelGGL((attn_bwd_dkv64_kernel<PK, 8>), dim3((S + 255) / 256, H, B), dim3(512), 0, st, (const bf16_t*)qkv,       \
                        (const bf16_t*)dout, lse, delta_ws, KR, (bf16_t*)dqkv, B, S, H, causal, D, R);                              \
   } while (0)
     // dQ: 4-wave blocks at 3 waves / SIMD (168 registers; the 128-register 8-wave build spills in its dropout / edge paths and

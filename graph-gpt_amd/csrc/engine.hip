@@ -172,6 +172,7 @@ struct Ws {
   uint64_t cnt, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
   // task head
   uint64_t tlogits, tdlogits, pooled_h, auc_lists;
+  uint64_t long_wgt;   // stack_method = "long": per-sample loss weights (fp32 [max_batch])
   uint64_t head_x[6] = {0}, head_a[5] = {0}, head_d[2] = {0};   // MLP head: layer inputs / activations (bf16), fp32 gradient ping-pong
   uint64_t total;
 };
@@ -224,6 +225,7 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.counts = b.take(256);
   w.segs = b.take((uint64_t)pl.params.size() * sizeof(GgetSegment));
   w.wg32 = b.take(kWgSplit * 4 * d * d * 4);   // split-K slabs of the q|k|v|o wgrad
+  w.long_wgt = b.take((uint64_t)c.max_batch * 4);
   w.emb_sort = b.take(k_embed_bwd_ws_elems(T * (uint64_t)c.stacked_feat, (uint64_t)c.vocab_size) * 4);
   w.emb_cnt = k_embed_dense_ok(c.vocab_size, pl.has_gate) ? b.take(T * align_up(c.vocab_size, 64) * 2) : 0;   // bf16 [T][Vp] count matrix
   w.emb_slab = k_embed_dense_ok(c.vocab_size, pl.has_gate) ? b.take((uint64_t)kEmbDenseSplit * c.vocab_size * d * 4) : 0;
@@ -311,6 +313,7 @@ struct gget_engine {
   int problem = 0;
   int auc_num_neg = 1;
   float focal_gamma = 0.f;        // focal loss on the SMTP head (config.focal_gamma)
+  bool stack_long = false;        // config.stack_method == "long" (gget_set_stack_method)
   // in-step kernel probe (gget_debug_probe): HIP events around the grouped weight-gradient launch [0] and the gate|up + GEGLU launch [1]
   // of every layer, on the stream they are launched on - the bench reads the launch durations INSIDE a step from them
   bool probe = false;
@@ -492,6 +495,12 @@ extern "C" int gget_set_dropout_ex(gget_handle_t h, float embed_p, float mlp_p, 
   GGET_REQUIRE(mlp_p == 0.f || h->cfg.mlp_pdrop > 0.f, "MLP dropout needs a handle created with config.mlp_pdrop > 0");
   h->embed_drop_p = embed_p;
   h->mlp_drop_p = mlp_p;
+  return 0;
+}
+
+extern "C" int gget_set_stack_method(gget_handle_t h, int stack_long) {
+  GGET_REQUIRE(h != nullptr, "null handle");
+  h->stack_long = stack_long != 0;
   return 0;
 }
 
@@ -731,6 +740,8 @@ int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t*
   if (int e = k_embed_fwd(ids, h->P + h->plan.emb, h->plan.has_gate ? h->P + h->plan.gate : nullptr,
                           h->wsp<bf16_t>(h->ws.xres[0]), h->T, c.stacked_feat, ldF, d, st, h->embed_drop()))
     return e;
+  if (h->stack_long)
+    if (int e = k_embed_long_ratio(ids, h->wsp<bf16_t>(h->ws.xres[0]), h->T, c.stacked_feat, ldF, d, st)) return e;
   for (int i = 0; i < c.num_layers; ++i)
     if (int e = layer_forward(h, i, st)) return e;
   return k_rmsnorm_fwd(h->wsp<bf16_t>(h->ws.xres[c.num_layers]), h->P + h->plan.normf, h->wsp<bf16_t>(h->ws.hidden),
@@ -771,6 +782,10 @@ static int forward_pretrain_impl(gget_handle_t h, const int64_t* input_ids_dev, 
                       counts + 1, st))
     return e;
   h->have_labels = labels_dev != nullptr;
+  if (h->stack_long && labels_dev) {   // the per-feature-level weights replace whatever the caller passed (modeling_helpers.py:368-374)
+    if (int e = k_sample_mask_wgt(labels_dev, h->wsp<float>(w.long_wgt), B, S * n, st)) return e;
+    sample_wgt_dev = h->wsp<float>(w.long_wgt);
+  }
   h->sample_wgt = sample_wgt_dev;
   if (labels_dev) {
     const int mean_rows = sample_wgt_dev == nullptr;
@@ -1066,6 +1081,8 @@ extern "C" int gget_backward_end(gget_handle_t h, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const gget_config_t& c = h->cfg;
   float* s32 = h->wsp<float>(h->ws.scratch32);
+  if (h->stack_long)   // d(e * ratio) / de = ratio
+    if (int e = k_embed_long_ratio(h->ids, h->dx_cur, h->T, c.stacked_feat, c.stacked_feat, c.hidden_size, st)) return e;
   if (int e = embed_bwd(h->ids, h->dx_cur, h->P + h->plan.emb, h->plan.has_gate ? h->P + h->plan.gate : nullptr,
                         s32 + h->plan.emb32, h->plan.has_gate ? s32 + h->plan.gate32 : nullptr, h->T, c.stacked_feat,
                         c.stacked_feat, c.hidden_size, c.vocab_size, c.pad_token_id, h->wsp<int32_t>(h->ws.emb_sort),

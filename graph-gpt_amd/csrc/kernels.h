@@ -20,6 +20,10 @@ struct GgetSegment {
 int k_embed_fwd(const int64_t* ids, const void* emb, const void* gate, void* out, int T, int F, int ldF, int d,
                 hipStream_t st, ElemDropArg E = ElemDropArg{0, 1.f, 0});
 int k_elem_dropout(void* x, long T, int n, unsigned stream, ElemDropArg E, hipStream_t st);
+// stack_method = "long": x[t,:] *= min(1, bf16(1 / (non-zero ids of token t + 1e-7))) in place (forward value and its gradient);
+// w[b] = 1 / (labelled cells of sample b + 1e-7) - modeling_helpers.py:106-110, :327-342
+int k_embed_long_ratio(const int64_t* ids, void* x, int T, int F, int ldF, int d, hipStream_t st);
+int k_sample_mask_wgt(const int64_t* labels, float* w, int B, int cells, hipStream_t st);
 // sort_ws: int32 scratch of k_embed_bwd_ws_elems(T*F, V) elements (device-side counting sort of the cells by id)
 int k_embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* gate, float* demb, float* dgate, int T,
                 int F, int ldF, int d, int V, int pad_id, int32_t* sort_ws, hipStream_t st, ElemDropArg E = ElemDropArg{0, 1.f, 0});

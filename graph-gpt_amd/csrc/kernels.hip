@@ -47,6 +47,45 @@ __global__ void __launch_bounds__(128) embed_fwd_kernel(const int64_t* __restric
   }
 }
 
+// stack_method = "long" (modeling_helpers.py:106-110): the stacked embedding of a token is divided by the number of its non-zero
+// feature ids - ratio = min(1, bf16(1 / (nnz + 1e-7))), the reference's fp32 reciprocal cast to the activation dtype and
+// clamped, and the product rounded to bf16 once more.  The multiplier is also the backward of the product (autograd rounds
+// grad * ratio to bf16 the same way), so this one in-place kernel serves the forward and the gradient.
+__global__ void __launch_bounds__(128) embed_long_ratio_kernel(const int64_t* __restrict__ ids, bf16_t* __restrict__ x, int F,
+                                                               int ldF, int d) {
+  const int t = blockIdx.x;
+  const int64_t* row = ids + (size_t)t * ldF;
+  int nnz = 0;
+  for (int f = 0; f < F; ++f) nnz += row[f] != 0;
+  const float ratio = fminf(bf2f(f2bf(1.0f / ((float)nnz + 1e-7f))), 1.0f);
+  if (ratio == 1.0f) return;
+  for (int c = threadIdx.x; c * 8 < d; c += blockDim.x) {
+    float v[8];
+    unpack8(ldg16(x + (size_t)t * d + c * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= ratio;
+    stg16(x + (size_t)t * d + c * 8, pack8(v));
+  }
+}
+
+// ... and its loss weights (_prepare_for_stacked_feat_labels_per_feat_lvl, modeling_helpers.py:327-342): every masked cell of
+// sample b weighs 1 / (masked cells of b + 1e-7).  One block per sample.
+__global__ void __launch_bounds__(kBlock) sample_mask_wgt_kernel(const int64_t* __restrict__ labels, float* __restrict__ w,
+                                                                 int cells) {
+  __shared__ int part[kBlock / GGET_WAVE];
+  const int64_t* row = labels + (size_t)blockIdx.x * cells;
+  int n = 0;
+  for (int i = threadIdx.x; i < cells; i += kBlock) n += row[i] != -100;
+  n = (int)wave_sum((float)n);   // (exact: at most 2^24 cells per sample)
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int i = 0; i < kBlock / GGET_WAVE; ++i) tot += part[i];
+    w[blockIdx.x] = 1.0f / ((float)tot + 1e-7f);
+  }
+}
+
 // backward of K1: dW[v,:] = sum over cells (t,f) with ids[t,f]==v of dx[t,:] (* G[f,:]).
 // SMTP batches hit a few hundred vocabulary rows with ~10^5 cells (half of them the <mask> row), so a direct
 // atomic scatter serialises on hot rows.  Instead: counting sort of the cells by id on the device
@@ -1428,6 +1467,20 @@ int k_embed_fwd(const int64_t* ids, const void* emb, const void* gate, void* out
   if (T == 0) return 0;
   hipLaunchKernelGGL(embed_fwd_kernel, dim3(T), dim3(128), 0, st, ids, (const bf16_t*)emb, (const bf16_t*)gate,
                      (bf16_t*)out, T, F, ldF, d, E);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_embed_long_ratio(const int64_t* ids, void* x, int T, int F, int ldF, int d, hipStream_t st) {
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(embed_long_ratio_kernel, dim3(T), dim3(128), 0, st, ids, (bf16_t*)x, F, ldF, d);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_sample_mask_wgt(const int64_t* labels, float* w, int B, int cells, hipStream_t st) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(sample_mask_wgt_kernel, dim3(B), dim3(kBlock), 0, st, labels, w, cells);
   GGET_LAUNCH_CHECK();
   return 0;
 }

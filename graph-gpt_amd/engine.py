@@ -204,6 +204,10 @@ class Engine:
         """config.focal_gamma: > 0 = focal loss on the SMTP head (un-weighted path)."""
         L.check(self.lib.gget_set_focal_gamma(self.h, float(gamma)))
 
+    def set_stack_method(self, stack_long: bool):
+        """config.stack_method == "long": per-token 1/nnz embedding ratio + per-feature-level SMTP loss weights."""
+        L.check(self.lib.gget_set_stack_method(self.h, int(bool(stack_long))))
+
     def set_auc(self, num_neg: int = 1, seed: int = 0):
         """Negatives per positive and the sampling seed of the NEXT forward_task(problem=PROBLEM_AUC)."""
         L.check(self.lib.gget_set_auc(self.h, int(num_neg), int(seed) & 0xFFFFFFFF))

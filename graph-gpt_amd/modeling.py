@@ -72,7 +72,7 @@ class GraphGPTConfig:
         need(self.head_dim == 64 and self.hidden_size == 64 * self.num_attention_heads, "head_dim must be 64")
         need(self.num_key_value_heads == self.num_attention_heads, "GQA is not used by the reference configs")
         need(self.embed_dim == 0, "raw-embedding inputs (embed_dim>0)")
-        need(self.stack_method in ("short", None), "stack_method='long'")
+        need(self.stack_method in ("short", "long", None), f"stack_method={self.stack_method!r}")
         need(not self.use_discriminative and self.use_generative, "contrastive (pretrain-cl) head")
         need(self.rope_range == 0, "rope_range rescaling")
         need(len(self.mlp) <= 4, "an MLP score head with more than 4 hidden layers")
@@ -259,6 +259,7 @@ class _GgetModel(nn.Module):
         for name, p in self._flat.items():
             p.data = new.view(name, "master")
         new.sync_params()
+        new.set_stack_method(getattr(self.config, "stack_method", None) == "long")
         self._engine = new
         self._anchor = torch.zeros(1, device=new.device, requires_grad=True)
         self._dirty = False

@@ -131,6 +131,14 @@ int gget_set_dropout(gget_handle_t h, float attention_p, float path_p, uint32_t 
  * dropout between activation and Linear inside the MLP score head (src/utils/modules_utils.py:27-33). */
 int gget_set_dropout_ex(gget_handle_t h, float embed_p, float mlp_p, float head_p);
 
+/* replaces: `config.stack_method` ("short" | "long", configuration_graphgpt.py:50; examples/node_lvl/proteins_supervised.sh:31 runs
+ * "long").  stack_long != 0: (i) the stacked embedding of every token is multiplied by min(1, 1 / (its non-zero feature ids + 1e-7))
+ * (_get_stacked_inputs_embeds, modeling_helpers.py:106-110) in forward and backward, both model kinds; (ii) the SMTP head weighs
+ * every labelled cell of sample b by 1 / (labelled cells of b + 1e-7) and sums / (B S F) - the per-feature-level path
+ * (_prepare_for_stacked_feat_labels_per_feat_lvl :327-342 -> _get_dlm_ce_loss :180-198, modeling_pretrain.py:230-236); a
+ * sample_wgt passed to the forward is ignored then, as in the reference (:368-374).  Default 0 = "short". */
+int gget_set_stack_method(gget_handle_t h, int stack_long);
+
 /* replaces: `config.focal_gamma` (configs/training/base.yaml:60): > 0 turns the SMTP head's mean cross-entropy into the focal loss
  * of utils_graphgpt.FocalLoss (:340-376) - every row weighted by (1 - p_target)^gamma, the weight detached as in the reference.
  * Applies to gget_forward_pretrain[_packed] without sample_wgt (_get_ce_loss, modeling_helpers.py:158-160). */

@@ -30,11 +30,13 @@ _EPSILON = 1e-7  # reference modeling_helpers.py `_EPSILON`
 
 
 # --------------------------------------------------------------------------- K1  (row A1)
-def stacked_embed(emb_w: torch.Tensor, input_ids: torch.Tensor, gate_w: Optional[torch.Tensor], embed_keep=None):
+def stacked_embed(emb_w: torch.Tensor, input_ids: torch.Tensor, gate_w: Optional[torch.Tensor], embed_keep=None,
+                  stack_long: bool = False):
     """`_get_stacked_inputs_embeds` (modeling_helpers.py:89-114) + `StackedFeatAggregation.forward`
     (modeling_common.py:127-135).  ids [B,S,F] (or [B,S]) -> [B,S,d]; returns (embeds, in_).
-    `embed_keep`: multipliers (0 or 1/(1-p)) of `embed_dropout` on the gathered rows [B,S,F,d] (:96-98); None = eval mode."""
-    e = emb_w[input_ids]                      # nn.Embedding gather; pad row is a zero row
+    `embed_keep`: multipliers (0 or 1/(1-p)) of `embed_dropout` on the gathered rows [B,S,F,d] (:96-98); None = eval mode.
+    `stack_long`: config.stack_method == "long" - the per-token 1 / (non-zero ids) ratio of :106-110."""
+    e = Fnn.embedding(input_ids, emb_w, padding_idx=0)   # nn.Embedding(padding_idx=pad_token_id): the pad row takes no gradient
     if embed_keep is not None:
         e = e * torch.as_tensor(embed_keep).reshape(e.shape).to(e.dtype)
     if input_ids.dim() == 3:
@@ -43,6 +45,10 @@ def stacked_embed(emb_w: torch.Tensor, input_ids: torch.Tensor, gate_w: Optional
         else:
             e = torch.sum(e, dim=-2)
         in_ = input_ids[:, :, 0]
+        if stack_long:
+            nonzero_feat = (input_ids != 0).sum(dim=-1, keepdim=True) + 1e-7     # int64 + float -> fp32
+            ratio = torch.clamp(1 / nonzero_feat.to(e.dtype), max=1)
+            e = e * ratio
     else:
         in_ = input_ids
     return e, in_
@@ -171,12 +177,14 @@ def backbone(spec, p: Dict[str, torch.Tensor], x, attention_mask, position_ids, 
 
 
 # --------------------------------------------------------------------------- K11-K14 (rows A5-A7)
-def smtp_head(spec, p, hidden, labels, sample_wgt=None, focal_gamma=0.0):
+def smtp_head(spec, p, hidden, labels, sample_wgt=None, focal_gamma=0.0, stack_long=False):
     """`prepare_for_stacked_feat_labels` (modeling_helpers.py:362-393), "short" stacking:
     no wgt -> `_prepare_for_stacked_feat_labels_per_mix_lvl` (:263-301);
     wgt    -> `_prepare_for_stacked_feat_labels_wgt_per_feat_lvl` (:345-359);
     then lm_head (modeling_pretrain.py:218) and `_get_ce_loss` (:145-177) or `_get_dlm_ce_loss`
-    (:180-198) / (B*S*F) (modeling_pretrain.py:230-236).  labels None => logits for every cell."""
+    (:180-198) / (B*S*F) (modeling_pretrain.py:230-236).  labels None => logits for every cell.
+    "long" stacking (`stack_long`): `_prepare_for_stacked_feat_labels_per_feat_lvl` (:327-342) - the wgt path with every
+    labelled cell of a sample weighted by 1 / (labelled cells of the sample + 1e-7), whatever sample_wgt was passed."""
     B, S, d = hidden.shape
     n = spec.next_n_token
     proj = p.get("n_token_proj.weight")
@@ -187,7 +195,14 @@ def smtp_head(spec, p, hidden, labels, sample_wgt=None, focal_gamma=0.0):
     wgt = None
     if labels is not None and labels.dim() == 2:
         labels = labels[:, :, None]
-    if sample_wgt is None:
+    if stack_long:
+        hs = _proj(hidden).reshape(B, S, n, d)
+        mask_m = labels != LABEL_PAD
+        hs = hs[mask_m]
+        wgt = mask_m.float()
+        wgt = (wgt / (wgt.sum(dim=-1).sum(dim=-1)[:, None, None] + 1e-7))[mask_m]
+        labels = labels[mask_m]
+    elif sample_wgt is None:
         if labels is not None:
             mask = labels != LABEL_PAD
             mask_m = mask.any(dim=-1)
@@ -220,11 +235,12 @@ def smtp_head(spec, p, hidden, labels, sample_wgt=None, focal_gamma=0.0):
 
 
 def pretrain_forward(spec, p, input_ids, attention_mask, labels=None, sample_wgt=None,
-                     position_ids=None, collect=None, embed_keep=None, mlp_keep=None, focal_gamma=0.0):
+                     position_ids=None, collect=None, embed_keep=None, mlp_keep=None, focal_gamma=0.0, stack_long=False):
     """`GraphGPTPretrainBase.forward` (modeling_pretrain.py:152-266), generative head only."""
-    x, _ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"), embed_keep=embed_keep)
+    x, _ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"), embed_keep=embed_keep,
+                         stack_long=stack_long)
     hidden = backbone(spec, p, x, attention_mask, position_ids, collect, mlp_keep=mlp_keep)
-    loss, logits = smtp_head(spec, p, hidden, labels, sample_wgt, focal_gamma=focal_gamma)
+    loss, logits = smtp_head(spec, p, hidden, labels, sample_wgt, focal_gamma=focal_gamma, stack_long=stack_long)
     return dict(head1_loss=loss, head1_logits=logits, hidden=hidden)
 
 
@@ -240,12 +256,13 @@ def auc_loss(y_pred, y_true, num_neg, idx):
 
 def task_forward(spec, p, input_ids, attention_mask, position_ids=None, task_labels=None,
                  sample_wgt=None, problem_type="single_label_classification", loss_type=None, path_mult=None, attn_keep=None,
-                 num_neg=1, auc_idx=None, embed_keep=None, mlp_keep=None, head_keep=None):
+                 num_neg=1, auc_idx=None, embed_keep=None, mlp_keep=None, head_keep=None, stack_long=False):
     """`GraphGPTTaskModel.forward` (modeling_finetune.py:236-326) + `calculate_task_loss`
     (:167-234) + `_get_sequence_len` (modeling_helpers.py:78-86); Linear score head, "last" pooling."""
     if input_ids.dim() == 3:
         input_ids = input_ids[:, :, : spec.stacked_feat]
-    x, in_ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"), embed_keep=embed_keep)
+    x, in_ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"), embed_keep=embed_keep,
+                           stack_long=stack_long)
     hidden = backbone(spec, p, x, attention_mask, position_ids, path_mult=path_mult, attn_keep=attn_keep, mlp_keep=mlp_keep)
     B = hidden.shape[0]
     seq_len = (in_ != spec.pad_token_id).sum(-1) - 1

@@ -1154,3 +1154,69 @@ def test_packed_long_rows_with_dropout_through_the_engine():
         err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
         record_error("pt_tiny_packed_S320_dropout", "grad_rel_l2 " + k, err, 6e-2)
         assert err < 6e-2, f"{k}: {err}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["pt", "ft"])
+def test_stack_method_long_matches_reference_and_oracle(kind):
+    """config.stack_method = "long" through the drop-in classes (proteins_supervised.sh:31): the per-token 1 / (non-zero ids) embedding
+    ratio in forward and backward (modeling_helpers.py:106-110) and, for pre-training, the per-feature-level loss weights
+    (:327-342).  The batch has empty (0-valued) feature cells in real rows.  Loss against the reference fixture, gradients against
+    the oracle on the bf16-rounded weights; the pad row of the embedding table takes no gradient (nn.Embedding padding_idx)."""
+    import os
+    from _util import GOLDEN, spec_mod, weights_mod
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    pt = kind == "pt"
+    z = np.load(os.path.join(GOLDEN, "pt_tiny_long.npz" if pt else "ft_tiny_long.npz"))
+    if pt:
+        spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=756, stacked_feat=13, next_n_token=13)
+    else:
+        spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=2)
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    cfg = M.GraphGPTConfig(vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+                           num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
+                           max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=13,
+                           next_n_token=13 if pt else 1, stack_method="long", num_labels=2)
+    model = (M.GraphGPTPretrainBase if pt else M.GraphGPTTaskModel)(cfg, seed=1)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model.eval()
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32)
+    if pt:
+        out = model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=b["labels"])
+        loss_t, lk = out.head1_loss, "head1_loss"
+        fn = lambda q: O.pretrain_forward(spec, q, b["input_ids"], b["attention_mask"], b["labels"], stack_long=True)
+        short = lambda q: O.pretrain_forward(spec, q, b["input_ids"], b["attention_mask"], b["labels"])
+    else:
+        out = model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], position_ids=b["position_ids"],
+                    task_labels=b["task_labels"])
+        loss_t, lk = out.task_loss, "task_loss"
+        fn = lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], stack_long=True)
+        short = lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"])
+    loss = float(loss_t.item())
+    loss_t.backward()
+    tag = f"{kind}_tiny_long"
+    ref = float(z["loss"])
+    tol = 2e-3 if pt else 2e-2       # (fine-tune: a 12-sample CE at head_std 0.3 - the rule's FT factor on the reference's own bf16 gap)
+    record_error(tag, "loss_rel_vs_reference_fp32", abs(loss - ref) / ref, tol)
+    assert abs(loss - ref) <= tol * ref, (loss, ref)
+    with torch.no_grad():
+        assert abs(float(short(p)[lk]) - ref) > 5 * abs(loss - ref)      # the engine is on the "long" arithmetic, not near "short"
+    o, grads = O.loss_and_grads(fn, p, lk)
+    if not pt:
+        lg = out.task_logits.float().cpu().numpy()
+        err = float(np.abs(lg - z["logits"]).max()) / float(np.abs(z["logits"]).max())
+        record_error(tag, "logits_max_rel_vs_reference_fp32", err, 3e-2)
+        assert err < 3e-2, err
+    got = model._engine.grads()
+    gmax = max(float(g.norm()) for g in grads.values())
+    keys = ["model.layers.0.self_attn.q_proj.weight", "model.layers.1.mlp.down_proj.weight", "model.embed_tokens.weight"]
+    keys += ["lm_head.weight", "n_token_proj.weight"] if pt else ["score.weight"]
+    for k in keys:
+        w = grads[k].numpy()
+        err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        record_error(tag, "grad_rel_l2 " + k, err, 6e-2)
+        assert err < 6e-2, f"{k}: {err}"
+    assert float(got["model.embed_tokens.weight"][0].abs().max()) == 0.0

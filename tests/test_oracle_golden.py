@@ -371,3 +371,49 @@ def test_oracle_focal_loss_matches_reference():
     for k, want in (("lm_head.weight", z["grad_lm_head"]), ("model.layers.0.self_attn.q_proj.weight", z["grad_l0_q"])):
         assert np.linalg.norm(grads[k].numpy() - want) <= 2e-4 * np.linalg.norm(want), k
     np.testing.assert_allclose(np.array([float(grads[str(n)].norm()) for n in z["names"]]), z["grad_norms"], rtol=5e-4, atol=1e-7)
+
+
+def _long_case(kind):
+    from _util import GOLDEN, spec_mod, weights_mod
+    if kind == "pt":
+        z = np.load(os.path.join(GOLDEN, "pt_tiny_long.npz"))
+        spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=756, stacked_feat=13, next_n_token=13)
+    else:
+        z = np.load(os.path.join(GOLDEN, "ft_tiny_long.npz"))
+        spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=2)
+    assert [int(x) for x in z["meta_spec"]] == list(spec.as_c_ints())
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    return z, spec, state, b
+
+
+def test_oracle_stack_long_pretrain_matches_reference():
+    """config.stack_method = "long": 1 / (non-zero ids) embedding ratio + per-feature-level loss weights, on a batch with empty
+    (0-valued) feature cells in real rows - loss and gradients of the reference."""
+    z, spec, state, b = _long_case("pt")
+    assert ((b["input_ids"][:, :, 1:] == 0) & (b["input_ids"][:, :, :1] != 0)).any()
+    p = O.to_params(state, torch.float32)
+    fn = lambda q: O.pretrain_forward(spec, q, b["input_ids"], b["attention_mask"], b["labels"], stack_long=True)
+    out, grads = O.loss_and_grads(fn, p, "head1_loss")
+    assert abs(out["head1_loss"].item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    for k, want in (("lm_head.weight", z["grad_lm_head"]), ("model.layers.0.self_attn.q_proj.weight", z["grad_l0_q"])):
+        assert np.linalg.norm(grads[k].numpy() - want) <= 2e-4 * np.linalg.norm(want), k
+    got = grads["model.embed_tokens.weight"].numpy()[:64]
+    assert np.linalg.norm(got - z["grad_embed_rows"]) <= 2e-4 * np.linalg.norm(z["grad_embed_rows"])
+    np.testing.assert_allclose(np.array([float(grads[str(n)].norm()) for n in z["names"]]), z["grad_norms"], rtol=5e-4, atol=1e-7)
+    # and it is not the "short" loss
+    short = O.pretrain_forward(spec, p, b["input_ids"], b["attention_mask"], b["labels"])["head1_loss"].item()
+    assert abs(short - float(z["loss"])) > 1e-3 * abs(float(z["loss"]))
+
+
+def test_oracle_stack_long_finetune_matches_reference():
+    z, spec, state, b = _long_case("ft")
+    p = O.to_params(state, torch.float32)
+    fn = lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], stack_long=True)
+    out, grads = O.loss_and_grads(fn, p, "task_loss")
+    assert abs(out["task_loss"].item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    np.testing.assert_allclose(out["task_logits"].detach().numpy(), z["logits"], rtol=1e-4, atol=2e-5)
+    got = grads["model.embed_tokens.weight"].numpy()[:64]
+    assert np.linalg.norm(got - z["grad_embed_rows"]) <= 2e-4 * np.linalg.norm(z["grad_embed_rows"])
+    np.testing.assert_allclose(np.array([float(grads[str(n)].norm()) for n in z["names"]]), z["grad_norms"], rtol=5e-4, atol=1e-7)

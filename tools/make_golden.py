@@ -703,6 +703,72 @@ def focal_fixture():
     print(f"pt_tiny_focal written: loss {res['loss']:.6f}")
 
 
+def long_fixture():
+    """config.stack_method = "long" (examples/node_lvl/proteins_supervised.sh:31): the 1 / (non-zero ids) embedding ratio
+    (modeling_helpers.py:106-110) in both models and the per-feature-level SMTP loss (:327-342, :368-374).  Real rows get empty
+    (0-valued) feature cells - only this stacking has them; a labelled empty cell keeps id 0 and label 0 (tokenizer_utils.py:112-148)."""
+    PT, FT, Cfg = import_reference()
+    rs = np.random.RandomState(77)
+
+    def with_empty_cells(ids, labels=None):
+        ids = ids.copy()
+        empty = (rs.uniform(size=ids.shape) < 0.3) & (ids[:, :, :1] != 0)
+        empty[:, :, 0] = False
+        ids[empty] = 0
+        if labels is not None:
+            labels = labels.copy()
+            labels[empty & (labels != -100)] = 0
+        return ids, labels
+
+    # pre-train
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=756, stacked_feat=13, next_n_token=13)
+    state = weights_mod.make_state_dict(spec, seed=1011, std=0.06, head_std=0.15)
+    batch = synth.make_pretrain_batch(B=5, S=24, F=13, V=756, seed=101)
+    batch["input_ids"], batch["labels"] = with_empty_cells(batch["input_ids"], batch["labels"])
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    model = PT(ref_config(Cfg, spec, stack_method="long"))
+    load_weights(model, state)
+    model.eval()
+    o = model(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"], labels=tb["labels"], inputs_raw_embeds=None)
+    model.zero_grad()
+    o.head1_loss.backward()
+    names = list(state.keys())
+    g = dict(model.named_parameters())
+    res = {"loss": np.float64(o.head1_loss.item()), "grad_norms": grad_norms(model, names), "names": np.array(names),
+           "grad_lm_head": g["lm_head.weight"].grad.numpy().copy(),
+           "grad_l0_q": g["model.layers.0.self_attn.q_proj.weight"].grad.numpy().copy(),
+           "grad_embed_rows": g["model.embed_tokens.weight"].grad.numpy()[:64].copy(),
+           "meta_spec": np.array(spec.as_c_ints(), np.int64), "meta_init": np.array([1011, 0.06, 0.15])}
+    for k, v in batch.items():
+        res["in_" + k] = v
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "pt_tiny_long.npz"), **res)
+    print(f"pt_tiny_long written: loss {res['loss']:.6f}")
+
+    # fine-tune
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=2)
+    state = weights_mod.make_state_dict(spec, seed=1012, std=0.06, head_std=0.3)
+    batch = synth.make_task_batch(B=12, S=24, F=13, V=756, seed=102)
+    batch["input_ids"], _ = with_empty_cells(batch["input_ids"])
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    model = FT(ref_config(Cfg, spec, stack_method="long", num_labels=2, loss_type=None))
+    load_weights(model, state)
+    model.eval()
+    o = model(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"], position_ids=tb["position_ids"],
+              task_labels=tb["task_labels"])
+    model.zero_grad()
+    o.task_loss.backward()
+    names = list(state.keys())
+    g = dict(model.named_parameters())
+    res = {"loss": np.float64(o.task_loss.item()), "logits": o.task_logits.detach().float().numpy(),
+           "grad_norms": grad_norms(model, names), "names": np.array(names),
+           "grad_embed_rows": g["model.embed_tokens.weight"].grad.numpy()[:64].copy(),
+           "meta_spec": np.array(spec.as_c_ints(), np.int64), "meta_init": np.array([1012, 0.06, 0.3])}
+    for k, v in batch.items():
+        res["in_" + k] = v
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ft_tiny_long.npz"), **res)
+    print(f"ft_tiny_long written: loss {res['loss']:.6f}")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -732,6 +798,8 @@ def main():
         mlp_head_fixture()
     if not only or "pt_tiny_focal" in only:
         focal_fixture()
+    if not only or "tiny_long" in only:
+        long_fixture()
 
 
 if __name__ == "__main__":

@@ -1007,7 +1007,21 @@ __global__ void __launch_bounds__(kBlock) grad_sqnorm_kernel(const bf16_t* __res
   __shared__ float part[kBlock / 64];
   float s = 0.f;
   const size_t nv = n >> 3;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (size_t)gridDim.x * kBlock) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  for (; i + 3 * stride < nv; i += 4 * stride) {   // four loads in flight per thread
+    uint4 q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q[u] = ldg16(g + (i + u * stride) * 8);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float v[8];
+      unpack8(q[u], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[e] * v[e];
+    }
+  }
+  for (; i < nv; i += stride) {
     float v[8];
     unpack8(ldg16(g + i * 8), v);
 #pragma unroll
@@ -1035,6 +1049,7 @@ __global__ void __launch_bounds__(kBlock) grad_sqnorm_final_kernel(float* __rest
   if (threadIdx.x == 0) ws[0] = part[0];
 }
 
+template <int UNR>
 __global__ void __launch_bounds__(kBlock) adamw_kernel(float* __restrict__ master, float* __restrict__ m_, float* __restrict__ v_,
                                                        const bf16_t* __restrict__ grad, bf16_t* __restrict__ param, size_t n,
                                                        float lr, float beta1, float beta2, float eps, float wd, float bc1,
@@ -1047,14 +1062,21 @@ __global__ void __launch_bounds__(kBlock) adamw_kernel(float* __restrict__ maste
     if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) gnorm_out[0] = nrm;
   }
   const size_t nv = n >> 2;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (size_t)gridDim.x * kBlock) {
-    const uint2 gr = *reinterpret_cast<const uint2*>(grad + i * 4);
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x; i0 < nv; i0 += stride * UNR)
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    const size_t i = i0 + u * stride;
+    if (i >= nv) break;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    const u2v gr = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(grad + i * 4));
     float g[4] = {__uint_as_float(gr.x << 16), __uint_as_float(gr.x & 0xffff0000u), __uint_as_float(gr.y << 16),
                   __uint_as_float(gr.y & 0xffff0000u)};
-    float4 w = reinterpret_cast<float4*>(master)[i];
-    float4 mm = reinterpret_cast<float4*>(m_)[i];
-    float4 vv = reinterpret_cast<float4*>(v_)[i];
-    float* wp = &w.x; float* mp = &mm.x; float* vp = &vv.x;
+    f4v w = __builtin_nontemporal_load(reinterpret_cast<f4v*>(master) + i);
+    f4v mm = __builtin_nontemporal_load(reinterpret_cast<f4v*>(m_) + i);
+    f4v vv = __builtin_nontemporal_load(reinterpret_cast<f4v*>(v_) + i);
+    float wp[4] = {w.x, w.y, w.z, w.w}, mp[4] = {mm.x, mm.y, mm.z, mm.w}, vp[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float ge = g[e] * coef;
@@ -1064,9 +1086,9 @@ __global__ void __launch_bounds__(kBlock) adamw_kernel(float* __restrict__ maste
       const float denom = sqrtf(vp[e]) / bc2_sqrt + eps;
       wp[e] -= (lr / bc1) * (mp[e] / denom);
     }
-    reinterpret_cast<float4*>(master)[i] = w;
-    reinterpret_cast<float4*>(m_)[i] = mm;
-    reinterpret_cast<float4*>(v_)[i] = vv;
+    __builtin_nontemporal_store(f4v{wp[0], wp[1], wp[2], wp[3]}, reinterpret_cast<f4v*>(master) + i);
+    __builtin_nontemporal_store(f4v{mp[0], mp[1], mp[2], mp[3]}, reinterpret_cast<f4v*>(m_) + i);
+    __builtin_nontemporal_store(f4v{vp[0], vp[1], vp[2], vp[3]}, reinterpret_cast<f4v*>(v_) + i);
     uint2 o;
     o.x = pack2bf(wp[0], wp[1]);
     o.y = pack2bf(wp[2], wp[3]);
@@ -1754,7 +1776,7 @@ int k_score_bwd(const float* dlogits, const void* hidden, const int32_t* pool_ro
 }
 
 int k_grad_sqnorm(const void* g, size_t n, float* ws, hipStream_t st) {
-  const int blocks = grid_for((long)(n / 8), kBlock, kSqnormBlocks);
+  const int blocks = grid_for((long)(n / 8), kBlock, kSqnormBlocks);   // (2048 .. 8192 blocks measured slower)
   hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(blocks), dim3(kBlock), 0, st, (const bf16_t*)g, n, ws);
   hipLaunchKernelGGL(grad_sqnorm_final_kernel, dim3(1), dim3(kBlock), 0, st, ws, blocks);
   GGET_LAUNCH_CHECK();
@@ -1766,7 +1788,9 @@ int k_adamw(float* master, float* m, float* v, const void* grad, void* param, si
             hipStream_t st) {
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2 = 1.0f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((long)(n / 4), kBlock, 4096)), dim3(kBlock), 0, st, master, m, v,
+  // one pass, two float4 groups per thread (grid up to 65536 blocks): the grid-stride form with 4096 blocks ran at 5.1 TB/s of
+  // state traffic, this one at 6.0 (profiles/r02_adamw_sweep.txt); loads and the fp32 state stores are non-temporal
+  hipLaunchKernelGGL(adamw_kernel<2>, dim3(grid_for((long)(n / 8), kBlock, 65536)), dim3(kBlock), 0, st, master, m, v,
                      (const bf16_t*)grad, (bf16_t*)param, n, lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2), max_norm,
                      grad_scale, sqnorm, gnorm_out);
   GGET_LAUNCH_CHECK();

@@ -281,13 +281,13 @@ def _attn_ref(qkv, lens, B, S, H, causal):
 
 @pytest.mark.parametrize("causal", [0, 1])
 @pytest.mark.parametrize("rope", [False, True])
-@pytest.mark.parametrize("B,S,H", [(3, 24, 2), (2, 32, 12), (2, 72, 2), (1, 160, 3), (2, 520, 2), (1, 2048, 1)])
+@pytest.mark.parametrize("B,S,H", [(3, 24, 2), (2, 32, 12), (2, 72, 2), (1, 160, 3), (2, 520, 2), (1, 2048, 1), (171, 32, 12), (700, 24, 3)])   # the last two: thousands of one-wave problems (the headline shape's launch geometry)
 def test_attention_fwd_bwd(lib, B, S, H, causal, rope):
     """QK^T / softmax / PV and their backward, with key-length + causal masking; rope=True also checks the fused
     rotary embedding (q,k rotated on load, dq,dk rotated back) against autograd through the un-rotated q,k."""
     d = H * 64
     qkv = rnd(B * S, 3 * d, seed=7, scale=1.0)
-    lens = torch.tensor([S, max(5, S // 2), max(1, S - 3)][:B], dtype=torch.int32).cuda()
+    lens = torch.tensor([[S, max(5, S // 2), max(1, S - 3)][i % 3] for i in range(B)], dtype=torch.int32).cuda()
     cos = sin = pos = None
     if rope:
         cos, sin = _tables(max(1024, S + 16))

@@ -296,25 +296,47 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
     // in the same lane and register of two accumulators of this wave (j and j+2 when the wave's 64 columns are one head).
     static_assert(EPI != GGET_EPI_ROPE || ILV || NJ == 4, "RoPE epilogue: a wave owns one 64-column head");
     constexpr int NP = ILV ? NJ / 2 : 2;
+    // Table reads first, math second, in batches of IB row blocks (<= 48 registers of cos / sin in flight): with per-row early-outs
+    // between them the reads were MI * NP dependent L2 round trips per tile - +30 % on the launch at T = 8192, +42 % at 65 536
+    // (tools/rope_ab.py).  Rows beyond M read the last row's angles (never stored); columns beyond rope_cols (the v block) keep
+    // their values.
+    constexpr int IB = MI * NP > 8 ? 2 : MI;
+    static_assert(MI % IB == 0, "RoPE epilogue: row blocks per batch");
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = mw + i * 16 + l15;
-      if (m >= M) continue;
-      const int pos = P.rope_pos ? (int)P.rope_pos[m] : (m % P.rope_S);
+    for (int i0 = 0; i0 < MI; i0 += IB) {
+      int pos[IB];
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int ja = ILV ? 2 * p : p, jb = ILV ? 2 * p + 1 : p + 2;
-        const int headcol = ILV ? nw - chan0 + p * 64 : nw;
-        if (headcol >= P.rope_cols) continue;
-        const int ch = (ILV ? chan0 : p * 16) + gq * 4;
-        const float4 c = *reinterpret_cast<const float4*>(P.rope_cos + (size_t)pos * 32 + ch);
-        const float4 sn = *reinterpret_cast<const float4*>(P.rope_sin + (size_t)pos * 32 + ch);
-        const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+      for (int ii = 0; ii < IB; ++ii) {
+        const int m = min(mw + (i0 + ii) * 16 + l15, M - 1);
+        pos[ii] = P.rope_pos ? (int)P.rope_pos[m] : (m % P.rope_S);
+      }
+      float4 cq[IB][NP], sq[IB][NP];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float a = acc[i][ja][e], b = acc[i][jb][e];
-          acc[i][ja][e] = a * cc[e] - b * ss[e];
-          acc[i][jb][e] = b * cc[e] + a * ss[e];
+      for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int ch = (ILV ? chan0 : p * 16) + gq * 4;
+          cq[ii][p] = *reinterpret_cast<const float4*>(P.rope_cos + (size_t)pos[ii] * 32 + ch);
+          sq[ii][p] = *reinterpret_cast<const float4*>(P.rope_sin + (size_t)pos[ii] * 32 + ch);
+        }
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii) {
+        const int i = i0 + ii;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int ja = ILV ? 2 * p : p, jb = ILV ? 2 * p + 1 : p + 2;
+          const int headcol = ILV ? nw - chan0 + p * 64 : nw;
+          const bool live = headcol < P.rope_cols;
+          const float cc[4] = {cq[ii][p].x, cq[ii][p].y, cq[ii][p].z, cq[ii][p].w};
+          const float ss[4] = {sq[ii][p].x, sq[ii][p].y, sq[ii][p].z, sq[ii][p].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a = acc[i][ja][e], b = acc[i][jb][e];
+            // explicit contraction: which product the compiler folds into the fma moved single bf16 roundings of q / k whenever
+            // the surrounding code changed, and the big-weight parity case turns one such flip into 1e-4 of loss
+            acc[i][ja][e] = live ? fmaf(a, cc[e], -(b * ss[e])) : a;
+            acc[i][jb][e] = live ? fmaf(b, cc[e], a * ss[e]) : b;
+          }
         }
       }
     }

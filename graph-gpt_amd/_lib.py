@@ -105,6 +105,7 @@ def gemm_grouped(lib, mode, problems, stream):
     num = lambda k: IA(*[int(p[k]) for p in problems])
     return lib.gget_op_gemm_grouped(mode, n, ptr(0), ptr(1), ptr(2), num(3), num(4), num(5), num(6), num(7), num(8), stream)
 PROBLEM_SINGLE_LABEL, PROBLEM_REGRESSION_L1, PROBLEM_REGRESSION_MSE, PROBLEM_MULTI_LABEL, PROBLEM_AUC = 0, 1, 2, 3, 4
+PROBLEM_TOKEN_CE = 5   # loss_type = "token_ce": score + cross-entropy on every labelled row, logits [B,S,C]
 
 _lib = None
 

@@ -172,6 +172,7 @@ struct Ws {
   uint64_t cnt, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
   // task head
   uint64_t tlogits, tdlogits, pooled_h, auc_lists;
+  uint64_t tok_stat;   // token-level head: loss sum, labelled rows, 1 / rows
   uint64_t long_wgt;   // stack_method = "long": per-sample loss weights (fp32 [max_batch])
   uint64_t head_x[6] = {0}, head_a[5] = {0}, head_d[2] = {0};   // MLP head: layer inputs / activations (bf16), fp32 gradient ping-pong
   uint64_t total;
@@ -253,8 +254,10 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
     w.logits = b.take(T * n * Vp * 2);
     w.dlogits = b.take(T * n * Vp * 2);
   } else {
-    w.tlogits = b.take(Bm * c.num_labels * 4);
-    w.tdlogits = b.take(Bm * c.num_labels * 4);
+    // (rows = tokens for the token-level head, loss_type = "token_ce": logits / dlogits of every row)
+    w.tlogits = b.take(std::max(Bm, T) * c.num_labels * 4);
+    w.tdlogits = b.take(std::max(Bm, T) * c.num_labels * 4);
+    w.tok_stat = b.take(256);
     w.auc_lists = b.take(Bm * 2 * 4);
     w.pooled_h = b.take(Bm * d * 2);
     if (pl.n_lin > 0) {
@@ -827,6 +830,7 @@ extern "C" int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, 
   const Ws& w = h->ws;
   const int d = c.hidden_size, C = c.num_labels;
   float* lg = h->wsp<float>(w.tlogits);
+  GGET_REQUIRE(problem_type != GGET_PROBLEM_TOKEN_CE || h->plan.n_lin == 0, "the token-level head is the Linear `score` (no MLP head)");
   if (h->plan.n_lin > 0) {
     const Plan& pl = h->plan;
     if (int e = k_pool_rows(h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.pool_row), h->wsp<bf16_t>(w.pooled_h), B, d, st)) return e;
@@ -835,10 +839,18 @@ extern "C" int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, 
                                     c.score_bias ? h->P + pl.head_b[i] : nullptr, h->wsp<bf16_t>(w.head_x[i + 1]),
                                     i + 1 == pl.n_lin ? lg : nullptr, B, pl.head_dim[i], pl.head_dim[i + 1], i, h->head_drop(), st))
         return e;
+  } else if (problem_type == GGET_PROBLEM_TOKEN_CE) {
+    // token-level task (loss_type = "token_ce", modeling_finetune.py:162-164, :198-202): `score` on EVERY row; the hidden state
+    // handed back is still the last token's (:291-296)
+    if (int e = k_tok_score_fwd(h->wsp<bf16_t>(w.hidden), h->P + h->plan.score, c.score_bias ? h->P + h->plan.sbias : nullptr, lg, h->T, C,
+                                d, st))
+      return e;
+    if (int e = k_pool_rows(h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.pool_row), h->wsp<bf16_t>(w.pooled_h), B, d, st)) return e;
   } else if (int e = k_score_fwd(h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.pool_row), h->P + h->plan.score,
                                  c.score_bias ? h->P + h->plan.sbias : nullptr, lg, h->wsp<bf16_t>(w.pooled_h), B, C, d, st))
     return e;
-  if (task_logits_dev) GGET_HIP_CHECK(hipMemcpyAsync(task_logits_dev, lg, (size_t)B * C * 4, hipMemcpyDeviceToDevice, st));
+  const int rows = problem_type == GGET_PROBLEM_TOKEN_CE ? h->T : B;   // rows of the logits
+  if (task_logits_dev) GGET_HIP_CHECK(hipMemcpyAsync(task_logits_dev, lg, (size_t)rows * C * 4, hipMemcpyDeviceToDevice, st));
   if (task_hidden_dev)
     GGET_HIP_CHECK(hipMemcpyAsync(task_hidden_dev, h->wsp<bf16_t>(w.pooled_h), (size_t)B * d * 2, hipMemcpyDeviceToDevice, st));
   h->have_labels = task_labels_dev != nullptr;
@@ -850,6 +862,9 @@ extern "C" int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, 
       GGET_REQUIRE((long)B * h->auc_num_neg <= 8192, "AUC loss: positives x num_neg is limited to 8192 pairs");
       if (int e = k_auc_loss(lg, (const int64_t*)task_labels_dev, B, C, h->auc_num_neg, h->auc_seed, loss_dev,
                              h->wsp<float>(w.tdlogits), h->wsp<int32_t>(w.auc_lists), st))
+        return e;
+    } else if (problem_type == GGET_PROBLEM_TOKEN_CE) {
+      if (int e = k_tok_ce(lg, (const int64_t*)task_labels_dev, h->wsp<float>(w.tdlogits), h->wsp<float>(w.tok_stat), loss_dev, rows, C, st))
         return e;
     } else if (int e = k_task_loss(lg, task_labels_dev, sample_wgt_dev, problem_type, B, C, loss_dev, h->wsp<float>(w.tdlogits), st))
       return e;
@@ -1030,6 +1045,10 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
       dy = dx;
     }
     if (int e = k_scatter_rows_f32(dy, h->wsp<int32_t>(w.pool_row), dhid, h->B, d, st)) return e;
+  } else if (h->problem == GGET_PROBLEM_TOKEN_CE) {
+    if (int e = k_tok_score_bwd(h->wsp<float>(w.tdlogits), h->wsp<float>(w.tok_stat), h->wsp<bf16_t>(w.hidden), h->P + h->plan.score,
+                                s32 + h->plan.score32, c.score_bias ? s32 + h->plan.sbias32 : nullptr, dhid, T, c.num_labels, d, st))
+      return e;
   } else {
     if (int e = k_score_bwd(h->wsp<float>(w.tdlogits), h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.pool_row),
                             h->P + h->plan.score, s32 + h->plan.score32, c.score_bias ? s32 + h->plan.sbias32 : nullptr, dhid,

@@ -53,6 +53,12 @@ int k_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const int32_
                  int mean_over_rows, float* loss_out, hipStream_t st, float focal_gamma = 0.f);
 int k_score_fwd(const void* hidden, const int32_t* pool_row, const void* w, const void* bias, float* logits,
                 void* pooled_h, int B, int C, int d, hipStream_t st);
+// token-level head (loss_type = "token_ce"): score on every row (fp32 logits rounded as bf16), cross-entropy with ignore_index -100
+// (stat: 4 floats of scratch - loss sum, labelled rows, 1 / rows), and the backward (dW / dbias accumulate, dhidden is overwritten)
+int k_tok_score_fwd(const void* hidden, const void* w, const void* bias, float* logits, int T, int C, int d, hipStream_t st);
+int k_tok_ce(const float* logits, const int64_t* labels, float* dl, float* stat, float* loss_out, int T, int C, hipStream_t st);
+int k_tok_score_bwd(const float* dl, const float* stat, const void* hidden, const void* w, float* dw, float* dbias, void* dhidden, int T,
+                    int C, int d, hipStream_t st);
 int k_pool_rows(const void* hidden, const int32_t* pool_row, void* out, int B, int d, hipStream_t st);
 int k_head_linear_fwd(const void* x, void* a, const void* w, const void* bias, void* y, float* y32, int B, int Din, int Dout,
                       int layer, ElemDropArg E, hipStream_t st);

@@ -814,6 +814,149 @@ __global__ void __launch_bounds__(64) score_fwd_kernel(const bf16_t* __restrict_
   if (threadIdx.x == 0) logits[b * C + c] = bf2f(f2bf(acc + (bias ? bf2f(bias[c]) : 0.f)));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Token-level head (loss_type = "token_ce", modeling_finetune.py:162-164, :198-202): `score` and the cross-entropy on EVERY row.
+// T is tens of thousands of rows and C tens of classes: too many rows for the pooled-row kernels above, too narrow for the GEMM
+// tiles (K = C in the backward).  A wave owns kTokRows consecutive rows and keeps them in registers; the weight rows come from L1.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTokRows = 4;
+constexpr int kTokMaxCols = 16;   // d <= 64 * kTokMaxCols
+// logits[t,c] = bf16(h[t] . W[c] + bias[c])   (fp32 out, rounded as the reference's bf16 `score` output)
+__global__ void __launch_bounds__(kBlock) tok_score_fwd_kernel(const bf16_t* __restrict__ hidden, const bf16_t* __restrict__ w,
+                                                               const bf16_t* __restrict__ bias, float* __restrict__ logits, int T, int C,
+                                                               int d) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = (blockIdx.x * (kBlock / 64) + wave) * kTokRows;
+  if (t0 >= T) return;
+  const int nc = d >> 6;
+  float hv[kTokRows][kTokMaxCols];
+#pragma unroll
+  for (int r = 0; r < kTokRows; ++r)
+#pragma unroll
+    for (int k = 0; k < kTokMaxCols; ++k)
+      hv[r][k] = (k < nc && t0 + r < T) ? bf2f(hidden[(size_t)(t0 + r) * d + k * 64 + lane]) : 0.f;
+  for (int c0 = 0; c0 < C; c0 += 64) {      // lane l keeps class c0 + l of every row
+    float out[kTokRows] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = c0; c < min(C, c0 + 64); ++c) {
+      float wv[kTokMaxCols];
+#pragma unroll
+      for (int k = 0; k < kTokMaxCols; ++k) wv[k] = k < nc ? bf2f(w[(size_t)c * d + k * 64 + lane]) : 0.f;
+      const float bc = bias ? bf2f(bias[c]) : 0.f;
+#pragma unroll
+      for (int r = 0; r < kTokRows; ++r) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < kTokMaxCols; ++k) a = fmaf(hv[r][k], wv[k], a);
+        a = wave_sum(a);
+        if (lane == c - c0) out[r] = bf2f(f2bf(a + bc));
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kTokRows; ++r)
+      if (t0 + r < T && c0 + lane < C) logits[(size_t)(t0 + r) * C + c0 + lane] = out[r];
+  }
+}
+// per-row cross-entropy with ignore_index = -100 (label < 0): dl[t,:] = softmax - onehot for labelled rows (NOT yet divided by
+// their number), zeros otherwise; stat[0] += sum of row losses, stat[1] += labelled rows (fp32 atomics; the count is exact)
+__global__ void __launch_bounds__(kBlock) tok_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                        float* __restrict__ dl, float* __restrict__ stat, int T, int C) {
+  __shared__ float red[2][kBlock / 64];
+  float ls = 0.f, cnt = 0.f;
+  for (int t = blockIdx.x * kBlock + threadIdx.x; t < T; t += gridDim.x * kBlock) {
+    const int y = (int)labels[t];
+    const float* lp = logits + (size_t)t * C;
+    float* dp = dl + (size_t)t * C;
+    if (y < 0) {
+      for (int c = 0; c < C; ++c) dp[c] = 0.f;
+      continue;
+    }
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, lp[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += __expf(lp[c] - mx);
+    ls += mx + __logf(se) - lp[y];
+    cnt += 1.f;
+    const float inv = 1.0f / se;
+    for (int c = 0; c < C; ++c) dp[c] = __expf(lp[c] - mx) * inv - (c == y ? 1.f : 0.f);
+  }
+  ls = wave_sum(ls); cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ls; red[1][threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < kBlock / 64; ++i) { a += red[0][i]; b += red[1][i]; }
+    if (b > 0.f) { unsafeAtomicAdd(stat, a); unsafeAtomicAdd(stat + 1, b); }
+  }
+}
+__global__ void tok_ce_final_kernel(float* __restrict__ stat, float* __restrict__ loss_out) {
+  const float n = stat[1];
+  stat[2] = n > 0.f ? 1.0f / n : 0.f;            // the mean's factor, read by the backward kernels
+  loss_out[0] = n > 0.f ? stat[0] / n : 0.f;
+}
+// dhidden[t,:] = bf16( sum_c bf16(dl[t,c] / n) W[c,:] )   (the reference's gradient is a bf16 tensor at both points)
+__global__ void __launch_bounds__(kBlock) tok_score_bwd_dx_kernel(const float* __restrict__ dl, const float* __restrict__ stat,
+                                                                  const bf16_t* __restrict__ w, bf16_t* __restrict__ dhidden, int T,
+                                                                  int C, int d) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = (blockIdx.x * (kBlock / 64) + wave) * kTokRows;
+  if (t0 >= T) return;
+  const int nc = d >> 6;
+  const float inv_n = stat[2];
+  float acc[kTokRows][kTokMaxCols];
+#pragma unroll
+  for (int r = 0; r < kTokRows; ++r)
+#pragma unroll
+    for (int k = 0; k < kTokMaxCols; ++k) acc[r][k] = 0.f;
+  for (int c = 0; c < C; ++c) {
+    float g[kTokRows];
+#pragma unroll
+    for (int r = 0; r < kTokRows; ++r) g[r] = t0 + r < T ? bf2f(f2bf(dl[(size_t)(t0 + r) * C + c] * inv_n)) : 0.f;
+#pragma unroll
+    for (int k = 0; k < kTokMaxCols; ++k) {
+      if (k < nc) {
+        const float wv = bf2f(w[(size_t)c * d + k * 64 + lane]);
+#pragma unroll
+        for (int r = 0; r < kTokRows; ++r) acc[r][k] = fmaf(g[r], wv, acc[r][k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kTokRows; ++r)
+#pragma unroll
+    for (int k = 0; k < kTokMaxCols; ++k)
+      if (k < nc && t0 + r < T) dhidden[(size_t)(t0 + r) * d + k * 64 + lane] = f2bf(acc[r][k]);
+}
+// dW[c,:] += sum_t bf16(dl[t,c] / n) h[t,:], dbias[c] += sum_t ...: a block owns kTokSlab rows x kTokCls classes, one fp32 atomic per
+// (class, column) per block
+constexpr int kTokSlab = 512, kTokCls = 8;
+__global__ void __launch_bounds__(kBlock) tok_score_bwd_dw_kernel(const float* __restrict__ dl, const float* __restrict__ stat,
+                                                                  const bf16_t* __restrict__ hidden, float* __restrict__ dw,
+                                                                  float* __restrict__ dbias, int T, int C, int d) {
+  const int tA = blockIdx.x * kTokSlab, tB = min(T, tA + kTokSlab);
+  const int c0 = blockIdx.y * kTokCls;
+  const float inv_n = stat[2];
+  for (int j0 = 0; j0 < d; j0 += kBlock) {
+    const int j = j0 + threadIdx.x;
+    float acc[kTokCls], bs[kTokCls];
+#pragma unroll
+    for (int q = 0; q < kTokCls; ++q) { acc[q] = 0.f; bs[q] = 0.f; }
+    for (int t = tA; t < tB; ++t) {
+      const float hvv = j < d ? bf2f(hidden[(size_t)t * d + j]) : 0.f;
+#pragma unroll
+      for (int q = 0; q < kTokCls; ++q) {
+        const float g = c0 + q < C ? bf2f(f2bf(dl[(size_t)t * C + c0 + q] * inv_n)) : 0.f;
+        acc[q] = fmaf(g, hvv, acc[q]);
+        bs[q] += g;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kTokCls; ++q) {
+      if (c0 + q < C && j < d && acc[q] != 0.f) unsafeAtomicAdd(dw + (size_t)(c0 + q) * d + j, acc[q]);
+      if (dbias && j == 0 && c0 + q < C) unsafeAtomicAdd(dbias + c0 + q, bs[q]);
+    }
+  }
+}
+
 // task loss + dlogits (calculate_task_loss, modeling_finetune.py:167-234); single block.
 __global__ void __launch_bounds__(kBlock) task_loss_kernel(const float* __restrict__ logits, const void* __restrict__ labels,
                                                            const float* __restrict__ sample_wgt, int problem, int B, int C,
@@ -1657,6 +1800,34 @@ int k_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const int32_
   }
   if (loss_out) hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(1), 0, st, loss_sum, n_rows_dev, scale_base,
                                    mean_over_rows, loss_out);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_tok_score_fwd(const void* hidden, const void* w, const void* bias, float* logits, int T, int C, int d, hipStream_t st) {
+  GGET_REQUIRE(d % 64 == 0 && d <= 64 * kTokMaxCols, "token-level head: d=%d unsupported", d);
+  if (T == 0) return 0;
+  const int rows_per_block = (kBlock / 64) * kTokRows;
+  hipLaunchKernelGGL(tok_score_fwd_kernel, dim3((T + rows_per_block - 1) / rows_per_block), dim3(kBlock), 0, st, (const bf16_t*)hidden,
+                     (const bf16_t*)w, (const bf16_t*)bias, logits, T, C, d);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+int k_tok_ce(const float* logits, const int64_t* labels, float* dl, float* stat, float* loss_out, int T, int C, hipStream_t st) {
+  GGET_HIP_CHECK(hipMemsetAsync(stat, 0, 4 * sizeof(float), st));
+  if (T > 0) hipLaunchKernelGGL(tok_ce_kernel, dim3(grid_for(T, kBlock, 1024)), dim3(kBlock), 0, st, logits, labels, dl, stat, T, C);
+  hipLaunchKernelGGL(tok_ce_final_kernel, dim3(1), dim3(1), 0, st, stat, loss_out);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+int k_tok_score_bwd(const float* dl, const float* stat, const void* hidden, const void* w, float* dw, float* dbias, void* dhidden, int T,
+                    int C, int d, hipStream_t st) {
+  if (T == 0) return 0;
+  const int rows_per_block = (kBlock / 64) * kTokRows;
+  hipLaunchKernelGGL(tok_score_bwd_dx_kernel, dim3((T + rows_per_block - 1) / rows_per_block), dim3(kBlock), 0, st, dl, stat,
+                     (const bf16_t*)w, (bf16_t*)dhidden, T, C, d);
+  hipLaunchKernelGGL(tok_score_bwd_dw_kernel, dim3((T + kTokSlab - 1) / kTokSlab, (C + kTokCls - 1) / kTokCls), dim3(kBlock), 0, st, dl,
+                     stat, (const bf16_t*)hidden, dw, dbias, T, C, d);
   GGET_LAUNCH_CHECK();
   return 0;
 }

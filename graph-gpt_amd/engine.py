@@ -172,12 +172,16 @@ class Engine:
         pos = self._i64(position_ids, dev)
         y = None
         if task_labels is not None:
-            if problem in (L.PROBLEM_SINGLE_LABEL, L.PROBLEM_AUC):
+            if problem in (L.PROBLEM_SINGLE_LABEL, L.PROBLEM_AUC, L.PROBLEM_TOKEN_CE):
                 y = task_labels.to(device=dev, dtype=torch.int64).contiguous()
             else:
                 y = task_labels.to(device=dev, dtype=torch.float32).contiguous()
         wgt = None if sample_wgt is None else sample_wgt.to(device=dev, dtype=torch.float32).contiguous()
-        logits = torch.empty(B, self.spec.num_labels, dtype=torch.float32, device=dev)
+        if problem == L.PROBLEM_TOKEN_CE:   # token-level task: labels and logits per row
+            assert y is None or tuple(y.shape) == (B, S), f"token-level labels must be [B,S], got {tuple(y.shape)}"
+            logits = torch.empty(B, S, self.spec.num_labels, dtype=torch.float32, device=dev)
+        else:
+            logits = torch.empty(B, self.spec.num_labels, dtype=torch.float32, device=dev)
         hid = torch.empty(B, self.spec.hidden_size, dtype=torch.bfloat16, device=dev)
         self._keep = (ids, att, pos, y, wgt)
         L.check(self.lib.gget_forward_task(self.h, _ptr(ids), _ptr(att), _ptr(pos), _ptr(y), _ptr(wgt), problem, B, S,

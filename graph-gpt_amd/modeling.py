@@ -404,9 +404,12 @@ class GraphGPTTaskModel(_GgetModel):
         if problem == "regression":
             code = L.PROBLEM_REGRESSION_L1 if cfg.loss_type == "l1" else L.PROBLEM_REGRESSION_MSE
         elif problem in ("single_label_classification", None):
-            if cfg.loss_type in ("token_ce", "token_ce_intra"):
-                raise NotImplementedError(f"loss_type={cfg.loss_type!r} (token-level tasks) is outside the hot-path scope")
-            code = L.PROBLEM_AUC if cfg.loss_type == "auc" else L.PROBLEM_SINGLE_LABEL
+            if cfg.loss_type == "token_ce_intra":
+                raise NotImplementedError("loss_type='token_ce_intra' (intra-instance label embeddings) is outside the hot-path scope")
+            # "token_ce" (node-level tasks): `score` and the cross-entropy on every row, task_logits [B,S,num_labels]
+            code = L.PROBLEM_TOKEN_CE if cfg.loss_type == "token_ce" else (L.PROBLEM_AUC if cfg.loss_type == "auc" else L.PROBLEM_SINGLE_LABEL)
+            if code == L.PROBLEM_TOKEN_CE and len(cfg.mlp) > 0:
+                raise NotImplementedError("loss_type='token_ce' with an MLP score head is outside the hot-path scope")
         else:
             code = L.PROBLEM_MULTI_LABEL   # BCE-with-logits on the labelled entries (modeling_finetune.py:227-230)
         self._check_positions(position_ids, S)

@@ -35,6 +35,7 @@ extern "C" {
 #define GGET_PROBLEM_SINGLE_LABEL 0 /* CrossEntropy on pooled logits (modeling_finetune.py:209-214) */
 #define GGET_PROBLEM_REGRESSION_L1 1 /* L1Loss  (modeling_finetune.py:183-197) */
 #define GGET_PROBLEM_REGRESSION_MSE 2 /* MSELoss */
+#define GGET_PROBLEM_TOKEN_CE 5 /* loss_type = "token_ce" (node-level tasks, modeling_finetune.py:162-164, :198-202): `score` on EVERY row, task_labels int64 [B,S] with -100 = unlabelled, mean cross-entropy over the labelled rows; task_logits_dev is then f32 [B,S,num_labels] (the reference hands the all-row logits back as `task_logits`), with or without labels */
 #define GGET_PROBLEM_AUC 4 /* pairwise squared-hinge AUC surrogate on logit[:,1]-logit[:,0] (src/utils/loss_utils.py:25-53, modeling_finetune.py:203-207); see gget_set_auc */
 #define GGET_PROBLEM_MULTI_LABEL 3 /* BCEWithLogitsLoss on the non-NaN entries of float labels [B,num_labels] (modeling_finetune.py:227-230) */
 

@@ -279,9 +279,14 @@ def task_forward(spec, p, input_ids, attention_mask, position_ids=None, task_lab
     else:
         logits = Fnn.linear(hidden, p["score.weight"], p.get("score.bias"))
         pooled = logits[torch.arange(B), seq_len]
+        if loss_type == "token_ce":
+            pooled = logits     # get_logits_for_token_lvl_task (modeling_finetune.py:162-164): the all-row logits are what is returned
     loss = None
     if task_labels is not None:
-        if problem_type == "regression":
+        if problem_type == "single_label_classification" and loss_type == "token_ce":
+            # modeling_finetune.py:198-202: CrossEntropyLoss over every row, labels [B,S] with -100 (ignore_index) on the unlabelled ones
+            loss = Fnn.cross_entropy(logits.view(-1, spec.num_labels).float(), task_labels.view(-1))
+        elif problem_type == "regression":
             y = task_labels.to(pooled.dtype)
             if loss_type == "l1":
                 loss = Fnn.l1_loss(pooled.squeeze(), y.squeeze())

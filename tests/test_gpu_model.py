@@ -1220,3 +1220,52 @@ def test_stack_method_long_matches_reference_and_oracle(kind):
         record_error(tag, "grad_rel_l2 " + k, err, 6e-2)
         assert err < 6e-2, f"{k}: {err}"
     assert float(got["model.embed_tokens.weight"][0].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_token_level_ce_matches_reference_and_oracle():
+    """config.loss_type = "token_ce" through the drop-in class (node-level tasks, modeling_finetune.py:162-164, :198-202): labels [B,S]
+    with -100 on unlabelled rows, `task_logits` for every row.  Logits and loss against the reference fixture, gradients against the
+    oracle on the bf16-rounded weights; evaluation without labels returns the same all-row logits."""
+    import os
+    from _util import GOLDEN, spec_mod, weights_mod
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    z = np.load(os.path.join(GOLDEN, "ft_tiny_tokence.npz"))
+    C = 7
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=C)
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    cfg = M.GraphGPTConfig(vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+                           num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
+                           max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=13, next_n_token=1,
+                           num_labels=C, loss_type="token_ce", problem_type="single_label_classification")
+    model = M.GraphGPTTaskModel(cfg, seed=1)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model.eval()
+    out = model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], position_ids=b["position_ids"], task_labels=b["task_labels"])
+    loss = float(out.task_loss.item())
+    out.task_loss.backward()
+    ref = float(z["loss"])
+    record_error("ft_tiny_tokence", "loss_rel_vs_reference_fp32", abs(loss - ref) / ref, 5e-3)
+    assert abs(loss - ref) <= 5e-3 * ref, (loss, ref)
+    lg = out.task_logits.float().cpu().numpy()
+    assert lg.shape == z["logits"].shape == (10, 24, C)
+    real = (b["input_ids"][:, :, 0] != 0).numpy()
+    err = float(np.abs(lg - z["logits"])[real].max()) / float(np.abs(z["logits"][real]).max())
+    record_error("ft_tiny_tokence", "logits_max_rel_vs_reference_fp32 (real rows)", err, 3e-2)
+    assert err < 3e-2, err
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32)
+    fn = lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], loss_type="token_ce")
+    o, grads = O.loss_and_grads(fn, p, "task_loss")
+    got = model._engine.grads()
+    gmax = max(float(g.norm()) for g in grads.values())
+    for k in ("score.weight", "model.layers.0.self_attn.q_proj.weight", "model.layers.1.mlp.down_proj.weight", "model.embed_tokens.weight"):
+        w = grads[k].numpy()
+        e = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        record_error("ft_tiny_tokence", "grad_rel_l2 " + k, e, 6e-2)
+        assert e < 6e-2, f"{k}: {e}"
+    with torch.no_grad():
+        ev = model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], position_ids=b["position_ids"])
+    assert ev.task_loss is None and torch.equal(ev.task_logits, out.task_logits)

@@ -417,3 +417,29 @@ def test_oracle_stack_long_finetune_matches_reference():
     got = grads["model.embed_tokens.weight"].numpy()[:64]
     assert np.linalg.norm(got - z["grad_embed_rows"]) <= 2e-4 * np.linalg.norm(z["grad_embed_rows"])
     np.testing.assert_allclose(np.array([float(grads[str(n)].norm()) for n in z["names"]]), z["grad_norms"], rtol=5e-4, atol=1e-7)
+
+
+def _tokence_case():
+    from _util import GOLDEN, spec_mod, weights_mod
+    z = np.load(os.path.join(GOLDEN, "ft_tiny_tokence.npz"))
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=7)
+    assert [int(x) for x in z["meta_spec"]] == list(spec.as_c_ints())
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    return z, spec, state, b
+
+
+def test_oracle_token_ce_matches_reference():
+    """config.loss_type = "token_ce" (node-level tasks): score + cross-entropy on every labelled row, all-row logits returned."""
+    z, spec, state, b = _tokence_case()
+    assert tuple(b["task_labels"].shape) == tuple(b["input_ids"].shape[:2]) and (b["task_labels"] == -100).any()
+    p = O.to_params(state, torch.float32)
+    fn = lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], loss_type="token_ce")
+    out, grads = O.loss_and_grads(fn, p, "task_loss")
+    assert abs(out["task_loss"].item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    assert tuple(out["task_logits"].shape) == tuple(z["logits"].shape)
+    np.testing.assert_allclose(out["task_logits"].detach().numpy(), z["logits"], rtol=1e-4, atol=3e-5)
+    for k, want in (("score.weight", z["grad_score"]), ("model.layers.1.mlp.down_proj.weight", z["grad_l1_down"])):
+        assert np.linalg.norm(grads[k].numpy() - want) <= 2e-4 * np.linalg.norm(want), k
+    np.testing.assert_allclose(np.array([float(grads[str(n)].norm()) for n in z["names"]]), z["grad_norms"], rtol=5e-4, atol=1e-7)

@@ -769,6 +769,40 @@ def long_fixture():
     print(f"ft_tiny_long written: loss {res['loss']:.6f}")
 
 
+def token_ce_fixture():
+    """Token-level task (config.loss_type = "token_ce", the nodev2 labelling of src/utils/tokenizer_utils.py:688-745): `score` on every
+    row, labels [B,S] with -100 on unlabelled rows (modeling_finetune.py:162-164, :198-202).  7 classes, roughly a third of the real
+    rows labelled."""
+    PT, FT, Cfg = import_reference()
+    C = 7
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=C)
+    state = weights_mod.make_state_dict(spec, seed=1311, std=0.06, head_std=0.3)
+    batch = synth.make_task_batch(B=10, S=24, F=13, V=756, seed=131)
+    rs = np.random.RandomState(13)
+    real = batch["input_ids"][:, :, 0] != 0
+    lab = rs.randint(0, C, size=real.shape).astype(np.int64)
+    lab[~real | (rs.uniform(size=real.shape) > 0.35)] = -100
+    batch["task_labels"] = lab
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    model = FT(ref_config(Cfg, spec, num_labels=C, loss_type="token_ce", problem_type="single_label_classification"))
+    load_weights(model, state)
+    model.eval()
+    o = model(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"], position_ids=tb["position_ids"],
+              task_labels=tb["task_labels"])
+    model.zero_grad()
+    o.task_loss.backward()
+    names = list(state.keys())
+    g = dict(model.named_parameters())
+    res = {"loss": np.float64(o.task_loss.item()), "logits": o.task_logits.detach().float().numpy(),
+           "grad_norms": grad_norms(model, names), "names": np.array(names), "grad_score": g["score.weight"].grad.numpy().copy(),
+           "grad_l1_down": g["model.layers.1.mlp.down_proj.weight"].grad.numpy().copy(),
+           "meta_spec": np.array(spec.as_c_ints(), np.int64), "meta_init": np.array([1311, 0.06, 0.3])}
+    for k, v in batch.items():
+        res["in_" + k] = v
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ft_tiny_tokence.npz"), **res)
+    print(f"ft_tiny_tokence written: loss {res['loss']:.6f}, logits {res['logits'].shape}, labelled rows {(lab >= 0).sum()}")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -800,6 +834,8 @@ def main():
         focal_fixture()
     if not only or "tiny_long" in only:
         long_fixture()
+    if not only or "ft_tiny_tokence" in only:
+        token_ce_fixture()
 
 
 if __name__ == "__main__":

@@ -84,6 +84,7 @@ SIGNATURES = {
     "gget_set_auc": (i32, [vp, i32, C.c_uint32]),
     "gget_set_focal_gamma": (i32, [vp, f32]),
     "gget_set_stack_method": (i32, [vp, i32]),
+    "gget_set_rope_range": (i32, [vp, f32]),
     "gget_debug_probe": (i32, [vp, i32, C.POINTER(f32)]),
     "gget_set_dropout_ex": (i32, [vp, f32, f32, f32]),
     "gget_op_gateup_geglu": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),

@@ -172,6 +172,7 @@ struct Ws {
   uint64_t cnt, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
   // task head
   uint64_t tlogits, tdlogits, pooled_h, auc_lists;
+  uint64_t rr_cos, rr_sin, rr_ids;   // rope_range: per-token angle tables [T][32] fp32 and the identity position list [T] int64
   uint64_t tok_stat;   // token-level head: loss sum, labelled rows, 1 / rows
   uint64_t long_wgt;   // stack_method = "long": per-sample loss weights (fp32 [max_batch])
   uint64_t head_x[6] = {0}, head_a[5] = {0}, head_d[2] = {0};   // MLP head: layer inputs / activations (bf16), fp32 gradient ping-pong
@@ -227,6 +228,9 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.segs = b.take((uint64_t)pl.params.size() * sizeof(GgetSegment));
   w.wg32 = b.take(kWgSplit * 4 * d * d * 4);   // split-K slabs of the q|k|v|o wgrad
   w.long_wgt = b.take((uint64_t)c.max_batch * 4);
+  w.rr_cos = b.take(T * 32 * 4);
+  w.rr_sin = b.take(T * 32 * 4);
+  w.rr_ids = b.take(T * 8);
   w.emb_sort = b.take(k_embed_bwd_ws_elems(T * (uint64_t)c.stacked_feat, (uint64_t)c.vocab_size) * 4);
   w.emb_cnt = k_embed_dense_ok(c.vocab_size, pl.has_gate) ? b.take(T * align_up(c.vocab_size, 64) * 2) : 0;   // bf16 [T][Vp] count matrix
   w.emb_slab = k_embed_dense_ok(c.vocab_size, pl.has_gate) ? b.take((uint64_t)kEmbDenseSplit * c.vocab_size * d * 4) : 0;
@@ -317,6 +321,10 @@ struct gget_engine {
   int auc_num_neg = 1;
   float focal_gamma = 0.f;        // focal loss on the SMTP head (config.focal_gamma)
   bool stack_long = false;        // config.stack_method == "long" (gget_set_stack_method)
+  float rope_range = 0.f;         // config.rope_range (gget_set_rope_range)
+  const float* cos_cur = nullptr; // angle tables / position list of the last forward (the per-token ones under rope_range)
+  const float* sin_cur = nullptr;
+  const int64_t* pos_cur = nullptr;
   // in-step kernel probe (gget_debug_probe): HIP events around the grouped weight-gradient launch [0] and the gate|up + GEGLU launch [1]
   // of every layer, on the stream they are launched on - the bench reads the launch durations INSIDE a step from them
   bool probe = false;
@@ -498,6 +506,13 @@ extern "C" int gget_set_dropout_ex(gget_handle_t h, float embed_p, float mlp_p, 
   GGET_REQUIRE(mlp_p == 0.f || h->cfg.mlp_pdrop > 0.f, "MLP dropout needs a handle created with config.mlp_pdrop > 0");
   h->embed_drop_p = embed_p;
   h->mlp_drop_p = mlp_p;
+  return 0;
+}
+
+extern "C" int gget_set_rope_range(gget_handle_t h, float rope_range) {
+  GGET_REQUIRE(h != nullptr, "null handle");
+  GGET_REQUIRE(rope_range >= 0.f, "rope_range must be >= 0");
+  h->rope_range = rope_range;
   return 0;
 }
 
@@ -687,7 +702,7 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
     GemmProblem& p = g.p[0];
     p.A = xn1; p.B = h->P + lo.wqkv; p.C = qkv;
     p.M = T; p.N = 3 * d; p.K = d; p.lda = d; p.ldb = d; p.ldc = 3 * d;
-    p.rope_cos = h->cos_tab; p.rope_sin = h->sin_tab; p.rope_pos = h->pos; p.rope_S = h->S; p.rope_cols = 2 * d;
+    p.rope_cos = h->cos_cur; p.rope_sin = h->sin_cur; p.rope_pos = h->pos_cur; p.rope_S = h->S; p.rope_cols = 2 * d;
     if (int e = gget_gemm_launch(GGET_GEMM_NT, GGET_EPI_ROPE, g, 1, st)) return e;
   }
   if (int e = k_attn_fwd(qkv, h->wsp<int32_t>(h->ws.key_len), attn, h->wsp<float>(lw.lse), h->B, h->S, H, c.causal,
@@ -730,6 +745,13 @@ int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t*
   GGET_REQUIRE(S <= c.max_position, "sequence length %d exceeds max_position %d", S, c.max_position);
   h->B = B; h->S = S; h->T = B * S;
   h->ids = ids; h->pos = pos;
+  h->cos_cur = h->cos_tab; h->sin_cur = h->sin_tab; h->pos_cur = pos;
+  if (h->rope_range > 0.f && pos) {
+    if (int e = k_rope_range_table(pos, h->wsp<float>(h->ws.rr_cos), h->wsp<float>(h->ws.rr_sin), h->wsp<int64_t>(h->ws.rr_ids), B, S,
+                                   h->rope_range, c.rope_theta > 0.f ? c.rope_theta : 10000.0f, st))
+      return e;
+    h->cos_cur = h->wsp<float>(h->ws.rr_cos); h->sin_cur = h->wsp<float>(h->ws.rr_sin); h->pos_cur = h->wsp<int64_t>(h->ws.rr_ids);
+  }
   const int d = c.hidden_size;
   h->packed = mask_is_3d;
   if (mask_is_3d) {
@@ -940,8 +962,8 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   // attention: dattn = dy_o W_o ; (dq,dk,dv) ; inverse RoPE ; dxn1 = dqkv W_qkv
   if (int e = gemm_nn(dy_o, h->P + lo.wo, dattn, T, d, d, d, d, d, nullptr, st)) return e;
   if (int e = k_attn_bwd(h->wsp<bf16_t>(lw.qkv), h->wsp<bf16_t>(lw.attn), dattn, h->wsp<float>(lw.lse),
-                         h->wsp<int32_t>(w.key_len), dqkv, h->wsp<float>(w.delta), h->B, h->S, H, c.causal, h->cos_tab,
-                         h->sin_tab, h->pos, /*qk_rotated=*/1, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st,
+                         h->wsp<int32_t>(w.key_len), dqkv, h->wsp<float>(w.delta), h->B, h->S, H, c.causal, h->cos_cur,
+                         h->sin_cur, h->pos_cur, /*qk_rotated=*/1, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st,
                          h->klo(), h->khi()))
     return e;
   if (int e = gemm_nn(dqkv, h->P + lo.wqkv, dxn, T, d, 3 * d, 3 * d, d, d, nullptr, st)) return e;

@@ -40,6 +40,9 @@ int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rst
 int k_rope(void* qkv, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, int T, int S, int H,
            int inverse, hipStream_t st);
 int k_rope_table(float* cos_tab, float* sin_tab, int max_pos, float theta, hipStream_t st);
+// rope_range > 0: per-token angle tables [B*S][32] from positions rescaled to [0, range) per row, and the identity ids [B*S]
+int k_rope_range_table(const int64_t* pos, float* cos_t, float* sin_t, int64_t* ids, int B, int S, float range, float theta,
+                       hipStream_t st);
 int k_geglu_fwd(const void* gu, void* h, int T, int ff, hipStream_t st);
 int k_geglu_bwd(const void* gu, const void* dh, void* dgu, int T, int ff, hipStream_t st);
 int k_lengths(const int64_t* mask, const int64_t* ids, int ldF, int pad_id, int32_t* key_len, int32_t* pool_row, int B,

@@ -509,6 +509,35 @@ __global__ void rope_table_kernel(float* cos_tab, float* sin_tab, int max_pos, f
   sin_tab[i] = (float)sin((double)fr);
 }
 
+// config.rope_range > 0 (utils_graphgpt.reset_pos_ids :574-581, applied whenever position ids are passed): the positions of a row are
+// rescaled into [0, range) before the rotary embedding - p' = float(p) * range / float(max_s p + 1) - so they are no longer integers
+// and the precomputed table does not apply: this kernel writes the angles of every TOKEN ([T][32] cos / sin, same evaluation as
+// rope_table_kernel) and the identity position list that addresses them.  One block per row.
+__global__ void __launch_bounds__(kBlock) rope_range_table_kernel(const int64_t* __restrict__ pos, float* __restrict__ cos_t,
+                                                                  float* __restrict__ sin_t, int64_t* __restrict__ ids, int S,
+                                                                  float range, float theta) {
+  __shared__ float red[kBlock / 64];
+  const int b = blockIdx.x;
+  const int64_t* row = pos + (size_t)b * S;
+  float mx = -INFINITY;
+  for (int s = threadIdx.x; s < S; s += kBlock) mx = fmaxf(mx, (float)row[s]);     // (positions < 2^24: exact in fp32)
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = red[0];
+  for (int i = 1; i < kBlock / 64; ++i) mx = fmaxf(mx, red[i]);
+  const float den = mx + 1.0f;
+  for (int i = threadIdx.x; i < S * 32; i += kBlock) {
+    const int s = i >> 5, j = i & 31;
+    const float scaled = (float)row[s] * range / den;
+    const float inv_freq = 1.0f / powf(theta, (float)(2 * j) / 64.0f);
+    const float fr = scaled * inv_freq;
+    cos_t[((size_t)b * S + s) * 32 + j] = (float)cos((double)fr);
+    sin_t[((size_t)b * S + s) * 32 + j] = (float)sin((double)fr);
+    if (j == 0) ids[(size_t)b * S + s] = (int64_t)b * S + s;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K9  GEGLU: h = bf16(gelu(g)) * u   (hf LlamaMLP.forward :174-176, exact-erf GELU)
 // gu is [T, 2ff] with gate columns [0,ff) and up columns [ff,2ff).
@@ -1736,6 +1765,14 @@ int k_rope(void* qkv, const float* cos_tab, const float* sin_tab, const int64_t*
 int k_rope_table(float* cos_tab, float* sin_tab, int max_pos, float theta, hipStream_t st) {
   hipLaunchKernelGGL(rope_table_kernel, dim3((max_pos * 32 + 255) / 256), dim3(256), 0, st, cos_tab, sin_tab, max_pos,
                      theta);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_rope_range_table(const int64_t* pos, float* cos_t, float* sin_t, int64_t* ids, int B, int S, float range, float theta,
+                       hipStream_t st) {
+  if (B * S == 0) return 0;
+  hipLaunchKernelGGL(rope_range_table_kernel, dim3(B), dim3(kBlock), 0, st, pos, cos_t, sin_t, ids, S, range, theta);
   GGET_LAUNCH_CHECK();
   return 0;
 }

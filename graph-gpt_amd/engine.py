@@ -212,6 +212,10 @@ class Engine:
         """config.stack_method == "long": per-token 1/nnz embedding ratio + per-feature-level SMTP loss weights."""
         L.check(self.lib.gget_set_stack_method(self.h, int(bool(stack_long))))
 
+    def set_rope_range(self, rope_range: float):
+        """config.rope_range: > 0 rescales the position ids of a forward to [0, rope_range) per row (per-token rotary angles)."""
+        L.check(self.lib.gget_set_rope_range(self.h, float(rope_range)))
+
     def set_auc(self, num_neg: int = 1, seed: int = 0):
         """Negatives per positive and the sampling seed of the NEXT forward_task(problem=PROBLEM_AUC)."""
         L.check(self.lib.gget_set_auc(self.h, int(num_neg), int(seed) & 0xFFFFFFFF))

@@ -74,7 +74,6 @@ class GraphGPTConfig:
         need(self.embed_dim == 0, "raw-embedding inputs (embed_dim>0)")
         need(self.stack_method in ("short", "long", None), f"stack_method={self.stack_method!r}")
         need(not self.use_discriminative and self.use_generative, "contrastive (pretrain-cl) head")
-        need(self.rope_range == 0, "rope_range rescaling")
         need(len(self.mlp) <= 4, "an MLP score head with more than 4 hidden layers")
         need(self.pooling_method == "last", "pooling other than 'last'")
         return ModelSpec(kind=kind, vocab_size=self.vocab_size, hidden_size=self.hidden_size,
@@ -88,7 +87,8 @@ class GraphGPTConfig:
                          path_pdrop=float(self.path_pdrop), mlp_pdrop=float(self.mlp_pdrop),
                          embed_pdrop=float(self.embed_pdrop),
                          head_mlp=tuple(int(x) for x in self.mlp) if kind == KIND_TASK else (),
-                         head_pdrop=float(self.dropout) if kind == KIND_TASK else 0.0)
+                         head_pdrop=float(self.dropout) if kind == KIND_TASK else 0.0,
+                         rope_range=float(self.rope_range or 0))
 
     def to_dict(self) -> Dict[str, Any]:
         return {k: v for k, v in self.__dict__.items() if not k.startswith("_")}
@@ -260,6 +260,7 @@ class _GgetModel(nn.Module):
             p.data = new.view(name, "master")
         new.sync_params()
         new.set_stack_method(getattr(self.config, "stack_method", None) == "long")
+        new.set_rope_range(float(getattr(self.config, "rope_range", 0) or 0))
         self._engine = new
         self._anchor = torch.zeros(1, device=new.device, requires_grad=True)
         self._dirty = False
@@ -319,8 +320,8 @@ class _GgetModel(nn.Module):
             if S > maxp:
                 raise IndexError(f"sequence length {S} exceeds max_position_embeddings {maxp}")
             return
-        if os.environ.get("GGET_SKIP_INPUT_CHECKS"):
-            return
+        if os.environ.get("GGET_SKIP_INPUT_CHECKS") or float(getattr(self.config, "rope_range", 0) or 0) > 0:
+            return      # (rope_range: the positions are rescaled per row, angles are evaluated per token - no table to overrun)
         hi = int(position_ids.max()) if position_ids.numel() else 0
         lo = int(position_ids.min()) if position_ids.numel() else 0
         if hi >= maxp or lo < 0:

@@ -41,6 +41,7 @@ class ModelSpec:
     embed_pdrop: float = 0.0        # dropout on the gathered token embeddings (modeling_helpers.py:96-98)
     head_mlp: Tuple[int, ...] = ()  # fine-tune: hidden widths of the `MLP` score head (config.mlp, src/utils/modules_utils.py:8-34); () = Linear
     head_pdrop: float = 0.0         # dropout inside that head (config.dropout)
+    rope_range: float = 0.0         # > 0: position ids passed to a forward are rescaled to [0, rope_range) per row (utils_graphgpt.py:574-581)
 
     def __post_init__(self):
         assert self.hidden_size == self.num_heads * self.head_dim, "no GQA / odd head dims on this path"

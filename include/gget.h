@@ -132,6 +132,13 @@ int gget_set_dropout(gget_handle_t h, float attention_p, float path_p, uint32_t 
  * dropout between activation and Linear inside the MLP score head (src/utils/modules_utils.py:27-33). */
 int gget_set_dropout_ex(gget_handle_t h, float embed_p, float mlp_p, float head_p);
 
+/* replaces: `config.rope_range` (configuration_graphgpt.py:42; utils_graphgpt.reset_pos_ids :574-581 through resolve_forward_defaults,
+ * modeling_common.py:185-203): when > 0 and position ids are passed to a forward, the positions of every row are rescaled to
+ * float(p) * rope_range / float(max_s p + 1) before the rotary embedding.  The engine then evaluates the angles per token (the
+ * precomputed integer-position table does not apply).  Default 0 = off; forwards without position ids are not affected, as in the
+ * reference. */
+int gget_set_rope_range(gget_handle_t h, float rope_range);
+
 /* replaces: `config.stack_method` ("short" | "long", configuration_graphgpt.py:50; examples/node_lvl/proteins_supervised.sh:31 runs
  * "long").  stack_long != 0: (i) the stacked embedding of every token is multiplied by min(1, 1 / (its non-zero feature ids + 1e-7))
  * (_get_stacked_inputs_embeds, modeling_helpers.py:106-110) in forward and backward, both model kinds; (ii) the SMTP head weighs

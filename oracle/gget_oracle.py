@@ -150,6 +150,11 @@ def backbone(spec, p: Dict[str, torch.Tensor], x, attention_mask, position_ids, 
     `attn_keep(layer)` -> [B,H,S,S] attention-dropout multipliers of that layer (see attention); `mlp_keep(layer)` -> the
     pair of MLP dropout multipliers (see mlp)."""
     B, S, d = x.shape
+    rope_range = float(getattr(spec, "rope_range", 0) or 0)
+    if rope_range > 0 and position_ids is not None:
+        # utils_graphgpt.reset_pos_ids (:574-581) via resolve_forward_defaults (modeling_common.py:185-203): per-row rescaling to
+        # [0, rope_range), float positions from here on
+        position_ids = position_ids.float() * rope_range / (position_ids.max(dim=-1, keepdim=True).values + 1).float()
     if position_ids is None:
         position_ids = torch.arange(S)[None, :].expand(B, S)      # hf :389-392
     cos, sin = rope_cos_sin(position_ids, spec.head_dim, spec.rope_theta, x.dtype)

@@ -1269,3 +1269,53 @@ def test_token_level_ce_matches_reference_and_oracle():
     with torch.no_grad():
         ev = model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], position_ids=b["position_ids"])
     assert ev.task_loss is None and torch.equal(ev.task_logits, out.task_logits)
+
+
+@pytest.mark.gpu
+def test_rope_range_matches_reference_and_oracle():
+    """config.rope_range = 6 through the drop-in class (utils_graphgpt.reset_pos_ids :574-581): uneven position ids per row, rescaled to
+    [0, 6) - the engine evaluates the rotary angles per token.  Logits / loss against the reference fixture, q / k projection
+    gradients (the rotation's backward) against the oracle on the bf16-rounded weights."""
+    import os
+    from _util import GOLDEN, spec_mod, weights_mod
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    z = np.load(os.path.join(GOLDEN, "ft_tiny_roperange.npz"))
+    rr = float(z["rope_range"])
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=2, rope_range=rr)
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    cfg = M.GraphGPTConfig(vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+                           num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
+                           max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=13, next_n_token=1,
+                           num_labels=2, rope_range=rr)
+    model = M.GraphGPTTaskModel(cfg, seed=1)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model.eval()
+    out = model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], position_ids=b["position_ids"], task_labels=b["task_labels"])
+    loss = float(out.task_loss.item())
+    out.task_loss.backward()
+    ref = float(z["loss"])
+    record_error("ft_tiny_roperange", "loss_rel_vs_reference_fp32", abs(loss - ref) / ref, 2e-2)
+    assert abs(loss - ref) <= 2e-2 * ref, (loss, ref)
+    lg = out.task_logits.float().cpu().numpy()
+    err = float(np.abs(lg - z["logits"]).max()) / float(np.abs(z["logits"]).max())
+    record_error("ft_tiny_roperange", "logits_max_rel_vs_reference_fp32", err, 3e-2)
+    assert err < 3e-2, err
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32)
+    fn = lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"])
+    o, grads = O.loss_and_grads(fn, p, "task_loss")
+    import dataclasses
+    with torch.no_grad():
+        plain = float(O.task_forward(dataclasses.replace(spec, rope_range=0.0), p, b["input_ids"], b["attention_mask"], b["position_ids"],
+                                     b["task_labels"])["task_loss"])
+    assert abs(plain - ref) > 5 * abs(loss - ref)          # the engine is on the rescaled positions, not on the raw ones
+    got = model._engine.grads()
+    gmax = max(float(g.norm()) for g in grads.values())
+    for k in ("model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.k_proj.weight", "model.layers.1.self_attn.k_proj.weight",
+              "model.layers.1.mlp.down_proj.weight", "score.weight"):
+        w = grads[k].numpy()
+        e = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        record_error("ft_tiny_roperange", "grad_rel_l2 " + k, e, 6e-2)
+        assert e < 6e-2, f"{k}: {e}"

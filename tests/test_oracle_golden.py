@@ -443,3 +443,32 @@ def test_oracle_token_ce_matches_reference():
     for k, want in (("score.weight", z["grad_score"]), ("model.layers.1.mlp.down_proj.weight", z["grad_l1_down"])):
         assert np.linalg.norm(grads[k].numpy() - want) <= 2e-4 * np.linalg.norm(want), k
     np.testing.assert_allclose(np.array([float(grads[str(n)].norm()) for n in z["names"]]), z["grad_norms"], rtol=5e-4, atol=1e-7)
+
+
+def _roperange_case():
+    from _util import GOLDEN, spec_mod, weights_mod
+    z = np.load(os.path.join(GOLDEN, "ft_tiny_roperange.npz"))
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=2,
+                                   rope_range=float(z["rope_range"]))
+    assert [int(x) for x in z["meta_spec"]] == list(spec.as_c_ints())
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    return z, spec, state, b
+
+
+def test_oracle_rope_range_matches_reference():
+    """config.rope_range = 6: position ids rescaled per row to [0, 6) (fractional rotary positions), fine-tune model."""
+    z, spec, state, b = _roperange_case()
+    p = O.to_params(state, torch.float32)
+    fn = lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"])
+    out, grads = O.loss_and_grads(fn, p, "task_loss")
+    assert abs(out["task_loss"].item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    np.testing.assert_allclose(out["task_logits"].detach().numpy(), z["logits"], rtol=1e-4, atol=3e-5)
+    for k, want in (("model.layers.0.self_attn.q_proj.weight", z["grad_l0_q"]), ("model.layers.0.self_attn.k_proj.weight", z["grad_l0_k"])):
+        assert np.linalg.norm(grads[k].numpy() - want) <= 2e-4 * np.linalg.norm(want), k
+    np.testing.assert_allclose(np.array([float(grads[str(n)].norm()) for n in z["names"]]), z["grad_norms"], rtol=5e-4, atol=1e-7)
+    # ... and the rescaling matters on this batch
+    import dataclasses
+    plain = O.task_forward(dataclasses.replace(spec, rope_range=0.0), p, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"])
+    assert abs(plain["task_loss"].item() - float(z["loss"])) > 1e-3 * abs(float(z["loss"]))

@@ -803,6 +803,38 @@ def token_ce_fixture():
     print(f"ft_tiny_tokence written: loss {res['loss']:.6f}, logits {res['logits'].shape}, labelled rows {(lab >= 0).sum()}")
 
 
+def rope_range_fixture():
+    """config.rope_range = 6 (utils_graphgpt.reset_pos_ids :574-581): the fine-tune model with arbitrary position ids per row,
+    rescaled to [0, 6) before the rotary embedding - fractional positions."""
+    PT, FT, Cfg = import_reference()
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=2)
+    state = weights_mod.make_state_dict(spec, seed=1411, std=0.06, head_std=0.3)
+    batch = synth.make_task_batch(B=12, S=24, F=13, V=756, seed=141)
+    rs = np.random.RandomState(14)
+    pos = batch["position_ids"].copy()
+    pos[::2] = pos[::2] * 3 + rs.randint(0, 5, size=(pos[::2].shape[0], 1))       # uneven ranges per row
+    batch["position_ids"] = pos
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    model = FT(ref_config(Cfg, spec, num_labels=2, loss_type=None, rope_range=6))
+    load_weights(model, state)
+    model.eval()
+    o = model(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"], position_ids=tb["position_ids"],
+              task_labels=tb["task_labels"])
+    model.zero_grad()
+    o.task_loss.backward()
+    names = list(state.keys())
+    g = dict(model.named_parameters())
+    res = {"loss": np.float64(o.task_loss.item()), "logits": o.task_logits.detach().float().numpy(), "rope_range": np.float64(6),
+           "grad_norms": grad_norms(model, names), "names": np.array(names),
+           "grad_l0_q": g["model.layers.0.self_attn.q_proj.weight"].grad.numpy().copy(),
+           "grad_l0_k": g["model.layers.0.self_attn.k_proj.weight"].grad.numpy().copy(),
+           "meta_spec": np.array(spec.as_c_ints(), np.int64), "meta_init": np.array([1411, 0.06, 0.3])}
+    for k, v in batch.items():
+        res["in_" + k] = v
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ft_tiny_roperange.npz"), **res)
+    print(f"ft_tiny_roperange written: loss {res['loss']:.6f}")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -836,6 +868,8 @@ def main():
         long_fixture()
     if not only or "ft_tiny_tokence" in only:
         token_ce_fixture()
+    if not only or "ft_tiny_roperange" in only:
+        rope_range_fixture()
 
 
 if __name__ == "__main__":

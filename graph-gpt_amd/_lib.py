@@ -16,7 +16,7 @@ class GgetConfig(C.Structure):
                                    "stacked_feat", "next_n_token", "gated_agg", "causal", "max_position", "num_labels",
                                    "score_bias", "pad_token_id")] + \
                [("rms_eps", f32), ("rope_theta", f32), ("layer_scale_init", f32), ("max_tokens", i32), ("max_batch", i32),
-                ("path_pdrop", f32), ("mlp_pdrop", f32), ("head_mlp_layers", i32), ("head_mlp", i32 * 4)]
+                ("path_pdrop", f32), ("mlp_pdrop", f32), ("head_mlp_layers", i32), ("head_mlp", i32 * 4), ("embed_dim", i32)]
 
 
 class GgetSizes(C.Structure):
@@ -85,6 +85,7 @@ SIGNATURES = {
     "gget_set_focal_gamma": (i32, [vp, f32]),
     "gget_set_stack_method": (i32, [vp, i32]),
     "gget_set_rope_range": (i32, [vp, f32]),
+    "gget_set_raw_embeds": (i32, [vp, vp, i32]),
     "gget_debug_probe": (i32, [vp, i32, C.POINTER(f32)]),
     "gget_set_dropout_ex": (i32, [vp, f32, f32, f32]),
     "gget_op_gateup_geglu": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),

@@ -61,6 +61,7 @@ struct Plan {
   uint64_t n_scratch32 = 0; // fp32 accumulation elements
   std::vector<LayerOff> layers;
   uint64_t emb = 0, emb32 = 0, gate = 0, gate32 = 0, normf = 0, normf32 = 0;
+  uint64_t raw_ln = 0, raw_ln32 = 0, raw_tok = 0, raw_tok32 = 0, raw_proj = 0;   // raw-embedding inputs (embed_dim > 0)
   uint64_t ntp = 0, lm = 0, lm32 = 0, score = 0, score32 = 0, sbias = 0, sbias32 = 0;
   bool has_gate = false, has_ntp = false, has_ls = false;
   // MLP score head (config.head_mlp_layers > 0): n_lin = layers + 1 Linears of widths head_dim[0] = d, ..., head_dim[n_lin] = num_labels
@@ -102,6 +103,11 @@ Plan make_plan(const gget_config_t& c) {
   pl.has_ntp = c.kind == GGET_KIND_PRETRAIN && c.next_n_token > 1;
   add_param(pl, "model.embed_tokens.weight", V, d, -1, true, &pl.emb, &pl.emb32);
   if (pl.has_gate) add_param(pl, "stacked_feat_agg.weight", F, d, -1, true, &pl.gate, &pl.gate32);
+  if (c.embed_dim > 0) {   // modeling_pretrain.py:69-84 / modeling_finetune.py:76-85
+    add_param(pl, "embed_layernorm.weight", c.embed_dim, 0, -1, true, &pl.raw_ln, &pl.raw_ln32);
+    if (c.kind == GGET_KIND_PRETRAIN) add_param(pl, "emb_mask_token", c.embed_dim, 0, -1, true, &pl.raw_tok, &pl.raw_tok32);
+    add_param(pl, "embed_proj.weight", d, c.embed_dim, -1, false, &pl.raw_proj, nullptr);
+  }
   pl.layers.resize(L);
   for (int i = 0; i < L; ++i) {
     LayerOff& lo = pl.layers[i];
@@ -172,6 +178,7 @@ struct Ws {
   uint64_t cnt, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
   // task head
   uint64_t tlogits, tdlogits, pooled_h, auc_lists;
+  uint64_t raw_x, raw_xn, raw_rstd, raw_dxn, raw_dx, raw_flag;   // raw-embedding inputs: blended bf16 [T,e], normalised [T,e], 1/rms [T], their gradients, mask flags [T]
   uint64_t rr_cos, rr_sin, rr_ids;   // rope_range: per-token angle tables [T][32] fp32 and the identity position list [T] int64
   uint64_t tok_stat;   // token-level head: loss sum, labelled rows, 1 / rows
   uint64_t long_wgt;   // stack_method = "long": per-sample loss weights (fp32 [max_batch])
@@ -228,6 +235,11 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.segs = b.take((uint64_t)pl.params.size() * sizeof(GgetSegment));
   w.wg32 = b.take(kWgSplit * 4 * d * d * 4);   // split-K slabs of the q|k|v|o wgrad
   w.long_wgt = b.take((uint64_t)c.max_batch * 4);
+  if (c.embed_dim > 0) {
+    const uint64_t e = c.embed_dim;
+    w.raw_x = b.take(T * e * 2); w.raw_xn = b.take(T * e * 2); w.raw_rstd = b.take(T * 4);
+    w.raw_dxn = b.take(T * e * 2); w.raw_dx = b.take(T * e * 2); w.raw_flag = b.take(T * 4);
+  }
   w.rr_cos = b.take(T * 32 * 4);
   w.rr_sin = b.take(T * 32 * 4);
   w.rr_ids = b.take(T * 8);
@@ -289,6 +301,7 @@ int check_cfg(const gget_config_t* c) {
   GGET_REQUIRE(c->max_tokens > 0 && c->max_batch > 0 && c->max_position > 0, "bad capacities");
   if (c->kind == GGET_KIND_PRETRAIN) GGET_REQUIRE(c->next_n_token >= 1, "next_n_token must be >= 1");
   else GGET_REQUIRE(c->num_labels >= 1, "num_labels must be >= 1");
+  GGET_REQUIRE(c->embed_dim >= 0 && c->embed_dim % 64 == 0 && c->embed_dim <= 2048, "embed_dim must be 0 or a multiple of 64 up to 2048");
   GGET_REQUIRE(c->head_mlp_layers >= 0 && c->head_mlp_layers <= 4, "the MLP score head holds at most 4 hidden layers");
   for (int i = 0; i < c->head_mlp_layers; ++i) GGET_REQUIRE(c->head_mlp[i] > 0, "bad MLP head width");
   return 0;
@@ -322,6 +335,9 @@ struct gget_engine {
   float focal_gamma = 0.f;        // focal loss on the SMTP head (config.focal_gamma)
   bool stack_long = false;        // config.stack_method == "long" (gget_set_stack_method)
   float rope_range = 0.f;         // config.rope_range (gget_set_rope_range)
+  const float* raw_next = nullptr;  // inputs_raw_embeds of the NEXT forward (gget_set_raw_embeds)
+  bool raw_first_label_only = false;   // smtp_inside: the mask-token rule looks at labels[:, :, 0] only (modeling_pretrain.py:136-137)
+  bool raw_used = false;          // the last forward consumed raw embeddings (its backward owes their gradients)
   const float* cos_cur = nullptr; // angle tables / position list of the last forward (the per-token ones under rope_range)
   const float* sin_cur = nullptr;
   const int64_t* pos_cur = nullptr;
@@ -506,6 +522,14 @@ extern "C" int gget_set_dropout_ex(gget_handle_t h, float embed_p, float mlp_p, 
   GGET_REQUIRE(mlp_p == 0.f || h->cfg.mlp_pdrop > 0.f, "MLP dropout needs a handle created with config.mlp_pdrop > 0");
   h->embed_drop_p = embed_p;
   h->mlp_drop_p = mlp_p;
+  return 0;
+}
+
+extern "C" int gget_set_raw_embeds(gget_handle_t h, const float* raw_embeds_dev, int first_label_only) {
+  GGET_REQUIRE(h != nullptr, "null handle");
+  GGET_REQUIRE(h->cfg.embed_dim > 0 || raw_embeds_dev == nullptr, "the handle was created with embed_dim = 0");
+  h->raw_next = raw_embeds_dev;
+  h->raw_first_label_only = first_label_only != 0;
   return 0;
 }
 
@@ -737,7 +761,7 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
 }
 
 int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t* mask, const int64_t* pos, int B, int S,
-                     hipStream_t st, bool mask_is_3d = false) {
+                     hipStream_t st, bool mask_is_3d = false, const int64_t* labels = nullptr) {
   const gget_config_t& c = h->cfg;
   GGET_REQUIRE(B > 0 && S > 0, "empty batch");
   GGET_REQUIRE((long)B * S <= c.max_tokens && B <= c.max_batch, "batch %dx%d exceeds capacity (%d tokens, %d rows)", B, S,
@@ -767,6 +791,26 @@ int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t*
     return e;
   if (h->stack_long)
     if (int e = k_embed_long_ratio(ids, h->wsp<bf16_t>(h->ws.xres[0]), h->T, c.stacked_feat, ldF, d, st)) return e;
+  h->raw_used = false;
+  if (c.embed_dim > 0) {
+    // raw-embedding inputs (modeling_pretrain.py:131-149, modeling_helpers.py:127-139): [rows that carry a label -> emb_mask_token,]
+    // RMSNorm, dropout, embed_proj, added to the stacked token embeddings (the sum is rounded once, in the GEMM epilogue)
+    GGET_REQUIRE(h->raw_next != nullptr, "this model was built with embed_dim > 0: hand the raw embeddings over with gget_set_raw_embeds");
+    const Ws& w = h->ws;
+    const int e_ = c.embed_dim;
+    const bool blend = c.kind == GGET_KIND_PRETRAIN && labels != nullptr;
+    if (int e = k_raw_blend(h->raw_next, blend ? labels : nullptr, c.next_n_token, h->raw_first_label_only,
+                            blend ? h->P + h->plan.raw_tok : nullptr, h->wsp<bf16_t>(w.raw_x), h->wsp<int32_t>(w.raw_flag), h->T, e_, st))
+      return e;
+    if (int e = k_rmsnorm_fwd(h->wsp<bf16_t>(w.raw_x), h->P + h->plan.raw_ln, h->wsp<bf16_t>(w.raw_xn), h->wsp<float>(w.raw_rstd), h->T, e_,
+                              c.rms_eps, st))
+      return e;
+    if (int e = k_elem_dropout(h->wsp<bf16_t>(w.raw_xn), h->T, e_, GGET_DROP_STREAM_RAW, h->embed_drop(), st)) return e;
+    bf16_t* x0 = h->wsp<bf16_t>(w.xres[0]);
+    if (int e = gemm_nt(h->wsp<bf16_t>(w.raw_xn), h->P + h->plan.raw_proj, x0, x0, h->T, d, e_, e_, e_, d, nullptr, st)) return e;
+    h->raw_used = true;
+    h->raw_next = nullptr;
+  }
   for (int i = 0; i < c.num_layers; ++i)
     if (int e = layer_forward(h, i, st)) return e;
   return k_rmsnorm_fwd(h->wsp<bf16_t>(h->ws.xres[c.num_layers]), h->P + h->plan.normf, h->wsp<bf16_t>(h->ws.hidden),
@@ -783,7 +827,7 @@ static int forward_pretrain_impl(gget_handle_t h, const int64_t* input_ids_dev, 
   hipStream_t st = (hipStream_t)stream;
   const gget_config_t& c = h->cfg;
   h->fwd_valid = false;
-  if (int e = backbone_forward(h, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st, mask_is_3d))
+  if (int e = backbone_forward(h, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st, mask_is_3d, labels_dev))
     return e;
   const Ws& w = h->ws;
   const int T = h->T, d = c.hidden_size, n = c.next_n_token, V = c.vocab_size;
@@ -1122,6 +1166,22 @@ extern "C" int gget_backward_end(gget_handle_t h, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const gget_config_t& c = h->cfg;
   float* s32 = h->wsp<float>(h->ws.scratch32);
+  if (h->raw_used) {
+    // backward of the raw-embedding branch (it received the same gradient as the token embeddings): dW_proj = dx^T xn,
+    // d xn = dx W_proj (dropout mask again), RMSNorm backward, and the labelled rows' gradient summed into emb_mask_token
+    const Ws& w = h->ws;
+    const int T = h->T, d = c.hidden_size, e_ = c.embed_dim;
+    if (int e = gget_gemm_single(GGET_GEMM_TN, GGET_EPI_NONE, h->dx_cur, h->wsp<bf16_t>(w.raw_xn), h->G + h->plan.raw_proj, nullptr, d, e_, T,
+                                 d, e_, e_, nullptr, nullptr, 1, st))
+      return e;
+    if (int e = gemm_nn(h->dx_cur, h->P + h->plan.raw_proj, h->wsp<bf16_t>(w.raw_dxn), T, e_, d, d, e_, e_, nullptr, st)) return e;
+    if (int e = k_elem_dropout(h->wsp<bf16_t>(w.raw_dxn), T, e_, GGET_DROP_STREAM_RAW, h->embed_drop(), st)) return e;
+    if (int e = k_rmsnorm_bwd(h->wsp<bf16_t>(w.raw_dxn), h->wsp<bf16_t>(w.raw_x), h->P + h->plan.raw_ln, h->wsp<float>(w.raw_rstd), nullptr,
+                              h->wsp<bf16_t>(w.raw_dx), s32 + h->plan.raw_ln32, T, e_, st, kAccumCopies, align_up((uint64_t)e_, 128)))
+      return e;
+    if (c.kind == GGET_KIND_PRETRAIN)
+      if (int e = k_raw_tok_grad(h->wsp<bf16_t>(w.raw_dx), h->wsp<int32_t>(w.raw_flag), s32 + h->plan.raw_tok32, T, e_, st)) return e;
+  }
   if (h->stack_long)   // d(e * ratio) / de = ratio
     if (int e = k_embed_long_ratio(h->ids, h->dx_cur, h->T, c.stacked_feat, c.stacked_feat, c.hidden_size, st)) return e;
   if (int e = embed_bwd(h->ids, h->dx_cur, h->P + h->plan.emb, h->plan.has_gate ? h->P + h->plan.gate : nullptr,

@@ -20,6 +20,13 @@ struct GgetSegment {
 int k_embed_fwd(const int64_t* ids, const void* emb, const void* gate, void* out, int T, int F, int ldF, int d,
                 hipStream_t st, ElemDropArg E = ElemDropArg{0, 1.f, 0});
 int k_elem_dropout(void* x, long T, int n, unsigned stream, ElemDropArg E, hipStream_t st);
+#define GGET_DROP_STREAM_RAW 60u      /* raw_embed_dropout (48-50: embed / MLP, 51 + layer: the MLP score head) */
+// raw-embedding inputs (config.embed_dim > 0; modeling_pretrain.py:131-149): out[t,:] = bf16(raw[t,:]), or the mask token on rows whose
+// labels are all set (first_only: whose first label is set); flag[t] = 1 on those rows.  labels == nullptr: no row is replaced.
+int k_raw_blend(const float* raw, const int64_t* labels, int n, bool first_only, const void* tok, void* out, int32_t* flag, int T, int e,
+                hipStream_t st);
+// d emb_mask_token += sum over the flagged rows of dx[t,:]  (fp32 accumulator, copy 0)
+int k_raw_tok_grad(const void* dx, const int32_t* flag, float* dtok, int T, int e, hipStream_t st);
 // stack_method = "long": x[t,:] *= min(1, bf16(1 / (non-zero ids of token t + 1e-7))) in place (forward value and its gradient);
 // w[b] = 1 / (labelled cells of sample b + 1e-7) - modeling_helpers.py:106-110, :327-342
 int k_embed_long_ratio(const int64_t* ids, void* x, int T, int F, int ldF, int d, hipStream_t st);

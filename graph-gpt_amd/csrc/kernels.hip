@@ -86,6 +86,34 @@ __global__ void __launch_bounds__(kBlock) sample_mask_wgt_kernel(const int64_t* 
   }
 }
 
+// raw-embedding inputs (config.embed_dim > 0): the `inputs_raw_embeds.to(dtype)` cast and the mask-token blend of
+// GraphGPTPretrainBase.prepare_inputs_embeds (modeling_pretrain.py:131-143): embed_mask = (labels == -100).sum(-1).bool() keeps the raw row
+// when ANY of the token's labels is unset (smtp_inside: when its first label is unset); the other rows become emb_mask_token.
+__global__ void __launch_bounds__(128) raw_blend_kernel(const float* __restrict__ raw, const int64_t* __restrict__ labels, int n,
+                                                        int first_only, const bf16_t* __restrict__ tok, bf16_t* __restrict__ out,
+                                                        int32_t* __restrict__ flag, int e) {
+  const int t = blockIdx.x;
+  bool masked = false;
+  if (labels) {
+    const int64_t* lr = labels + (size_t)t * n;
+    int unset = 0;
+    for (int f = 0; f < (first_only ? 1 : n); ++f) unset += lr[f] == -100;
+    masked = unset == 0;
+  }
+  if (threadIdx.x == 0) flag[t] = masked ? 1 : 0;
+  for (int j = threadIdx.x; j < e; j += blockDim.x) out[(size_t)t * e + j] = masked ? tok[j] : f2bf(raw[(size_t)t * e + j]);
+}
+__global__ void __launch_bounds__(kBlock) raw_tok_grad_kernel(const bf16_t* __restrict__ dx, const int32_t* __restrict__ flag,
+                                                              float* __restrict__ dtok, int T, int e) {
+  const int t0 = blockIdx.x * 256, t1 = min(T, t0 + 256);
+  for (int j = threadIdx.x; j < e; j += kBlock) {
+    float s = 0.f;
+    for (int t = t0; t < t1; ++t)
+      if (flag[t]) s += bf2f(dx[(size_t)t * e + j]);
+    if (s != 0.f) unsafeAtomicAdd(dtok + j, s);
+  }
+}
+
 // backward of K1: dW[v,:] = sum over cells (t,f) with ids[t,f]==v of dx[t,:] (* G[f,:]).
 // SMTP batches hit a few hundred vocabulary rows with ~10^5 cells (half of them the <mask> row), so a direct
 // atomic scatter serialises on hot rows.  Instead: counting sort of the cells by id on the device
@@ -1661,6 +1689,20 @@ int k_embed_fwd(const int64_t* ids, const void* emb, const void* gate, void* out
   if (T == 0) return 0;
   hipLaunchKernelGGL(embed_fwd_kernel, dim3(T), dim3(128), 0, st, ids, (const bf16_t*)emb, (const bf16_t*)gate,
                      (bf16_t*)out, T, F, ldF, d, E);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_raw_blend(const float* raw, const int64_t* labels, int n, bool first_only, const void* tok, void* out, int32_t* flag, int T, int e,
+                hipStream_t st) {
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(raw_blend_kernel, dim3(T), dim3(128), 0, st, raw, labels, n, first_only ? 1 : 0, (const bf16_t*)tok, (bf16_t*)out, flag, e);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+int k_raw_tok_grad(const void* dx, const int32_t* flag, float* dtok, int T, int e, hipStream_t st) {
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(raw_tok_grad_kernel, dim3((T + 255) / 256), dim3(kBlock), 0, st, (const bf16_t*)dx, flag, dtok, T, e);
   GGET_LAUNCH_CHECK();
   return 0;
 }

@@ -52,6 +52,7 @@ class Engine:
         cfg.head_mlp_layers = len(hm)
         for i, x in enumerate(hm):
             cfg.head_mlp[i] = x
+        cfg.embed_dim = int(getattr(spec, "embed_dim", 0) or 0)
         self.cfg = cfg
         sz = L.GgetSizes()
         L.check(self.lib.gget_query_sizes(C.byref(cfg), C.byref(sz)))
@@ -211,6 +212,17 @@ class Engine:
     def set_stack_method(self, stack_long: bool):
         """config.stack_method == "long": per-token 1/nnz embedding ratio + per-feature-level SMTP loss weights."""
         L.check(self.lib.gget_set_stack_method(self.h, int(bool(stack_long))))
+
+    def set_raw_embeds(self, raw_embeds, first_label_only: bool = False):
+        """inputs_raw_embeds [B,S,embed_dim] of the NEXT forward (config.embed_dim > 0); first_label_only = the smtp_inside mask rule."""
+        if raw_embeds is None:
+            self._raw_keep = None
+            L.check(self.lib.gget_set_raw_embeds(self.h, None, 0))
+            return
+        assert raw_embeds.dim() == 3 and raw_embeds.shape[-1] == self.cfg.embed_dim, \
+            f"inputs_raw_embeds must be [B,S,{self.cfg.embed_dim}], got {tuple(raw_embeds.shape)} (the [B,S,S,e] form is not supported)"
+        self._raw_keep = raw_embeds.to(device=self.device, dtype=torch.float32).contiguous()
+        L.check(self.lib.gget_set_raw_embeds(self.h, _ptr(self._raw_keep), int(bool(first_label_only))))
 
     def set_rope_range(self, rope_range: float):
         """config.rope_range: > 0 rescales the position ids of a forward to [0, rope_range) per row (per-token rotary angles)."""

@@ -71,7 +71,7 @@ class GraphGPTConfig:
         need(self.hidden_act == "gelu", f"hidden_act={self.hidden_act!r}; the reference configs use exact-erf 'gelu'")
         need(self.head_dim == 64 and self.hidden_size == 64 * self.num_attention_heads, "head_dim must be 64")
         need(self.num_key_value_heads == self.num_attention_heads, "GQA is not used by the reference configs")
-        need(self.embed_dim == 0, "raw-embedding inputs (embed_dim>0)")
+        need(self.embed_dim % 64 == 0 and 0 <= self.embed_dim <= 2048, f"embed_dim={self.embed_dim}: raw-embedding width must be a multiple of 64 (<= 2048)")
         need(self.stack_method in ("short", "long", None), f"stack_method={self.stack_method!r}")
         need(not self.use_discriminative and self.use_generative, "contrastive (pretrain-cl) head")
         need(len(self.mlp) <= 4, "an MLP score head with more than 4 hidden layers")
@@ -88,7 +88,7 @@ class GraphGPTConfig:
                          embed_pdrop=float(self.embed_pdrop),
                          head_mlp=tuple(int(x) for x in self.mlp) if kind == KIND_TASK else (),
                          head_pdrop=float(self.dropout) if kind == KIND_TASK else 0.0,
-                         rope_range=float(self.rope_range or 0))
+                         rope_range=float(self.rope_range or 0), embed_dim=int(self.embed_dim or 0))
 
     def to_dict(self) -> Dict[str, Any]:
         return {k: v for k, v in self.__dict__.items() if not k.startswith("_")}
@@ -251,13 +251,13 @@ class _GgetModel(nn.Module):
         cap_b = max(need_b, e.cfg.max_batch if e else 0)
         new = Engine(self.spec, cap_tok, cap_b)
         for name, p in self._flat.items():
-            new.view(name, "master").copy_(p.data.to(new.device, torch.float32))
+            new.view(name, "master").view(p.shape).copy_(p.data.to(new.device, torch.float32))
         if e is not None:
             new.adam_m.copy_(e.adam_m)
             new.adam_v.copy_(e.adam_v)
             new.step_count = e.step_count
         for name, p in self._flat.items():
-            p.data = new.view(name, "master")
+            p.data = new.view(name, "master").view(p.shape)      # (emb_mask_token is [1,1,e] in the reference, flat in the engine)
         new.sync_params()
         new.set_stack_method(getattr(self.config, "stack_method", None) == "long")
         new.set_rope_range(float(getattr(self.config, "rope_range", 0) or 0))
@@ -307,7 +307,7 @@ class _GgetModel(nn.Module):
         if self.materialize_grads:
             scale = g.to(torch.float32) / world
             for name, p in self._flat.items():
-                p.grad = e.view(name, "grad").to(torch.float32) * scale
+                p.grad = (e.view(name, "grad").to(torch.float32) * scale).view(p.shape)
         self._dirty = True  # an external optimizer will now touch the master weights
 
     def _check_positions(self, position_ids, S):
@@ -351,7 +351,8 @@ class GraphGPTPretrainBase(_GgetModel):
                 inputs_raw_embeds=None, labels=None, label_mask=None, sample_wgt=None, use_cache=None,
                 output_attentions=None, output_hidden_states=None, return_dict=None, cache_position=None):
         assert inputs_embeds is None, "inputs_embeds is not supported (reference asserts the same, modeling_helpers.py:95)"
-        assert inputs_raw_embeds is None, "raw embeddings need embed_dim>0 which this engine rejects at construction"
+        assert (inputs_raw_embeds is not None) == (int(self.config.embed_dim or 0) > 0), \
+            "inputs_raw_embeds are given exactly when the model was built with embed_dim > 0 (modeling_pretrain.py:131-132)"
         if input_ids.dim() == 2:
             input_ids = input_ids[:, :, None]
         if getattr(self.config, "smtp_inside", False):
@@ -376,6 +377,8 @@ class GraphGPTPretrainBase(_GgetModel):
         self._check_positions(position_ids, S)
         self._validate_inputs(input_ids, attention_mask, labels)
         e = self._pre_forward(B, S)
+        if inputs_raw_embeds is not None:
+            e.set_raw_embeds(inputs_raw_embeds, first_label_only=bool(getattr(self.config, "smtp_inside", False)))
         loss = e.forward_pretrain(input_ids, attention_mask, labels, sample_wgt, position_ids)
         return _PretrainOutput(self._wrap_loss(loss), _LazyLogits(self))
 
@@ -386,7 +389,9 @@ class GraphGPTTaskModel(_GgetModel):
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 inputs_raw_embeds=None, task_labels=None, cls_idx=None, sample_wgt=None, use_cache=None,
                 output_attentions=None, output_hidden_states=None, return_dict=None, **kwargs):
-        assert inputs_embeds is None and inputs_raw_embeds is None
+        assert inputs_embeds is None
+        assert (inputs_raw_embeds is not None) == (int(self.config.embed_dim or 0) > 0), \
+            "inputs_raw_embeds are given exactly when the model was built with embed_dim > 0 (modeling_helpers.py:127-139)"
         if input_ids.dim() == 2:
             input_ids = input_ids[:, :, None]
         B, S = input_ids.shape[:2]
@@ -421,6 +426,8 @@ class GraphGPTTaskModel(_GgetModel):
             self._auc_calls = getattr(self, "_auc_calls", 0) + 1
             self.last_auc_seed = (int(getattr(self, "auc_seed", 0)) + 0x9E3779B1 * self._auc_calls) & 0xFFFFFFFF
             e.set_auc(cfg.num_neg or 1, self.last_auc_seed)
+        if inputs_raw_embeds is not None:
+            e.set_raw_embeds(inputs_raw_embeds)
         loss, logits, hid = e.forward_task(input_ids, attention_mask, position_ids, task_labels, sample_wgt, code)
         return DoubleHeadsModelOutput(pretrain_loss=None, task_loss=self._wrap_loss(loss), pretrain_logits=None,
                                       task_logits=logits, task_hidden_states=hid)
@@ -452,8 +459,8 @@ def elem_drop_keep(seed: int, which: str, layer: int, rows: int, cols: int, p: f
     from .smtp import _rng24
     if p <= 0:
         return np.ones((rows, cols), np.float32)
-    stream = {"embed": 48, "mlp_act": 49, "mlp_out": 50, "head": 51 + layer}[which]
-    s = (seed ^ 0x5BD1E995) if which == "embed" else ((seed ^ 0x2545F491) if which == "head" else (seed + 0x7F4A7C15 * (layer + 1)))
+    stream = {"embed": 48, "raw": 60, "mlp_act": 49, "mlp_out": 50, "head": 51 + layer}[which]     # "raw": raw_embed_dropout, [T, embed_dim]
+    s = (seed ^ 0x5BD1E995) if which in ("embed", "raw") else ((seed ^ 0x2545F491) if which == "head" else (seed + 0x7F4A7C15 * (layer + 1)))
     s &= 0xFFFFFFFF
     thresh = int(np.float32(p) * np.float32(16777216.0))
     a = np.arange(rows, dtype=np.uint64)[:, None]

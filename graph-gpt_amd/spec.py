@@ -42,6 +42,7 @@ class ModelSpec:
     head_mlp: Tuple[int, ...] = ()  # fine-tune: hidden widths of the `MLP` score head (config.mlp, src/utils/modules_utils.py:8-34); () = Linear
     head_pdrop: float = 0.0         # dropout inside that head (config.dropout)
     rope_range: float = 0.0         # > 0: position ids passed to a forward are rescaled to [0, rope_range) per row (utils_graphgpt.py:574-581)
+    embed_dim: int = 0              # > 0: raw-embedding inputs [B,S,embed_dim] (embed_layernorm, emb_mask_token (pre-train), embed_proj)
 
     def __post_init__(self):
         assert self.hidden_size == self.num_heads * self.head_dim, "no GQA / odd head dims on this path"
@@ -54,6 +55,11 @@ class ModelSpec:
         t["model.embed_tokens.weight"] = (V, d)
         if self.gated_agg:
             t["stacked_feat_agg.weight"] = (F, d)
+        if self.embed_dim > 0:    # modeling_pretrain.py:69-84 / modeling_finetune.py:76-85
+            t["embed_layernorm.weight"] = (self.embed_dim,)
+            if self.kind == KIND_PRETRAIN:
+                t["emb_mask_token"] = (1, 1, self.embed_dim)
+            t["embed_proj.weight"] = (d, self.embed_dim)
         for i in range(self.num_layers):
             p = f"model.layers.{i}."
             t[p + "input_layernorm.weight"] = (d,)

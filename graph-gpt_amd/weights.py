@@ -22,7 +22,7 @@ def make_state_dict(spec: ModelSpec, seed: int = 0, std: float = 0.02, head_std:
     rng = np.random.RandomState(seed)
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     for name, shape in spec.param_table().items():
-        if name.endswith("layernorm.weight") or name == "model.norm.weight":
+        if name.endswith("layernorm.weight") or name == "model.norm.weight":      # (incl. embed_layernorm.weight)
             w = np.ones(shape, np.float32)
         elif name.endswith("lambda_1") or name.endswith("lambda_2"):
             w = np.full(shape, spec.layer_scale_init, np.float32)

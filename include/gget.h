@@ -64,6 +64,7 @@ typedef struct gget_config_t {
   float mlp_pdrop;        /* >0 => MLP dropouts are available (utils_graphgpt.py:69-80): the residual adds run as their own kernels */
   int32_t head_mlp_layers;/* fine-tune: hidden layers of the `MLP` score head (len(config.mlp), src/utils/modules_utils.py:8-34); 0 = Linear */
   int32_t head_mlp[4];    /* their widths */
+  int32_t embed_dim;      /* >0 => raw-embedding inputs [B,S,embed_dim] are projected and added to the token embeddings (config.embed_dim; modeling_pretrain.py:69-84, :131-149; modeling_helpers.py:127-139); multiple of 64 */
 } gget_config_t;
 
 /* Arena sizes the caller must provide (all 256-byte aligned device buffers). */
@@ -131,6 +132,13 @@ int gget_set_dropout(gget_handle_t h, float attention_p, float path_p, uint32_t 
  * are evaluation behaviour.  mlp_p > 0 needs a handle created with config.mlp_pdrop > 0.  head_p: `config.dropout`, the
  * dropout between activation and Linear inside the MLP score head (src/utils/modules_utils.py:27-33). */
 int gget_set_dropout_ex(gget_handle_t h, float embed_p, float mlp_p, float head_p);
+
+/* replaces: the `inputs_raw_embeds` argument of the model forwards (config.embed_dim > 0): fp32 [B,S,embed_dim] on the device, consumed by the
+ * NEXT gget_forward_* call (then forgotten).  Pre-train (modeling_pretrain.py:131-149): rows that carry a label are replaced by the learned
+ * `emb_mask_token` (ALL of its next_n_token labels set - or, first_label_only != 0 = the smtp_inside rule, its first label), then RMSNorm (`embed_layernorm`), dropout (embed_pdrop of gget_set_dropout_ex) and `embed_proj`, added to the stacked token
+ * embeddings; fine-tune (modeling_helpers.py:127-139): the same without the mask token.  A forward of a handle created with embed_dim > 0
+ * fails without it, as the reference's does. */
+int gget_set_raw_embeds(gget_handle_t h, const float* raw_embeds_dev, int first_label_only);
 
 /* replaces: `config.rope_range` (configuration_graphgpt.py:42; utils_graphgpt.reset_pos_ids :574-581 through resolve_forward_defaults,
  * modeling_common.py:185-203): when > 0 and position ids are passed to a forward, the positions of every row are rescaled to

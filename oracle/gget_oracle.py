@@ -55,6 +55,22 @@ def stacked_embed(emb_w: torch.Tensor, input_ids: torch.Tensor, gate_w: Optional
 
 
 # --------------------------------------------------------------------------- K4  (row A4a)
+def raw_embeds_branch(spec, p, raw, dtype, labels=None, first_label_only=False, raw_keep=None):
+    """Raw-embedding inputs (config.embed_dim > 0).  Pre-train (modeling_pretrain.py:131-149, `labels` given): rows whose labels are all
+    set (smtp_inside: whose first label is set) are replaced by emb_mask_token; then embed_layernorm, raw_embed_dropout (`raw_keep`
+    multipliers; None = eval) and embed_proj.  Fine-tune (modeling_helpers.py:127-139): the same without the mask token."""
+    x = raw.to(dtype)
+    if labels is not None:
+        if labels.dim() == 2:
+            labels = labels[:, :, None]
+        embed_mask = (labels[:, :, 0:1] == LABEL_PAD) if first_label_only else (labels == LABEL_PAD).sum(dim=-1, keepdim=True).to(torch.bool)
+        x = embed_mask.to(dtype) * x + (~embed_mask).to(dtype) * p["emb_mask_token"].reshape(1, 1, -1)
+    x = rmsnorm(x, p["embed_layernorm.weight"], spec.rms_eps)
+    if raw_keep is not None:
+        x = x * torch.as_tensor(raw_keep).reshape(x.shape).to(x.dtype)
+    return Fnn.linear(x, p["embed_proj.weight"])
+
+
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float):
     """hf LlamaRMSNorm.forward :62-67 - statistics in fp32, cast back, then scale by weight."""
     dt = x.dtype
@@ -240,10 +256,13 @@ def smtp_head(spec, p, hidden, labels, sample_wgt=None, focal_gamma=0.0, stack_l
 
 
 def pretrain_forward(spec, p, input_ids, attention_mask, labels=None, sample_wgt=None,
-                     position_ids=None, collect=None, embed_keep=None, mlp_keep=None, focal_gamma=0.0, stack_long=False):
+                     position_ids=None, collect=None, embed_keep=None, mlp_keep=None, focal_gamma=0.0, stack_long=False,
+                     inputs_raw_embeds=None, raw_keep=None, smtp_inside=False):
     """`GraphGPTPretrainBase.forward` (modeling_pretrain.py:152-266), generative head only."""
     x, _ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"), embed_keep=embed_keep,
                          stack_long=stack_long)
+    if inputs_raw_embeds is not None:
+        x = x + raw_embeds_branch(spec, p, inputs_raw_embeds, x.dtype, labels, smtp_inside, raw_keep)
     hidden = backbone(spec, p, x, attention_mask, position_ids, collect, mlp_keep=mlp_keep)
     loss, logits = smtp_head(spec, p, hidden, labels, sample_wgt, focal_gamma=focal_gamma, stack_long=stack_long)
     return dict(head1_loss=loss, head1_logits=logits, hidden=hidden)
@@ -261,13 +280,16 @@ def auc_loss(y_pred, y_true, num_neg, idx):
 
 def task_forward(spec, p, input_ids, attention_mask, position_ids=None, task_labels=None,
                  sample_wgt=None, problem_type="single_label_classification", loss_type=None, path_mult=None, attn_keep=None,
-                 num_neg=1, auc_idx=None, embed_keep=None, mlp_keep=None, head_keep=None, stack_long=False):
+                 num_neg=1, auc_idx=None, embed_keep=None, mlp_keep=None, head_keep=None, stack_long=False,
+                 inputs_raw_embeds=None, raw_keep=None):
     """`GraphGPTTaskModel.forward` (modeling_finetune.py:236-326) + `calculate_task_loss`
     (:167-234) + `_get_sequence_len` (modeling_helpers.py:78-86); Linear score head, "last" pooling."""
     if input_ids.dim() == 3:
         input_ids = input_ids[:, :, : spec.stacked_feat]
     x, in_ = stacked_embed(p["model.embed_tokens.weight"], input_ids, p.get("stacked_feat_agg.weight"), embed_keep=embed_keep,
                            stack_long=stack_long)
+    if inputs_raw_embeds is not None:
+        x = x + raw_embeds_branch(spec, p, inputs_raw_embeds, x.dtype, None, False, raw_keep)
     hidden = backbone(spec, p, x, attention_mask, position_ids, path_mult=path_mult, attn_keep=attn_keep, mlp_keep=mlp_keep)
     B = hidden.shape[0]
     seq_len = (in_ != spec.pad_token_id).sum(-1) - 1

@@ -1319,3 +1319,117 @@ def test_rope_range_matches_reference_and_oracle():
         e = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
         record_error("ft_tiny_roperange", "grad_rel_l2 " + k, e, 6e-2)
         assert e < 6e-2, f"{k}: {e}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["pt", "ft"])
+def test_raw_embedding_inputs_match_reference_and_oracle(kind):
+    """config.embed_dim = 64 through the drop-in classes: `inputs_raw_embeds` [B,S,64] -> (pre-train: emb_mask_token on the rows whose labels
+    are all set) -> embed_layernorm -> embed_proj -> added to the stacked token embeddings (modeling_pretrain.py:131-149,
+    modeling_helpers.py:127-139).  Loss against the reference fixture, the branch's three gradients against the oracle."""
+    import os
+    from _util import GOLDEN, spec_mod, weights_mod
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    pt = kind == "pt"
+    z = np.load(os.path.join(GOLDEN, f"{kind}_tiny_rawembed.npz"))
+    E = int(z["embed_dim"])
+    if pt:
+        spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=756, stacked_feat=13, next_n_token=13, embed_dim=E)
+    else:
+        spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=2, embed_dim=E)
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    state["embed_layernorm.weight"] = z["w_embed_ln"]
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    cfg = M.GraphGPTConfig(vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+                           num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
+                           max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=13,
+                           next_n_token=13 if pt else 1, num_labels=2, embed_dim=E)
+    model = (M.GraphGPTPretrainBase if pt else M.GraphGPTTaskModel)(cfg, seed=1)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    assert tuple(model.state_dict()["embed_proj.weight"].shape) == (spec.hidden_size, E)
+    model.eval()
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32)
+    if pt:
+        assert tuple(model.state_dict()["emb_mask_token"].shape) == (1, 1, E)
+        out = model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=b["labels"], inputs_raw_embeds=b["inputs_raw_embeds"])
+        loss_t, lk = out.head1_loss, "head1_loss"
+        fn = lambda q: O.pretrain_forward(spec, q, b["input_ids"], b["attention_mask"], b["labels"], inputs_raw_embeds=b["inputs_raw_embeds"])
+        without = lambda q: O.pretrain_forward(spec, q, b["input_ids"], b["attention_mask"], b["labels"])
+    else:
+        out = model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], position_ids=b["position_ids"], task_labels=b["task_labels"],
+                    inputs_raw_embeds=b["inputs_raw_embeds"])
+        loss_t, lk = out.task_loss, "task_loss"
+        fn = lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"],
+                                      inputs_raw_embeds=b["inputs_raw_embeds"])
+        without = lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"])
+    loss = float(loss_t.item())
+    loss_t.backward()
+    ref = float(z["loss"])
+    tag = f"{kind}_tiny_rawembed"
+    tol = 2e-3 if pt else 2e-2
+    record_error(tag, "loss_rel_vs_reference_fp32", abs(loss - ref) / ref, tol)
+    assert abs(loss - ref) <= tol * ref, (loss, ref)
+    with torch.no_grad():
+        assert abs(float(without(p)[lk]) - ref) > 5 * abs(loss - ref)       # the branch matters on this batch
+    o, grads = O.loss_and_grads(fn, p, lk)
+    got = model._engine.grads()
+    gmax = max(float(g.norm()) for g in grads.values())
+    keys = ["embed_proj.weight", "embed_layernorm.weight", "model.embed_tokens.weight", "model.layers.0.self_attn.q_proj.weight"]
+    keys += ["emb_mask_token", "lm_head.weight"] if pt else ["score.weight"]
+    for k in keys:
+        w = grads[k].numpy().reshape(-1)
+        e = float(np.linalg.norm(got[k].float().cpu().numpy().reshape(-1) - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        record_error(tag, "grad_rel_l2 " + k, e, 6e-2)
+        assert e < 6e-2, f"{k}: {e}"
+    with pytest.raises(AssertionError):      # the forward needs the raw embeddings, like the reference's
+        model(input_ids=b["input_ids"], attention_mask=b["attention_mask"])
+
+
+@pytest.mark.gpu
+def test_raw_embedding_dropout_exact_mask():
+    """Training mode with embed_pdrop = 0.2 on a model with raw-embedding inputs: `raw_embed_dropout` (modeling_pretrain.py:71-72, :146-147)
+    sits between embed_layernorm and embed_proj; its counter-hash mask (stream 60) and the token-embedding mask (stream 48) are
+    regenerated by the Python twin and handed to the oracle."""
+    import os
+    from _util import GOLDEN, spec_mod, weights_mod
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    z = np.load(os.path.join(GOLDEN, "pt_tiny_rawembed.npz"))
+    E, pdrop = int(z["embed_dim"]), 0.2
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=756, stacked_feat=13, next_n_token=13, embed_dim=E, embed_pdrop=pdrop)
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    state["embed_layernorm.weight"] = z["w_embed_ln"]
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    B, S, F = b["input_ids"].shape
+    cfg = M.GraphGPTConfig(vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+                           num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
+                           max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=13, next_n_token=13,
+                           embed_dim=E, embed_pdrop=pdrop)
+    model = M.GraphGPTPretrainBase(cfg, seed=1)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model.train()
+    out = model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=b["labels"], inputs_raw_embeds=b["inputs_raw_embeds"])
+    loss = float(out.head1_loss.item())
+    out.head1_loss.backward()
+    sd = model.last_dropout_seed
+    ek = torch.from_numpy(M.elem_drop_keep(sd, "embed", 0, B * S * F, spec.hidden_size, pdrop)).view(B, S, F, spec.hidden_size)
+    rk = torch.from_numpy(M.elem_drop_keep(sd, "raw", 0, B * S, E, pdrop)).view(B, S, E)
+    assert abs(float((rk == 0).float().mean()) - pdrop) < 0.02
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32)
+    fn = lambda q: O.pretrain_forward(spec, q, b["input_ids"], b["attention_mask"], b["labels"], inputs_raw_embeds=b["inputs_raw_embeds"],
+                                      embed_keep=ek, raw_keep=rk)
+    o, grads = O.loss_and_grads(fn, p, "head1_loss")
+    want = float(o["head1_loss"])
+    record_error("pt_tiny_rawembed_dropout", "loss_rel_vs_oracle_same_masks", abs(loss - want) / want, 2e-3)
+    assert abs(loss - want) <= 2e-3 * want, (loss, want)
+    assert abs(loss - float(z["loss"])) > 1e-3 * want          # the masks are really applied
+    got = model._engine.grads()
+    gmax = max(float(g.norm()) for g in grads.values())
+    for k in ("embed_proj.weight", "embed_layernorm.weight", "emb_mask_token", "model.embed_tokens.weight"):
+        w = grads[k].numpy().reshape(-1)
+        e = float(np.linalg.norm(got[k].float().cpu().numpy().reshape(-1) - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        record_error("pt_tiny_rawembed_dropout", "grad_rel_l2 " + k, e, 6e-2)
+        assert e < 6e-2, f"{k}: {e}"

@@ -472,3 +472,42 @@ def test_oracle_rope_range_matches_reference():
     import dataclasses
     plain = O.task_forward(dataclasses.replace(spec, rope_range=0.0), p, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"])
     assert abs(plain["task_loss"].item() - float(z["loss"])) > 1e-3 * abs(float(z["loss"]))
+
+
+def _rawembed_case(kind):
+    from _util import GOLDEN, spec_mod, weights_mod
+    z = np.load(os.path.join(GOLDEN, f"{kind}_tiny_rawembed.npz"))
+    E = int(z["embed_dim"])
+    if kind == "pt":
+        spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=756, stacked_feat=13, next_n_token=13, embed_dim=E)
+    else:
+        spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=2, embed_dim=E)
+    assert [int(x) for x in z["meta_spec"]] == list(spec.as_c_ints())
+    seed, std, hstd = z["meta_init"]
+    state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
+    state["embed_layernorm.weight"] = z["w_embed_ln"]
+    b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    return z, spec, state, b
+
+
+@pytest.mark.parametrize("kind", ["pt", "ft"])
+def test_oracle_raw_embeds_matches_reference(kind):
+    """config.embed_dim = 64: raw-embedding inputs (mask-token blend in pre-training, RMSNorm, projection, sum with the token embeddings)."""
+    z, spec, state, b = _rawembed_case(kind)
+    p = O.to_params(state, torch.float32)
+    if kind == "pt":
+        fn = lambda q: O.pretrain_forward(spec, q, b["input_ids"], b["attention_mask"], b["labels"], inputs_raw_embeds=b["inputs_raw_embeds"])
+        lk = "head1_loss"
+    else:
+        fn = lambda q: O.task_forward(spec, q, b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"],
+                                      inputs_raw_embeds=b["inputs_raw_embeds"])
+        lk = "task_loss"
+    out, grads = O.loss_and_grads(fn, p, lk)
+    assert abs(out[lk].item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    pairs = [("embed_proj.weight", z["grad_embed_proj"]), ("embed_layernorm.weight", z["grad_embed_ln"])]
+    if kind == "pt":
+        pairs.append(("emb_mask_token", z["grad_mask_token"]))
+    for k, want in pairs:
+        got = grads[k].numpy().reshape(want.shape)
+        assert np.linalg.norm(got - want) <= 2e-4 * np.linalg.norm(want), k
+    np.testing.assert_allclose(np.array([float(grads[str(n)].norm()) for n in z["names"]]), z["grad_norms"], rtol=5e-4, atol=1e-7)

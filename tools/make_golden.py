@@ -835,6 +835,62 @@ def rope_range_fixture():
     print(f"ft_tiny_roperange written: loss {res['loss']:.6f}")
 
 
+def raw_embeds_fixture():
+    """config.embed_dim = 64: raw-embedding inputs [B,S,64] (modeling_pretrain.py:69-84, :131-149; modeling_helpers.py:127-139).  Pre-train: the
+    batch is masked token-wise for half of the samples (every label of a masked token set - those rows take emb_mask_token) and cell-wise
+    for the rest (rows with some label unset keep their raw embedding).  Fine-tune: no mask token.  Evaluation mode."""
+    PT, FT, Cfg = import_reference()
+    E = 64
+    rs = np.random.RandomState(151)
+    for kind in ("pt", "ft"):
+        if kind == "pt":
+            spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN, vocab_size=756, stacked_feat=13, next_n_token=13, embed_dim=E)
+            batch = synth.make_pretrain_batch(B=6, S=24, F=13, V=756, seed=151)
+            ids, lab = batch["input_ids"], batch["labels"]
+            real = batch["attention_mask"] != 0
+            for b in range(0, ids.shape[0], 2):           # token-wise masking on the even samples
+                tok = real[b] & (rs.uniform(size=real[b].shape) < 0.4)
+                orig = np.where(lab[b] != -100, lab[b], ids[b])
+                lab[b] = np.where(tok[:, None], orig, -100)
+                ids[b] = np.where(tok[:, None], 1, orig)
+        else:
+            spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=756, stacked_feat=13, next_n_token=1, num_labels=2, embed_dim=E)
+            batch = synth.make_task_batch(B=12, S=24, F=13, V=756, seed=152)
+        state = weights_mod.make_state_dict(spec, seed=1511 if kind == "pt" else 1512, std=0.06, head_std=0.15 if kind == "pt" else 0.3)
+        state["embed_layernorm.weight"] = rs.uniform(0.5, 1.5, size=state["embed_layernorm.weight"].shape).astype(np.float32)
+        raw = rs.standard_normal(size=batch["input_ids"].shape[:2] + (E,)).astype(np.float32)
+        batch["inputs_raw_embeds"] = raw
+        tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+        model = (PT if kind == "pt" else FT)(ref_config(Cfg, spec, embed_dim=E, **({} if kind == "pt" else dict(num_labels=2, loss_type=None))))
+        load_weights(model, state)
+        model.eval()
+        if kind == "pt":
+            o = model(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"], labels=tb["labels"], inputs_raw_embeds=tb["inputs_raw_embeds"])
+            loss = o.head1_loss
+        else:
+            o = model(input_ids=tb["input_ids"], attention_mask=tb["attention_mask"], position_ids=tb["position_ids"],
+                      task_labels=tb["task_labels"], inputs_raw_embeds=tb["inputs_raw_embeds"])
+            loss = o.task_loss
+        model.zero_grad()
+        loss.backward()
+        names = list(state.keys())
+        g = dict(model.named_parameters())
+        res = {"loss": np.float64(loss.item()), "grad_norms": grad_norms(model, names), "names": np.array(names), "embed_dim": np.int64(E),
+               "grad_embed_proj": g["embed_proj.weight"].grad.numpy().copy(), "grad_embed_ln": g["embed_layernorm.weight"].grad.numpy().copy(),
+               "w_embed_ln": state["embed_layernorm.weight"],
+               "meta_spec": np.array(spec.as_c_ints(), np.int64), "meta_init": np.array([1511 if kind == "pt" else 1512, 0.06, 0.15 if kind == "pt" else 0.3])}
+        if kind == "pt":
+            res["grad_mask_token"] = g["emb_mask_token"].grad.numpy().reshape(-1).copy()
+            full = (batch["labels"] != -100).all(-1)
+            assert full.any() and ((batch["labels"] != -100).any(-1) & ~full).any()
+        else:
+            res["logits"] = o.task_logits.detach().float().numpy()
+        for k, v in batch.items():
+            res["in_" + k] = v
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"{kind}_tiny_rawembed.npz"), **res)
+        print(f"{kind}_tiny_rawembed written: loss {res['loss']:.6f}")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -870,6 +926,8 @@ def main():
         token_ce_fixture()
     if not only or "ft_tiny_roperange" in only:
         rope_range_fixture()
+    if not only or "tiny_rawembed" in only:
+        raw_embeds_fixture()
 
 
 if __name__ == "__main__":

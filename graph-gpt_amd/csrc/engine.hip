@@ -660,6 +660,94 @@ __global__ void __launch_bounds__(256) ls_fwd_kernel(const bf16_t* __restrict__ 
     *reinterpret_cast<uint4*>(out + w * 8) = pack8(r);
   }
 }
+// ls_fwd_kernel and the RMSNorm that always follows it (rmsnorm_fwd_kernel, kernels.hip) in one pass over the rows: the residual stream
+// is written (out) and normalised (xn, rstd) without being read back - same arithmetic and rounding points as the two kernels.
+// A wave owns a row at a time; NCH = 16-byte chunks per lane.
+template <int NCH>
+__global__ void __launch_bounds__(256) ls_rmsnorm_fwd_kernel(const bf16_t* __restrict__ res, const bf16_t* __restrict__ y,
+                                                             const bf16_t* __restrict__ lam, bf16_t* __restrict__ out,
+                                                             const bf16_t* __restrict__ w, bf16_t* __restrict__ xn,
+                                                             float* __restrict__ rstd_out, int T, int d, float eps, PathDrop D,
+                                                             ElemDropArg E) {
+  const int lane = threadIdx.x & 63;
+  const int nchunk = d >> 3;
+  const int stride = gridDim.x * 4;
+  float wv[NCH][8], lv[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { wv[i][e] = 0.f; lv[i][e] = 1.f; }
+    if (c < nchunk) {
+      unpack8(*reinterpret_cast<const uint4*>(w + c * 8), wv[i]);
+      if (lam) unpack8(*reinterpret_cast<const uint4*>(lam + c * 8), lv[i]);
+    }
+  }
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  uint4 cr[NCH], cy[NCH], nr[NCH], ny[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    const bool ok = c < nchunk && row < T;
+    cr[i] = ok ? *reinterpret_cast<const uint4*>(res + (size_t)row * d + c * 8) : make_uint4(0, 0, 0, 0);
+    cy[i] = ok ? *reinterpret_cast<const uint4*>(y + (size_t)row * d + c * 8) : make_uint4(0, 0, 0, 0);
+  }
+  for (; row < T; row += stride) {
+    const int nrow = row + stride;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      const bool ok = c < nchunk && nrow < T;
+      nr[i] = ok ? *reinterpret_cast<const uint4*>(res + (size_t)nrow * d + c * 8) : make_uint4(0, 0, 0, 0);
+      ny[i] = ok ? *reinterpret_cast<const uint4*>(y + (size_t)nrow * d + c * 8) : make_uint4(0, 0, 0, 0);
+    }
+    const float keep = path_keep(D, row);
+    float v[NCH][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      float r[8], yv[8];
+      unpack8(cr[i], r);
+      unpack8(cy[i], yv);
+      if (E.thresh) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          yv[e] = bf2f(f2bf(yv[e] * elem_drop_mul(E, GGET_DROP_STREAM_MLP_OUT, (unsigned)row, (unsigned)(c * 8 + e))));
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] += keep * bf2f(f2bf(lv[i][e] * yv[e]));
+      const uint4 pk = pack8(r);                    // the residual stream is a bf16 tensor: the norm sees the rounded values
+      if (c < nchunk) *reinterpret_cast<uint4*>(out + (size_t)row * d + c * 8) = pk;
+      unpack8(pk, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)d + eps);
+    if (lane == 0) rstd_out[row] = rstd;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = wv[i][e] * bf2f(f2bf(v[i][e] * rstd));
+        *reinterpret_cast<uint4*>(xn + (size_t)row * d + c * 8) = pack8(o);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) { cr[i] = nr[i]; cy[i] = ny[i]; }
+  }
+}
+int ls_rmsnorm_fwd(const bf16_t* res, const bf16_t* y, const bf16_t* lam, bf16_t* out, const bf16_t* w, bf16_t* xn, float* rstd, int T,
+                   int d, float eps, PathDrop D, ElemDropArg E, hipStream_t st) {
+  const int grid = (int)std::min<long>(2048, ((long)T + 3) / 4);
+  if (d <= 1024) hipLaunchKernelGGL(ls_rmsnorm_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, res, y, lam, out, w, xn, rstd, T, d, eps, D, E);
+  else hipLaunchKernelGGL(ls_rmsnorm_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, res, y, lam, out, w, xn, rstd, T, d, eps, D, E);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
 __global__ void __launch_bounds__(256) ls_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
                                                      const bf16_t* __restrict__ lam, bf16_t* __restrict__ dscaled,
                                                      float* __restrict__ dlam, int T, int d, PathDrop D, int copies,
@@ -702,6 +790,10 @@ __global__ void __launch_bounds__(256) ls_bwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
+bool ls_norm_fused() {
+  static const int off = getenv("GGET_NO_LS_NORM_FUSION") != nullptr;
+  return !off;
+}
 int layer_forward(gget_engine* h, int i, hipStream_t st) {
   const gget_config_t& c = h->cfg;
   const int T = h->T, d = c.hidden_size, ff = c.intermediate_size, H = c.num_heads;
@@ -716,7 +808,9 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
   bf16_t* xn2 = h->wsp<bf16_t>(lw.xn2);
   bf16_t* gu = h->wsp<bf16_t>(lw.gu);
   bf16_t* hh = h->wsp<bf16_t>(lw.h);
-  if (int e = k_rmsnorm_fwd(x_in, h->P + lo.ln1, xn1, h->wsp<float>(lw.rstd1), T, d, c.rms_eps, st)) return e;
+  // (LayerScale / DropPath path: the previous layer's residual kernel already normalised this layer's input - see below)
+  if (!(h->plan.has_res && i > 0 && ls_norm_fused()))
+    if (int e = k_rmsnorm_fwd(x_in, h->P + lo.ln1, xn1, h->wsp<float>(lw.rstd1), T, d, c.rms_eps, st)) return e;
   {
     // q|k|v projection with RoPE applied to the q and k columns in the GEMM epilogue (fp32 accumulators, one rounding):
     // qkv holds ROTATED q,k; attention consumes them as they are, its backward rotates dq,dk back.
@@ -741,12 +835,28 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
     const PathDrop pd1 = h->path_drop(i, 0), pd2 = h->path_drop(i, 1);
     const int g = (int)std::min<long>(4096, ((long)T * (d / 8) + 255) / 256);
     if (int e = gemm_nt(attn, h->P + lo.wo, araw, nullptr, T, d, d, d, d, d, nullptr, st)) return e;
-    hipLaunchKernelGGL(ls_fwd_kernel, dim3(g), dim3(256), 0, st, x_in, araw, lam1, xmid, (long)T, d, pd1, ElemDropArg{0, 1.f, 0});
-    if (int e = k_rmsnorm_fwd(xmid, h->P + lo.ln2, xn2, h->wsp<float>(lw.rstd2), T, d, c.rms_eps, st)) return e;
+    // the residual kernels also produce what the RMSNorm behind them would: the residual stream is written and normalised in one pass
+    // (the second one normalises for the NEXT layer, or with the final norm)
+    const bool fused = ls_norm_fused();
+    if (fused) {
+      if (int e = ls_rmsnorm_fwd(x_in, araw, lam1, xmid, h->P + lo.ln2, xn2, h->wsp<float>(lw.rstd2), T, d, c.rms_eps, pd1,
+                                 ElemDropArg{0, 1.f, 0}, st))
+        return e;
+    } else {
+      hipLaunchKernelGGL(ls_fwd_kernel, dim3(g), dim3(256), 0, st, x_in, araw, lam1, xmid, (long)T, d, pd1, ElemDropArg{0, 1.f, 0});
+      if (int e = k_rmsnorm_fwd(xmid, h->P + lo.ln2, xn2, h->wsp<float>(lw.rstd2), T, d, c.rms_eps, st)) return e;
+    }
     if (int e = gateup_geglu(xn2, h->P + lo.wgu, gu, hh, T, d, ff, st)) return e;
     const ElemDropArg md = h->mlp_drop(i);
     if (int e = k_elem_dropout(hh, T, ff, GGET_DROP_STREAM_MLP_ACT, md, st)) return e;     // mlp_act_dropout (utils_graphgpt.py:78)
     if (int e = gemm_nt(hh, h->P + lo.wdown, mraw, nullptr, T, d, ff, ff, ff, d, nullptr, st)) return e;
+    if (fused) {
+      const bool last = i + 1 == c.num_layers;
+      const bf16_t* nw = last ? h->P + h->plan.normf : h->P + h->plan.layers[i + 1].ln1;
+      bf16_t* nxn = last ? h->wsp<bf16_t>(h->ws.hidden) : h->wsp<bf16_t>(h->ws.lw[i + 1].xn1);
+      float* nrs = last ? h->wsp<float>(h->ws.rstd_f) : h->wsp<float>(h->ws.lw[i + 1].rstd1);
+      return ls_rmsnorm_fwd(xmid, mraw, lam2, x_out, nw, nxn, nrs, T, d, c.rms_eps, pd2, md, st);
+    }
     hipLaunchKernelGGL(ls_fwd_kernel, dim3(g), dim3(256), 0, st, xmid, mraw, lam2, x_out, (long)T, d, pd2, md);
     GGET_LAUNCH_CHECK();
     return 0;
@@ -813,6 +923,7 @@ int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t*
   }
   for (int i = 0; i < c.num_layers; ++i)
     if (int e = layer_forward(h, i, st)) return e;
+  if (h->plan.has_res && ls_norm_fused()) return 0;   // (the last layer's residual kernel applied the final norm)
   return k_rmsnorm_fwd(h->wsp<bf16_t>(h->ws.xres[c.num_layers]), h->P + h->plan.normf, h->wsp<bf16_t>(h->ws.hidden),
                        h->wsp<float>(h->ws.rstd_f), h->T, d, c.rms_eps, st);
 }

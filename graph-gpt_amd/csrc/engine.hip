@@ -337,6 +337,7 @@ struct gget_engine {
   float rope_range = 0.f;         // config.rope_range (gget_set_rope_range)
   const float* raw_next = nullptr;  // inputs_raw_embeds of the NEXT forward (gget_set_raw_embeds)
   bool raw_first_label_only = false;   // smtp_inside: the mask-token rule looks at labels[:, :, 0] only (modeling_pretrain.py:136-137)
+  bool ls2_done = false;          // the LayerScale / DropPath backward of the next layer_backward's down branch is already done (fused)
   bool raw_used = false;          // the last forward consumed raw embeddings (its backward owes their gradients)
   const float* cos_cur = nullptr; // angle tables / position list of the last forward (the per-token ones under rope_range)
   const float* sin_cur = nullptr;
@@ -790,6 +791,127 @@ __global__ void __launch_bounds__(256) ls_bwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// RMSNorm backward (rmsnorm_bwd_kernel, kernels.hip) and the LayerScale / DropPath backward that consumes its result (ls_bwd_kernel) in
+// one pass over the rows: dx = dres + rstd (dy w - xhat mean(dy w xhat)) is written once and, rounded to bf16 as the separate kernel would
+// read it, scaled into the gradient of the branch behind it (dsc = lam keep dx, dlam += keep dx y).  Same arithmetic as the two kernels.
+template <int NCH>
+__global__ void __launch_bounds__(256) rmsnorm_bwd_ls_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                             const bf16_t* __restrict__ w, const float* __restrict__ rstd_in,
+                                                             const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                                             float* __restrict__ dw_accum, const bf16_t* __restrict__ y,
+                                                             const bf16_t* __restrict__ lam, bf16_t* __restrict__ dsc,
+                                                             float* __restrict__ dlam_accum, int T, int d, int copies,
+                                                             uint64_t copy_stride, PathDrop D, ElemDropArg E) {
+  extern __shared__ float red_lds[];  // [2][4][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = d >> 3;
+  float dwp[NCH][8], dlp[NCH][8], wv[NCH][8], lv[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dwp[i][e] = 0.f; dlp[i][e] = 0.f; wv[i][e] = 0.f; lv[i][e] = 1.f; }
+    if (c < nchunk) {
+      unpack8(*reinterpret_cast<const uint4*>(w + c * 8), wv[i]);
+      if (lam) unpack8(*reinterpret_cast<const uint4*>(lam + c * 8), lv[i]);
+    }
+  }
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + wave;
+  uint4 xr[NCH], dr[NCH], rr[NCH], yr[NCH];
+  float rstd = 0.f;
+  auto fetch = [&](int r) {
+    rstd = rstd_in[r];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        xr[i] = *reinterpret_cast<const uint4*>(x + (size_t)r * d + c * 8);
+        dr[i] = *reinterpret_cast<const uint4*>(dy + (size_t)r * d + c * 8);
+        rr[i] = dres ? *reinterpret_cast<const uint4*>(dres + (size_t)r * d + c * 8) : make_uint4(0, 0, 0, 0);
+        yr[i] = *reinterpret_cast<const uint4*>(y + (size_t)r * d + c * 8);
+      }
+    }
+  };
+  if (row < T) fetch(row);
+  for (; row < T; row += stride) {
+    const float rs = rstd;
+    float xh[NCH][8], g[NCH][8], res[NCH][8], yv[NCH][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        float xv[8], dv[8];
+        unpack8(xr[i], xv);
+        unpack8(dr[i], dv);
+        unpack8(rr[i], res[i]);
+        unpack8(yr[i], yv[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[i][e] = xv[e] * rs;
+          g[i][e] = dv[e] * wv[i][e];
+          dot += g[i][e] * xh[i][e];
+          dwp[i][e] += dv[e] * xh[i][e];
+        }
+      }
+    }
+    if (row + stride < T) fetch(row + stride);
+    dot = wave_sum(dot) / (float)d;
+    const float keep = path_keep(D, row);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        float o[8], gq[8], sc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = res[i][e] + rs * (g[i][e] - xh[i][e] * dot);
+        const uint4 pk = pack8(o);
+        *reinterpret_cast<uint4*>(dx + (size_t)row * d + c * 8) = pk;
+        unpack8(pk, gq);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float em = elem_drop_mul(E, GGET_DROP_STREAM_MLP_OUT, (unsigned)row, (unsigned)(c * 8 + e));
+          sc[e] = lv[i][e] * keep * gq[e] * em;
+          dlp[i][e] += keep * gq[e] * bf2f(f2bf(yv[i][e] * em));
+        }
+        *reinterpret_cast<uint4*>(dsc + (size_t)row * d + c * 8) = pack8(sc);
+      }
+    }
+  }
+  float* dl_lds = red_lds + 4 * d;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { red_lds[wave * d + c * 8 + e] = dwp[i][e]; dl_lds[wave * d + c * 8 + e] = dlp[i][e]; }
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < d; j += 256) {
+    const size_t off = (size_t)(blockIdx.x % copies) * copy_stride + j;
+    unsafeAtomicAdd(dw_accum + off, red_lds[j] + red_lds[d + j] + red_lds[2 * d + j] + red_lds[3 * d + j]);
+    if (dlam_accum) unsafeAtomicAdd(dlam_accum + off, dl_lds[j] + dl_lds[d + j] + dl_lds[2 * d + j] + dl_lds[3 * d + j]);
+  }
+}
+int rmsnorm_bwd_ls(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres, bf16_t* dx, float* dw_accum,
+                   const bf16_t* y, const bf16_t* lam, bf16_t* dsc, float* dlam_accum, int T, int d, PathDrop D, ElemDropArg E,
+                   hipStream_t st) {
+  if (T == 0) return 0;
+  const int grid = (int)std::min<long>(4096, ((long)T + 15) / 16);
+  const size_t lds = (size_t)8 * d * sizeof(float);
+  const uint64_t cs = align_up((uint64_t)d, 128);
+  if (d <= 1024)
+    hipLaunchKernelGGL(rmsnorm_bwd_ls_kernel<2>, dim3(grid), dim3(256), lds, st, dy, x, w, rstd, dres, dx, dw_accum, y, lam, dsc, dlam_accum, T,
+                       d, kAccumCopies, cs, D, E);
+  else
+    hipLaunchKernelGGL(rmsnorm_bwd_ls_kernel<4>, dim3(grid), dim3(256), lds, st, dy, x, w, rstd, dres, dx, dw_accum, y, lam, dsc, dlam_accum, T,
+                       d, kAccumCopies, cs, D, E);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
 bool ls_norm_fused() {
   static const int off = getenv("GGET_NO_LS_NORM_FUSION") != nullptr;
   return !off;
@@ -1089,12 +1211,16 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   const int ls_rl = 256 / (d / 8);
   dim3 lsgrid((unsigned)std::min(512, (T + ls_rl - 1) / ls_rl));
   const size_t ls_lds_bytes = (size_t)ls_rl * d * sizeof(float);
+  const bool fuse_ls = h->plan.has_res && ls_norm_fused();
   if (h->plan.has_res) {
     // x_out = xmid + keep_b * lam2 * mraw  =>  d mraw = keep_b * lam2 * dx_out, dlam2 += sum keep_b * dx_out * mraw
+    // (already done by the RMSNorm backward that produced dx_out when the two are fused - see the end of this function)
     bf16_t* dsc = h->wsp<bf16_t>(w.dscaled);
-    hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), ls_lds_bytes, st, dx_out, h->wsp<bf16_t>(lw.mraw),
-                       h->plan.has_ls ? h->P + lo.lam2 : nullptr, dsc, h->plan.has_ls ? s32 + lo.lam2_32 : nullptr, T, d,
-                       h->path_drop(i, 1), kAccumCopies, align_up((uint64_t)d, 128), h->mlp_drop(i));
+    if (!h->ls2_done)
+      hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), ls_lds_bytes, st, dx_out, h->wsp<bf16_t>(lw.mraw),
+                         h->plan.has_ls ? h->P + lo.lam2 : nullptr, dsc, h->plan.has_ls ? s32 + lo.lam2_32 : nullptr, T, d,
+                         h->path_drop(i, 1), kAccumCopies, align_up((uint64_t)d, 128), h->mlp_drop(i));
+    h->ls2_done = false;
     dy_down = dsc;   // stays alive for the grouped wgrad at the end of the layer (the o_proj branch has its own buffer)
   }
   // MLP: dh = dy_down W_down ; dgu = geglu'(dh) ; dxn2 = dgu W_gu
@@ -1104,10 +1230,17 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
     if (int e = k_geglu_bwd(h->wsp<bf16_t>(lw.gu), dh, dgu, T, ff, st)) return e;
   } else if (int e = down_dgrad_geglu(dy_down, h->P + lo.wdown, h->wsp<bf16_t>(lw.gu), dgu, dh, T, d, ff, st)) return e;
   if (int e = gemm_nn(dgu, h->P + lo.wgu, dxn, T, d, 2 * ff, 2 * ff, d, d, nullptr, st)) return e;
-  if (int e = k_rmsnorm_bwd(dxn, xmid, h->P + lo.ln2, h->wsp<float>(lw.rstd2), dx_out, dx_mid, s32 + lo.ln2_32, T, d, st, kAccumCopies, align_up((uint64_t)d, 128)))
+  if (fuse_ls) {
+    if (int e = rmsnorm_bwd_ls(dxn, xmid, h->P + lo.ln2, h->wsp<float>(lw.rstd2), dx_out, dx_mid, s32 + lo.ln2_32, h->wsp<bf16_t>(lw.araw),
+                               h->plan.has_ls ? h->P + lo.lam1 : nullptr, h->wsp<bf16_t>(w.dscaled2),
+                               h->plan.has_ls ? s32 + lo.lam1_32 : nullptr, T, d, h->path_drop(i, 0), ElemDropArg{0, 1.f, 0}, st))
+      return e;
+  } else if (int e = k_rmsnorm_bwd(dxn, xmid, h->P + lo.ln2, h->wsp<float>(lw.rstd2), dx_out, dx_mid, s32 + lo.ln2_32, T, d, st, kAccumCopies, align_up((uint64_t)d, 128)))
     return e;
   dy_o = dx_mid;
-  if (h->plan.has_res) {
+  if (fuse_ls) {
+    dy_o = h->wsp<bf16_t>(w.dscaled2);
+  } else if (h->plan.has_res) {
     bf16_t* dsc = h->wsp<bf16_t>(w.dscaled2);
     hipLaunchKernelGGL(ls_bwd_kernel, lsgrid, dim3(256), ls_lds_bytes, st, dx_mid, h->wsp<bf16_t>(lw.araw),
                        h->plan.has_ls ? h->P + lo.lam1 : nullptr, dsc, h->plan.has_ls ? s32 + lo.lam1_32 : nullptr, T, d,
@@ -1122,8 +1255,12 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
                          h->klo(), h->khi()))
     return e;
   if (int e = gemm_nn(dqkv, h->P + lo.wqkv, dxn, T, d, 3 * d, 3 * d, d, d, nullptr, st)) return e;
-  if (int e = k_rmsnorm_bwd(dxn, x_in, h->P + lo.ln1, h->wsp<float>(lw.rstd1), dx_mid, dx_in, s32 + lo.ln1_32, T, d, st, kAccumCopies, align_up((uint64_t)d, 128)))
-    return e;
+  // (fused with the LayerScale backward of the layer below, this RMSNorm backward writes w.dscaled - which this layer's down_proj weight
+  //  gradient still reads - so it runs behind the weight gradients then)
+  const bool fuse_next = fuse_ls && i > 0;
+  if (!fuse_next)
+    if (int e = k_rmsnorm_bwd(dxn, x_in, h->P + lo.ln1, h->wsp<float>(lw.rstd1), dx_mid, dx_in, s32 + lo.ln1_32, T, d, st, kAccumCopies, align_up((uint64_t)d, 128)))
+      return e;
   // weight gradients of the layer (dW = dY^T X, K = T).  All four dY / X pairs are still alive here.
   const GemmProblem wg_gu{dgu, h->wsp<bf16_t>(lw.xn2), h->G + lo.wgu, nullptr, 2 * ff, d, T, 2 * ff, d, d, nullptr, nullptr, 0, 0};
   const GemmProblem wg_dn{dy_down, h->wsp<bf16_t>(lw.h), h->G + lo.wdown, nullptr, d, ff, T, d, ff, ff, nullptr, nullptr, 0, 0};
@@ -1162,6 +1299,14 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
     const int split = T >= kWgSplit * 1024 ? kWgSplit : 1;
     if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_SLAB_F32, g, split, st)) return e;
     if (int e = k_slab_reduce(wg, slab, split, h->G + lo.wqkv, (size_t)4 * d * d, st)) return e;
+  }
+  if (fuse_next) {
+    const LayerOff& lp = h->plan.layers[i - 1];
+    if (int e = rmsnorm_bwd_ls(dxn, x_in, h->P + lo.ln1, h->wsp<float>(lw.rstd1), dx_mid, dx_in, s32 + lo.ln1_32,
+                               h->wsp<bf16_t>(h->ws.lw[i - 1].mraw), h->plan.has_ls ? h->P + lp.lam2 : nullptr, h->wsp<bf16_t>(w.dscaled),
+                               h->plan.has_ls ? s32 + lp.lam2_32 : nullptr, T, d, h->path_drop(i - 1, 1), h->mlp_drop(i - 1), st))
+      return e;
+    h->ls2_done = true;
   }
   h->dx_cur = dx_in;
   return convert_bucket(h, h->bucket_of_layer(i), st);
@@ -1233,8 +1378,18 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
       return e;
   }
   bf16_t* dx = h->wsp<bf16_t>(w.dxa);
-  if (int e = k_rmsnorm_bwd(dhid, h->wsp<bf16_t>(w.xres[c.num_layers]), h->P + h->plan.normf, h->wsp<float>(w.rstd_f), nullptr,
-                            dx, s32 + h->plan.normf32, T, d, st, kAccumCopies, align_up((uint64_t)d, 128)))
+  h->ls2_done = false;
+  if (h->plan.has_res && ls_norm_fused()) {     // ... fused with the LayerScale backward of the last layer (layer_backward)
+    const int li = c.num_layers - 1;
+    const LayerOff& lp = h->plan.layers[li];
+    if (int e = rmsnorm_bwd_ls(dhid, h->wsp<bf16_t>(w.xres[c.num_layers]), h->P + h->plan.normf, h->wsp<float>(w.rstd_f), nullptr, dx,
+                               s32 + h->plan.normf32, h->wsp<bf16_t>(h->ws.lw[li].mraw), h->plan.has_ls ? h->P + lp.lam2 : nullptr,
+                               h->wsp<bf16_t>(w.dscaled), h->plan.has_ls ? s32 + lp.lam2_32 : nullptr, T, d, h->path_drop(li, 1),
+                               h->mlp_drop(li), st))
+      return e;
+    h->ls2_done = true;
+  } else if (int e = k_rmsnorm_bwd(dhid, h->wsp<bf16_t>(w.xres[c.num_layers]), h->P + h->plan.normf, h->wsp<float>(w.rstd_f), nullptr,
+                                   dx, s32 + h->plan.normf32, T, d, st, kAccumCopies, align_up((uint64_t)d, 128)))
     return e;
   h->dx_cur = dx;
   return convert_bucket(h, 0, st);

@@ -948,7 +948,7 @@ __global__ void __launch_bounds__(kBlock) tok_ce_kernel(const float* __restrict_
 __global__ void tok_ce_final_kernel(float* __restrict__ stat, float* __restrict__ loss_out) {
   const float n = stat[1];
   stat[2] = n > 0.f ? 1.0f / n : 0.f;            // the mean's factor, read by the backward kernels
-  loss_out[0] = n > 0.f ? stat[0] / n : 0.f;
+  loss_out[0] = n > 0.f ? stat[0] / n : __builtin_nanf("");   // (torch's mean over no labelled row is nan too)
 }
 // dhidden[t,:] = bf16( sum_c bf16(dl[t,c] / n) W[c,:] )   (the reference's gradient is a bf16 tensor at both points)
 __global__ void __launch_bounds__(kBlock) tok_score_bwd_dx_kernel(const float* __restrict__ dl, const float* __restrict__ stat,

@@ -1433,3 +1433,23 @@ def test_raw_embedding_dropout_exact_mask():
         e = float(np.linalg.norm(got[k].float().cpu().numpy().reshape(-1) - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
         record_error("pt_tiny_rawembed_dropout", "grad_rel_l2 " + k, e, 6e-2)
         assert e < 6e-2, f"{k}: {e}"
+
+
+@pytest.mark.gpu
+def test_token_level_ce_without_any_labelled_row_is_nan_like_the_reference():
+    """CrossEntropyLoss over rows that are all ignore_index is nan in torch (mean over nothing); the engine reports the same and a
+    zero gradient instead of dividing by zero."""
+    from _util import spec_mod, synth
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=300, stacked_feat=1, next_n_token=1, num_labels=5)
+    cfg = M.GraphGPTConfig(vocab_size=300, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+                           num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads, max_position_embeddings=64,
+                           causal_attention=False, stacked_feat=1, next_n_token=1, num_labels=5, loss_type="token_ce",
+                           problem_type="single_label_classification")
+    model = M.GraphGPTTaskModel(cfg, seed=3)
+    batch = synth.make_task_batch(B=4, S=16, F=1, V=300, seed=5, num_labels=5)
+    ids = torch.from_numpy(batch["input_ids"]); att = torch.from_numpy(batch["attention_mask"])
+    lab = torch.full((4, 16), -100, dtype=torch.int64)
+    out = model(input_ids=ids, attention_mask=att, task_labels=lab)
+    assert torch.isnan(out.task_loss).item() and tuple(out.task_logits.shape) == (4, 16, 5)
+    assert torch.isfinite(out.task_logits).all()

@@ -424,8 +424,15 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
           bf16_t* base = (FWD && o == 2) ? C2 : C;
           const int ld = (FWD && o == 2) ? P.ldc2 : P.ldc;
           const int col = nst + (o == 1 ? ff : 0);
-          if (ma < M) *reinterpret_cast<uint4*>(base + (size_t)ma * ld + col) = pa;
-          if (mb < M) *reinterpret_cast<uint4*>(base + (size_t)mb * ld + col) = pb;
+          typedef unsigned u4v __attribute__((ext_vector_type(4)));
+          if (FWD && o < 2) {   // gu is read again only in the backward: non-temporal stores keep it out of the caches, which the
+                                // step's next kernels use (h IS read by the next GEMM); 8.54 -> 8.45 ms per C1 step, same box
+            if (ma < M) __builtin_nontemporal_store(u4v{pa.x, pa.y, pa.z, pa.w}, reinterpret_cast<u4v*>(base + (size_t)ma * ld + col));
+            if (mb < M) __builtin_nontemporal_store(u4v{pb.x, pb.y, pb.z, pb.w}, reinterpret_cast<u4v*>(base + (size_t)mb * ld + col));
+          } else {
+            if (ma < M) *reinterpret_cast<uint4*>(base + (size_t)ma * ld + col) = pa;
+            if (mb < M) *reinterpret_cast<uint4*>(base + (size_t)mb * ld + col) = pb;
+          }
         }
       }
     }

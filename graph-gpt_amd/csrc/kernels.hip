@@ -1292,7 +1292,7 @@ __global__ void __launch_bounds__(kBlock) adamw_kernel(float* __restrict__ maste
     uint2 o;
     o.x = pack2bf(wp[0], wp[1]);
     o.y = pack2bf(wp[2], wp[3]);
-    *reinterpret_cast<uint2*>(param + i * 4) = o;
+    __builtin_nontemporal_store(u2v{o.x, o.y}, reinterpret_cast<u2v*>(param + i * 4));
   }
 }
 

@@ -270,6 +270,13 @@ constexpr int kSuper = 8;  // row panels per L2 super-tile
 // 16-column groups but the even (wave 0) or odd (wave 1) 16-column groups of each 32-channel half of three heads, so
 // that a channel c < 32 and its partner c + 32 still sit in the same lane: accumulator j covers columns
 // nw + (j/2)*64 + (j%2)*32 .. +15 with nw = tile origin + 16*wave, i.e. head j/2, channels chan0 + (j%2)*32 .. +15.
+// 16-byte C store with the non-temporal hint.  Every output of these GEMMs is consumed by a LATER kernel from HBM / the memory-side
+// cache anyway (12-100 MB per launch against 4 MB of L2 per XCD); written with the default policy the lines displace the A / B panels the
+// running kernel and its neighbours re-read.  Measured in the step (stand-alone loops do not show it): C1 8.54 -> 8.43 ms, C3 55.3 -> 54.1 ms.
+__device__ __forceinline__ void stc16(bf16_t* p, const uint4& v) {
+  typedef unsigned u4nt __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(u4nt{v.x, v.y, v.z, v.w}, reinterpret_cast<u4nt*>(p));
+}
 template <int EPI, int MI, int NJ, bool ILV = false>
 __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmProblem& P, int M, int N, int mw, int nw, int lane,
                                            int kslice = 0, int chan0 = 0) {
@@ -424,15 +431,8 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
           bf16_t* base = (FWD && o == 2) ? C2 : C;
           const int ld = (FWD && o == 2) ? P.ldc2 : P.ldc;
           const int col = nst + (o == 1 ? ff : 0);
-          typedef unsigned u4v __attribute__((ext_vector_type(4)));
-          if (FWD && o < 2) {   // gu is read again only in the backward: non-temporal stores keep it out of the caches, which the
-                                // step's next kernels use (h IS read by the next GEMM); 8.54 -> 8.45 ms per C1 step, same box
-            if (ma < M) __builtin_nontemporal_store(u4v{pa.x, pa.y, pa.z, pa.w}, reinterpret_cast<u4v*>(base + (size_t)ma * ld + col));
-            if (mb < M) __builtin_nontemporal_store(u4v{pb.x, pb.y, pb.z, pb.w}, reinterpret_cast<u4v*>(base + (size_t)mb * ld + col));
-          } else {
-            if (ma < M) *reinterpret_cast<uint4*>(base + (size_t)ma * ld + col) = pa;
-            if (mb < M) *reinterpret_cast<uint4*>(base + (size_t)mb * ld + col) = pb;
-          }
+          if (ma < M) stc16(base + (size_t)ma * ld + col, pa);
+          if (mb < M) stc16(base + (size_t)mb * ld + col, pb);
         }
       }
     }
@@ -490,8 +490,8 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
           const uint4 pb = low ? xr : y;
           const int n = nw + ja * 32 + (low ? c0 : c0 + 4) * 8;
           if (n + 8 <= N) {
-            if (ma < M) *reinterpret_cast<uint4*>(C + (size_t)ma * P.ldc + n) = pa;
-            if (mb < M) *reinterpret_cast<uint4*>(C + (size_t)mb * P.ldc + n) = pb;
+            if (ma < M) stc16(C + (size_t)ma * P.ldc + n, pa);
+            if (mb < M) stc16(C + (size_t)mb * P.ldc + n, pb);
           } else if (n < N) {
             if (ma < M) *reinterpret_cast<uint2*>(C + (size_t)ma * P.ldc + n) = make_uint2(pa.x, pa.y);
             if (mb < M) *reinterpret_cast<uint2*>(C + (size_t)mb * P.ldc + n) = make_uint2(pb.x, pb.y);
@@ -501,7 +501,7 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
           const int jl = lead ? 0 : 2;
           const uint4 z = lead ? piece(i, 0, m) : piece(i, NJ / 2 - 1, m);
           const int n = nw + jl * 32 + c0 * 8;
-          if (m < M && n + 8 <= N) *reinterpret_cast<uint4*>(C + (size_t)m * P.ldc + n) = z;
+          if (m < M && n + 8 <= N) stc16(C + (size_t)m * P.ldc + n, z);
           else if (m < M && n < N) *reinterpret_cast<uint2*>(C + (size_t)m * P.ldc + n) = make_uint2(z.x, z.y);
         }
       }
@@ -541,7 +541,7 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
-        *reinterpret_cast<uint4*>(cp) = pack8(v);
+        stc16(cp, pack8(v));
       } else {  // N % 8 == 4 : only the first half of this chunk exists
         if (EPI == GGET_EPI_RESIDUAL) {
           const uint2 r = *reinterpret_cast<const uint2*>(P.R + (size_t)m * P.ldc + n);

@@ -10,7 +10,10 @@ namespace {
 constexpr int kBlock = 256;
 
 __device__ __forceinline__ uint4 ldg16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
-__device__ __forceinline__ void stg16(bf16_t* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+__device__ __forceinline__ void stg16(bf16_t* p, const uint4& v) {   // non-temporal (see stc16 in gemm.hip)
+  typedef unsigned u4nt __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(u4nt{v.x, v.y, v.z, v.w}, reinterpret_cast<u4nt*>(p));
+}
 
 // ---------------------------------------------------------------------------------------------
 // K1  stacked-token embedding: E[t,:] = sum_f W[ids[t,f],:] (* G[f,:])

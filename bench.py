@@ -199,7 +199,7 @@ def main():
         extra = dict(layer_scale_init_value=1.0, path_pdrop=0.2, num_labels=2, problem_type="single_label_classification")
     elif kind == "ft-long":
         extra = dict(num_labels=2, problem_type="single_label_classification")
-    cfg = modeling.GraphGPTConfig(vocab_size=V, hidden_size=sz["hidden_size"], intermediate_size=4 * sz["hidden_size"],
+    cfg = modeling.GraphGPTConfig(hidden_act="gelu", vocab_size=V, hidden_size=sz["hidden_size"], intermediate_size=4 * sz["hidden_size"],
                                   num_hidden_layers=sz["num_layers"], num_attention_heads=sz["hidden_size"] // 64,
                                   max_position_embeddings=max(1024, S), causal_attention=False, stacked_feat=F,
                                   next_n_token=F if pt else 1,

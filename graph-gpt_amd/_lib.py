@@ -56,6 +56,7 @@ SIGNATURES = {
     "gget_comm_unique_id": (i32, [vp]),
     "gget_comm_init": (i32, [vp, i32, i32, vp]),
     "gget_comm_destroy": (i32, [vp]),
+    "gget_comm_move": (i32, [vp, vp]),
     "gget_allreduce_grads_async": (i32, [vp, i32, i32, vp]),
     "gget_head_counts": (i32, [vp, C.POINTER(i32 * 2), vp]),
     "gget_head_logits": (i32, [vp, C.POINTER(vp), C.POINTER(i32)]),

@@ -1734,6 +1734,7 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
+  char why[256] = "symbols missing";     // dlerror() text captured once, at the failing dlopen (a second dlerror() call returns NULL)
 };
 
 RcclApi* rccl() {
@@ -1743,6 +1744,10 @@ RcclApi* rccl() {
     tried = true;
     void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) {
+      const char* e = dlerror();
+      snprintf(api.why, sizeof(api.why), "%s", e ? e : "dlopen failed");
+    }
     if (lib) {
       api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
       api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
@@ -1778,7 +1783,7 @@ __global__ void __launch_bounds__(256) bf16_to_f32_kernel(const bf16_t* __restri
 
 extern "C" int gget_comm_unique_id(void* out_bytes) {
   GGET_REQUIRE(out_bytes, "comm_unique_id: null argument");
-  GGET_REQUIRE(rccl()->ok, "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+  GGET_REQUIRE(rccl()->ok, "RCCL (librccl.so.1) could not be loaded: %s", rccl()->why);
   static_assert(sizeof(ncclUniqueId) == GGET_UNIQUE_ID_BYTES, "ncclUniqueId size");
   ncclUniqueId id;
   GGET_RCCL_CHECK(rccl()->GetUniqueId(&id));
@@ -1789,7 +1794,7 @@ extern "C" int gget_comm_unique_id(void* out_bytes) {
 extern "C" int gget_comm_init(gget_handle_t h, int rank, int world, const void* unique_id_bytes) {
   GGET_REQUIRE(h && unique_id_bytes && world >= 1 && rank >= 0 && rank < world, "comm_init: bad arguments (rank %d world %d)", rank, world);
   GGET_REQUIRE(h->comm == nullptr, "comm_init: this handle already has a communicator");
-  GGET_REQUIRE(rccl()->ok, "RCCL (librccl.so.1) could not be loaded");
+  GGET_REQUIRE(rccl()->ok, "RCCL (librccl.so.1) could not be loaded: %s", rccl()->why);
   ncclUniqueId id;
   memcpy(&id, unique_id_bytes, sizeof(id));
   ncclComm_t c = nullptr;
@@ -1812,6 +1817,24 @@ extern "C" int gget_comm_destroy(gget_handle_t h) {
     h->comm_f32_elems = 0;
   }
   h->comm_world = 1;
+  return 0;
+}
+
+extern "C" int gget_comm_move(gget_handle_t dst, gget_handle_t src) {
+  // A handle that is re-created with larger capacities (a bigger batch arrived) must keep exchanging gradients with the SAME
+  // communicator: creating a new one is a collective, and only the ranks whose batch grew would enter it.
+  GGET_REQUIRE(dst && src && dst != src, "comm_move: bad arguments");
+  GGET_REQUIRE(dst->comm == nullptr, "comm_move: the destination handle already has a communicator");
+  GGET_REQUIRE(dst->plan.n_params == src->plan.n_params, "comm_move: the two handles hold different models");
+  dst->comm = src->comm;
+  dst->comm_rank = src->comm_rank;
+  dst->comm_world = src->comm_world;
+  dst->comm_f32 = src->comm_f32;
+  dst->comm_f32_elems = src->comm_f32_elems;
+  src->comm = nullptr;
+  src->comm_f32 = nullptr;
+  src->comm_f32_elems = 0;
+  src->comm_world = 1;
   return 0;
 }
 

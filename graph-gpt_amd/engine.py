@@ -96,6 +96,7 @@ class Engine:
             L.check(self.lib.gget_bucket_range(self.h, b, C.byref(o), C.byref(c)))
             self.buckets.append((int(o.value), int(c.value)))
         self.step_count = 0
+        self.comm_world = 0     # > 0 once this handle owns an RCCL communicator (comm_init / comm_adopt)
         self._keep = None  # keeps the last batch tensors alive until backward has consumed them
 
     def __del__(self):
@@ -264,6 +265,14 @@ class Engine:
 
     def comm_destroy(self):
         L.check(self.lib.gget_comm_destroy(self.h))
+        self.comm_world = 0
+
+    def comm_adopt(self, other: "Engine"):
+        """Take over `other`'s communicator (gget_comm_move): used when the model re-creates its engine with larger capacities,
+        so that the ranks whose batch grew keep the communicator the other ranks still use (no collective re-init)."""
+        if other.comm_world > 0:
+            L.check(self.lib.gget_comm_move(self.h, other.h))
+            self.comm_world, other.comm_world = other.comm_world, 0
 
     def allreduce_grads_async(self, bucket: int = -1, fp32_accumulate: bool = False, stream: Optional[torch.cuda.Stream] = None):
         st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)

@@ -89,16 +89,27 @@ class SingleLabelClassificationMetrics:
         self.ls_labels.append(labels.detach().cpu())
         self.ls_idx.append(idx.detach().cpu())
 
-    def compute(self):
+    def compute(self, gathered=None):
+        """`gathered`: {"y_true", "prob" | "y_pred"} collected from ALL ranks (the reference's torchmetrics objects synchronise
+        across ranks inside compute(); here the caller passes what it gathered).  None = this rank's own lists."""
         import torch
-        y = torch.hstack(self.ls_labels).numpy()
+        y = torch.hstack(self.ls_labels).numpy() if gathered is None else np.asarray(gathered["y_true"])
         if self.num_labels == 2:
-            prob = torch.hstack(self.ls_prob).numpy()
+            prob = torch.hstack(self.ls_prob).numpy() if gathered is None else np.asarray(gathered["prob"])
             self.auroc = auroc(prob, y)
             self.acc = float(((prob > 0.5).astype(np.int64) == y).mean())
         else:
             self.auroc = -1
-            self.acc = float((torch.hstack(self.ls_pred).numpy() == y).mean())
+            pred = torch.hstack(self.ls_pred).numpy() if gathered is None else np.asarray(gathered["y_pred"])
+            self.acc = float((pred == y).mean())
+
+    def sync_dict(self):
+        """what compute() needs from every rank (superset of to_dict for the two-class case: the class-1 probabilities)"""
+        import torch
+        d = {"y_true": torch.hstack(self.ls_labels), "y_pred": torch.hstack(self.ls_pred)}
+        if self.num_labels == 2:
+            d["prob"] = torch.hstack(self.ls_prob)
+        return d
 
     def to_dict(self):
         import torch
@@ -124,9 +135,12 @@ class RegressionMetrics:
         self.ls_labels.append(labels.detach().float().reshape(-1).cpu())
         self.ls_idx.append(idx.detach().reshape(-1).cpu())
 
-    def compute(self):
+    def compute(self, gathered=None):
         import torch
-        p, y = torch.hstack(self.ls_pred).numpy(), torch.hstack(self.ls_labels).numpy()
+        if gathered is None:
+            p, y = torch.hstack(self.ls_pred).numpy(), torch.hstack(self.ls_labels).numpy()
+        else:
+            p, y = np.asarray(gathered["y_pred"]), np.asarray(gathered["y_true"])
         self.mae = mae(p, y)
         self.mse = float(((p.astype(np.float64) - y) ** 2).mean())
 
@@ -134,8 +148,12 @@ class RegressionMetrics:
         import torch
         return {"y_true": torch.hstack(self.ls_labels), "y_pred": torch.hstack(self.ls_pred), "idx": torch.hstack(self.ls_idx)}
 
+    def sync_dict(self):
+        import torch
+        return {"y_true": torch.hstack(self.ls_labels), "y_pred": torch.hstack(self.ls_pred)}
+
     def results_in_tuple(self):
-        return self.mae, self.mse
+        return self.mse, self.mae       # the reference's order (metrics_utils.py:184-185)
 
     def results_in_dict(self):
         return {"mae": self.mae, "mse": self.mse}

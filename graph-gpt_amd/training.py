@@ -167,7 +167,6 @@ class GgetEngine:
         # torch.distributed on the data path; the unique id travels once over the existing process group).
         self.fp32_reduce = bool(int(os.environ.get("GGET_DP_FP32_REDUCE", "0")))
         self.abi_comm = os.environ.get("GGET_DP_BACKEND", "torch") == "abi"
-        self._abi_ready = False
         model.materialize_grads = False  # fused path: gradients stay in the flat bf16 arena
         model._managed_by_engine = True  # the bucketed exchange below replaces the all-reduce of _autograd_backward
 
@@ -186,14 +185,15 @@ class GgetEngine:
         return self.train(False)
 
     def _ensure_abi_comm(self, e):
-        if self._abi_ready:
+        # readiness belongs to the ENGINE INSTANCE: a model that re-creates its engine for a larger batch hands the
+        # communicator over (Engine.comm_adopt), so this collective bootstrap runs once per job, on every rank together
+        if e.comm_world > 0:
             return
         rank = dist.get_rank(self.pg) if self.world > 1 else 0
         uid = [e.comm_unique_id() if rank == 0 else None]
         if self.world > 1:
             dist.broadcast_object_list(uid, src=0, group=self.pg)
         e.comm_init(rank, self.world, uid[0])
-        self._abi_ready = True
 
     # -- backward with bucketed all-reduce overlapped on a side stream
     def backward(self, loss=None):
@@ -258,7 +258,8 @@ class GgetEngine:
         d = os.path.join(save_dir, tag) if tag else save_dir
         os.makedirs(d, exist_ok=True)
         e = self.module._engine
-        torch.save({k: v.cpu() for k, v in e.state_dict().items()}, os.path.join(d, "model.pt"))
+        # the MODULE's state dict: reference shapes (emb_mask_token is [1,1,embed_dim] there, flat in the engine arena)
+        torch.save({k: v.detach().cpu().clone() for k, v in self.module.state_dict().items()}, os.path.join(d, "model.pt"))
         torch.save({"m": {k: e.view(k, "m").cpu() for k in e.params}, "v": {k: e.view(k, "v").cpu() for k in e.params},
                     "step": e.step_count, "global_steps": self.global_steps}, os.path.join(d, "optimizer.pt"))
         self.module.config.save_pretrained(d)
@@ -289,7 +290,7 @@ def batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine):
     """reference training_utils.batch_training DeepSpeed branch (:30-45): loss = head1 (+head2); backward; step.
     position_ids are NOT passed in pre-training (reference comments them out at :35)."""
     out = engine(input_ids=data["input_ids"], attention_mask=data["attention_mask"], labels=data["labels"],
-                 inputs_raw_embeds=None, sample_wgt=data.get("wgt"))
+                 inputs_raw_embeds=data.get("embed"), sample_wgt=data.get("wgt"))
     loss = out.head1_loss
     if out.head2_loss is not None:
         loss = loss + out.head2_loss
@@ -301,7 +302,8 @@ def batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine):
 def ft_batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine, label_key: str = "task_labels"):
     """reference training_utils.ft_batch_training (:98-205): passes position_ids, task labels, sample weights."""
     out = engine(input_ids=data["input_ids"], attention_mask=data["attention_mask"], position_ids=data.get("position_ids"),
-                 task_labels=data[label_key], cls_idx=data.get("cls_idx"), sample_wgt=data.get("wgt"))
+                 task_labels=data[label_key], cls_idx=data.get("cls_idx"), inputs_raw_embeds=data.get("embed"),
+                 sample_wgt=data.get("wgt"))
     loss = out.task_loss
     engine.backward(loss)
     engine.step()
@@ -377,6 +379,7 @@ def ft_evaluate(model, loader, *, problem_type: str = "single_label_classificati
         labels = labels.float() if problem_type == "multi_label_classification" else labels
         res = model(input_ids=data["input_ids"].to(device), attention_mask=data["attention_mask"].to(device),
                     task_labels=labels, cls_idx=data["cls_idx"].to(device) if "cls_idx" in data else None,
+                    inputs_raw_embeds=data["embed"].to(device) if "embed" in data else None,     # log_eval_dump_utils.py:108-110
                     sample_wgt=data["wgt"].to(device) if "wgt" in data else None,
                     position_ids=data["position_ids"].to(device) if "position_ids" in data else None)
         test_loss = test_loss + res.task_loss.detach()
@@ -391,7 +394,10 @@ def ft_evaluate(model, loader, *, problem_type: str = "single_label_classificati
     if world > 1:
         gdev = device if dist.get_backend() == "nccl" else torch.device("cpu")
         input_dict = {k: all_gather_varlen(v.to(gdev)).cpu() for k, v in input_dict.items()}
-    cls_metrics.compute()
+        # the reference's torchmetrics objects synchronise across ranks inside compute(): feed ours the gathered lists
+        cls_metrics.compute({k: all_gather_varlen(v.to(gdev)).cpu().numpy() for k, v in cls_metrics.sync_dict().items()})
+    else:
+        cls_metrics.compute()
     res = M.evaluate_ogb(dataset_name, {k: v.numpy() for k, v in input_dict.items()})
     if res is None:
         res = cls_metrics.results_in_dict()

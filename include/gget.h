@@ -221,6 +221,9 @@ int gget_backward_end(gget_handle_t h, void* stream);
 int gget_comm_unique_id(void* out_bytes /* GGET_UNIQUE_ID_BYTES */);
 int gget_comm_init(gget_handle_t h, int rank, int world, const void* unique_id_bytes);
 int gget_comm_destroy(gget_handle_t h);
+/* hands the communicator of `src` (and its staging buffer) to `dst`, a handle of the same model created with other capacities
+ * (the host re-creates the handle when a larger batch arrives): no collective, so ranks may do it independently. */
+int gget_comm_move(gget_handle_t dst, gget_handle_t src);
 int gget_allreduce_grads_async(gget_handle_t h, int bucket, int fp32_accumulate, void* side_stream);
 
 /* replaces: clip_grad_norm_ + AdamW.step / FusedAdam (training_utils.py:68-80, opt_utils.py:18-24,

@@ -59,7 +59,7 @@ def test_no_cpu_fallback():
     with pytest.raises(L.GgetError):
         eng.Engine(spec, 64, 4)
     from src.models import GraphGPTConfig, GraphGPTPretrainBase
-    m = GraphGPTPretrainBase(GraphGPTConfig(vocab_size=300, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
+    m = GraphGPTPretrainBase(GraphGPTConfig(hidden_act="gelu", vocab_size=300, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
                                             num_attention_heads=2, causal_attention=False, stacked_feat=1, next_n_token=1))
     with pytest.raises(L.GgetError):
         m(input_ids=torch.zeros(2, 8, 1, dtype=torch.long))
@@ -67,7 +67,7 @@ def test_no_cpu_fallback():
 
 def test_state_dict_keys_match_reference_names():
     from src.models import GraphGPTConfig, GraphGPTTaskModel
-    m = GraphGPTTaskModel(GraphGPTConfig(vocab_size=1000, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
+    m = GraphGPTTaskModel(GraphGPTConfig(hidden_act="gelu", vocab_size=1000, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
                                          num_attention_heads=2, causal_attention=False, stacked_feat=4, num_labels=2,
                                          layer_scale_init_value=1.0))
     keys = list(m.state_dict().keys())

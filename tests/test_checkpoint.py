@@ -15,7 +15,7 @@ def _cfg(**kw):
     base = dict(vocab_size=97, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
                 max_position_embeddings=64, causal_attention=False, stacked_feat=3, next_n_token=3)
     base.update(kw)
-    return modeling.GraphGPTConfig(**base)
+    return modeling.GraphGPTConfig(hidden_act="gelu", **base)
 
 
 def test_get_latest_ckp(tmp_path):
@@ -79,7 +79,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def _ref_ckpt_model():
     z = np.load(os.path.join(GOLD, "ref_ckpt.npz"))
-    cfg = modeling.GraphGPTConfig(vocab_size=300, hidden_size=128, intermediate_size=256, num_hidden_layers=1,
+    cfg = modeling.GraphGPTConfig(hidden_act="gelu", vocab_size=300, hidden_size=128, intermediate_size=256, num_hidden_layers=1,
                                   num_attention_heads=2, max_position_embeddings=1024, causal_attention=False, stacked_feat=4,
                                   next_n_token=4)
     return z, modeling.GraphGPTPretrainBase(cfg, seed=123)

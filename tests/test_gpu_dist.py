@@ -24,7 +24,7 @@ def _free_port():
 
 
 def _cfg(modeling):
-    return modeling.GraphGPTConfig(vocab_size=756, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
+    return modeling.GraphGPTConfig(hidden_act="gelu", vocab_size=756, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
                                    num_attention_heads=2, max_position_embeddings=1024, causal_attention=False,
                                    stacked_feat=13, next_n_token=13)
 
@@ -119,8 +119,17 @@ def test_rccl_one_rank_communicator_through_staged_backward(monkeypatch):
         e = model._engine
         out = (losses, e.grad_bf16.detach().float().cpu().numpy().copy(), e.master.detach().cpu().numpy().copy())
         if abi:
-            assert eng._abi_ready and e.comm_world == 1
-            e.comm_destroy()
+            assert e.comm_world == 1
+            # a larger batch re-creates the engine handle: the communicator must MOVE to the new handle (no collective re-init,
+            # which would hang the ranks whose batch did not grow - ADVICE r2) and the next exchange must still work
+            big = synth.make_pretrain_batch(B=16, S=40, F=13, V=756, seed=900)
+            big = {k: torch.from_numpy(v).cuda() for k, v in big.items() if k != "lengths"}
+            l3 = float(tr.batch_training(big, eng))
+            torch.cuda.synchronize()
+            e2 = model._engine
+            assert e2 is not e and e2.comm_world == 1 and e.comm_world == 0 and np.isfinite(l3)
+            assert e2.step_count == 3
+            e2.comm_destroy()
         return out
 
     ref0_master = modeling.GraphGPTPretrainBase(_cfg(modeling), seed=1).cuda()._engine.master.detach().cpu().numpy().copy()

@@ -245,7 +245,7 @@ def test_staged_backward_equals_monolithic():
     tr = importlib.import_module("graph-gpt_amd.training")
     modeling = importlib.import_module("graph-gpt_amd.modeling")
     from _util import synth
-    cfg = modeling.GraphGPTConfig(vocab_size=756, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
+    cfg = modeling.GraphGPTConfig(hidden_act="gelu", vocab_size=756, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
                                   num_attention_heads=2, max_position_embeddings=1024, causal_attention=False,
                                   stacked_feat=13, next_n_token=13)
     batch = synth.make_pretrain_batch(B=8, S=32, F=13, V=756, seed=3)
@@ -335,8 +335,8 @@ def test_smtp_inside_forward_matches_explicit_masking():
     F, V, B, S = 4, 211, 6, 24
     kw = dict(vocab_size=V, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
               max_position_embeddings=64, causal_attention=False, stacked_feat=F, next_n_token=F)
-    m_in = modeling.GraphGPTPretrainBase(modeling.GraphGPTConfig(smtp_inside=True, smtp_power=1.0, **kw), seed=4).cuda().eval()
-    m_ex = modeling.GraphGPTPretrainBase(modeling.GraphGPTConfig(**kw), seed=4).cuda().eval()
+    m_in = modeling.GraphGPTPretrainBase(modeling.GraphGPTConfig(hidden_act="gelu", smtp_inside=True, smtp_power=1.0, **kw), seed=4).cuda().eval()
+    m_ex = modeling.GraphGPTPretrainBase(modeling.GraphGPTConfig(hidden_act="gelu", **kw), seed=4).cuda().eval()
     g = torch.Generator().manual_seed(9)
     lens = torch.randint(10, S + 1, (B,), generator=g)
     full = torch.zeros(B, S, F + 4, dtype=torch.int64)
@@ -380,7 +380,7 @@ def test_generation_loop(case):
     weights = importlib.import_module("graph-gpt_amd.weights")
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "generation.npz"))
     std, head_std, seed = g["meta_init"]
-    cfg = modeling.GraphGPTConfig(vocab_size=300, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
+    cfg = modeling.GraphGPTConfig(hidden_act="gelu", vocab_size=300, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
                                   num_attention_heads=2, max_position_embeddings=1024, causal_attention=False, stacked_feat=4,
                                   next_n_token=4)
     model = modeling.GraphGPTPretrainBase(cfg, seed=0).cuda()
@@ -533,7 +533,7 @@ def test_evaluate_pass_matches_oracle_losses():
     tr = importlib.import_module("graph-gpt_amd.training")
     from _util import synth
     F, V = 4, 300
-    cfg = modeling.GraphGPTConfig(vocab_size=V, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
+    cfg = modeling.GraphGPTConfig(hidden_act="gelu", vocab_size=V, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
                                   num_attention_heads=2, max_position_embeddings=1024, causal_attention=False, stacked_feat=F,
                                   next_n_token=F, attention_dropout=0.1)
     model = modeling.GraphGPTPretrainBase(cfg, seed=2).cuda()
@@ -676,7 +676,7 @@ def test_module_moves_after_engine_and_position_guard():
     `.cpu()` / `.half()` raise instead of silently detaching them; position_ids beyond the RoPE table raise (the reference
     evaluates the rotary embedding on the fly and would accept them - DESIGN.md section 7)."""
     modeling = importlib.import_module("graph-gpt_amd.modeling")
-    cfg = modeling.GraphGPTConfig(vocab_size=300, hidden_size=128, intermediate_size=512, num_hidden_layers=1,
+    cfg = modeling.GraphGPTConfig(hidden_act="gelu", vocab_size=300, hidden_size=128, intermediate_size=512, num_hidden_layers=1,
                                   num_attention_heads=2, max_position_embeddings=64, causal_attention=False, stacked_feat=4,
                                   next_n_token=1, num_labels=2, problem_type="single_label_classification")
     m = modeling.GraphGPTTaskModel(cfg, seed=0).cuda()
@@ -881,7 +881,7 @@ def test_auc_loss_matches_oracle_with_the_same_pairs():
     state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
     b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
     num_neg = int(z["num_neg"])
-    cfg = M.GraphGPTConfig(vocab_size=1000, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+    cfg = M.GraphGPTConfig(hidden_act="gelu", vocab_size=1000, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
                            num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
                            max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=4, num_labels=2,
                            loss_type="auc", num_neg=num_neg, problem_type="single_label_classification")
@@ -978,7 +978,7 @@ def test_embed_and_mlp_dropouts_exact_mask(gated, layer_scale):
 
 @pytest.mark.gpu
 def test_model_class_applies_embed_and_mlp_dropout_only_in_training_mode():
-    """GraphGPTConfig(embed_pdrop, mlp_pdrop) through the drop-in class: train() draws fresh masks every call (nn.Dropout),
+    """GraphGPTConfig(hidden_act="gelu", embed_pdrop, mlp_pdrop) through the drop-in class: train() draws fresh masks every call (nn.Dropout),
     eval() is deterministic and equal to the dropout-free model."""
     M = importlib.import_module("graph-gpt_amd.modeling")
     from _util import synth
@@ -987,8 +987,8 @@ def test_model_class_applies_embed_and_mlp_dropout_only_in_training_mode():
     batch = synth.make_pretrain_batch(B=4, S=24, F=4, V=300, seed=3)
     b = {k: torch.from_numpy(v) for k, v in batch.items()}
     call = lambda m: float(m(input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=b["labels"]).head1_loss.item())
-    plain = M.GraphGPTPretrainBase(M.GraphGPTConfig(**kw), seed=5)
-    drop = M.GraphGPTPretrainBase(M.GraphGPTConfig(embed_pdrop=0.1, mlp_pdrop=0.1, **kw), seed=5)
+    plain = M.GraphGPTPretrainBase(M.GraphGPTConfig(hidden_act="gelu", **kw), seed=5)
+    drop = M.GraphGPTPretrainBase(M.GraphGPTConfig(hidden_act="gelu", embed_pdrop=0.1, mlp_pdrop=0.1, **kw), seed=5)
     plain.eval(); drop.eval()
     ref = call(plain)
     ev = call(drop)
@@ -1021,7 +1021,7 @@ def test_mlp_score_head_matches_oracle_eval_and_training_dropout():
         if k.startswith("score."):
             state[k] = z["w_" + k]
     b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
-    cfg = M.GraphGPTConfig(vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+    cfg = M.GraphGPTConfig(hidden_act="gelu", vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
                            num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
                            max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=13, num_labels=1,
                            mlp=list(hm), dropout=float(z["p"]), problem_type="regression")
@@ -1084,7 +1084,7 @@ def test_focal_loss_matches_reference_and_oracle():
     state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
     b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
     gamma = float(z["gamma"])
-    cfg = M.GraphGPTConfig(vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+    cfg = M.GraphGPTConfig(hidden_act="gelu", vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
                            num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
                            max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=13, next_n_token=13,
                            focal_gamma=gamma)
@@ -1175,7 +1175,7 @@ def test_stack_method_long_matches_reference_and_oracle(kind):
     seed, std, hstd = z["meta_init"]
     state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
     b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
-    cfg = M.GraphGPTConfig(vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+    cfg = M.GraphGPTConfig(hidden_act="gelu", vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
                            num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
                            max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=13,
                            next_n_token=13 if pt else 1, stack_method="long", num_labels=2)
@@ -1236,7 +1236,7 @@ def test_token_level_ce_matches_reference_and_oracle():
     seed, std, hstd = z["meta_init"]
     state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
     b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
-    cfg = M.GraphGPTConfig(vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+    cfg = M.GraphGPTConfig(hidden_act="gelu", vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
                            num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
                            max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=13, next_n_token=1,
                            num_labels=C, loss_type="token_ce", problem_type="single_label_classification")
@@ -1285,7 +1285,7 @@ def test_rope_range_matches_reference_and_oracle():
     seed, std, hstd = z["meta_init"]
     state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
     b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
-    cfg = M.GraphGPTConfig(vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+    cfg = M.GraphGPTConfig(hidden_act="gelu", vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
                            num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
                            max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=13, next_n_token=1,
                            num_labels=2, rope_range=rr)
@@ -1341,7 +1341,7 @@ def test_raw_embedding_inputs_match_reference_and_oracle(kind):
     state = weights_mod.make_state_dict(spec, seed=int(seed), std=float(std), head_std=float(hstd))
     state["embed_layernorm.weight"] = z["w_embed_ln"]
     b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
-    cfg = M.GraphGPTConfig(vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+    cfg = M.GraphGPTConfig(hidden_act="gelu", vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
                            num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
                            max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=13,
                            next_n_token=13 if pt else 1, num_labels=2, embed_dim=E)
@@ -1403,7 +1403,7 @@ def test_raw_embedding_dropout_exact_mask():
     state["embed_layernorm.weight"] = z["w_embed_ln"]
     b = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
     B, S, F = b["input_ids"].shape
-    cfg = M.GraphGPTConfig(vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+    cfg = M.GraphGPTConfig(hidden_act="gelu", vocab_size=756, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
                            num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
                            max_position_embeddings=spec.max_position, causal_attention=False, stacked_feat=13, next_n_token=13,
                            embed_dim=E, embed_pdrop=pdrop)
@@ -1442,7 +1442,7 @@ def test_token_level_ce_without_any_labelled_row_is_nan_like_the_reference():
     from _util import spec_mod, synth
     M = importlib.import_module("graph-gpt_amd.modeling")
     spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=300, stacked_feat=1, next_n_token=1, num_labels=5)
-    cfg = M.GraphGPTConfig(vocab_size=300, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+    cfg = M.GraphGPTConfig(hidden_act="gelu", vocab_size=300, hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
                            num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads, max_position_embeddings=64,
                            causal_attention=False, stacked_feat=1, next_n_token=1, num_labels=5, loss_type="token_ce",
                            problem_type="single_label_classification")

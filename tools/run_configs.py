@@ -11,7 +11,7 @@ training = importlib.import_module("graph-gpt_amd.training")
 
 def run(name, kind, size, B, S, F, V, steps=6, warmup=2, **cfgkw):
     sz = spec_mod.MODEL_SIZES[size]
-    cfg = modeling.GraphGPTConfig(vocab_size=V, hidden_size=sz["hidden_size"], intermediate_size=4 * sz["hidden_size"],
+    cfg = modeling.GraphGPTConfig(hidden_act="gelu", vocab_size=V, hidden_size=sz["hidden_size"], intermediate_size=4 * sz["hidden_size"],
                                   num_hidden_layers=sz["num_layers"], num_attention_heads=sz["hidden_size"] // 64,
                                   max_position_embeddings=max(1024, S), causal_attention=False, stacked_feat=F,
                                   next_n_token=F if kind == "pt" else 1, attention_dropout=0.1, **cfgkw)

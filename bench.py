@@ -41,11 +41,14 @@ WORKLOADS = {
 }
 
 
-def flops_per_step(spec, B, S, M, Lm, kind="pt"):
+def flops_per_step(spec, B, S, M, Lm, kind="pt", rows=None, lengths=None):
     """Algorithmic FLOPs of one training step: F_step = 3*F_fwd, no recompute credit,
-    full SxS attention, head terms with the measured M / Lm of the batch (fine-tune: the pooled score head)."""
+    full SxS attention, head terms with the measured M / Lm of the batch (fine-tune: the pooled score head).
+    rows / lengths: the EXECUTED count of a var-len step - token-wise terms over the rows the engine ran on, attention over
+    each sample's own len x len block."""
     T, d, ff, L, F, V = B * S, spec.hidden_size, spec.intermediate_size, spec.num_layers, spec.next_n_token, spec.vocab_size
-    fwd = T * L * (8 * d * d + 6 * d * ff) + 4 * L * B * S * S * d
+    att = B * S * S if lengths is None else float((np.asarray(lengths, np.float64) ** 2).sum())
+    fwd = (rows if rows is not None else T) * L * (8 * d * d + 6 * d * ff) + 4 * L * att * d
     if kind.startswith("pt"):
         fwd += M * 2 * d * (F * d if F > 1 else 0) + Lm * 2 * d * V
     else:
@@ -168,6 +171,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="pcqm4m-v2-pretrain-base", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layout", default="varlen", choices=["varlen", "padded"],
+                    help="token layout of the step: the engine's padding-free layout (default) or every row of the padded [B,S] grid")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -220,6 +225,13 @@ def main():
                                       min_len=S // 4)
         real_tokens = synth.real_tokens(batch)
     dev = {k: torch.from_numpy(v).cuda() for k, v in batch.items() if k not in ("lengths", "segments")}
+    # Token layout of the step.  "varlen" (default): the batch carries its real-token count (a host int the collator knows:
+    # sum(attention_mask)), and the engine runs embedding, layer stack and backward on the compacted real tokens instead of the padded
+    # [B,S] grid (include/gget.h: gget_set_token_count) - same batch, same loss, same gradients.  "padded": every row of the grid,
+    # as the reference computes it.  Packed batches (3-D masks) have no padding to skip.
+    layout = a.layout if kind != "pt-packed" else "padded"
+    if layout == "varlen":
+        dev["num_tokens"] = int(real_tokens)
 
     def step():
         return training.batch_training(dev, engine) if pt else training.ft_batch_training(dev, engine)[0]
@@ -261,10 +273,12 @@ def main():
 
     if rank == 0:
         M, Lm = model._engine.head_counts() if pt else (0, 0)
-        fstep = flops_per_step(spec, B, S, M, Lm, kind)
+        ran_varlen, t_rows, _ = model._engine.varlen_status()
+        fstep = flops_per_step(spec, B, S, M, Lm, kind)                    # the reference's computation, padded grid
+        fexec = flops_per_step(spec, B, S, M, Lm, kind, rows=t_rows, lengths=batch.get("lengths") if ran_varlen else None)
         ms = dt / a.steps * 1e3
         step_tflops = fstep / (ms * 1e-3) / 1e12
-        kt = time_kernels(spec, B * S)
+        kt = time_kernels(spec, t_rows)
         L_ = spec.num_layers
         share = lambda fl_per_layer: round(100.0 * fl_per_layer * L_ / fstep, 1)
         # the dominant kernel = the launch that takes the largest share of the step's TIME (each of the three runs once per
@@ -297,13 +311,20 @@ def main():
                        f"({spec.num_params() / 1e6:.1f}M params)", "per_gpu_batch": B, "global_batch": B * world,
                        "seq_len": S, "stacked_feat": F, "vocab": V, "parallelism": f"dp{world}",
                        "step": "fwd+bwd+allreduce+clip+AdamW", "attention_dropout": cfg.attention_dropout,
+                       "token_layout": "varlen (real tokens compacted on the device; same batch, loss and gradients as the padded grid)"
+                       if ran_varlen else "padded",
                        **({"path_pdrop": 0.2, "layer_scale_init_value": 1.0} if kind == "ft" else {}),
                        **({"packing": "whole graphs back to back, block-diagonal attention"} if kind == "pt-packed" else {})},
             ("smtp_loss" if pt else "task_loss"): mean_loss,
             "padded_tokens_per_s": B * S * world * a.steps / dt,
             "tokens_per_s_per_gpu": tot_real * a.steps / dt / world,
+            # frac_of_peak: SURVEY 8(d)'s accounting - the FLOPs of the reference's computation of this batch (every row of the padded
+            # [B,S] grid, full S x S attention) over the step time.  frac_of_peak_executed: only what the engine executed (var-len
+            # layout: the real-token rows, len x len attention blocks) - the matrix pipes' actual duty.
             "step_mfma": {"flops_per_step": fstep, "achieved_tflops_per_gpu": step_tflops,
-                          "frac_of_peak": step_tflops / PEAK_BF16_TFLOPS},
+                          "frac_of_peak": step_tflops / PEAK_BF16_TFLOPS,
+                          "flops_per_step_executed": fexec, "frac_of_peak_executed": fexec / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                          "token_layout": "varlen" if ran_varlen else "padded", "rows": t_rows, "padded_rows": B * S},
             "roofline": roofline,
         }
         if world == 1 and not a.no_cpu_baseline and kind == "pt":

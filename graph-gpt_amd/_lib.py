@@ -62,6 +62,8 @@ SIGNATURES = {
     "gget_head_logits": (i32, [vp, C.POINTER(vp), C.POINTER(i32)]),
     "gget_hidden_states": (i32, [vp, C.POINTER(vp)]),
     "gget_op_gemm": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "gget_op_gemm_streamk": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "gget_op_gemm_streamk_bytes": (u64, []),
     "gget_debug_set": (i32, [i32, i32]),
     "gget_debug_occupy": (i32, [vp, u64, i32, i32, i32, vp]),
     "gget_op_gemm_grouped": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -83,6 +85,8 @@ SIGNATURES = {
     "gget_op_ranges_from_mask3d": (i32, [vp, vp, vp, i32, i32, vp]),
     "gget_set_dropout": (i32, [vp, f32, f32, C.c_uint32]),
     "gget_set_auc": (i32, [vp, i32, C.c_uint32]),
+    "gget_set_token_count": (i32, [vp, C.c_int64]),
+    "gget_varlen_status": (i32, [vp, vp, vp]),
     "gget_set_focal_gamma": (i32, [vp, f32]),
     "gget_set_stack_method": (i32, [vp, i32]),
     "gget_set_rope_range": (i32, [vp, f32]),

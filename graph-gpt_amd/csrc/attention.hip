@@ -226,6 +226,10 @@ struct KeyRange {
   const int32_t* key_len;   // [B] or nullptr (=> S); ignored when lo/hi are given
   const int32_t* lo;        // [B,S] or nullptr
   const int32_t* hi;        // [B,S]
+  // var-len (padding-free) token layout: first row of sample b in the token-major buffers (qkv / out / dout / dqkv); its rows are
+  // [row_base[b], row_base[b] + key_len[b]).  nullptr = padded layout, sample b at rows [b * S, b * S + S).  Logical [B,S] arrays
+  // (lse, delta, position ids, the dropout hash coordinates) keep their (b, s) indexing in both layouts.  Not combined with lo / hi.
+  const int32_t* row_base;
 };
 // wave-uniform min / max of small non-negative integers (exact in fp32)
 __device__ __forceinline__ int wave_imin(int v) { return (int)-wave_max(-(float)v); }
@@ -324,10 +328,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
+  // var-len token layout (KR.row_base): sample b owns rows [rb, rb + SL) of the token-major buffers; padded layout: rb = b * S, SL = S
+  const int rb = KR.row_base ? KR.row_base[b] : b * S;
+  const int SL = KR.row_base ? KR.key_len[b] : S;
   const int q0 = (blockIdx.x * NW + wave) * 32;
   const int d = H * 64;
   const size_t pitch = (size_t)3 * d;
-  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
   const bf16_t* kb = qb + d;
   const bf16_t* vb = qb + 2 * d;
   const int qrow = q0 + l31;
@@ -338,7 +345,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
   int qlo = 0, qhi = (KR.key_len ? KR.key_len[b] : S) - 1;
   int ulo = 0, uhi = qhi, ilo = 0, ihi = qhi;
   if (packed) {
-    const bool v = qrow < S;
+    const bool v = qrow < SL;
     qlo = v ? KR.lo[(size_t)b * S + qrow] : 0;
     qhi = v ? KR.hi[(size_t)b * S + qrow] : -1;
     ulo = wave_imin(qhi >= qlo ? qlo : S); uhi = wave_imax(qhi >= qlo ? qhi + 1 : 0) - 1;
@@ -347,32 +354,32 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
   const int klen = packed ? S : qhi + 1;     // block-level upper bound of the key loop
 
   bf16x8_t qf[4];
-  frags_global_rope(qf, qb, qrow, S, pitch, lane, R, b);
+  frags_global_rope(qf, qb, qrow, SL, pitch, lane, R, b);
   f32x16_t o0 = zero16(), o1 = zero16();
   float m = -INFINITY, l = 0.f;
   const unsigned dbase = drop_base(D, b * H + h, qrow, 0);
-  const int q_end_blk = min(S, (int)(blockIdx.x + 1) * NW * 32);       // one past the block's last query row
+  const int q_end_blk = min(SL, (int)(blockIdx.x + 1) * NW * 32);       // one past the block's last query row
   const int kend_blk = causal ? min(klen, q_end_blk) : klen;
-  const int kend = (q0 < S) ? min(uhi + 1, causal ? q0 + 32 : S) : 0;  // this wave's own key range
+  const int kend = (q0 < SL) ? min(uhi + 1, causal ? q0 + 32 : SL) : 0;  // this wave's own key range
   constexpr bool PF = NW > 1;   // single-wave blocks see one tile (S <= 32): nothing to prefetch, registers are tight
   TilePref<NW * 64> pk, pv;
   if (PF && kend_blk > 0) {
-    tile_fetch<NW * 64>(pk, kb, 0, S, pitch, tid, R);
-    tile_fetch<NW * 64>(pv, vb, 0, S, pitch, tid, Rnone);
+    tile_fetch<NW * 64>(pk, kb, 0, SL, pitch, tid, R);
+    tile_fetch<NW * 64>(pv, vb, 0, SL, pitch, tid, Rnone);
   }
   for (int k0 = 0; k0 < kend_blk; k0 += 32) {
     __syncthreads();  // previous tile fully consumed
     if constexpr (PF) {
-      tile_commit<NW * 64>(kt, pk, k0, S, tid, R, b);
-      tile_commit<NW * 64>(vt, pv, k0, S, tid, Rnone, b);
+      tile_commit<NW * 64>(kt, pk, k0, SL, tid, R, b);
+      tile_commit<NW * 64>(vt, pv, k0, SL, tid, Rnone, b);
     } else {
-      load_tile_coop<NW * 64>(kt, kb, k0, S, pitch, tid, R, b);
-      load_tile_coop<NW * 64>(vt, vb, k0, S, pitch, tid, Rnone, b);
+      load_tile_coop<NW * 64>(kt, kb, k0, SL, pitch, tid, R, b);
+      load_tile_coop<NW * 64>(vt, vb, k0, SL, pitch, tid, Rnone, b);
     }
     __syncthreads();
     if (PF && k0 + 32 < kend_blk) {   // next tile's loads fly while this one is computed
-      tile_fetch<NW * 64>(pk, kb, k0 + 32, S, pitch, tid, R);
-      tile_fetch<NW * 64>(pv, vb, k0 + 32, S, pitch, tid, Rnone);
+      tile_fetch<NW * 64>(pk, kb, k0 + 32, SL, pitch, tid, R);
+      tile_fetch<NW * 64>(pv, vb, k0 + 32, SL, pitch, tid, Rnone);
     }
     if (k0 >= kend || k0 + 31 < ulo) continue;
     f32x16_t sc = zero16();
@@ -381,7 +388,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
     // The loop is VALU-bound (head_dim 64: ~0.25 MFMA cycles but several VALU cycles per score), so: scores stay raw
     // until one fma + exp2 (scale and log2(e) folded, running max kept in the log2 domain); the key / causal mask is only
     // evaluated on tiles that touch the sequence end or the diagonal; O is rescaled only when some lane's max moved.
-    const bool edge = (k0 < ilo) || (k0 + 31 > ihi) || (causal && k0 + 31 > q0) || (q0 + 32 > S);
+    const bool edge = (k0 < ilo) || (k0 + 31 > ihi) || (causal && k0 + 31 > q0) || (q0 + 32 > SL);
     float mx = -INFINITY;
     if (edge) {
 #pragma unroll
@@ -420,9 +427,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
     o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 0, lane), pb0, o1, 0, 0, 0);
     o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 1, lane), pb1, o1, 0, 0, 0);
   }
-  if (qrow < S) {
+  if (qrow < SL) {
     const float inv = l > 0.f ? 1.f / l : 0.f;   // (the keep scale 1/(1-p) is already folded into the dropped P)
-    store_t(out + ((size_t)b * S + qrow) * d + h * 64, o0, o1, inv, hi);
+    store_t(out + ((size_t)rb + qrow) * d + h * 64, o0, o1, inv, hi);
     if (hi == 0 && lse) lse[((size_t)b * H + h) * S + qrow] = l > 0.f ? (m + log2f(l)) * (1.0f / kLog2e) : 0.f;   // natural log
   }
 }
@@ -439,20 +446,23 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
+  // var-len token layout (KR.row_base): sample b owns rows [rb, rb + SL) of the token-major buffers; padded layout: rb = b * S, SL = S
+  const int rb = KR.row_base ? KR.row_base[b] : b * S;
+  const int SL = KR.row_base ? KR.key_len[b] : S;
   const int q0 = (blockIdx.x * NW + wave) * 32;
   const int d = H * 64;
   const size_t pitch = (size_t)3 * d;
-  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
   const bf16_t* kb = qb + d;
   const bf16_t* vb = qb + 2 * d;
-  const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
+  const bf16_t* dob = dout + (size_t)rb * d + h * 64;
   const int qrow = q0 + l31;
   const Rope Rnone{nullptr, nullptr, nullptr, S};
   constexpr bool packed = PK;      // see attn_fwd_kernel
   int qlo = 0, qhi = (KR.key_len ? KR.key_len[b] : S) - 1;
   int ulo = 0, uhi = qhi, ilo = 0, ihi = qhi;
   if (packed) {
-    const bool v = qrow < S;
+    const bool v = qrow < SL;
     qlo = v ? KR.lo[(size_t)b * S + qrow] : 0;
     qhi = v ? KR.hi[(size_t)b * S + qrow] : -1;
     ulo = wave_imin(qhi >= qlo ? qlo : S); uhi = wave_imax(qhi >= qlo ? qhi + 1 : 0) - 1;
@@ -460,51 +470,51 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
   }
   const int klen = packed ? S : qhi + 1;
   bf16x8_t qf[4], dof[4];
-  frags_global_rope(qf, qb, qrow, S, pitch, lane, Rin, b);
+  frags_global_rope(qf, qb, qrow, SL, pitch, lane, Rin, b);
 #pragma unroll
-  for (int s = 0; s < 4; ++s) dof[s] = frag_global(dob, qrow, S, (size_t)d, s, lane);
+  for (int s = 0; s < 4; ++s) dof[s] = frag_global(dob, qrow, SL, (size_t)d, s, lane);
   const size_t sidx = ((size_t)b * H + h) * S + min(qrow, S - 1);
   // delta_q = sum_dh dO*O of this query row (the lane holds half of the row's dO already; the other half sits in lane^32);
   // stored for the dK/dV kernel that follows on the same stream
   float dl = 0.f;
   {
-    const bf16_t* ob = out + (size_t)b * S * d + h * 64;
+    const bf16_t* ob = out + (size_t)rb * d + h * 64;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       float a[8], gg[8];
-      unpack8(__builtin_bit_cast(uint4, frag_global(ob, qrow, S, (size_t)d, s, lane)), a);
+      unpack8(__builtin_bit_cast(uint4, frag_global(ob, qrow, SL, (size_t)d, s, lane)), a);
       unpack8(__builtin_bit_cast(uint4, dof[s]), gg);
 #pragma unroll
       for (int e = 0; e < 8; ++e) dl += a[e] * gg[e];
     }
     dl += __shfl_xor(dl, 32, 64);
-    if (hi == 0 && qrow < S) delta[sidx] = dl;
+    if (hi == 0 && qrow < SL) delta[sidx] = dl;
   }
   const float nlse2 = -lse[sidx] * kLog2e, ndl = -dl;
   const unsigned dbase = drop_base(D, b * H + h, qrow, 0);
   f32x16_t a0 = zero16(), a1 = zero16();
-  const int q_end_blk = min(S, (int)(blockIdx.x + 1) * NW * 32);
+  const int q_end_blk = min(SL, (int)(blockIdx.x + 1) * NW * 32);
   const int kend_blk = causal ? min(klen, q_end_blk) : klen;
-  const int kend = (q0 < S) ? min(uhi + 1, causal ? q0 + 32 : S) : 0;
+  const int kend = (q0 < SL) ? min(uhi + 1, causal ? q0 + 32 : SL) : 0;
   constexpr bool PF = NW > 1;
   TilePref<NW * 64> pk, pv;
   if (PF && kend_blk > 0) {
-    tile_fetch<NW * 64>(pk, kb, 0, S, pitch, tid, Rin);
-    tile_fetch<NW * 64>(pv, vb, 0, S, pitch, tid, Rnone);
+    tile_fetch<NW * 64>(pk, kb, 0, SL, pitch, tid, Rin);
+    tile_fetch<NW * 64>(pv, vb, 0, SL, pitch, tid, Rnone);
   }
   for (int k0 = 0; k0 < kend_blk; k0 += 32) {
     __syncthreads();
     if constexpr (PF) {
-      tile_commit<NW * 64>(kt, pk, k0, S, tid, Rin, b);
-      tile_commit<NW * 64>(vt, pv, k0, S, tid, Rnone, b);
+      tile_commit<NW * 64>(kt, pk, k0, SL, tid, Rin, b);
+      tile_commit<NW * 64>(vt, pv, k0, SL, tid, Rnone, b);
     } else {
-      load_tile_coop<NW * 64>(kt, kb, k0, S, pitch, tid, Rin, b);
-      load_tile_coop<NW * 64>(vt, vb, k0, S, pitch, tid, Rnone, b);
+      load_tile_coop<NW * 64>(kt, kb, k0, SL, pitch, tid, Rin, b);
+      load_tile_coop<NW * 64>(vt, vb, k0, SL, pitch, tid, Rnone, b);
     }
     __syncthreads();
     if (PF && k0 + 32 < kend_blk) {
-      tile_fetch<NW * 64>(pk, kb, k0 + 32, S, pitch, tid, Rin);
-      tile_fetch<NW * 64>(pv, vb, k0 + 32, S, pitch, tid, Rnone);
+      tile_fetch<NW * 64>(pk, kb, k0 + 32, SL, pitch, tid, Rin);
+      tile_fetch<NW * 64>(pv, vb, k0 + 32, SL, pitch, tid, Rnone);
     }
     if (k0 >= kend || k0 + 31 < ulo) continue;
     f32x16_t dp = zero16(), sc = zero16();
@@ -513,12 +523,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, s, lane), dof[s], dp, 0, 0, 0);
       sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), qf[s], sc, 0, 0, 0);
     }
-    const bool edge = (k0 < ilo) || (k0 + 31 > ihi) || (causal && k0 + 31 > q0) || (q0 + 32 > S);
+    const bool edge = (k0 < ilo) || (k0 + 31 > ihi) || (causal && k0 + 31 > q0) || (q0 + 32 > SL);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + acc_row(r, hi);
       float p = fast_exp2(fmaf(sc[r], kScaleL2, nlse2));
-      if (edge) p = (key >= qlo && key <= qhi && (!causal || key <= qrow) && qrow < S) ? p : 0.f;
+      if (edge) p = (key >= qlo && key <= qhi && (!causal || key <= qrow) && qrow < SL) ? p : 0.f;
       sc[r] = p * fmaf(dp[r], drop_mul_x(D, dbase + (unsigned)(key >> 1) * 0xC2B2AE3Du, key & 1), ndl) * kScale;
     }
     const bf16x8_t ds0 = acc_to_b(sc, 0), ds1 = acc_to_b(sc, 1);
@@ -527,9 +537,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
     a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 0, lane), ds0, a1, 0, 0, 0);
     a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 1, lane), ds1, a1, 0, 0, 0);
   }
-  if (qrow < S) {
+  if (qrow < SL) {
     unrope_acc(a0, a1, R, rope_pos(R, b, qrow), hi);
-    store_t(dqkv + ((size_t)b * S + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
+    store_t(dqkv + ((size_t)rb + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
   }
 }
 
@@ -547,21 +557,24 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
+  // var-len token layout (KR.row_base): sample b owns rows [rb, rb + SL) of the token-major buffers; padded layout: rb = b * S, SL = S
+  const int rb = KR.row_base ? KR.row_base[b] : b * S;
+  const int SL = KR.row_base ? KR.key_len[b] : S;
   const int k0 = (blockIdx.x * NW + wave) * 32;
   const int d = H * 64;
   const size_t pitch = (size_t)3 * d;
-  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
   const bf16_t* kb = qb + d;
   const bf16_t* vb = qb + 2 * d;
-  const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
+  const bf16_t* dob = dout + (size_t)rb * d + h * 64;
   constexpr bool packed = PK;
   const int klen = packed ? S : (KR.key_len ? KR.key_len[b] : S);
   const int krow = k0 + l31;
   const Rope Rnone{nullptr, nullptr, nullptr, S};
   bf16x8_t kf[4], vf[4];
-  frags_global_rope(kf, kb, krow, S, pitch, lane, Rin, b);
+  frags_global_rope(kf, kb, krow, SL, pitch, lane, Rin, b);
 #pragma unroll
-  for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, krow, S, pitch, s, lane);
+  for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, krow, SL, pitch, s, lane);
   f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
   const unsigned dbase = drop_base(D, b * H + h, 0, (unsigned)krow >> 1);
   const bool key_ok = krow < klen;                 // right-padded rows: one key length per batch row
@@ -572,49 +585,49 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
     float p_lse = 0.f, p_dl = 0.f;
     int p_lo = 0, p_hi = klen - 1;
     auto fetch_q = [&](int q0) {
-      tile_fetch<NW * 64>(pq, qb, q0, S, pitch, tid, Rin);
-      tile_fetch<NW * 64>(pdo, dob, q0, S, (size_t)d, tid, Rnone);
+      tile_fetch<NW * 64>(pq, qb, q0, SL, pitch, tid, Rin);
+      tile_fetch<NW * 64>(pdo, dob, q0, SL, (size_t)d, tid, Rnone);
       if (tid < 32) {
         const int q = min(q0 + tid, S - 1);
         p_lse = lse[((size_t)b * H + h) * S + q];
         p_dl = delta[((size_t)b * H + h) * S + q];
         if (packed) {
-          const bool v = q0 + tid < S;
+          const bool v = q0 + tid < SL;
           p_lo = v ? KR.lo[(size_t)b * S + q] : 0;
           p_hi = v ? KR.hi[(size_t)b * S + q] : -1;
         }
       }
     };
     constexpr bool PF = NW > 1;
-    if (PF && qstart < S) fetch_q(qstart);
-    for (int q0 = qstart; q0 < S; q0 += 32) {
+    if (PF && qstart < SL) fetch_q(qstart);
+    for (int q0 = qstart; q0 < SL; q0 += 32) {
       __syncthreads();
       if constexpr (PF) {
-        tile_commit<NW * 64>(qt, pq, q0, S, tid, Rin, b);
-        tile_commit<NW * 64>(dot_, pdo, q0, S, tid, Rnone, b);
+        tile_commit<NW * 64>(qt, pq, q0, SL, tid, Rin, b);
+        tile_commit<NW * 64>(dot_, pdo, q0, SL, tid, Rnone, b);
         if (tid < 32) {
           lse_s[tid] = -p_lse * kLog2e; dl_s[tid] = -p_dl;
           if (packed) { qlo_s[tid] = p_lo; qhi_s[tid] = p_hi; }
         }
       } else {
-        load_tile_coop<NW * 64>(qt, qb, q0, S, pitch, tid, Rin, b);
-        load_tile_coop<NW * 64>(dot_, dob, q0, S, (size_t)d, tid, Rnone, b);
+        load_tile_coop<NW * 64>(qt, qb, q0, SL, pitch, tid, Rin, b);
+        load_tile_coop<NW * 64>(dot_, dob, q0, SL, (size_t)d, tid, Rnone, b);
         if (tid < 32) {
           const int q = min(q0 + tid, S - 1);
           lse_s[tid] = -lse[((size_t)b * H + h) * S + q] * kLog2e;
           dl_s[tid] = -delta[((size_t)b * H + h) * S + q];
           if (packed) {
-            const bool v = q0 + tid < S;
+            const bool v = q0 + tid < SL;
             qlo_s[tid] = v ? KR.lo[(size_t)b * S + q] : 0;
             qhi_s[tid] = v ? KR.hi[(size_t)b * S + q] : -1;
           }
         }
       }
       __syncthreads();
-      if (PF && q0 + 32 < S) fetch_q(q0 + 32);
+      if (PF && q0 + 32 < SL) fetch_q(q0 + 32);
       if (k0 >= klen || (causal && q0 + 31 < k0)) continue;   // this wave's keys are padding / all in the future
       // packed rows: union / intersection of the tile's query ranges decide skipping and masking for this wave's 32 keys
-      bool edge = (k0 + 32 > klen) || (q0 + 32 > S) || (causal && k0 + 31 > q0);
+      bool edge = (k0 + 32 > klen) || (q0 + 32 > SL) || (causal && k0 + 31 > q0);
       if (packed) {
         const int lo = qlo_s[l31], hi_ = qhi_s[l31];
         const int ulo = wave_imin(hi_ >= lo ? lo : S), uhi = wave_imax(hi_ >= lo ? hi_ + 1 : 0) - 1;
@@ -635,7 +648,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
         float p = fast_exp2(fmaf(sc[r], kScaleL2, lse_s[qi]));          // lse_s holds -lse * log2(e)
         if (edge) {
           const bool in_range = packed ? (krow >= qlo_s[qi] && krow <= qhi_s[qi]) : key_ok;
-          p = (in_range && q < S && (!causal || krow <= q)) ? p : 0.f;
+          p = (in_range && q < SL && (!causal || krow <= q)) ? p : 0.f;
         }
         const float dm = drop_mul_x(D, dbase + (unsigned)q * 0x85EBCA77u, krow & 1);
         sc[r] = p * dm;                                  // dropped probabilities: what multiplied V in forward
@@ -653,8 +666,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
       dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 1, lane), s1, dk1, 0, 0, 0);
     }
   }
-  if (krow < S) {
-    bf16_t* row = dqkv + ((size_t)b * S + krow) * pitch + h * 64;
+  if (krow < SL) {
+    bf16_t* row = dqkv + ((size_t)rb + krow) * pitch + h * 64;
     unrope_acc(dk0, dk1, R, rope_pos(R, b, krow), hi);
     store_t(row + d, dk0, dk1, 1.f, hi);
     store_t(row + 2 * d, dv0, dv1, 1.f, hi);
@@ -668,29 +681,33 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
 __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __restrict__ qkv,
                                                                const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
-                                                               int B, int S, int H, int causal, Rope Rin, Rope R, Drop D) {
+                                                               int B, int S, int H, int causal, Rope Rin, Rope R, Drop D,
+                                                               const int32_t* __restrict__ row_base) {
   __shared__ __attribute__((aligned(16))) unsigned char kt[4096];
   __shared__ __attribute__((aligned(16))) unsigned char qt[4096];
   __shared__ __attribute__((aligned(16))) unsigned char dot_[4096];
   __shared__ float lse_s[32], dl_s[32];
   const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
+  // var-len token layout (row_base): sample b owns rows [rb, rb + SL) of the token-major buffers; padded layout: rb = b * S, SL = S
+  const int rb = row_base ? row_base[b] : b * S;
+  const int SL = row_base ? key_len[b] : S;
   const int d = H * 64;
   const size_t pitch = (size_t)3 * d;
-  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
   const bf16_t* kb = qb + d;
   const bf16_t* vb = qb + 2 * d;
-  const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
+  const bf16_t* dob = dout + (size_t)rb * d + h * 64;
   const int klen = key_len ? key_len[b] : S;
   const Rope Rnone{nullptr, nullptr, nullptr, S};
-  load_tile_coop<64>(kt, kb, 0, S, pitch, lane, Rin, b);
+  load_tile_coop<64>(kt, kb, 0, SL, pitch, lane, Rin, b);
   // V is only ever read row-wise (operand rows = keys): its fragments come straight from global memory, which keeps the
   // block at 12 KiB of LDS = 12 single-wave blocks per CU, i.e. B*H = 3072 problems of the headline shape in ONE round
   bf16x8_t vf[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, l31, S, pitch, s, lane);
-  load_tile_coop<64>(qt, qb, 0, S, pitch, lane, Rin, b);
-  load_tile_coop<64>(dot_, dob, 0, S, (size_t)d, lane, Rnone, b);
+  for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, l31, SL, pitch, s, lane);
+  load_tile_coop<64>(qt, qb, 0, SL, pitch, lane, Rin, b);
+  load_tile_coop<64>(dot_, dob, 0, SL, (size_t)d, lane, Rnone, b);
   const float nlse2 = -lse[((size_t)b * H + h) * S + min(l31, S - 1)] * kLog2e;
   if (hi == 0) lse_s[l31] = nlse2;
   __syncthreads();
@@ -711,7 +728,7 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = acc_row(r, hi);
-      const bool ok = key < klen && (!causal || key <= qrow) && qrow < S;
+      const bool ok = key < klen && (!causal || key <= qrow) && qrow < SL;
       const float p = ok ? fast_exp2(fmaf(sc[r], kScaleL2, nlse2)) : 0.f;
       const float t = dp[r] * drop_mul_x(D, dbase + (unsigned)(key >> 1) * 0xC2B2AE3Du, key & 1);
       dl = fmaf(p, t, dl);
@@ -728,9 +745,9 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
     a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 1, lane), ds1, a0, 0, 0, 0);
     a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 0, lane), ds0, a1, 0, 0, 0);
     a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 1, lane), ds1, a1, 0, 0, 0);
-    if (qrow < S) {
+    if (qrow < SL) {
       unrope_acc(a0, a1, R, rope_pos(R, b, qrow), hi);
-      store_t(dqkv + ((size_t)b * S + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
+      store_t(dqkv + ((size_t)rb + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
     }
   }
   __syncthreads();   // dl_s (written above) is read per query below
@@ -747,7 +764,7 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int q = acc_row(r, hi);
-      const bool ok = key_ok && q < S && (!causal || krow <= q);
+      const bool ok = key_ok && q < SL && (!causal || krow <= q);
       const float p = ok ? fast_exp2(fmaf(sc[r], kScaleL2, lse_s[q])) : 0.f;
       const float dm = drop_mul_x(D, dbase + (unsigned)q * 0x85EBCA77u, krow & 1);
       sc[r] = p * dm;
@@ -764,8 +781,8 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
     dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 0, 1, lane), s1, dk0, 0, 0, 0);
     dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 0, lane), s0, dk1, 0, 0, 0);
     dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 1, lane), s1, dk1, 0, 0, 0);
-    if (krow < S) {
-      bf16_t* row = dqkv + ((size_t)b * S + krow) * pitch + h * 64;
+    if (krow < SL) {
+      bf16_t* row = dqkv + ((size_t)rb + krow) * pitch + h * 64;
       unrope_acc(dk0, dk1, R, rope_pos(R, b, krow), hi);
       store_t(row + d, dk0, dk1, 1.f, hi);
       store_t(row + 2 * d, dv0, dv1, 1.f, hi);
@@ -803,7 +820,7 @@ __device__ __forceinline__ void stage_piece(unsigned char* arr, const bf16_t* __
   const int row = p * 8 + (lane >> 3), slot = lane & 7;
   const int x = (row >> 1) & 7;
   const int f = ((x & 1) << 2) | (x >> 1);
-  const int gr = min(r0 + row, row_lim - 1);
+  const int gr = max(min(r0 + row, row_lim - 1), 0);
   attn_glds16(base + (size_t)gr * pitch + ((slot ^ f) << 3), arr + p * 1024);
 }
 // the block's 8 waves load one stage (two arrays): wave w issues pieces w and w + 8
@@ -837,10 +854,13 @@ __global__ void __launch_bounds__(NWB * 64, QT == 1 ? 4 : 2) attn_fwd64_kernel(c
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
+  // var-len token layout (KR.row_base): sample b owns rows [rb, rb + SL) of the token-major buffers; padded layout: rb = b * S, SL = S
+  const int rb = KR.row_base ? KR.row_base[b] : b * S;
+  const int SL = KR.row_base ? KR.key_len[b] : S;
   const int q0 = blockIdx.x * QB + wave * (QT * 32);      // first query of this wave
   const int d = H * 64;
   const size_t pitch = (size_t)3 * d;
-  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
   const bf16_t* kb = qb + d;
   const bf16_t* vb = qb + 2 * d;
   int qlo[QT], qhi[QT];
@@ -851,7 +871,7 @@ __global__ void __launch_bounds__(NWB * 64, QT == 1 ? 4 : 2) attn_fwd64_kernel(c
     const int qrow = q0 + 32 * t + l31;
     qlo[t] = 0; qhi[t] = len - 1;
     if (PK) {
-      const bool v = qrow < S;
+      const bool v = qrow < SL;
       qlo[t] = v ? KR.lo[(size_t)b * S + qrow] : 0;
       qhi[t] = v ? KR.hi[(size_t)b * S + qrow] : -1;
       ulo = min(ulo, wave_imin(qhi[t] >= qlo[t] ? qlo[t] : S)); uhi = max(uhi, wave_imax(qhi[t] >= qlo[t] ? qhi[t] + 1 : 0) - 1);
@@ -860,7 +880,7 @@ __global__ void __launch_bounds__(NWB * 64, QT == 1 ? 4 : 2) attn_fwd64_kernel(c
   }
   if (!PK) { ulo = 0; uhi = len - 1; ilo = 0; ihi = len - 1; }
   const int klen = PK ? S : len;
-  const int q_end_blk = min(S, (int)(blockIdx.x + 1) * QB);
+  const int q_end_blk = min(SL, (int)(blockIdx.x + 1) * QB);
   int kbeg_blk = 0, kend_blk = causal ? min(klen, q_end_blk) : klen;
   // right padding: queries at or beyond the row's length are padding rows - nothing downstream reads their outputs and their
   // upstream gradient is zero - so a block (and below, a wave) made of them alone does no work and writes zeros
@@ -871,7 +891,7 @@ __global__ void __launch_bounds__(NWB * 64, QT == 1 ? 4 : 2) attn_fwd64_kernel(c
     kbeg_blk = min(max(blo, 0), S) & ~63;
     kend_blk = min(kend_blk, bhi + 1);
   }
-  const int kend = (q0 < S && (PK || q0 < len)) ? min(uhi + 1, causal ? q0 + QT * 32 : S) : 0;   // this wave's own key range
+  const int kend = (q0 < SL && (PK || q0 < len)) ? min(uhi + 1, causal ? q0 + QT * 32 : SL) : 0;   // this wave's own key range
 
   bf16x8_t qf[QT][4];
   f32x16_t o0[QT], o1[QT];
@@ -881,7 +901,7 @@ __global__ void __launch_bounds__(NWB * 64, QT == 1 ? 4 : 2) attn_fwd64_kernel(c
   for (int t = 0; t < QT; ++t) {
     const int qrow = q0 + 32 * t + l31;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[t][s] = frag_global(qb, qrow, S, pitch, s, lane);
+    for (int s = 0; s < 4; ++s) qf[t][s] = frag_global(qb, qrow, SL, pitch, s, lane);
     o0[t] = zero16(); o1[t] = zero16();
     m[t] = -INFINITY; l[t] = 0.f;
     dbase[t] = drop_base(D, b * H + h, qrow, 0);
@@ -891,8 +911,8 @@ __global__ void __launch_bounds__(NWB * 64, QT == 1 ? 4 : 2) attn_fwd64_kernel(c
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int pc = wave * PPW + i;   // 0..15
-      if (pc < 8) stage_piece(st[buf], kb, pitch, r0, S, pc, lane);
-      else stage_piece(st[buf] + 8192, vb, pitch, r0, S, pc - 8, lane);
+      if (pc < 8) stage_piece(st[buf], kb, pitch, r0, SL, pc, lane);
+      else stage_piece(st[buf] + 8192, vb, pitch, r0, SL, pc - 8, lane);
     }
   };
   const int nst = kend_blk > kbeg_blk ? (kend_blk - kbeg_blk + 63) >> 6 : 0;
@@ -919,7 +939,7 @@ __global__ void __launch_bounds__(NWB * 64, QT == 1 ? 4 : 2) attn_fwd64_kernel(c
 #pragma unroll
         for (int t2 = 0; t2 < QT; ++t2) sc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t2][s], sc[t2], 0, 0, 0);
       }
-      const bool edge = (k0 < ilo) || (k0 + 31 > ihi) || (causal && k0 + 31 > q0) || (q0 + QT * 32 > S);
+      const bool edge = (k0 < ilo) || (k0 + 31 > ihi) || (causal && k0 + 31 > q0) || (q0 + QT * 32 > SL);
       bf16x8_t pb[QT][2];
 #pragma unroll
       for (int t2 = 0; t2 < QT; ++t2) {
@@ -1001,9 +1021,9 @@ __global__ void __launch_bounds__(NWB * 64, QT == 1 ? 4 : 2) attn_fwd64_kernel(c
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const int qrow = q0 + 32 * t + l31;
-    if (qrow < S) {
+    if (qrow < SL) {
       const float inv = l[t] > 0.f ? D.inv_keep / l[t] : 0.f;   // (D.inv_keep = 1 without dropout)
-      store_t(out + ((size_t)b * S + qrow) * d + h * 64, o0[t], o1[t], inv, hi);
+      store_t(out + ((size_t)rb + qrow) * d + h * 64, o0[t], o1[t], inv, hi);
       if (hi == 0 && lse) lse[((size_t)b * H + h) * S + qrow] = l[t] > 0.f ? (m[t] + log2f(l[t])) * (1.0f / kLog2e) : 0.f;
     }
   }
@@ -1025,17 +1045,20 @@ __global__ void __launch_bounds__(NWB * 64, QT == 1 ? 4 : 2) attn_fwd64_kernel(c
 template <bool DROP, int NWB>
 __global__ void __launch_bounds__(NWB * 64, NWB == 8 ? 4 : 3) attn_fwd_dense_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
                                                                                     bf16_t* __restrict__ out, float* __restrict__ lse, int B, int S,
-                                                                                    int H, Drop D) {
+                                                                                    int H, Drop D, const int32_t* __restrict__ row_base) {
   __shared__ __attribute__((aligned(16))) unsigned char kr[3][8192];
   __shared__ __attribute__((aligned(16))) unsigned char vr[3][8192];
   constexpr int QB = NWB * 32;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
+  // var-len token layout (row_base): sample b owns rows [rb, rb + SL) of the token-major buffers; padded layout: rb = b * S, SL = S
+  const int rb = row_base ? row_base[b] : b * S;
+  const int SL = row_base ? key_len[b] : S;
   const int q0 = blockIdx.x * QB + wave * 32;
   const int d = H * 64;
   const size_t pitch = (size_t)3 * d;
-  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
   const bf16_t* kb = qb + d;
   const bf16_t* vb = qb + 2 * d;
   const int qrow = q0 + l31;
@@ -1051,7 +1074,7 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 8 ? 4 : 3) attn_fwd_dense_ker
 
   bf16x8_t qf[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = frag_global(qb, qrow, S, pitch, s, lane);
+  for (int s = 0; s < 4; ++s) qf[s] = frag_global(qb, qrow, SL, pitch, s, lane);
   f32x16_t o0 = zero16(), o1 = zero16();
   float m = -INFINITY, l = 0.f;
   const unsigned dbase = drop_base(D, b * H + h, qrow, 0);
@@ -1061,8 +1084,8 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 8 ? 4 : 3) attn_fwd_dense_ker
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int pc = wave * PPW + i;
-      if (pc < 8) { if (t + 2 < nst) stage_piece(kdst, kb, pitch, (t + 2) * 64, S, pc, lane); }
-      else { if (t + 1 < nst) stage_piece(vdst, vb, pitch, (t + 1) * 64, S, pc - 8, lane); }
+      if (pc < 8) { if (t + 2 < nst) stage_piece(kdst, kb, pitch, (t + 2) * 64, SL, pc, lane); }
+      else { if (t + 1 < nst) stage_piece(vdst, vb, pitch, (t + 1) * 64, SL, pc - 8, lane); }
     }
   };
   auto qk = [&](const unsigned char* kt, f32x16_t& sc) {
@@ -1207,9 +1230,9 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 8 ? 4 : 3) attn_fwd_dense_ker
     for (int i = 0; i < PPW; ++i) {
       const int pc = wave * PPW + i;
       if (pc < 8) {
-        stage_piece(kr[0], kb, pitch, 0, S, pc, lane);
-        if (nst > 1) stage_piece(kr[1], kb, pitch, 64, S, pc, lane);
-      } else stage_piece(vr[0], vb, pitch, 0, S, pc - 8, lane);
+        stage_piece(kr[0], kb, pitch, 0, SL, pc, lane);
+        if (nst > 1) stage_piece(kr[1], kb, pitch, 64, SL, pc, lane);
+      } else stage_piece(vr[0], vb, pitch, 0, SL, pc - 8, lane);
     }
   }
   for (int i = tid; i < 512; i += NWB * 64) reinterpret_cast<uint4*>(vr[2])[i] = make_uint4(0, 0, 0, 0);
@@ -1254,9 +1277,9 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 8 ? 4 : 3) attn_fwd_dense_ker
     rescale(softmax_seq(32 * jt + 32, true, sB, pB));
     pv(vr[nfs % 3] + 4096, pB);
   }
-  if (qrow < S) {
+  if (qrow < SL) {
     const float inv = l > 0.f ? D.inv_keep / l : 0.f;
-    store_t(out + ((size_t)b * S + qrow) * d + h * 64, o0, o1, inv, hi);
+    store_t(out + ((size_t)rb + qrow) * d + h * 64, o0, o1, inv, hi);
     if (hi == 0 && lse) lse[((size_t)b * H + h) * S + qrow] = l > 0.f ? (m + log2f(l)) * (1.0f / kLog2e) : 0.f;
   }
 }
@@ -1273,26 +1296,29 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 4) attn_bwd_dq64_kern
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
+  // var-len token layout (KR.row_base): sample b owns rows [rb, rb + SL) of the token-major buffers; padded layout: rb = b * S, SL = S
+  const int rb = KR.row_base ? KR.row_base[b] : b * S;
+  const int SL = KR.row_base ? KR.key_len[b] : S;
   const int q0 = blockIdx.x * QB + wave * 32;
   const int d = H * 64;
   const size_t pitch = (size_t)3 * d;
-  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
   const bf16_t* kb = qb + d;
   const bf16_t* vb = qb + 2 * d;
-  const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
+  const bf16_t* dob = dout + (size_t)rb * d + h * 64;
   const int qrow = q0 + l31;
   const int len = KR.key_len ? KR.key_len[b] : S;
   int qlo = 0, qhi = len - 1;
   int ulo = 0, uhi = qhi, ilo = 0, ihi = qhi;
   if (PK) {
-    const bool v = qrow < S;
+    const bool v = qrow < SL;
     qlo = v ? KR.lo[(size_t)b * S + qrow] : 0;
     qhi = v ? KR.hi[(size_t)b * S + qrow] : -1;
     ulo = wave_imin(qhi >= qlo ? qlo : S); uhi = wave_imax(qhi >= qlo ? qhi + 1 : 0) - 1;
     ilo = wave_imax(v ? qlo : 0); ihi = wave_imin(v ? qhi + 1 : S) - 1;
   }
   const int klen = PK ? S : len;
-  const int q_end_blk = min(S, (int)(blockIdx.x + 1) * QB);
+  const int q_end_blk = min(SL, (int)(blockIdx.x + 1) * QB);
   int kbeg_blk = 0, kend_blk = causal ? min(klen, q_end_blk) : klen;
   // right padding: queries at or beyond the row's length are padding rows - nothing downstream reads their outputs and their
   // upstream gradient is zero - so a block (and below, a wave) made of them alone does no work and writes zeros
@@ -1303,29 +1329,29 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 4) attn_bwd_dq64_kern
     kbeg_blk = min(max(blo, 0), S) & ~63;
     kend_blk = min(kend_blk, bhi + 1);
   }
-  const int kend = (q0 < S && (PK || q0 < len)) ? min(uhi + 1, causal ? q0 + 32 : S) : 0;
+  const int kend = (q0 < SL && (PK || q0 < len)) ? min(uhi + 1, causal ? q0 + 32 : SL) : 0;
 
   bf16x8_t qf[4], dof[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    qf[s] = frag_global(qb, qrow, S, pitch, s, lane);
-    dof[s] = frag_global(dob, qrow, S, (size_t)d, s, lane);
+    qf[s] = frag_global(qb, qrow, SL, pitch, s, lane);
+    dof[s] = frag_global(dob, qrow, SL, (size_t)d, s, lane);
   }
   const size_t sidx = ((size_t)b * H + h) * S + min(qrow, S - 1);
   float dl = 0.f;   // delta_q = rowsum(dO * O): the softmax-backward row term, stored for the dK/dV kernel
   {
-    const bf16_t* ob = out + (size_t)b * S * d + h * 64;
+    const bf16_t* ob = out + (size_t)rb * d + h * 64;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       float a[8], gg[8];
-      unpack8(__builtin_bit_cast(uint4, frag_global(ob, qrow, S, (size_t)d, s, lane)), a);
+      unpack8(__builtin_bit_cast(uint4, frag_global(ob, qrow, SL, (size_t)d, s, lane)), a);
       unpack8(__builtin_bit_cast(uint4, dof[s]), gg);
 #pragma unroll
       for (int e = 0; e < 8; ++e) dl += a[e] * gg[e];
     }
     const hw_u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(dl), __float_as_uint(dl), false, false);
     dl = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    if (hi == 0 && qrow < S) delta[sidx] = dl;
+    if (hi == 0 && qrow < SL) delta[sidx] = dl;
   }
   const float nlse2 = -lse[sidx] * kLog2e;
   const float ndl_k = -dl * kScale;                        // ds = p * (dp * keep * scale - delta * scale)
@@ -1337,8 +1363,8 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 4) attn_bwd_dq64_kern
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int pc = wave * PPW + i;
-      if (pc < 8) stage_piece(st[buf], kb, pitch, r0, S, pc, lane);
-      else stage_piece(st[buf] + 8192, vb, pitch, r0, S, pc - 8, lane);
+      if (pc < 8) stage_piece(st[buf], kb, pitch, r0, SL, pc, lane);
+      else stage_piece(st[buf] + 8192, vb, pitch, r0, SL, pc - 8, lane);
     }
   };
   const int nst = kend_blk > kbeg_blk ? (kend_blk - kbeg_blk + 63) >> 6 : 0;
@@ -1371,7 +1397,7 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 4) attn_bwd_dq64_kern
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      const bool edge = (k0 < ilo) || (k0 + 31 > ihi) || (causal && k0 + 31 > q0) || (q0 + 32 > S);
+      const bool edge = (k0 < ilo) || (k0 + 31 > ihi) || (causal && k0 + 31 > q0) || (q0 + 32 > SL);
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[r] = fast_exp2(fmaf(sc[r], kScaleL2, nlse2));      // P (un-dropped)
       if (edge) {
@@ -1380,7 +1406,7 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 4) attn_bwd_dq64_kern
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = k0v + acc_row(r, hi);
-          sc[r] = (key >= qlo && key <= qhi && (!causal || key <= qrow) && qrow < S) ? sc[r] : 0.f;
+          sc[r] = (key >= qlo && key <= qhi && (!causal || key <= qrow) && qrow < SL) ? sc[r] : 0.f;
         }
       }
       if (D.thresh == 0) {
@@ -1415,9 +1441,9 @@ __global__ void __launch_bounds__(NWB * 64, NWB == 4 ? 3 : 4) attn_bwd_dq64_kern
     stage(t, std::integral_constant<int, 0>{});
     if (t + 1 < nst) stage(t + 1, std::integral_constant<int, 1>{});
   }
-  if (qrow < S) {
+  if (qrow < SL) {
     unrope_acc(a0, a1, Rout, rope_pos(Rout, b, qrow), hi);     // q is stored rotated (engine layout): rotate dq back; no-op without tables
-    store_t(dqkv + ((size_t)b * S + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
+    store_t(dqkv + ((size_t)rb + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
   }
 }
 
@@ -1453,20 +1479,23 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
+  // var-len token layout (KR.row_base): sample b owns rows [rb, rb + SL) of the token-major buffers; padded layout: rb = b * S, SL = S
+  const int rb = KR.row_base ? KR.row_base[b] : b * S;
+  const int SL = KR.row_base ? KR.key_len[b] : S;
   const int k0 = blockIdx.x * KB + wave * 32;
   const int d = H * 64;
   const size_t pitch = (size_t)3 * d;
-  const bf16_t* qb = qkv + (size_t)b * S * pitch + h * 64;
+  const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
   const bf16_t* kb = qb + d;
   const bf16_t* vb = qb + 2 * d;
-  const bf16_t* dob = dout + (size_t)b * S * d + h * 64;
+  const bf16_t* dob = dout + (size_t)rb * d + h * 64;
   const int klen = PK ? S : (KR.key_len ? KR.key_len[b] : S);
   const int krow = k0 + l31;
   bf16x8_t kf[4], vf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    kf[s] = frag_global(kb, krow, S, pitch, s, lane);
-    vf[s] = frag_global(vb, krow, S, pitch, s, lane);
+    kf[s] = frag_global(kb, krow, SL, pitch, s, lane);
+    vf[s] = frag_global(vb, krow, SL, pitch, s, lane);
   }
   f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
   const unsigned dbase = drop_base(D, b * H + h, 0, (unsigned)krow >> 1);
@@ -1481,8 +1510,8 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int pc = wave * PPW + i;
-      if (pc < STG / 8) stage_piece(st[buf], qb, pitch, r0, S, pc, lane);
-      else stage_piece(st[buf] + ARR, dob, (size_t)d, r0, S, pc - STG / 8, lane);
+      if (pc < STG / 8) stage_piece(st[buf], qb, pitch, r0, SL, pc, lane);
+      else stage_piece(st[buf] + ARR, dob, (size_t)d, r0, SL, pc - STG / 8, lane);
     }
   };
   // the stage's per-query scalars: fetched by the first 64 threads one stage ahead (registers), written to LDS behind the compute
@@ -1494,7 +1523,7 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
       p_lse = lse[((size_t)b * H + h) * S + q];          // raw: the scaling waits for commit_vec (no wait for the load here)
       p_dl = delta[((size_t)b * H + h) * S + q];
       if (PK) {
-        const bool v = r0 + tid < S;
+        const bool v = r0 + tid < SL;
         p_lo = v ? KR.lo[(size_t)b * S + q] : 0;
         p_hi = v ? KR.hi[(size_t)b * S + q] : -1;
       }
@@ -1531,8 +1560,8 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
 #pragma unroll
     for (int j = 0; j < NTILE; ++j) {
       const int q0 = qs + 32 * j;
-      if (k0 >= klen || q0 >= S || (causal && q0 + 31 < k0)) continue;
-      bool edge = (k0 + 32 > klen) || (q0 + 32 > S) || (causal && k0 + 31 > q0);
+      if (k0 >= klen || q0 >= SL || (causal && q0 + 31 < k0)) continue;
+      bool edge = (k0 + 32 > klen) || (q0 + 32 > SL) || (causal && k0 + 31 > q0);
       if (PK) {
         const int lo = qlo_s[vb_][32 * j + l31], hi_ = qhi_s[vb_][32 * j + l31];
         const int ulo = wave_imin(hi_ >= lo ? lo : S), uhi = wave_imax(hi_ >= lo ? hi_ + 1 : 0) - 1;
@@ -1570,7 +1599,7 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
           const int qi = 32 * j + acc_row(r, hi);
           const int q = q0v + acc_row(r, hi);
           const bool in_range = PK ? (krow >= qlo_s[vb_][qi] && krow <= qhi_s[vb_][qi]) : key_ok;
-          sc[r] = (in_range && q < S && (!causal || krow <= q)) ? sc[r] : 0.f;
+          sc[r] = (in_range && q < SL && (!causal || krow <= q)) ? sc[r] : 0.f;
         }
       }
       if (D.thresh == 0) {
@@ -1604,8 +1633,8 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
     if (dma_due) { issue((t + 1) & 1, qs + STG); fetch_vec(qs + STG); }     // (both tiles of the stage skipped)
     if (t + 1 < nst) commit_vec((t + 1) & 1);
   }
-  if (krow < S) {
-    bf16_t* row = dqkv + ((size_t)b * S + krow) * pitch + h * 64;
+  if (krow < SL) {
+    bf16_t* row = dqkv + ((size_t)rb + krow) * pitch + h * 64;
     unrope_acc(dk0, dk1, Rout, rope_pos(Rout, b, krow), hi);
     store_t(row + d, dk0, dk1, 1.f, hi);
     store_t(row + 2 * d, dv0, dv1, 1.f, hi);
@@ -1627,8 +1656,9 @@ Drop make_drop(float p, unsigned seed) {
 
 int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
                const float* cos_tab, const float* sin_tab, const int64_t* position_ids, float dropout_p,
-               unsigned dropout_seed, hipStream_t st, const int32_t* key_lo, const int32_t* key_hi) {
-  const KeyRange KR{key_len, key_lo, key_hi};
+               unsigned dropout_seed, hipStream_t st, const int32_t* key_lo, const int32_t* key_hi, const int32_t* row_base) {
+  GGET_REQUIRE(!row_base || (key_len && !key_lo), "attention: the var-len token layout needs key_len and excludes per-token key ranges");
+  const KeyRange KR{key_len, key_lo, key_hi, row_base};
   if (B == 0 || S == 0) return 0;
   const Rope R{cos_tab, sin_tab, position_ids, S};
   const Drop D = make_drop(dropout_p, dropout_seed);
@@ -1641,9 +1671,9 @@ int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, i
                                           (bf16_t*)out, lse, B, S, H, causal, D)
     if (dense && !key_lo && !causal && S >= 512) {   // (shorter rows: the pipeline's fill and drain cost more than it hides)
       if (D.thresh) hipLaunchKernelGGL((attn_fwd_dense_kernel<true, 8>), dim3((S + 255) / 256, H, B), dim3(512), 0, st, (const bf16_t*)qkv, key_len,
-                                       (bf16_t*)out, lse, B, S, H, D);
+                                       (bf16_t*)out, lse, B, S, H, D, row_base);
       else hipLaunchKernelGGL((attn_fwd_dense_kernel<false, 8>), dim3((S + 255) / 256, H, B), dim3(512), 0, st, (const bf16_t*)qkv, key_len,
-                              (bf16_t*)out, lse, B, S, H, D);
+                              (bf16_t*)out, lse, B, S, H, D, row_base);
     } else if (key_lo) GGET_FWD64(true);
     else GGET_FWD64(false);   // (one query tile per wave at 4 waves / SIMD beat two tiles per wave at 2)
 #undef GGET_FWD64
@@ -1664,8 +1694,9 @@ int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, i
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
                const int64_t* position_ids, int qk_rotated, float dropout_p, unsigned dropout_seed, hipStream_t st,
-               const int32_t* key_lo, const int32_t* key_hi) {
-  const KeyRange KR{key_len, key_lo, key_hi};
+               const int32_t* key_lo, const int32_t* key_hi, const int32_t* row_base) {
+  GGET_REQUIRE(!row_base || (key_len && !key_lo), "attention: the var-len token layout needs key_len and excludes per-token key ranges");
+  const KeyRange KR{key_len, key_lo, key_hi, row_base};
   if (B == 0 || S == 0) return 0;
   const Rope R{cos_tab, sin_tab, position_ids, S};     // rotation of dq, dk back to the un-rotated projections
   const Rope Rin = qk_rotated ? Rope{nullptr, nullptr, nullptr, S} : R;   // q,k in memory are already rotated?
@@ -1674,7 +1705,7 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
   if (small < 0) { const char* e = getenv("GGET_ATTN_SMALL"); small = e ? atoi(e) : 1; }
   if (S <= 32 && !key_lo && small) {
     hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(1, H, B), dim3(64), 0, st, (const bf16_t*)qkv,
-                       (const bf16_t*)dout, lse, key_len, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D);
+                       (const bf16_t*)dout, lse, key_len, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D, row_base);
     GGET_LAUNCH_CHECK();
     return 0;
   }

@@ -30,7 +30,7 @@ void gget_set_error(const char* fmt, ...) {
 extern "C" const char* gget_last_error(void) { return g_err; }
 extern "C" int gget_version(void) { return 101; }
 
-struct PathDropArg { float rate; unsigned seed; int S; };
+struct PathDropArg { float rate; unsigned seed; int S; const int32_t* row_b; };   // row_b: sample index of every row (var-len token layout) or NULL (row / S)
 
 namespace {
 
@@ -182,6 +182,10 @@ struct Ws {
   uint64_t rr_cos, rr_sin, rr_ids;   // rope_range: per-token angle tables [T][32] fp32 and the identity position list [T] int64
   uint64_t tok_stat;   // token-level head: loss sum, labelled rows, 1 / rows
   uint64_t long_wgt;   // stack_method = "long": per-sample loss weights (fp32 [max_batch])
+  // var-len token layout: first compact row of every sample [max_batch + 1], per compact row its sample index / position / ids, the
+  // padded -> compact row map [max_tokens], a status word
+  uint64_t vl_cu, vl_rowb, vl_pos, vl_ids, vl_pad2c, vl_status;
+  uint64_t sk_ws;      // stream-K GEMM launches: flags + one fp32 partial tile per block (gemm.h)
   uint64_t head_x[6] = {0}, head_a[5] = {0}, head_d[2] = {0};   // MLP head: layer inputs / activations (bf16), fp32 gradient ping-pong
   uint64_t total;
 };
@@ -235,6 +239,13 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.segs = b.take((uint64_t)pl.params.size() * sizeof(GgetSegment));
   w.wg32 = b.take(kWgSplit * 4 * d * d * 4);   // split-K slabs of the q|k|v|o wgrad
   w.long_wgt = b.take((uint64_t)c.max_batch * 4);
+  w.vl_cu = b.take((Bm + 1) * 4);
+  w.vl_rowb = b.take(T * 4);
+  w.vl_pos = b.take(T * 8);
+  w.vl_ids = b.take(T * (uint64_t)c.stacked_feat * 8);
+  w.vl_pad2c = b.take(T * 4);
+  w.vl_status = b.take(256);
+  w.sk_ws = b.take(gget_gemm_streamk_bytes());
   if (c.embed_dim > 0) {
     const uint64_t e = c.embed_dim;
     w.raw_x = b.take(T * e * 2); w.raw_xn = b.take(T * e * 2); w.raw_rstd = b.take(T * 4);
@@ -325,7 +336,14 @@ struct gget_engine {
   std::vector<std::pair<uint64_t, uint64_t>> bucket_range;  // elements
   std::vector<std::pair<int, int>> bucket_segs;              // [first, count) into the device segment table
   // state of the last forward
-  int B = 0, S = 0, T = 0;
+  // T = rows of the token-major activation buffers: B * S (padded layout) or round_up(real tokens, 64) (var-len layout, see
+  // backbone_forward); TP = B * S always (the index space of ids / labels / the SMTP head's selections)
+  int B = 0, S = 0, T = 0, TP = 0;
+  bool varlen = false;            // the last forward ran on the compacted (padding-free) token layout
+  int tc = 0;                     // its number of real tokens
+  long tc_next = -1;              // real-token count of the NEXT forward's batch (gget_set_token_count); < 0 = unknown -> padded layout
+  const int64_t* pos_rows = nullptr;   // position of every ROW (GEMM RoPE epilogue): pos_cur, or the compacted positions
+  const int32_t* row_base() const { return varlen ? wsp<int32_t>(ws.vl_cu) : nullptr; }
   const int64_t* ids = nullptr;
   const int64_t* pos = nullptr;
   const float* sample_wgt = nullptr;
@@ -369,7 +387,7 @@ struct gget_engine {
   PathDropArg path_drop(int layer, int which) const {
     const int L = cfg.num_layers;
     const float rate = (path_drop_p > 0.f && L > 1) ? path_drop_p * (float)layer / (float)(L - 1) : 0.f;
-    return PathDropArg{rate, attn_drop_seed ^ (0xD6E8FEB8u * (unsigned)(layer * 2 + which + 1)), S};
+    return PathDropArg{rate, attn_drop_seed ^ (0xD6E8FEB8u * (unsigned)(layer * 2 + which + 1)), S, varlen ? wsp<int32_t>(ws.vl_rowb) : nullptr};
   }
   bf16_t* dx_cur = nullptr;  // gradient w.r.t. the residual stream entering the next backward stage
   bool packed = false;       // last forward used a 3-D block-diagonal attention mask (per-token key ranges)
@@ -390,6 +408,13 @@ struct gget_engine {
     if (layer < 0) return L + 1;
     return L - layer;
   }
+};
+
+// the engine's GEMM launches may run stream-K through the handle's workspace slice (zeroed at creation); op-level calls of the same
+// thread afterwards must not see it
+struct StreamKScope {
+  explicit StreamKScope(gget_engine* h) { gget_gemm_streamk_workspace(h->W + h->ws.sk_ws); }
+  ~StreamKScope() { gget_gemm_streamk_workspace(nullptr); }
 };
 
 // ================================================================================================
@@ -562,6 +587,24 @@ extern "C" int gget_set_auc(gget_handle_t h, int num_neg, uint32_t seed) {
   return 0;
 }
 
+extern "C" int gget_set_token_count(gget_handle_t h, int64_t n_real_tokens) {
+  GGET_REQUIRE(h != nullptr, "null handle");
+  h->tc_next = n_real_tokens > 0 ? (long)n_real_tokens : -1;
+  return 0;
+}
+
+extern "C" int gget_varlen_status(gget_handle_t h, int32_t out[3], void* stream) {
+  GGET_REQUIRE(h && out, "null argument");
+  out[0] = h->varlen ? 1 : 0;
+  out[1] = h->T;
+  out[2] = 0;
+  if (h->varlen) {
+    GGET_HIP_CHECK(hipMemcpyAsync(&out[2], h->wsp<int32_t>(h->ws.vl_status), 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GGET_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  }
+  return 0;
+}
+
 extern "C" int gget_set_dropout(gget_handle_t h, float attention_p, float path_p, uint32_t seed) {
   GGET_REQUIRE(h, "null handle");
   GGET_REQUIRE(attention_p >= 0.f && attention_p < 1.f && path_p >= 0.f && path_p < 1.f, "dropout probability out of range");
@@ -635,7 +678,7 @@ int down_dgrad_geglu(const bf16_t* dy, const bf16_t* wdown, const bf16_t* gu, bf
 typedef PathDropArg PathDrop;
 __device__ __forceinline__ float path_keep(const PathDrop& D, long t) {
   if (D.rate <= 0.f) return 1.f;
-  unsigned x = D.seed + (unsigned)(t / D.S) * 0x85EBCA77u;
+  unsigned x = D.seed + (unsigned)(D.row_b ? D.row_b[t] : t / D.S) * 0x85EBCA77u;
   x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
   return (float)(x >> 8) * (1.0f / 16777216.0f) < D.rate ? 0.f : 1.0f / (1.0f - D.rate);
 }
@@ -942,12 +985,12 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
     GemmProblem& p = g.p[0];
     p.A = xn1; p.B = h->P + lo.wqkv; p.C = qkv;
     p.M = T; p.N = 3 * d; p.K = d; p.lda = d; p.ldb = d; p.ldc = 3 * d;
-    p.rope_cos = h->cos_cur; p.rope_sin = h->sin_cur; p.rope_pos = h->pos_cur; p.rope_S = h->S; p.rope_cols = 2 * d;
+    p.rope_cos = h->cos_cur; p.rope_sin = h->sin_cur; p.rope_pos = h->pos_rows; p.rope_S = h->S; p.rope_cols = 2 * d;
     if (int e = gget_gemm_launch(GGET_GEMM_NT, GGET_EPI_ROPE, g, 1, st)) return e;
   }
   if (int e = k_attn_fwd(qkv, h->wsp<int32_t>(h->ws.key_len), attn, h->wsp<float>(lw.lse), h->B, h->S, H, c.causal,
                          nullptr, nullptr, nullptr, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st, h->klo(),
-                         h->khi()))
+                         h->khi(), h->row_base()))
     return e;
   if (h->plan.has_res) {
     bf16_t* araw = h->wsp<bf16_t>(lw.araw);
@@ -992,16 +1035,39 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
   return 0;
 }
 
+bool varlen_enabled() {
+  static const int off = getenv("GGET_NO_VARLEN") != nullptr;
+  return !off;
+}
 int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t* mask, const int64_t* pos, int B, int S,
-                     hipStream_t st, bool mask_is_3d = false, const int64_t* labels = nullptr) {
+                     hipStream_t st, bool mask_is_3d = false, const int64_t* labels = nullptr, bool allow_varlen = true) {
   const gget_config_t& c = h->cfg;
   GGET_REQUIRE(B > 0 && S > 0, "empty batch");
   GGET_REQUIRE((long)B * S <= c.max_tokens && B <= c.max_batch, "batch %dx%d exceeds capacity (%d tokens, %d rows)", B, S,
                c.max_tokens, c.max_batch);
   GGET_REQUIRE(S <= c.max_position, "sequence length %d exceeds max_position %d", S, c.max_position);
-  h->B = B; h->S = S; h->T = B * S;
+  h->B = B; h->S = S; h->T = h->TP = B * S;
   h->ids = ids; h->pos = pos;
   h->cos_cur = h->cos_tab; h->sin_cur = h->sin_tab; h->pos_cur = pos;
+  // Var-len (padding-free) token layout: when the caller told us how many real tokens the right-padded batch holds
+  // (gget_set_token_count: the host knows sum(attention_mask) from its collator, the device would need a sync), the real tokens are
+  // compacted sample after sample and every token-wise kernel and GEMM of the layer stack runs on round_up(real, 64) rows instead of
+  // B * S (PCQM4M-v2 batches are ~30 % padding, ogbl-ppa ~37 %).  Logical [B,S] quantities (labels, lse, dropout coordinates, loss
+  // normalisers) are unchanged.  Not taken where a kernel's random stream or an output is indexed by the padded row: element dropouts,
+  // raw-embedding inputs, rope_range tables, the token-level head; packed rows carry no padding to begin with.
+  const long tc_hint = h->tc_next;
+  h->tc_next = -1;
+  h->varlen = false;
+  h->tc = B * S;
+  {
+    const long t_rows = (tc_hint + 63) / 64 * 64;
+    if (allow_varlen && varlen_enabled() && tc_hint > 0 && !mask_is_3d && mask != nullptr && c.embed_dim == 0 && h->embed_drop_p == 0.f &&
+        h->mlp_drop_p == 0.f && !(h->rope_range > 0.f && pos) && t_rows < (long)B * S) {
+      h->varlen = true;
+      h->tc = (int)tc_hint;
+      h->T = (int)t_rows;
+    }
+  }
   if (h->rope_range > 0.f && pos) {
     if (int e = k_rope_range_table(pos, h->wsp<float>(h->ws.rr_cos), h->wsp<float>(h->ws.rr_sin), h->wsp<int64_t>(h->ws.rr_ids), B, S,
                                    h->rope_range, c.rope_theta > 0.f ? c.rope_theta : 10000.0f, st))
@@ -1017,6 +1083,18 @@ int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t*
                                h->wsp<int32_t>(h->ws.key_len),
                                c.kind == GGET_KIND_TASK ? h->wsp<int32_t>(h->ws.pool_row) : nullptr, B, S, st)) {
     return e;
+  }
+  h->pos_rows = h->pos_cur;
+  if (h->varlen) {
+    const Ws& w = h->ws;
+    if (int e = k_varlen_plan(ids, ldF, c.stacked_feat, pos, h->wsp<int32_t>(w.key_len),
+                              c.kind == GGET_KIND_TASK ? h->wsp<int32_t>(w.pool_row) : nullptr, h->wsp<int32_t>(w.vl_cu),
+                              h->wsp<int64_t>(w.vl_ids), h->wsp<int64_t>(w.vl_pos), h->wsp<int32_t>(w.vl_rowb), h->wsp<int32_t>(w.vl_pad2c),
+                              h->wsp<int32_t>(w.vl_status), B, S, h->tc, h->T, c.pad_token_id, st))
+      return e;
+    h->ids = ids = h->wsp<int64_t>(w.vl_ids);
+    ldF = c.stacked_feat;
+    h->pos_rows = h->wsp<int64_t>(w.vl_pos);
   }
   if (int e = k_embed_fwd(ids, h->P + h->plan.emb, h->plan.has_gate ? h->P + h->plan.gate : nullptr,
                           h->wsp<bf16_t>(h->ws.xres[0]), h->T, c.stacked_feat, ldF, d, st, h->embed_drop()))
@@ -1059,17 +1137,20 @@ static int forward_pretrain_impl(gget_handle_t h, const int64_t* input_ids_dev, 
   GGET_REQUIRE(h->cfg.kind == GGET_KIND_PRETRAIN, "handle was not created as a pre-train model");
   hipStream_t st = (hipStream_t)stream;
   const gget_config_t& c = h->cfg;
+  StreamKScope sk_scope(h);
   h->fwd_valid = false;
   if (int e = backbone_forward(h, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st, mask_is_3d, labels_dev))
     return e;
   const Ws& w = h->ws;
-  const int T = h->T, d = c.hidden_size, n = c.next_n_token, V = c.vocab_size;
+  const int T = h->TP, d = c.hidden_size, n = c.next_n_token, V = c.vocab_size;   // (capacities of the head: the padded token space)
   const int Vp = (int)align_up(V, 64);
   int32_t* counts = h->wsp<int32_t>(w.counts);
   if (int e = k_head_compact(labels_dev, T, n, h->wsp<int32_t>(w.cnt), h->wsp<int32_t>(w.m_off), h->wsp<int32_t>(w.l_off),
                              counts, h->wsp<int32_t>(w.row_idx), h->wsp<int32_t>(w.sel_src), h->wsp<int32_t>(w.sel_label),
                              h->wsp<int32_t>(w.sel_tok), st))
     return e;
+  if (h->varlen)   // the selected rows live at their compact positions (sel_tok / sel_label keep the padded coordinates the loss weights need)
+    if (int e = k_remap_rows(h->wsp<int32_t>(w.row_idx), counts, h->wsp<int32_t>(w.vl_pad2c), T, st)) return e;
   if (int e = k_gather_rows(h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.row_idx), counts, h->wsp<bf16_t>(w.Hm), T, d, 0, st))
     return e;
   if (h->plan.has_ntp) {
@@ -1124,8 +1205,11 @@ extern "C" int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, 
   GGET_REQUIRE(h->cfg.kind == GGET_KIND_TASK, "handle was not created as a task model");
   hipStream_t st = (hipStream_t)stream;
   const gget_config_t& c = h->cfg;
+  StreamKScope sk_scope(h);
   h->fwd_valid = false;
-  if (int e = backbone_forward(h, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st)) return e;
+  if (int e = backbone_forward(h, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st, false, nullptr,
+                               /*allow_varlen=*/problem_type != GGET_PROBLEM_TOKEN_CE))
+    return e;
   const Ws& w = h->ws;
   const int d = c.hidden_size, C = c.num_labels;
   float* lg = h->wsp<float>(w.tlogits);
@@ -1252,7 +1336,7 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   if (int e = k_attn_bwd(h->wsp<bf16_t>(lw.qkv), h->wsp<bf16_t>(lw.attn), dattn, h->wsp<float>(lw.lse),
                          h->wsp<int32_t>(w.key_len), dqkv, h->wsp<float>(w.delta), h->B, h->S, H, c.causal, h->cos_cur,
                          h->sin_cur, h->pos_cur, /*qk_rotated=*/1, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st,
-                         h->klo(), h->khi()))
+                         h->klo(), h->khi(), h->row_base()))
     return e;
   if (int e = gemm_nn(dqkv, h->P + lo.wqkv, dxn, T, d, 3 * d, 3 * d, d, d, nullptr, st)) return e;
   // (fused with the LayerScale backward of the layer below, this RMSNorm backward writes w.dscaled - which this layer's down_proj weight
@@ -1318,14 +1402,19 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
   GGET_REQUIRE(h, "null handle");
   GGET_REQUIRE(h->fwd_valid && h->have_labels, "backward needs a preceding forward with labels");
   GGET_REQUIRE(loss_scale == 1.0f, "loss scaling is not used on the bf16 path (pass 1.0)");
+  StreamKScope sk_scope(h);
   hipStream_t st = (hipStream_t)stream;
   const gget_config_t& c = h->cfg;
   const Ws& w = h->ws;
-  const int T = h->T, d = c.hidden_size;
+  const int d = c.hidden_size;
   float* s32 = h->wsp<float>(w.scratch32);
   GGET_HIP_CHECK(hipMemsetAsync(s32, 0, h->plan.n_scratch32 * 4, st));
   bf16_t* dhid = h->wsp<bf16_t>(w.dxb);  // gradient w.r.t. the final-norm output
-  GGET_HIP_CHECK(hipMemsetAsync(dhid, 0, (size_t)T * d * 2, st));
+  GGET_HIP_CHECK(hipMemsetAsync(dhid, 0, (size_t)h->T * d * 2, st));
+  if (h->varlen && h->T > h->tc)   // var-len layout: the <= 63 pad rows behind the last sample belong to no attention problem - their
+    // q|k|v gradient rows are written by nobody and must read as zeros in the weight gradients (K = T) and the dgrad below them
+    GGET_HIP_CHECK(hipMemsetAsync(h->wsp<bf16_t>(w.dqkv) + (size_t)h->tc * 3 * d, 0, (size_t)(h->T - h->tc) * 3 * d * 2, st));
+  int T = h->TP;   // the head works in the padded token index space (capacities only: the counts are on the device)
   if (c.kind == GGET_KIND_PRETRAIN) {
     const int n = c.next_n_token, V = c.vocab_size, Vp = (int)align_up(V, 64);
     int32_t* counts = h->wsp<int32_t>(w.counts);
@@ -1379,6 +1468,7 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
   }
   bf16_t* dx = h->wsp<bf16_t>(w.dxa);
   h->ls2_done = false;
+  T = h->T;   // from here on: rows of the token-major buffers
   if (h->plan.has_res && ls_norm_fused()) {     // ... fused with the LayerScale backward of the last layer (layer_backward)
     const int li = c.num_layers - 1;
     const LayerOff& lp = h->plan.layers[li];
@@ -1398,6 +1488,7 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
 extern "C" int gget_backward_layer(gget_handle_t h, int layer, void* stream) {
   GGET_REQUIRE(h && h->fwd_valid && h->dx_cur, "backward_layer before backward_begin");
   GGET_REQUIRE(layer >= 0 && layer < h->cfg.num_layers, "layer %d out of range", layer);
+  StreamKScope sk_scope(h);
   return layer_backward(h, layer, (hipStream_t)stream);
 }
 
@@ -1429,6 +1520,7 @@ int embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* g
 
 extern "C" int gget_backward_end(gget_handle_t h, void* stream) {
   GGET_REQUIRE(h && h->fwd_valid && h->dx_cur, "backward_end before backward_begin");
+  StreamKScope sk_scope(h);
   hipStream_t st = (hipStream_t)stream;
   const gget_config_t& c = h->cfg;
   float* s32 = h->wsp<float>(h->ws.scratch32);
@@ -1508,6 +1600,7 @@ extern "C" int gget_head_logits(gget_handle_t h, const void** logits_dev, int32_
 
 extern "C" int gget_hidden_states(gget_handle_t h, const void** hidden_dev) {
   GGET_REQUIRE(h && hidden_dev, "null argument");
+  GGET_REQUIRE(!h->varlen, "hidden_states: the last forward ran on the var-len token layout (rows are compacted); run it without a token count");
   *hidden_dev = h->wsp<bf16_t>(h->ws.hidden);
   return 0;
 }
@@ -1545,6 +1638,7 @@ extern "C" int gget_debug_occupy(void* scratch, uint64_t scratch_bytes, int bloc
 
 extern int g_gemm_variant;
 extern int g_gemm_lds_headroom;
+extern int g_gemm_split_last;
 extern "C" int gget_debug_probe(gget_handle_t h, int enable, float* avg_ms_out /* [2] or NULL */) {
   GGET_REQUIRE(h != nullptr, "null handle");
   if (avg_ms_out) {   // mean launch duration over the layers of the last forward / backward that ran with the probe on
@@ -1568,6 +1662,7 @@ extern "C" int gget_debug_set(int key, int value) {
   switch (key) {
     case 1: g_gemm_variant = value; return 0;
     case 2: g_gemm_lds_headroom = value; return 0;
+    case 3: g_gemm_split_last = value; return 0;
   }
   gget_set_error("debug_set: unknown key %d", key);
   return 2;
@@ -1576,6 +1671,15 @@ extern "C" int gget_op_gemm(int mode, int epilogue, const void* A, const void* B
                             int lda, int ldb, int ldc, int split_k, void* stream) {
   return gget_gemm_single(mode, epilogue, A, B, C, R, M, N, K, lda, ldb, ldc, nullptr, nullptr, split_k, (hipStream_t)stream);
 }
+extern "C" int gget_op_gemm_streamk(int mode, int epilogue, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
+                                    int lda, int ldb, int ldc, void* streamk_ws, void* stream) {
+  GGET_REQUIRE(streamk_ws != nullptr, "gemm_streamk: null workspace");
+  gget_gemm_streamk_workspace(streamk_ws);
+  const int rc = gget_gemm_single(mode, epilogue, A, B, C, R, M, N, K, lda, ldb, ldc, nullptr, nullptr, 1, (hipStream_t)stream);
+  gget_gemm_streamk_workspace(nullptr);
+  return rc;
+}
+extern "C" uint64_t gget_op_gemm_streamk_bytes(void) { return gget_gemm_streamk_bytes(); }
 extern "C" int gget_op_gemm_grouped(int mode, int count, const void* const* A, const void* const* B, void* const* Cs, const int* M,
                                    const int* N, const int* K, const int* lda, const int* ldb, const int* ldc, void* stream) {
   GGET_REQUIRE(count >= 1 && count <= GGET_MAX_GROUP && A && B && Cs && M && N && K && lda && ldb && ldc, "gemm_grouped: bad arguments");

@@ -36,7 +36,23 @@ struct GemmGroup {
   int count;
   int super;   // row panels per L2 super-tile (tile order)
   int ablate;  // diagnostics (env GGET_GEMM_ABLATE): bit0 skip LDS-DMA, bit1 skip MFMA, bit2 skip the C store
+  // stream-K launches (filled by the launcher from the workspace registered with gget_gemm_streamk_workspace): one fp32 tile slot and
+  // one flag word per block, the epoch that marks this launch's flags
+  float* sk_partial;
+  unsigned* sk_flags;
+  unsigned sk_epoch;
+  int sk_rounds, sk_rem, sk_parts, sk_a;   // full rounds, tiles of the last round, K parts per tile (1: owners + helpers), owner K-tiles
 };
+
+// Split-K of the last round (gemm.hip: gemm_persist_kernel<..., SK = true>): launches whose tile count is no multiple of the CU count
+// split the K range of the last round's tiles among the otherwise idle blocks; the blocks exchange fp32 partial tiles through this workspace.  `ws` = device memory,
+// zero-initialised once by the caller, >= gget_gemm_streamk_bytes(); the launcher of the calling thread uses it until it is replaced
+// (nullptr: stream-K off).  Launches that share a workspace must be ordered on one stream.
+constexpr size_t kStreamKBlocks = 512;                                  // >= CUs
+constexpr size_t kStreamKSlotBytes = (size_t)128 * 192 * 4;             // the largest tile that runs stream-K
+constexpr size_t kStreamKFlagBytes = (kStreamKBlocks + 64) * sizeof(unsigned);
+inline size_t gget_gemm_streamk_bytes() { return kStreamKFlagBytes + kStreamKBlocks * kStreamKSlotBytes; }
+void gget_gemm_streamk_workspace(void* ws);
 
 // mode: GGET_GEMM_NT/NN/TN, epi: GGET_EPI_*; problems of one group share mode and epilogue.
 int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t st);

@@ -36,6 +36,9 @@
 
 int g_gemm_lds_headroom = 1;   // 1 (default): the 128x192 tile kernels run a 3-slot ring and leave 40 KiB of LDS free, 0: 4 slots = all 160 KiB
                                // (gget_debug_set key 2, env GGET_GEMM_LDS_HEADROOM; measured in profiles/r02_coresidency.txt)
+int g_gemm_split_last = 0;   // split the K range of the last, partial round's tiles among the idle blocks (gget_debug_set key 3, env
+                            // GGET_GEMM_SPLIT_LAST).  Off by default: on the C1 shapes the hand-over of the partial tiles costs more than the
+                            // shorter last round returns (profiles/r03_gemm_varlen_shapes.txt); correct and tested (tests/test_gpu_ops.py)
 int g_gemm_variant = 0;   // measurement knob (gget_debug_set key 1): selects experimental kernel variants for in-process A/B timing
 
 namespace {
@@ -106,8 +109,12 @@ struct TileIO {
   static constexpr int ROWB = ROWS * 2;         // bytes per k-row of an M/N-contiguous tile
   static constexpr int CPR = ROWS / 8;          // chunks per k-row of an M/N-contiguous tile
   static constexpr int NPIECE = ROWS * BK * 2 / 1024;
-  static constexpr int PIECES = NPIECE / NWAVES;  // LDS-DMA instructions per wave per tile
-  static_assert(CHUNKS % NTHREADS == 0 && NPIECE % NWAVES == 0, "tile/thread shape");
+  // LDS-DMA instructions per wave per tile.  A piece count that is no multiple of the wave count (96-row tiles: 12 pieces, 8 waves)
+  // is rounded up and the surplus slots fetch pieces 0.. a second time (same data to the same LDS bytes): every wave then issues the
+  // same number of instructions, which is what the counted vmcnt waits need; the DMA is not what bounds these tiles.
+  static constexpr int PIECES = (NPIECE + NWAVES - 1) / NWAVES;
+  static constexpr bool WRAP = NPIECE % NWAVES != 0;
+  static_assert(ROWS * BK * 2 % 1024 == 0, "tile/thread shape");
   static_assert(!MC || ROWS == 128 || ROWS == 192 || ROWS == 256, "M/N-contiguous tile widths");
   static constexpr int NWIN = ROWS / 16;        // 32-byte windows per k-row of an M/N-contiguous tile
 
@@ -139,6 +146,7 @@ struct TileIO {
   }
   __device__ __forceinline__ static void glds_piece(unsigned char* lds, const bf16_t* __restrict__ base, int ld, int row0,
                                                     int row_lim, int k0, int wave, int lane, int i) {
+    static_assert(!WRAP, "wrapped piece lists are issued by the K-split kernel only");
     {
       const int q = wave + i * NWAVES;
       const bf16_t* p;
@@ -161,8 +169,12 @@ struct TileIO {
   }
   // The same DMA split into a per-tile part (the lane's byte offset from the K-origin of the operand, < 4 GiB) and a
   // per-K-tile part (the uniform K-origin): the persistent kernel computes the offsets once per output tile.
-  __device__ __forceinline__ static unsigned piece_off(int ld, int row0, int row_lim, int wave, int lane, int i) {
+  __device__ __forceinline__ static int piece_index(int wave, int i) {
     const int q = wave + i * NWAVES;
+    return WRAP && q >= NPIECE ? q - NPIECE : q;
+  }
+  __device__ __forceinline__ static unsigned piece_off(int ld, int row0, int row_lim, int wave, int lane, int i) {
+    const int q = piece_index(wave, i);
     if (!MC) {
       const int r = q * RPP + lane / CR;
       const int lc = (lane % CR) ^ kc_swz(r);
@@ -199,6 +211,7 @@ struct TileIO {
   // global -> registers (zero fill outside [row_lim) x [k_lim)) : used for a partial last K tile only
   __device__ __forceinline__ static void load(uint4 (&r)[PER_THREAD], const bf16_t* __restrict__ base, int ld,
                                               int row0, int row_lim, int k0, int k_lim, int tid) {
+    static_assert(CHUNKS % NTHREADS == 0, "register path: chunks per thread");
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i) {
       const int c = tid + i * NTHREADS;
@@ -691,7 +704,19 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const
 // first/last are hidden (at K = 768 they are ~30 % of a non-persistent tile's life).
 // Counted waits stay valid with stores in flight: vmcnt <= PIECES means >= (stores + PIECES) older operations have
 // retired, and loads retire in order among themselves, so the oldest PIECES loads (the tile being waited for) are in.
-template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0>
+//
+// SK (aligned split-K of the LAST, partial round; single problem, host-side shapes): a launch whose tile count is no multiple of the CU
+// count - the var-len token layout: M = the batch's real tokens - would leave most CUs idle in its last round.  Full rounds run as
+// always; the rem = tiles % G tiles of the last round share the idle CUs:
+//   rem <= G/2 : every tile's K range is cut into s = min(G / rem, 4) equal parts, part p of tile t on block p * rem + t;
+//   rem >  G/2 : block t < rem computes K-tiles [0, a) of tile t, the H = G - rem helper blocks each take the tails [a, nk) of up to
+//                q = ceil(rem / H) tiles (t = h, h + H, ...), a = ceil(nk q / (q + 1)) balances the two.
+// Blocks that work on the same K range at the same time sit next to each other, so the operand panels keep their L2 reuse (a first
+// version handed every block one contiguous range of (tile, K-tile) units: perfectly balanced, and 40 % SLOWER - neighbouring blocks
+// were at different K offsets of the same panels and every K-slice was fetched once per block).  The block with a tile's K-tile 0 owns
+// it; the others write fp32 partial accumulators to their slot of the workspace and publish a flag (agent-scope release, Guideline 16
+// of the CDNA guide); the owner adds them (acquire) and runs the epilogue.
+template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0, bool SK = false>
 __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_persist_kernel(const GemmGroup g, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = WM * WN * 64;
@@ -721,8 +746,51 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
   // caller guarantees that the rows between K and the capacity are finite on one side and zero on the other
   const bool dyn_k = g.p[0].k_dev != nullptr;
   const int k_tiles_dyn = dyn_k ? max(1, (min(*g.p[0].k_dev, g.p[0].K) + BK - 1) >> KSH) : 0;
-  struct Ctx { int pi, m0, n0, nk, M; };
+  struct Ctx { int pi, m0, n0, nk, M, kb, owner, nwait, slot; };
+  // SK pieces: kb = first K-tile, nk = K-tiles of the piece; owner = this block runs the epilogue after adding `nwait` partials (slots
+  // slot, slot + rem, ...); otherwise it writes its accumulators to `slot`
+  const int nkf = SK ? (g.p[0].K >> KSH) : 1;
   auto tile_at = [&](int r, Ctx& c) -> bool {
+    if constexpr (SK) {
+      const int R = g.sk_rounds, rem = g.sk_rem, parts = g.sk_parts;
+      int tile, kb, ke;
+      c.owner = 1; c.nwait = 0; c.slot = 0;
+      if (r < R) {
+        tile = r * G + perm; kb = 0; ke = nkf;
+      } else if (parts > 1) {                       // equal K parts
+        if (r > R || perm >= rem * parts) return false;
+        const int part = perm / rem, t = perm - part * rem;
+        tile = R * G + t;
+        kb = (int)((long)nkf * part / parts); ke = (int)((long)nkf * (part + 1) / parts);
+        c.owner = part == 0; c.nwait = parts - 1; c.slot = part == 0 ? t : (part - 1) * rem + t;
+      } else {                                      // owners + helpers
+        const int H = G - rem, a = g.sk_a;
+        if (perm < rem) {
+          if (r > R) return false;
+          tile = R * G + perm; kb = 0; ke = a;
+          c.nwait = 1; c.slot = perm;
+        } else {
+          const int t = (perm - rem) + (r - R) * H;
+          if (t >= rem) return false;
+          tile = R * G + t; kb = a; ke = nkf;
+          c.owner = 0; c.slot = t;
+        }
+      }
+      // (the divisions above run on the vector unit: tell the compiler again that the results are wave-uniform - the K origins they
+      //  lead to feed the scalar operand of the LDS-DMA instruction)
+      tile = __builtin_amdgcn_readfirstlane(tile);
+      kb = __builtin_amdgcn_readfirstlane(kb);
+      ke = __builtin_amdgcn_readfirstlane(ke);
+      c.slot = __builtin_amdgcn_readfirstlane(c.slot);
+      c.owner = __builtin_amdgcn_readfirstlane(c.owner);
+      c.pi = 0;
+      c.M = g.p[0].M;
+      tile_origin(g.p[0], c.M, tile, BM, BN, g.super, c.m0, c.n0);
+      c.kb = kb;
+      c.nk = ke - kb;
+      return true;
+    }
+    c.kb = 0;
     const int tile = r * G + perm;
     if (tile >= total_tiles) return false;
     int pi = 0;
@@ -762,10 +830,10 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
   auto load_issue_tile = [&]() {
     if (!ivalid) return;
     const GemmProblem& P = g.p[ic.pi];
-    kA = reinterpret_cast<const unsigned char*>(P.A);
-    kB = reinterpret_cast<const unsigned char*>(P.B);
     strideA = A_MC ? (long)BK * P.lda * 2 : (long)BK * 2;
     strideB = B_MC ? (long)BK * P.ldb * 2 : (long)BK * 2;
+    kA = reinterpret_cast<const unsigned char*>(P.A) + (SK ? ic.kb * strideA : 0);
+    kB = reinterpret_cast<const unsigned char*>(P.B) + (SK ? ic.kb * strideB : 0);
 #pragma unroll
     for (int i = 0; i < TA::PIECES; ++i) offA[i] = TA::piece_off(P.lda, ic.m0, ic.M, wave, lane, i);
 #pragma unroll
@@ -804,7 +872,55 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
   };
   auto finish_tile = [&]() {
     const GemmProblem& P = g.p[cc.pi];
-    if (g.ablate != 32 || acc[0][0][0] == 123.456f)   // GGET_GEMM_ABLATE=32: persistent kernel without the epilogue (timing only)
+    bool store = true;
+    if constexpr (SK) {
+      typedef __attribute__((address_space(1))) unsigned gu32;
+      constexpr int SLOT4 = BM * BN / 4;                       // float4 per slot; thread t holds float4 (i * NJ + j) * NT + t
+      if (!cc.owner) {
+        // a later part of a tile another block owns: hand the partial accumulators over (payload, every wave drains its stores,
+        // barrier, ONE lane's agent-scope release, the flag)
+        float4* slot = reinterpret_cast<float4*>(g.sk_partial) + (size_t)cc.slot * SLOT4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            slot[(i * NJ + j) * NT + tid] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store((gu32*)(g.sk_flags + cc.slot), g.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        store = false;
+      } else {
+        // the owner of a split tile: add the other parts (in slot order: the sum is deterministic), then the usual epilogue
+        for (int w = 0; w < cc.nwait; ++w) {
+          const int sl = cc.slot + w * g.sk_rem;
+          if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load((gu32*)(g.sk_flags + sl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.sk_epoch) {
+              __builtin_amdgcn_s_sleep(2);
+              if (++spins > (1u << 24)) {   // bounded: a block that never becomes resident must not hang the device
+                __hip_atomic_store((gu32*)(g.sk_flags + kStreamKBlocks), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          }
+          __syncthreads();
+          const float4* slot = reinterpret_cast<const float4*>(g.sk_partial) + (size_t)sl * SLOT4;
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+              const float4 v = slot[(i * NJ + j) * NT + tid];
+              acc[i][j][0] += v.x; acc[i][j][1] += v.y; acc[i][j][2] += v.z; acc[i][j][3] += v.w;
+            }
+        }
+      }
+    }
+    if (store && (g.ablate != 32 || acc[0][0][0] == 123.456f))   // GGET_GEMM_ABLATE=32: persistent kernel without the epilogue (timing only)
       store_tile<EPI, MI, NJ, ILV>(acc, P, cc.M, (P.N + 3) & ~3, cc.m0 + wm * (MI * 16),
                                    EPI == GGET_EPI_GEGLU_FWD ? (cc.n0 >> 1) + wn * (NJ * 8) : cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, wn * 16);
 #pragma unroll
@@ -874,9 +990,11 @@ __global__ void __launch_bounds__(512, 2) gemm_ks_kernel(const GemmGroup g, int 
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int NSLOT = NSLOT_ > 0 ? NSLOT_ : persist_slots(STAGE);
   constexpr int PIECES = TA::PIECES + TB::PIECES;
-  constexpr int MI = BM / 2 / 16, NJ = BN / 2 / 16, HI = MI / 2, HT = HI * NJ;
-  static_assert(MI % 2 == 0 || MI == 3 * 2 / 2 * 2 || true, "row halves");
+  // row blocks of a wave's sub-tile: after the K loop wave (wk = 0) keeps blocks [0, H0), its K partner (wk = 1) blocks [H0, MI)
+  constexpr int MI = BM / 2 / 16, NJ = BN / 2 / 16, H0 = (MI + 1) / 2, H1 = MI - H0, HT = H0 * NJ;
+  static_assert(H1 >= 1, "at least two row blocks per wave");
   static_assert(8 * HT * 64 * 16 <= NSLOT * STAGE, "accumulator exchange fits in the ring");
+  static_assert(!TB::WRAP, "only the A tile may have a wrapped piece list");
 
   const int G = gridDim.x;
   const int tile = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);   // XCD-contiguous
@@ -911,8 +1029,12 @@ __global__ void __launch_bounds__(512, 2) gemm_ks_kernel(const GemmGroup g, int 
   for (int i = 0; i < TB::PIECES; ++i) offB[i] = TB::piece_off(P.ldb, n0, P.N, wave, lane, i);
   int islot = 0, cslot = 0, issued = 0;
   unsigned islot_off = lds0;
+  // (a wrapped A piece - TileIO::WRAP - lands where the piece it repeats lives: a wave-uniform correction of the LDS offset)
+  int adjA[TA::PIECES];
+#pragma unroll
+  for (int i = 0; i < TA::PIECES; ++i) adjA[i] = (TA::piece_index(wave, i) - (wave + i * TA::NWAVES)) * 1024;
   auto issue_piece = [&](int q) {
-    if (q < TA::PIECES) glds16m(kA, offA[q < TA::PIECES ? q : 0], islot_off + (unsigned)(q * TA::NWAVES * 1024));
+    if (q < TA::PIECES) glds16m(kA, offA[q < TA::PIECES ? q : 0], islot_off + (unsigned)(q * TA::NWAVES * 1024 + (TA::WRAP ? adjA[q < TA::PIECES ? q : 0] : 0)));
     else glds16m(kB, offB[q >= TA::PIECES ? q - TA::PIECES : 0], islot_off + (unsigned)(A_BYTES + (q - TA::PIECES) * TB::NWAVES * 1024));
   };
   auto issue_advance = [&]() {
@@ -955,28 +1077,51 @@ __global__ void __launch_bounds__(512, 2) gemm_ks_kernel(const GemmGroup g, int 
     if (did) issue_advance();
     cslot = cslot == NSLOT - 1 ? 0 : cslot + 1;
   }
-  // ---- add the two K halves: wave w keeps row half (wk) of the sub-tile, gives the other half to wave w ^ 4
+  // ---- add the two K halves: wave w keeps its row blocks (see H0 / H1) of the sub-tile and gives the others to wave w ^ 4
   __syncthreads();
   float4* xch = reinterpret_cast<float4*>(smem);
-#pragma unroll
-  for (int ii = 0; ii < HI; ++ii)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const f32x4_t v = wk == 0 ? acc[HI + ii][j] : acc[ii][j];
-      xch[(size_t)(wave * HT + ii * NJ + j) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
-    }
-  __syncthreads();
-  f32x4_t own[HI][NJ];
   const int partner = wave ^ 4;
+  if (wk == 0) {
 #pragma unroll
-  for (int ii = 0; ii < HI; ++ii)
+    for (int ii = 0; ii < H1; ++ii)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const float4 o = xch[(size_t)(partner * HT + ii * NJ + j) * 64 + lane];
-      const f32x4_t mine = wk == 0 ? acc[ii][j] : acc[HI + ii][j];
-      own[ii][j] = f32x4_t{mine[0] + o.x, mine[1] + o.y, mine[2] + o.z, mine[3] + o.w};
-    }
-  store_tile<EPI, HI, NJ>(own, P, P.M, (P.N + 3) & ~3, m0 + wm * (MI * 16) + wk * (HI * 16), n0 + wn * (NJ * 16), lane);
+      for (int j = 0; j < NJ; ++j) {
+        const f32x4_t v = acc[H0 + ii][j];
+        xch[(size_t)(wave * HT + ii * NJ + j) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+  } else {
+#pragma unroll
+    for (int ii = 0; ii < H0; ++ii)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const f32x4_t v = acc[ii][j];
+        xch[(size_t)(wave * HT + ii * NJ + j) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+  }
+  __syncthreads();
+  if (wk == 0) {
+    f32x4_t own[H0][NJ];
+#pragma unroll
+    for (int ii = 0; ii < H0; ++ii)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const float4 o = xch[(size_t)(partner * HT + ii * NJ + j) * 64 + lane];
+        const f32x4_t mine = acc[ii][j];
+        own[ii][j] = f32x4_t{mine[0] + o.x, mine[1] + o.y, mine[2] + o.z, mine[3] + o.w};
+      }
+    store_tile<EPI, H0, NJ>(own, P, P.M, (P.N + 3) & ~3, m0 + wm * (MI * 16), n0 + wn * (NJ * 16), lane);
+  } else {
+    f32x4_t own[H1][NJ];
+#pragma unroll
+    for (int ii = 0; ii < H1; ++ii)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const float4 o = xch[(size_t)(partner * HT + ii * NJ + j) * 64 + lane];
+        const f32x4_t mine = acc[H0 + ii][j];
+        own[ii][j] = f32x4_t{mine[0] + o.x, mine[1] + o.y, mine[2] + o.z, mine[3] + o.w};
+      }
+    store_tile<EPI, H1, NJ>(own, P, P.M, (P.N + 3) & ~3, m0 + wm * (MI * 16) + H0 * 16, n0 + wn * (NJ * 16), lane);
+  }
 }
 
 template <int BM, int BN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0>
@@ -996,22 +1141,53 @@ int launch_ks_cfg(GemmGroup& g, int total, hipStream_t st) {
 }
 
 // launch one persistent configuration: one block per CU (grid rounded to the 8 XCDs)
-template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0>
+template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0, bool SK = false>
 int launch_persist_cfg(GemmGroup& g, int total, int num_cu, hipStream_t st) {
   constexpr int STG = (BM + BN) * BK * 2;
   constexpr int SM = (NSLOT_ > 0 ? NSLOT_ : persist_slots(STG)) * STG;
   static_assert(SM <= 160 * 1024, "LDS ring");
-  int G = total < num_cu ? total : num_cu;
+  static_assert(!SK || (size_t)BM * BN * 4 <= kStreamKSlotBytes, "stream-K slot");
+  int G = total < num_cu && !SK ? total : num_cu;
   G = (G + 7) & ~7;  // the XCD permutation needs a multiple of 8 (idle blocks exit at once)
   static bool attr0 = false;
   if (!attr0) {
-    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BM, BN, BK, WM, WN, A_MC, B_MC, EPI, NSLOT_>),
+    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BM, BN, BK, WM, WN, A_MC, B_MC, EPI, NSLOT_, SK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SM));
     attr0 = true;
   }
-  hipLaunchKernelGGL((gemm_persist_kernel<BM, BN, BK, WM, WN, A_MC, B_MC, EPI, NSLOT_>), dim3(G), dim3(WM * WN * 64), SM, st, g, total);
+  hipLaunchKernelGGL((gemm_persist_kernel<BM, BN, BK, WM, WN, A_MC, B_MC, EPI, NSLOT_, SK>), dim3(G), dim3(WM * WN * 64), SM, st, g, total);
   GGET_LAUNCH_CHECK();
   return 0;
+}
+
+// The last round's split pays when it shortens the launch by more than the hand-over of the partial tiles costs (one write and one
+// read of BM x BN fp32 per split tile: a few K-tiles' worth).  Fills g.sk_* and returns true when the launch should run split.
+thread_local void* t_streamk_ws = nullptr;
+unsigned g_streamk_epoch = 0;
+inline bool streamk_plan(GemmGroup& g, int tiles, int num_cu, int bk) {
+  if (!g_gemm_split_last || !t_streamk_ws || g.count != 1 || (g_gemm_variant & 8)) return false;
+  const GemmProblem& p = g.p[0];
+  if (p.m_dev || p.k_dev || num_cu > 256 || num_cu % 8 != 0) return false;
+  const int nk = p.K / bk, G = num_cu;
+  const int R = tiles / G, rem = tiles % G;
+  if (rem == 0 || nk < 8) return false;
+  int parts = 1, a = nk, last;
+  if (rem <= G / 2) {
+    parts = G / rem < 4 ? G / rem : 4;
+    last = (nk + parts - 1) / parts;
+  } else {
+    const int H = G - rem, q = (rem + H - 1) / H;
+    a = (nk * q + q) / (q + 1);            // ceil(nk q / (q + 1))
+    if (a >= nk) return false;
+    last = a > q * (nk - a) ? a : q * (nk - a);
+  }
+  const long plain = (long)(R + 1) * nk, split = (long)R * nk + last + 4;
+  if (split > plain - plain / 16) return false;
+  g.sk_rounds = R; g.sk_rem = rem; g.sk_parts = parts; g.sk_a = a;
+  g.sk_flags = static_cast<unsigned*>(t_streamk_ws);
+  g.sk_partial = reinterpret_cast<float*>(static_cast<unsigned char*>(t_streamk_ws) + kStreamKFlagBytes);
+  g.sk_epoch = ++g_streamk_epoch ? g_streamk_epoch : ++g_streamk_epoch;   // never 0 (the flags start zeroed)
+  return true;
 }
 
 template <int WM, int WN, bool A_MC, bool B_MC, int EPI>
@@ -1091,15 +1267,42 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
           tot3 += ((p.M + 127) / 128) * p.tiles_n;
         }
         if constexpr (EPI != GGET_EPI_ROPE) {
-          // one tile per CU, nothing device-sized: the K-split arrangement of the same tile (g_gemm_variant bit 0 turns it off)
+          // one tile per CU, nothing device-sized: the K-split arrangement of the tile (g_gemm_variant bit 0 turns it off)
           bool ks = tot3 <= num_cu && !(g_gemm_variant & 1);
           // (K >= 1536: with only 12 K-tiles the accumulator exchange costs what the lighter fragment traffic saves)
           for (int i = 0; i < g.count; ++i)
-            ks = ks && !g.p[i].m_dev && !g.p[i].k_dev && (g.p[i].N % 192) == 0 && (g.p[i].M % 128) == 0 && g.p[i].K >= 1536;
-          // g_gemm_lds_headroom (gget_debug_set key 2 / GGET_GEMM_LDS_HEADROOM): 3 ring slots (120 KiB) instead of 4, so that a
-          // collective's workgroup (a few KiB of LDS) can share the CU with the GEMM block
-          if (ks && g_gemm_lds_headroom) return launch_ks_cfg<128, 192, A_MC, B_MC, EPI, 3>(g, tot3, st);
-          if (ks) return launch_ks_cfg<128, 192, A_MC, B_MC, EPI>(g, tot3, st);
+            ks = ks && !g.p[i].m_dev && !g.p[i].k_dev && (g.p[i].N % 192) == 0 && g.p[i].K >= 1536;
+          if (ks) {
+            // Rows per tile: the smallest of 64 / 96 / 128 whose tiles still fit in ONE round - more, smaller tiles keep more CUs
+            // busy for a shorter time (var-len token layout: 5 696 x 768 is 180 tiles of 128 rows = 70 % of the CUs, 240 tiles of 96
+            // rows = 94 % at 3/4 of the work each; the padded 8 192 x 768 stays at 256 tiles of 128 rows).  g_gemm_variant bit 4:
+            // 128 rows only.
+            int bm = 128;
+            if (!(g_gemm_variant & 16))
+              for (int cand : {64, 96}) {
+                long t = 0;
+                for (int i = 0; i < g.count; ++i) t += (long)((g.p[i].M + cand - 1) / cand) * (g.p[i].N / 192);
+                if (t <= num_cu) { bm = cand; break; }
+              }
+            int tot = 0;
+            for (int i = 0; i < g.count; ++i) {
+              GemmProblem& p = g.p[i];
+              p.tiles_n = p.N / 192;
+              p.tile_begin = tot;
+              tot += ((p.M + bm - 1) / bm) * p.tiles_n;
+            }
+            // g_gemm_lds_headroom (gget_debug_set key 2 / GGET_GEMM_LDS_HEADROOM): 3 ring slots instead of 4, so that a
+            // collective's workgroup (a few KiB of LDS) can share the CU with the GEMM block
+            if (bm == 64) return launch_ks_cfg<64, 192, A_MC, B_MC, EPI, 3>(g, tot, st);
+            if (bm == 96) return launch_ks_cfg<96, 192, A_MC, B_MC, EPI, 3>(g, tot, st);
+            if (g_gemm_lds_headroom) return launch_ks_cfg<128, 192, A_MC, B_MC, EPI, 3>(g, tot, st);
+            return launch_ks_cfg<128, 192, A_MC, B_MC, EPI>(g, tot, st);
+          }
+        }
+        if constexpr (EPI != GGET_EPI_ROPE) {
+          if (streamk_plan(g, tot3, num_cu, 64)) {
+            return launch_persist_cfg<128, 192, 64, 4, 2, A_MC, B_MC, EPI, 3, true>(g, tot3, num_cu, st);
+          }
         }
         if (g_gemm_lds_headroom) return launch_persist_cfg<128, 192, 64, 4, 2, A_MC, B_MC, EPI, 3>(g, tot3, num_cu, st);
         return launch_persist_cfg<128, 192, 64, 4, 2, A_MC, B_MC, EPI>(g, tot3, num_cu, st);
@@ -1132,6 +1335,28 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
           if (ks) return launch_ks_cfg<192, 192, true, true, EPI>(g, tot4, st);
         }
         return launch_persist_cfg<192, 192, 64, 4, 2, true, true, EPI>(g, tot4, num_cu, st);
+      }
+    }
+    // 192-row variant of the 256x128 tile (waves 4 x 2, 48 x 64 each): a row count that is no multiple of 256 x (CUs / column tiles)
+    // - the var-len token layout: M = real tokens, e.g. 5 696 instead of 8 192 - leaves the last round of 256-row tiles mostly
+    // empty; rounds x rows decides (8192 x 3072: 3 x 256 against 5 x 192 -> 256; 5696 x 3072: 3 x 256 against 3 x 192 -> 192)
+    if constexpr (WM == 4 && WN == 2 && !A_MC && (EPI == GGET_EPI_GEGLU_BWD || EPI == GGET_EPI_NONE || EPI == GGET_EPI_RESIDUAL)) {
+      bool ok = !(g_gemm_variant & 4);
+      long t192 = 0;
+      for (int i = 0; i < g.count; ++i) {
+        ok = ok && !g.p[i].m_dev && !g.p[i].k_dev && (g.p[i].N % BN) == 0;
+        t192 += (long)((g.p[i].M + 191) / 192) * (g.p[i].N / BN);
+      }
+      const long cur_rounds = (total + num_cu - 1) / num_cu, r192 = (t192 + num_cu - 1) / num_cu;
+      if (ok && r192 * 192 < cur_rounds * 256) {
+        int tot5 = 0;
+        for (int i = 0; i < g.count; ++i) {
+          GemmProblem& p = g.p[i];
+          p.tiles_n = p.N / BN;
+          p.tile_begin = tot5;
+          tot5 += ((p.M + 191) / 192) * p.tiles_n;
+        }
+        return launch_persist_cfg<192, BN, 64, WM, WN, A_MC, B_MC, EPI>(g, tot5, num_cu, st);
       }
     }
     return launch_persist_cfg<BM, BN, 64, WM, WN, A_MC, B_MC, EPI>(g, total, num_cu, st);
@@ -1192,6 +1417,18 @@ int launch_mode(GemmGroup& g, int epi, int split_k, hipStream_t st) {
           GGET_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
           num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
+        // (192-row tiles when they need fewer rounds x rows than 256-row tiles - see launch_t)
+        long t192 = 0;
+        for (int i = 0; i < g.count; ++i) t192 += (long)((g.p[i].M + 191) / 192) * (g.p[i].N / 256);
+        if (!(g_gemm_variant & 4) && ((t192 + num_cu - 1) / num_cu) * 192 < ((total + num_cu - 1) / num_cu) * 256) {
+          int tot2 = 0;
+          for (int i = 0; i < g.count; ++i) {
+            GemmProblem& p = g.p[i];
+            p.tile_begin = tot2;
+            tot2 += ((p.M + 191) / 192) * p.tiles_n;
+          }
+          return launch_persist_cfg<192, 256, 64, 4, 2, false, false, GGET_EPI_GEGLU_FWD, 2>(g, tot2, num_cu, st);
+        }
         return launch_persist_cfg<256, 256, 64, 4, 2, false, false, GGET_EPI_GEGLU_FWD, 2>(g, total, num_cu, st);
       }
       break;
@@ -1202,14 +1439,19 @@ int launch_mode(GemmGroup& g, int epi, int split_k, hipStream_t st) {
 
 }  // namespace
 
+void gget_gemm_streamk_workspace(void* ws) { t_streamk_ws = ws; }
+
 int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t st) {
   GGET_REQUIRE(g.count >= 1 && g.count <= GGET_MAX_GROUP, "gemm: bad group size %d", g.count);
+  g.sk_partial = nullptr; g.sk_flags = nullptr; g.sk_epoch = 0;
+  g.sk_rounds = g.sk_rem = g.sk_a = 0; g.sk_parts = 1;
   static int ablate = -1;
   if (ablate < 0) {
     const char* e = getenv("GGET_GEMM_ABLATE");
     ablate = e ? atoi(e) : 0;
     if (const char* v = getenv("GGET_GEMM_VARIANT")) g_gemm_variant = atoi(v);
-    if (const char* v = getenv("GGET_GEMM_LDS_HEADROOM")) g_gemm_lds_headroom = atoi(v);   // same knob as gget_debug_set(1, .), for whole-step A/B
+    if (const char* v = getenv("GGET_GEMM_LDS_HEADROOM")) g_gemm_lds_headroom = atoi(v);
+    if (const char* v = getenv("GGET_GEMM_SPLIT_LAST")) g_gemm_split_last = atoi(v);   // same knob as gget_debug_set(1, .), for whole-step A/B
   }
   g.ablate = ablate;
   static int super = -1;

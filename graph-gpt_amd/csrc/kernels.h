@@ -54,6 +54,13 @@ int k_geglu_fwd(const void* gu, void* h, int T, int ff, hipStream_t st);
 int k_geglu_bwd(const void* gu, const void* dh, void* dgu, int T, int ff, hipStream_t st);
 int k_lengths(const int64_t* mask, const int64_t* ids, int ldF, int pad_id, int32_t* key_len, int32_t* pool_row, int B,
               int S, hipStream_t st);
+// Var-len (padding-free) token layout of a right-padded batch: cu[b] = first compact row of sample b (exclusive scan of key_len, cu[B] =
+// total), compact ids [t_rows][F] / row positions / sample index per row, pad2c[b*S+s] = compact row or -1; rows [tc, t_rows) are pad
+// tokens.  pool_row (task head, may be NULL) is moved to the compact rows; status[0] = 1 if sum(key_len) != tc.
+int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, const int32_t* key_len, int32_t* pool_row, int32_t* cu,
+                  int64_t* ids_c, int64_t* pos_c, int32_t* row_b, int32_t* pad2c, int32_t* status, int B, int S, int tc, int t_rows,
+                  int pad_id, hipStream_t st);
+int k_remap_rows(int32_t* idx, const int32_t* count, const int32_t* pad2c, int cap, hipStream_t st);
 int k_head_compact(const int64_t* labels, int T, int n, int32_t* cnt, int32_t* m_off, int32_t* l_off, int32_t* counts,
                    int32_t* row_idx, int32_t* sel_src, int32_t* sel_label, int32_t* sel_tok, hipStream_t st);
 int k_gather_rows(const void* src, const int32_t* idx, const int32_t* count, void* dst, int cap, int d, int scatter,
@@ -96,11 +103,14 @@ int k_convert_segments(const float* scratch, void* grads, const GgetSegment* seg
 // already rotated them) and undone on dq,dk, so dqkv is always the gradient of the UN-rotated projections
 int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
                const float* cos_tab, const float* sin_tab, const int64_t* position_ids, float dropout_p,
-               unsigned dropout_seed, hipStream_t st, const int32_t* key_lo = nullptr, const int32_t* key_hi = nullptr);
+               unsigned dropout_seed, hipStream_t st, const int32_t* key_lo = nullptr, const int32_t* key_hi = nullptr,
+               const int32_t* row_base = nullptr);
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
                const int64_t* position_ids, int qk_rotated, float dropout_p, unsigned dropout_seed, hipStream_t st,
-               const int32_t* key_lo = nullptr, const int32_t* key_hi = nullptr);
+               const int32_t* key_lo = nullptr, const int32_t* key_hi = nullptr, const int32_t* row_base = nullptr);
+// row_base ([B] int32, needs key_len): var-len (padding-free) token layout - sample b owns rows [row_base[b], row_base[b] + key_len[b]) of
+// qkv / out / dout / dqkv instead of [b * S, b * S + S); lse / delta / position ids stay [B,S]-indexed.
 // packed rows: inclusive key range [lo, hi] of every token from the block-diagonal mask [B,S,S] (first / last 1 of its row)
 int k_ranges_from_mask3d(const int64_t* mask3d, int32_t* key_lo, int32_t* key_hi, int B, int S, hipStream_t st);
 int k_smtp2d(const int64_t* ids_in, int ld_in, const int64_t* node_idx, int ld_node, int64_t* ids_out, int64_t* labels_out,

@@ -1845,6 +1845,101 @@ int k_lengths(const int64_t* mask, const int64_t* ids, int ldF, int pad_id, int3
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Var-len (padding-free) token layout.  The reference runs every token-wise op over the padded [B,S] grid (modeling_helpers.py:38-64
+// builds the additive mask; a third of a PCQM4M-v2 batch is padding); here the real tokens of a right-padded batch are compacted once,
+// sample after sample, and the whole layer stack runs on T = round_up(sum(len), 64) rows.  cu[b] = first row of sample b.
+// ---------------------------------------------------------------------------------------------
+// one block: exclusive scan of key_len over the batch (any B), cu[B] = total; the pooled row of the task head (lengths_kernel: b*S + p)
+// moves to cu[b] + min(p, len - 1); status[0] = 1 when the total differs from the caller's token count
+__global__ void __launch_bounds__(1024) varlen_scan_kernel(const int32_t* __restrict__ key_len, int32_t* __restrict__ cu,
+                                                           int32_t* __restrict__ pool_row, int32_t* __restrict__ status, int B, int S,
+                                                           int expect_total) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < B; b0 += 1024) {
+    const int b = b0 + tid;
+    const int v = b < B ? key_len[b] : 0;
+    int x = v;   // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int base = carry_s;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    if (b < B) {
+      const int start = base + x - v;
+      cu[b] = start;
+      if (pool_row) {
+        const int pidx = pool_row[b] - b * S;
+        pool_row[b] = start + max(min(pidx, v - 1), 0);
+      }
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = base + x;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    cu[B] = carry_s;
+    status[0] = carry_s == expect_total ? 0 : 1;
+  }
+}
+// one thread per padded token (b, s) plus one per tail row: compact ids / positions / sample index of its row, the padded -> compact map
+__global__ void __launch_bounds__(kBlock) varlen_fill_kernel(const int64_t* __restrict__ ids, int ldF, int F, const int64_t* __restrict__ pos,
+                                                             const int32_t* __restrict__ key_len, const int32_t* __restrict__ cu,
+                                                             int64_t* __restrict__ ids_c, int64_t* __restrict__ pos_c,
+                                                             int32_t* __restrict__ row_b, int32_t* __restrict__ pad2c, int B, int S,
+                                                             int tc, int t_rows, int64_t pad_id) {
+  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+  const long TP = (long)B * S;
+  if (i < TP) {
+    const int b = (int)(i / S), sq = (int)(i % S);
+    if (sq < key_len[b]) {
+      const int r = cu[b] + sq;
+      for (int f = 0; f < F; ++f) ids_c[(size_t)r * F + f] = ids[(size_t)i * ldF + f];
+      pos_c[r] = pos ? pos[i] : (int64_t)sq;
+      row_b[r] = b;
+      pad2c[i] = r;
+    } else {
+      pad2c[i] = -1;
+    }
+  } else if (i < TP + (t_rows - tc)) {   // tail rows [tc, t_rows): pad tokens of sample 0, position 0 (finite activations, zero gradients)
+    const int r = tc + (int)(i - TP);
+    for (int f = 0; f < F; ++f) ids_c[(size_t)r * F + f] = pad_id;
+    pos_c[r] = 0;
+    row_b[r] = 0;
+  }
+}
+// SMTP head: the selected rows (padded token indices, head_fill_kernel) -> rows of the compact layout
+__global__ void __launch_bounds__(kBlock) remap_rows_kernel(int32_t* __restrict__ idx, const int32_t* __restrict__ count,
+                                                            const int32_t* __restrict__ pad2c, int cap) {
+  const int n = min(cap, *count);
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) idx[i] = max(pad2c[idx[i]], 0);
+}
+
+int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, const int32_t* key_len, int32_t* pool_row, int32_t* cu,
+                  int64_t* ids_c, int64_t* pos_c, int32_t* row_b, int32_t* pad2c, int32_t* status, int B, int S, int tc, int t_rows,
+                  int pad_id, hipStream_t st) {
+  hipLaunchKernelGGL(varlen_scan_kernel, dim3(1), dim3(1024), 0, st, key_len, cu, pool_row, status, B, S, tc);
+  const long n = (long)B * S + (t_rows - tc);
+  hipLaunchKernelGGL(varlen_fill_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, ids, ldF, F, pos, key_len, cu,
+                     ids_c, pos_c, row_b, pad2c, B, S, tc, t_rows, (int64_t)pad_id);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+int k_remap_rows(int32_t* idx, const int32_t* count, const int32_t* pad2c, int cap, hipStream_t st) {
+  if (cap == 0) return 0;
+  hipLaunchKernelGGL(remap_rows_kernel, dim3(grid_for(cap)), dim3(kBlock), 0, st, idx, count, pad2c, cap);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
 int k_head_compact(const int64_t* labels, int T, int n, int32_t* cnt, int32_t* m_off, int32_t* l_off, int32_t* counts,
                    int32_t* row_idx, int32_t* sel_src, int32_t* sel_label, int32_t* sel_tok, hipStream_t st) {
   const int g = (T + kBlock - 1) / kBlock;

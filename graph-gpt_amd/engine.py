@@ -140,7 +140,18 @@ class Engine:
     def _i64(t, dev):
         return None if t is None else t.to(device=dev, dtype=torch.int64).contiguous()
 
-    def forward_pretrain(self, input_ids, attention_mask, labels=None, sample_wgt=None, position_ids=None):
+    def _set_layout(self, att, num_tokens):
+        """Token layout of the forward about to run: `num_tokens` (host int: real tokens of the batch) selects the var-len layout;
+        GGET_VARLEN=sync (tests, A/B runs) counts a 2-D device mask here at the price of a stream sync; GGET_VARLEN=0 keeps the padded
+        layout whatever the caller passed."""
+        import os
+        mode = os.environ.get("GGET_VARLEN", "")
+        n = None if mode == "0" else num_tokens
+        if n is None and mode == "sync" and att is not None and att.dim() == 2:
+            n = int((att != 0).sum())
+        self.set_token_count(n)
+
+    def forward_pretrain(self, input_ids, attention_mask, labels=None, sample_wgt=None, position_ids=None, num_tokens=None):
         dev = self.device
         ids = self._i64(input_ids, dev)
         if ids.dim() == 2:
@@ -154,6 +165,7 @@ class Engine:
         wgt = None if sample_wgt is None else sample_wgt.to(device=dev, dtype=torch.float32).contiguous()
         pos = self._i64(position_ids, dev)
         self._keep = (ids, att, lab, wgt, pos)
+        self._set_layout(att if lab is not None else None, num_tokens if lab is not None else None)   # (full-logit inference: padded rows)
         if att is not None and att.dim() == 3:      # packed rows: block-diagonal [B,S,S] mask
             assert att.shape == (B, S, S), f"3-D attention mask must be [B,S,S], got {tuple(att.shape)}"
             fn = self.lib.gget_forward_pretrain_packed
@@ -163,7 +175,7 @@ class Engine:
         return self._loss[0] if lab is not None else None
 
     def forward_task(self, input_ids, attention_mask, position_ids=None, task_labels=None, sample_wgt=None,
-                     problem: int = L.PROBLEM_SINGLE_LABEL):
+                     problem: int = L.PROBLEM_SINGLE_LABEL, num_tokens=None):
         dev = self.device
         ids = self._i64(input_ids, dev)
         if ids.dim() == 2:
@@ -186,6 +198,7 @@ class Engine:
             logits = torch.empty(B, self.spec.num_labels, dtype=torch.float32, device=dev)
         hid = torch.empty(B, self.spec.hidden_size, dtype=torch.bfloat16, device=dev)
         self._keep = (ids, att, pos, y, wgt)
+        self._set_layout(att, num_tokens)
         L.check(self.lib.gget_forward_task(self.h, _ptr(ids), _ptr(att), _ptr(pos), _ptr(y), _ptr(wgt), problem, B, S,
                                            _ptr(self._loss), _ptr(logits), _ptr(hid), _stream()))
         return (self._loss[0] if y is not None else None), logits, hid
@@ -228,6 +241,17 @@ class Engine:
     def set_rope_range(self, rope_range: float):
         """config.rope_range: > 0 rescales the position ids of a forward to [0, rope_range) per row (per-token rotary angles)."""
         L.check(self.lib.gget_set_rope_range(self.h, float(rope_range)))
+
+    def set_token_count(self, n_real_tokens: Optional[int]):
+        """sum(attention_mask) of the NEXT forward's batch, when the host knows it: switches that step to the var-len (padding-free)
+        token layout (gget_set_token_count).  None / 0 = unknown -> padded layout."""
+        L.check(self.lib.gget_set_token_count(self.h, int(n_real_tokens or -1)))
+
+    def varlen_status(self):
+        """(ran var-len, rows, count mismatch) of the last forward; synchronises."""
+        out = (C.c_int32 * 3)()
+        L.check(self.lib.gget_varlen_status(self.h, out, _stream()))
+        return bool(out[0]), int(out[1]), bool(out[2])
 
     def set_auc(self, num_neg: int = 1, seed: int = 0):
         """Negatives per positive and the sampling seed of the NEXT forward_task(problem=PROBLEM_AUC)."""

@@ -356,6 +356,18 @@ class _GgetModel(nn.Module):
             return
         check_batch(input_ids, attention_mask, labels, self.config.vocab_size)
 
+    @staticmethod
+    def _token_count(attention_mask, num_tokens):
+        """Real (un-padded) tokens of the batch for the var-len token layout (Engine.set_token_count): the caller's `num_tokens`, or
+        sum(attention_mask) when the mask still lives on the HOST (the reference's loops receive CPU batches from the DataLoader and
+        move them, training_utils.py:14-26) - counting there costs nothing, counting a device tensor would stall the stream, so a
+        device-side mask without a count keeps the padded layout."""
+        if num_tokens is not None:
+            return int(num_tokens)
+        if attention_mask is not None and attention_mask.dim() == 2 and attention_mask.device.type == "cpu":
+            return int((attention_mask != 0).sum())
+        return None       # (GGET_VARLEN=sync / =0 are handled by Engine._set_layout)
+
     def _wrap_loss(self, loss):
         if loss is None:
             return None
@@ -369,7 +381,7 @@ class GraphGPTPretrainBase(_GgetModel):
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 inputs_raw_embeds=None, labels=None, label_mask=None, sample_wgt=None, use_cache=None,
-                output_attentions=None, output_hidden_states=None, return_dict=None, cache_position=None):
+                output_attentions=None, output_hidden_states=None, return_dict=None, cache_position=None, num_tokens=None):
         assert inputs_embeds is None, "inputs_embeds is not supported (reference asserts the same, modeling_helpers.py:95)"
         assert (inputs_raw_embeds is not None) == (int(self.config.embed_dim or 0) > 0), \
             "inputs_raw_embeds are given exactly when the model was built with embed_dim > 0 (modeling_pretrain.py:131-132)"
@@ -389,6 +401,7 @@ class GraphGPTPretrainBase(_GgetModel):
         B, S = input_ids.shape[:2]
         assert input_ids.shape[2] == self.spec.stacked_feat, \
             f"stacked_feat: {self.spec.stacked_feat}\nx.shape: {tuple(input_ids.shape)}"  # modeling_common.py:131-133
+        n_real = self._token_count(attention_mask, num_tokens)
         if attention_mask is None:
             attention_mask = torch.ones(B, S, dtype=torch.int64)
         assert attention_mask.dim() in (2, 3), "attention_mask is [B,S] (right padding) or [B,S,S] (packed, block-diagonal)"
@@ -399,7 +412,7 @@ class GraphGPTPretrainBase(_GgetModel):
         e = self._pre_forward(B, S)
         if inputs_raw_embeds is not None:
             e.set_raw_embeds(inputs_raw_embeds, first_label_only=bool(getattr(self.config, "smtp_inside", False)))
-        loss = e.forward_pretrain(input_ids, attention_mask, labels, sample_wgt, position_ids)
+        loss = e.forward_pretrain(input_ids, attention_mask, labels, sample_wgt, position_ids, num_tokens=n_real)
         return _PretrainOutput(self._wrap_loss(loss), _LazyLogits(self))
 
 
@@ -408,13 +421,14 @@ class GraphGPTTaskModel(_GgetModel):
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 inputs_raw_embeds=None, task_labels=None, cls_idx=None, sample_wgt=None, use_cache=None,
-                output_attentions=None, output_hidden_states=None, return_dict=None, **kwargs):
+                output_attentions=None, output_hidden_states=None, return_dict=None, num_tokens=None, **kwargs):
         assert inputs_embeds is None
         assert (inputs_raw_embeds is not None) == (int(self.config.embed_dim or 0) > 0), \
             "inputs_raw_embeds are given exactly when the model was built with embed_dim > 0 (modeling_helpers.py:127-139)"
         if input_ids.dim() == 2:
             input_ids = input_ids[:, :, None]
         B, S = input_ids.shape[:2]
+        n_real = self._token_count(attention_mask, num_tokens)
         if attention_mask is None:
             attention_mask = torch.ones(B, S, dtype=torch.int64)
         cfg = self.config
@@ -448,7 +462,7 @@ class GraphGPTTaskModel(_GgetModel):
             e.set_auc(cfg.num_neg or 1, self.last_auc_seed)
         if inputs_raw_embeds is not None:
             e.set_raw_embeds(inputs_raw_embeds)
-        loss, logits, hid = e.forward_task(input_ids, attention_mask, position_ids, task_labels, sample_wgt, code)
+        loss, logits, hid = e.forward_task(input_ids, attention_mask, position_ids, task_labels, sample_wgt, code, num_tokens=n_real)
         return DoubleHeadsModelOutput(pretrain_loss=None, task_loss=self._wrap_loss(loss), pretrain_logits=None,
                                       task_logits=logits, task_hidden_states=hid)
 

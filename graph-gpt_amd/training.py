@@ -288,9 +288,11 @@ def initialize(model: _GgetModel, optim: Optional[OptimConfig] = None, process_g
 # ----------------------------------------------------------------------------- one optimisation step
 def batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine):
     """reference training_utils.batch_training DeepSpeed branch (:30-45): loss = head1 (+head2); backward; step.
-    position_ids are NOT passed in pre-training (reference comments them out at :35)."""
+    position_ids are NOT passed in pre-training (reference comments them out at :35).  `data["num_tokens"]` (optional, a host int =
+    sum of the attention mask, e.g. written by the collator) or a host-side attention mask lets the engine run the step on the
+    padding-free token layout (modeling._GgetModel._token_count)."""
     out = engine(input_ids=data["input_ids"], attention_mask=data["attention_mask"], labels=data["labels"],
-                 inputs_raw_embeds=data.get("embed"), sample_wgt=data.get("wgt"))
+                 inputs_raw_embeds=data.get("embed"), sample_wgt=data.get("wgt"), num_tokens=data.get("num_tokens"))
     loss = out.head1_loss
     if out.head2_loss is not None:
         loss = loss + out.head2_loss
@@ -303,7 +305,7 @@ def ft_batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine, label_k
     """reference training_utils.ft_batch_training (:98-205): passes position_ids, task labels, sample weights."""
     out = engine(input_ids=data["input_ids"], attention_mask=data["attention_mask"], position_ids=data.get("position_ids"),
                  task_labels=data[label_key], cls_idx=data.get("cls_idx"), inputs_raw_embeds=data.get("embed"),
-                 sample_wgt=data.get("wgt"))
+                 sample_wgt=data.get("wgt"), num_tokens=data.get("num_tokens"))
     loss = out.task_loss
     engine.backward(loss)
     engine.step()

@@ -126,6 +126,21 @@ int gget_bucket_range(gget_handle_t h, int bucket, uint64_t* offset, uint64_t* c
  * handle created with config.path_pdrop > 0. */
 int gget_set_dropout(gget_handle_t h, float attention_p, float path_p, uint32_t seed);
 
+/* Var-len (padding-free) token layout.  replaces: nothing the reference has as an operator - it runs every token-wise module over the
+ * padded [B,S] grid and masks attention (src/models/graphgpt/modeling_helpers.py:38-64); its only remedy against padding is the
+ * collator-side `pack_tokens` option (src/data/tokenizer.py:359-415, served by gget_forward_pretrain_packed).  n_real_tokens =
+ * sum(attention_mask) of the NEXT gget_forward_pretrain / gget_forward_task batch (the host knows it from its collator; < 1 = unknown).
+ * When given, and the batch is right-padded, the engine compacts the real tokens once (sample b owns rows [cu[b], cu[b] + len[b]))
+ * and runs embedding, every GEMM / norm / residual of the layer stack, attention (per-sample row offsets) and the backward on
+ * round_up(n_real_tokens, 64) rows instead of B*S.  Results are those of the padded layout (pad rows never influence real rows; the
+ * loss, its normalisers, the dropout streams and all [B,S]-shaped inputs keep their logical coordinates).  The engine falls back to the
+ * padded layout by itself where a random stream or an output is indexed by the padded row (element dropouts, raw-embedding inputs,
+ * rope_range, the token-level head) and for packed rows.  gget_hidden_states refuses after a var-len forward.
+ * gget_varlen_status: out[0] = 1 if the last forward ran var-len, out[1] = rows it ran on, out[2] = 1 if sum(key lengths) on the
+ * device differed from n_real_tokens (results are then invalid: the caller's count was wrong); synchronises the stream. */
+int gget_set_token_count(gget_handle_t h, int64_t n_real_tokens);
+int gget_varlen_status(gget_handle_t h, int32_t out[3], void* stream);
+
 /* replaces: `embed_pdrop` / `mlp_pdrop` of the config + model.train()/eval(): nn.Dropout on the gathered token embeddings
  * (modeling_helpers.py:96-98) and the two dropouts of the decoder MLP - on act(gate)*up and on down_proj's output
  * (utils_graphgpt.py:69-80) - for the NEXT forward and its backward, keyed by the seed of gget_set_dropout; zeros (default)
@@ -257,13 +272,23 @@ int gget_hidden_states(gget_handle_t h, const void** hidden_dev);
 #define GGET_EPI_GEGLU_BWD 6 /* dh = dy W_down with the gated-GELU backward fused into the epilogue (gget_op_down_dgrad_geglu) */
 int gget_op_gemm(int mode, int epilogue, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
                  int lda, int ldb, int ldc, int split_k, void* stream);
+/* the same contraction with stream-K allowed (csrc/gemm.h): `streamk_ws` = gget_op_gemm_streamk_bytes() of device memory zeroed ONCE by
+ * the caller and reusable by later calls on the same stream; launches whose tile count is no multiple of the CU count then cut the
+ * K range of their boundary tiles between neighbouring workgroups (fp32 partial tiles through the workspace).  The engine does this
+ * by itself with a slice of its workspace arena. */
+int gget_op_gemm_streamk(int mode, int epilogue, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
+                         int lda, int ldb, int ldc, void* streamk_ws, void* stream);
+uint64_t gget_op_gemm_streamk_bytes(void);
 /* up to 4 independent GEMMs of one mode in ONE persistent launch (plain bf16 epilogue): how the engine issues the four
  * weight gradients of a decoder layer (dW = dY^T X for gate|up, down, q|k|v, o: hf LlamaMLP / LlamaAttention Linear backward) -
  * exactly 256 tiles of 192x192 for d = 768, one per CU */
 int gget_op_gemm_grouped(int mode, int count, const void* const* A, const void* const* B, void* const* C, const int* M,
                          const int* N, const int* K, const int* lda, const int* ldb, const int* ldc, void* stream);
-/* measurement knob (tools/ only; no reference counterpart): key 1 = bit mask selecting experimental GEMM kernel variants,
- * so that two variants can be timed interleaved in one process (0 = the shipped configuration) */
+/* measurement knob (tools/ and tests; no reference counterpart).  key 1 = bit mask that switches GEMM kernel variants OFF, so that
+ * two selections can be timed interleaved in one process or pinned to the same summation order (0 = the shipped selection): 1 K-split
+ * kernel for one-round N = d launches, 2 K-split kernel for the grouped weight gradients, 4 the 192-row tiles, 8 the split of the
+ * last round, 16 the 64- / 96-row tiles of the K-split kernel.  key 2 = LDS headroom of the 128x192 tile (0: 4-slot ring).
+ * key 3 = 1: split the K range of the last, partial round's tiles among the idle workgroups (off by default). */
 int gget_debug_set(int key, int value);
 /* measurement aid: with enable != 0 the engine brackets, with HIP events on the launch stream, the grouped weight-gradient launch
  * (avg_ms_out[0]) and the gate|up + GEGLU launch (avg_ms_out[1]) of every layer of the following forward / backward calls;

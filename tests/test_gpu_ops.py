@@ -95,6 +95,49 @@ def test_gemm_tile_128x192(lib, mode, M, N, K):
     assert rel_l2(Cm.float().cpu().numpy(), ref.cpu().numpy()) < 4e-3
 
 
+@pytest.mark.parametrize("mode", [L.GEMM_NT, L.GEMM_NN])
+@pytest.mark.parametrize("M,N,K,res", [(5696, 768, 3072, True), (5696, 768, 2304, False), (5632, 768, 6144, False), (5700, 768, 3072, True),
+                                       (41000, 768, 3072, False), (3000, 768, 2048, True), (9000, 768, 1536, False), (10900, 768, 3072, True),
+                                       (12000, 768, 2304, False), (1000, 768, 1536, True), (8192, 768, 3072, True), (6100, 384, 1536, False)])
+def test_gemm_stream_k(lib, mode, M, N, K, res):  # (name kept: the split of the last round grew out of a stream-K schedule)
+    """Row counts that are no multiple of the tile grid - the shapes the var-len token layout produces (M = a batch's real tokens).
+    (a) plain entry point: one-round N = d launches take the K-split kernel with 64 / 96 / 128 rows per tile, whichever fills the CUs
+    best (csrc/gemm.hip launch_t), ragged last tile included; (b) gget_op_gemm_streamk with the split of the last round switched on (gget_debug_set key 3): the last,
+    partial round splits its tiles' K range among the idle workgroups (fp32 partial tiles through the workspace, agent-scope
+    release / acquire) - the result must be the plain kernel's up to fp32 summation order, repeatedly (the workspace is reused launch
+    after launch: the flag epochs keep the launches apart), and exact against an fp32 matmul within the bf16 output rounding."""
+    A = rnd(M, K, seed=51)
+    B = rnd(N, K, seed=52) if mode == L.GEMM_NT else rnd(K, N, seed=52)
+    R = rnd(M, N, seed=53) if res else None
+    ref = A.float() @ (B.float().T if mode == L.GEMM_NT else B.float()) + (R.float() if res else 0)
+    epi = L.EPI_RESIDUAL if res else L.EPI_NONE
+    ldb = K if mode == L.GEMM_NT else N
+    plain = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.gget_op_gemm(mode, epi, P(A), P(B), P(plain), P(R) if res else None, M, N, K, K, ldb, N, 1, ST()))
+    assert rel_l2(plain.float().cpu().numpy(), ref.cpu().numpy()) < 4e-3
+    ws = torch.zeros(int(lib.gget_op_gemm_streamk_bytes()), dtype=torch.uint8, device="cuda")
+    outs = []
+    L.check(lib.gget_debug_set(3, 1))            # split the last round (off by default)
+    L.check(lib.gget_debug_set(1, 1))            # ... on the plain 128-row persistent tile (the K-split kernel takes one-round launches otherwise)
+    try:
+        for it in range(3):
+            Cm = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+            L.check(lib.gget_op_gemm_streamk(mode, epi, P(A), P(B), P(Cm), P(R) if res else None, M, N, K, K, ldb, N, P(ws), ST()))
+            outs.append(Cm)
+        torch.cuda.synchronize()
+    finally:
+        L.check(lib.gget_debug_set(3, 0))
+        L.check(lib.gget_debug_set(1, 0))
+    err_flag = int(ws[512 * 4: 512 * 4 + 4].view(torch.int32)[0])
+    assert err_flag == 0, "a stream-K owner gave up waiting for its contributor"
+    for Cm in outs:
+        assert rel_l2(Cm.float().cpu().numpy(), ref.cpu().numpy()) < 4e-3
+        d = (Cm.float() - plain.float()).abs()
+        # same products, another fp32 summation order in the split tiles: isolated one-ulp bf16 differences at most
+        assert float(d.max()) <= 2.0 ** -6 * float(plain.float().abs().max()) and float((d > 0).float().mean()) < 0.05
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])        # deterministic: fixed split, fixed order
+
+
 @pytest.mark.parametrize("M,N,K", [(1536, 768, 2048), (768, 3072, 1024), (768, 768, 8192), (6144, 768, 512)])
 def test_gemm_tn_tile_192x192(lib, M, N, K):
     # weight-gradient shapes (M, N multiples of 192) take the 192x192 persistent TN tile when it fills the chip better

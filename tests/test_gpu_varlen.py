@@ -1,0 +1,231 @@
+"""Var-len (padding-free) token layout of the engine (include/gget.h: gget_set_token_count) against the padded layout and the
+reference fixtures.  The reference runs every token-wise module over the padded [B,S] grid (modeling_helpers.py:38-64) - pad
+rows never influence real rows - so the two layouts must agree on every reference-visible output: loss, head logits, task
+logits, every gradient.  Not bit-wise: a different row count selects other GEMM tile shapes / K splits (fp32 summation order),
+whose differences surface as isolated bf16 rounding flips; the tolerances below are a tenth of the bf16-class tolerances the
+padded path is held to against the fp32 reference."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from _util import FT_CASES, PT_CASES, ft_problem, load_case, loss_tolerance, record_error, rel_l2, tb
+
+pytestmark = pytest.mark.gpu
+
+eng_mod = importlib.import_module("graph-gpt_amd.engine")
+L = importlib.import_module("graph-gpt_amd._lib")
+spec_mod = importlib.import_module("graph-gpt_amd.spec")
+weights_mod = importlib.import_module("graph-gpt_amd.weights")
+synth = importlib.import_module("graph-gpt_amd.synth")
+
+
+def _forward(e, spec, b, kind, name, n_tok):
+    if kind == "pt":
+        return e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], b.get("wgt"), num_tokens=n_tok), None
+    pt_, lt_ = ft_problem(spec, b, name)
+    problem = {"regression": L.PROBLEM_REGRESSION_L1 if lt_ == "l1" else L.PROBLEM_REGRESSION_MSE,
+               "multi_label_classification": L.PROBLEM_MULTI_LABEL, "single_label_classification": L.PROBLEM_SINGLE_LABEL}[pt_]
+    loss, logits, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], b.get("wgt"), problem,
+                                     num_tokens=n_tok)
+    return loss, logits
+
+
+def _run(spec, state, batch, kind, name, varlen, dropout=None, seed=77):
+    b = tb(batch)
+    B, S = batch["input_ids"].shape[:2]
+    e = eng_mod.Engine(spec, max_tokens=B * S, max_batch=B)
+    e.load_state_dict(state)
+    if dropout:
+        e.set_dropout(dropout[0], dropout[1], seed)
+    n_tok = int(batch["attention_mask"].sum()) if varlen else None
+    loss, tlog = _forward(e, spec, b, kind, name, n_tok)
+    e.backward()
+    torch.cuda.synchronize()
+    ran, rows, mismatch = e.varlen_status()
+    out = {"loss": float(loss.item()), "grads": {k: v.float().cpu().numpy().copy() for k, v in e.grads().items()},
+           "varlen": ran, "rows": rows, "mismatch": mismatch}
+    if kind == "pt":
+        out["logits"] = e.head_logits().float().cpu().numpy()
+    else:
+        out["logits"] = tlog.cpu().numpy().copy()
+    return out
+
+
+def _compare(name, a, b, loss_tol=2e-5, logit_tol=3e-3, grad_tol=6e-3):
+    """a: padded, b: var-len"""
+    assert abs(a["loss"] - b["loss"]) <= loss_tol * abs(a["loss"]) + 1e-7, f"{name}: loss {a['loss']} (padded) vs {b['loss']} (var-len)"
+    record_error(name, "varlen_vs_padded_loss_rel", abs(a["loss"] - b["loss"]) / (abs(a["loss"]) + 1e-30), loss_tol)
+    assert a["logits"].shape == b["logits"].shape
+    err = rel_l2(b["logits"], a["logits"])
+    record_error(name, "varlen_vs_padded_logits_rel_l2", err, logit_tol)
+    assert err < logit_tol, f"{name}: logits rel-L2 {err}"
+    gmax = max(float(np.linalg.norm(v)) for v in a["grads"].values())
+    worst = (0.0, "")
+    for k, ga in a["grads"].items():
+        gb = b["grads"][k]
+        scale = max(float(np.linalg.norm(ga)), 1e-2 * gmax)
+        err = float(np.linalg.norm(ga.astype(np.float64) - gb)) / scale
+        worst = max(worst, (err, k))
+    record_error(name, "varlen_vs_padded_worst_grad_rel_l2 (" + worst[1] + ")", worst[0], grad_tol)
+    assert worst[0] < grad_tol, f"{name}: gradient {worst[1]} differs by {worst[0]} between the layouts"
+
+
+@pytest.mark.parametrize("name", [c for c in PT_CASES + FT_CASES if c != "pt_tiny_packed"])
+def test_varlen_matches_padded_and_reference_on_fixtures(name):
+    """Every reference fixture with right padding: the var-len run reproduces the padded run AND sits within the padded path's
+    own tolerance of the reference's fp32 loss."""
+    z, spec, state, batch = load_case(name)
+    kind = "pt" if name.startswith("pt") else "ft"
+    pad = _run(spec, state, batch, kind, name, varlen=False)
+    vl = _run(spec, state, batch, kind, name, varlen=True)
+    B, S = batch["input_ids"].shape[:2]
+    n_tok = int(batch["attention_mask"].sum())
+    assert not pad["varlen"] and pad["rows"] == B * S
+    if (n_tok + 63) // 64 * 64 < B * S:
+        assert vl["varlen"] and vl["rows"] == (n_tok + 63) // 64 * 64 and not vl["mismatch"]
+    else:
+        assert not vl["varlen"]          # nothing to gain: the engine keeps the padded rows
+    _compare(name, pad, vl)
+    want = float(z["loss"])
+    from test_gpu_model import FT_FACTOR, LOSS_FLOOR
+    tol = max(loss_tolerance(z, factor=1.5 if kind == "pt" else FT_FACTOR), LOSS_FLOOR.get(name, 0.0))
+    assert abs(vl["loss"] - want) <= tol * abs(want) + 1e-6, f"{name}: var-len loss {vl['loss']} vs reference fp32 {want}"
+
+
+def _tiny_spec(kind, S, causal=False, layer_scale=0.0, path_pdrop=0.0, F=4, V=500, layers=2):
+    return spec_mod.ModelSpec(kind=kind, vocab_size=V, hidden_size=128, intermediate_size=512, num_layers=layers, num_heads=2,
+                              head_dim=64, stacked_feat=F, next_n_token=F if kind == spec_mod.KIND_PRETRAIN else 1, gated_agg=False,
+                              causal=causal, max_position=max(1024, S), num_labels=2, score_bias=False, pad_token_id=0,
+                              layer_scale_init=layer_scale, path_pdrop=path_pdrop)
+
+
+@pytest.mark.parametrize("S,B,causal", [(24, 12, False), (32, 64, False), (72, 6, False), (160, 5, True), (256, 6, False), (320, 4, True),
+                                         (640, 3, False), (1088, 2, False)])
+@pytest.mark.parametrize("kind", ["pt", "ft"])
+def test_varlen_every_attention_kernel_class(kind, S, B, causal):
+    """S <= 32 (one-wave kernels), 32 < S < 256 (multi-wave register-prefetch kernels), S >= 256 (64-row LDS-DMA stages; the dense
+    pipelined forward from S = 512 when not causal; 128-row dK/dV stages from S = 512), with attention dropout 0.1 (the masks are
+    hashes of the LOGICAL (b, h, q, k) coordinates, so both layouts draw the same one), ragged lengths incl. very short samples."""
+    pt = kind == "pt"
+    spec = _tiny_spec(spec_mod.KIND_PRETRAIN if pt else spec_mod.KIND_TASK, S, causal=causal)
+    state = weights_mod.make_state_dict(spec, seed=3, std=0.06, head_std=0.15)
+    if pt:
+        batch = synth.make_pretrain_batch(B=B, S=S, F=4, V=500, seed=11 + S, lengths="uniform", min_len=max(2, S // 8))
+    else:
+        batch = synth.make_task_batch(B=B, S=S, F=4, V=500, seed=13 + S, lengths="uniform", min_len=max(2, S // 8))
+    batch = {k: v for k, v in batch.items() if k != "lengths"}
+    name = f"varlen_{kind}_S{S}{'_causal' if causal else ''}"
+    pad = _run(spec, state, batch, kind, "", varlen=False, dropout=(0.1, 0.0))
+    vl = _run(spec, state, batch, kind, "", varlen=True, dropout=(0.1, 0.0))
+    assert vl["varlen"] and not vl["mismatch"] and vl["rows"] < B * S
+    _compare(name, pad, vl)
+
+
+def test_varlen_layerscale_droppath_training_mode():
+    """The ogbl-ppa fine-tune form (LayerScale 1.0, stochastic depth 0.2, attention dropout 0.1; examples/edge_lvl/ppa_supervised.sh):
+    DropPath draws one decision per SAMPLE - the compact rows carry their sample index - so both layouts drop the same branches."""
+    S, B = 96, 24
+    spec = _tiny_spec(spec_mod.KIND_TASK, S, layer_scale=1.0, path_pdrop=0.2, layers=3)
+    state = weights_mod.make_state_dict(spec, seed=5, std=0.06, head_std=0.15)
+    batch = {k: v for k, v in synth.make_task_batch(B=B, S=S, F=4, V=500, seed=21, lengths="uniform", min_len=8).items() if k != "lengths"}
+    pad = _run(spec, state, batch, "ft", "", varlen=False, dropout=(0.1, 0.2), seed=1234)
+    vl = _run(spec, state, batch, "ft", "", varlen=True, dropout=(0.1, 0.2), seed=1234)
+    assert vl["varlen"]
+    _compare("varlen_ft_layerscale_droppath", pad, vl)
+    # the mask is really applied: another seed moves the loss
+    other = _run(spec, state, batch, "ft", "", varlen=True, dropout=(0.1, 0.2), seed=99)
+    assert abs(other["loss"] - vl["loss"]) > 1e-5
+
+
+def test_varlen_wrong_token_count_is_flagged_and_fallbacks():
+    """A caller's count that disagrees with the mask raises the device-side flag (gget_varlen_status); element dropouts, the
+    token-level head and full rows keep the padded layout by themselves."""
+    spec = _tiny_spec(spec_mod.KIND_PRETRAIN, 32)
+    state = weights_mod.make_state_dict(spec, seed=3)
+    batch = synth.make_pretrain_batch(B=16, S=32, F=4, V=500, seed=5)
+    b = tb({k: v for k, v in batch.items() if k != "lengths"})
+    e = eng_mod.Engine(spec, max_tokens=16 * 32, max_batch=16)
+    e.load_state_dict(state)
+    n = int(batch["attention_mask"].sum())
+    e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], num_tokens=n - 3)
+    assert e.varlen_status() == (True, (n - 3 + 63) // 64 * 64, True)
+    e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], num_tokens=n)
+    assert e.varlen_status() == (True, (n + 63) // 64 * 64, False)
+    with pytest.raises(L.GgetError):
+        e.hidden_states(16, 32)                      # compact rows: the [B,S,d] view does not exist
+    e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"])           # no count -> padded
+    assert e.varlen_status()[0] is False
+    e.hidden_states(16, 32)
+    e.forward_pretrain(b["input_ids"], b["attention_mask"], None, num_tokens=n)    # full-logit inference -> padded rows
+    assert e.varlen_status()[0] is False
+    full = torch.ones_like(b["attention_mask"])
+    e.forward_pretrain(b["input_ids"], full, b["labels"], num_tokens=16 * 32)       # no padding -> nothing to compact
+    assert e.varlen_status()[0] is False
+    e.set_dropout_ex(0.1, 0.0, 0.0)                                                 # element dropout hashes the padded row index
+    e.set_dropout(0.0, 0.0, 5)
+    e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], num_tokens=n)
+    assert e.varlen_status()[0] is False
+
+
+def test_varlen_model_classes_and_training_step(monkeypatch):
+    """Through the drop-in classes: a HOST-side attention mask (what the reference's loops receive from the DataLoader) or
+    data["num_tokens"] selects the var-len layout; three clip + AdamW steps track the padded run."""
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    tr = importlib.import_module("graph-gpt_amd.training")
+    cfg = dict(hidden_act="gelu", vocab_size=756, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+               max_position_embeddings=1024, causal_attention=False, stacked_feat=13, next_n_token=13)
+    batch = synth.make_pretrain_batch(B=32, S=32, F=13, V=756, seed=8)
+    n = synth.real_tokens(batch)
+    host = {k: torch.from_numpy(v) for k, v in batch.items() if k != "lengths"}
+    dev = {k: v.cuda() for k, v in host.items()}
+
+    def run(data):
+        model = M.GraphGPTPretrainBase(M.GraphGPTConfig(**cfg), seed=1).cuda().eval()
+        eng = tr.initialize(model, tr.OptimConfig(lr=1e-3, max_grad_norm=1.0))
+        losses = [float(tr.batch_training(data, eng)) for _ in range(3)]
+        torch.cuda.synchronize()
+        return losses, model._engine.varlen_status()[0], model._engine.master.detach().cpu().numpy().copy()
+
+    lp, vp, mp = run(dev)                                   # device mask, no count: padded
+    lh, vh, mh = run(host)                                  # host mask: counted for free
+    ln, vn, mn = run(dict(dev, num_tokens=n))               # explicit count
+    assert (vp, vh, vn) == (False, True, True)
+    np.testing.assert_allclose(lh, lp, rtol=5e-4)
+    np.testing.assert_allclose(ln, lp, rtol=5e-4)
+    np.testing.assert_array_equal(mh, mn)                   # the two var-len runs are the same computation
+    upd = np.linalg.norm(mp - M.GraphGPTPretrainBase(M.GraphGPTConfig(**cfg), seed=1).cuda()._engine.master.detach().cpu().numpy())
+    assert np.linalg.norm(mh - mp) < 0.05 * upd
+    monkeypatch.setenv("GGET_VARLEN", "0")
+    assert run(host)[1] is False
+    monkeypatch.setenv("GGET_VARLEN", "sync")
+    assert run(dev)[1] is True
+
+
+def test_varlen_c1_full_size_matches_padded():
+    """BASELINE's headline shape (base d768 / L12, B = 256, S = 32, F = 13, V = 756, attention dropout 0.1): loss and every gradient
+    of the var-len step against the padded step."""
+    spec = spec_mod.spec_from_size("base", kind=spec_mod.KIND_PRETRAIN, vocab_size=756, stacked_feat=13, next_n_token=13, causal=False,
+                                   max_position=1024)
+    state = weights_mod.make_state_dict(spec, seed=0)
+    batch = {k: v for k, v in synth.make_pretrain_batch(B=256, S=32, F=13, V=756, seed=1234).items() if k != "lengths"}
+    lib = L.load()
+    try:
+        # (i) both layouts on the SAME summation orders (no in-block K split, no stream-K, 256-row tiles only: gget_debug_set key 1):
+        # every real row then goes through identical arithmetic, so the forward must agree bit for bit - any difference would be an
+        # indexing error of the compact layout, not rounding
+        L.check(lib.gget_debug_set(1, 1 | 2 | 4 | 8))
+        pad = _run(spec, state, batch, "pt", "", varlen=False, dropout=(0.1, 0.0))
+        vl = _run(spec, state, batch, "pt", "", varlen=True, dropout=(0.1, 0.0))
+        assert vl["varlen"] and vl["rows"] < 0.8 * 256 * 32
+        assert np.array_equal(pad["logits"], vl["logits"]), "head logits of the two layouts differ with identical kernels"
+        _compare("varlen_c1_full_size_same_kernels", pad, vl, loss_tol=2e-6, logit_tol=1e-9, grad_tol=2e-3)
+    finally:
+        L.check(lib.gget_debug_set(1, 0))
+    # (ii) the shipped kernel selection (192-row tiles, stream-K, K-split kernels differ between the layouts): bf16-class agreement - at
+    # the standard init the logits carry ~1e-2 of bf16 noise against fp32 in EITHER layout (tests/test_gpu_model.py holds the padded
+    # path to max(2.5 x reference bf16 error, 1.5e-2)), and two summation orders draw two noise patterns
+    pad = _run(spec, state, batch, "pt", "", varlen=False, dropout=(0.1, 0.0))
+    vl = _run(spec, state, batch, "pt", "", varlen=True, dropout=(0.1, 0.0))
+    _compare("varlen_c1_full_size", pad, vl, loss_tol=5e-5, logit_tol=1.5e-2, grad_tol=3e-2)

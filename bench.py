@@ -250,6 +250,28 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # N > 1: how much of the step is gradient exchange the backward does not hide - the same K steps once more (outside the reported
+    # time) with the collectives switched off (GgetEngine.exchange = False: identical kernels on the compute stream, nothing on the
+    # side stream), max over ranks; exposed = reported step - that.  The replicas drift apart in these steps: they come last.
+    dp_info = None
+    if world > 1:
+        engine.exchange = False
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt_nox = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+        dist.all_reduce(dt_nox, op=dist.ReduceOp.MAX)
+        engine.exchange = True
+        dp_info = engine.describe_dp()
+        dp_info["ms_per_step_without_exchange"] = float(dt_nox[0]) / a.steps * 1e3
     # the dominant kernels' launch durations INSIDE a step: three more (untimed) steps with HIP events around those launches, on the
     # stream they run on (single process only - the extra steps would otherwise need every rank)
     in_step = {}
@@ -327,6 +349,9 @@ def main():
                           "token_layout": "varlen" if ran_varlen else "padded", "rows": t_rows, "padded_rows": B * S},
             "roofline": roofline,
         }
+        if dp_info is not None:
+            dp_info["exposed_comm_ms"] = ms - dp_info["ms_per_step_without_exchange"]
+            out["dp"] = dp_info
         if world == 1 and not a.no_cpu_baseline and kind == "pt":
             state = weights.make_state_dict(spec, seed=0)
             out["cpu_baseline"] = cpu_baseline(spec, state, B, S, F, V, 1234, min(os.cpu_count() or 1, 32))

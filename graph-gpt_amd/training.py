@@ -167,6 +167,9 @@ class GgetEngine:
         # torch.distributed on the data path; the unique id travels once over the existing process group).
         self.fp32_reduce = bool(int(os.environ.get("GGET_DP_FP32_REDUCE", "0")))
         self.abi_comm = os.environ.get("GGET_DP_BACKEND", "torch") == "abi"
+        # measurement switch (bench.py `dp.exposed_comm_ms`): False runs the same staged backward WITHOUT issuing the collectives -
+        # the ranks then drift apart, so it is only ever set for a few untimed-for-throughput diagnostic steps
+        self.exchange = True
         model.materialize_grads = False  # fused path: gradients stay in the flat bf16 arena
         model._managed_by_engine = True  # the bucketed exchange below replaces the all-reduce of _autograd_backward
 
@@ -205,6 +208,8 @@ class GgetEngine:
             return
         if not self.overlap:
             e.backward()
+            if not self.exchange:
+                return
             if self.abi_comm:
                 e.allreduce_grads_async(-1, self.fp32_reduce)
             elif self.world > 1:
@@ -221,7 +226,9 @@ class GgetEngine:
             ev.record(main)
             self._comm_stream.wait_event(ev)
             with torch.cuda.stream(self._comm_stream):
-                if self.abi_comm:   # RCCL through the C ABI on the side stream (works at world 1 too: a one-rank communicator)
+                if not self.exchange:
+                    self._pending.append(None)
+                elif self.abi_comm:   # RCCL through the C ABI on the side stream (works at world 1 too: a one-rank communicator)
                     e.allreduce_grads_async(b, self.fp32_reduce, self._comm_stream)
                     self._pending.append(None)
                 elif self.world > 1:
@@ -237,6 +244,21 @@ class GgetEngine:
             reduce_bucket(L_ - i)
         e.backward_end()
         reduce_bucket(L_ + 1)
+
+    def describe_dp(self) -> Dict[str, Any]:
+        """What the data-parallel exchange of this engine looks like (bench.py prints it on N > 1 lines)."""
+        e = self.module._engine
+        backend = "none" if self.world == 1 else (dist.get_backend(self.pg) if dist.is_initialized() else "none")
+        info = {"world": self.world, "backend": ("rccl-via-c-abi" if self.abi_comm else f"torch.distributed/{backend}"),
+                "n_buckets": len(e.buckets) if e is not None else None, "overlap_with_backward": bool(self.overlap),
+                "reduce_dtype": "fp32" if self.fp32_reduce else "bf16",
+                "bucket_mb": [round(c * 2 / 2 ** 20, 1) for _, c in e.buckets] if e is not None else None}
+        try:
+            v = torch.cuda.nccl.version()
+            info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+        except Exception:
+            info["rccl_version"] = None
+        return info
 
     def step(self):
         e = self.module._engine

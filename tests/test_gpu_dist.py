@@ -186,3 +186,30 @@ def test_bf16_vs_fp32_bucket_reduction_drift_world8():
     with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "dp_reduce_drift.json"), "w") as fh:
         json.dump({"world": 8, "grad_rel_l2_bf16_ring_vs_fp32": rel, "grad_rel_l2_single_rounding": rel_exact,
                    "param_update_rel_l2_drift_after_one_adamw_step": drift}, fh)
+
+
+def test_bench_two_ranks_gloo_smoke():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), on ONE GPU over gloo
+    (GGET_BENCH_BACKEND=gloo: RCCL refuses two ranks on a device): the N > 1 line must carry the whole-job value, weak scaling and the
+    `dp` diagnostics (bucket layout, step time without the exchange, exposed communication)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GGET_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", "toy-tiny", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["value"] > 0
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"]
+    dp = d["dp"]
+    assert dp["world"] == 2 and dp["n_buckets"] == 2 + 2 and dp["backend"].endswith("gloo") and dp["overlap_with_backward"] is True
+    assert dp["ms_per_step_without_exchange"] > 0 and abs(dp["exposed_comm_ms"] - (d["ms_per_step"] - dp["ms_per_step_without_exchange"])) < 1e-9
+    assert np.isfinite(d["smtp_loss"])

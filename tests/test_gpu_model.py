@@ -562,19 +562,57 @@ def _c1_engine_and_batch(seed=77, size="base"):
     return spec, state, batch, e
 
 
+@pytest.mark.parametrize("layout", ["padded", "varlen"])
 @pytest.mark.parametrize("size", ["base", "base24"])
-def test_c1_full_size_loss_matches_oracle(size):
+def test_c1_full_size_loss_matches_oracle(size, layout):
     """BASELINE configs[1] (base d768/L12) and configs[2] (base24, 24 layers) at full size (B=256, S=32, F=13, V=756): SMTP loss of the HIP forward against the
     oracle forward on the same bf16-rounded weights (tolerance: north_star's 1e-4 relative is for same-cast-point fp32
-    arithmetic; the 12-layer bf16 path is held to 3e-4, the reference's own bf16-vs-fp32 gap on the fixtures is 1.3e-4)."""
+    arithmetic; the 12-layer bf16 path is held to 3e-4, the reference's own bf16-vs-fp32 gap on the full-width fixtures is 1e-5 ...
+    1.3e-4), on the padded grid and on the var-len token layout the bench runs (include/gget.h: gget_set_token_count)."""
     spec, state, batch, e = _c1_engine_and_batch(size=size)
     b = tb(batch)
-    loss, _ = run_forward(e, spec, b, "pt")
+    n_tok = int(batch["attention_mask"].sum()) if layout == "varlen" else None
+    loss = e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], b.get("wgt"), num_tokens=n_tok)
+    assert e.varlen_status()[0] == (layout == "varlen")
     st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
     p = O.to_params(st_bf, torch.float32, requires_grad=False)
     with torch.no_grad():
         want = O.pretrain_forward(spec, p, b["input_ids"], b["attention_mask"], b["labels"])["head1_loss"].item()
+    record_error(f"c1_full_size_{size}_{layout}", "loss_rel_vs_oracle (B=256, S=32)", abs(float(loss) - want) / abs(want), 3e-4)
     assert abs(float(loss) - want) <= 3e-4 * abs(want), (float(loss), want)
+
+
+@pytest.mark.parametrize("layout", ["padded", "varlen"])
+def test_c1_full_size_backward_matches_oracle(layout):
+    """The headline configuration at FULL size (base d768 / L12, B = 256, S = 32, F = 13, V = 756: one oracle fwd + bwd, ~6 s on the
+    box's host cores): loss and the gradients of ten tensors spread over the stack - embedding, first / middle / last layer
+    attention and MLP projections, a norm weight, n_token_proj and lm_head - against the oracle, on both token layouts."""
+    spec, state, batch, e = _c1_engine_and_batch(size="base", seed=79)
+    b = tb(batch)
+    n_tok = int(batch["attention_mask"].sum()) if layout == "varlen" else None
+    loss = e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], b.get("wgt"), num_tokens=n_tok)
+    e.backward()
+    torch.cuda.synchronize()
+    st_bf = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+    p = O.to_params(st_bf, torch.float32)
+    fn, lk, _ = oracle_fn(spec, b, "pt")
+    out, grads = O.loss_and_grads(fn, p, lk)
+    want = out[lk].item()
+    tag = f"c1_full_size_backward_{layout}"
+    record_error(tag, "loss_rel_vs_oracle", abs(float(loss) - want) / abs(want), 3e-4)
+    assert abs(float(loss) - want) <= 3e-4 * abs(want), (float(loss), want)
+    got = e.grads()
+    gmax = max(float(g.norm()) for g in grads.values())
+    for k in ("model.embed_tokens.weight", "model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.v_proj.weight",
+              "model.layers.0.mlp.gate_proj.weight", "model.layers.5.self_attn.o_proj.weight", "model.layers.5.mlp.down_proj.weight",
+              "model.layers.5.post_attention_layernorm.weight", "model.layers.11.self_attn.k_proj.weight",
+              "model.layers.11.mlp.up_proj.weight", "n_token_proj.weight", "lm_head.weight"):
+        w = grads[k].numpy()
+        # (standard init: q / k gradients are ~1e-3 of the largest - near-uniform attention - and sit at the bf16 noise floor of the
+        #  signal that feeds them: tensors below 1 % of the largest norm are judged on that scale, like test_backward_matches_oracle)
+        err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
+        record_error(tag, "grad_rel_l2 " + k, err, 6e-2)
+        assert err < 6e-2, f"{k}: {err}"
 
 
 def test_c1_full_size_properties():
@@ -616,6 +654,13 @@ def test_c1_full_size_properties():
     assert float((e.grad_bf16.float() - g0).norm() / g0.norm()) < 1e-3
 
 
+def _ft_loss_tol(fixture):
+    """Loss tolerance of the full-width fine-tune checks against the ORACLE: max(1e-4, 2 x the gap between the reference's own bf16
+    and fp32 losses on the reference fixture of the same architecture and sequence length (tools/make_golden.py ft_base_*))."""
+    z = np.load(__import__("os").path.join(__import__("_util").GOLDEN, fixture + ".npz"))
+    return loss_tolerance(z, factor=FT_FACTOR)
+
+
 def test_c4_long_sequence_full_model_matches_oracle():
     """The longest configuration of BASELINE.json (C4: base model, S = 2048, F = 4, V = 41245) at a batch the CPU oracle
     finishes in seconds (B = 2): fine-tune loss and logits of the full 12-layer HIP forward (4-wave attention kernels over 64
@@ -637,8 +682,10 @@ def test_c4_long_sequence_full_model_matches_oracle():
         out = fn(p)
     want = out[gk].float().numpy()
     got = logits.float().cpu().numpy()
+    ltol = _ft_loss_tol("ft_base_s2048")
+    record_error("c4_S2048_B2_forward", "loss_rel_vs_oracle", abs(float(loss) - out[lk].item()) / max(abs(out[lk].item()), 0.1), ltol)
     assert np.abs(got - want).max() <= 3e-2 * max(1.0, np.abs(want).max()), (got, want)
-    assert abs(float(loss) - out[lk].item()) <= 3e-2 * max(abs(out[lk].item()), 0.1)
+    assert abs(float(loss) - out[lk].item()) <= ltol * max(abs(out[lk].item()), 0.1)
 
 
 def test_c3_shape_full_model_backward_matches_oracle():
@@ -661,7 +708,9 @@ def test_c3_shape_full_model_backward_matches_oracle():
     p = O.to_params(st_bf, torch.float32)
     fn, lk, _ = oracle_fn(spec, b, "ft")
     out, grads = O.loss_and_grads(fn, p, lk)
-    assert abs(float(loss) - out[lk].item()) <= 3e-2 * max(abs(out[lk].item()), 0.1)
+    ltol = _ft_loss_tol("ft_base_ls_s256")
+    record_error("c3_S256_B8_backward", "loss_rel_vs_oracle", abs(float(loss) - out[lk].item()) / max(abs(out[lk].item()), 0.1), ltol)
+    assert abs(float(loss) - out[lk].item()) <= ltol * max(abs(out[lk].item()), 0.1)
     got = e.grads()
     gmax = max(float(g.norm()) for g in grads.values())
     for k in ("score.weight", "model.layers.11.mlp.down_proj.weight", "model.layers.6.self_attn.q_proj.weight",
@@ -694,6 +743,60 @@ def test_module_moves_after_engine_and_position_guard():
     assert torch.isfinite(out.task_loss)
     with pytest.raises(IndexError):
         m(input_ids=ids, attention_mask=att, position_ids=pos + 60, task_labels=y)
+
+
+@pytest.mark.parametrize("layout", ["padded", "varlen"])
+@pytest.mark.parametrize("name", ["ft_base_ls_s256", "ft_base_s2048"])
+def test_full_width_finetune_matches_reference(name, layout):
+    """BASELINE's fine-tune configurations at full width and full sequence length against outputs of the REAL reference at a small
+    batch (tools/make_golden.py): C3 = ogbl-ppa form (base model, LayerScale 1.0, S = 256, V = 41245, B = 4) and C4 (S = 2048, B =
+    2).  The loss tolerance is derived, not a constant: max(1e-4, 2 x the reference's own bf16-vs-fp32 loss gap on the case) - 2.1e-3
+    for C3, 1.5e-2 for C4 (the 3e-2 of round 2 was 3-30x wider than anything measured).  Pooled logits, every per-parameter gradient
+    norm and 64x64 gradient blocks against the reference's; both token layouts."""
+    z, spec, state, batch = load_case(name)
+    b = tb(batch)
+    e = make_engine(spec, batch)
+    e.load_state_dict(state)
+    n_tok = int(batch["attention_mask"].sum()) if layout == "varlen" else None
+    loss, logits, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], None, L.PROBLEM_SINGLE_LABEL,
+                                     num_tokens=n_tok)
+    e.backward()
+    torch.cuda.synchronize()
+    assert e.varlen_status()[0] == (layout == "varlen")
+    tag = f"{name}_{layout}"
+    got, want = float(loss.item()), float(z["loss"])
+    tol = loss_tolerance(z, factor=FT_FACTOR)
+    record_error(tag, "loss_rel_vs_reference_fp32", abs(got - want) / abs(want), tol)
+    record_error(tag, "reference_bf16_vs_fp32_loss_gap", abs(float(z["loss_bf16"]) - want) / abs(want), float("nan"))
+    assert abs(got - want) <= tol * abs(want), f"{tag}: loss {got} vs reference fp32 {want} (reference bf16 {float(z['loss_bf16'])})"
+    err = np.abs(logits.cpu().numpy() - z["logits"]).max()
+    ref_err = np.abs(z["logits_bf16"] - z["logits"]).max()
+    record_error(tag, "task_logits_max_abs_vs_reference_fp32", err, max(2 * ref_err, 1e-2))
+    assert err < max(2 * ref_err, 1e-2), f"{tag}: task logits max-abs {err} (reference bf16-vs-fp32 {ref_err})"
+    grads = e.grads()
+    names = list(state.keys())
+    gn = np.array([float(grads[n].float().norm()) for n in names])
+    ref, ref_bf = z["grad_norms"], z["grad_norms_bf16"]
+    big = ref >= 1e-3 * ref.max()
+    worst = float(np.max(np.abs(gn[big] - ref[big]) / ref[big]))
+    worst_ref = float(np.max(np.abs(ref_bf[big] - ref[big]) / ref[big]))
+    # (B = 2 ... 4 pooled rows: every gradient carries the common factor softmax(logits) of a handful of samples, which moves with
+    #  the forward's bf16 rounding - the reference's own bf16 backward shows how much)
+    tolg = max(5e-2, 1.5 * worst_ref)
+    record_error(tag, "per_parameter_grad_norm_max_rel (norm >= 1e-3 of the largest)", worst, tolg)
+    record_error(tag, "reference_bf16_vs_fp32 per_parameter_grad_norm_max_rel", worst_ref, float("nan"))
+    assert worst < tolg, [(names[i], gn[i], ref[i]) for i in np.argsort(-np.abs(gn - ref) / np.maximum(ref, 1e-3 * ref.max()))[:4]]
+    for tagb, pn in (("l0_q", "model.layers.0.self_attn.q_proj.weight"), ("l0_k", "model.layers.0.self_attn.k_proj.weight"),
+                     ("l11_q", "model.layers.11.self_attn.q_proj.weight"), ("l11_k", "model.layers.11.self_attn.k_proj.weight"),
+                     ("l5_down", "model.layers.5.mlp.down_proj.weight"), ("l5_gate", "model.layers.5.mlp.gate_proj.weight")):
+        blk = grads[pn].float().cpu().numpy()[:64, :64]
+        ref_blk = z["gradblk_" + tagb]
+        err = rel_l2(blk, ref_blk)
+        ref_err = rel_l2(z["gradblk_bf16_" + tagb], ref_blk)
+        tolb = max(6e-2, 1.5 * ref_err)
+        record_error(tag, f"grad_block_rel_l2_own_norm {pn}[:64,:64]", err, tolb)
+        record_error(tag, f"reference_bf16_vs_fp32 grad_block {pn}[:64,:64]", ref_err, float("nan"))
+        assert err < tolb, f"{tag}: {pn} block rel-L2 {err} (reference bf16 {ref_err})"
 
 
 @pytest.mark.parametrize("name", BASE_CASES)
@@ -779,8 +882,9 @@ def test_c4_long_sequence_full_model_backward_matches_oracle():
     fn, lk, gk = oracle_fn(spec, b, "ft")
     out, grads = O.loss_and_grads(fn, p, lk)
     want = out[lk].item()
-    record_error("c4_S2048_B1_backward", "loss_rel_vs_oracle", abs(float(loss) - want) / max(abs(want), 0.1), 3e-2)
-    assert abs(float(loss) - want) <= 3e-2 * max(abs(want), 0.1), (float(loss), want)
+    ltol = _ft_loss_tol("ft_base_s2048")
+    record_error("c4_S2048_B1_backward", "loss_rel_vs_oracle", abs(float(loss) - want) / max(abs(want), 0.1), ltol)
+    assert abs(float(loss) - want) <= ltol * max(abs(want), 0.1), (float(loss), want)
     got = e.grads()
     gmax = max(float(g.norm()) for g in grads.values())
     # ONE sample, two classes: d loss / d logits = (-p0, p0), so every gradient of the model carries the factor p0 - and p0 comes

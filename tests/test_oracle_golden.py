@@ -63,6 +63,25 @@ def test_oracle_fp32_matches_reference_full_width(name):
         assert rel_l2(grads[pn].numpy()[:64, :64], z["gradblk_" + tag]) < 5e-4, tag
 
 
+@pytest.mark.parametrize("name", ["ft_base_ls_s256", "ft_base_s2048"])
+def test_oracle_fp32_matches_reference_full_width_finetune(name):
+    """BASELINE's fine-tune configurations at full width and full sequence length, small batch (round 3 fixtures): the ogbl-ppa form
+    (base model + LayerScale, S = 256, V = 41245) and the long-sequence form (S = 2048) - oracle loss, pooled logits, per-parameter
+    gradient norms and gradient blocks against the REAL reference."""
+    z, spec, state, batch = load_case(name)
+    b = tb(batch)
+    p = O.to_params(state, torch.float32)
+    fn, lk, gk = _fwd_fn(spec, b, "ft", name)
+    out, grads = O.loss_and_grads(fn, p, lk)
+    assert abs(out[lk].item() - float(z["loss"])) <= 2e-5 * abs(float(z["loss"]))
+    np.testing.assert_allclose(out[gk].detach().float().numpy()[:64], z["logits"], rtol=5e-4, atol=5e-5)
+    gn = np.array([float(grads[n].norm()) for n in state.keys()])
+    np.testing.assert_allclose(gn, z["grad_norms"], rtol=1e-3, atol=1e-7)
+    for tag, pn in (("l0_q", "model.layers.0.self_attn.q_proj.weight"), ("l11_k", "model.layers.11.self_attn.k_proj.weight"),
+                    ("l5_down", "model.layers.5.mlp.down_proj.weight"), ("l5_gate", "model.layers.5.mlp.gate_proj.weight")):
+        assert rel_l2(grads[pn].numpy()[:64, :64], z["gradblk_" + tag]) < 1e-3, tag
+
+
 @pytest.mark.parametrize("name", ["pt_tiny_f13_a", "pt_tiny_bigw", "pt_tiny_s72", "ft_tiny_f4", "ft_tiny_ls"])
 def test_oracle_bf16_tracks_reference_bf16(name):
     z, spec, state, batch = load_case(name)

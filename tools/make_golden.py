@@ -138,6 +138,13 @@ CASES = [
      dict(std=0.06, head_std=0.15, size="base")),
     ("pt_base_std", "pt", dict(vocab_size=756, stacked_feat=13, next_n_token=13), dict(B=4, S=32, seed=19),
      dict(size="base")),
+    # round 3: the fine-tune configurations of BASELINE.json at full width and full sequence length, small batch - C3 (ogbl-ppa: base
+    # model + LayerScale, S = 256, V = 41245) and C4 (S = 2048) - so that their loss tolerances derive from the reference's own
+    # bf16-vs-fp32 gap instead of a constant
+    ("ft_base_ls_s256", "ft", dict(vocab_size=41245, stacked_feat=4, next_n_token=1, num_labels=2, layer_scale_init=1.0),
+     dict(B=4, S=256, seed=20, lengths="uniform", min_len=64), dict(size="base")),
+    ("ft_base_s2048", "ft", dict(vocab_size=41245, stacked_feat=4, next_n_token=1, num_labels=2, max_position=2048),
+     dict(B=2, S=2048, seed=21, lengths="uniform", min_len=1024), dict(size="base")),
 ]
 
 ADAM = dict(lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
@@ -227,7 +234,8 @@ def run_case(name, kind, skw, bkw, ikw, classes):
     out["loss_bf16"] = np.float64(lb.item())
     if big:   # the reference's own bf16 backward: how far a bf16 implementation's gradients sit from the fp32 ones
         mb.zero_grad()
-        fwd(mb).head1_loss.backward()
+        ob2 = fwd(mb)
+        (ob2.head1_loss if kind == "pt" else ob2.task_loss).backward()
         gb = dict(mb.named_parameters())
         for tag, pn in (("l0_q", "model.layers.0.self_attn.q_proj.weight"), ("l0_k", "model.layers.0.self_attn.k_proj.weight"),
                         ("l11_q", "model.layers.11.self_attn.q_proj.weight"), ("l11_k", "model.layers.11.self_attn.k_proj.weight"),

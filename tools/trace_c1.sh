@@ -8,4 +8,5 @@ rocprofv3 --kernel-trace --output-format rocpd -d /tmp/prof_$tag -- python $GRAF
 db=$(find /tmp/prof_$tag -name "*.db" | head -1)
 python $GRAFT_REPO_ROOT/tools/prof_summary.py $db > $GRAFT_REPO_ROOT/gpurun_out/${tag}_trace.txt 2>&1
 python $GRAFT_REPO_ROOT/tools/gap_stats.py $db > $GRAFT_REPO_ROOT/gpurun_out/${tag}_gaps.txt 2>&1
+python $GRAFT_REPO_ROOT/tools/step_seq.py $db > $GRAFT_REPO_ROOT/gpurun_out/${tag}_seq.txt 2>&1
 tail -1 /tmp/prof_$tag.log | cut -c1-300

@@ -87,6 +87,7 @@ SIGNATURES = {
     "gget_set_auc": (i32, [vp, i32, C.c_uint32]),
     "gget_set_token_count": (i32, [vp, C.c_int64]),
     "gget_varlen_status": (i32, [vp, vp, vp]),
+    "gget_position_status": (i32, [vp, vp, vp]),
     "gget_set_focal_gamma": (i32, [vp, f32]),
     "gget_set_stack_method": (i32, [vp, i32]),
     "gget_set_rope_range": (i32, [vp, f32]),

@@ -185,6 +185,7 @@ struct Ws {
   // var-len token layout: first compact row of every sample [max_batch + 1], per compact row its sample index / position / ids, the
   // padded -> compact row map [max_tokens], a status word
   uint64_t vl_cu, vl_rowb, vl_pos, vl_ids, vl_pad2c, vl_status;
+  uint64_t pos_safe;   // position ids clamped into the RoPE table (int64 [max_tokens]); the sticky "clamped" flag is vl_status[1]
   uint64_t sk_ws;      // stream-K GEMM launches: flags + one fp32 partial tile per block (gemm.h)
   uint64_t head_x[6] = {0}, head_a[5] = {0}, head_d[2] = {0};   // MLP head: layer inputs / activations (bf16), fp32 gradient ping-pong
   uint64_t total;
@@ -245,6 +246,7 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.vl_ids = b.take(T * (uint64_t)c.stacked_feat * 8);
   w.vl_pad2c = b.take(T * 4);
   w.vl_status = b.take(256);
+  w.pos_safe = b.take(T * 8);
   w.sk_ws = b.take(gget_gemm_streamk_bytes());
   if (c.embed_dim > 0) {
     const uint64_t e = c.embed_dim;
@@ -590,6 +592,15 @@ extern "C" int gget_set_auc(gget_handle_t h, int num_neg, uint32_t seed) {
 extern "C" int gget_set_token_count(gget_handle_t h, int64_t n_real_tokens) {
   GGET_REQUIRE(h != nullptr, "null handle");
   h->tc_next = n_real_tokens > 0 ? (long)n_real_tokens : -1;
+  return 0;
+}
+
+extern "C" int gget_position_status(gget_handle_t h, int32_t* clamped_out, void* stream) {
+  GGET_REQUIRE(h && clamped_out, "null argument");
+  int32_t* flag = h->wsp<int32_t>(h->ws.vl_status) + 1;
+  GGET_HIP_CHECK(hipMemcpyAsync(clamped_out, flag, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  GGET_HIP_CHECK(hipMemsetAsync(flag, 0, 4, (hipStream_t)stream));
+  GGET_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
 
@@ -1047,6 +1058,11 @@ int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t*
                c.max_tokens, c.max_batch);
   GGET_REQUIRE(S <= c.max_position, "sequence length %d exceeds max_position %d", S, c.max_position);
   h->B = B; h->S = S; h->T = h->TP = B * S;
+  if (pos && !(h->rope_range > 0.f)) {   // (rope_range: angles are evaluated per token from the rescaled positions - no table to overrun)
+    if (int e = k_clamp_positions(pos, h->wsp<int64_t>(h->ws.pos_safe), h->wsp<int32_t>(h->ws.vl_status) + 1, (long)B * S, c.max_position, st))
+      return e;
+    pos = h->wsp<int64_t>(h->ws.pos_safe);
+  }
   h->ids = ids; h->pos = pos;
   h->cos_cur = h->cos_tab; h->sin_cur = h->sin_tab; h->pos_cur = pos;
   // Var-len (padding-free) token layout: when the caller told us how many real tokens the right-padded batch holds

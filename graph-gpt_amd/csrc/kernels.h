@@ -60,6 +60,8 @@ int k_lengths(const int64_t* mask, const int64_t* ids, int ldF, int pad_id, int3
 int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, const int32_t* key_len, int32_t* pool_row, int32_t* cu,
                   int64_t* ids_c, int64_t* pos_c, int32_t* row_b, int32_t* pad2c, int32_t* status, int B, int S, int tc, int t_rows,
                   int pad_id, hipStream_t st);
+// out = clamp(pos, 0, max_pos - 1); *flag = 1 (sticky) if anything was clamped
+int k_clamp_positions(const int64_t* pos, int64_t* out, int32_t* flag, long n, int max_pos, hipStream_t st);
 int k_remap_rows(int32_t* idx, const int32_t* count, const int32_t* pad2c, int cap, hipStream_t st);
 int k_head_compact(const int64_t* labels, int T, int n, int32_t* cnt, int32_t* m_off, int32_t* l_off, int32_t* counts,
                    int32_t* row_idx, int32_t* sel_src, int32_t* sel_label, int32_t* sel_tok, hipStream_t st);

@@ -1923,6 +1923,27 @@ __global__ void __launch_bounds__(kBlock) remap_rows_kernel(int32_t* __restrict_
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) idx[i] = max(pad2c[idx[i]], 0);
 }
 
+// position ids handed to a forward index the precomputed RoPE table [max_pos][32]: a copy clamped to [0, max_pos) keeps every table read
+// in bounds, and a sticky flag tells the host (at a time of its choosing, not per step) that a clamp happened - the reference evaluates
+// the rotary embedding on the fly and accepts any position (hf LlamaRotaryEmbedding.forward :111-127), so an out-of-range position is a
+// configuration error of the caller (max_position_embeddings too small), reported instead of silently diverging
+__global__ void __launch_bounds__(kBlock) clamp_positions_kernel(const int64_t* __restrict__ pos, int64_t* __restrict__ out,
+                                                                 int32_t* __restrict__ flag, long n, int max_pos) {
+  bool bad = false;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+    const int64_t v = pos[i];
+    bad |= v < 0 || v >= max_pos;
+    out[i] = v < 0 ? 0 : (v >= max_pos ? max_pos - 1 : v);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) *flag = 1;
+}
+int k_clamp_positions(const int64_t* pos, int64_t* out, int32_t* flag, long n, int max_pos, hipStream_t st) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(clamp_positions_kernel, dim3(grid_for(n, kBlock, 1024)), dim3(kBlock), 0, st, pos, out, flag, n, max_pos);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
 int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, const int32_t* key_len, int32_t* pool_row, int32_t* cu,
                   int64_t* ids_c, int64_t* pos_c, int32_t* row_b, int32_t* pad2c, int32_t* status, int B, int S, int tc, int t_rows,
                   int pad_id, hipStream_t st) {

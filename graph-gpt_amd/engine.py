@@ -247,6 +247,13 @@ class Engine:
         token layout (gget_set_token_count).  None / 0 = unknown -> padded layout."""
         L.check(self.lib.gget_set_token_count(self.h, int(n_real_tokens or -1)))
 
+    def positions_clamped(self) -> bool:
+        """True if a forward since the last call met position_ids outside [0, max_position) (they were clamped into the RoPE table);
+        clears the flag; synchronises."""
+        out = C.c_int32(0)
+        L.check(self.lib.gget_position_status(self.h, C.byref(out), _stream()))
+        return bool(out.value)
+
     def varlen_status(self):
         """(ran var-len, rows, count mismatch) of the last forward; synchronises."""
         out = (C.c_int32 * 3)()

@@ -332,21 +332,33 @@ class _GgetModel(nn.Module):
 
     def _check_positions(self, position_ids, S):
         """The RoPE table is precomputed for max_position_embeddings rows (the reference evaluates the rotary embedding on the
-        fly, hf LlamaRotaryEmbedding.forward :111-127, and accepts any position): a larger position would read past the
-        table, so it raises here instead of silently diverging.  One scalar device->host read per forward that passes
-        position_ids (fine-tuning); GGET_SKIP_INPUT_CHECKS=1 removes it."""
+        fly, hf LlamaRotaryEmbedding.forward :111-127, and accepts any position): a larger position raises IndexError instead of
+        silently diverging.  HOST tensors (what the reference's loops receive from the DataLoader) are checked here, for free.
+        DEVICE tensors are NOT read back per step (that would stall the stream on every fine-tune forward): the engine clamps them
+        into the table and raises a sticky device flag, which `check_deferred()` turns into the same IndexError at a time of the
+        caller's choosing (TrainingMode.run_training: every log step and at the end; evaluate / ft_evaluate: at the end);
+        GGET_CHECK_INPUTS=1 checks every forward immediately."""
         maxp = self.spec.max_position
         if position_ids is None:
             if S > maxp:
                 raise IndexError(f"sequence length {S} exceeds max_position_embeddings {maxp}")
             return
-        if os.environ.get("GGET_SKIP_INPUT_CHECKS") or float(getattr(self.config, "rope_range", 0) or 0) > 0:
+        if float(getattr(self.config, "rope_range", 0) or 0) > 0 or not position_ids.numel():
             return      # (rope_range: the positions are rescaled per row, angles are evaluated per token - no table to overrun)
-        hi = int(position_ids.max()) if position_ids.numel() else 0
-        lo = int(position_ids.min()) if position_ids.numel() else 0
-        if hi >= maxp or lo < 0:
-            raise IndexError(f"position_ids must lie in [0, max_position_embeddings = {maxp}); got [{lo}, {hi}] - build the model "
-                             "with a larger max_position_embeddings")
+        if position_ids.device.type == "cpu" or os.environ.get("GGET_CHECK_INPUTS"):
+            hi, lo = int(position_ids.max()), int(position_ids.min())
+            if hi >= maxp or lo < 0:
+                raise IndexError(f"position_ids must lie in [0, max_position_embeddings = {maxp}); got [{lo}, {hi}] - build the model "
+                                 "with a larger max_position_embeddings")
+
+    def check_deferred(self):
+        """Raise what the per-step device-side guards recorded since the last call (one stream sync): position_ids outside the RoPE
+        table (IndexError, as _check_positions raises for host tensors)."""
+        e = self._engine
+        if e is not None and e.positions_clamped():
+            raise IndexError(f"position_ids outside [0, max_position_embeddings = {self.spec.max_position}) were passed to a forward since "
+                             "the last check (the engine clamped them into the RoPE table: results diverge from the reference) - build "
+                             "the model with a larger max_position_embeddings")
 
     def _validate_inputs(self, input_ids, attention_mask, labels=None):
         """Debug-mode input validation (GGET_CHECK_INPUTS=1; costs device->host reads): the kernels index with the ids / labels

@@ -410,6 +410,8 @@ def ft_evaluate(model, loader, *, problem_type: str = "single_label_classificati
         idx = data["idx"].to(device) if "idx" in data else torch.arange(labels.shape[0], device=device) + (j - 1) * labels.shape[0]
         cls_metrics.update(res.task_logits, labels, idx)
     model.train()
+    if hasattr(model, "check_deferred"):
+        model.check_deferred()
     if j == 0:
         raise ValueError(f"ft_evaluate: the {eval_name} loader yielded no batch")
     test_loss = test_loss / j
@@ -484,8 +486,10 @@ class TrainingMode(abc.ABC):
                 dt = time.time() - t0
                 pipeline.log(f"step {step + 1} loss {float(loss):.5f} lr {pipeline.engine.last_lr:.3e} "
                              f"tokens/s/gpu {int(tokens) / dt:.0f}")
+                pipeline.model.check_deferred()      # device-side input guards (position ids), read where the loop syncs anyway
             if pipeline.max_steps and step + 1 >= pipeline.max_steps:
                 break
+        pipeline.model.check_deferred()
 
 
 class PretrainMode(TrainingMode):

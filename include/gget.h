@@ -139,6 +139,11 @@ int gget_set_dropout(gget_handle_t h, float attention_p, float path_p, uint32_t 
  * gget_varlen_status: out[0] = 1 if the last forward ran var-len, out[1] = rows it ran on, out[2] = 1 if sum(key lengths) on the
  * device differed from n_real_tokens (results are then invalid: the caller's count was wrong); synchronises the stream. */
 int gget_set_token_count(gget_handle_t h, int64_t n_real_tokens);
+/* position_ids of a forward index the RoPE table precomputed for config.max_position rows (the reference evaluates the rotary embedding
+ * per call, hf LlamaRotaryEmbedding.forward :111-127, and accepts any position): the engine reads them through a copy clamped to
+ * [0, max_position) and raises a sticky device-side flag when it had to clamp.  *clamped_out = that flag (then cleared); synchronises
+ * the stream - call it when convenient (end of an epoch, a logging step), not per step. */
+int gget_position_status(gget_handle_t h, int32_t* clamped_out, void* stream);
 int gget_varlen_status(gget_handle_t h, int32_t out[3], void* stream);
 
 /* replaces: `embed_pdrop` / `mlp_pdrop` of the config + model.train()/eval(): nn.Dropout on the gathered token embeddings

@@ -139,21 +139,25 @@ def _source_digest():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(which="wgrad_layer"):
+def pmc_traffic(which="wgrad_layer", rows=8192):
     """L2<->fabric bytes per launch of a timed kernel from the committed PMC passes (FETCH_SIZE x2 (gfx950 correction) +
-    WRITE_SIZE, separate --pmc runs: tools/pmc_wgrad.sh -> profiles/r02_wgrad_gemm_pmc.json, tools/pmc_gu.sh ->
-    profiles/r02_gu_geglu_gemm_pmc.json).  PMC counters cannot be collected from inside the process being timed, so the figure
-    is a recorded one: it carries the digest of the kernel sources it was measured on and is reported as null when those
-    sources have changed since."""
-    name = {"wgrad_layer": "r02_wgrad_gemm_pmc.json", "gateup": "r02_gu_geglu_gemm_pmc.json"}.get(which)
-    if name is None:
+    WRITE_SIZE, separate --pmc runs: tools/pmc_wgrad.sh -> profiles/r0N_wgrad_gemm_pmc*.json, tools/pmc_gu.sh ->
+    profiles/r0N_gu_geglu_gemm_pmc*.json).  PMC counters cannot be collected from inside the process being timed, so the figure
+    is a recorded one: it carries the digest of the kernel sources and the row count (T, = K of the weight-gradient launch) it was
+    measured on and is reported as null when no record matches both."""
+    import glob
+    pat = {"wgrad_layer": "r0*_wgrad_gemm_pmc*.json", "gateup": "r0*_gu_geglu_gemm_pmc*.json"}.get(which)
+    if pat is None:
         return None
-    try:
-        with open(os.path.join(ROOT, "profiles", name)) as f:
-            rec = json.load(f)
-        return rec["traffic_bytes_per_launch"] if rec.get("source_digest") == _source_digest() else None
-    except (OSError, KeyError, ValueError):
-        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pat)), reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+            if rec.get("source_digest") == _source_digest() and int(rec.get("rows", 8192)) == int(rows):
+                return rec["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 KERNEL_NAMES = {
@@ -314,7 +318,7 @@ def main():
             return {"kernel": KERNEL_NAMES[k], "step_flops_pct": share(fl), "step_time_pct": round(100.0 * kms * L_ / ms, 1),
                     "avg_launch_ms": kms, "timed": "HIP events around the launch inside the step" if k in in_step else "stand-alone loop",
                     "avg_launch_ms_standalone": alone, "achieved": tf, "frac": tf / PEAK_BF16_TFLOPS,
-                    "traffic": pmc_traffic(k) if c1_shape else None}
+                    "traffic": pmc_traffic(k, t_rows) if c1_shape else None}
         order = sorted(kt, key=lambda k: -in_step.get(k, kt[k][1]))
         dom = entry(order[0])
         roofline = {"bound": "mfma", "kernel": dom["kernel"] + f" ({dom['step_time_pct']}% of the step's time, {dom['step_flops_pct']}% of its FLOPs)",

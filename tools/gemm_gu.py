@@ -4,7 +4,7 @@ import ctypes as C, importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = importlib.import_module("graph-gpt_amd._lib"); lib = L.load()
 P = lambda t: C.c_void_p(t.data_ptr()); st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-T, d, ff = 8192, 768, 3072
+T, d, ff = int(__import__("os").environ.get("GGET_T", "8192")), 768, 3072   # GGET_T: rows of the launch
 A = torch.randn(T, d, device="cuda").to(torch.bfloat16); B = (torch.randn(2 * ff, d, device="cuda") * 0.02).to(torch.bfloat16)
 Cm = torch.empty(T, 2 * ff, dtype=torch.bfloat16, device="cuda"); H = torch.empty(T, ff, dtype=torch.bfloat16, device="cuda")
 for _ in range(5):

@@ -4,7 +4,7 @@ import ctypes as C, importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = importlib.import_module("graph-gpt_amd._lib"); lib = L.load()
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-T, d, ff = 8192, 768, 3072
+T, d, ff = int(os.environ.get("GGET_T", "8192")), 768, 3072     # GGET_T: rows = K of the launch (var-len layout: a batch's real tokens)
 bf = lambda *s: torch.randn(*s, device="cuda").to(torch.bfloat16)
 dgu, dy, dqkv, xn, h, attn = bf(T, 2 * ff), bf(T, d), bf(T, 3 * d), bf(T, d), bf(T, ff), bf(T, d)
 gw = [torch.empty(2 * ff, d, dtype=torch.bfloat16, device="cuda"), torch.empty(d, ff, dtype=torch.bfloat16, device="cuda"),

@@ -2,6 +2,7 @@
 # PMC passes (one counter per run, no trace domains besides --kernel-trace) over the dominant kernel -> gpurun_out/<tag>_gu_pmc.json
 # FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of 16 B/lane reads at 64 B).
 tag=${1:-r02}
+export GGET_T=${2:-8192}     # rows of the launch
 cd /tmp && export TMPDIR=/tmp
 declare -A val
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
@@ -21,14 +22,15 @@ def get(c):
 fetch, dur, _ = get("FETCH_SIZE"); write, _, _ = get("WRITE_SIZE"); mfma, _, recs = get("SQ_VALU_MFMA_BUSY_CYCLES"); act, _, arecs = get("GRBM_GUI_ACTIVE")
 h = hashlib.sha256()
 for f in ("gemm.hip", "common.h", "gemm.h"): h.update(open(os.path.join(root, "graph-gpt_amd", "csrc", f), "rb").read())
-T, d, ff = 8192, 768, 3072
+T, d, ff = int(os.environ.get("GGET_T", "8192")), 768, 3072
 alg = T * d * 2 + 2 * ff * d * 2 + T * 2 * ff * 2 + T * ff * 2
-out = {"kernel": "gemm_persist_kernel<256,256,64,4,2,NT,EPI_GEGLU_FWD, 2-slot ring> on [8192,768] x [6144,768]^T -> gu bf16 [8192,6144] + h bf16 [8192,3072] (FFN gate|up + gated GELU, C1)",
+out = {"kernel": f"gemm_persist_kernel<256 or 192,256,64,4,2,NT,EPI_GEGLU_FWD, 2-slot ring> on [{T},768] x [6144,768]^T -> gu bf16 [{T},6144] + h bf16 [{T},3072] (FFN gate|up + gated GELU, C1)",
+       "rows": T,
        "command": "rocprofv3 --kernel-trace --pmc <COUNTER> -- python tools/gemm_gu.py (one counter per pass; 5 launches averaged; tools/pmc_gu.sh)",
        "source_digest": h.hexdigest()[:16], "avg_duration_us": dur, "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB": write,
        "FETCH_SIZE_note": "gfx950 tallies 128-B requests of 16 B/lane reads at 64 B: doubled (MI355X_MICROARCH.md, HBM section)",
        "traffic_bytes_per_launch": int(2 * fetch * 1024 + write * 1024), "algorithmic_bytes_per_launch": alg,
-       "algorithmic_note": "A 8192*768*2 + B 6144*768*2 read once; gu 8192*6144*2 + h 8192*3072*2 written once",
+       "algorithmic_note": "A T*768*2 + B 6144*768*2 read once; gu T*6144*2 + h T*3072*2 written once",
        "SQ_VALU_MFMA_BUSY_CYCLES_sum": mfma, "GRBM_GUI_ACTIVE_sum": act, "mfma_busy_frac": mfma / 1024.0 / (act / max(arecs, 1)) if act else None}
 json.dump(out, open(os.path.join(root, "gpurun_out", "${tag}_gu_pmc.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

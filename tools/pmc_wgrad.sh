@@ -2,6 +2,7 @@
 # PMC passes (one counter per run) over the grouped weight-gradient launch of a decoder layer -> gpurun_out/<tag>_wgrad_pmc.json
 # (same recipe as tools/pmc_gu.sh: FETCH_SIZE doubled per MI355X_MICROARCH.md)
 tag=${1:-r02}
+export GGET_T=${2:-8192}     # rows (= K) of the launch
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   rm -rf /tmp/pmcw_$c
@@ -20,10 +21,11 @@ def get(c):
 fetch, dur, _ = get("FETCH_SIZE"); write, _, _ = get("WRITE_SIZE"); mfma, _, recs = get("SQ_VALU_MFMA_BUSY_CYCLES"); act, _, arecs = get("GRBM_GUI_ACTIVE")
 h = hashlib.sha256()
 for f in ("gemm.hip", "common.h", "gemm.h"): h.update(open(os.path.join(root, "graph-gpt_amd", "csrc", f), "rb").read())
-T, d, ff = 8192, 768, 3072
+T, d, ff = int(os.environ.get("GGET_T", "8192")), 768, 3072
 # operands read once: dgu [T,2ff], dy [T,d], dqkv [T,3d], xn [T,d], h [T,ff], attn [T,d]; outputs written once: 2ff*d + d*ff + 3d*d + d*d
 alg = 2 * (T * (2 * ff + d + 3 * d + d + ff + d) + (2 * ff * d + d * ff + 4 * d * d))
-out = {"kernel": "gemm_ks_kernel<192,192,TN> (in-block K split): grouped weight gradients of one decoder layer, dW = dY^T X for gate|up, down, q|k|v, o; K = T = 8192, 256 tiles = one per CU (C1)",
+out = {"kernel": f"gemm_ks_kernel<192,192,TN> (in-block K split): grouped weight gradients of one decoder layer, dW = dY^T X for gate|up, down, q|k|v, o; K = T = {T}, 256 tiles = one per CU (C1)",
+       "rows": T,
        "command": "rocprofv3 --kernel-trace --pmc <COUNTER> -- python tools/gemm_wgrad.py (one counter per pass; 5 launches averaged; tools/pmc_wgrad.sh)",
        "source_digest": h.hexdigest()[:16], "avg_duration_us": dur, "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB": write,
        "FETCH_SIZE_note": "gfx950 tallies 128-B requests of 16 B/lane reads at 64 B: doubled (MI355X_MICROARCH.md, HBM section)",

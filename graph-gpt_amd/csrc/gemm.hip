@@ -1269,7 +1269,8 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
         if constexpr (EPI != GGET_EPI_ROPE) {
           // one tile per CU, nothing device-sized: the K-split arrangement of the tile (g_gemm_variant bit 0 turns it off)
           bool ks = tot3 <= num_cu && !(g_gemm_variant & 1);
-          // (K >= 1536: with only 12 K-tiles the accumulator exchange costs what the lighter fragment traffic saves)
+          // (K >= 1536: with only 12 K-tiles the accumulator exchange costs what the lighter fragment traffic saves - measured again in
+          //  round 3 with the 96-row tiles: K = 768 launches through this kernel left the C1 step unchanged, 7.44-7.48 ms either way)
           for (int i = 0; i < g.count; ++i)
             ks = ks && !g.p[i].m_dev && !g.p[i].k_dev && (g.p[i].N % 192) == 0 && g.p[i].K >= 1536;
           if (ks) {

@@ -7,7 +7,7 @@
 // Small fp32 accumulators (norm weights, LayerScale, ...) exist in kAccumCopies copies, `stride` elements apart: a block
 // adds into copy blockIdx % copies (an atomic add of 512 blocks into ONE 768-float vector serialises in L2: that was
 // the whole cost of the RMSNorm backward), and the bf16 conversion sums the copies.
-constexpr int kAccumCopies = 8;
+constexpr int kAccumCopies = 8;   // (round 3: 32 / 128 / 512 copies leave the C1 step unchanged or slower - 7.30 / 7.31 / 7.36 / 7.57 ms)
 constexpr uint64_t kAccumCopyMax = 8192;   // parameters up to this many elements are replicated
 struct GgetSegment {
   uint64_t src;    // element offset into the fp32 scratch (copy 0)

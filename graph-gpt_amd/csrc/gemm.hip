@@ -1216,6 +1216,7 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
       GGET_HIP_CHECK(hipGetDevice(&dev));
       GGET_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
       num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      if (const char* e = getenv("GGET_GEMM_NUM_CU")) num_cu = atoi(e);   // measurement knob: pretend the chip has fewer CUs (tools/halfchip.py)
     }
     // wide tile for the widest forward GEMM: 256x256x32 (8 waves of 128x64, 4-slot ring) moves 2/3 of the bytes per
     // FLOP of the 256x128 tile
@@ -1417,6 +1418,8 @@ int launch_mode(GemmGroup& g, int epi, int split_k, hipStream_t st) {
           GGET_HIP_CHECK(hipGetDevice(&dev));
           GGET_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
           num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+          if (const char* e = getenv("GGET_GEMM_NUM_CU")) num_cu = atoi(e);
+      if (const char* e = getenv("GGET_GEMM_NUM_CU")) num_cu = atoi(e);   // measurement knob: pretend the chip has fewer CUs (tools/halfchip.py)
         }
         // (192-row tiles when they need fewer rounds x rows than 256-row tiles - see launch_t)
         long t192 = 0;

@@ -334,6 +334,24 @@ def ft_batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine, label_k
     return loss, out.task_logits
 
 
+def _host_token_count(data) -> Optional[int]:
+    """Real tokens of a collated batch when that is free to know: `data["num_tokens"]`, or the sum of a HOST-side 2-D attention mask (the
+    evaluation loops receive CPU batches and move them: counting before the move costs nothing) - lets the engine run the batch on the
+    padding-free token layout (modeling._GgetModel._token_count).  None = unknown (device-side mask): padded layout."""
+    if data.get("num_tokens") is not None:
+        return int(data["num_tokens"])
+    am = data.get("attention_mask")
+    if am is not None and am.dim() == 2 and am.device.type == "cpu":
+        return int((am != 0).sum())
+    return None
+
+
+def _layout_kw(model, data) -> Dict[str, Any]:
+    """`num_tokens=` for the engine-backed model classes only (the reference's call keeps its exact keyword set for any other model)."""
+    n = _host_token_count(data) if isinstance(getattr(model, "module", model), _GgetModel) else None
+    return {} if n is None else {"num_tokens": n}
+
+
 # ----------------------------------------------------------------------------- evaluation pass
 @torch.no_grad()
 def evaluate(model, loader, eval_name: str = "valid", do_eval: bool = True):
@@ -351,7 +369,7 @@ def evaluate(model, loader, eval_name: str = "valid", do_eval: bool = True):
     for data in loader:
         out = model(input_ids=data["input_ids"].to(device), attention_mask=data["attention_mask"].to(device),
                     labels=data["labels"].to(device), inputs_raw_embeds=None,
-                    sample_wgt=data["wgt"].to(device) if "wgt" in data else None)
+                    sample_wgt=data["wgt"].to(device) if "wgt" in data else None, **_layout_kw(model, data))
         loss, aux = out.head1_loss.clone(), out.head2_loss
         if world > 1:
             dist.reduce(loss, 0)
@@ -404,7 +422,7 @@ def ft_evaluate(model, loader, *, problem_type: str = "single_label_classificati
         res = model(input_ids=data["input_ids"].to(device), attention_mask=data["attention_mask"].to(device),
                     task_labels=labels, cls_idx=data["cls_idx"].to(device) if "cls_idx" in data else None,
                     inputs_raw_embeds=data["embed"].to(device) if "embed" in data else None,     # log_eval_dump_utils.py:108-110
-                    sample_wgt=data["wgt"].to(device) if "wgt" in data else None,
+                    sample_wgt=data["wgt"].to(device) if "wgt" in data else None, **_layout_kw(model, data),
                     position_ids=data["position_ids"].to(device) if "position_ids" in data else None)
         test_loss = test_loss + res.task_loss.detach()
         idx = data["idx"].to(device) if "idx" in data else torch.arange(labels.shape[0], device=device) + (j - 1) * labels.shape[0]

@@ -299,7 +299,8 @@ def main():
 
     if rank == 0:
         M, Lm = model._engine.head_counts() if pt else (0, 0)
-        ran_varlen, t_rows, _ = model._engine.varlen_status()
+        ran_varlen, t_rows, mismatch = model._engine.varlen_status()
+        assert not mismatch, "the batch's real-token count handed to the engine disagrees with its attention mask"
         fstep = flops_per_step(spec, B, S, M, Lm, kind)                    # the reference's computation, padded grid
         fexec = flops_per_step(spec, B, S, M, Lm, kind, rows=t_rows, lengths=batch.get("lengths") if ran_varlen else None)
         ms = dt / a.steps * 1e3

@@ -29,12 +29,15 @@ def _cfg(modeling):
                                    stacked_feat=13, next_n_token=13)
 
 
-def _batch(synth, rank):
+def _batch(synth, rank, layout="padded"):
     b = synth.make_pretrain_batch(B=8, S=32, F=13, V=756, seed=700 + rank)
-    return {k: torch.from_numpy(v).cuda() for k, v in b.items() if k != "lengths"}
+    d = {k: torch.from_numpy(v).cuda() for k, v in b.items() if k != "lengths"}
+    if layout == "varlen":      # the collator's token count: the step runs on the rank's compacted real tokens (another row count per rank)
+        d["num_tokens"] = int(b["attention_mask"].sum())
+    return d
 
 
-def _worker(rank, world, port, q, overlap="1"):
+def _worker(rank, world, port, q, overlap="1", layout="padded"):
     os.environ["GGET_DP_OVERLAP"] = overlap
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     torch.cuda.set_device(0)
@@ -45,27 +48,29 @@ def _worker(rank, world, port, q, overlap="1"):
     model = modeling.GraphGPTPretrainBase(_cfg(modeling), seed=1)
     eng = tr.initialize(model, tr.OptimConfig(lr=1e-3, max_grad_norm=0.05))
     assert eng.world == 2
-    data = _batch(synth, rank)
+    data = _batch(synth, rank, layout)
     losses = []
     for _ in range(2):
         losses.append(float(tr.batch_training(data, eng)))
     torch.cuda.synchronize()
     e = model._engine
+    assert e.varlen_status()[0] == (layout == "varlen")
     q.put((rank, losses, e.master.detach().cpu().numpy(), float(eng.last_grad_norm)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", ["1", "0"])
-def test_two_rank_step_matches_manual_gradient_average(overlap):
-    """overlap=1: bucketed all-reduce on a side stream behind the staged backward; overlap=0: one all-reduce after it."""
+@pytest.mark.parametrize("overlap,layout", [("1", "padded"), ("0", "padded"), ("1", "varlen")])
+def test_two_rank_step_matches_manual_gradient_average(overlap, layout):
+    """overlap=1: bucketed all-reduce on a side stream behind the staged backward; overlap=0: one all-reduce after it; layout "varlen":
+    every rank runs its step on its own compacted real tokens (the gradient buckets are the same on every rank whatever its row count)."""
     modeling = importlib.import_module("graph-gpt_amd.modeling")
     tr = importlib.import_module("graph-gpt_amd.training")
     synth = importlib.import_module("graph-gpt_amd.synth")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap, layout)) for r in range(2)]
     for p in ps:
         p.start()
     res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
@@ -79,10 +84,10 @@ def test_two_rank_step_matches_manual_gradient_average(overlap):
     # one process, two replicas' gradients averaged by hand (fp32 sum of the bf16 buckets, then the same 1/world scale)
     models = [modeling.GraphGPTPretrainBase(_cfg(modeling), seed=1) for _ in range(2)]
     engs = [tr.initialize(m, tr.OptimConfig(lr=1e-3, max_grad_norm=0.05)) for m in models]
-    datas = [_batch(synth, r) for r in range(2)]
+    datas = [_batch(synth, r, layout) for r in range(2)]
     for _ in range(2):
         for m, en, d in zip(models, engs, datas):
-            out = en(input_ids=d["input_ids"], attention_mask=d["attention_mask"], labels=d["labels"])
+            out = en(input_ids=d["input_ids"], attention_mask=d["attention_mask"], labels=d["labels"], num_tokens=d.get("num_tokens"))
             en.backward(out.head1_loss)
         torch.cuda.synchronize()
         g = [m._engine.grad_bf16 for m in models]

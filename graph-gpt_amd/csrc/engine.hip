@@ -36,7 +36,22 @@ namespace {
 
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 constexpr int kWgSplit = 3;    // K slices of the attention-projection wgrad (72 output tiles -> 216 blocks)
-constexpr int kLmSplit = 16;   // K slices of the lm_head wgrad (6x6 output tiles, K = Lm ~ 5e4)
+constexpr int kLmSplit = 16;   // K slices of the lm_head wgrad at most (few output tiles, K = Lm ~ 4e4); see fit_split
+// K slices of a split-K launch whose output has only `tiles` tiles: as many as asked for, but tiles x slices must fit in ONE round of
+// the CUs (one 96-144 KiB block per CU) - 18 tiles x 16 slices = 288 blocks ran a second round for 32 of them (lm_head weight
+// gradient 88.6 -> measured below; profiles/r03_step_experiments.txt)
+int fit_split(int tiles, int want) {
+  static int num_cu = 0;
+  if (!num_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                 ? prop.multiProcessorCount : 256;
+  }
+  int s = want;
+  while (s > 1 && tiles * s > num_cu) --s;
+  return s;
+}
 
 struct ParamRec {
   std::string name;
@@ -1447,12 +1462,16 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
       memset(&g, 0, sizeof(g));
       g.count = 1;
       g.p[0] = GemmProblem{dlog, h->wsp<bf16_t>(w.Hl), slabs, nullptr, V, d, T * n, Vp, d, d, nullptr, counts + 1, 0, 0, slab};
-      if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_SLAB_F32, g, kLmSplit, st)) return e;
-      if (int e = k_slab_reduce(slabs, slab, kLmSplit, h->G + h->plan.lm, (size_t)V * d, st)) return e;
+      // (256 x 128 tiles from 160 tile-slices on, 128 x 128 below - gemm.hip launch_shape)
+      int lm_split = fit_split(((V + 255) / 256) * ((d + 127) / 128), kLmSplit);
+      if (((V + 255) / 256) * ((d + 127) / 128) * lm_split < 160) lm_split = fit_split(((V + 127) / 128) * ((d + 127) / 128), kLmSplit);
+      if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_SLAB_F32, g, lm_split, st)) return e;
+      if (int e = k_slab_reduce(slabs, slab, lm_split, h->G + h->plan.lm, (size_t)V * d, st)) return e;
     }
     if (h->plan.has_ntp) {
       bf16_t* dP = h->wsp<bf16_t>(w.dP);
-      GGET_HIP_CHECK(hipMemsetAsync(dP, 0, (size_t)T * n * d * 2, st));
+      // (rows M.. are read as zeros by the K-tail of the weight gradient; M <= real tokens <= h->T on the var-len layout)
+      GGET_HIP_CHECK(hipMemsetAsync(dP, 0, (size_t)(h->varlen ? h->T : T) * n * d * 2, st));
       if (int e = k_gather_rows(h->wsp<bf16_t>(w.dHl), h->wsp<int32_t>(w.sel_src), counts + 1, dP, T * n, d, 1, st)) return e;
       if (int e = gemm_nn(dP, h->P + h->plan.ntp, h->wsp<bf16_t>(w.dHm), T, d, n * d, n * d, d, d, counts, st)) return e;
       if (int e = gget_gemm_single(GGET_GEMM_TN, GGET_EPI_NONE, dP, h->wsp<bf16_t>(w.Hm), h->G + h->plan.ntp, nullptr, n * d, d,
@@ -1523,6 +1542,10 @@ int embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* g
     // non-empty: nslab is recomputed from the 64-row K-tiles), then one pass sums the slabs into the accumulator
     const int ktiles = (T + 63) / 64;
     int split = ktiles / 4 < 1 ? 1 : (ktiles / 4 > kEmbDenseSplit ? kEmbDenseSplit : ktiles / 4);
+    {   // one round of the CUs (see fit_split): 36 tiles of 128 x 128 x 8 slices were 288 blocks
+      const int t_big = ((V + 255) / 256) * ((d + 127) / 128), t_small = ((V + 127) / 128) * ((d + 127) / 128);
+      split = t_big * split >= 160 ? fit_split(t_big, split) : fit_split(t_small, split);
+    }
     const int per = (ktiles + split - 1) / split;
     const int nslab = (ktiles + per - 1) / per;
     float* slabs = static_cast<float*>(slab_ws);

@@ -798,22 +798,40 @@ __global__ void __launch_bounds__(kBlock) ce_rows_kernel(const bf16_t* __restric
   const float scale = mean_over_rows ? (n_rows > 0 ? 1.0f / (float)n_rows : 0.f) : scale_base;
   const int nch = ld >> 3;
   float local = 0.f;
-  for (int row = blockIdx.x * (kBlock / 64) + wave; row < n_rows; row += gridDim.x * (kBlock / 64)) {
-    const bf16_t* lp = logits + (size_t)row * ld;
-    float x[CH][8];
-    float mx = -INFINITY;
+  // software-pipelined over the wave's rows: the 16-byte chunks and the label of the NEXT row are in flight while the current row is
+  // reduced, exponentiated and stored (a row is one dependent chain otherwise: chunks -> max -> exp -> sum -> store, with the label's
+  // own load -> logit-at-label load behind it; 45 -> measured below, profiles/r03_step_experiments.txt)
+  const int rstride = gridDim.x * (kBlock / 64);
+  int row = blockIdx.x * (kBlock / 64) + wave;
+  uint4 nx[CH];
+  int ny = 0;
+  auto fetch = [&](int r) {
+    const bf16_t* q = logits + (size_t)r * ld;
 #pragma unroll
     for (int t = 0; t < CH; ++t) {
       const int ch = lane + 64 * t;
-      if (ch < nch) unpack8(ldg16(lp + ch * 8), x[t]);
+      nx[t] = ch < nch ? ldg16(q + ch * 8) : make_uint4(0, 0, 0, 0);
+    }
+    ny = labels[r];
+  };
+  if (row < n_rows) fetch(row);
+  for (; row < n_rows; row += rstride) {
+    const bf16_t* lp = logits + (size_t)row * ld;
+    float x[CH][8];
+    float mx = -INFINITY;
+    const int y = ny;
+    const float xy = bf2f(lp[y]);
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+      const int ch = lane + 64 * t;
+      unpack8(nx[t], x[t]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         if (ch >= nch || ch * 8 + e >= V) x[t][e] = -INFINITY;
         mx = fmaxf(mx, x[t][e]);
       }
     }
-    const int y = labels[row];
-    const float xy = bf2f(lp[y]);
+    if (row + rstride < n_rows) fetch(row + rstride);
     mx = wave_max(mx);
     float se = 0.f;
 #pragma unroll

@@ -657,8 +657,12 @@ int gemm_nt(const void* A, const void* Bw, void* C, const void* R, int M, int N,
                           nullptr, 1, st);
 }
 int gemm_nn(const void* A, const void* Bw, void* C, int M, int N, int K, int lda, int ldb, int ldc, const int* m_dev,
-            hipStream_t st) {
-  return gget_gemm_single(GGET_GEMM_NN, GGET_EPI_NONE, A, Bw, C, nullptr, M, N, K, lda, ldb, ldc, m_dev, nullptr, 1, st);
+            hipStream_t st, const int* c_rows = nullptr) {
+  return gget_gemm_single(GGET_GEMM_NN, GGET_EPI_NONE, A, Bw, C, nullptr, M, N, K, lda, ldb, ldc, m_dev, nullptr, 1, st, false, c_rows);
+}
+bool head_scatter_fused() {
+  static const int off = getenv("GGET_NO_HEAD_SCATTER_FUSION") != nullptr;
+  return !off;
 }
 
 // Gated-GELU MLP with the activation fused into the GEMMs around it (hf LlamaMLP.forward :174-176):
@@ -1450,8 +1454,15 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
     const int n = c.next_n_token, V = c.vocab_size, Vp = (int)align_up(V, 64);
     int32_t* counts = h->wsp<int32_t>(w.counts);
     bf16_t* dlog = h->wsp<bf16_t>(w.dlogits);
-    // lm_head: dHl = dlogits W_lm ; dW_lm = dlogits^T Hl (split-K, fp32 atomics: only 6x6 output tiles)
-    if (int e = gemm_nn(dlog, h->P + h->plan.lm, h->wsp<bf16_t>(w.dHl), T * n, d, Vp, Vp, d, d, counts + 1, st)) return e;   // K = Vp: zero pads on both sides
+    // lm_head: dHl = dlogits W_lm ; dW_lm = dlogits^T Hl (split-K, fp32 slabs: only a few output tiles)
+    // With n_token_proj the rows of dHl are scattered into dP (row sel_src[i] of the [M n, d] view) - fused into the GEMM's epilogue
+    // (GemmProblem::c_rows), so dHl is never materialised and the separate scatter launch disappears; dP is cleared first.
+    const bool fuse_sc = h->plan.has_ntp && head_scatter_fused();
+    if (fuse_sc) {
+      GGET_HIP_CHECK(hipMemsetAsync(h->wsp<bf16_t>(w.dP), 0, (size_t)(h->varlen ? h->T : T) * n * d * 2, st));
+      if (int e = gemm_nn(dlog, h->P + h->plan.lm, h->wsp<bf16_t>(w.dP), T * n, d, Vp, Vp, d, d, counts + 1, st, h->wsp<int32_t>(w.sel_src)))
+        return e;
+    } else if (int e = gemm_nn(dlog, h->P + h->plan.lm, h->wsp<bf16_t>(w.dHl), T * n, d, Vp, Vp, d, d, counts + 1, st)) return e;   // K = Vp: zero pads on both sides
     {
       // K = Lm (device-side count, ~5e4) over only 6x6 output tiles: kLmSplit K-slices, one fp32 slab each, then a sum.
       // Slices that fall beyond a short Lm write nothing, so the slabs are cleared first.
@@ -1471,14 +1482,20 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
     if (h->plan.has_ntp) {
       bf16_t* dP = h->wsp<bf16_t>(w.dP);
       // (rows M.. are read as zeros by the K-tail of the weight gradient; M <= real tokens <= h->T on the var-len layout)
-      GGET_HIP_CHECK(hipMemsetAsync(dP, 0, (size_t)(h->varlen ? h->T : T) * n * d * 2, st));
-      if (int e = k_gather_rows(h->wsp<bf16_t>(w.dHl), h->wsp<int32_t>(w.sel_src), counts + 1, dP, T * n, d, 1, st)) return e;
-      if (int e = gemm_nn(dP, h->P + h->plan.ntp, h->wsp<bf16_t>(w.dHm), T, d, n * d, n * d, d, d, counts, st)) return e;
+      if (!fuse_sc) {
+        GGET_HIP_CHECK(hipMemsetAsync(dP, 0, (size_t)(h->varlen ? h->T : T) * n * d * 2, st));
+        if (int e = k_gather_rows(h->wsp<bf16_t>(w.dHl), h->wsp<int32_t>(w.sel_src), counts + 1, dP, T * n, d, 1, st)) return e;
+      }
+      // dHm = dP W_ntp, its rows scattered into the gradient of the final-norm output (row row_idx[i]) by the same fused epilogue
+      if (head_scatter_fused()) {
+        if (int e = gemm_nn(dP, h->P + h->plan.ntp, dhid, T, d, n * d, n * d, d, d, counts, st, h->wsp<int32_t>(w.row_idx))) return e;
+      } else if (int e = gemm_nn(dP, h->P + h->plan.ntp, h->wsp<bf16_t>(w.dHm), T, d, n * d, n * d, d, d, counts, st)) return e;
       if (int e = gget_gemm_single(GGET_GEMM_TN, GGET_EPI_NONE, dP, h->wsp<bf16_t>(w.Hm), h->G + h->plan.ntp, nullptr, n * d, d,
                                    T, n * d, d, d, nullptr, counts, 1, st, /*k_pad_zero=*/true))   // dP is cleared above, Hm is finite
         return e;
     }
-    if (int e = k_gather_rows(h->wsp<bf16_t>(w.dHm), h->wsp<int32_t>(w.row_idx), counts, dhid, T, d, 1, st)) return e;
+    if (!(h->plan.has_ntp && head_scatter_fused()))
+      if (int e = k_gather_rows(h->wsp<bf16_t>(w.dHm), h->wsp<int32_t>(w.row_idx), counts, dhid, T, d, 1, st)) return e;
   } else if (h->plan.n_lin > 0) {
     const Plan& pl = h->plan;
     const float* dy = h->wsp<float>(w.tdlogits);

@@ -29,6 +29,9 @@ struct GemmProblem {
   void* C2;
   const bf16_t* G;
   int ldc2, ldg, ff;
+  // EPI_NONE only: row m of the product is stored at row c_rows[m] of C (a scatter fused into the epilogue: the SMTP head's
+  // dHl -> dP and dHm -> d hidden, which were separate gather_rows launches); nullptr = row m
+  const int* c_rows;
 };
 
 struct GemmGroup {
@@ -57,4 +60,5 @@ void gget_gemm_streamk_workspace(void* ws);
 // mode: GGET_GEMM_NT/NN/TN, epi: GGET_EPI_*; problems of one group share mode and epilogue.
 int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t st);
 int gget_gemm_single(int mode, int epi, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
-                     int lda, int ldb, int ldc, const int* m_dev, const int* k_dev, int split_k, hipStream_t st, bool k_pad_zero = false);
+                     int lda, int ldb, int ldc, const int* m_dev, const int* k_dev, int split_k, hipStream_t st, bool k_pad_zero = false,
+                     const int* c_rows = nullptr);

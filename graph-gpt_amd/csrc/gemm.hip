@@ -28,6 +28,7 @@
 // one-tile kernel; 32 = persistent kernel without epilogue), GGET_GEMM_NO_PERSIST, GGET_GEMM_NO_256,
 // GGET_GEMM_192=0, GGET_GEMM_SUPER=<rows per L2 super-tile>.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 #include "gemm.h"
@@ -486,10 +487,13 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
       };
       auto ror8 = [](unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true); };
       bf16_t* C = reinterpret_cast<bf16_t*>(P.C);
+      const int* crows = EPI == GGET_EPI_NONE ? P.c_rows : nullptr;   // fused row scatter (see GemmProblem::c_rows)
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int m = mw + i * 16 + l15;          // the row whose values this lane holds before the regrouping
         const int ma = mw + i * 16 + (l15 & 7), mb = ma + 8;
+        const size_t ra = crows && ma < M ? (size_t)crows[ma] : (size_t)ma, rb = crows && mb < M ? (size_t)crows[mb] : (size_t)mb;
+        const size_t rm = crows && m < M ? (size_t)crows[m] : (size_t)m;
 #pragma unroll
         for (int jq = 0; jq < NJ / 4; ++jq) {
           const int ja = 2 * jq + lead;           // group = (ja, ja + 1): 64 columns from nw + 32 * ja
@@ -503,19 +507,19 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
           const uint4 pb = low ? xr : y;
           const int n = nw + ja * 32 + (low ? c0 : c0 + 4) * 8;
           if (n + 8 <= N) {
-            if (ma < M) stc16(C + (size_t)ma * P.ldc + n, pa);
-            if (mb < M) stc16(C + (size_t)mb * P.ldc + n, pb);
+            if (ma < M) stc16(C + ra * P.ldc + n, pa);
+            if (mb < M) stc16(C + rb * P.ldc + n, pb);
           } else if (n < N) {
-            if (ma < M) *reinterpret_cast<uint2*>(C + (size_t)ma * P.ldc + n) = make_uint2(pa.x, pa.y);
-            if (mb < M) *reinterpret_cast<uint2*>(C + (size_t)mb * P.ldc + n) = make_uint2(pb.x, pb.y);
+            if (ma < M) *reinterpret_cast<uint2*>(C + ra * P.ldc + n) = make_uint2(pa.x, pa.y);
+            if (mb < M) *reinterpret_cast<uint2*>(C + rb * P.ldc + n) = make_uint2(pb.x, pb.y);
           }
         }
         if constexpr (NJ == 6) {   // the remaining 32 columns: 16 rows x 64 B per instruction
           const int jl = lead ? 0 : 2;
           const uint4 z = lead ? piece(i, 0, m) : piece(i, NJ / 2 - 1, m);
           const int n = nw + jl * 32 + c0 * 8;
-          if (m < M && n + 8 <= N) stc16(C + (size_t)m * P.ldc + n, z);
-          else if (m < M && n < N) *reinterpret_cast<uint2*>(C + (size_t)m * P.ldc + n) = make_uint2(z.x, z.y);
+          if (m < M && n + 8 <= N) stc16(C + rm * P.ldc + n, z);
+          else if (m < M && n < N) *reinterpret_cast<uint2*>(C + rm * P.ldc + n) = make_uint2(z.x, z.y);
         }
       }
       return;
@@ -546,7 +550,7 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
         if (n + 8 <= N) *reinterpret_cast<float4*>(fp + 4) = make_float4(v[4], v[5], v[6], v[7]);
         continue;
       }
-      bf16_t* cp = reinterpret_cast<bf16_t*>(P.C) + (size_t)m * P.ldc + n;
+      bf16_t* cp = reinterpret_cast<bf16_t*>(P.C) + (EPI == GGET_EPI_NONE && P.c_rows ? (size_t)P.c_rows[m] : (size_t)m) * P.ldc + n;
       if (n + 8 <= N) {
         if (EPI == GGET_EPI_RESIDUAL) {
           float r[8];
@@ -1465,6 +1469,7 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
                "gemm: split-K needs the fp32 atomic or slab epilogue");
   for (int i = 0; i < g.count; ++i) {
     const GemmProblem& p = g.p[i];
+    GGET_REQUIRE(p.c_rows == nullptr || (epi == GGET_EPI_NONE && split_k <= 1), "gemm: the fused row scatter needs the plain bf16 epilogue");
     if (epi == GGET_EPI_GEGLU_FWD || epi == GGET_EPI_GEGLU_BWD) {
       const bool fwd = epi == GGET_EPI_GEGLU_FWD;
       GGET_REQUIRE(mode == (fwd ? GGET_GEMM_NT : GGET_GEMM_NN) && split_k <= 1 && !p.m_dev && !p.k_dev, "gemm: GEGLU epilogue: wrong mode");
@@ -1494,8 +1499,10 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
 }
 
 int gget_gemm_single(int mode, int epi, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
-                     int lda, int ldb, int ldc, const int* m_dev, const int* k_dev, int split_k, hipStream_t st, bool k_pad_zero) {
+                     int lda, int ldb, int ldc, const int* m_dev, const int* k_dev, int split_k, hipStream_t st, bool k_pad_zero,
+                     const int* c_rows) {
   GemmGroup g;
+  memset(&g, 0, sizeof(g));
   g.count = 1;
   GemmProblem& p = g.p[0];
   p.A = static_cast<const bf16_t*>(A);
@@ -1507,5 +1514,6 @@ int gget_gemm_single(int mode, int epi, const void* A, const void* B, void* C, c
   p.m_dev = m_dev; p.k_dev = k_dev;
   p.k_pad_zero = k_pad_zero ? 1 : 0;
   p.slab_stride = (long)M * ldc;  // EPI_SLAB_F32 through the op-level entry: dense [split_k][M][ldc] slabs
+  p.c_rows = c_rows;
   return gget_gemm_launch(mode, epi, g, split_k, st);
 }

@@ -291,6 +291,57 @@ __device__ __forceinline__ void stc16(bf16_t* p, const uint4& v) {
   typedef unsigned u4nt __attribute__((ext_vector_type(4)));
   __builtin_nontemporal_store(u4nt{v.x, v.y, v.z, v.w}, reinterpret_cast<u4nt*>(p));
 }
+// GEGLU' epilogue (EPI_GEGLU_BWD, see store_tile) of ONE 16-row block x ONE 64-column group: a0..a3 = the four dh accumulators of the
+// group, gv[hf] / uv[hf] = the lane's 8 gate / up pre-activations (row mrow + (lane & 15), columns n64 + hf * 32 + c0 * 8).  Writes
+// d gate / d up of the block with whole-line stores.
+__device__ __forceinline__ void geglu_bwd_block(const f32x4_t& a0, const f32x4_t& a1, const f32x4_t& a2, const f32x4_t& a3,
+                                                const uint4 (&gv)[2], const uint4 (&uv)[2], const GemmProblem& P, int M, int mrow,
+                                                int n64, int lane) {
+  const int l15 = lane & 15, gq = lane >> 4;
+  const bool low = (l15 & 8) == 0;
+  const int c0 = 2 * (gq & 1) + (gq >> 1);
+  const int ma = mrow + (l15 & 7), mb = ma + 8;
+  auto ror8 = [](unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true); };
+  uint4 pk[2][2];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const f32x4_t& x = hf ? a2 : a0;
+    const f32x4_t& y = hf ? a3 : a1;
+    float a[8], gt[8], u[8], dg[8], du[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[e]), __float_as_uint(y[e]), false, false);
+      a[e] = __uint_as_float(r[0]);
+      a[4 + e] = __uint_as_float(r[1]);
+    }
+    unpack8(gv[hf], gt);
+    unpack8(uv[hf], u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float dv = bf2f(f2bf(a[e]));
+      float gval, gd;
+      gelu_erf_both(gt[e], gval, gd);
+      dg[e] = dv * u[e] * gd;
+      du[e] = dv * gval;
+    }
+    pk[hf][0] = pack8(dg);
+    pk[hf][1] = pack8(du);
+  }
+  bf16_t* C = reinterpret_cast<bf16_t*>(P.C);
+  const int nst = n64 + (low ? c0 : c0 + 4) * 8;
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const uint4 x = pk[0][o], y = pk[1][o];
+    const uint4 xr = make_uint4(ror8(x.x), ror8(x.y), ror8(x.z), ror8(x.w));
+    const uint4 yr = make_uint4(ror8(y.x), ror8(y.y), ror8(y.z), ror8(y.w));
+    const uint4 pa = low ? x : yr;
+    const uint4 pb = low ? xr : y;
+    const int col = nst + (o == 1 ? P.ff : 0);
+    if (ma < M) stc16(C + (size_t)ma * P.ldc + col, pa);
+    if (mb < M) stc16(C + (size_t)mb * P.ldc + col, pb);
+  }
+}
+
 template <int EPI, int MI, int NJ, bool ILV = false>
 __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmProblem& P, int M, int N, int mw, int nw, int lane,
                                            int kslice = 0, int chan0 = 0) {
@@ -389,17 +440,37 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
     };
     bf16_t* C = reinterpret_cast<bf16_t*>(P.C);
     bf16_t* C2 = reinterpret_cast<bf16_t*>(P.C2);
+    if constexpr (!FWD) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = mw + i * 16 + l15;
+#pragma unroll
+        for (int jq = 0; jq < NG; ++jq) {
+          uint4 gv[2], uv[2];
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int n = nw + (2 * jq + hf) * 32 + c0 * 8;
+            gv[hf] = make_uint4(0, 0, 0, 0);
+            uv[hf] = make_uint4(0, 0, 0, 0);
+            if (m < M) {
+              gv[hf] = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + n);
+              uv[hf] = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + ff + n);
+            }
+          }
+          geglu_bwd_block(acc[i][4 * jq], acc[i][4 * jq + 1], acc[i][4 * jq + 2], acc[i][4 * jq + 3], gv, uv, P, M, mw + i * 16, nw + jq * 64, lane);
+        }
+      }
+      return;
+    } else {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      const int m = mw + i * 16 + l15;
       const int ma = mw + i * 16 + (l15 & 7), mb = ma + 8;
 #pragma unroll
       for (int jq = 0; jq < NG; ++jq) {
         uint4 pk[2][NOUT];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-          const int jp = 2 * jq + hf;                 // 32-column group: accumulators 2 jp, 2 jp + 1
-          const int n = nw + jp * 32 + c0 * 8;        // (gate) column of the lane's 8 values, row m
+          const int jp = 2 * jq + hf;                 // 32-column group: accumulators 2 jp, 2 jp + 1 (gate columns nw + jp * 32 + c0 * 8 ..)
           float a[8];
           xchg(i, 2 * jp, a);
           if constexpr (FWD) {
@@ -413,25 +484,6 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
             pk[hf][0] = gb;
             pk[hf][1] = ub;
             pk[hf][2] = pack8(hv);
-          } else {
-            float gt[8], u[8], dg[8], du[8];
-            uint4 gq4 = make_uint4(0, 0, 0, 0), uq4 = make_uint4(0, 0, 0, 0);
-            if (m < M) {
-              gq4 = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + n);
-              uq4 = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + ff + n);
-            }
-            unpack8(gq4, gt);
-            unpack8(uq4, u);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float dv = bf2f(f2bf(a[e]));
-              float gv, gd;
-              gelu_erf_both(gt[e], gv, gd);
-              dg[e] = dv * u[e] * gd;
-              du[e] = dv * gv;
-            }
-            pk[hf][0] = pack8(dg);
-            pk[hf][1] = pack8(du);
           }
         }
         const int nst = nw + jq * 64 + (low ? c0 : c0 + 4) * 8;
@@ -449,6 +501,7 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
           if (mb < M) stc16(base + (size_t)mb * ld + col, pb);
         }
       }
+    }
     }
     return;
   }
@@ -720,8 +773,15 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const
 // were at different K offsets of the same panels and every K-slice was fetched once per block).  The block with a tile's K-tile 0 owns
 // it; the others write fp32 partial accumulators to their slot of the workspace and publish a flag (agent-scope release, Guideline 16
 // of the CDNA guide); the owner adds them (acquire) and runs the epilogue.
-template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0, bool SK = false>
-__global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_persist_kernel(const GemmGroup g, int total_tiles) {
+//
+// MODE 2 (the dh + GEGLU' launch, whose epilogue - 96 KiB of gate|up read, 96 KiB of d gate|up written and an erf-GELU value + derivative
+// per element for every 192x128 tile - takes as long as its K = 768 loop): TWO blocks per CU (2-slot rings of 40 KiB, <= 128 VGPRs),
+// grid = 2 x CUs, so that one block's epilogue runs under the other's K-loop with its own VMEM counter and barrier.  -5 % on the launch
+// (cold 74.5 -> 70.5 us), -0.02 ms on the C1 step.  Measured and dropped (profiles/r03_step_experiments.txt, item 11): the same epilogue
+// run one 16-row block at a time inside the NEXT tile's K-loop of a one-block-per-CU kernel (operands prefetched by LDS-DMA into a
+// landing area) - the in-order VMEM queue makes every K-tile wait for the HBM-latency operand loads issued before it: -2 % / nothing.
+template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0, bool SK = false, int MODE = 0>
+__global__ void __launch_bounds__(WM * WN * 64, MODE == 2 ? 4 : ((WM * WN) >= 8 ? 2 : 1)) gemm_persist_kernel(const GemmGroup g, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = WM * WN * 64;
   using TA = TileIO<BM, A_MC, NT, BK>;
@@ -734,6 +794,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
   constexpr int KSH = BK == 64 ? 6 : 5;
   constexpr bool ILV = EPI == GGET_EPI_ROPE && BN == 192;   // see store_tile
   static_assert(!ILV || WN == 2, "interleaved RoPE tile: two waves across N");
+  static_assert(MODE == 0 || MODE == 2, "persistent kernel modes");
 
   const int G = gridDim.x;                                     // multiple of 8
   const int perm = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);  // XCD-contiguous inside every round
@@ -795,7 +856,13 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? 2 : 1) gemm_per
       return true;
     }
     c.kb = 0;
-    const int tile = r * G + perm;
+    int tile = r * G + perm;
+    if constexpr (MODE == 2) {
+      // the last, partial round goes to the blocks dispatched first (one per CU, spread over the XCDs), not to the first XCDs
+      const int full = total_tiles / G;
+      if (r == full) tile = full * G + (int)blockIdx.x;
+      if (r > full || (r == full && (int)blockIdx.x >= total_tiles - full * G)) return false;
+    }
     if (tile >= total_tiles) return false;
     int pi = 0;
 #pragma unroll
@@ -1145,21 +1212,22 @@ int launch_ks_cfg(GemmGroup& g, int total, hipStream_t st) {
 }
 
 // launch one persistent configuration: one block per CU (grid rounded to the 8 XCDs)
-template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0, bool SK = false>
+template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0, bool SK = false, int MODE = 0>
 int launch_persist_cfg(GemmGroup& g, int total, int num_cu, hipStream_t st) {
   constexpr int STG = (BM + BN) * BK * 2;
   constexpr int SM = (NSLOT_ > 0 ? NSLOT_ : persist_slots(STG)) * STG;
+  if (MODE == 2) num_cu *= 2;
   static_assert(SM <= 160 * 1024, "LDS ring");
   static_assert(!SK || (size_t)BM * BN * 4 <= kStreamKSlotBytes, "stream-K slot");
   int G = total < num_cu && !SK ? total : num_cu;
   G = (G + 7) & ~7;  // the XCD permutation needs a multiple of 8 (idle blocks exit at once)
   static bool attr0 = false;
   if (!attr0) {
-    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BM, BN, BK, WM, WN, A_MC, B_MC, EPI, NSLOT_, SK>),
+    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BM, BN, BK, WM, WN, A_MC, B_MC, EPI, NSLOT_, SK, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SM));
     attr0 = true;
   }
-  hipLaunchKernelGGL((gemm_persist_kernel<BM, BN, BK, WM, WN, A_MC, B_MC, EPI, NSLOT_, SK>), dim3(G), dim3(WM * WN * 64), SM, st, g, total);
+  hipLaunchKernelGGL((gemm_persist_kernel<BM, BN, BK, WM, WN, A_MC, B_MC, EPI, NSLOT_, SK, MODE>), dim3(G), dim3(WM * WN * 64), SM, st, g, total);
   GGET_LAUNCH_CHECK();
   return 0;
 }
@@ -1361,6 +1429,10 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
           p.tiles_n = p.N / BN;
           p.tile_begin = tot5;
           tot5 += ((p.M + 191) / 192) * p.tiles_n;
+        }
+        // the GEGLU' launch: two blocks per CU (kernel comment, MODE 2); g_gemm_variant bit 5: one block per CU as everywhere else
+        if constexpr (EPI == GGET_EPI_GEGLU_BWD && BN == 128) {
+          if (!(g_gemm_variant & 32)) return launch_persist_cfg<192, BN, 64, WM, WN, A_MC, B_MC, EPI, 2, false, 2>(g, tot5, num_cu, st);
         }
         return launch_persist_cfg<192, BN, 64, WM, WN, A_MC, B_MC, EPI>(g, tot5, num_cu, st);
       }

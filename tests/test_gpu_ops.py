@@ -435,11 +435,14 @@ def test_geglu(lib):
     assert rel_l2(dgu.float().cpu().numpy(), gf.grad.cpu().numpy()) < 4e-3
 
 
-@pytest.mark.parametrize("T,d,ff", [(77, 128, 512), (600, 192, 384), (1000, 768, 3072), (96, 128, 320)])
+@pytest.mark.parametrize("T,d,ff", [(77, 128, 512), (600, 192, 384), (1000, 768, 3072), (96, 128, 320),
+                                    (5696, 768, 3072), (3000, 128, 3072), (3000, 256, 3072), (2990, 320, 3072)])
 def test_gateup_geglu_fused(lib, T, d, ff):
     """gate|up projection with the gated-GELU product in the GEMM epilogue and its backward in the epilogue of the down
     dgrad GEMM: bit-identical to the un-fused op sequence (same bf16 rounding points), close to the fp32 statement of
-    hf LlamaMLP.forward :174-176.  ff = 320 takes the un-fused fallback (ff % 128 != 0)."""
+    hf LlamaMLP.forward :174-176.  ff = 320 takes the un-fused fallback (ff % 128 != 0).  The last four shapes run the backward
+    through the 192-row persistent kernel with the DEFERRED epilogue (a tile's GEGLU' inside the next tile's K-loop): the C1
+    var-len shape, K = 128 / 256 (fewer K-tiles than epilogue steps / exactly as many) and a ragged last row tile."""
     x, wgu, wdown, dy = rnd(T, d, seed=1), rnd(2 * ff, d, seed=2, scale=0.08), rnd(d, ff, seed=3, scale=0.05), rnd(T, d, seed=4)
     gu = torch.zeros(T, 2 * ff, dtype=torch.bfloat16, device="cuda")
     h = torch.zeros(T, ff, dtype=torch.bfloat16, device="cuda")

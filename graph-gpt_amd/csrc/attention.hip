@@ -193,18 +193,23 @@ struct Drop {
   unsigned seed;
 };
 // One hash serves TWO scores: w(seed, bh, q, k >> 1) = mix((seed ^ bh*C0) + q*C1 + (k>>1)*C2), mix = one multiply between two
-// xor-shifts; key k uses the low (k even) or high (k odd) 16 bits of w (measured on 3 M scores: drop rates 0.1000 / 0.2998
-// for p = 0.1 / 0.3 in both fields, correlations between the fields of a pair, neighbouring keys, queries and heads <= 2e-3).
-// The softmax loops are VALU-bound at head_dim 64 and a 32-bit multiply is quarter rate: in the kernels whose lanes walk
-// along keys (forward, dQ) a lane's accumulator registers come in (k, k+1) pairs, so the hash costs one multiply per two
-// scores.  Callers pass the partial sum of everything fixed for the lane (drop_base) and add the moving term.
-// tests/test_gpu_ops.py:_drop_mask is the Python twin.
+// xor-shifts; key k uses the low (k even) or high (k odd) 16 bits of w.  The multiply is the full-rate 24-bit one (v_mul_u32_u24:
+// low 24 bits of the folded word x a 24-bit constant, low 32 bits of the product); a hash word is {v_add, v_xor sdwa, v_mul_u32_u24,
+// v_lshrrev, v_xor}.  (Round 3: replacing the quarter-rate 32-bit multiply changed NO kernel time - B16/S2048/H12 with p = 0.1: forward
+// 438.6 us, backward 1097 us before and after; what the dropout costs at head_dim 64 is its instruction COUNT beside the MFMAs, five
+// per score on top of 6.6, not the rate of any one of them.  The 24-bit mix stays for its better mask statistics.)
+// Measured on 3 x 6.3 M scores (tools/drop_hash_eval.py): drop rates 0.1000-0.1003 / 0.2997-0.3003 for
+// p = 0.1 / 0.3 in both fields; correlations between the two fields of a word, keys 1 / 2 apart, queries 1 / 2 apart, neighbouring
+// heads and the two diagonals all <= 1.5e-3 (noise floor 4e-4; the 32-bit multiply it replaces: <= 5e-3); per-row and per-column
+// drop-rate dispersion 0.98-1.02 of binomial.  In the kernels whose lanes walk along keys (forward, dQ) a lane's accumulator
+// registers come in (k, k+1) pairs, so one word serves two scores.  Callers pass the partial sum of everything fixed for the lane
+// (drop_base) and add the moving term.  tests/test_gpu_ops.py:_drop_mask is the Python twin.
 __device__ __forceinline__ unsigned drop_base(const Drop& D, unsigned bh, unsigned q_or_0, unsigned khalf_or_0) {
   return (D.seed ^ (bh * 0x9E3779B1u)) + q_or_0 * 0x85EBCA77u + khalf_or_0 * 0xC2B2AE3Du;
 }
 __device__ __forceinline__ unsigned drop_word(unsigned x) {
   x ^= x >> 16;
-  x *= 0x7FEB352Du;
+  x = __umul24(x, 0x9E3779u);
   x ^= x >> 15;
   return x;
 }

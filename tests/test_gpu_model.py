@@ -937,7 +937,7 @@ def _attn_drop_keep(seed, B, H, S, p):
     x = (np.uint64(seed) ^ ((bh * np.uint64(0x9E3779B1)) & M32)) & M32
     x = (x + q * np.uint64(0x85EBCA77) + (k >> np.uint64(1)) * np.uint64(0xC2B2AE3D)) & M32
     x ^= x >> np.uint64(16)
-    x = (x * np.uint64(0x7FEB352D)) & M32
+    x = ((x & np.uint64(0xFFFFFF)) * np.uint64(0x9E3779)) & M32      # v_mul_u32_u24: the low 24 bits times a 24-bit constant
     w = x ^ (x >> np.uint64(15))
     f = np.where((k & np.uint64(1)) == 1, w >> np.uint64(16), w & np.uint64(0xFFFF))
     thresh = np.uint64(int(np.float32(p) * np.float32(65536.0)))

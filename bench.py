@@ -279,6 +279,7 @@ def main():
     # the dominant kernels' launch durations INSIDE a step: three more (untimed) steps with HIP events around those launches, on the
     # stream they run on (single process only - the extra steps would otherwise need every rank)
     in_step = {}
+    gemm_info = None
     if world == 1:
         eng_ = model._engine
         eng_.debug_probe(True)
@@ -287,6 +288,23 @@ def main():
         torch.cuda.synchronize()
         w_ms, g_ms = eng_.debug_probe(False)
         in_step = {k: v for k, v in (("wgrad_layer", w_ms), ("gateup", g_ms)) if v > 0}
+        # every GEMM launch of three more steps between events: the TIME-WEIGHTED rate of the step's GEMMs (sum of 2 M N K over the
+        # sum of the launch durations; the SMTP head's device-sized launches are counted but left out of both sums)
+        import ctypes as C_
+        L = importlib.import_module("graph-gpt_amd._lib")
+        lib_ = L.load()
+        L.check(lib_.gget_debug_gemm_probe(1, None, None, None, None))
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        fl_, ms_, n_, sk_ = C_.c_double(), C_.c_double(), C_.c_int32(), C_.c_int32()
+        L.check(lib_.gget_debug_gemm_probe(0, C_.byref(fl_), C_.byref(ms_), C_.byref(n_), C_.byref(sk_)))
+        if ms_.value > 0:
+            gemm_info = {"launches_per_step": n_.value // 3, "device_sized_launches_left_out_per_step": sk_.value // 3,
+                         "ms_per_step": ms_.value / 3, "tflops_time_weighted": fl_.value / (ms_.value * 1e-3) / 1e12,
+                         "frac_of_peak_time_weighted": fl_.value / (ms_.value * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                         "flops_per_step": fl_.value / 3,
+                         "note": "executed rows (var-len layout: real tokens); HIP events around every launch, untimed extra steps"}
     stats = torch.tensor([dt, float(real_tokens), float(loss.item())], dtype=torch.float64, device="cuda")
     if world > 1:
         mx = stats.clone()
@@ -354,6 +372,8 @@ def main():
                           "token_layout": "varlen" if ran_varlen else "padded", "rows": t_rows, "padded_rows": B * S},
             "roofline": roofline,
         }
+        if gemm_info is not None:
+            out["step_mfma"]["gemms"] = gemm_info
         if dp_info is not None:
             dp_info["exposed_comm_ms"] = ms - dp_info["ms_per_step_without_exchange"]
             out["dp"] = dp_info

@@ -93,6 +93,7 @@ SIGNATURES = {
     "gget_set_rope_range": (i32, [vp, f32]),
     "gget_set_raw_embeds": (i32, [vp, vp, i32]),
     "gget_debug_probe": (i32, [vp, i32, C.POINTER(f32)]),
+    "gget_debug_gemm_probe": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(i32)]),
     "gget_set_dropout_ex": (i32, [vp, f32, f32, f32]),
     "gget_op_gateup_geglu": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "gget_op_down_dgrad_geglu": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),

@@ -29,6 +29,7 @@
 // GGET_GEMM_192=0, GGET_GEMM_SUPER=<rows per L2 super-tile>.
 #include <stdlib.h>
 #include <string.h>
+#include <deque>
 
 #include "common.h"
 #include "gemm.h"
@@ -1521,6 +1522,10 @@ int launch_mode(GemmGroup& g, int epi, int split_k, hipStream_t st) {
 
 void gget_gemm_streamk_workspace(void* ws) { t_streamk_ws = ws; }
 
+struct GemmProbeRec { hipEvent_t e0, e1; double flops; bool dyn; };
+static std::deque<GemmProbeRec> g_probe;   // (deque: records keep their address while launches are appended)
+static bool g_probe_on = false;
+
 int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t st) {
   GGET_REQUIRE(g.count >= 1 && g.count <= GGET_MAX_GROUP, "gemm: bad group size %d", g.count);
   g.sk_partial = nullptr; g.sk_flags = nullptr; g.sk_epoch = 0;
@@ -1561,13 +1566,65 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
     GGET_REQUIRE(((size_t)p.M + 64) * (size_t)p.lda * 2 < (1ull << 32) && ((size_t)p.N + 64) * (size_t)p.ldb * 2 < (1ull << 32),
                  "gemm: operand spans more than 4 GiB (M %d lda %d N %d ldb %d)", p.M, p.lda, p.N, p.ldb);
   }
-  switch (mode) {
-    case GGET_GEMM_NT: return launch_mode<false, false>(g, epi, split_k, st);
-    case GGET_GEMM_NN: return launch_mode<false, true>(g, epi, split_k, st);
-    case GGET_GEMM_TN: return launch_mode<true, true>(g, epi, split_k, st);
+  // measurement aid (gget_debug_gemm_probe): bracket the launch with events and keep its algorithmic FLOPs.  Launches whose row or
+  // K count lives on the device (the SMTP head) have no host-side FLOP count: counted separately, left out of both sums.
+  GemmProbeRec* rec = nullptr;
+  if (g_probe_on) {
+    double fl = 0;
+    bool dyn = false;
+    for (int i = 0; i < g.count; ++i) {
+      fl += 2.0 * g.p[i].M * g.p[i].N * g.p[i].K;
+      dyn = dyn || g.p[i].m_dev || g.p[i].k_dev;
+    }
+    g_probe.emplace_back();
+    rec = &g_probe.back();
+    rec->flops = fl;
+    rec->dyn = dyn;
+    GGET_HIP_CHECK(hipEventCreate(&rec->e0));
+    GGET_HIP_CHECK(hipEventCreate(&rec->e1));
+    GGET_HIP_CHECK(hipEventRecord(rec->e0, st));
   }
-  gget_set_error("gemm: unknown mode %d", mode);
-  return 2;
+  int rc = 2;
+  switch (mode) {
+    case GGET_GEMM_NT: rc = launch_mode<false, false>(g, epi, split_k, st); break;
+    case GGET_GEMM_NN: rc = launch_mode<false, true>(g, epi, split_k, st); break;
+    case GGET_GEMM_TN: rc = launch_mode<true, true>(g, epi, split_k, st); break;
+    default: gget_set_error("gemm: unknown mode %d", mode);
+  }
+  if (rec) GGET_HIP_CHECK(hipEventRecord(rec->e1, st));
+  return rc;
+}
+
+// Measurement aid behind bench.py's time-weighted GEMM figure (no reference counterpart).  enable = 1: start recording every GEMM
+// launch of this process (previous records dropped); enable = 0: stop, wait for the recorded launches and report the sum of their
+// algorithmic FLOPs (2 M N K per problem), the sum of their durations (HIP events on the launch stream: includes the launch gaps
+// the events themselves open, so the figure is a lower bound of the in-step rate), the number of launches summed and the number left
+// out (device-sized row / K counts).
+extern "C" int gget_debug_gemm_probe(int enable, double* flops_out, double* ms_out, int* launches_out, int* skipped_out) {
+  if (enable) {
+    for (auto& r : g_probe) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    g_probe.clear();
+    g_probe_on = true;
+    return 0;
+  }
+  g_probe_on = false;
+  double fl = 0, ms = 0;
+  int n = 0, skipped = 0;
+  for (auto& r : g_probe) {
+    GGET_HIP_CHECK(hipEventSynchronize(r.e1));
+    float t = 0.f;
+    GGET_HIP_CHECK(hipEventElapsedTime(&t, r.e0, r.e1));
+    if (r.dyn) { ++skipped; }
+    else { fl += r.flops; ms += t; ++n; }
+    hipEventDestroy(r.e0);
+    hipEventDestroy(r.e1);
+  }
+  g_probe.clear();
+  if (flops_out) *flops_out = fl;
+  if (ms_out) *ms_out = ms;
+  if (launches_out) *launches_out = n;
+  if (skipped_out) *skipped_out = skipped;
+  return 0;
 }
 
 int gget_gemm_single(int mode, int epi, const void* A, const void* B, void* C, const void* R, int M, int N, int K,

@@ -300,6 +300,10 @@ int gget_debug_set(int key, int value);
  * avg_ms_out (may be NULL) receives the mean durations recorded so far.  bench.py uses it for the roofline of the dominant kernel
  * as it runs INSIDE a step. */
 int gget_debug_probe(gget_handle_t h, int enable, float* avg_ms_out);
+/* measurement aid behind bench.py's time-weighted GEMM figure (no reference counterpart).  enable = 1: start recording every GEMM
+ * launch of the process between HIP events; enable = 0: stop and report the sum of the algorithmic FLOPs (2 M N K) and of the
+ * durations of the recorded launches, how many were summed and how many were left out (row / K counts that live on the device) */
+int gget_debug_gemm_probe(int enable, double* flops_out, double* ms_out, int* launches_out, int* skipped_out);
 /* measurement aid (tools/coresidency.py; no reference counterpart): occupies `blocks` CU slots (256 threads, lds_bytes of LDS
  * each) for ~microseconds on `stream`, as a stand-in for a collective's kernel running beside the compute stream */
 int gget_debug_occupy(void* scratch, uint64_t scratch_bytes, int blocks, int lds_bytes, int microseconds, void* stream);

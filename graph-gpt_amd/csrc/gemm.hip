@@ -1423,7 +1423,9 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
         t192 += (long)((g.p[i].M + 191) / 192) * (g.p[i].N / BN);
       }
       const long cur_rounds = (total + num_cu - 1) / num_cu, r192 = (t192 + num_cu - 1) / num_cu;
-      if (ok && r192 * 192 < cur_rounds * 256) {
+      // (a 192-row tile moves 8 % more operand bytes per FLOP than the 256-row one: it has to save more than that in rounds x rows -
+      //  gate|up at T = 41 472: 21 x 192 against 16 x 256 is 1.5 % less work and ran 463 us against 432; tools/gemm_gu_ab.py)
+      if (ok && r192 * 192 * 100 < cur_rounds * 256 * 92) {
         int tot5 = 0;
         for (int i = 0; i < g.count; ++i) {
           GemmProblem& p = g.p[i];
@@ -1501,7 +1503,7 @@ int launch_mode(GemmGroup& g, int epi, int split_k, hipStream_t st) {
         // (192-row tiles when they need fewer rounds x rows than 256-row tiles - see launch_t)
         long t192 = 0;
         for (int i = 0; i < g.count; ++i) t192 += (long)((g.p[i].M + 191) / 192) * (g.p[i].N / 256);
-        if (!(g_gemm_variant & 4) && ((t192 + num_cu - 1) / num_cu) * 192 < ((total + num_cu - 1) / num_cu) * 256) {
+        if (!(g_gemm_variant & 4) && ((t192 + num_cu - 1) / num_cu) * 192 * 100 < ((total + num_cu - 1) / num_cu) * 256 * 92) {   // (margin: see launch_t)
           int tot2 = 0;
           for (int i = 0; i < g.count; ++i) {
             GemmProblem& p = g.p[i];

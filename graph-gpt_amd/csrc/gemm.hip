@@ -1301,7 +1301,12 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
         ok256 = ok256 && (g.p[i].N % 256) == 0;
       }
       // measured (profiles/r01_gemm_tiles.txt): pays only with >= ~2.5 tiles per CU (FFN gate|up), loses on N = 2304 / 3072
-      if (ok256 && t256 >= (5 * num_cu) / 2) {
+      // ... or, from 1.5 tiles per CU on, when its rounds x tile area come within 10 % of the default tile's (the 256x256 tile moves
+      // 2/3 of the operand bytes per FLOP: the N = d GEMMs of a 41 472-row batch - ogbl-ppa fine-tune - are 486 tiles = two rounds
+      // against 972 = four rounds of 256x128: dxn2 386 -> 343 us, down 216 -> 198, dxn1 143 -> 134, o 70 -> 64; tools/gemm_bench.py)
+      const long r256 = (t256 + num_cu - 1) / num_cu, r_cur = (total + num_cu - 1) / num_cu;
+      const bool near = 2 * t256 >= 3L * num_cu && r256 * 256 * 256 * 9 <= r_cur * BM * BN * 10;
+      if (ok256 && (t256 >= (5 * num_cu) / 2 || near)) {
         int tot2 = 0;
         for (int i = 0; i < g.count; ++i) {
           GemmProblem& p = g.p[i];

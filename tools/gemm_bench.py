@@ -25,7 +25,7 @@ def bench(mode, M, N, K, iters=20, epi=0):
     ms = e0.elapsed_time(e1) / iters
     return ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12
 
-T, d, ff = 8192, 768, 3072
+T, d, ff = int(os.environ.get('GGET_T', '8192')), 768, 3072   # GGET_T: rows
 shapes = [("NT qkv", L.GEMM_NT, T, 3 * d, d, 0), ("NT gu", L.GEMM_NT, T, 2 * ff, d, 0), ("NT o+res", L.GEMM_NT, T, d, d, 1),
           ("NT down+res", L.GEMM_NT, T, d, ff, 1), ("NN dh", L.GEMM_NN, T, ff, d, 0), ("NN dxn2", L.GEMM_NN, T, d, 2 * ff, 0),
           ("NN dattn", L.GEMM_NN, T, d, d, 0), ("NN dxn1", L.GEMM_NN, T, d, 3 * d, 0), ("TN dWgu", L.GEMM_TN, 2 * ff, d, T, 0),

@@ -1962,6 +1962,8 @@ extern "C" int gget_comm_init(gget_handle_t h, int rank, int world, const void* 
   h->comm = c;
   h->comm_rank = rank;
   h->comm_world = world;
+  // a collective's kernel will share the chip with the compute stream: keep LDS headroom on every CU
+  if (world > 1 && g_gemm_lds_headroom < 2) g_gemm_lds_headroom = 2;
   return 0;
 }
 

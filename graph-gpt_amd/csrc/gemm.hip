@@ -36,7 +36,8 @@
 
 #define LDS_AS __attribute__((address_space(3)))
 
-int g_gemm_lds_headroom = 1;   // 1 (default): the 128x192 tile kernels run a 3-slot ring and leave 40 KiB of LDS free, 0: 4 slots = all 160 KiB
+int g_gemm_lds_headroom = 1;   // 1 (default): the 128x192 / 192x128 tile kernels run a 3-slot ring and leave 40 KiB of LDS free, 0: 4 slots = all 160 KiB,
+                               // 2 (set when a communicator is attached: world > 1): also no launch with two LDS-filling blocks per CU
                                // (gget_debug_set key 2, env GGET_GEMM_LDS_HEADROOM; measured in profiles/r02_coresidency.txt)
 int g_gemm_split_last = 0;   // split the K range of the last, partial round's tiles among the idle blocks (gget_debug_set key 3, env
                             // GGET_GEMM_SPLIT_LAST).  Off by default: on the C1 shapes the hand-over of the partial tiles costs more than the
@@ -1439,9 +1440,12 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
           tot5 += ((p.M + 191) / 192) * p.tiles_n;
         }
         // the GEGLU' launch: two blocks per CU (kernel comment, MODE 2); g_gemm_variant bit 5: one block per CU as everywhere else
+        // (g_gemm_lds_headroom 2 = a collective's kernel shares the chip, data-parallel runs: the two blocks fill a CU's LDS and a foreign
+        //  workgroup on a CU would push one of them into a second round - one block per CU with a 3-slot ring then)
         if constexpr (EPI == GGET_EPI_GEGLU_BWD && BN == 128) {
-          if (!(g_gemm_variant & 32)) return launch_persist_cfg<192, BN, 64, WM, WN, A_MC, B_MC, EPI, 2, false, 2>(g, tot5, num_cu, st);
+          if (!(g_gemm_variant & 32) && g_gemm_lds_headroom < 2) return launch_persist_cfg<192, BN, 64, WM, WN, A_MC, B_MC, EPI, 2, false, 2>(g, tot5, num_cu, st);
         }
+        if (g_gemm_lds_headroom) return launch_persist_cfg<192, BN, 64, WM, WN, A_MC, B_MC, EPI, 3>(g, tot5, num_cu, st);
         return launch_persist_cfg<192, BN, 64, WM, WN, A_MC, B_MC, EPI>(g, tot5, num_cu, st);
       }
     }

@@ -170,6 +170,11 @@ class GgetEngine:
         # measurement switch (bench.py `dp.exposed_comm_ms`): False runs the same staged backward WITHOUT issuing the collectives -
         # the ranks then drift apart, so it is only ever set for a few untimed-for-throughput diagnostic steps
         self.exchange = True
+        if self.world > 1 and torch.cuda.is_available():
+            # a collective's kernel shares the chip with the compute stream from now on: the GEMM launcher keeps LDS headroom on every
+            # CU (no launch with two LDS-filling workgroups per CU; gget_debug_set key 2)
+            from . import _lib as L
+            L.check(L.load().gget_debug_set(2, 2))
         model.materialize_grads = False  # fused path: gradients stay in the flat bf16 arena
         model._managed_by_engine = True  # the bucketed exchange below replaces the all-reduce of _autograd_backward
 

@@ -163,8 +163,8 @@ def pmc_traffic(which="wgrad_layer", rows=8192):
 KERNEL_NAMES = {
     "wgrad_layer": "gemm_ks_kernel<192,192,TN> (in-block K split): grouped weight gradients of one decoder layer - dW = dY^T X for "
                    "gate|up, down, q|k|v, o in ONE launch, K = T, 256 tiles = one per CU",
-    "gateup": "gemm_persist_kernel<256,256,64,NT,EPI_GEGLU_FWD>: FFN gate|up [T,d]x[d,2ff] with the gated-GELU product in its epilogue",
-    "dgrad_gu": "gemm_ks_kernel<128,192,NN> (in-block K split): dgrad dxn2 = dgu W_gu [T,2ff]x[2ff,d]",
+    "gateup": "gemm_persist_kernel<192 or 256,256,64,NT,EPI_GEGLU_FWD> (192-row tiles at T = 5696): FFN gate|up [T,d]x[d,2ff] with the gated-GELU product in its epilogue",
+    "dgrad_gu": "gemm_ks_kernel<64, 96 or 128,192,NN> (in-block K split; 96-row tiles at T = 5696): dgrad dxn2 = dgu W_gu [T,2ff]x[2ff,d]",
 }
 
 

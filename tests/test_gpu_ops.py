@@ -84,9 +84,11 @@ def test_gemm_residual_and_atomic(lib):
 
 
 @pytest.mark.parametrize("mode", [L.GEMM_NT, L.GEMM_NN])
-@pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (1000, 768, 256), (40000, 384, 128)])
+@pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (1000, 768, 256), (40000, 384, 128), (41472, 768, 768), (41413, 768, 2304), (33000, 1536, 320)])
 def test_gemm_tile_128x192(lib, mode, M, N, K):
-    # N = d outputs take the 128x192 persistent tile (N % 192 == 0); residual epilogue, ragged M, several tiles per block
+    # N = d outputs take the 128x192 persistent tile (N % 192 == 0); residual epilogue, ragged M, several tiles per block.  The last three
+    # shapes (ogbl-ppa-sized row counts) take 256x256 tiles by the "within 10 % of the default tile's rounds x area" rule, one with a ragged
+    # last row tile, one with K no multiple of 64 x ring depth
     A, R = rnd(M, K, seed=11), rnd(M, N, seed=13)
     B = rnd(N, K, seed=12) if mode == L.GEMM_NT else rnd(K, N, seed=12)
     ref = A.float() @ (B.float().T if mode == L.GEMM_NT else B.float()) + R.float()

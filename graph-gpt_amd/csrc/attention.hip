@@ -70,17 +70,31 @@ __device__ __forceinline__ void rope_pair(uint4& lo, uint4& up, const Rope& R, i
   up = pack8(ob);
 }
 
+// Global loads of these helpers are UNCONDITIONAL: the row index is clamped into the sample ([0, row_lim - 1], at least 0) and rows
+// beyond the limit are zeroed with a select afterwards.  Written as `if (row < row_lim) v = load` the compiler branches around every
+// load and waits vmcnt(0) behind each one (round 3, ISA of the S <= 32 kernels: twelve serialised load -> wait -> ds_write round trips
+// per problem plus four for the V fragments - the kernels were bound by that chain, not by bytes); the RoPE test is made once per tile,
+// outside the chunk loops, for the same reason.
+__device__ __forceinline__ uint4 zero_if(bool dead, const uint4& v) {
+  return make_uint4(dead ? 0u : v.x, dead ? 0u : v.y, dead ? 0u : v.z, dead ? 0u : v.w);
+}
+__device__ __forceinline__ int clamp_row(int gr, int row_lim) { return max(min(gr, row_lim - 1), 0); }
+
 // [32 rows][64 dh] bf16 tile -> LDS (rows >= row_lim are zero-filled so masked probabilities never meet NaNs)
 __device__ __forceinline__ void load_tile(unsigned char* lds, const bf16_t* __restrict__ base, int r0, int row_lim,
                                           size_t pitch, int lane) {
+  uint4 v[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = lane + i * 64;
     const int row = c >> 3, ch = c & 7;
-    const int gr = r0 + row;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (gr < row_lim) v = *reinterpret_cast<const uint4*>(base + (size_t)gr * pitch + ch * 8);
-    *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = v;
+    v[i] = *reinterpret_cast<const uint4*>(base + (size_t)clamp_row(r0 + row, row_lim) * pitch + ch * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + i * 64;
+    const int row = c >> 3, ch = c & 7;
+    *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = zero_if(r0 + row >= row_lim, v[i]);
   }
 }
 // same, rotating every row by its position (each lane fetches its chunk and the chunk 32 channels away).
@@ -88,24 +102,39 @@ __device__ __forceinline__ void load_tile(unsigned char* lds, const bf16_t* __re
 template <int NT>
 __device__ __forceinline__ void load_tile_coop(unsigned char* lds, const bf16_t* __restrict__ base, int r0, int row_lim,
                                                size_t pitch, int tid, const Rope& R, int b) {
+  constexpr int N = 256 / NT;
+  if (R.cos_tab) {
+    uint4 lo[N], up[N];
 #pragma unroll
-  for (int i = 0; i < 256 / NT; ++i) {
-    const int c = tid + i * NT;
-    const int row = c >> 3, ch = c & 7;
-    const int gr = r0 + row;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (gr < row_lim) {
-      const bf16_t* rp = base + (size_t)gr * pitch;
-      if (R.cos_tab) {
-        uint4 lo = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8);
-        uint4 up = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8 + 32);
-        rope_pair(lo, up, R, rope_pos(R, b, gr), (ch & 3) * 8);
-        v = (ch & 4) ? up : lo;
-      } else {
-        v = *reinterpret_cast<const uint4*>(rp + ch * 8);
-      }
+    for (int i = 0; i < N; ++i) {
+      const int c = tid + i * NT;
+      const int row = c >> 3, ch = c & 7;
+      const bf16_t* rp = base + (size_t)clamp_row(r0 + row, row_lim) * pitch;
+      lo[i] = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8);
+      up[i] = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8 + 32);
     }
-    *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int c = tid + i * NT;
+      const int row = c >> 3, ch = c & 7;
+      const int gr = r0 + row;
+      rope_pair(lo[i], up[i], R, rope_pos(R, b, clamp_row(gr, row_lim)), (ch & 3) * 8);
+      *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = zero_if(gr >= row_lim, (ch & 4) ? up[i] : lo[i]);
+    }
+  } else {
+    uint4 v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int c = tid + i * NT;
+      const int row = c >> 3, ch = c & 7;
+      v[i] = *reinterpret_cast<const uint4*>(base + (size_t)clamp_row(r0 + row, row_lim) * pitch + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int c = tid + i * NT;
+      const int row = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = zero_if(r0 + row >= row_lim, v[i]);
+    }
   }
 }
 // Register-prefetched variant of load_tile_coop: `tile_fetch` only issues the global loads of a tile (they stay in flight
@@ -118,59 +147,49 @@ struct TilePref {
 template <int NT>
 __device__ __forceinline__ void tile_fetch(TilePref<NT>& p, const bf16_t* __restrict__ base, int r0, int row_lim, size_t pitch,
                                            int tid, const Rope& R) {
+  if (R.cos_tab) {
 #pragma unroll
-  for (int i = 0; i < 256 / NT; ++i) {
-    const int c = tid + i * NT;
-    const int row = c >> 3, ch = c & 7;
-    const int gr = r0 + row;
-    p.lo[i] = make_uint4(0, 0, 0, 0);
-    p.up[i] = make_uint4(0, 0, 0, 0);
-    if (gr < row_lim) {
-      const bf16_t* rp = base + (size_t)gr * pitch;
-      if (R.cos_tab) {
-        p.lo[i] = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8);
-        p.up[i] = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8 + 32);
-      } else {
-        p.lo[i] = *reinterpret_cast<const uint4*>(rp + ch * 8);
-      }
+    for (int i = 0; i < 256 / NT; ++i) {
+      const int c = tid + i * NT;
+      const int row = c >> 3, ch = c & 7;
+      const bf16_t* rp = base + (size_t)clamp_row(r0 + row, row_lim) * pitch;
+      p.lo[i] = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8);
+      p.up[i] = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8 + 32);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 256 / NT; ++i) {
+      const int c = tid + i * NT;
+      const int row = c >> 3, ch = c & 7;
+      p.lo[i] = *reinterpret_cast<const uint4*>(base + (size_t)clamp_row(r0 + row, row_lim) * pitch + ch * 8);
     }
   }
 }
 template <int NT>
 __device__ __forceinline__ void tile_commit(unsigned char* lds, TilePref<NT>& p, int r0, int row_lim, int tid, const Rope& R,
                                             int b) {
+  if (R.cos_tab) {
 #pragma unroll
-  for (int i = 0; i < 256 / NT; ++i) {
-    const int c = tid + i * NT;
-    const int row = c >> 3, ch = c & 7;
-    const int gr = r0 + row;
-    uint4 v = p.lo[i];
-    if (R.cos_tab && gr < row_lim) {
+    for (int i = 0; i < 256 / NT; ++i) {
+      const int c = tid + i * NT;
+      const int row = c >> 3, ch = c & 7;
+      const int gr = r0 + row;
       uint4 lo = p.lo[i], up = p.up[i];
-      rope_pair(lo, up, R, rope_pos(R, b, gr), (ch & 3) * 8);
-      v = (ch & 4) ? up : lo;
+      rope_pair(lo, up, R, rope_pos(R, b, clamp_row(gr, row_lim)), (ch & 3) * 8);
+      *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = zero_if(gr >= row_lim, (ch & 4) ? up : lo);
     }
-    *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = v;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 256 / NT; ++i) {
+      const int c = tid + i * NT;
+      const int row = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = zero_if(r0 + row >= row_lim, p.lo[i]);
+    }
   }
 }
 __device__ __forceinline__ void load_tile_rope(unsigned char* lds, const bf16_t* __restrict__ base, int r0, int row_lim,
                                                size_t pitch, int lane, const Rope& R, int b) {
-  if (!R.cos_tab) { load_tile(lds, base, r0, row_lim, pitch, lane); return; }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = lane + i * 64;
-    const int row = c >> 3, ch = c & 7;
-    const int gr = r0 + row;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (gr < row_lim) {
-      const bf16_t* rp = base + (size_t)gr * pitch;
-      uint4 lo = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8);
-      uint4 up = *reinterpret_cast<const uint4*>(rp + (ch & 3) * 8 + 32);
-      rope_pair(lo, up, R, rope_pos(R, b, gr), (ch & 3) * 8);
-      v = (ch & 4) ? up : lo;
-    }
-    *reinterpret_cast<uint4*>(lds + swz(row, ch * 16)) = v;
-  }
+  load_tile_coop<64>(lds, base, r0, row_lim, pitch, lane, R, b);
 }
 
 // MFMA operand whose "row/col" index is the tile row (lane&31) and whose k-chunk is dh [16s + 8*hi, +8)
@@ -180,9 +199,8 @@ __device__ __forceinline__ bf16x8_t frag_rows(const unsigned char* lds, int s, i
 }
 __device__ __forceinline__ bf16x8_t frag_global(const bf16_t* __restrict__ base, int row, int row_lim, size_t pitch, int s,
                                                 int lane) {
-  uint4 v = make_uint4(0, 0, 0, 0);
-  if (row < row_lim) v = *reinterpret_cast<const uint4*>(base + (size_t)row * pitch + 16 * s + (lane >> 5) * 8);
-  return __builtin_bit_cast(bf16x8_t, v);
+  const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)clamp_row(row, row_lim) * pitch + 16 * s + (lane >> 5) * 8);
+  return __builtin_bit_cast(bf16x8_t, zero_if(row >= row_lim, v));
 }
 // Attention dropout (hf eager_attention_forward :210: dropout on the softmax output, training only; every reference
 // launch script sets attention_dropout=0.1).  Counter-based: the keep decision of element (batch*head, query, key) is a
@@ -244,18 +262,16 @@ __device__ __forceinline__ int wave_imax(int v) { return (int)wave_max((float)v)
 __device__ __forceinline__ void frags_global_rope(bf16x8_t (&f)[4], const bf16_t* __restrict__ base, int row, int row_lim,
                                                   size_t pitch, int lane, const Rope& R, int b) {
   uint4 v[4];
+  const int rowc = clamp_row(row, row_lim);
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    v[s] = make_uint4(0, 0, 0, 0);
-    if (row < row_lim) v[s] = *reinterpret_cast<const uint4*>(base + (size_t)row * pitch + 16 * s + (lane >> 5) * 8);
-  }
-  if (R.cos_tab && row < row_lim) {
-    const int pos = rope_pos(R, b, row);
+  for (int s = 0; s < 4; ++s) v[s] = *reinterpret_cast<const uint4*>(base + (size_t)rowc * pitch + 16 * s + (lane >> 5) * 8);
+  if (R.cos_tab) {
+    const int pos = rope_pos(R, b, rowc);
     rope_pair(v[0], v[2], R, pos, (lane >> 5) * 8);
     rope_pair(v[1], v[3], R, pos, 16 + (lane >> 5) * 8);
   }
 #pragma unroll
-  for (int s = 0; s < 4; ++s) f[s] = __builtin_bit_cast(bf16x8_t, v[s]);
+  for (int s = 0; s < 4; ++s) f[s] = __builtin_bit_cast(bf16x8_t, zero_if(row >= row_lim, v[s]));
 }
 // transposed operand: MFMA row = dh (dhb*32 + lane&31), k = tile rows {16j + 4hi + (e&3) + 8(e>>2)}
 __device__ __forceinline__ bf16x8_t frag_tr(const unsigned char* lds, int dhb, int j, int lane) {
@@ -705,6 +721,8 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
   const bf16_t* dob = dout + (size_t)rb * d + h * 64;
   const int klen = key_len ? key_len[b] : S;
   const Rope Rnone{nullptr, nullptr, nullptr, S};
+  // (one tile at a time: issuing all 17 loads of a problem before the first wait - or K + V first, then Q + dO - measured SLOWER,
+  //  29.4 / 28.7 against 23.4 us: with all 3072 problems resident at once the chip's memory queues overflow; profiles/r03_step_experiments.txt, item 14)
   load_tile_coop<64>(kt, kb, 0, SL, pitch, lane, Rin, b);
   // V is only ever read row-wise (operand rows = keys): its fragments come straight from global memory, which keeps the
   // block at 12 KiB of LDS = 12 single-wave blocks per CU, i.e. B*H = 3072 problems of the headline shape in ONE round

@@ -344,7 +344,7 @@ __device__ __forceinline__ void geglu_bwd_block(const f32x4_t& a0, const f32x4_t
   }
 }
 
-template <int EPI, int MI, int NJ, bool ILV = false>
+template <int EPI, int MI, int NJ, bool ILV = false, bool LEAN = false>   // LEAN: a kernel held to 128 registers (no operand prefetch)
 __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmProblem& P, int M, int N, int mw, int nw, int lane,
                                            int kslice = 0, int chan0 = 0) {
   const int l15 = lane & 15, gq = lane >> 4;
@@ -443,24 +443,32 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
     bf16_t* C = reinterpret_cast<bf16_t*>(P.C);
     bf16_t* C2 = reinterpret_cast<bf16_t*>(P.C2);
     if constexpr (!FWD) {
+      // gate / up operands: unconditional loads (rows clamped: what a clamped row yields is never stored), the NEXT 16-row block's four
+      // pieces in flight while the current block is computed and stored.  Behind `if (m < M)` the compiler branched around the loads
+      // of every block and waited vmcnt(0) for them before any math (round 3, ISA); all blocks at once would cost MI x 16 registers
+      // (the 256x256 tile has MI = 8, the two-workgroups-per-CU form 128 registers in all).
+      uint4 gv[2][NG][2], uv[2][NG][2];
+      auto fetch = [&](int i, int buf) {
+        const int m = min(mw + i * 16 + l15, M - 1);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int m = mw + i * 16 + l15;
-#pragma unroll
-        for (int jq = 0; jq < NG; ++jq) {
-          uint4 gv[2], uv[2];
+        for (int jq = 0; jq < NG; ++jq)
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
             const int n = nw + (2 * jq + hf) * 32 + c0 * 8;
-            gv[hf] = make_uint4(0, 0, 0, 0);
-            uv[hf] = make_uint4(0, 0, 0, 0);
-            if (m < M) {
-              gv[hf] = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + n);
-              uv[hf] = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + ff + n);
-            }
+            gv[buf][jq][hf] = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + n);
+            uv[buf][jq][hf] = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + ff + n);
           }
-          geglu_bwd_block(acc[i][4 * jq], acc[i][4 * jq + 1], acc[i][4 * jq + 2], acc[i][4 * jq + 3], gv, uv, P, M, mw + i * 16, nw + jq * 64, lane);
-        }
+      };
+      if constexpr (!LEAN) fetch(0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        if constexpr (LEAN) fetch(i, 0);
+        else if (i + 1 < MI) fetch(i + 1, (i + 1) & 1);
+        constexpr int kOne = LEAN ? 0 : 1;
+#pragma unroll
+        for (int jq = 0; jq < NG; ++jq)
+          geglu_bwd_block(acc[i][4 * jq], acc[i][4 * jq + 1], acc[i][4 * jq + 2], acc[i][4 * jq + 3], gv[(i & 1) * kOne][jq], uv[(i & 1) * kOne][jq], P, M,
+                          mw + i * 16, nw + jq * 64, lane);
       }
       return;
     } else {
@@ -521,6 +529,22 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
     if (((N & 63) == 0 || EPI == GGET_EPI_NONE) && (P.ldc & 63) == 0 && ((nw & 63) == 0 || lead) && ((uintptr_t)P.C & 127) == 0) {
       const bool low = (l15 & 8) == 0;
       const int c0 = 2 * (gq & 1) + (gq >> 1);   // 16-byte chunk (of the 8 in a 64-column group) this lane holds for the first jp
+      // Residual pieces of the whole wave tile: ALL loads first, unconditional (row / column clamped into the matrix - what a clamped
+      // piece adds lands in values that are never stored).  With `if (m < M && n < N) load` inside the piece the compiler branched around
+      // every load and waited vmcnt(0) behind it: MI x NJ/2 serialised round trips per tile epilogue (round 3, ISA of the o / down
+      // projection kernels).
+      uint4 rres[EPI == GGET_EPI_RESIDUAL ? MI : 1][EPI == GGET_EPI_RESIDUAL ? NJ / 2 : 1];
+      if constexpr (EPI == GGET_EPI_RESIDUAL) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int m = min(mw + i * 16 + l15, M - 1);
+#pragma unroll
+          for (int jp = 0; jp < NJ / 2; ++jp) {
+            const int n = min(nw + jp * 32 + c0 * 8, N - 8);
+            rres[i][jp] = *reinterpret_cast<const uint4*>(P.R + (size_t)m * P.ldc + n);
+          }
+        }
+      }
       auto piece = [&](int i, int jp, int m) {   // epilogue math of (i, jp): the lane's 8 columns of row m, packed
         float v[8];
 #pragma unroll
@@ -529,14 +553,11 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
           v[e] = __uint_as_float(r[0]);
           v[4 + e] = __uint_as_float(r[1]);
         }
-        if (EPI == GGET_EPI_RESIDUAL) {
-          const int n = nw + jp * 32 + c0 * 8;
-          if (m < M && n < N) {
-            float r[8];
-            unpack8(*reinterpret_cast<const uint4*>(P.R + (size_t)m * P.ldc + n), r);
+        if constexpr (EPI == GGET_EPI_RESIDUAL) {
+          float r[8];
+          unpack8(rres[i][jp], r);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += r[e];
-          }
+          for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
         return pack8(v);
       };
@@ -994,8 +1015,8 @@ __global__ void __launch_bounds__(WM * WN * 64, MODE == 2 ? 4 : ((WM * WN) >= 8 
       }
     }
     if (store && (g.ablate != 32 || acc[0][0][0] == 123.456f))   // GGET_GEMM_ABLATE=32: persistent kernel without the epilogue (timing only)
-      store_tile<EPI, MI, NJ, ILV>(acc, P, cc.M, (P.N + 3) & ~3, cc.m0 + wm * (MI * 16),
-                                   EPI == GGET_EPI_GEGLU_FWD ? (cc.n0 >> 1) + wn * (NJ * 8) : cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, wn * 16);
+      store_tile<EPI, MI, NJ, ILV, MODE == 2>(acc, P, cc.M, (P.N + 3) & ~3, cc.m0 + wm * (MI * 16),
+                                              EPI == GGET_EPI_GEGLU_FWD ? (cc.n0 >> 1) + wn * (NJ * 8) : cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, wn * 16);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll

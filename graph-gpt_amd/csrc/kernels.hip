@@ -27,23 +27,36 @@ __global__ void __launch_bounds__(128) embed_fwd_kernel(const int64_t* __restric
   const int64_t* row = ids + (size_t)t * ldF;
   for (int c = threadIdx.x; c * 8 < d; c += blockDim.x) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int f = 0; f < F; ++f) {
-      const int64_t id = row[f];
-      float v[8];
-      unpack8(ldg16(emb + (size_t)id * d + c * 8), v);
-      if (E.thresh) {   // embed_dropout acts on the gathered rows, before the stacking (modeling_helpers.py:96-101)
+    // four gathered rows in flight at a time (unconditional loads of a clamped feature index; the sum keeps the feature order):
+    // one row per loop trip was a chain of F dependent L2 round trips per thread
+    for (int f0 = 0; f0 < F; f0 += 4) {
+      uint4 r[4], gr[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          v[e] = bf2f(f2bf(v[e] * elem_drop_mul(E, GGET_DROP_STREAM_EMBED, (unsigned)(t * F + f), (unsigned)(c * 8 + e))));
+      for (int u = 0; u < 4; ++u) {
+        const int fu = min(f0 + u, F - 1);
+        r[u] = ldg16(emb + (size_t)row[fu] * d + c * 8);
+        if (gate) gr[u] = ldg16(gate + (size_t)fu * d + c * 8);
       }
-      if (gate) {
-        float gv[8];
-        unpack8(ldg16(gate + (size_t)f * d + c * 8), gv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += v[e] * gv[e];
-      } else {
+      for (int u = 0; u < 4; ++u) {
+        const int f = f0 + u;
+        if (f >= F) break;
+        float v[8];
+        unpack8(r[u], v);
+        if (E.thresh) {   // embed_dropout acts on the gathered rows, before the stacking (modeling_helpers.py:96-101)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+          for (int e = 0; e < 8; ++e)
+            v[e] = bf2f(f2bf(v[e] * elem_drop_mul(E, GGET_DROP_STREAM_EMBED, (unsigned)(t * F + f), (unsigned)(c * 8 + e))));
+        }
+        if (gate) {
+          float gv[8];
+          unpack8(gr[u], gv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += v[e] * gv[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
       }
     }
     stg16(out + (size_t)t * d + c * 8, pack8(acc));

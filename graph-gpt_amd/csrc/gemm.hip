@@ -529,22 +529,6 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
     if (((N & 63) == 0 || EPI == GGET_EPI_NONE) && (P.ldc & 63) == 0 && ((nw & 63) == 0 || lead) && ((uintptr_t)P.C & 127) == 0) {
       const bool low = (l15 & 8) == 0;
       const int c0 = 2 * (gq & 1) + (gq >> 1);   // 16-byte chunk (of the 8 in a 64-column group) this lane holds for the first jp
-      // Residual pieces of the whole wave tile: ALL loads first, unconditional (row / column clamped into the matrix - what a clamped
-      // piece adds lands in values that are never stored).  With `if (m < M && n < N) load` inside the piece the compiler branched around
-      // every load and waited vmcnt(0) behind it: MI x NJ/2 serialised round trips per tile epilogue (round 3, ISA of the o / down
-      // projection kernels).
-      uint4 rres[EPI == GGET_EPI_RESIDUAL ? MI : 1][EPI == GGET_EPI_RESIDUAL ? NJ / 2 : 1];
-      if constexpr (EPI == GGET_EPI_RESIDUAL) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const int m = min(mw + i * 16 + l15, M - 1);
-#pragma unroll
-          for (int jp = 0; jp < NJ / 2; ++jp) {
-            const int n = min(nw + jp * 32 + c0 * 8, N - 8);
-            rres[i][jp] = *reinterpret_cast<const uint4*>(P.R + (size_t)m * P.ldc + n);
-          }
-        }
-      }
       auto piece = [&](int i, int jp, int m) {   // epilogue math of (i, jp): the lane's 8 columns of row m, packed
         float v[8];
 #pragma unroll
@@ -553,11 +537,16 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
           v[e] = __uint_as_float(r[0]);
           v[4 + e] = __uint_as_float(r[1]);
         }
-        if constexpr (EPI == GGET_EPI_RESIDUAL) {
-          float r[8];
-          unpack8(rres[i][jp], r);
+        if (EPI == GGET_EPI_RESIDUAL) {
+          // (loading all residual pieces of the wave tile up front, unconditionally, instead of one behind each `if`: o + residual 18.8 ->
+          //  16.8 us stand-alone, but 16.5 -> 20.1 us inside the step and the step +0.03 ms - profiles/r03_step_experiments.txt item 15)
+          const int n = nw + jp * 32 + c0 * 8;
+          if (m < M && n < N) {
+            float r[8];
+            unpack8(*reinterpret_cast<const uint4*>(P.R + (size_t)m * P.ldc + n), r);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += r[e];
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+          }
         }
         return pack8(v);
       };

@@ -1,0 +1,20 @@
+"""Per-step SMTP loss of the bench batch over N steps (one line of floats): run several times to see where runs part."""
+import importlib, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+modeling = importlib.import_module("graph-gpt_amd.modeling"); training = importlib.import_module("graph-gpt_amd.training")
+synth = importlib.import_module("graph-gpt_amd.synth")
+B, S, F, V = 256, 32, 13, 756
+N = int(os.environ.get("STEPS", "38"))
+cfg = modeling.GraphGPTConfig(hidden_act="gelu", vocab_size=V, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                              max_position_embeddings=1024, causal_attention=False, stacked_feat=F, next_n_token=F, attention_dropout=0.1)
+model = modeling.GraphGPTPretrainBase(cfg, seed=0)
+model._ensure_engine(B, S)
+engine = training.initialize(model, training.OptimConfig(lr=3e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1, max_grad_norm=1.0))
+batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=1234)
+dev = {k: torch.from_numpy(v).cuda() for k, v in batch.items() if k not in ("lengths", "segments")}
+if os.environ.get("LAYOUT", "varlen") == "varlen":
+    dev["num_tokens"] = int(synth.real_tokens(batch))
+out = []
+for _ in range(N):
+    out.append(training.batch_training(dev, engine).item())
+print(" ".join(f"{x:.7f}" for x in out))

@@ -344,7 +344,7 @@ __device__ __forceinline__ void geglu_bwd_block(const f32x4_t& a0, const f32x4_t
   }
 }
 
-template <int EPI, int MI, int NJ, bool ILV = false, bool LEAN = false>   // LEAN: a kernel held to 128 registers (no operand prefetch)
+template <int EPI, int MI, int NJ, bool ILV = false>
 __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmProblem& P, int M, int N, int mw, int nw, int lane,
                                            int kslice = 0, int chan0 = 0) {
   const int l15 = lane & 15, gq = lane >> 4;
@@ -443,32 +443,23 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
     bf16_t* C = reinterpret_cast<bf16_t*>(P.C);
     bf16_t* C2 = reinterpret_cast<bf16_t*>(P.C2);
     if constexpr (!FWD) {
-      // gate / up operands: unconditional loads (rows clamped: what a clamped row yields is never stored), the NEXT 16-row block's four
-      // pieces in flight while the current block is computed and stored.  Behind `if (m < M)` the compiler branched around the loads
-      // of every block and waited vmcnt(0) for them before any math (round 3, ISA); all blocks at once would cost MI x 16 registers
-      // (the 256x256 tile has MI = 8, the two-workgroups-per-CU form 128 registers in all).
-      uint4 gv[2][NG][2], uv[2][NG][2];
-      auto fetch = [&](int i, int buf) {
+      // gate / up operands of one 16-row block at a time, loaded unconditionally (rows clamped: what a clamped row yields is never
+      // stored) - behind `if (m < M)` the compiler branched around the loads.  Prefetching the next block's pieces while the current one
+      // is computed measured equal inside the C3 / C4 steps and cost the 128-register two-workgroups-per-CU kernel 32 spills: not kept.
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
         const int m = min(mw + i * 16 + l15, M - 1);
 #pragma unroll
-        for (int jq = 0; jq < NG; ++jq)
+        for (int jq = 0; jq < NG; ++jq) {
+          uint4 gv[2], uv[2];
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
             const int n = nw + (2 * jq + hf) * 32 + c0 * 8;
-            gv[buf][jq][hf] = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + n);
-            uv[buf][jq][hf] = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + ff + n);
+            gv[hf] = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + n);
+            uv[hf] = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + ff + n);
           }
-      };
-      if constexpr (!LEAN) fetch(0, 0);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        if constexpr (LEAN) fetch(i, 0);
-        else if (i + 1 < MI) fetch(i + 1, (i + 1) & 1);
-        constexpr int kOne = LEAN ? 0 : 1;
-#pragma unroll
-        for (int jq = 0; jq < NG; ++jq)
-          geglu_bwd_block(acc[i][4 * jq], acc[i][4 * jq + 1], acc[i][4 * jq + 2], acc[i][4 * jq + 3], gv[(i & 1) * kOne][jq], uv[(i & 1) * kOne][jq], P, M,
-                          mw + i * 16, nw + jq * 64, lane);
+          geglu_bwd_block(acc[i][4 * jq], acc[i][4 * jq + 1], acc[i][4 * jq + 2], acc[i][4 * jq + 3], gv, uv, P, M, mw + i * 16, nw + jq * 64, lane);
+        }
       }
       return;
     } else {
@@ -1004,8 +995,8 @@ __global__ void __launch_bounds__(WM * WN * 64, MODE == 2 ? 4 : ((WM * WN) >= 8 
       }
     }
     if (store && (g.ablate != 32 || acc[0][0][0] == 123.456f))   // GGET_GEMM_ABLATE=32: persistent kernel without the epilogue (timing only)
-      store_tile<EPI, MI, NJ, ILV, MODE == 2>(acc, P, cc.M, (P.N + 3) & ~3, cc.m0 + wm * (MI * 16),
-                                              EPI == GGET_EPI_GEGLU_FWD ? (cc.n0 >> 1) + wn * (NJ * 8) : cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, wn * 16);
+      store_tile<EPI, MI, NJ, ILV>(acc, P, cc.M, (P.N + 3) & ~3, cc.m0 + wm * (MI * 16),
+                                   EPI == GGET_EPI_GEGLU_FWD ? (cc.n0 >> 1) + wn * (NJ * 8) : cc.n0 + wn * (ILV ? 16 : NJ * 16), lane, 0, wn * 16);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll

@@ -379,10 +379,12 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
 #pragma unroll
     for (int i0 = 0; i0 < MI; i0 += IB) {
       int pos[IB];
+      if (P.rope_pos) {   // (the test outside the loop: inside it every position load sat behind its own branch and vmcnt(0))
 #pragma unroll
-      for (int ii = 0; ii < IB; ++ii) {
-        const int m = min(mw + (i0 + ii) * 16 + l15, M - 1);
-        pos[ii] = P.rope_pos ? (int)P.rope_pos[m] : (m % P.rope_S);
+        for (int ii = 0; ii < IB; ++ii) pos[ii] = (int)P.rope_pos[min(mw + (i0 + ii) * 16 + l15, M - 1)];
+      } else {
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) pos[ii] = min(mw + (i0 + ii) * 16 + l15, M - 1) % P.rope_S;
       }
       float4 cq[IB][NP], sq[IB][NP];
 #pragma unroll

@@ -522,6 +522,17 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
     if (((N & 63) == 0 || EPI == GGET_EPI_NONE) && (P.ldc & 63) == 0 && ((nw & 63) == 0 || lead) && ((uintptr_t)P.C & 127) == 0) {
       const bool low = (l15 & 8) == 0;
       const int c0 = 2 * (gq & 1) + (gq >> 1);   // 16-byte chunk (of the 8 in a 64-column group) this lane holds for the first jp
+      // residual pieces of ONE 16-row block at a time, loaded unconditionally (row / column clamped: what a clamped piece adds lands in
+      // values that are never stored).  One load behind each `if (m < M && n < N)` was a branch + vmcnt(0) per piece; all pieces of the
+      // wave tile at once measured slower INSIDE the step (profiles/r03_step_experiments.txt item 15).
+      uint4 rrow[EPI == GGET_EPI_RESIDUAL ? NJ / 2 : 1];
+      auto fetch_res = [&](int i) {
+        if constexpr (EPI == GGET_EPI_RESIDUAL) {
+          const int m = min(mw + i * 16 + l15, M - 1);
+#pragma unroll
+          for (int jp = 0; jp < NJ / 2; ++jp) rrow[jp] = *reinterpret_cast<const uint4*>(P.R + (size_t)m * P.ldc + min(nw + jp * 32 + c0 * 8, N - 8));
+        }
+      };
       auto piece = [&](int i, int jp, int m) {   // epilogue math of (i, jp): the lane's 8 columns of row m, packed
         float v[8];
 #pragma unroll
@@ -530,16 +541,11 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
           v[e] = __uint_as_float(r[0]);
           v[4 + e] = __uint_as_float(r[1]);
         }
-        if (EPI == GGET_EPI_RESIDUAL) {
-          // (loading all residual pieces of the wave tile up front, unconditionally, instead of one behind each `if`: o + residual 18.8 ->
-          //  16.8 us stand-alone, but 16.5 -> 20.1 us inside the step and the step +0.03 ms - profiles/r03_step_experiments.txt item 15)
-          const int n = nw + jp * 32 + c0 * 8;
-          if (m < M && n < N) {
-            float r[8];
-            unpack8(*reinterpret_cast<const uint4*>(P.R + (size_t)m * P.ldc + n), r);
+        if constexpr (EPI == GGET_EPI_RESIDUAL) {
+          float r[8];
+          unpack8(rrow[jp], r);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += r[e];
-          }
+          for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
         return pack8(v);
       };
@@ -548,6 +554,7 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
       const int* crows = EPI == GGET_EPI_NONE ? P.c_rows : nullptr;   // fused row scatter (see GemmProblem::c_rows)
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
+        fetch_res(i);
         const int m = mw + i * 16 + l15;          // the row whose values this lane holds before the regrouping
         const int ma = mw + i * 16 + (l15 & 7), mb = ma + 8;
         const size_t ra = crows && ma < M ? (size_t)crows[ma] : (size_t)ma, rb = crows && mb < M ? (size_t)crows[mb] : (size_t)mb;

@@ -1718,6 +1718,7 @@ extern "C" int gget_debug_set(int key, int value) {
   switch (key) {
     case 1: g_gemm_variant = value; return 0;
     case 2: g_gemm_lds_headroom = value; return 0;
+    case 4: k_set_deterministic(value); return 0;
     case 3: g_gemm_split_last = value; return 0;
   }
   gget_set_error("debug_set: unknown key %d", key);

@@ -42,6 +42,8 @@ inline bool k_embed_dense_ok(int V, bool gated) { return !gated && ((V + 63) / 6
 constexpr int kEmbDenseSplit = 8;   // K slices (fp32 slabs of V*d each) of that GEMM
 int k_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, hipStream_t st);
 // dw_accum: fp32 [copies][copy_stride] accumulators (see GgetSegment); copies = 1 for a plain vector
+void k_set_deterministic(int on);   // reproducible summation order of the RMSNorm weight gradients (gget_debug_set key 4)
+int k_get_deterministic();
 int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
                   float* dw_accum, int T, int d, hipStream_t st, int copies = 1, uint64_t copy_stride = 0);
 int k_rope(void* qkv, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, int T, int S, int H,

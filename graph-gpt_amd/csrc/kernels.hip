@@ -5,6 +5,10 @@
 #include "common.h"
 #include "kernels.h"
 
+static int g_deterministic = getenv("GGET_DETERMINISTIC") ? atoi(getenv("GGET_DETERMINISTIC")) : 0;   // k_set_deterministic
+static float* g_det_scratch = nullptr;
+static size_t g_det_bytes = 0;
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -422,7 +426,7 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_bwd_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ w, const float* __restrict__ rstd_in,
                                                              const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
                                                              float* __restrict__ dw_accum, int T, int d, int copies,
-                                                             uint64_t copy_stride) {
+                                                             uint64_t copy_stride, float* __restrict__ dw_part) {
   extern __shared__ float dw_lds[];  // [4][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = d >> 3;
@@ -499,7 +503,35 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_bwd_kernel(const bf16_t* __res
   __syncthreads();
   for (int j = threadIdx.x; j < d; j += kBlock) {
     const float s = dw_lds[j] + dw_lds[d + j] + dw_lds[2 * d + j] + dw_lds[3 * d + j];
-    unsafeAtomicAdd(dw_accum + (size_t)(blockIdx.x % copies) * copy_stride + j, s);
+    if (dw_part) dw_part[(size_t)blockIdx.x * d + j] = s;     // reproducible mode: summed in block order by ordered_colsum_kernel
+    else unsafeAtomicAdd(dw_accum + (size_t)(blockIdx.x % copies) * copy_stride + j, s);
+  }
+}
+
+// reproducible mode (k_set_deterministic): dst[j] += part[0][j] + part[1][j] + ... in block order (one thread per column)
+// A fixed order, not the sequential one: the rows are cut into segments of `per` (one block each), the four waves of a block interleave a
+// segment's rows and every lane keeps 8 running sums (32 coalesced row reads in flight per block); lane sums, wave sums and - in a
+// second launch over the segment sums - the segments are folded in fixed trees.
+__global__ void __launch_bounds__(kBlock) ordered_colsum_kernel(const float* __restrict__ part, int nblk, int d, int per, float* __restrict__ out,
+                                                                int accumulate) {
+  __shared__ float ws[kBlock / 64][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const int b_lo = blockIdx.y * per, b_hi = min(b_lo + per, nblk);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (j < d) {
+    for (int b0 = b_lo + wave * 8; b0 < b_hi; b0 += (kBlock / 64) * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (b0 + u < b_hi) a[u] += part[(size_t)(b0 + u) * d + j];
+    }
+  }
+  ws[wave][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (wave == 0 && j < d) {
+    const float t = (ws[0][lane] + ws[1][lane]) + (ws[2][lane] + ws[3][lane]);
+    if (accumulate) out[j] += t;
+    else out[(size_t)blockIdx.y * d + j] = t;
   }
 }
 
@@ -1819,15 +1851,37 @@ int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rst
   static int rpw = 0;
   if (!rpw) { const char* e = getenv("GGET_RMS_ROWS"); rpw = e ? atoi(e) : 4; }
   const int grid = grid_for(T, 4 * rpw, 4096);  // rows per wave: amortises the dw atomics, pipelined row loads
+  // Reproducible mode: the per-block partials of the weight gradient go to a scratch matrix and are summed in block order (the
+  // fp32 atomics into the replicated accumulators are the one unordered sum of the pre-train gradient path: DESIGN.md section 5).
+  float* part = nullptr;
+  if (g_deterministic) {
+    const size_t need = (size_t)(4096 + 64) * d * sizeof(float);   // per-block partials [4096][d] + segment sums [64][d]
+    if (g_det_bytes < need) {
+      if (g_det_scratch) GGET_HIP_CHECK(hipFree(g_det_scratch));
+      GGET_HIP_CHECK(hipMalloc(&g_det_scratch, need));
+      g_det_bytes = need;
+    }
+    part = g_det_scratch;
+  }
   if (d <= 1024)
     hipLaunchKernelGGL(rmsnorm_bwd_kernel<2>, dim3(grid), dim3(kBlock), 4 * d * sizeof(float), st, (const bf16_t*)dy,
-                       (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_accum, T, d, copies, copy_stride);
+                       (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_accum, T, d, copies, copy_stride, part);
   else
     hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, dim3(grid), dim3(kBlock), 4 * d * sizeof(float), st, (const bf16_t*)dy,
-                       (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_accum, T, d, copies, copy_stride);
+                       (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_accum, T, d, copies, copy_stride, part);
+  if (part) {
+    constexpr int kPer = 64;
+    const int nseg = (grid + kPer - 1) / kPer;
+    float* seg = part + (size_t)4096 * d;
+    hipLaunchKernelGGL(ordered_colsum_kernel, dim3((d + 63) / 64, nseg), dim3(kBlock), 0, st, part, grid, d, kPer, seg, 0);
+    hipLaunchKernelGGL(ordered_colsum_kernel, dim3((d + 63) / 64, 1), dim3(kBlock), 0, st, seg, nseg, d, nseg, dw_accum, 1);
+  }
   GGET_LAUNCH_CHECK();
   return 0;
 }
+
+void k_set_deterministic(int on) { g_deterministic = on; }
+int k_get_deterministic() { return g_deterministic; }
 
 int k_rope(void* qkv, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, int T, int S, int H,
            int inverse, hipStream_t st) {

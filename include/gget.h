@@ -293,7 +293,9 @@ int gget_op_gemm_grouped(int mode, int count, const void* const* A, const void* 
  * two selections can be timed interleaved in one process or pinned to the same summation order (0 = the shipped selection): 1 K-split
  * kernel for one-round N = d launches, 2 K-split kernel for the grouped weight gradients, 4 the 192-row tiles, 8 the split of the
  * last round, 16 the 64- / 96-row tiles of the K-split kernel, 32 two co-resident workgroups per CU for the dh + GEGLU' launch.  key 2 = LDS headroom of the 128x192 tile (0: 4-slot ring).
- * key 3 = 1: split the K range of the last, partial round's tiles among the idle workgroups (off by default). */
+ * key 3 = 1: split the K range of the last, partial round's tiles among the idle workgroups (off by default).
+ * key 4 = 1 (also env GGET_DETERMINISTIC=1): reproducible mode of the pre-train step - the RMSNorm weight gradients, the one sum of that
+ * gradient path added with fp32 atomics, are summed in block order instead; two runs then produce bit-identical parameters. */
 int gget_debug_set(int key, int value);
 /* measurement aid: with enable != 0 the engine brackets, with HIP events on the launch stream, the grouped weight-gradient launch
  * (avg_ms_out[0]) and the gate|up + GEGLU launch (avg_ms_out[1]) of every layer of the following forward / backward calls;

@@ -423,6 +423,57 @@ def test_generation_loop(case):
         gen.GenerationConfig(alg="no_such_alg").validate()
 
 
+def test_reproducible_mode_gives_bit_identical_parameters():
+    """gget_debug_set(4, 1): the RMSNorm weight gradients - the one sum of the pre-train gradient path that is added with fp32 atomics -
+    are summed in block order.  Two engines started from the same state then hold BIT-IDENTICAL fp32 master parameters and Adam moments
+    after several clip + AdamW steps on the var-len layout (attention dropout on), and the same loss to the last bits of its own
+    (atomic) sum; the default mode must stay within tolerance of it."""
+    from _util import spec_mod, weights_mod, synth
+    LL = L
+    lib = LL.load()
+    B, S, F, V = 96, 32, 13, 756
+    spec = spec_mod.ModelSpec(kind=spec_mod.KIND_PRETRAIN, vocab_size=V, hidden_size=768, intermediate_size=3072, num_layers=2,
+                              num_heads=12, head_dim=64, stacked_feat=F, next_n_token=F)
+    batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=5)
+    state = weights_mod.make_state_dict(spec, seed=3, std=0.03, head_std=0.05)
+    b = tb(batch)
+    n_real = int(batch["attention_mask"].sum())
+
+    def run(det):
+        LL.check(lib.gget_debug_set(4, det))
+        e = make_engine(spec, batch)
+        e.load_state_dict(state)
+        e.set_dropout(0.1, 0.0, 1234)
+        losses = []
+        for _ in range(4):
+            losses.append(e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], num_tokens=n_real).item())
+            e.backward()
+            e.adamw_step(1e-3, max_grad_norm=1.0)
+        torch.cuda.synchronize()
+        out = (e.master.clone(), e.adam_m.clone(), e.adam_v.clone(), losses)
+        del e
+        return out
+    try:
+        a = run(1)
+        c = run(1)
+        d = run(0)
+    finally:
+        LL.check(lib.gget_debug_set(4, 0))
+    for k in range(3):
+        assert torch.equal(a[k], c[k]), ("master", "adam_m", "adam_v")[k] + " differs between two reproducible-mode runs"
+    assert a[3] == pytest.approx(c[3], rel=1e-5)      # (the REPORTED loss is still an atomic sum over blocks: equal to its last bits only)
+    assert a[3] == pytest.approx(d[3], rel=2e-4), "default mode drifted from the reproducible one"
+    assert float((a[0] - d[0]).norm()) <= 3e-2 * float((a[0] - run_init_master(spec, state, batch)).norm() + 1e-12)
+
+
+def run_init_master(spec, state, batch):
+    e = make_engine(spec, batch)
+    e.load_state_dict(state)
+    m = e.master.clone()
+    del e
+    return m
+
+
 @pytest.mark.parametrize("alg", ["maskgit_plus", "topk_margin", "entropy"])
 def test_generation_single_iterations_match_reference_fixture(alg):
     """Teacher-forced comparison with the REFERENCE's recorded run (tests/golden/generation.npz: sample_per_batch of

@@ -450,15 +450,20 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
       // is computed measured equal inside the C3 / C4 steps and cost the 128-register two-workgroups-per-CU kernel 32 spills: not kept.
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const int m = min(mw + i * 16 + l15, M - 1);
 #pragma unroll
         for (int jq = 0; jq < NG; ++jq) {
           uint4 gv[2], uv[2];
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            const int n = nw + (2 * jq + hf) * 32 + c0 * 8;
-            gv[hf] = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + n);
-            uv[hf] = *reinterpret_cast<const uint4*>(P.G + (size_t)m * P.ldg + ff + n);
+          // whole-line loads (8 rows x 128 B per instruction, the mapping of the stores) and the inverse of the stores' regrouping:
+          // a low lane (row < 8 of the block) gets its second piece from lane ^ 8's first load, a high lane its first from lane ^ 8's second
+          {
+            const int ra = min(mw + i * 16 + (l15 & 7), M - 1), rb = min(mw + i * 16 + (l15 & 7) + 8, M - 1);
+            const int nl = nw + jq * 64 + (low ? c0 : c0 + 4) * 8;
+            const uint4 ga = *reinterpret_cast<const uint4*>(P.G + (size_t)ra * P.ldg + nl), gb = *reinterpret_cast<const uint4*>(P.G + (size_t)rb * P.ldg + nl);
+            const uint4 ua = *reinterpret_cast<const uint4*>(P.G + (size_t)ra * P.ldg + ff + nl), ub = *reinterpret_cast<const uint4*>(P.G + (size_t)rb * P.ldg + ff + nl);
+            auto r4 = [&](const uint4& v) { return make_uint4(ror8(v.x), ror8(v.y), ror8(v.z), ror8(v.w)); };
+            const uint4 gar = r4(ga), gbr = r4(gb), uar = r4(ua), ubr = r4(ub);
+            gv[0] = low ? ga : gbr; gv[1] = low ? gar : gb;
+            uv[0] = low ? ua : ubr; uv[1] = low ? uar : ub;
           }
           geglu_bwd_block(acc[i][4 * jq], acc[i][4 * jq + 1], acc[i][4 * jq + 2], acc[i][4 * jq + 3], gv, uv, P, M, mw + i * 16, nw + jq * 64, lane);
         }

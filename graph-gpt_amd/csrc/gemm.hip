@@ -533,6 +533,7 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
       uint4 rrow[EPI == GGET_EPI_RESIDUAL ? NJ / 2 : 1];
       auto fetch_res = [&](int i) {
         if constexpr (EPI == GGET_EPI_RESIDUAL) {
+          // (the same pieces as whole lines + the inverse of the stores' regrouping, as in the GEGLU' epilogue: step 7.14 -> 7.32 ms - item 21)
           const int m = min(mw + i * 16 + l15, M - 1);
 #pragma unroll
           for (int jp = 0; jp < NJ / 2; ++jp) rrow[jp] = *reinterpret_cast<const uint4*>(P.R + (size_t)m * P.ldc + min(nw + jp * 32 + c0 * 8, N - 8));
@@ -1632,7 +1633,7 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
 // out (device-sized row / K counts).
 extern "C" int gget_debug_gemm_probe(int enable, double* flops_out, double* ms_out, int* launches_out, int* skipped_out) {
   if (enable) {
-    for (auto& r : g_probe) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (auto& r : g_probe) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_probe.clear();
     g_probe_on = true;
     return 0;
@@ -1646,8 +1647,8 @@ extern "C" int gget_debug_gemm_probe(int enable, double* flops_out, double* ms_o
     GGET_HIP_CHECK(hipEventElapsedTime(&t, r.e0, r.e1));
     if (r.dyn) { ++skipped; }
     else { fl += r.flops; ms += t; ++n; }
-    hipEventDestroy(r.e0);
-    hipEventDestroy(r.e1);
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
   }
   g_probe.clear();
   if (flops_out) *flops_out = fl;

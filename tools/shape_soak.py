@@ -34,8 +34,10 @@ def run(kind, size, B, S, F, V, steps=3):
         del eng, model
         torch.cuda.empty_cache()
     lp, lv = out["padded"][0], out["varlen"][0]
-    rel = max(abs(a - b) / max(abs(a), 1e-2) for a, b in zip(lp, lv))   # (fine-tune losses of a memorised synthetic batch fall to ~1e-5: absolute floor)
-    ok = rel < 2e-3
+    # the synthetic fine-tune batch is memorised within two steps (loss ~1e-2 ... 1e-5): there the two layouts - different kernels, different
+    # bf16 roundings - are compared on an absolute scale
+    rel = max(abs(a - b) / max(abs(a), 1e-6) for a, b in zip(lp, lv))
+    ok = all(abs(a - b) <= max(2e-3 * abs(a), 3e-4) for a, b in zip(lp, lv))
     print(f"{kind} {size} B={B} S={S} F={F} V={V}: padded {out['padded'][1]:.2f} ms, varlen {out['varlen'][1]:.2f} ms {out['varlen'][2]}, losses {lp[-1]:.5f} / {lv[-1]:.5f}, "
           f"max rel diff {rel:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
     return ok

@@ -65,6 +65,12 @@ def cpu_baseline(spec, state, B, S, F, V, seed, threads, budget_s=30.0):
     torch.set_num_threads(threads)
     b = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=seed)
     tb = {k: torch.from_numpy(v) for k, v in b.items()}
+    # parity leg (the oracle as CHECKER, not timed): SMTP loss of the oracle's forward on the bench batch, weights rounded to bf16 first
+    # (the cast point of the engine's compute copy) - compared with the engine's eval-mode forward in `loss_parity`
+    with torch.no_grad():
+        p_bf = O.to_params({k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}, torch.float32,
+                           requires_grad=False)
+        oracle_loss = float(O.pretrain_forward(spec, p_bf, tb["input_ids"], tb["attention_mask"], tb["labels"])["head1_loss"])
     p = O.to_params(state, torch.float32)
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v = {k: torch.zeros_like(x) for k, x in p.items()}
@@ -84,7 +90,7 @@ def cpu_baseline(spec, state, B, S, F, V, seed, threads, budget_s=30.0):
     real = int(b["attention_mask"].sum())
     return {"value": real / dt, "unit": "graph-tokens/s", "cores": threads, "kind": "port",
             "sample": f"oracle fp32 fwd+bwd+AdamW, same batch shape as the GPU step (B={B} S={S} F={F}), 1 warm-up + {len(timed)} timed "
-                      f"step(s), {dt:.2f} s/step"}
+                      f"step(s), {dt:.2f} s/step"}, oracle_loss
 
 
 def _event_time(fn, iters):
@@ -175,8 +181,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="pcqm4m-v2-pretrain-base", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--layout", default="varlen", choices=["varlen", "padded"],
-                    help="token layout of the step: the engine's padding-free layout (default) or every row of the padded [B,S] grid")
+    ap.add_argument("--layout", default="varlen", choices=["varlen", "varlen-count", "padded"],
+                    help="token layout of the timed steps.  varlen (default): the call of the reference's own step - device-resident "
+                         "tensors, no token count passed - the engine counts the mask on the device and runs the padding-free layout; "
+                         "varlen-count: the same layout with the count handed over by the caller (data['num_tokens']: no device->host "
+                         "read); padded: every row of the padded [B,S] grid")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -234,11 +243,29 @@ def main():
     # [B,S] grid (include/gget.h: gget_set_token_count) - same batch, same loss, same gradients.  "padded": every row of the grid,
     # as the reference computes it.  Packed batches (3-D masks) have no padding to skip.
     layout = a.layout if kind != "pt-packed" else "padded"
-    if layout == "varlen":
-        dev["num_tokens"] = int(real_tokens)
 
-    def step():
-        return training.batch_training(dev, engine) if pt else training.ft_batch_training(dev, engine)[0]
+    def make_step(lay):
+        data = dict(dev, num_tokens=int(real_tokens)) if lay == "varlen-count" else dev
+
+        def one():
+            if lay == "padded":
+                os.environ["GGET_VARLEN"] = "0"
+            try:
+                return training.batch_training(data, engine) if pt else training.ft_batch_training(data, engine)[0]
+            finally:
+                if lay == "padded":
+                    del os.environ["GGET_VARLEN"]
+        return one
+
+    step = make_step(layout)
+
+    # eval-mode forward of the bench batch on the initial (seed 0) weights: the loss the oracle leg is compared with (`loss_parity`)
+    gpu_eval_loss = None
+    if pt and kind == "pt":
+        model.eval()
+        with torch.no_grad():
+            gpu_eval_loss = float(model(input_ids=dev["input_ids"], attention_mask=dev["attention_mask"], labels=dev["labels"]).head1_loss)
+        model.train()
 
     for _ in range(a.warmup):
         loss = step()
@@ -254,6 +281,24 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the other token layouts, same batch, same K steps each (outside the reported time; single process only)
+    layouts = None
+    if world == 1 and kind != "pt-packed":
+        layouts = {layout: dt / a.steps * 1e3}
+        for lay in ("varlen", "varlen-count", "padded"):
+            if lay in layouts:
+                continue
+            other = make_step(lay)
+            for _ in range(2):
+                other()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                other()
+            torch.cuda.synchronize()
+            layouts[lay] = (time.perf_counter() - t1) / a.steps * 1e3
+        step()     # (the probes below run on the reported layout again)
+        torch.cuda.synchronize()
     # N > 1: how much of the step is gradient exchange the backward does not hide - the same K steps once more (outside the reported
     # time) with the collectives switched off (GgetEngine.exchange = False: identical kernels on the compute stream, nothing on the
     # side stream), max over ranks; exposed = reported step - that.  The replicas drift apart in these steps: they come last.
@@ -356,20 +401,23 @@ def main():
                        f"({spec.num_params() / 1e6:.1f}M params)", "per_gpu_batch": B, "global_batch": B * world,
                        "seq_len": S, "stacked_feat": F, "vocab": V, "parallelism": f"dp{world}",
                        "step": "fwd+bwd+allreduce+clip+AdamW", "attention_dropout": cfg.attention_dropout,
-                       "token_layout": "varlen (real tokens compacted on the device; same batch, loss and gradients as the padded grid)"
-                       if ran_varlen else "padded",
+                       "token_layout": ("varlen (real tokens compacted on the device; same batch, loss and gradients as the padded grid); "
+                                        + ("the step is called like the reference's - device tensors, no token count: the engine counts the mask"
+                                           if layout == "varlen" else "token count passed by the caller")) if ran_varlen else "padded",
                        **({"path_pdrop": 0.2, "layer_scale_init_value": 1.0} if kind == "ft" else {}),
                        **({"packing": "whole graphs back to back, block-diagonal attention"} if kind == "pt-packed" else {})},
             ("smtp_loss" if pt else "task_loss"): mean_loss,
             "padded_tokens_per_s": B * S * world * a.steps / dt,
             "tokens_per_s_per_gpu": tot_real * a.steps / dt / world,
-            # frac_of_peak: SURVEY 8(d)'s accounting - the FLOPs of the reference's computation of this batch (every row of the padded
-            # [B,S] grid, full S x S attention) over the step time.  frac_of_peak_executed: only what the engine executed (var-len
-            # layout: the real-token rows, len x len attention blocks) - the matrix pipes' actual duty.
-            "step_mfma": {"flops_per_step": fstep, "achieved_tflops_per_gpu": step_tflops,
-                          "frac_of_peak": step_tflops / PEAK_BF16_TFLOPS,
-                          "flops_per_step_executed": fexec, "frac_of_peak_executed": fexec / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                          "token_layout": "varlen" if ran_varlen else "padded", "rows": t_rows, "padded_rows": B * S},
+            # frac_of_peak: what the engine EXECUTED (var-len layout: the real-token rows, len x len attention blocks) over the step
+            # time and the dense bf16 peak - the matrix pipes' duty.  reference_grid: SURVEY 8(d)'s accounting - the FLOPs the reference
+            # spends on this batch (every row of the padded [B,S] grid, full S x S attention) over the same time: a throughput
+            # equivalent (pad-row work is never executed here), NOT an MFMA utilisation.
+            "step_mfma": {"flops_per_step": fexec, "achieved_tflops_per_gpu": fexec / (ms * 1e-3) / 1e12,
+                          "frac_of_peak": fexec / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                          "token_layout": "varlen" if ran_varlen else "padded", "rows": t_rows, "padded_rows": B * S,
+                          "reference_grid": {"flops_per_step": fstep, "equivalent_tflops_per_gpu": step_tflops,
+                                             "equivalent_frac_of_peak": step_tflops / PEAK_BF16_TFLOPS}},
             "roofline": roofline,
         }
         if gemm_info is not None:
@@ -377,9 +425,19 @@ def main():
         if dp_info is not None:
             dp_info["exposed_comm_ms"] = ms - dp_info["ms_per_step_without_exchange"]
             out["dp"] = dp_info
+        if layouts is not None:
+            out["layouts"] = {"ms_per_step": layouts, "reported": layout,
+                              "note": "varlen = reference-shaped call (device tensors only; the engine sums the mask and reads 4 bytes back), "
+                                      "varlen-count = caller passes data['num_tokens'], padded = every row of the [B,S] grid; same batch, same "
+                                      "K steps each, outside the reported time"}
         if world == 1 and not a.no_cpu_baseline and kind == "pt":
             state = weights.make_state_dict(spec, seed=0)
-            out["cpu_baseline"] = cpu_baseline(spec, state, B, S, F, V, 1234, min(os.cpu_count() or 1, 32))
+            out["cpu_baseline"], oracle_loss = cpu_baseline(spec, state, B, S, F, V, 1234, min(os.cpu_count() or 1, 32))
+            if gpu_eval_loss is not None:
+                out["loss_parity"] = {"gpu_eval_loss": gpu_eval_loss, "oracle_loss": oracle_loss,
+                                      "rel": abs(gpu_eval_loss - oracle_loss) / abs(oracle_loss),
+                                      "what": "SMTP loss of the bench batch (seed 1234) on the initial weights (seed 0, rounded to bf16), "
+                                              "eval mode: HIP engine forward vs the CPU oracle's forward"}
         elif world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = None   # the CPU port is timed on the headline workload only
         print(json.dumps(out), flush=True)

@@ -88,6 +88,7 @@ SIGNATURES = {
     "gget_set_token_count": (i32, [vp, C.c_int64]),
     "gget_varlen_status": (i32, [vp, vp, vp]),
     "gget_position_status": (i32, [vp, vp, vp]),
+    "gget_deferred_status": (i32, [vp, vp, vp]),
     "gget_set_focal_gamma": (i32, [vp, f32]),
     "gget_set_stack_method": (i32, [vp, i32]),
     "gget_set_rope_range": (i32, [vp, f32]),
@@ -103,6 +104,7 @@ SIGNATURES = {
 }
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+TOKENS_AUTO = -2   # gget_set_token_count: count the real tokens on the device (include/gget.h GGET_TOKENS_AUTO)
 EPI_NONE, EPI_RESIDUAL, EPI_ATOMIC_F32, EPI_SLAB_F32 = 0, 1, 2, 3
 
 

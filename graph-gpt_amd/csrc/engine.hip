@@ -358,7 +358,10 @@ struct gget_engine {
   int B = 0, S = 0, T = 0, TP = 0;
   bool varlen = false;            // the last forward ran on the compacted (padding-free) token layout
   int tc = 0;                     // its number of real tokens
-  long tc_next = -1;              // real-token count of the NEXT forward's batch (gget_set_token_count); < 0 = unknown -> padded layout
+  long tc_next = -1;              // real-token count of the NEXT forward's batch (gget_set_token_count); -1 = unknown -> padded layout,
+                                  // GGET_TOKENS_AUTO = count on the device and read back; consumed (reset) at the ENTRY of every forward
+  bool tc_from_caller = false;    // the last var-len forward ran on a caller's count (a wrong one poisons the loss, see poison_loss)
+  int32_t* host_word = nullptr;   // pinned host word the counted total lands in
   const int64_t* pos_rows = nullptr;   // position of every ROW (GEMM RoPE epilogue): pos_cur, or the compacted positions
   const int32_t* row_base() const { return varlen ? wsp<int32_t>(ws.vl_cu) : nullptr; }
   const int64_t* ids = nullptr;
@@ -526,6 +529,7 @@ extern "C" int gget_create(const gget_config_t* cfg, const gget_buffers_t* bufs,
 extern "C" int gget_comm_destroy(gget_handle_t h);
 extern "C" int gget_destroy(gget_handle_t h) {
   if (h) gget_comm_destroy(h);
+  if (h && h->host_word) (void)hipHostFree(h->host_word);
   delete h;
   return 0;
 }
@@ -606,7 +610,17 @@ extern "C" int gget_set_auc(gget_handle_t h, int num_neg, uint32_t seed) {
 
 extern "C" int gget_set_token_count(gget_handle_t h, int64_t n_real_tokens) {
   GGET_REQUIRE(h != nullptr, "null handle");
-  h->tc_next = n_real_tokens > 0 ? (long)n_real_tokens : -1;
+  h->tc_next = n_real_tokens > 0 ? (long)n_real_tokens : (n_real_tokens == GGET_TOKENS_AUTO ? (long)GGET_TOKENS_AUTO : -1);
+  return 0;
+}
+
+extern "C" int gget_deferred_status(gget_handle_t h, int32_t out[2], void* stream) {
+  GGET_REQUIRE(h && out, "null argument");
+  int32_t* st = h->wsp<int32_t>(h->ws.vl_status);
+  GGET_HIP_CHECK(hipMemcpyAsync(&out[0], st + 1, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  GGET_HIP_CHECK(hipMemcpyAsync(&out[1], st + 2, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  GGET_HIP_CHECK(hipMemsetAsync(st + 1, 0, 8, (hipStream_t)stream));
+  GGET_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
 
@@ -1069,7 +1083,7 @@ bool varlen_enabled() {
   static const int off = getenv("GGET_NO_VARLEN") != nullptr;
   return !off;
 }
-int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t* mask, const int64_t* pos, int B, int S,
+int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, const int64_t* mask, const int64_t* pos, int B, int S,
                      hipStream_t st, bool mask_is_3d = false, const int64_t* labels = nullptr, bool allow_varlen = true) {
   const gget_config_t& c = h->cfg;
   GGET_REQUIRE(B > 0 && S > 0, "empty batch");
@@ -1084,31 +1098,17 @@ int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t*
   }
   h->ids = ids; h->pos = pos;
   h->cos_cur = h->cos_tab; h->sin_cur = h->sin_tab; h->pos_cur = pos;
-  // Var-len (padding-free) token layout: when the caller told us how many real tokens the right-padded batch holds
-  // (gget_set_token_count: the host knows sum(attention_mask) from its collator, the device would need a sync), the real tokens are
-  // compacted sample after sample and every token-wise kernel and GEMM of the layer stack runs on round_up(real, 64) rows instead of
-  // B * S (PCQM4M-v2 batches are ~30 % padding, ogbl-ppa ~37 %).  Logical [B,S] quantities (labels, lse, dropout coordinates, loss
-  // normalisers) are unchanged.  Not taken where a kernel's random stream or an output is indexed by the padded row: element dropouts,
-  // raw-embedding inputs, rope_range tables, the token-level head; packed rows carry no padding to begin with.
-  const long tc_hint = h->tc_next;
-  h->tc_next = -1;
+  // Var-len (padding-free) token layout: when the number of real tokens of the right-padded batch is known - from the caller
+  // (gget_set_token_count(n): the host knows sum(attention_mask) from its collator) or counted here (GGET_TOKENS_AUTO: the key lengths
+  // are summed on the device and the total read back: 4 bytes and ONE stream synchronisation, which is what the reference's step pays
+  // on every `.to(device)` of a batch tensor anyway, training_utils.py:17-26) - the real tokens are compacted sample after sample and
+  // every token-wise kernel and GEMM of the layer stack runs on round_up(real, 64) rows instead of B * S (PCQM4M-v2 batches are ~30 %
+  // padding, ogbl-ppa ~37 %).  Logical [B,S] quantities (labels, lse, dropout coordinates, loss normalisers) are unchanged.  Not taken
+  // where a kernel's random stream or an output is indexed by the padded row: element dropouts, raw-embedding inputs, rope_range
+  // tables, the token-level head; packed rows carry no padding to begin with.
   h->varlen = false;
+  h->tc_from_caller = false;
   h->tc = B * S;
-  {
-    const long t_rows = (tc_hint + 63) / 64 * 64;
-    if (allow_varlen && varlen_enabled() && tc_hint > 0 && !mask_is_3d && mask != nullptr && c.embed_dim == 0 && h->embed_drop_p == 0.f &&
-        h->mlp_drop_p == 0.f && !(h->rope_range > 0.f && pos) && t_rows < (long)B * S) {
-      h->varlen = true;
-      h->tc = (int)tc_hint;
-      h->T = (int)t_rows;
-    }
-  }
-  if (h->rope_range > 0.f && pos) {
-    if (int e = k_rope_range_table(pos, h->wsp<float>(h->ws.rr_cos), h->wsp<float>(h->ws.rr_sin), h->wsp<int64_t>(h->ws.rr_ids), B, S,
-                                   h->rope_range, c.rope_theta > 0.f ? c.rope_theta : 10000.0f, st))
-      return e;
-    h->cos_cur = h->wsp<float>(h->ws.rr_cos); h->sin_cur = h->wsp<float>(h->ws.rr_sin); h->pos_cur = h->wsp<int64_t>(h->ws.rr_ids);
-  }
   const int d = c.hidden_size;
   h->packed = mask_is_3d;
   if (mask_is_3d) {
@@ -1118,6 +1118,31 @@ int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t*
                                h->wsp<int32_t>(h->ws.key_len),
                                c.kind == GGET_KIND_TASK ? h->wsp<int32_t>(h->ws.pool_row) : nullptr, B, S, st)) {
     return e;
+  }
+  if (allow_varlen && varlen_enabled() && (tc_hint > 0 || tc_hint == GGET_TOKENS_AUTO) && !mask_is_3d && mask != nullptr && c.embed_dim == 0 &&
+      h->embed_drop_p == 0.f && h->mlp_drop_p == 0.f && !(h->rope_range > 0.f && pos)) {
+    long tc = tc_hint;
+    if (tc_hint == GGET_TOKENS_AUTO) {
+      int32_t* dst = h->wsp<int32_t>(h->ws.vl_status) + 3;
+      if (!h->host_word) GGET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->host_word), 64, hipHostMallocDefault));
+      if (int e = k_sum_lengths(h->wsp<int32_t>(h->ws.key_len), B, dst, st)) return e;
+      GGET_HIP_CHECK(hipMemcpyAsync(h->host_word, dst, 4, hipMemcpyDeviceToHost, st));
+      GGET_HIP_CHECK(hipStreamSynchronize(st));
+      tc = *h->host_word;
+    }
+    const long t_rows = (tc + 63) / 64 * 64;
+    if (tc > 0 && t_rows < (long)B * S) {
+      h->varlen = true;
+      h->tc_from_caller = tc_hint > 0;
+      h->tc = (int)tc;
+      h->T = (int)t_rows;
+    }
+  }
+  if (h->rope_range > 0.f && pos) {
+    if (int e = k_rope_range_table(pos, h->wsp<float>(h->ws.rr_cos), h->wsp<float>(h->ws.rr_sin), h->wsp<int64_t>(h->ws.rr_ids), B, S,
+                                   h->rope_range, c.rope_theta > 0.f ? c.rope_theta : 10000.0f, st))
+      return e;
+    h->cos_cur = h->wsp<float>(h->ws.rr_cos); h->sin_cur = h->wsp<float>(h->ws.rr_sin); h->pos_cur = h->wsp<int64_t>(h->ws.rr_ids);
   }
   h->pos_rows = h->pos_cur;
   if (h->varlen) {
@@ -1168,13 +1193,16 @@ int backbone_forward(gget_engine* h, const int64_t* ids, int ldF, const int64_t*
 static int forward_pretrain_impl(gget_handle_t h, const int64_t* input_ids_dev, const int64_t* attention_mask_dev,
                                  bool mask_is_3d, const int64_t* labels_dev, const float* sample_wgt_dev,
                                  const int64_t* position_ids_dev, int B, int S, float* loss_dev, void* stream) {
-  GGET_REQUIRE(h && input_ids_dev, "null argument");
+  GGET_REQUIRE(h != nullptr, "null argument");
+  const long tc_hint = h->tc_next;   // the token count belongs to THIS call whatever happens below (a failing forward must not leave it
+  h->tc_next = -1;                   // to the next batch)
+  GGET_REQUIRE(input_ids_dev, "null argument");
   GGET_REQUIRE(h->cfg.kind == GGET_KIND_PRETRAIN, "handle was not created as a pre-train model");
   hipStream_t st = (hipStream_t)stream;
   const gget_config_t& c = h->cfg;
   StreamKScope sk_scope(h);
   h->fwd_valid = false;
-  if (int e = backbone_forward(h, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st, mask_is_3d, labels_dev))
+  if (int e = backbone_forward(h, tc_hint, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st, mask_is_3d, labels_dev))
     return e;
   const Ws& w = h->ws;
   const int T = h->TP, d = c.hidden_size, n = c.next_n_token, V = c.vocab_size;   // (capacities of the head: the padded token space)
@@ -1185,7 +1213,9 @@ static int forward_pretrain_impl(gget_handle_t h, const int64_t* input_ids_dev, 
                              h->wsp<int32_t>(w.sel_tok), st))
     return e;
   if (h->varlen)   // the selected rows live at their compact positions (sel_tok / sel_label keep the padded coordinates the loss weights need)
-    if (int e = k_remap_rows(h->wsp<int32_t>(w.row_idx), counts, h->wsp<int32_t>(w.vl_pad2c), T, st)) return e;
+    if (int e = k_remap_rows(h->wsp<int32_t>(w.row_idx), counts, h->wsp<int32_t>(w.vl_pad2c), T, h->T > h->tc ? h->tc : 0,
+                             h->wsp<int32_t>(w.vl_status), st))
+      return e;
   if (int e = k_gather_rows(h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.row_idx), counts, h->wsp<bf16_t>(w.Hm), T, d, 0, st))
     return e;
   if (h->plan.has_ntp) {
@@ -1212,6 +1242,8 @@ static int forward_pretrain_impl(gget_handle_t h, const int64_t* input_ids_dev, 
                              sample_wgt_dev, S, counts + 1, T * n, V, h->wsp<float>(w.loss_sum), h->wsp<bf16_t>(w.dlogits),
                              base, mean_rows, loss_dev, st, mean_rows ? h->focal_gamma : 0.f))   // (the dLM-weighted loss has no focal form)
       return e;
+    if (h->varlen && h->tc_from_caller && loss_dev)
+      if (int e = k_poison_loss(h->wsp<int32_t>(w.vl_status), loss_dev, st)) return e;
   }
   h->fwd_valid = true;
   return 0;
@@ -1236,13 +1268,16 @@ extern "C" int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, 
                                  const int64_t* position_ids_dev, const void* task_labels_dev, const float* sample_wgt_dev,
                                  int problem_type, int B, int S, float* loss_dev, float* task_logits_dev,
                                  void* task_hidden_dev, void* stream) {
-  GGET_REQUIRE(h && input_ids_dev, "null argument");
+  GGET_REQUIRE(h != nullptr, "null argument");
+  const long tc_hint = h->tc_next;   // (consumed at entry: see forward_pretrain_impl)
+  h->tc_next = -1;
+  GGET_REQUIRE(input_ids_dev, "null argument");
   GGET_REQUIRE(h->cfg.kind == GGET_KIND_TASK, "handle was not created as a task model");
   hipStream_t st = (hipStream_t)stream;
   const gget_config_t& c = h->cfg;
   StreamKScope sk_scope(h);
   h->fwd_valid = false;
-  if (int e = backbone_forward(h, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st, false, nullptr,
+  if (int e = backbone_forward(h, tc_hint, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st, false, nullptr,
                                /*allow_varlen=*/problem_type != GGET_PROBLEM_TOKEN_CE))
     return e;
   const Ws& w = h->ws;
@@ -1286,6 +1321,8 @@ extern "C" int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, 
         return e;
     } else if (int e = k_task_loss(lg, task_labels_dev, sample_wgt_dev, problem_type, B, C, loss_dev, h->wsp<float>(w.tdlogits), st))
       return e;
+    if (h->varlen && h->tc_from_caller)
+      if (int e = k_poison_loss(h->wsp<int32_t>(w.vl_status), loss_dev, st)) return e;
   }
   h->fwd_valid = true;
   return 0;

@@ -59,12 +59,14 @@ int k_lengths(const int64_t* mask, const int64_t* ids, int ldF, int pad_id, int3
 // Var-len (padding-free) token layout of a right-padded batch: cu[b] = first compact row of sample b (exclusive scan of key_len, cu[B] =
 // total), compact ids [t_rows][F] / row positions / sample index per row, pad2c[b*S+s] = compact row or -1; rows [tc, t_rows) are pad
 // tokens.  pool_row (task head, may be NULL) is moved to the compact rows; status[0] = 1 if sum(key_len) != tc.
-int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, const int32_t* key_len, int32_t* pool_row, int32_t* cu,
+int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, int32_t* key_len, int32_t* pool_row, int32_t* cu,
                   int64_t* ids_c, int64_t* pos_c, int32_t* row_b, int32_t* pad2c, int32_t* status, int B, int S, int tc, int t_rows,
                   int pad_id, hipStream_t st);
 // out = clamp(pos, 0, max_pos - 1); *flag = 1 (sticky) if anything was clamped
 int k_clamp_positions(const int64_t* pos, int64_t* out, int32_t* flag, long n, int max_pos, hipStream_t st);
-int k_remap_rows(int32_t* idx, const int32_t* count, const int32_t* pad2c, int cap, hipStream_t st);
+int k_remap_rows(int32_t* idx, const int32_t* count, const int32_t* pad2c, int cap, int pad_row, int32_t* status, hipStream_t st);
+int k_poison_loss(const int32_t* flag, float* loss, hipStream_t st);
+int k_sum_lengths(const int32_t* key_len, int B, int32_t* out, hipStream_t st);
 int k_head_compact(const int64_t* labels, int T, int n, int32_t* cnt, int32_t* m_off, int32_t* l_off, int32_t* counts,
                    int32_t* row_idx, int32_t* sel_src, int32_t* sel_label, int32_t* sel_tok, hipStream_t st);
 int k_gather_rows(const void* src, const int32_t* idx, const int32_t* count, void* dst, int cap, int d, int scatter,

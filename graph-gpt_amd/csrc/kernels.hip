@@ -1936,8 +1936,9 @@ int k_lengths(const int64_t* mask, const int64_t* ids, int ldF, int pad_id, int3
 // sample after sample, and the whole layer stack runs on T = round_up(sum(len), 64) rows.  cu[b] = first row of sample b.
 // ---------------------------------------------------------------------------------------------
 // one block: exclusive scan of key_len over the batch (any B), cu[B] = total; the pooled row of the task head (lengths_kernel: b*S + p)
-// moves to cu[b] + min(p, len - 1); status[0] = 1 when the total differs from the caller's token count
-__global__ void __launch_bounds__(1024) varlen_scan_kernel(const int32_t* __restrict__ key_len, int32_t* __restrict__ cu,
+// moves to cu[b] + min(p, len - 1); status[0] = 1 when the total differs from the caller's token count (status[2]: the same, sticky -
+// gget_deferred_status reads and clears it)
+__global__ void __launch_bounds__(1024) varlen_scan_kernel(int32_t* __restrict__ key_len, int32_t* __restrict__ cu,
                                                            int32_t* __restrict__ pool_row, int32_t* __restrict__ status, int B, int S,
                                                            int expect_total) {
   __shared__ int wsum[16];
@@ -1959,11 +1960,15 @@ __global__ void __launch_bounds__(1024) varlen_scan_kernel(const int32_t* __rest
     int base = carry_s;
     for (int w = 0; w < wave; ++w) base += wsum[w];
     if (b < B) {
-      const int start = base + x - v;
+      // (a caller's count SMALLER than the mask's total - flagged below, the step's results are invalid - must still not send any
+      //  kernel behind the rows the step runs on: samples are cut at expect_total)
+      const int start = min(base + x - v, expect_total);
+      const int len = min(v, expect_total - start);
       cu[b] = start;
+      if (len != v) key_len[b] = len;
       if (pool_row) {
         const int pidx = pool_row[b] - b * S;
-        pool_row[b] = start + max(min(pidx, v - 1), 0);
+        pool_row[b] = min(start + max(min(pidx, len - 1), 0), max(expect_total - 1, 0));
       }
     }
     __syncthreads();
@@ -1971,8 +1976,9 @@ __global__ void __launch_bounds__(1024) varlen_scan_kernel(const int32_t* __rest
     __syncthreads();
   }
   if (tid == 0) {
-    cu[B] = carry_s;
+    cu[B] = min(carry_s, expect_total);
     status[0] = carry_s == expect_total ? 0 : 1;
+    if (carry_s != expect_total) status[2] = 1;
   }
 }
 // one thread per padded token (b, s) plus one per tail row: compact ids / positions / sample index of its row, the padded -> compact map
@@ -1985,7 +1991,7 @@ __global__ void __launch_bounds__(kBlock) varlen_fill_kernel(const int64_t* __re
   const long TP = (long)B * S;
   if (i < TP) {
     const int b = (int)(i / S), sq = (int)(i % S);
-    if (sq < key_len[b]) {
+    if (sq < key_len[b]) {   // (key_len was cut by the scan kernel where a too-small caller's count would overrun the rows of the step)
       const int r = cu[b] + sq;
       for (int f = 0; f < F; ++f) ids_c[(size_t)r * F + f] = ids[(size_t)i * ldF + f];
       pos_c[r] = pos ? pos[i] : (int64_t)sq;
@@ -2001,11 +2007,33 @@ __global__ void __launch_bounds__(kBlock) varlen_fill_kernel(const int64_t* __re
     row_b[r] = 0;
   }
 }
-// SMTP head: the selected rows (padded token indices, head_fill_kernel) -> rows of the compact layout
+// SMTP head: the selected rows (padded token indices, head_fill_kernel) -> rows of the compact layout.  A label != -100 at a PADDED
+// position (the reference's collator never writes one: labels are padded with -100) selects a row the compact layout does not hold: it
+// is sent to `pad_row` (a pad-token row behind the real tokens when the row count was rounded up, else row 0) and the sticky flag
+// status[2] is raised - gget_deferred_status reports that this step's loss differs from the padded layout's.
 __global__ void __launch_bounds__(kBlock) remap_rows_kernel(int32_t* __restrict__ idx, const int32_t* __restrict__ count,
-                                                            const int32_t* __restrict__ pad2c, int cap) {
+                                                            const int32_t* __restrict__ pad2c, int cap, int pad_row,
+                                                            int32_t* __restrict__ status) {
   const int n = min(cap, *count);
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) idx[i] = max(pad2c[idx[i]], 0);
+  bool bad = false;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const int r = pad2c[idx[i]];
+    bad |= r < 0;
+    idx[i] = r < 0 ? pad_row : r;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) status[2] = 1;
+}
+// sum of the key lengths of a batch (one block): the real-token count the host reads back when it asked the engine to count
+// (gget_set_token_count(GGET_TOKENS_AUTO))
+__global__ void __launch_bounds__(1024) sum_lengths_kernel(const int32_t* __restrict__ key_len, int B, int32_t* __restrict__ out) {
+  __shared__ int tot;
+  if (threadIdx.x == 0) tot = 0;
+  __syncthreads();
+  int v = 0;
+  for (int b = threadIdx.x; b < B; b += 1024) v += key_len[b];
+  if (v) atomicAdd(&tot, v);
+  __syncthreads();
+  if (threadIdx.x == 0) *out = tot;
 }
 
 // position ids handed to a forward index the precomputed RoPE table [max_pos][32]: a copy clamped to [0, max_pos) keeps every table read
@@ -2029,7 +2057,7 @@ int k_clamp_positions(const int64_t* pos, int64_t* out, int32_t* flag, long n, i
   return 0;
 }
 
-int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, const int32_t* key_len, int32_t* pool_row, int32_t* cu,
+int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, int32_t* key_len, int32_t* pool_row, int32_t* cu,
                   int64_t* ids_c, int64_t* pos_c, int32_t* row_b, int32_t* pad2c, int32_t* status, int B, int S, int tc, int t_rows,
                   int pad_id, hipStream_t st) {
   hipLaunchKernelGGL(varlen_scan_kernel, dim3(1), dim3(1024), 0, st, key_len, cu, pool_row, status, B, S, tc);
@@ -2039,9 +2067,24 @@ int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, const 
   GGET_LAUNCH_CHECK();
   return 0;
 }
-int k_remap_rows(int32_t* idx, const int32_t* count, const int32_t* pad2c, int cap, hipStream_t st) {
+// a var-len step that ran on a caller's token count the mask contradicts computed garbage: its loss becomes NaN (and the sticky flag
+// status[2] stays up for gget_deferred_status) instead of a plausible number
+__global__ void poison_loss_kernel(const int32_t* __restrict__ flag, float* __restrict__ loss) {
+  if (*flag) *loss = __builtin_nanf("");
+}
+int k_poison_loss(const int32_t* flag, float* loss, hipStream_t st) {
+  hipLaunchKernelGGL(poison_loss_kernel, dim3(1), dim3(1), 0, st, flag, loss);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+int k_sum_lengths(const int32_t* key_len, int B, int32_t* out, hipStream_t st) {
+  hipLaunchKernelGGL(sum_lengths_kernel, dim3(1), dim3(1024), 0, st, key_len, B, out);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+int k_remap_rows(int32_t* idx, const int32_t* count, const int32_t* pad2c, int cap, int pad_row, int32_t* status, hipStream_t st) {
   if (cap == 0) return 0;
-  hipLaunchKernelGGL(remap_rows_kernel, dim3(grid_for(cap)), dim3(kBlock), 0, st, idx, count, pad2c, cap);
+  hipLaunchKernelGGL(remap_rows_kernel, dim3(grid_for(cap)), dim3(kBlock), 0, st, idx, count, pad2c, cap, pad_row, status);
   GGET_LAUNCH_CHECK();
   return 0;
 }

@@ -141,15 +141,19 @@ class Engine:
         return None if t is None else t.to(device=dev, dtype=torch.int64).contiguous()
 
     def _set_layout(self, att, num_tokens):
-        """Token layout of the forward about to run: `num_tokens` (host int: real tokens of the batch) selects the var-len layout;
-        GGET_VARLEN=sync (tests, A/B runs) counts a 2-D device mask here at the price of a stream sync; GGET_VARLEN=0 keeps the padded
-        layout whatever the caller passed."""
+        """Token layout of the forward about to run.  `num_tokens`: a host int (real tokens of the batch, no device traffic), the
+        string "auto" (the engine sums the key lengths of the 2-D device mask and reads the total back: 4 bytes + one stream
+        synchronisation - what the model classes pass for a device-resident mask) or None (unknown: padded layout, the default of this
+        low-level class).  GGET_VARLEN=0 keeps the padded layout whatever the caller passed; =sync counts even when the caller passed
+        nothing; =nosync never counts on the device."""
         import os
         mode = os.environ.get("GGET_VARLEN", "")
         n = None if mode == "0" else num_tokens
-        if n is None and mode == "sync" and att is not None and att.dim() == 2:
-            n = int((att != 0).sum())
-        self.set_token_count(n)
+        if n is None and mode == "sync":
+            n = "auto"
+        if n == "auto" and (mode == "nosync" or att is None or att.dim() != 2):
+            n = None
+        self.set_token_count(L.TOKENS_AUTO if n == "auto" else n)
 
     def forward_pretrain(self, input_ids, attention_mask, labels=None, sample_wgt=None, position_ids=None, num_tokens=None):
         dev = self.device
@@ -245,7 +249,7 @@ class Engine:
     def set_token_count(self, n_real_tokens: Optional[int]):
         """sum(attention_mask) of the NEXT forward's batch, when the host knows it: switches that step to the var-len (padding-free)
         token layout (gget_set_token_count).  None / 0 = unknown -> padded layout."""
-        L.check(self.lib.gget_set_token_count(self.h, int(n_real_tokens or -1)))
+        L.check(self.lib.gget_set_token_count(self.h, int(n_real_tokens or -1)))   # (L.TOKENS_AUTO = -2 passes through)
 
     def positions_clamped(self) -> bool:
         """True if a forward since the last call met position_ids outside [0, max_position) (they were clamped into the RoPE table);
@@ -253,6 +257,12 @@ class Engine:
         out = C.c_int32(0)
         L.check(self.lib.gget_position_status(self.h, C.byref(out), _stream()))
         return bool(out.value)
+
+    def deferred_status(self):
+        """(positions clamped, var-len token count / label mismatch) since the last call (gget_deferred_status); clears both; synchronises."""
+        out = (C.c_int32 * 2)()
+        L.check(self.lib.gget_deferred_status(self.h, out, _stream()))
+        return bool(out[0]), bool(out[1])
 
     def varlen_status(self):
         """(ran var-len, rows, count mismatch) of the last forward; synchronises."""

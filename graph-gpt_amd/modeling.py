@@ -47,10 +47,13 @@ class GraphGPTConfig:
                  smtp_inside=False, cls_token_id=None, mlp=None, dropout=0.0, loss_type=None, num_neg=None, num_labels=2,
                  problem_type=None, attention_dropout=0.0, rope_theta=10000.0, head_dim=None, num_key_value_heads=None,
                  attention_bias=False, mlp_bias=False, pretraining_tp=1, **kwargs):
-        if "rope_scaling" in kwargs:
-            # the reference passes its own `rope_scaling=None` next to **kwargs (configuration_graphgpt.py:118,185-199):
-            # a caller-supplied value is a TypeError there, too
+        # the reference passes its own `rope_scaling=None` next to **kwargs (configuration_graphgpt.py:118,185-199): a
+        # caller-supplied VALUE is a TypeError there, too.  A null / False entry is what to_dict() / save_pretrained() (and any
+        # hf LlamaConfig config.json) write for these two fields: dropped, so saved configs load again.
+        if kwargs.pop("rope_scaling", None):
             raise TypeError("GraphGPTConfig() got multiple values for keyword argument 'rope_scaling'")
+        if kwargs.pop("rope_3d", False):
+            raise NotImplementedError("gget engine: rope_3d (out of the hot-path scope, see DESIGN.md)")
         assert pooling_method in {"last", "sum", "mean"}            # configuration_graphgpt.py:137
         self.vocab_size, self.hidden_size, self.intermediate_size = vocab_size, hidden_size, intermediate_size
         self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
@@ -353,12 +356,21 @@ class _GgetModel(nn.Module):
 
     def check_deferred(self):
         """Raise what the per-step device-side guards recorded since the last call (one stream sync): position_ids outside the RoPE
-        table (IndexError, as _check_positions raises for host tensors)."""
+        table (IndexError, as _check_positions raises for host tensors); a var-len step whose `num_tokens` disagreed with its
+        attention mask, or labels != -100 at padded positions on the var-len layout (ValueError - the step's loss was NaN / differed
+        from the padded grid's)."""
         e = self._engine
-        if e is not None and e.positions_clamped():
+        if e is None:
+            return
+        clamped, mismatch = e.deferred_status()
+        if clamped:
             raise IndexError(f"position_ids outside [0, max_position_embeddings = {self.spec.max_position}) were passed to a forward since "
                              "the last check (the engine clamped them into the RoPE table: results diverge from the reference) - build "
                              "the model with a larger max_position_embeddings")
+        if mismatch:
+            raise ValueError("a forward since the last check ran on the var-len token layout with a `num_tokens` that differs from "
+                             "sum(attention_mask) (its loss was set to NaN), or met labels != -100 at padded positions; pass the right "
+                             "count, no count at all (the engine counts a device mask itself), or GGET_VARLEN=0")
 
     def _validate_inputs(self, input_ids, attention_mask, labels=None):
         """Debug-mode input validation (GGET_CHECK_INPUTS=1; costs device->host reads): the kernels index with the ids / labels
@@ -370,15 +382,16 @@ class _GgetModel(nn.Module):
 
     @staticmethod
     def _token_count(attention_mask, num_tokens):
-        """Real (un-padded) tokens of the batch for the var-len token layout (Engine.set_token_count): the caller's `num_tokens`, or
-        sum(attention_mask) when the mask still lives on the HOST (the reference's loops receive CPU batches from the DataLoader and
-        move them, training_utils.py:14-26) - counting there costs nothing, counting a device tensor would stall the stream, so a
-        device-side mask without a count keeps the padded layout."""
+        """Real (un-padded) tokens of the batch for the var-len token layout (Engine.set_token_count): the caller's `num_tokens`;
+        sum(attention_mask) when the mask still lives on the HOST (the loops of graph-gpt_amd.training pass CPU batches: counting
+        there costs nothing); "auto" for a DEVICE mask - the call shape of the reference's own step, which moves every tensor first
+        (training_utils.py:14-26): the engine then sums the key lengths on the device and reads 4 bytes back (one stream
+        synchronisation, right behind the ones `.to(device)` just paid)."""
         if num_tokens is not None:
             return int(num_tokens)
-        if attention_mask is not None and attention_mask.dim() == 2 and attention_mask.device.type == "cpu":
-            return int((attention_mask != 0).sum())
-        return None       # (GGET_VARLEN=sync / =0 are handled by Engine._set_layout)
+        if attention_mask is not None and attention_mask.dim() == 2:
+            return int((attention_mask != 0).sum()) if attention_mask.device.type == "cpu" else "auto"
+        return None       # (GGET_VARLEN=sync / nosync / 0 are handled by Engine._set_layout)
 
     def _wrap_loss(self, loss):
         if loss is None:
@@ -435,6 +448,8 @@ class GraphGPTTaskModel(_GgetModel):
                 inputs_raw_embeds=None, task_labels=None, cls_idx=None, sample_wgt=None, use_cache=None,
                 output_attentions=None, output_hidden_states=None, return_dict=None, num_tokens=None, **kwargs):
         assert inputs_embeds is None
+        if kwargs.get("pretrain_labels") is not None:     # (the reference's ft step passes the keyword, None unless finetune.use_aux)
+            raise NotImplementedError("pretrain_labels (use_aux: the double-heads fine-tune model) is outside the hot-path scope")
         assert (inputs_raw_embeds is not None) == (int(self.config.embed_dim or 0) > 0), \
             "inputs_raw_embeds are given exactly when the model was built with embed_dim > 0 (modeling_helpers.py:127-139)"
         if input_ids.dim() == 2:

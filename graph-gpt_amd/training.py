@@ -313,30 +313,85 @@ def initialize(model: _GgetModel, optim: Optional[OptimConfig] = None, process_g
 
 
 # ----------------------------------------------------------------------------- one optimisation step
-def batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine):
+def _reference_step_args(model, train_cfg, train_stats):
+    """The reference's positional form `batch_training(data, model, train_cfg, train_stats, opt_stats)` (training_utils.py:7-13):
+    `model` is the engine `deepspeed.initialize` returned, `train_stats` carries `.device`, `.has_embeds_input`, `.use_deepspeed`."""
+    if not getattr(train_stats, "use_deepspeed", True):
+        raise NotImplementedError("the fp16 autocast + GradScaler DDP branch (training_utils.py:46-86) is outside the bf16 hot path "
+                                  "(DESIGN.md section 7): run with use_deepspeed=True semantics (engine.backward / engine.step)")
+    return getattr(train_stats, "device", None) or model.device, bool(getattr(train_stats, "has_embeds_input", False))
+
+
+def batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine, train_cfg=None, train_stats=None, opt_stats=None):
     """reference training_utils.batch_training DeepSpeed branch (:30-45): loss = head1 (+head2); backward; step.
-    position_ids are NOT passed in pre-training (reference comments them out at :35).  `data["num_tokens"]` (optional, a host int =
-    sum of the attention mask, e.g. written by the collator) or a host-side attention mask lets the engine run the step on the
-    padding-free token layout (modeling._GgetModel._token_count)."""
-    out = engine(input_ids=data["input_ids"], attention_mask=data["attention_mask"], labels=data["labels"],
-                 inputs_raw_embeds=data.get("embed"), sample_wgt=data.get("wgt"), num_tokens=data.get("num_tokens"))
-    loss = out.head1_loss
-    if out.head2_loss is not None:
-        loss = loss + out.head2_loss
-    engine.backward(loss)
-    engine.step()
+    position_ids are NOT passed in pre-training (reference comments them out at :35).
+
+    Two call forms.  `batch_training(data, engine)`: host tensors go to the engine as they are; `data["num_tokens"]` (optional host
+    int = sum of the attention mask) or the host-side mask itself gives the var-len layout its row count for free.
+    `batch_training(data, model, train_cfg, train_stats, opt_stats)` - the reference's own signature (training_utils.py:7-13): every
+    tensor is moved to `train_stats.device` first, exactly like :17-26, the model sees device tensors only (the engine then counts
+    the mask on the device), and the losses / shapes are recorded on `train_stats` like :87-95."""
+    if train_stats is None:
+        out = engine(input_ids=data["input_ids"], attention_mask=data["attention_mask"], labels=data["labels"],
+                     inputs_raw_embeds=data.get("embed"), sample_wgt=data.get("wgt"), num_tokens=data.get("num_tokens"))
+        loss = out.head1_loss
+        if out.head2_loss is not None:
+            loss = loss + out.head2_loss
+        engine.backward(loss)
+        engine.step()
+        return loss
+    model = engine
+    device, has_embeds = _reference_step_args(model, train_cfg, train_stats)
+    input_ids = data["input_ids"].to(device)
+    attention_mask = data["attention_mask"].to(device)
+    labels = data["labels"].to(device)
+    inputs_raw_embeds = data["embed"].to(device) if has_embeds else None
+    sample_wgt = data["wgt"].to(device) if "wgt" in data else None
+    output = model(input_ids=input_ids, attention_mask=attention_mask, labels=labels, inputs_raw_embeds=inputs_raw_embeds,
+                   sample_wgt=sample_wgt)
+    main_loss, aux_loss = output.head1_loss, output.head2_loss
+    loss = main_loss + aux_loss if aux_loss is not None else main_loss
+    model.backward(loss)
+    model.step()
+    train_stats.loss, train_stats.main_loss, train_stats.aux_loss = loss, main_loss, aux_loss
+    train_stats.inputs_shape = input_ids.shape
+    train_stats.sliced_raw_embeds = inputs_raw_embeds[:2, :8] if inputs_raw_embeds is not None else None
     return loss
 
 
-def ft_batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine, label_key: str = "task_labels"):
-    """reference training_utils.ft_batch_training (:98-205): passes position_ids, task labels, sample weights."""
-    out = engine(input_ids=data["input_ids"], attention_mask=data["attention_mask"], position_ids=data.get("position_ids"),
-                 task_labels=data[label_key], cls_idx=data.get("cls_idx"), inputs_raw_embeds=data.get("embed"),
-                 sample_wgt=data.get("wgt"), num_tokens=data.get("num_tokens"))
-    loss = out.task_loss
-    engine.backward(loss)
-    engine.step()
-    return loss, out.task_logits
+def ft_batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine, *ref_args, label_key: str = "task_labels"):
+    """reference training_utils.ft_batch_training (:98-205): passes position_ids, task labels, sample weights.
+    `ft_batch_training(data, engine[, label_key=])` or the reference's positional form
+    `ft_batch_training(data, model, fthead_cfg, train_cfg, train_stats, opt_stats)` (tensors moved to the device first, :114-133;
+    `fthead_cfg.task_type` names the label key, multi-label targets become float, the losses are recorded on `train_stats`)."""
+    if not ref_args:
+        out = engine(input_ids=data["input_ids"], attention_mask=data["attention_mask"], position_ids=data.get("position_ids"),
+                     task_labels=data[label_key], cls_idx=data.get("cls_idx"), inputs_raw_embeds=data.get("embed"),
+                     sample_wgt=data.get("wgt"), num_tokens=data.get("num_tokens"))
+        loss = out.task_loss
+        engine.backward(loss)
+        engine.step()
+        return loss, out.task_logits
+    if len(ref_args) != 4:
+        raise TypeError("ft_batch_training(data, model, fthead_cfg, train_cfg, train_stats, opt_stats)")
+    fthead_cfg, train_cfg, train_stats, _opt_stats = ref_args
+    model = engine
+    device, has_embeds = _reference_step_args(model, train_cfg, train_stats)
+    if getattr(getattr(train_cfg, "finetune", None), "use_aux", False):
+        raise NotImplementedError("finetune.use_aux (the double-heads fine-tune model) is outside the hot-path scope")
+    task_labels = data[f"{fthead_cfg.task_type}_labels"].to(device)
+    if fthead_cfg.problem_type == "multi_label_classification":
+        task_labels = task_labels.float()
+    output = model(input_ids=data["input_ids"].to(device), attention_mask=data["attention_mask"].to(device), pretrain_labels=None,
+                   task_labels=task_labels, cls_idx=data["cls_idx"].to(device) if "cls_idx" in data else None,
+                   inputs_raw_embeds=data["embed"].to(device) if has_embeds else None,
+                   sample_wgt=data["wgt"].to(device) if "wgt" in data else None, position_ids=data["position_ids"].to(device))
+    task_loss = output.task_loss
+    loss = task_loss.float()
+    model.backward(loss)
+    model.step()
+    train_stats.loss, train_stats.main_loss, train_stats.aux_loss = loss, task_loss, None
+    return loss, output.task_logits
 
 
 def _host_token_count(data) -> Optional[int]:
@@ -373,7 +428,8 @@ def evaluate(model, loader, eval_name: str = "valid", do_eval: bool = True):
     losses, aux_losses = [], []
     for data in loader:
         out = model(input_ids=data["input_ids"].to(device), attention_mask=data["attention_mask"].to(device),
-                    labels=data["labels"].to(device), inputs_raw_embeds=None,
+                    labels=data["labels"].to(device),
+                    inputs_raw_embeds=data["embed"].to(device) if "embed" in data else None,     # log_eval_dump_utils.py:53-59
                     sample_wgt=data["wgt"].to(device) if "wgt" in data else None, **_layout_kw(model, data))
         loss, aux = out.head1_loss.clone(), out.head2_loss
         if world > 1:
@@ -388,9 +444,32 @@ def evaluate(model, loader, eval_name: str = "valid", do_eval: bool = True):
         if aux is not None and not torch.isnan(aux).item():
             aux_losses.append(aux)
     model.train()
+    _check_deferred_all_ranks(model)
     if not losses:
         raise ValueError(f"evaluate: the {eval_name} loader yielded no batch")
     return sum(losses) / len(losses), None
+
+
+def _check_deferred_all_ranks(model):
+    """`model.check_deferred()` so that EVERY rank raises when any rank's device-side input guard fired: a single rank raising in
+    front of a collective would leave the others blocked in it.  The flag is max-reduced over the default group."""
+    m = getattr(model, "module", model)
+    if not hasattr(m, "check_deferred"):
+        return
+    err = None
+    try:
+        m.check_deferred()
+    except (IndexError, ValueError) as ex:
+        err = ex
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dev = m.device if dist.get_backend() == "nccl" else torch.device("cpu")
+        flag = torch.tensor([1 if err is not None else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if err is None and int(flag.item()):
+            err = RuntimeError("another rank's device-side input guard fired (position_ids outside the RoPE table or a var-len token "
+                               "count mismatch): see that rank's error")
+    if err is not None:
+        raise err
 
 
 def all_gather_varlen(q: torch.Tensor) -> torch.Tensor:
@@ -433,8 +512,7 @@ def ft_evaluate(model, loader, *, problem_type: str = "single_label_classificati
         idx = data["idx"].to(device) if "idx" in data else torch.arange(labels.shape[0], device=device) + (j - 1) * labels.shape[0]
         cls_metrics.update(res.task_logits, labels, idx)
     model.train()
-    if hasattr(model, "check_deferred"):
-        model.check_deferred()
+    _check_deferred_all_ranks(model)      # (a collective itself: every rank raises together, none is left inside the gathers below)
     if j == 0:
         raise ValueError(f"ft_evaluate: the {eval_name} loader yielded no batch")
     test_loss = test_loss / j
@@ -573,7 +651,36 @@ class TrainingPipeline:
         return self
 
 
+def parse_space_separated_args(args):
+    """reference conf_utils.parse_space_separated_args (:9-27): "key value" pairs (one string or two) -> dict; a key without a value is a flag."""
+    config, i = {}, 0
+    while i < len(args):
+        if " " in args[i] and args[i].count(" ") == 1:
+            key, value = args[i].split(" ", 1)
+            config[key] = value
+            i += 1
+        elif i + 1 < len(args) and not args[i + 1].startswith("--"):
+            config[args[i]] = args[i + 1]
+            i += 2
+        else:
+            config[args[i]] = True
+            i += 1
+    return config
+
+
 def launch(fn: Callable, *args, **kwargs):
-    """reference `launch(train)` (pipeline.py:229-257) strips launcher args and calls the entry point; ranks are
-    created by `python -m torch.distributed.run`, one per GPU."""
+    """reference `launch(train)` (pipeline.py:229-257): spawn start method, `--local_rank*` (injected by the DeepSpeed launcher,
+    unknown to Hydra) stripped from sys.argv, space-separated "key value" arguments rewritten as key=value overrides, then the entry
+    point is called.  Ranks are created by `python -m torch.distributed.run`, one per GPU.  Extra positional / keyword arguments are
+    handed to `fn` (the reference's `train` takes none)."""
+    import multiprocessing as mp
+    import sys
+    try:
+        mp.set_start_method("spawn")
+    except RuntimeError:
+        pass
+    sys.argv = [a for a in sys.argv if not a.startswith("--local_rank")]
+    if len(sys.argv) > 1 and sys.argv[0].endswith(".py") and "=" not in sys.argv[-1]:
+        parsed = parse_space_separated_args(sys.argv[1:])
+        sys.argv = [sys.argv[0]] + [f"{k}='{v}'" if v == "" else f"{k}={v}" for k, v in parsed.items()]
     return fn(*args, **kwargs)

@@ -129,15 +129,28 @@ int gget_set_dropout(gget_handle_t h, float attention_p, float path_p, uint32_t 
 /* Var-len (padding-free) token layout.  replaces: nothing the reference has as an operator - it runs every token-wise module over the
  * padded [B,S] grid and masks attention (src/models/graphgpt/modeling_helpers.py:38-64); its only remedy against padding is the
  * collator-side `pack_tokens` option (src/data/tokenizer.py:359-415, served by gget_forward_pretrain_packed).  n_real_tokens =
- * sum(attention_mask) of the NEXT gget_forward_pretrain / gget_forward_task batch (the host knows it from its collator; < 1 = unknown).
- * When given, and the batch is right-padded, the engine compacts the real tokens once (sample b owns rows [cu[b], cu[b] + len[b]))
+ * sum(attention_mask) of the NEXT gget_forward_pretrain / gget_forward_task batch, one of
+ *     n > 0              the caller's count (the host knows it from its collator): no device->host traffic at all;
+ *     GGET_TOKENS_AUTO   counted by the engine: the key lengths are summed on the device and the total is read back before the
+ *                        launches are sized - 4 bytes and ONE stream synchronisation per forward.  This is what the model classes
+ *                        pass for a device-resident mask, i.e. for a call shaped exactly like the reference's step, which has just
+ *                        synchronised on `.to(device)` of every batch tensor (src/utils/training_utils.py:17-26): the stream is
+ *                        drained, the read costs a kernel launch + a 4-byte copy (measured: bench.py `layouts`);
+ *     anything else      unknown -> padded layout (the default of a bare C-ABI forward).
+ * The count is consumed at the ENTRY of the next forward call, whether that call succeeds or not.
+ * In the var-len layout the engine compacts the real tokens once (sample b owns rows [cu[b], cu[b] + len[b]))
  * and runs embedding, every GEMM / norm / residual of the layer stack, attention (per-sample row offsets) and the backward on
  * round_up(n_real_tokens, 64) rows instead of B*S.  Results are those of the padded layout (pad rows never influence real rows; the
  * loss, its normalisers, the dropout streams and all [B,S]-shaped inputs keep their logical coordinates).  The engine falls back to the
  * padded layout by itself where a random stream or an output is indexed by the padded row (element dropouts, raw-embedding inputs,
  * rope_range, the token-level head) and for packed rows.  gget_hidden_states refuses after a var-len forward.
+ * A caller's count that DISAGREES with the mask cannot go unnoticed: the samples are cut at the count (no kernel leaves the rows of
+ * the step), the step's loss is NaN, and a sticky device flag is raised that gget_deferred_status reports; the same flag is raised by
+ * a label != -100 at a padded position (the reference's collator pads labels with -100; such a row does not exist in the compact
+ * layout - its loss term is taken from a pad-token row instead of the padded grid's row).
  * gget_varlen_status: out[0] = 1 if the last forward ran var-len, out[1] = rows it ran on, out[2] = 1 if sum(key lengths) on the
- * device differed from n_real_tokens (results are then invalid: the caller's count was wrong); synchronises the stream. */
+ * device differed from n_real_tokens; synchronises the stream. */
+#define GGET_TOKENS_AUTO (-2)
 int gget_set_token_count(gget_handle_t h, int64_t n_real_tokens);
 /* position_ids of a forward index the RoPE table precomputed for config.max_position rows (the reference evaluates the rotary embedding
  * per call, hf LlamaRotaryEmbedding.forward :111-127, and accepts any position): the engine reads them through a copy clamped to
@@ -145,6 +158,11 @@ int gget_set_token_count(gget_handle_t h, int64_t n_real_tokens);
  * the stream - call it when convenient (end of an epoch, a logging step), not per step. */
 int gget_position_status(gget_handle_t h, int32_t* clamped_out, void* stream);
 int gget_varlen_status(gget_handle_t h, int32_t out[3], void* stream);
+/* The sticky device-side input guards in one read (then cleared; synchronises the stream - call it where the loop synchronises anyway):
+ * out[0] = position_ids were clamped into the RoPE table (as gget_position_status), out[1] = a var-len step ran on a token count the
+ * mask contradicted, or met a label at a padded position (see gget_set_token_count).  replaces: the IndexError / shape error the
+ * reference's nn.Embedding / rotary embedding raise synchronously for such inputs. */
+int gget_deferred_status(gget_handle_t h, int32_t out[2], void* stream);
 
 /* replaces: `embed_pdrop` / `mlp_pdrop` of the config + model.train()/eval(): nn.Dropout on the gathered token embeddings
  * (modeling_helpers.py:96-98) and the two dropouts of the decoder MLP - on act(gate)*up and on down_proj's output

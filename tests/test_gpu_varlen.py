@@ -188,19 +188,23 @@ def test_varlen_model_classes_and_training_step(monkeypatch):
         torch.cuda.synchronize()
         return losses, model._engine.varlen_status()[0], model._engine.master.detach().cpu().numpy().copy()
 
-    lp, vp, mp = run(dev)                                   # device mask, no count: padded
+    monkeypatch.setenv("GGET_VARLEN", "nosync")
+    lp, vp, mp = run(dev)                                   # device mask, counting on the device switched off: padded
+    monkeypatch.delenv("GGET_VARLEN")
+    ld, vd, md = run(dev)                                   # device mask, no count: the engine counts it (GGET_TOKENS_AUTO)
     lh, vh, mh = run(host)                                  # host mask: counted for free
     ln, vn, mn = run(dict(dev, num_tokens=n))               # explicit count
-    assert (vp, vh, vn) == (False, True, True)
+    assert (vp, vd, vh, vn) == (False, True, True, True)
     np.testing.assert_allclose(lh, lp, rtol=5e-4)
     np.testing.assert_allclose(ln, lp, rtol=5e-4)
-    np.testing.assert_array_equal(mh, mn)                   # the two var-len runs are the same computation
+    np.testing.assert_array_equal(mh, mn)                   # the three var-len runs are the same computation
+    np.testing.assert_array_equal(md, mn)
+    assert ld == ln
     upd = np.linalg.norm(mp - M.GraphGPTPretrainBase(M.GraphGPTConfig(**cfg), seed=1).cuda()._engine.master.detach().cpu().numpy())
     assert np.linalg.norm(mh - mp) < 0.05 * upd
     monkeypatch.setenv("GGET_VARLEN", "0")
     assert run(host)[1] is False
-    monkeypatch.setenv("GGET_VARLEN", "sync")
-    assert run(dev)[1] is True
+    assert run(dev)[1] is False
 
 
 def test_varlen_c1_full_size_matches_padded():
@@ -267,3 +271,88 @@ def test_varlen_changing_batches_do_not_leak_stale_rows():
     base.load_state_dict(state)
     upd = np.linalg.norm(mp - base.master.detach().cpu().numpy())
     assert np.linalg.norm(mv - mp) < 0.03 * upd, (np.linalg.norm(mv - mp), upd)
+
+
+def test_reference_shaped_step_runs_varlen_from_device_tensors():
+    """a step shaped EXACTLY like the reference's (training_utils.py:7-45: positional `batch_training(data, model,
+    train_cfg, train_stats, opt_stats)`, every tensor moved with `.to(device)` before the model sees it, no `num_tokens` keyword
+    anywhere) runs on the compact layout - the engine counts the device-side mask itself - and is the SAME computation as the step that
+    was handed the count: loss and every master weight after three clip + AdamW steps are bit-equal."""
+    import types
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    tr = importlib.import_module("graph-gpt_amd.training")
+    from src.utils.training_utils import batch_training as ref_batch_training          # the drop-in import path
+    cfg = dict(hidden_act="gelu", vocab_size=756, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+               max_position_embeddings=1024, causal_attention=False, stacked_feat=13, next_n_token=13)
+    batch = synth.make_pretrain_batch(B=32, S=32, F=13, V=756, seed=8)
+    n = synth.real_tokens(batch)
+    host = {k: torch.from_numpy(v) for k, v in batch.items() if k != "lengths"}
+    host["position_ids"] = torch.arange(32)[None, :].repeat(32, 1)
+
+    def run(reference_form):
+        model = M.GraphGPTPretrainBase(M.GraphGPTConfig(**cfg), seed=1).cuda().eval()
+        eng = tr.initialize(model, tr.OptimConfig(lr=1e-3, max_grad_norm=1.0))
+        stats = types.SimpleNamespace(device=torch.device("cuda"), has_embeds_input=False, use_deepspeed=True)
+        losses = []
+        for _ in range(3):
+            if reference_form:
+                ref_batch_training(host, eng, types.SimpleNamespace(optimizer=None), stats, None)
+                losses.append(float(stats.loss))
+                assert stats.main_loss is stats.loss and stats.aux_loss is None and tuple(stats.inputs_shape) == (32, 32, 13)
+            else:
+                losses.append(float(tr.batch_training(dict({k: v.cuda() for k, v in host.items()}, num_tokens=n), eng)))
+        torch.cuda.synchronize()
+        st = model._engine.varlen_status()
+        model.check_deferred()
+        return losses, st, model._engine.master.detach().cpu().numpy().copy()
+
+    lr_, sr, mr = run(True)
+    lc, sc, mc = run(False)
+    assert sr == (True, (n + 63) // 64 * 64, False) and sc == sr
+    assert lr_ == lc
+    np.testing.assert_array_equal(mr, mc)
+
+
+def test_varlen_wrong_count_poisons_loss_and_raises_deferred():
+    """a caller's token count that disagrees with the mask cannot pass silently - the step's loss is NaN, the sticky
+    device flag survives later (correct) steps until `check_deferred()` raises ValueError, no kernel leaves the rows of the step (the
+    samples are cut at the count), and a FAILED forward does not leave its count to the next call.  Labels at padded positions raise
+    the same flag."""
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    cfg = dict(hidden_act="gelu", vocab_size=500, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+               max_position_embeddings=64, causal_attention=False, stacked_feat=4, next_n_token=4)
+    batch = synth.make_pretrain_batch(B=16, S=32, F=4, V=500, seed=5)
+    n = synth.real_tokens(batch)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in batch.items() if k != "lengths"}
+    model = M.GraphGPTPretrainBase(M.GraphGPTConfig(**cfg), seed=2).cuda().eval()
+    good = float(model(input_ids=dev["input_ids"], attention_mask=dev["attention_mask"], labels=dev["labels"]).head1_loss)
+    assert np.isfinite(good) and model._engine.varlen_status() == (True, (n + 63) // 64 * 64, False)
+    model.check_deferred()
+    for wrong in (n - 70, n + 5):
+        bad = float(model(input_ids=dev["input_ids"], attention_mask=dev["attention_mask"], labels=dev["labels"], num_tokens=wrong).head1_loss)
+        assert np.isnan(bad)
+        again = float(model(input_ids=dev["input_ids"], attention_mask=dev["attention_mask"], labels=dev["labels"]).head1_loss)
+        assert again == good                                   # the next, correct step is untouched ...
+        with pytest.raises(ValueError):
+            model.check_deferred()                             # ... and the flag is still up
+        model.check_deferred()                                 # cleared by the read
+    # a forward that fails its argument checks consumes the count it was given
+    import ctypes as C
+    e = model._engine
+    ids, att, lab0 = (dev[k].to(torch.int64).contiguous() for k in ("input_ids", "attention_mask", "labels"))
+    loss = torch.zeros(1, device="cuda")
+    args = lambda B: (e.h, C.c_void_p(ids.data_ptr()), C.c_void_p(att.data_ptr()), C.c_void_p(lab0.data_ptr()), None, None, B, 32,
+                      C.c_void_p(loss.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    e.set_token_count(n - 9)
+    assert e.lib.gget_forward_pretrain(*args(10 ** 6)) != 0   # exceeds the handle's capacity: fails its argument checks
+    assert e.lib.gget_forward_pretrain(*args(16)) == 0
+    assert e.varlen_status()[0] is False                      # no stale count: padded layout
+    model.check_deferred()
+    # labels at padded positions: flagged on the compact layout
+    lab = dev["labels"].clone()
+    pad = (dev["attention_mask"] == 0).nonzero()[0]
+    lab[pad[0], pad[1], 0] = 30
+    out = float(model(input_ids=dev["input_ids"], attention_mask=dev["attention_mask"], labels=lab).head1_loss)
+    assert np.isfinite(out)
+    with pytest.raises(ValueError):
+        model.check_deferred()

@@ -151,3 +151,72 @@ def test_graphgpt_config_defaults_and_guards():
         M.GraphGPTConfig(**ok, rope_scaling={"rope_type": "dynamic", "factor": 2.0})
     with pytest.raises(AssertionError):
         M.GraphGPTConfig(**ok, pooling_method="max")
+
+
+def test_config_save_pretrained_roundtrip(tmp_path):
+    """to_dict() / save_pretrained() write `rope_scaling: null`, `rope_3d: false`; from_pretrained and
+    GraphGPTConfig(**cfg.to_dict()) must load that again (hf LlamaConfig / reference config.json files carry the null, too), while a
+    real rope_scaling VALUE is still the TypeError the reference raises (configuration_graphgpt.py:118,185-199)."""
+    import importlib
+    import json
+    import pytest
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    cfg = M.GraphGPTConfig(vocab_size=756, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                           hidden_act="gelu", stacked_feat=13, next_n_token=13, causal_attention=False, my_extra_field="kept")
+    cfg.save_pretrained(str(tmp_path))
+    on_disk = json.load(open(tmp_path / "config.json"))
+    assert on_disk["rope_scaling"] is None and on_disk["model_type"] == "graphgpt"
+    back = M.GraphGPTConfig.from_pretrained(str(tmp_path))
+    assert back.to_dict() == cfg.to_dict()
+    assert M.GraphGPTConfig(**cfg.to_dict()).to_dict() == cfg.to_dict()
+    with pytest.raises(TypeError):
+        M.GraphGPTConfig(rope_scaling={"rope_type": "linear", "factor": 2.0})
+    with pytest.raises(NotImplementedError):
+        M.GraphGPTConfig(rope_3d=True)
+
+
+def test_reference_entry_script_imports():
+    """the import lines of the reference's entry scripts (examples/train_pretrain.py:5-7, train_supervised.py:5-7)
+    and of its own modules (`src.models.graphgpt.*`, `src.utils.training_utils`) resolve against this repo's `src/`."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "\n".join([
+        "import sys", "sys.path.insert(0, '.')",
+        "from src.training import TrainingPipeline, launch",
+        "from src.training.pretrain_mode import PretrainMode",
+        "from src.training.finetune_mode import FinetuneMode",
+        "from src.conf import Config",
+        "from src.training.mode import TrainingMode",
+        "from src.training.pipeline import TrainingPipeline as TP2",
+        "from src.models import GraphGPTPretrainBase, GraphGPTTaskModel, GraphGPTConfig, convert_to_legacy_config",
+        "from src.models.graphgpt.modeling_graphgpt import GraphGPTPretrainBase as P2, DoubleHeadsModelOutput",
+        "from src.models.graphgpt.configuration_graphgpt import GraphGPTConfig as C2",
+        "from src.utils.training_utils import batch_training, ft_batch_training",
+        "from src.utils.log_eval_dump_utils import evaluate, ft_evaluate",
+        "from src.utils import loader_utils, misc_utils, metrics_utils",
+        "assert TP2 is TrainingPipeline and P2 is GraphGPTPretrainBase and C2 is GraphGPTConfig",
+        "assert issubclass(PretrainMode, TrainingMode) and issubclass(FinetuneMode, TrainingMode)",
+        "assert PretrainMode.model_cls is GraphGPTPretrainBase and FinetuneMode.model_cls is GraphGPTTaskModel",
+        "import inspect",
+        "assert list(inspect.signature(batch_training).parameters)[:5] == ['data', 'engine', 'train_cfg', 'train_stats', 'opt_stats']",
+        "print('imports-ok')"])
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "imports-ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_launch_filters_launcher_arguments(monkeypatch):
+    """reference pipeline.launch (:229-257): `--local_rank=N` never reaches the entry point; space-separated "key value" arguments
+    become key=value overrides; key=value arguments pass untouched."""
+    import importlib
+    import sys
+    tr = importlib.import_module("graph-gpt_amd.training")
+    seen = []
+    monkeypatch.setattr(sys, "argv", ["train_pretrain.py", "--local_rank=3", "training.batch_size=8", "model.graph_input.stacked_feat=13"])
+    tr.launch(lambda: seen.append(list(sys.argv)))
+    assert seen[-1] == ["train_pretrain.py", "training.batch_size=8", "model.graph_input.stacked_feat=13"]
+    monkeypatch.setattr(sys, "argv", ["train_pretrain.py", "--local_rank=0", "training.batch_size", "8", "training.note", ""])
+    tr.launch(lambda: seen.append(list(sys.argv)))
+    assert seen[-1] == ["train_pretrain.py", "training.batch_size=8", "training.note=''"]
+    assert tr.parse_space_separated_args(["a b", "c", "d", "--flag"]) == {"a": "b", "c": "d", "--flag": True}

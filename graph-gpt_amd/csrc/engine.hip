@@ -1698,6 +1698,16 @@ extern "C" int gget_hidden_states(gget_handle_t h, const void** hidden_dev) {
   return 0;
 }
 
+// residual stream entering decoder layer `layer` (layer == num_layers: leaving the last one) of the last forward - the quantity
+// hf LlamaModel's `output_hidden_states=True` returns as hidden_states[layer] (modeling_llama.py :401-414).  Padded layout only.
+extern "C" int gget_layer_hidden_states(gget_handle_t h, int layer, const void** hidden_dev) {
+  GGET_REQUIRE(h && hidden_dev, "null argument");
+  GGET_REQUIRE(layer >= 0 && layer <= h->cfg.num_layers, "layer_hidden_states: layer %d out of range", layer);
+  GGET_REQUIRE(!h->varlen, "layer_hidden_states: the last forward ran on the var-len token layout (rows are compacted); run it without a token count");
+  *hidden_dev = h->wsp<bf16_t>(h->ws.xres[layer]);
+  return 0;
+}
+
 // ================================================================================================
 // operator-level entry points
 // ================================================================================================
@@ -1732,6 +1742,7 @@ extern "C" int gget_debug_occupy(void* scratch, uint64_t scratch_bytes, int bloc
 extern int g_gemm_variant;
 extern int g_gemm_lds_headroom;
 extern int g_gemm_split_last;
+extern int g_gemm_stagger_ticks;
 extern "C" int gget_debug_probe(gget_handle_t h, int enable, float* avg_ms_out /* [2] or NULL */) {
   GGET_REQUIRE(h != nullptr, "null handle");
   if (avg_ms_out) {   // mean launch duration over the layers of the last forward / backward that ran with the probe on
@@ -1757,6 +1768,7 @@ extern "C" int gget_debug_set(int key, int value) {
     case 2: g_gemm_lds_headroom = value; return 0;
     case 4: k_set_deterministic(value); return 0;
     case 3: g_gemm_split_last = value; return 0;
+    case 5: g_gemm_stagger_ticks = value; return 0;
   }
   gget_set_error("debug_set: unknown key %d", key);
   return 2;

@@ -45,6 +45,11 @@ struct GemmGroup {
   unsigned* sk_flags;
   unsigned sk_epoch;
   int sk_rounds, sk_rem, sk_parts, sk_a;   // full rounds, tiles of the last round, K parts per tile (1: owners + helpers), owner K-tiles
+  // two-workgroups-per-CU launches (gemm_persist_kernel MODE 2): the second workgroup to arrive on a CU starts `stagger_ticks` (100 MHz
+  // ticks) late, so that one workgroup's epilogue meets the other's K-loop instead of its epilogue; cu_slots = one arrival counter per
+  // (XCC, SE, SH, CU), monotonic (parity = arrival order)
+  unsigned* cu_slots;
+  int stagger_ticks;
 };
 
 // Split-K of the last round (gemm.hip: gemm_persist_kernel<..., SK = true>): launches whose tile count is no multiple of the CU count

@@ -43,6 +43,8 @@ int g_gemm_split_last = 0;   // split the K range of the last, partial round's t
                             // GGET_GEMM_SPLIT_LAST).  Off by default: on the C1 shapes the hand-over of the partial tiles costs more than the
                             // shorter last round returns (profiles/r03_gemm_varlen_shapes.txt); correct and tested (tests/test_gpu_ops.py)
 int g_gemm_variant = 0;   // measurement knob (gget_debug_set key 1): selects experimental kernel variants for in-process A/B timing
+int g_gemm_stagger_ticks = 0;   // MODE 2 launches (two workgroups per CU): start delay of a CU's second workgroup in 100 MHz ticks (gget_debug_set
+                                // key 5, env GGET_GEMM_STAGGER); 0 = both start together (round 3)
 
 namespace {
 
@@ -899,6 +901,27 @@ __global__ void __launch_bounds__(WM * WN * 64, MODE == 2 ? 4 : ((WM * WN) >= 8 
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (MODE == 2) {
+    // Anti-phase start of the two workgroups of a CU: launched together and given equal work they run in lockstep - both in their
+    // K-loops (sharing the matrix pipe), then both in their epilogues (matrix pipe idle) - and the second workgroup buys nothing.  The
+    // workgroup that arrives second on its CU (arrival counter keyed by the hardware CU id) waits about one tile's K-loop before it
+    // touches memory; from then on one workgroup's epilogue runs beside the other's K-loop.
+    if (g.stagger_ticks > 0) {
+      if (tid == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg(((8 - 1) << 11) | (8 << 6) | 4);     // HW_REG_HW_ID[15:8] = {SE, SH, CU}
+        const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID
+        *reinterpret_cast<volatile unsigned*>(smem) = atomicAdd(g.cu_slots + ((xcc & 7u) << 8) + (hw & 255u), 1u) & 1u;
+      }
+      __syncthreads();
+      const unsigned second = *reinterpret_cast<volatile unsigned*>(smem);
+      __syncthreads();   // (the word is read before the first DMA piece may land on it)
+      if (second) {
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (long long)g.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+      }
+    }
+  }
+
   Ctx ic, cc;
   int ir = 0, ik = 0, cr = 0, ck = 0;
   bool ivalid = tile_at(0, ic);
@@ -1217,6 +1240,228 @@ __global__ void __launch_bounds__(512, 2) gemm_ks_kernel(const GemmGroup g, int 
   }
 }
 
+// ---- the same in-block K split on v_mfma_f32_32x32x16_bf16 (round 4; weight gradients: both operands M/N-contiguous) -----------------
+// A wave owns (BM/2) x (BN/2) of the block tile as 32x32 accumulator blocks (192x192: 3 x 3 blocks = 144 accumulator registers) and the
+// two 16-deep k-steps [32 wk, 32 wk + 32) of every 64-deep K-tile: per k-step 3 + 3 fragments (two transposing LDS reads each - the
+// window rotation of TileIO<192, MC> is conflict-free for this lane pattern as well: the 32 lanes of an LDS cycle read 2 windows x 4
+// k-rows, (4 kr + window + rotation) mod 8 all distinct) feed 9 MFMAs of 32 cycles - the same LDS bytes per FLOP as the 16x16x32 form,
+// half the matrix instructions, and the 32x32 shape issues back to back at the pipe's full rate (32 cycles for 32 K FLOP; 16x16x32
+// measures ~17 for 16 K).  MEASURED (profiles/r04_step_experiments.txt item 1): same bits out, 15 % slower launch - kept as an
+// experiment behind g_gemm_variant bit 6, not the default.  Fragment of block `sb` (32 rows), k-step `ks` (of the K-tile): lane l holds row l % 32, k = 8 (l / 32) .. + 7.
+template <int ROWS>
+__device__ __forceinline__ bf16x8_t frag32_mc(const unsigned char* lds, int sb, int ks, int lane) {
+  using T = TileIO<ROWS, true, 512, 64>;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int w = sb * 2 + (g & 1);
+  const int kr0 = ks * 16 + (g >> 1) * 8 + (l15 >> 2), kr1 = kr0 + 4;
+  const int inw = (l15 & 3) * 8;
+  const unsigned char* p0 = lds + kr0 * T::ROWB + (T::mc_lds_win(kr0, w) << 5) + inw;
+  const unsigned char* p1 = lds + kr1 * T::ROWB + (T::mc_lds_win(kr1, w) << 5) + inw;
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(p0));
+  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(p1));
+  bf16x8_t out;
+  out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; out[3] = lo[3];
+  out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
+  return out;
+}
+// bf16 store of one 32x32 accumulator block (operands swapped: lane l holds row m = l % 32 and, in register quad q, the columns
+// 8 q + 4 (l / 32) .. + 3): v_permlane32_swap between the two lanes of a row pairs the quads so that every lane owns 8 consecutive
+// columns (16 bytes) of two 16-column groups
+__device__ __forceinline__ void store32_block(const f32x16_t& a, bf16_t* C, int ldc, int M, int N, int mrow, int ncol, int lane) {
+  const int m = mrow + (lane & 31);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[8 * p + e]), __float_as_uint(a[8 * p + 4 + e]), false, false);
+      v[e] = __uint_as_float(r[0]);
+      v[4 + e] = __uint_as_float(r[1]);
+    }
+    const int n = ncol + 16 * p + 8 * (lane >> 5);
+    if (m < M && n + 8 <= N) stc16(C + (size_t)m * ldc + n, pack8(v));
+    else if (m < M && n < N) {
+      const uint4 pk = pack8(v);
+      *reinterpret_cast<uint2*>(C + (size_t)m * ldc + n) = make_uint2(pk.x, pk.y);   // (N % 8 == 4: the first half of the chunk)
+    }
+  }
+}
+template <int BM, int BN, int NSLOT_ = 0>
+__global__ void __launch_bounds__(512, 2) gemm_ks32_kernel(const GemmGroup g, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BK = 64, NT = 512;
+  using TA = TileIO<BM, true, NT, BK>;
+  using TB = TileIO<BN, true, NT, BK>;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int NSLOT = NSLOT_ > 0 ? NSLOT_ : persist_slots(STAGE);
+  constexpr int PIECES = TA::PIECES + TB::PIECES;
+  constexpr int MI = BM / 2 / 32, NJ = BN / 2 / 32, H0 = (MI + 1) / 2, H1 = MI - H0;
+  static_assert(BM % 64 == 0 && BN % 64 == 0 && H1 >= 1, "wave tile = whole 32x32 blocks, at least two row blocks");
+  static_assert(!TA::WRAP && !TB::WRAP, "piece lists");
+  // accumulator exchange: the wk = 1 waves hand over H0 row blocks, the wk = 0 waves H1 (float4 units of 1 KiB per wave)
+  constexpr int SEND1 = H0 * NJ * 4, SEND0 = H1 * NJ * 4;
+  static_assert(4 * (SEND0 + SEND1) * 1024 <= NSLOT * STAGE, "accumulator exchange fits in the ring");
+
+  const int G = gridDim.x;
+  const int tile = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);   // XCD-contiguous
+  if (tile >= total_tiles) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GGET_MAX_GROUP; ++i)
+    if (i < g.count && tile >= g.p[i].tile_begin) pi = i;
+  const GemmProblem& P = g.p[pi];
+  int m0, n0;
+  tile_origin(P, P.M, tile - P.tile_begin, BM, BN, g.super, m0, n0);
+  const int nk = P.K >> 6;
+
+  f32x16_t acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(LDS_AS const void*)smem) + (unsigned)wave * 1024u;
+  const unsigned char* kA = reinterpret_cast<const unsigned char*>(P.A);
+  const unsigned char* kB = reinterpret_cast<const unsigned char*>(P.B);
+  const long strideA = (long)BK * P.lda * 2, strideB = (long)BK * P.ldb * 2;
+  unsigned offA[TA::PIECES], offB[TB::PIECES];
+#pragma unroll
+  for (int i = 0; i < TA::PIECES; ++i) offA[i] = TA::piece_off(P.lda, m0, P.M, wave, lane, i);
+#pragma unroll
+  for (int i = 0; i < TB::PIECES; ++i) offB[i] = TB::piece_off(P.ldb, n0, P.N, wave, lane, i);
+  int islot = 0, cslot = 0, issued = 0;
+  unsigned islot_off = lds0;
+  auto issue_piece = [&](int q) {
+    if (q < TA::PIECES) glds16m(kA, offA[q < TA::PIECES ? q : 0], islot_off + (unsigned)(q * TA::NWAVES * 1024));
+    else glds16m(kB, offB[q >= TA::PIECES ? q - TA::PIECES : 0], islot_off + (unsigned)(A_BYTES + (q - TA::PIECES) * TB::NWAVES * 1024));
+  };
+  auto issue_advance = [&]() {
+    islot = islot == NSLOT - 1 ? 0 : islot + 1;
+    islot_off = islot == 0 ? lds0 : islot_off + (unsigned)STAGE;
+    kA += strideA;
+    kB += strideB;
+    ++issued;
+  };
+#pragma unroll
+  for (int i = 0; i < NSLOT - 1; ++i) {
+    if (issued < nk) {
+#pragma unroll
+      for (int q = 0; q < PIECES; ++q) issue_piece(q);
+      issue_advance();
+    }
+  }
+  for (int t = 0; t < nk; ++t) {
+    if (issued - t == NSLOT - 1) vm_wait<(NSLOT - 2) * PIECES>();
+    else vm_wait<0>();
+    __syncthreads();
+    const bool did = issued < nk;
+    const unsigned char* a_l = smem + cslot * STAGE;
+    const unsigned char* b_l = a_l + A_BYTES;
+    bf16x8_t af[2][MI], bf[2][NJ];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[s][i] = frag32_mc<BM>(a_l, wm * MI + i, wk * 2 + s, lane);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[s][j] = frag32_mc<BN>(b_l, wn * NJ + j, wk * 2 + s, lane);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
+        if (did) {
+          constexpr int NG = 2 * MI;
+          const int grp = s * MI + i;
+#pragma unroll
+          for (int q = grp * PIECES / NG; q < (grp + 1) * PIECES / NG; ++q) issue_piece(q);
+        }
+      }
+    if (did) issue_advance();
+    cslot = cslot == NSLOT - 1 ? 0 : cslot + 1;
+  }
+  // ---- add the two K halves: wave (wk = 0) keeps row blocks [0, H0), its partner (wave ^ 4) the blocks [H0, MI)
+  __syncthreads();
+  float4* xch = reinterpret_cast<float4*>(smem);
+  // 1 KiB units: the wk = 1 waves' sends first (SEND1 units each), then the wk = 0 waves' (SEND0 each)
+  auto unit_of = [&](int w, int u) { return (w >= 4 ? (w - 4) * SEND1 : 4 * SEND1 + w * SEND0) + u; };
+  if (wk == 0) {
+#pragma unroll
+    for (int ii = 0; ii < H1; ++ii)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x16_t& v = acc[H0 + ii][j];
+          xch[(size_t)unit_of(wave, (ii * NJ + j) * 4 + q) * 64 + lane] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
+  } else {
+#pragma unroll
+    for (int ii = 0; ii < H0; ++ii)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x16_t& v = acc[ii][j];
+          xch[(size_t)unit_of(wave, (ii * NJ + j) * 4 + q) * 64 + lane] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
+  }
+  __syncthreads();
+  const int partner = wave ^ 4;
+  bf16_t* C = reinterpret_cast<bf16_t*>(P.C);
+  const int Nst = (P.N + 3) & ~3;
+  if (wk == 0) {
+#pragma unroll
+    for (int ii = 0; ii < H0; ++ii)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        f32x16_t own = acc[ii][j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 o = xch[(size_t)unit_of(partner, (ii * NJ + j) * 4 + q) * 64 + lane];
+          own[4 * q] += o.x; own[4 * q + 1] += o.y; own[4 * q + 2] += o.z; own[4 * q + 3] += o.w;
+        }
+        store32_block(own, C, P.ldc, P.M, Nst, m0 + wm * (MI * 32) + ii * 32, n0 + wn * (NJ * 32) + j * 32, lane);
+      }
+  } else {
+#pragma unroll
+    for (int ii = 0; ii < H1; ++ii)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        f32x16_t own = acc[H0 + ii][j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 o = xch[(size_t)unit_of(partner, (ii * NJ + j) * 4 + q) * 64 + lane];
+          own[4 * q] += o.x; own[4 * q + 1] += o.y; own[4 * q + 2] += o.z; own[4 * q + 3] += o.w;
+        }
+        store32_block(own, C, P.ldc, P.M, Nst, m0 + wm * (MI * 32) + (H0 + ii) * 32, n0 + wn * (NJ * 32) + j * 32, lane);
+      }
+  }
+}
+
+template <int BM, int BN, int NSLOT_ = 0>
+int launch_ks32_cfg(GemmGroup& g, int total, hipStream_t st) {
+  constexpr int STG = (BM + BN) * 64 * 2;
+  constexpr int SM = (NSLOT_ > 0 ? NSLOT_ : persist_slots(STG)) * STG;
+  const int G = (total + 7) & ~7;
+  static bool attr0 = false;
+  if (!attr0) {
+    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ks32_kernel<BM, BN, NSLOT_>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SM));
+    attr0 = true;
+  }
+  hipLaunchKernelGGL((gemm_ks32_kernel<BM, BN, NSLOT_>), dim3(G), dim3(512), SM, st, g, total);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int BM, int BN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0>
 int launch_ks_cfg(GemmGroup& g, int total, hipStream_t st) {
   constexpr int STG = (BM + BN) * 64 * 2;
@@ -1241,6 +1486,15 @@ int launch_persist_cfg(GemmGroup& g, int total, int num_cu, hipStream_t st) {
   if (MODE == 2) num_cu *= 2;
   static_assert(SM <= 160 * 1024, "LDS ring");
   static_assert(!SK || (size_t)BM * BN * 4 <= kStreamKSlotBytes, "stream-K slot");
+  if constexpr (MODE == 2) {
+    static unsigned* cu_slots = nullptr;   // 8 XCC x 256 hardware CU ids, zeroed once (the counters only ever count up)
+    if (!cu_slots && g_gemm_stagger_ticks > 0) {
+      GGET_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&cu_slots), 2048 * sizeof(unsigned)));
+      GGET_HIP_CHECK(hipMemset(cu_slots, 0, 2048 * sizeof(unsigned)));
+    }
+    g.cu_slots = cu_slots;
+    g.stagger_ticks = cu_slots ? g_gemm_stagger_ticks : 0;
+  }
   int G = total < num_cu && !SK ? total : num_cu;
   G = (G + 7) & ~7;  // the XCD permutation needs a multiple of 8 (idle blocks exit at once)
   static bool attr0 = false;
@@ -1433,6 +1687,9 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
         if (tot4 <= num_cu && !(g_gemm_variant & 2)) {
           bool ks = true;
           for (int i = 0; i < g.count; ++i) ks = ks && !g.p[i].m_dev && !g.p[i].k_dev;
+          // g_gemm_variant bit 6: the 32x32x16 MFMA form (gemm_ks32_kernel, round 4) - bit-identical results, measured SLOWER in the step
+          // (7.285 against 7.119 ms, same box, alternated: profiles/r04_step_experiments.txt item 1), so the 16x16x32 form stays the default
+          if (ks && (g_gemm_variant & 64)) return launch_ks32_cfg<192, 192>(g, tot4, st);
           if (ks) return launch_ks_cfg<192, 192, true, true, EPI>(g, tot4, st);
         }
         return launch_persist_cfg<192, 192, 64, 4, 2, true, true, EPI>(g, tot4, num_cu, st);
@@ -1561,6 +1818,7 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
   GGET_REQUIRE(g.count >= 1 && g.count <= GGET_MAX_GROUP, "gemm: bad group size %d", g.count);
   g.sk_partial = nullptr; g.sk_flags = nullptr; g.sk_epoch = 0;
   g.sk_rounds = g.sk_rem = g.sk_a = 0; g.sk_parts = 1;
+  g.cu_slots = nullptr; g.stagger_ticks = 0;
   static int ablate = -1;
   if (ablate < 0) {
     const char* e = getenv("GGET_GEMM_ABLATE");
@@ -1568,6 +1826,7 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
     if (const char* v = getenv("GGET_GEMM_VARIANT")) g_gemm_variant = atoi(v);
     if (const char* v = getenv("GGET_GEMM_LDS_HEADROOM")) g_gemm_lds_headroom = atoi(v);
     if (const char* v = getenv("GGET_GEMM_SPLIT_LAST")) g_gemm_split_last = atoi(v);   // same knob as gget_debug_set(1, .), for whole-step A/B
+    if (const char* v = getenv("GGET_GEMM_STAGGER")) g_gemm_stagger_ticks = atoi(v);
   }
   g.ablate = ablate;
   static int super = -1;

@@ -351,3 +351,11 @@ class Engine:
         off = p.value - self.workspace.data_ptr()
         d = self.spec.hidden_size
         return self.workspace[off: off + B * S * d * 2].view(torch.bfloat16).view(B, S, d).clone()
+
+    def layer_hidden_states(self, layer: int, B: int, S: int) -> torch.Tensor:
+        """bf16 [B,S,d] residual stream entering decoder layer `layer` (num_layers = leaving the last one) of the last forward (a copy)."""
+        p = C.c_void_p()
+        L.check(self.lib.gget_layer_hidden_states(self.h, int(layer), C.byref(p)))
+        off = p.value - self.workspace.data_ptr()
+        d = self.spec.hidden_size
+        return self.workspace[off: off + B * S * d * 2].view(torch.bfloat16).view(B, S, d).clone()

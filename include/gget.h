@@ -278,6 +278,10 @@ int gget_head_counts(gget_handle_t h, int32_t counts[2], void* stream);
 int gget_head_logits(gget_handle_t h, const void** logits_dev, int32_t* ld);
 /* final hidden states bf16 [B*S][d] of the last forward (outputs[0] of the backbone) */
 int gget_hidden_states(gget_handle_t h, const void** hidden_dev);
+/* residual stream bf16 [B*S][d] ENTERING decoder layer `layer` (layer = num_layers: leaving the last layer, before the final norm) of
+ * the last forward.  replaces: `output_hidden_states=True` of the reference's backbone (hf LlamaModel.forward modeling_llama.py
+ * :401-414 collects exactly these tensors); used by the per-layer error budget of tests/test_error_budget.py.  Padded layout only. */
+int gget_layer_hidden_states(gget_handle_t h, int layer, const void** hidden_dev);
 
 /* ------------------------------------------------------------------------------------------
  * Operator-level entry points (the individual HIP kernels), used by the parity tests and by

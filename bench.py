@@ -181,6 +181,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="pcqm4m-v2-pretrain-base", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batches", type=int, default=4,
+                    help="distinct synthetic batches the steps rotate through (pre-train workloads; every batch has its own lengths, so the "
+                         "var-len row count - and with it the launch shapes - changes from step to step like in a real epoch; 1 = the "
+                         "single repeated batch of rounds 1-3)")
     ap.add_argument("--layout", default="varlen", choices=["varlen", "varlen-count", "padded"],
                     help="token layout of the timed steps.  varlen (default): the call of the reference's own step - device-resident "
                          "tensors, no token count passed - the engine counts the mask on the device and runs the padding-free layout; "
@@ -227,9 +231,11 @@ def main():
     model._ensure_engine(B, S)
     engine = training.initialize(model, training.OptimConfig(lr=3e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1,
                                                              max_grad_norm=1.0))
+    extra_batches = []
     if kind == "pt":
         batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=1234 + rank)     # distinct data per rank
         real_tokens = synth.real_tokens(batch)
+        extra_batches = [synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=1234 + rank + 1000 * i) for i in range(1, max(1, a.batches))]
     elif kind == "pt-packed":
         batch = synth.make_packed_pretrain_batch(B=B, S=S, F=F, V=V, seed=1234 + rank, mean_len=22, min_len=6)
         real_tokens = int(batch["lengths"].sum())
@@ -238,6 +244,11 @@ def main():
                                       min_len=S // 4)
         real_tokens = synth.real_tokens(batch)
     dev = {k: torch.from_numpy(v).cuda() for k, v in batch.items() if k not in ("lengths", "segments")}
+    # the rotation: batch 0 (seed 1234 + rank: the batch of the probes, the parity leg and the CPU baseline) and the extra ones
+    host_batches = [batch] + extra_batches
+    devs = [dev] + [{k: torch.from_numpy(v).cuda() for k, v in b_.items() if k not in ("lengths", "segments")} for b_ in extra_batches]
+    reals = [int(real_tokens)] + [int(synth.real_tokens(b_)) for b_ in extra_batches]
+    nb = len(devs)
     # Token layout of the step.  "varlen" (default): the batch carries its real-token count (a host int the collator knows:
     # sum(attention_mask)), and the engine runs embedding, layer stack and backward on the compacted real tokens instead of the padded
     # [B,S] grid (include/gget.h: gget_set_token_count) - same batch, same loss, same gradients.  "padded": every row of the grid,
@@ -245,9 +256,10 @@ def main():
     layout = a.layout if kind != "pt-packed" else "padded"
 
     def make_step(lay):
-        data = dict(dev, num_tokens=int(real_tokens)) if lay == "varlen-count" else dev
+        datas = [dict(d_, num_tokens=r_) if lay == "varlen-count" else d_ for d_, r_ in zip(devs, reals)]
 
-        def one():
+        def one(i=0):
+            data = datas[i % nb]
             if lay == "padded":
                 os.environ["GGET_VARLEN"] = "0"
             try:
@@ -267,15 +279,15 @@ def main():
             gpu_eval_loss = float(model(input_ids=dev["input_ids"], attention_mask=dev["attention_mask"], labels=dev["labels"]).head1_loss)
         model.train()
 
-    for _ in range(a.warmup):
-        loss = step()
+    for i in range(a.warmup):
+        loss = step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
+    for i in range(a.steps):
+        loss = step(a.warmup + i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -289,30 +301,38 @@ def main():
             if lay in layouts:
                 continue
             other = make_step(lay)
-            for _ in range(2):
-                other()
+            for i in range(2):
+                other(a.warmup - 2 + i)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(a.steps):
-                other()
+            for i in range(a.steps):
+                other(a.warmup + i)      # (the same rotation as the reported steps)
             torch.cuda.synchronize()
             layouts[lay] = (time.perf_counter() - t1) / a.steps * 1e3
-        step()     # (the probes below run on the reported layout again)
+        step(0)     # (the probes below run on the reported layout again, on batch 0)
         torch.cuda.synchronize()
     # N > 1: how much of the step is gradient exchange the backward does not hide - the same K steps once more (outside the reported
     # time) with the collectives switched off (GgetEngine.exchange = False: identical kernels on the compute stream, nothing on the
     # side stream), max over ranks; exposed = reported step - that.  The replicas drift apart in these steps: they come last.
     dp_info = None
+    replicas_identical = None
     if world > 1:
+        # replicas must still be bit-identical after the timed steps (same init, averaged gradients, same update on every rank): a
+        # 64-bit checksum of the fp32 master weights, min- and max-reduced over the ranks
+        chk = model._engine.master.view(torch.int32).to(torch.int64).sum().reshape(1)
+        lo_, hi_ = chk.clone(), chk.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(int(lo_[0]) == int(hi_[0]))
         engine.exchange = False
-        for _ in range(2):
-            step()
+        for i in range(2):
+            step(a.warmup - 2 + i)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(a.steps):
-            step()
+        for i in range(a.steps):
+            step(a.warmup + i)       # (the same rotation as the reported steps)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -321,6 +341,7 @@ def main():
         engine.exchange = True
         dp_info = engine.describe_dp()
         dp_info["ms_per_step_without_exchange"] = float(dt_nox[0]) / a.steps * 1e3
+        dp_info["replicas_bit_identical"] = replicas_identical
     # the dominant kernels' launch durations INSIDE a step: three more (untimed) steps with HIP events around those launches, on the
     # stream they run on (single process only - the extra steps would otherwise need every rank)
     in_step = {}
@@ -350,7 +371,9 @@ def main():
                          "frac_of_peak_time_weighted": fl_.value / (ms_.value * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                          "flops_per_step": fl_.value / 3,
                          "note": "executed rows (var-len layout: real tokens); HIP events around every launch, untimed extra steps"}
-    stats = torch.tensor([dt, float(real_tokens), float(loss.item())], dtype=torch.float64, device="cuda")
+    timed = [(a.warmup + i) % nb for i in range(a.steps)]        # batch index of every timed step
+    real_per_step = sum(reals[j] for j in timed) / a.steps           # real tokens of this rank per timed step (mean over the rotation)
+    stats = torch.tensor([dt, float(real_per_step), float(loss.item())], dtype=torch.float64, device="cuda")
     if world > 1:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -358,14 +381,29 @@ def main():
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt, tot_real, mean_loss = float(mx[0]), float(sm[1]), float(sm[2]) / world
     else:
-        tot_real, mean_loss = float(real_tokens), float(loss.item())
+        tot_real, mean_loss = float(real_per_step), float(loss.item())
 
     if rank == 0:
-        M, Lm = model._engine.head_counts() if pt else (0, 0)
+        M, Lm = model._engine.head_counts() if pt else (0, 0)       # (batch 0: the last forward was a probe step)
         ran_varlen, t_rows, mismatch = model._engine.varlen_status()
         assert not mismatch, "the batch's real-token count handed to the engine disagrees with its attention mask"
-        fstep = flops_per_step(spec, B, S, M, Lm, kind)                    # the reference's computation, padded grid
-        fexec = flops_per_step(spec, B, S, M, Lm, kind, rows=t_rows, lengths=batch.get("lengths") if ran_varlen else None)
+        if kind == "pt":
+            lab0 = host_batches[0]["labels"] != -100
+            assert (M, Lm) == (int(lab0.any(-1).sum()), int(lab0.sum())), "head counts of batch 0 differ from its labels"
+
+        def batch_flops(j, executed):
+            """FLOPs of one step on batch j (M / Lm from its labels; executed: the var-len rows and len x len attention blocks)"""
+            b_ = host_batches[j]
+            if kind == "pt":
+                lab = b_["labels"] != -100
+                m_, lm_ = int(lab.any(-1).sum()), int(lab.sum())
+            else:
+                m_, lm_ = M, Lm
+            if not executed or not ran_varlen:
+                return flops_per_step(spec, B, S, m_, lm_, kind)
+            return flops_per_step(spec, B, S, m_, lm_, kind, rows=(reals[j] + 63) // 64 * 64, lengths=b_.get("lengths"))
+        fstep = sum(batch_flops(j, False) for j in timed) / a.steps      # SURVEY 8(d): the reference's computation, padded grid
+        fexec = sum(batch_flops(j, True) for j in timed) / a.steps       # what the engine executed (mean over the timed steps)
         ms = dt / a.steps * 1e3
         step_tflops = fstep / (ms * 1e-3) / 1e12
         kt = time_kernels(spec, t_rows)
@@ -396,7 +434,7 @@ def main():
                       + ("PCQM4M-v2 base pre-train" if a.workload == "pcqm4m-v2-pretrain-base" else a.workload),
             "value": tot_real * a.steps / dt, "unit": "graph-tokens/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "synthetic" + (f" ({nb} batches in rotation)" if nb > 1 else ""),
             "config": {"workload": a.workload, "model": f"{size} d{spec.hidden_size}/L{spec.num_layers}/H{spec.num_heads} "
                        f"({spec.num_params() / 1e6:.1f}M params)", "per_gpu_batch": B, "global_batch": B * world,
                        "seq_len": S, "stacked_feat": F, "vocab": V, "parallelism": f"dp{world}",
@@ -416,6 +454,7 @@ def main():
             "step_mfma": {"flops_per_step": fexec, "achieved_tflops_per_gpu": fexec / (ms * 1e-3) / 1e12,
                           "frac_of_peak": fexec / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                           "token_layout": "varlen" if ran_varlen else "padded", "rows": t_rows, "padded_rows": B * S,
+                          "rows_per_batch": [(r_ + 63) // 64 * 64 if ran_varlen else B * S for r_ in reals],
                           "reference_grid": {"flops_per_step": fstep, "equivalent_tflops_per_gpu": step_tflops,
                                              "equivalent_frac_of_peak": step_tflops / PEAK_BF16_TFLOPS}},
             "roofline": roofline,

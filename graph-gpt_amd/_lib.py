@@ -58,6 +58,8 @@ SIGNATURES = {
     "gget_comm_destroy": (i32, [vp]),
     "gget_comm_move": (i32, [vp, vp]),
     "gget_allreduce_grads_async": (i32, [vp, i32, i32, vp]),
+    "gget_allreduce_range_async": (i32, [vp, u64, u64, i32, vp]),
+    "gget_comm_init_loopback": (i32, [vp, i32]),
     "gget_head_counts": (i32, [vp, C.POINTER(i32 * 2), vp]),
     "gget_head_logits": (i32, [vp, C.POINTER(vp), C.POINTER(i32)]),
     "gget_hidden_states": (i32, [vp, C.POINTER(vp)]),
@@ -87,6 +89,7 @@ SIGNATURES = {
     "gget_set_dropout": (i32, [vp, f32, f32, C.c_uint32]),
     "gget_set_auc": (i32, [vp, i32, C.c_uint32]),
     "gget_set_token_count": (i32, [vp, C.c_int64]),
+    "gget_set_option": (i32, [vp, i32, i32]),
     "gget_varlen_status": (i32, [vp, vp, vp]),
     "gget_position_status": (i32, [vp, vp, vp]),
     "gget_deferred_status": (i32, [vp, vp, vp]),
@@ -105,6 +108,7 @@ SIGNATURES = {
 }
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+OPT_NORM_FROM_BACKWARD = 1   # gget_set_option
 TOKENS_AUTO = -2   # gget_set_token_count: count the real tokens on the device (include/gget.h GGET_TOKENS_AUTO)
 EPI_NONE, EPI_RESIDUAL, EPI_ATOMIC_F32, EPI_SLAB_F32 = 0, 1, 2, 3
 

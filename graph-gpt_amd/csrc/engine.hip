@@ -36,6 +36,7 @@ namespace {
 
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 constexpr int kWgSplit = 3;    // K slices of the attention-projection wgrad (72 output tiles -> 216 blocks)
+constexpr int kSqTilesPerLayer = 256;   // tiles of a layer's grouped weight-gradient launch that may leave norm partials (one per CU)
 constexpr int kLmSplit = 16;   // K slices of the lm_head wgrad at most (few output tiles, K = Lm ~ 4e4); see fit_split
 // K slices of a split-K launch whose output has only `tiles` tiles: as many as asked for, but tiles x slices must fit in ONE round of
 // the CUs (one 96-144 KiB block per CU) - 18 tiles x 16 slices = 288 blocks ran a second round for 32 of them (lm_head weight
@@ -189,6 +190,7 @@ struct Ws {
   uint64_t rstd_f, hidden;
   uint64_t dxa, dxb, dxc, dxn, dqkv, dattn, dgu, dh, delta, dscaled, dscaled2;
   uint64_t scratch32, loss_sum, sqnorm, counts, segs, emb_sort, emb_cnt, emb_slab, wg32, lm_slab;
+  uint64_t sq_chunks, sq_tiles;   // gradient-norm shortcut: chunk table of everything but the layers' weight matrices; per-tile sums of those
   // pre-train head
   uint64_t cnt, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
   // task head
@@ -251,6 +253,8 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.scratch32 = b.take(pl.n_scratch32 * 4);
   w.loss_sum = b.take(256);
   w.sqnorm = b.take(k_grad_sqnorm_ws_bytes());
+  w.sq_chunks = b.take(1024 * sizeof(GgetSqChunk));
+  w.sq_tiles = b.take((uint64_t)c.num_layers * kSqTilesPerLayer * sizeof(float));
   w.counts = b.take(256);
   w.segs = b.take((uint64_t)pl.params.size() * sizeof(GgetSegment));
   w.wg32 = b.take(kWgSplit * 4 * d * d * 4);   // split-K slabs of the q|k|v|o wgrad
@@ -360,6 +364,11 @@ struct gget_engine {
   int tc = 0;                     // its number of real tokens
   long tc_next = -1;              // real-token count of the NEXT forward's batch (gget_set_token_count); -1 = unknown -> padded layout,
                                   // GGET_TOKENS_AUTO = count on the device and read back; consumed (reset) at the ENTRY of every forward
+  // gget_set_option(GGET_OPT_NORM_FROM_BACKWARD): the squared gradient norm of the layers' weight matrices comes from partial sums
+  // their weight-gradient launches left behind (sq_layers = layers of the last backward that did), the rest from a chunked pass
+  bool opt_norm_from_backward = false;
+  int sq_layers = 0;
+  int n_sq_chunks = 0;
   bool tc_from_caller = false;    // the last var-len forward ran on a caller's count (a wrong one poisons the loss, see poison_loss)
   int32_t* host_word = nullptr;   // pinned host word the counted total lands in
   const int64_t* pos_rows = nullptr;   // position of every ROW (GEMM RoPE epilogue): pos_cur, or the compacted positions
@@ -414,6 +423,7 @@ struct gget_engine {
   bool defer_convert = false;
   // data-parallel exchange (gget_comm_*): RCCL communicator of this rank and an fp32 staging buffer for the largest bucket
   void* comm = nullptr;
+  bool comm_loopback = false;     // gget_comm_init_loopback: no peers, an all-reduce multiplies by comm_world
   int comm_rank = 0, comm_world = 1;
   float* comm_f32 = nullptr;
   uint64_t comm_f32_elems = 0;
@@ -508,6 +518,32 @@ extern "C" int gget_create(const gget_config_t* cfg, const gget_buffers_t* bufs,
       gget_set_error("segment table upload failed: %s", hipGetErrorString(e));
       delete h;
       return 1;
+    }
+  }
+  {
+    // chunk table of every gradient that is NOT one of the layers' seven projection matrices (those carry per-tile partial sums)
+    uint64_t other = 0;
+    auto is_layer_matrix = [&](const ParamRec& p) { return p.layer >= 0 && p.layer < L && !p.accum32 && p.ndim == 2; };
+    for (const ParamRec& p : h->plan.params)
+      if (!is_layer_matrix(p)) other += align_up(p.count, 128);
+    const uint64_t chunk = std::max<uint64_t>(32768, align_up((other + 899) / 900, 128));
+    std::vector<GgetSqChunk> chunks;
+    for (const ParamRec& p : h->plan.params) {
+      if (is_layer_matrix(p)) continue;
+      const uint64_t n = align_up(p.count, 128);
+      for (uint64_t o = 0; o < n; o += chunk) chunks.push_back(GgetSqChunk{p.off + o, std::min(chunk, n - o)});
+    }
+    if (h->plan.lm_pad_count) chunks.push_back(GgetSqChunk{h->plan.lm_pad_off, align_up(h->plan.lm_pad_count, 128)});   // (zeros; kept for symmetry with the full pass)
+    if (chunks.size() <= 1024) {
+      h->n_sq_chunks = (int)chunks.size();
+      if (!chunks.empty() &&
+          hipMemcpy(h->W + h->ws.sq_chunks, chunks.data(), chunks.size() * sizeof(GgetSqChunk), hipMemcpyHostToDevice) != hipSuccess) {
+        gget_set_error("norm chunk table upload failed");
+        delete h;
+        return 1;
+      }
+    } else {
+      h->n_sq_chunks = -1;   // (never with the chunk size above; the full pass is used then)
     }
   }
   if (bufs->rope_cos_dev && bufs->rope_sin_dev) {
@@ -612,6 +648,15 @@ extern "C" int gget_set_token_count(gget_handle_t h, int64_t n_real_tokens) {
   GGET_REQUIRE(h != nullptr, "null handle");
   h->tc_next = n_real_tokens > 0 ? (long)n_real_tokens : (n_real_tokens == GGET_TOKENS_AUTO ? (long)GGET_TOKENS_AUTO : -1);
   return 0;
+}
+
+extern "C" int gget_set_option(gget_handle_t h, int option, int value) {
+  GGET_REQUIRE(h != nullptr, "null handle");
+  switch (option) {
+    case GGET_OPT_NORM_FROM_BACKWARD: h->opt_norm_from_backward = value != 0; return 0;
+  }
+  gget_set_error("set_option: unknown option %d", option);
+  return 2;
 }
 
 extern "C" int gget_deferred_status(gget_handle_t h, int32_t out[2], void* stream) {
@@ -1430,9 +1475,16 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
     g.p[1] = wg_dn;
     g.p[2] = GemmProblem{dqkv, h->wsp<bf16_t>(lw.xn1), h->G + lo.wqkv, nullptr, 3 * d, d, T, 3 * d, d, d, nullptr, nullptr, 0, 0};
     g.p[3] = GemmProblem{dy_o, h->wsp<bf16_t>(lw.attn), h->G + lo.wo, nullptr, d, d, T, d, d, d, nullptr, nullptr, 0, 0};
+    const long wg_tiles = ((long)2 * ff * d + (long)d * ff + (long)4 * d * d) / (192 * 192);
+    g.sq_partials = h->opt_norm_from_backward && wg_tiles <= kSqTilesPerLayer ? h->wsp<float>(w.sq_tiles) + (size_t)i * kSqTilesPerLayer : nullptr;
     if (h->probe) GGET_HIP_CHECK(hipEventRecord(h->probe_event(0, 2 * i), st));
     if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_NONE, g, 1, st)) return e;
     if (h->probe) GGET_HIP_CHECK(hipEventRecord(h->probe_event(0, 2 * i + 1), st));
+    if (g.sq_written) {
+      if (wg_tiles < kSqTilesPerLayer)   // (slots no tile writes must read as zero)
+        GGET_HIP_CHECK(hipMemsetAsync(h->wsp<float>(w.sq_tiles) + (size_t)i * kSqTilesPerLayer + wg_tiles, 0, (kSqTilesPerLayer - wg_tiles) * sizeof(float), st));
+      ++h->sq_layers;
+    }
   } else {
     {
       GemmGroup g;
@@ -1474,6 +1526,7 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
   GGET_REQUIRE(h, "null handle");
   GGET_REQUIRE(h->fwd_valid && h->have_labels, "backward needs a preceding forward with labels");
   GGET_REQUIRE(loss_scale == 1.0f, "loss scaling is not used on the bf16 path (pass 1.0)");
+  h->sq_layers = 0;
   StreamKScope sk_scope(h);
   hipStream_t st = (hipStream_t)stream;
   const gget_config_t& c = h->cfg;
@@ -1669,8 +1722,15 @@ extern "C" int gget_adamw_step(gget_handle_t h, float lr, float beta1, float bet
   hipStream_t st = (hipStream_t)stream;
   float* sq = h->wsp<float>(h->ws.sqnorm);
   const bool need_norm = max_grad_norm > 0.f || gnorm_dev != nullptr;
-  if (need_norm)
-    if (int e = k_grad_sqnorm(h->G, h->plan.n_params, sq, st)) return e;
+  if (need_norm) {
+    // the shortcut holds only while the gradient array is exactly what the last backward wrote: the caller promised that
+    // (GGET_OPT_NORM_FROM_BACKWARD), grad_scale != 1 means an exchange happened anyway, and every layer must have left its partials
+    if (h->opt_norm_from_backward && grad_scale == 1.0f && h->sq_layers == h->cfg.num_layers && h->n_sq_chunks >= 0) {
+      if (int e = k_grad_sqnorm_chunks(h->G, h->wsp<GgetSqChunk>(h->ws.sq_chunks), h->n_sq_chunks, h->wsp<float>(h->ws.sq_tiles),
+                                       h->cfg.num_layers * kSqTilesPerLayer, sq, st))
+        return e;
+    } else if (int e = k_grad_sqnorm(h->G, h->plan.n_params, sq, st)) return e;
+  }
   return k_adamw(h->master, h->am, h->av, h->G, h->P, h->plan.n_params, lr, beta1, beta2, eps, weight_decay, step,
                  max_grad_norm, grad_scale, need_norm ? sq : nullptr, gnorm_dev, st);
 }
@@ -2029,6 +2089,7 @@ extern "C" int gget_comm_destroy(gget_handle_t h) {
     h->comm_f32_elems = 0;
   }
   h->comm_world = 1;
+  h->comm_loopback = false;
   return 0;
 }
 
@@ -2036,9 +2097,11 @@ extern "C" int gget_comm_move(gget_handle_t dst, gget_handle_t src) {
   // A handle that is re-created with larger capacities (a bigger batch arrived) must keep exchanging gradients with the SAME
   // communicator: creating a new one is a collective, and only the ranks whose batch grew would enter it.
   GGET_REQUIRE(dst && src && dst != src, "comm_move: bad arguments");
-  GGET_REQUIRE(dst->comm == nullptr, "comm_move: the destination handle already has a communicator");
+  GGET_REQUIRE(dst->comm == nullptr && !dst->comm_loopback, "comm_move: the destination handle already has a communicator");
   GGET_REQUIRE(dst->plan.n_params == src->plan.n_params, "comm_move: the two handles hold different models");
   dst->comm = src->comm;
+  dst->comm_loopback = src->comm_loopback;
+  src->comm_loopback = false;
   dst->comm_rank = src->comm_rank;
   dst->comm_world = src->comm_world;
   dst->comm_f32 = src->comm_f32;
@@ -2050,14 +2113,34 @@ extern "C" int gget_comm_move(gget_handle_t dst, gget_handle_t src) {
   return 0;
 }
 
-extern "C" int gget_allreduce_grads_async(gget_handle_t h, int bucket, int fp32_accumulate, void* side_stream) {
-  GGET_REQUIRE(h && h->comm, "allreduce_grads: call gget_comm_init first");
-  GGET_REQUIRE(bucket >= -1 && bucket < (int)h->bucket_range.size(), "allreduce_grads: bucket %d out of range", bucket);
+__global__ void __launch_bounds__(256) scale_bf16_kernel(bf16_t* __restrict__ g, uint64_t n, float mul) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) g[i] = f2bf(bf2f(g[i]) * mul);
+}
+
+extern "C" int gget_comm_init_loopback(gget_handle_t h, int world) {
+  GGET_REQUIRE(h && world >= 1, "comm_init_loopback: bad arguments (world %d)", world);
+  GGET_REQUIRE(h->comm == nullptr && !h->comm_loopback, "comm_init_loopback: this handle already has a communicator");
+  h->comm_loopback = true;
+  h->comm_rank = 0;
+  h->comm_world = world;
+  if (world > 1 && g_gemm_lds_headroom < 2) g_gemm_lds_headroom = 2;   // (the launch menu of a data-parallel run, as gget_comm_init)
+  return 0;
+}
+
+extern "C" int gget_allreduce_range_async(gget_handle_t h, uint64_t offset, uint64_t count, int fp32_accumulate, void* side_stream) {
+  GGET_REQUIRE(h && (h->comm || h->comm_loopback), "allreduce_grads: call gget_comm_init first");
+  GGET_REQUIRE(offset <= h->plan.n_params && count <= h->plan.n_params - offset, "allreduce_range: [%llu, +%llu) leaves the gradient array",
+               (unsigned long long)offset, (unsigned long long)count);
+  if (count == 0) return 0;
   hipStream_t st = (hipStream_t)side_stream;
-  const uint64_t lo = bucket < 0 ? 0 : h->bucket_range[bucket].first;
-  const uint64_t hi = bucket < 0 ? h->plan.n_params : h->bucket_range[bucket].second;
-  bf16_t* g = h->G + lo;
-  const uint64_t n = hi - lo;
+  bf16_t* g = h->G + offset;
+  const uint64_t n = count;
+  if (h->comm_loopback) {   // world identical contributions: the sum is world x (exact in bf16 for a power of two)
+    const int grid = (int)std::min<uint64_t>(4096, (n + 255) / 256);
+    hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid), dim3(256), 0, st, g, n, (float)h->comm_world);
+    GGET_LAUNCH_CHECK();
+    return 0;
+  }
   ncclComm_t c = static_cast<ncclComm_t>(h->comm);
   if (!fp32_accumulate) {
     GGET_RCCL_CHECK(rccl()->AllReduce(g, g, n, ncclBfloat16, ncclSum, c, st));
@@ -2079,4 +2162,12 @@ extern "C" int gget_allreduce_grads_async(gget_handle_t h, int bucket, int fp32_
   GGET_LAUNCH_CHECK();
   GGET_RCCL_CHECK(rccl()->AllReduce(h->comm_f32, h->comm_f32, n, ncclFloat32, ncclSum, c, st));
   return k_f32_to_bf16(h->comm_f32, g, n, st);
+}
+
+extern "C" int gget_allreduce_grads_async(gget_handle_t h, int bucket, int fp32_accumulate, void* side_stream) {
+  GGET_REQUIRE(h && (h->comm || h->comm_loopback), "allreduce_grads: call gget_comm_init first");
+  GGET_REQUIRE(bucket >= -1 && bucket < (int)h->bucket_range.size(), "allreduce_grads: bucket %d out of range", bucket);
+  const uint64_t lo = bucket < 0 ? 0 : h->bucket_range[bucket].first;
+  const uint64_t hi = bucket < 0 ? h->plan.n_params : h->bucket_range[bucket].second;
+  return gget_allreduce_range_async(h, lo, hi - lo, fp32_accumulate, side_stream);
 }

@@ -50,6 +50,11 @@ struct GemmGroup {
   // (XCC, SE, SH, CU), monotonic (parity = arrival order)
   unsigned* cu_slots;
   int stagger_ticks;
+  // grouped weight gradients (TN, gemm_ks_kernel<192,192>): when set, tile t of the launch also leaves the sum of squares of the bf16
+  // values it stored in sq_partials[t] (the gradient-norm pass then skips these matrices: engine.hip gget_adamw_step); the launcher
+  // sets sq_written when the kernel that does so was the one launched
+  float* sq_partials;
+  int sq_written;
 };
 
 // Split-K of the last round (gemm.hip: gemm_persist_kernel<..., SK = true>): launches whose tile count is no multiple of the CU count

@@ -1215,6 +1215,14 @@ __global__ void __launch_bounds__(512, 2) gemm_ks_kernel(const GemmGroup g, int 
       }
   }
   __syncthreads();
+  // (weight gradients: the sum of squares of the stored bf16 values of this tile, for the gradient norm - see GemmGroup::sq_partials;
+  //  the tiles of these launches are whole - M, N multiples of the tile - so every accumulator is a stored value)
+  constexpr bool SQ = A_MC && B_MC && EPI == GGET_EPI_NONE;
+  float sq = 0.f;
+  auto sq_add = [&](const f32x4_t& v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float r = bf2f(f2bf(v[e])); sq = fmaf(r, r, sq); }
+  };
   if (wk == 0) {
     f32x4_t own[H0][NJ];
 #pragma unroll
@@ -1224,6 +1232,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ks_kernel(const GemmGroup g, int 
         const float4 o = xch[(size_t)(partner * HT + ii * NJ + j) * 64 + lane];
         const f32x4_t mine = acc[ii][j];
         own[ii][j] = f32x4_t{mine[0] + o.x, mine[1] + o.y, mine[2] + o.z, mine[3] + o.w};
+        if constexpr (SQ) sq_add(own[ii][j]);
       }
     store_tile<EPI, H0, NJ>(own, P, P.M, (P.N + 3) & ~3, m0 + wm * (MI * 16), n0 + wn * (NJ * 16), lane);
   } else {
@@ -1235,8 +1244,23 @@ __global__ void __launch_bounds__(512, 2) gemm_ks_kernel(const GemmGroup g, int 
         const float4 o = xch[(size_t)(partner * HT + ii * NJ + j) * 64 + lane];
         const f32x4_t mine = acc[H0 + ii][j];
         own[ii][j] = f32x4_t{mine[0] + o.x, mine[1] + o.y, mine[2] + o.z, mine[3] + o.w};
+        if constexpr (SQ) sq_add(own[ii][j]);
       }
     store_tile<EPI, H1, NJ>(own, P, P.M, (P.N + 3) & ~3, m0 + wm * (MI * 16) + H0 * 16, n0 + wn * (NJ * 16), lane);
+  }
+  if constexpr (SQ) {
+    if (g.sq_partials) {   // (uniform over the block; fixed reduction order: lanes by DPP, waves 0..7)
+      float* red = reinterpret_cast<float*>(smem + NSLOT * STAGE);   // 64 bytes behind the ring (launch_ks_cfg)
+      sq = wave_sum(sq);
+      if (lane == 0) red[wave] = sq;
+      __syncthreads();
+      if (tid == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += red[w];
+        g.sq_partials[tile] = t;
+      }
+    }
   }
 }
 
@@ -1465,7 +1489,8 @@ int launch_ks32_cfg(GemmGroup& g, int total, hipStream_t st) {
 template <int BM, int BN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0>
 int launch_ks_cfg(GemmGroup& g, int total, hipStream_t st) {
   constexpr int STG = (BM + BN) * 64 * 2;
-  constexpr int SM = (NSLOT_ > 0 ? NSLOT_ : persist_slots(STG)) * STG;
+  constexpr int SM = (NSLOT_ > 0 ? NSLOT_ : persist_slots(STG)) * STG + (A_MC && B_MC && EPI == GGET_EPI_NONE ? 64 : 0);   // (+ the norm partials' scratch)
+  static_assert(SM <= 160 * 1024, "LDS ring");
   const int G = (total + 7) & ~7;
   static bool attr0 = false;
   if (!attr0) {
@@ -1690,7 +1715,10 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
           // g_gemm_variant bit 6: the 32x32x16 MFMA form (gemm_ks32_kernel, round 4) - bit-identical results, measured SLOWER in the step
           // (7.285 against 7.119 ms, same box, alternated: profiles/r04_step_experiments.txt item 1), so the 16x16x32 form stays the default
           if (ks && (g_gemm_variant & 64)) return launch_ks32_cfg<192, 192>(g, tot4, st);
-          if (ks) return launch_ks_cfg<192, 192, true, true, EPI>(g, tot4, st);
+          if (ks) {
+            g.sq_written = g.sq_partials != nullptr;
+            return launch_ks_cfg<192, 192, true, true, EPI>(g, tot4, st);
+          }
         }
         return launch_persist_cfg<192, 192, 64, 4, 2, true, true, EPI>(g, tot4, num_cu, st);
       }
@@ -1819,6 +1847,7 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
   g.sk_partial = nullptr; g.sk_flags = nullptr; g.sk_epoch = 0;
   g.sk_rounds = g.sk_rem = g.sk_a = 0; g.sk_parts = 1;
   g.cu_slots = nullptr; g.stagger_ticks = 0;
+  g.sq_written = 0;
   static int ablate = -1;
   if (ablate < 0) {
     const char* e = getenv("GGET_GEMM_ABLATE");

@@ -97,6 +97,10 @@ int k_score_bwd(const float* dlogits, const void* hidden, const int32_t* pool_ro
 // ws: k_grad_sqnorm_ws_bytes() of scratch; ws[0] receives sum(g^2) (deterministic reduction order, two launches)
 int k_grad_sqnorm(const void* g, size_t n, float* ws, hipStream_t st);
 inline size_t k_grad_sqnorm_ws_bytes() { return (16 + 1024) * sizeof(float); }
+// the same over a list of chunks of the gradient array (offset / count pairs, counts multiples of 8, at most 1024 chunks) plus `nextra`
+// ready-made partial sums (the weight-gradient kernels' per-tile sums): ws[0] = sum of both, fixed order
+struct GgetSqChunk { uint64_t off; uint64_t cnt; };
+int k_grad_sqnorm_chunks(const void* g, const GgetSqChunk* chunks_dev, int nchunks, const float* extra, int nextra, float* ws, hipStream_t st);
 int k_adamw(float* master, float* m, float* v, const void* grad, void* param, size_t n, float lr, float beta1, float beta2,
             float eps, float wd, int step, float max_norm, float grad_scale, const float* sqnorm, float* gnorm_out,
             hipStream_t st);

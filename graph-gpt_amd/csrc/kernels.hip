@@ -1315,6 +1315,43 @@ __global__ void __launch_bounds__(kBlock) grad_sqnorm_final_kernel(float* __rest
   if (threadIdx.x == 0) ws[0] = part[0];
 }
 
+// one block per chunk (see k_grad_sqnorm_chunks): ws[16 + chunk] = sum of squares of the chunk
+__global__ void __launch_bounds__(kBlock) grad_sqnorm_chunks_kernel(const bf16_t* __restrict__ g, const GgetSqChunk* __restrict__ chunks,
+                                                                    float* __restrict__ ws) {
+  __shared__ float part[kBlock / 64];
+  const GgetSqChunk c = chunks[blockIdx.x];
+  const bf16_t* p = g + c.off;
+  float s = 0.f;
+  for (size_t i = threadIdx.x; i < (c.cnt >> 3); i += kBlock) {
+    float v[8];
+    unpack8(ldg16(p + i * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e] * v[e];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kBlock / 64; ++w) t += part[w];
+    ws[16 + blockIdx.x] = t;
+  }
+}
+__global__ void __launch_bounds__(kBlock) grad_sqnorm_final2_kernel(float* __restrict__ ws, int nblocks, const float* __restrict__ extra,
+                                                                    int nextra) {
+  __shared__ float part[kBlock];
+  float t = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += kBlock) t += ws[16 + i];
+  for (int i = threadIdx.x; i < nextra; i += kBlock) t += extra[i];
+  part[threadIdx.x] = t;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ws[0] = part[0];
+}
+
 template <int UNR>
 __global__ void __launch_bounds__(kBlock) adamw_kernel(float* __restrict__ master, float* __restrict__ m_, float* __restrict__ v_,
                                                        const bf16_t* __restrict__ grad, bf16_t* __restrict__ param, size_t n,
@@ -2276,6 +2313,14 @@ int k_grad_sqnorm(const void* g, size_t n, float* ws, hipStream_t st) {
   const int blocks = grid_for((long)(n / 8), kBlock, kSqnormBlocks);   // (2048 .. 8192 blocks measured slower)
   hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(blocks), dim3(kBlock), 0, st, (const bf16_t*)g, n, ws);
   hipLaunchKernelGGL(grad_sqnorm_final_kernel, dim3(1), dim3(kBlock), 0, st, ws, blocks);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_grad_sqnorm_chunks(const void* g, const GgetSqChunk* chunks_dev, int nchunks, const float* extra, int nextra, float* ws, hipStream_t st) {
+  if (nchunks > 0)
+    hipLaunchKernelGGL(grad_sqnorm_chunks_kernel, dim3(nchunks), dim3(kBlock), 0, st, (const bf16_t*)g, chunks_dev, ws);
+  hipLaunchKernelGGL(grad_sqnorm_final2_kernel, dim3(1), dim3(kBlock), 0, st, ws, nchunks, extra, nextra);
   GGET_LAUNCH_CHECK();
   return 0;
 }

@@ -175,6 +175,9 @@ class Engine:
             fn = self.lib.gget_forward_pretrain_packed
         else:
             fn = self.lib.gget_forward_pretrain
+        # (a fresh 1-element result tensor per call - a host-side allocator operation - instead of one buffer whose value every caller
+        #  had to copy out with a kernel before the next step overwrote it)
+        self._loss = torch.empty(1, dtype=torch.float32, device=dev)
         L.check(fn(self.h, _ptr(ids), _ptr(att), _ptr(lab), _ptr(wgt), _ptr(pos), B, S, _ptr(self._loss), _stream()))
         return self._loss[0] if lab is not None else None
 
@@ -203,6 +206,7 @@ class Engine:
         hid = torch.empty(B, self.spec.hidden_size, dtype=torch.bfloat16, device=dev)
         self._keep = (ids, att, pos, y, wgt)
         self._set_layout(att, num_tokens)
+        self._loss = torch.empty(1, dtype=torch.float32, device=dev)
         L.check(self.lib.gget_forward_task(self.h, _ptr(ids), _ptr(att), _ptr(pos), _ptr(y), _ptr(wgt), problem, B, S,
                                            _ptr(self._loss), _ptr(logits), _ptr(hid), _stream()))
         return (self._loss[0] if y is not None else None), logits, hid
@@ -251,6 +255,9 @@ class Engine:
         token layout (gget_set_token_count).  None / 0 = unknown -> padded layout."""
         L.check(self.lib.gget_set_token_count(self.h, int(n_real_tokens or -1)))   # (L.TOKENS_AUTO = -2 passes through)
 
+    def set_option(self, option: int, value: int):
+        L.check(self.lib.gget_set_option(self.h, int(option), int(value)))
+
     def positions_clamped(self) -> bool:
         """True if a forward since the last call met position_ids outside [0, max_position) (they were clamped into the RoPE table);
         clears the flag; synchronises."""
@@ -288,9 +295,10 @@ class Engine:
 
     def adamw_step(self, lr, beta1=0.9, beta2=0.95, eps=1e-8, weight_decay=0.1, max_grad_norm=1.0, grad_scale=1.0):
         self.step_count += 1
+        self._gnorm = torch.empty(1, dtype=torch.float32, device=self.device)     # (fresh per step: nothing to copy out, see forward_pretrain)
         L.check(self.lib.gget_adamw_step(self.h, lr, beta1, beta2, eps, weight_decay, max_grad_norm, grad_scale,
                                          self.step_count, _ptr(self._gnorm), _stream()))
-        return self._gnorm[0].clone()   # a copy: the buffer is overwritten by the next step
+        return self._gnorm[0]
 
     # ------------------------------------------------------------------ data-parallel exchange through the C ABI (RCCL)
     @staticmethod
@@ -302,6 +310,12 @@ class Engine:
     def comm_init(self, rank: int, world: int, unique_id: bytes):
         assert len(unique_id) == 128
         L.check(self.lib.gget_comm_init(self.h, int(rank), int(world), C.create_string_buffer(unique_id, 128)))
+        self.comm_world = int(world)
+
+    def comm_init_loopback(self, world: int):
+        """A peer-less communicator (gget_comm_init_loopback): every all-reduce multiplies the range by `world` - the exchange schedule
+        of a `world`-rank job on one GPU."""
+        L.check(self.lib.gget_comm_init_loopback(self.h, int(world)))
         self.comm_world = int(world)
 
     def comm_destroy(self):
@@ -318,6 +332,10 @@ class Engine:
     def allreduce_grads_async(self, bucket: int = -1, fp32_accumulate: bool = False, stream: Optional[torch.cuda.Stream] = None):
         st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
         L.check(self.lib.gget_allreduce_grads_async(self.h, int(bucket), int(bool(fp32_accumulate)), st))
+
+    def allreduce_range_async(self, offset: int, count: int, fp32_accumulate: bool = False, stream: Optional[torch.cuda.Stream] = None):
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        L.check(self.lib.gget_allreduce_range_async(self.h, int(offset), int(count), int(bool(fp32_accumulate)), st))
 
     # ------------------------------------------------------------------ head outputs
     def head_counts(self):

@@ -174,7 +174,7 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, loss_val):
         ctx.model = model
-        return loss_val.detach().clone()
+        return loss_val.detach()      # (an alias of the engine's per-call result tensor: no copy kernel in the step)
 
     @staticmethod
     def backward(ctx, g):
@@ -398,7 +398,7 @@ class _GgetModel(nn.Module):
             return None
         if torch.is_grad_enabled():
             return _LossFn.apply(self._anchor, self, loss)
-        return loss.detach().clone()
+        return loss.detach()
 
 
 class GraphGPTPretrainBase(_GgetModel):

@@ -167,6 +167,18 @@ class GgetEngine:
         # torch.distributed on the data path; the unique id travels once over the existing process group).
         self.fp32_reduce = bool(int(os.environ.get("GGET_DP_FP32_REDUCE", "0")))
         self.abi_comm = os.environ.get("GGET_DP_BACKEND", "torch") == "abi"
+        # GGET_DP_LOOPBACK_WORLD=W (with GGET_DP_BACKEND=abi, single process): the C-ABI exchange runs as rank 0 of W ranks that all hold
+        # this rank's gradients (gget_comm_init_loopback) - the schedule of a W-rank job (bucket ranges, side-stream waits, 1/W folded
+        # into AdamW) on a one-GPU box; the step must equal the single-rank step
+        self.loopback_world = int(os.environ.get("GGET_DP_LOOPBACK_WORLD", "0")) if self.abi_comm else 0
+        if self.loopback_world > 0:
+            assert self.world == 1, "the loopback communicator replaces the process group: run it in a single process"
+            self.world = self.loopback_world
+            self.force_staged = True
+        # GGET_DP_BUCKET_MB=N: consecutive buckets (completion order) are exchanged in ONE collective once they add up to >= N MiB -
+        # fewer, larger messages (14 buckets of ~19 MB for the base model; 60 -> 4-5 collectives).  0 (default) = one per bucket.
+        self.bucket_mb = float(os.environ.get("GGET_DP_BUCKET_MB", "0"))
+        self._groups = None
         # measurement switch (bench.py `dp.exposed_comm_ms`): False runs the same staged backward WITHOUT issuing the collectives -
         # the ranks then drift apart, so it is only ever set for a few untimed-for-throughput diagnostic steps
         self.exchange = True
@@ -197,6 +209,9 @@ class GgetEngine:
         # communicator over (Engine.comm_adopt), so this collective bootstrap runs once per job, on every rank together
         if e.comm_world > 0:
             return
+        if self.loopback_world > 0:
+            e.comm_init_loopback(self.loopback_world)
+            return
         rank = dist.get_rank(self.pg) if self.world > 1 else 0
         uid = [e.comm_unique_id() if rank == 0 else None]
         if self.world > 1:
@@ -208,6 +223,15 @@ class GgetEngine:
         e = self.module._engine
         if self.abi_comm:
             self._ensure_abi_comm(e)
+        # single-rank step: nothing touches the gradient array between this backward and AdamW - the engine MAY take the layers' share
+        # of the gradient norm from its weight-gradient launches (include/gget.h GGET_OPT_NORM_FROM_BACKWARD).  Opt-in
+        # (GGET_NORM_FROM_BACKWARD=1): measured in the step it saves its 31 us of norm pass and loses them again in AdamW, whose
+        # gradient reads the full pass had warmed the memory-side cache for (7.095 against 7.093 ms, profiles/r04_step_experiments.txt)
+        fold = self.world == 1 and not self.force_staged and bool(os.environ.get("GGET_NORM_FROM_BACKWARD"))
+        if getattr(e, "_norm_fold", None) != fold:
+            from . import _lib as L
+            e.set_option(L.OPT_NORM_FROM_BACKWARD, int(fold))
+            e._norm_fold = fold
         if self.world == 1 and not self.force_staged:
             e.backward()
             return
@@ -225,8 +249,12 @@ class GgetEngine:
         main = torch.cuda.current_stream()
         L_ = e.spec.num_layers
 
+        groups = self.exchange_groups(e)
+
         def reduce_bucket(b):
-            off, cnt = e.buckets[b]
+            if b not in groups:          # a bucket inside a coalesced group: exchanged with the group's last bucket
+                return
+            off, cnt = groups[b]
             ev = torch.cuda.Event()
             ev.record(main)
             self._comm_stream.wait_event(ev)
@@ -234,7 +262,7 @@ class GgetEngine:
                 if not self.exchange:
                     self._pending.append(None)
                 elif self.abi_comm:   # RCCL through the C ABI on the side stream (works at world 1 too: a one-rank communicator)
-                    e.allreduce_grads_async(b, self.fp32_reduce, self._comm_stream)
+                    e.allreduce_range_async(off, cnt, self.fp32_reduce, self._comm_stream)
                     self._pending.append(None)
                 elif self.world > 1:
                     self._pending.append(all_reduce_bucket(e.grad_bf16, (off, cnt), self.pg, async_op=True,
@@ -250,6 +278,28 @@ class GgetEngine:
         e.backward_end()
         reduce_bucket(L_ + 1)
 
+    def exchange_groups(self, e) -> Dict[int, Any]:
+        """{last bucket of a group: (offset, count)} - what one collective covers.  Buckets are numbered in completion order and laid
+        out back to front in the flat array, so consecutive buckets are adjacent ranges; a group is closed when it reaches
+        GGET_DP_BUCKET_MB (or at the last bucket).  Non-adjacent neighbours (never the case for the engine's layout) close a group too."""
+        if self._groups is not None and self._groups[0] is e:
+            return self._groups[1]
+        groups, lo, hi = {}, None, None
+        thresh = self.bucket_mb * 2 ** 20 / 2        # elements (bf16)
+        nb = len(e.buckets)
+        for b, (off, cnt) in enumerate(e.buckets):
+            if lo is not None and (off + cnt == lo or off == hi):
+                lo, hi = min(lo, off), max(hi, off + cnt)
+            else:
+                if lo is not None:
+                    groups[b - 1] = (lo, hi - lo)
+                lo, hi = off, off + cnt
+            if hi - lo >= thresh or b == nb - 1:
+                groups[b] = (lo, hi - lo)
+                lo = hi = None
+        self._groups = (e, groups)
+        return groups
+
     def describe_dp(self) -> Dict[str, Any]:
         """What the data-parallel exchange of this engine looks like (bench.py prints it on N > 1 lines)."""
         e = self.module._engine
@@ -257,7 +307,9 @@ class GgetEngine:
         info = {"world": self.world, "backend": ("rccl-via-c-abi" if self.abi_comm else f"torch.distributed/{backend}"),
                 "n_buckets": len(e.buckets) if e is not None else None, "overlap_with_backward": bool(self.overlap),
                 "reduce_dtype": "fp32" if self.fp32_reduce else "bf16",
-                "bucket_mb": [round(c * 2 / 2 ** 20, 1) for _, c in e.buckets] if e is not None else None}
+                "bucket_mb": [round(c * 2 / 2 ** 20, 1) for _, c in e.buckets] if e is not None else None,
+                "collectives_per_step": len(self.exchange_groups(e)) if e is not None else None,
+                "collective_mb": [round(c * 2 / 2 ** 20, 1) for _, c in self.exchange_groups(e).values()] if e is not None else None}
         try:
             v = torch.cuda.nccl.version()
             info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)

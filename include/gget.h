@@ -244,6 +244,16 @@ int gget_backward_begin(gget_handle_t h, float loss_scale, void* stream);
 int gget_backward_layer(gget_handle_t h, int layer, void* stream);
 int gget_backward_end(gget_handle_t h, void* stream);
 
+/* Engine options (no reference counterpart: promises of the caller that let the engine skip work).
+ * GGET_OPT_NORM_FROM_BACKWARD = 1: "nothing rewrites the bf16 gradient array between gget_backward* and gget_adamw_step" (a single-rank
+ *   step; any exchange rewrites it).  gget_adamw_step then takes the squared norm of the decoder layers' weight-gradient matrices
+ *   (93 % of the base model's parameters) from per-tile partial sums their weight-gradient launches left behind and reads only the
+ *   remaining tensors again - the clip + AdamW step (reference: torch.nn.utils.clip_grad_norm_ + AdamW, src/utils/training_utils.py
+ *   :72-82, DeepSpeed's gradient_clipping) loses its 244 MB norm pass.  Ignored (full pass) whenever grad_scale != 1 or a layer's launch
+ *   left no partials.  The norm is the same sum in another (fixed) order: equal to fp32 rounding. */
+#define GGET_OPT_NORM_FROM_BACKWARD 1
+int gget_set_option(gget_handle_t h, int option, int value);
+
 /* ------------------------------------------------------------------------------------------
  * Data-parallel gradient exchange.  replaces: the DDP gradient all-reduce (src/utils/opt_utils.py:13),
  * DeepSpeed ZeRO-2's reduce-scatter/all-gather (examples/ds_config2_pt.json:29-32) and the communicator bootstrap of
@@ -263,6 +273,16 @@ int gget_comm_destroy(gget_handle_t h);
  * (the host re-creates the handle when a larger batch arrives): no collective, so ranks may do it independently. */
 int gget_comm_move(gget_handle_t dst, gget_handle_t src);
 int gget_allreduce_grads_async(gget_handle_t h, int bucket, int fp32_accumulate, void* side_stream);
+/* the same collective over an arbitrary element range [offset, offset + count) of the flat gradient array: several consecutive
+ * buckets in ONE collective (fewer, larger messages - xGMI rings are per-link bound; the host picks the coalescing, e.g.
+ * GGET_DP_BUCKET_MB in graph-gpt_amd/training.py).  The range must lie inside [0, n_params). */
+int gget_allreduce_range_async(gget_handle_t h, uint64_t offset, uint64_t count, int fp32_accumulate, void* side_stream);
+/* A communicator that needs no peers (tests / dry runs of the exchange schedule on one GPU): the handle behaves as rank 0 of `world`
+ * ranks that all hold THIS rank's gradients, i.e. every "all-reduce" multiplies the range by `world` on the side stream (the same
+ * stream / event protocol as the RCCL collective; with grad_scale = 1/world the step equals the single-rank step).  No reference
+ * counterpart - RCCL refuses two ranks on one device, and the exchange schedule (bucket ranges, stream waits, the 1/world folded into
+ * AdamW) must be testable beyond world 1 on a one-GPU box. */
+int gget_comm_init_loopback(gget_handle_t h, int world);
 
 /* replaces: clip_grad_norm_ + AdamW.step / FusedAdam (training_utils.py:68-80, opt_utils.py:18-24,
  * examples/ds_config2_pt.json:11-19).  grad_scale multiplies every gradient first (1/world after a

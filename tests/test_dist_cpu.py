@@ -240,3 +240,29 @@ def test_ft_evaluate_gathers_all_ranks_gloo_world2():
         assert ogb == {"hits@100": 1.0}
     # per-rank mean of per-batch mean scores
     assert abs(res[0][1] - np.mean([np.mean([0, 2, 4, 6]), np.mean([8, 10])])) < 1e-6
+
+
+def test_exchange_groups_coalesce_buckets_in_completion_order():
+    """GGET_DP_BUCKET_MB: consecutive buckets of the completion order become ONE collective once they reach the size;
+    the groups tile the flat gradient array exactly, every group is exchanged when its LAST bucket completes, the default is one
+    collective per bucket."""
+    sizes = [8_000_000] + [9_437_184] * 12 + [600_000]          # head, layers L-1..0, embeddings (the base model's layout)
+    offs, o = [], sum(sizes)
+    for s_ in sizes:
+        o -= s_
+        offs.append(o)
+    e = types.SimpleNamespace(buckets=list(zip(offs, sizes)))
+    eng = tr.GgetEngine.__new__(tr.GgetEngine)
+    for mb, want in ((0, 14), (40, 5), (60, 4), (10 ** 6, 1)):
+        eng.bucket_mb, eng._groups = mb, None
+        groups = eng.exchange_groups(e)
+        assert len(groups) == want
+        covered = sorted((off, off + cnt) for off, cnt in groups.values())
+        assert covered[0][0] == 0 and covered[-1][1] == sum(sizes)
+        assert all(a[1] == b[0] for a, b in zip(covered[:-1], covered[1:]))       # an exact tiling, no overlap
+        for last, (off, cnt) in groups.items():                                     # a group ends with the bucket that closes it
+            assert off == e.buckets[last][0] and (mb == 0 or cnt * 2 >= mb * 2 ** 20 or last == len(sizes) - 1)
+    # neighbours that are NOT adjacent in memory are never merged
+    e2 = types.SimpleNamespace(buckets=[(100, 10), (50, 10), (40, 10)])
+    eng.bucket_mb, eng._groups = 10 ** 6, None
+    assert eng.exchange_groups(e2) == {0: (100, 10), 2: (40, 20)}

@@ -39,6 +39,7 @@ def _batch(synth, rank, layout="padded"):
 
 def _worker(rank, world, port, q, overlap="1", layout="padded"):
     os.environ["GGET_DP_OVERLAP"] = overlap
+    os.environ["GGET_VARLEN"] = "0" if layout == "padded" else ""      # (a device-side mask alone selects the var-len layout since round 4)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method="env://")
@@ -61,9 +62,10 @@ def _worker(rank, world, port, q, overlap="1", layout="padded"):
 
 
 @pytest.mark.parametrize("overlap,layout", [("1", "padded"), ("0", "padded"), ("1", "varlen")])
-def test_two_rank_step_matches_manual_gradient_average(overlap, layout):
+def test_two_rank_step_matches_manual_gradient_average(overlap, layout, monkeypatch):
     """overlap=1: bucketed all-reduce on a side stream behind the staged backward; overlap=0: one all-reduce after it; layout "varlen":
     every rank runs its step on its own compacted real tokens (the gradient buckets are the same on every rank whatever its row count)."""
+    monkeypatch.setenv("GGET_VARLEN", "0" if layout == "padded" else "")
     modeling = importlib.import_module("graph-gpt_amd.modeling")
     tr = importlib.import_module("graph-gpt_amd.training")
     synth = importlib.import_module("graph-gpt_amd.synth")
@@ -73,7 +75,7 @@ def test_two_rank_step_matches_manual_gradient_average(overlap, layout):
     ps = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap, layout)) for r in range(2)]
     for p in ps:
         p.start()
-    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
     for p in ps:
         p.join(120)
         assert p.exitcode == 0
@@ -218,3 +220,87 @@ def test_bench_two_ranks_gloo_smoke():
     assert dp["world"] == 2 and dp["n_buckets"] == 2 + 2 and dp["backend"].endswith("gloo") and dp["overlap_with_backward"] is True
     assert dp["ms_per_step_without_exchange"] > 0 and abs(dp["exposed_comm_ms"] - (d["ms_per_step"] - dp["ms_per_step_without_exchange"])) < 1e-9
     assert np.isfinite(d["smtp_loss"])
+
+
+def test_c_abi_exchange_schedule_loopback_world2_and_coalesced_buckets(monkeypatch):
+    """The C-ABI exchange beyond one rank on a one-GPU box: a loopback communicator (gget_comm_init_loopback) makes this
+    process rank 0 of TWO ranks that hold the same gradients - every collective doubles its range on the side stream, AdamW's grad_scale
+    is 1/2 - so the staged backward + per-bucket exchange + step must reproduce the single-rank step (doubling / halving is exact in
+    bf16; the runs still differ by the order of the fp32-atomic reductions).  A collective that ran before its bucket was final, a
+    missing stream wait in front of AdamW, a wrong range or a forgotten 1/world would all break the match.  Repeated with the buckets
+    coalesced into >= 1 MiB collectives (GGET_DP_BUCKET_MB) - fewer collectives, same result."""
+    modeling = importlib.import_module("graph-gpt_amd.modeling")
+    tr = importlib.import_module("graph-gpt_amd.training")
+    synth = importlib.import_module("graph-gpt_amd.synth")
+    data = _batch(synth, 0)
+
+    def run(loop_world, bucket_mb="0"):
+        monkeypatch.setenv("GGET_DP_BACKEND", "abi" if loop_world else "torch")
+        monkeypatch.setenv("GGET_DP_LOOPBACK_WORLD", str(loop_world))
+        monkeypatch.setenv("GGET_FORCE_STAGED", "1")
+        monkeypatch.setenv("GGET_DP_BUCKET_MB", bucket_mb)
+        model = modeling.GraphGPTPretrainBase(_cfg(modeling), seed=1)
+        eng = tr.initialize(model, tr.OptimConfig(lr=1e-3, max_grad_norm=0.05))
+        losses = [float(tr.batch_training(data, eng)) for _ in range(3)]
+        torch.cuda.synchronize()
+        e = model._engine
+        info = eng.describe_dp()
+        if loop_world:
+            assert eng.world == loop_world and e.comm_world == loop_world
+            e.comm_destroy()
+        return losses, e.master.detach().cpu().numpy().copy(), float(eng.last_grad_norm), info
+
+    master0 = modeling.GraphGPTPretrainBase(_cfg(modeling), seed=1).cuda()._engine.master.detach().cpu().numpy().copy()
+    ref = run(0)
+    upd = np.linalg.norm(ref[1] - master0)
+    for world, mb in ((2, "0"), (2, "1"), (4, "1000")):
+        got = run(world, mb)
+        np.testing.assert_allclose(got[0], ref[0], rtol=2e-6)
+        assert float(np.linalg.norm(got[1] - ref[1])) < 0.02 * upd, (world, mb)
+        # the clipped global norm is the norm of the AVERAGED gradient: world x the gradients, scaled by 1/world
+        assert abs(got[2] - ref[2]) <= 2e-3 * ref[2]
+        nb = got[3]["n_buckets"]
+        assert got[3]["collectives_per_step"] == (nb if mb == "0" else (1 if mb == "1000" else got[3]["collectives_per_step"]))
+        assert got[3]["collectives_per_step"] <= nb and abs(sum(got[3]["collective_mb"]) - sum(got[3]["bucket_mb"])) < 0.2
+    # without the 1/world the loopback run must NOT match (the test has teeth): world 2 with grad_scale forced to 1
+    monkeypatch.setenv("GGET_DP_BACKEND", "abi")
+    monkeypatch.setenv("GGET_DP_LOOPBACK_WORLD", "2")
+    model = modeling.GraphGPTPretrainBase(_cfg(modeling), seed=1)
+    eng = tr.initialize(model, tr.OptimConfig(lr=1e-3, max_grad_norm=1e9))     # no clipping: the raw scale reaches AdamW's moments
+    out = eng(input_ids=data["input_ids"], attention_mask=data["attention_mask"], labels=data["labels"])
+    eng.backward(out.head1_loss)
+    eng.world = 1
+    gn_unscaled = float(eng.step())
+    eng.world = 2
+    out = eng(input_ids=data["input_ids"], attention_mask=data["attention_mask"], labels=data["labels"])
+    eng.backward(out.head1_loss)
+    gn_scaled = float(eng.step())
+    model._engine.comm_destroy()
+    assert gn_unscaled > 1.5 * gn_scaled
+
+
+def test_bench_eight_ranks_gloo_smoke():
+    """`bench.py --gpus 8` as the driver launches it, eight ranks sharing the one GPU over gloo (no 8-GPU node is
+    available to this round - this is the readiness check, not a scaling number): the line must carry the L + 2 bucket layout, the
+    replicas must be bit-identical after the timed steps, the exposed-communication diagnostic must be finite."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GGET_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", GGET_DP_BUCKET_MB="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+           "--workload", "toy-tiny", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp8"
+    assert d["config"]["global_batch"] == 8 * d["config"]["per_gpu_batch"]
+    dp = d["dp"]
+    assert dp["world"] == 8 and dp["n_buckets"] == 2 + 2 and dp["collectives_per_step"] == 4
+    assert dp["replicas_bit_identical"] is True
+    assert np.isfinite(dp["exposed_comm_ms"]) and np.isfinite(d["smtp_loss"])

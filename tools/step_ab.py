@@ -14,8 +14,14 @@ L = importlib.import_module("graph-gpt_amd._lib")
 
 
 def parse(v):
+    """name:key=value,...  - integer keys are gget_debug_set keys, `env.NAME=value` sets an environment variable for the variant's steps"""
     name, _, rest = v.partition(":")
-    pairs = [tuple(int(x) for x in kv.split("=")) for kv in rest.split(",") if kv]
+    pairs = []
+    for kv in rest.split(","):
+        if not kv:
+            continue
+        k, _, val = kv.partition("=")
+        pairs.append((k, val) if k.startswith("env.") else (int(k), int(val)))
     return name, pairs
 
 
@@ -52,13 +58,19 @@ def main():
     dev["num_tokens"] = synth.real_tokens(batch)
     step = (lambda: training.batch_training(dev, engine)) if pt else (lambda: training.ft_batch_training(dev, engine)[0])
     variants = [parse(v) for v in a.variants]
-    keys = sorted({k for _, ps in variants for k, _ in ps})
+    keys = sorted({k for _, ps in variants for k, _ in ps if isinstance(k, int)})
+    envs = sorted({k[4:] for _, ps in variants for k, _ in ps if not isinstance(k, int)})
 
     def apply(pairs):
         for k in keys:
             L.check(lib.gget_debug_set(k, 0 if k != 2 else 1))      # defaults (key 2 = LDS headroom: 1)
+        for k in envs:
+            os.environ.pop(k, None)
         for k, v in pairs:
-            L.check(lib.gget_debug_set(k, v))
+            if isinstance(k, int):
+                L.check(lib.gget_debug_set(k, v))
+            else:
+                os.environ[k[4:]] = v
 
     for _, ps in variants:          # warm every variant's kernels up
         apply(ps)

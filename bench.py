@@ -384,12 +384,14 @@ def main():
         tot_real, mean_loss = float(real_per_step), float(loss.item())
 
     if rank == 0:
-        M, Lm = model._engine.head_counts() if pt else (0, 0)       # (batch 0: the last forward was a probe step)
+        M, Lm = model._engine.head_counts() if pt else (0, 0)       # (of the last forward)
         ran_varlen, t_rows, mismatch = model._engine.varlen_status()
         assert not mismatch, "the batch's real-token count handed to the engine disagrees with its attention mask"
-        if kind == "pt":
+        if kind == "pt" and world == 1:                             # (single process: the last forward was a probe step on batch 0)
             lab0 = host_batches[0]["labels"] != -100
             assert (M, Lm) == (int(lab0.any(-1).sum()), int(lab0.sum())), "head counts of batch 0 differ from its labels"
+        if ran_varlen:
+            t_rows = (reals[0] + 63) // 64 * 64                     # rows of batch 0: the shape the kernel timings below are taken on
 
         def batch_flops(j, executed):
             """FLOPs of one step on batch j (M / Lm from its labels; executed: the var-len rows and len x len attention blocks)"""

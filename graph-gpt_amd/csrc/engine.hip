@@ -1803,6 +1803,7 @@ extern int g_gemm_variant;
 extern int g_gemm_lds_headroom;
 extern int g_gemm_split_last;
 extern int g_gemm_stagger_ticks;
+extern int g_gemm_ablate_set;
 extern "C" int gget_debug_probe(gget_handle_t h, int enable, float* avg_ms_out /* [2] or NULL */) {
   GGET_REQUIRE(h != nullptr, "null handle");
   if (avg_ms_out) {   // mean launch duration over the layers of the last forward / backward that ran with the probe on
@@ -1829,6 +1830,7 @@ extern "C" int gget_debug_set(int key, int value) {
     case 4: k_set_deterministic(value); return 0;
     case 3: g_gemm_split_last = value; return 0;
     case 5: g_gemm_stagger_ticks = value; return 0;
+    case 7: g_gemm_ablate_set = value > 0 ? value : -1; return 0;
   }
   gget_set_error("debug_set: unknown key %d", key);
   return 2;

@@ -43,6 +43,7 @@ int g_gemm_split_last = 0;   // split the K range of the last, partial round's t
                             // GGET_GEMM_SPLIT_LAST).  Off by default: on the C1 shapes the hand-over of the partial tiles costs more than the
                             // shorter last round returns (profiles/r03_gemm_varlen_shapes.txt); correct and tested (tests/test_gpu_ops.py)
 int g_gemm_variant = 0;   // measurement knob (gget_debug_set key 1): selects experimental kernel variants for in-process A/B timing
+int g_gemm_ablate_set = -1;     // >= 0: replaces GGET_GEMM_ABLATE at run time (gget_debug_set key 7; in-process A/B of the experiment bits)
 int g_gemm_stagger_ticks = 0;   // MODE 2 launches (two workgroups per CU): start delay of a CU's second workgroup in 100 MHz ticks (gget_debug_set
                                 // key 5, env GGET_GEMM_STAGGER); 0 = both start together (round 3)
 
@@ -800,6 +801,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) gemm_kernel(const
 // (cold 74.5 -> 70.5 us), -0.02 ms on the C1 step.  Measured and dropped (profiles/r03_step_experiments.txt, item 11): the same epilogue
 // run one 16-row block at a time inside the NEXT tile's K-loop of a one-block-per-CU kernel (operands prefetched by LDS-DMA into a
 // landing area) - the in-order VMEM queue makes every K-tile wait for the HBM-latency operand loads issued before it: -2 % / nothing.
+// (Round 4: the LDS-DMA issued by the first four waves only - what pays in the K-split kernel below - measured +0.3 % here: every wave
+//  keeps issuing its own share.  profiles/r04_step_experiments.txt item 5.)
 template <int BM, int BN, int BK, int WM, int WN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0, bool SK = false, int MODE = 0>
 __global__ void __launch_bounds__(WM * WN * 64, MODE == 2 ? 4 : ((WM * WN) >= 8 ? 2 : 1)) gemm_persist_kernel(const GemmGroup g, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1096,10 +1099,15 @@ __global__ void __launch_bounds__(WM * WN * 64, MODE == 2 ? 4 : ((WM * WN) >= 8 
 // is bound by LDS fragment traffic (profiles/r02_gemm_structure_experiments.txt: +17 % / +8 % in the pipe micro-benchmark).
 // At the end the two K halves of a sub-tile (waves w and w ^ 4, same SIMD) are added through LDS - the ring is free by
 // then, one tile per block - each wave keeps one row half, and the usual epilogue stores it.
-template <int BM, int BN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0>
+// DW = waves that issue the LDS-DMA.  4 (default since round 4): only the first wave of every SIMD, twice the pieces each - the other
+// four never enter the vector-memory queue during the K-loop and keep issuing MFMAs while the first four sit in DMA issue (a DMA piece
+// costs its wave 60-180 cycles of issue when the queue is busy).  Bit-identical results, C1 step -1.0 ... -1.2 % on two boxes (7.173 ->
+// 7.100, 7.402 -> 7.314 ms, same process, alternated: profiles/r04_step_experiments.txt item 5).  8 = every wave its own share
+// (rounds 2-3; g_gemm_variant bit 7).
+template <int BM, int BN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0, int DW = 8>
 __global__ void __launch_bounds__(512, 2) gemm_ks_kernel(const GemmGroup g, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int BK = 64, NT = 512;
+  constexpr int BK = 64, NT = DW * 64;     // (threads that take part in the DMA: TileIO's piece lists are cut for them)
   using TA = TileIO<BM, A_MC, NT, BK>;
   using TB = TileIO<BN, B_MC, NT, BK>;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -1133,22 +1141,23 @@ __global__ void __launch_bounds__(512, 2) gemm_ks_kernel(const GemmGroup g, int 
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(LDS_AS const void*)smem) + (unsigned)wave * 1024u;
+  const int pw = DW == 8 ? wave : (wave & (DW - 1));     // this wave's index in the piece lists (only the issuing waves use it)
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(LDS_AS const void*)smem) + (unsigned)pw * 1024u;
   const unsigned char* kA = reinterpret_cast<const unsigned char*>(P.A);
   const unsigned char* kB = reinterpret_cast<const unsigned char*>(P.B);
   const long strideA = A_MC ? (long)BK * P.lda * 2 : (long)BK * 2;
   const long strideB = B_MC ? (long)BK * P.ldb * 2 : (long)BK * 2;
   unsigned offA[TA::PIECES], offB[TB::PIECES];
 #pragma unroll
-  for (int i = 0; i < TA::PIECES; ++i) offA[i] = TA::piece_off(P.lda, m0, P.M, wave, lane, i);
+  for (int i = 0; i < TA::PIECES; ++i) offA[i] = TA::piece_off(P.lda, m0, P.M, pw, lane, i);
 #pragma unroll
-  for (int i = 0; i < TB::PIECES; ++i) offB[i] = TB::piece_off(P.ldb, n0, P.N, wave, lane, i);
+  for (int i = 0; i < TB::PIECES; ++i) offB[i] = TB::piece_off(P.ldb, n0, P.N, pw, lane, i);
   int islot = 0, cslot = 0, issued = 0;
   unsigned islot_off = lds0;
   // (a wrapped A piece - TileIO::WRAP - lands where the piece it repeats lives: a wave-uniform correction of the LDS offset)
   int adjA[TA::PIECES];
 #pragma unroll
-  for (int i = 0; i < TA::PIECES; ++i) adjA[i] = (TA::piece_index(wave, i) - (wave + i * TA::NWAVES)) * 1024;
+  for (int i = 0; i < TA::PIECES; ++i) adjA[i] = (TA::piece_index(pw, i) - (pw + i * TA::NWAVES)) * 1024;
   auto issue_piece = [&](int q) {
     if (q < TA::PIECES) glds16m(kA, offA[q < TA::PIECES ? q : 0], islot_off + (unsigned)(q * TA::NWAVES * 1024 + (TA::WRAP ? adjA[q < TA::PIECES ? q : 0] : 0)));
     else glds16m(kB, offB[q >= TA::PIECES ? q - TA::PIECES : 0], islot_off + (unsigned)(A_BYTES + (q - TA::PIECES) * TB::NWAVES * 1024));
@@ -1160,18 +1169,26 @@ __global__ void __launch_bounds__(512, 2) gemm_ks_kernel(const GemmGroup g, int 
     kB += strideB;
     ++issued;
   };
+  // The issuing waves are the FIRST four (dispatched first = oldest on their SIMDs: the issue arbiter serves them first).  Measured
+  // alternatives, same box (profiles/r04_step_experiments.txt item 5): the last four instead - no gain over all eight; priority 1 for the
+  // non-issuing waves - the gain is gone; all pieces of a K-tile up front instead of between the MFMA groups - half the gain.
+  const bool dma_wave = DW == 8 || wave < DW;
 #pragma unroll
   for (int i = 0; i < NSLOT - 1; ++i) {
     if (issued < nk) {
+      if (dma_wave) {
 #pragma unroll
-      for (int q = 0; q < PIECES; ++q) issue_piece(q);
+        for (int q = 0; q < PIECES; ++q) issue_piece(q);
+      }
       issue_advance();
     }
   }
   for (int t = 0; t < nk; ++t) {
     // this wave's pieces of K-tile t have landed (issued - t - 1 younger K-tiles may stay in flight)
-    if (issued - t == NSLOT - 1) vm_wait<(NSLOT - 2) * PIECES>();
-    else vm_wait<0>();
+    if (dma_wave) {
+      if (issued - t == NSLOT - 1) vm_wait<(NSLOT - 2) * PIECES>();
+      else vm_wait<0>();
+    }
     __syncthreads();
     const bool did = issued < nk;
     const unsigned char* a_l = smem + cslot * STAGE;
@@ -1185,7 +1202,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ks_kernel(const GemmGroup g, int 
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-      if (did) {
+      if (did && dma_wave) {
 #pragma unroll
         for (int q = i * PIECES / MI; q < (i + 1) * PIECES / MI; ++q) issue_piece(q);
       }
@@ -1486,19 +1503,22 @@ int launch_ks32_cfg(GemmGroup& g, int total, hipStream_t st) {
   return 0;
 }
 
-template <int BM, int BN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0>
+template <int BM, int BN, bool A_MC, bool B_MC, int EPI, int NSLOT_ = 0, int DW = 8>
 int launch_ks_cfg(GemmGroup& g, int total, hipStream_t st) {
+  if constexpr (DW == 8 && BM != 64) {
+    if (!(g_gemm_variant & 128)) return launch_ks_cfg<BM, BN, A_MC, B_MC, EPI, NSLOT_, 4>(g, total, st);
+  }
   constexpr int STG = (BM + BN) * 64 * 2;
   constexpr int SM = (NSLOT_ > 0 ? NSLOT_ : persist_slots(STG)) * STG + (A_MC && B_MC && EPI == GGET_EPI_NONE ? 64 : 0);   // (+ the norm partials' scratch)
   static_assert(SM <= 160 * 1024, "LDS ring");
   const int G = (total + 7) & ~7;
   static bool attr0 = false;
   if (!attr0) {
-    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ks_kernel<BM, BN, A_MC, B_MC, EPI, NSLOT_>),
+    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ks_kernel<BM, BN, A_MC, B_MC, EPI, NSLOT_, DW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SM));
     attr0 = true;
   }
-  hipLaunchKernelGGL((gemm_ks_kernel<BM, BN, A_MC, B_MC, EPI, NSLOT_>), dim3(G), dim3(512), SM, st, g, total);
+  hipLaunchKernelGGL((gemm_ks_kernel<BM, BN, A_MC, B_MC, EPI, NSLOT_, DW>), dim3(G), dim3(512), SM, st, g, total);
   GGET_LAUNCH_CHECK();
   return 0;
 }
@@ -1857,7 +1877,7 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
     if (const char* v = getenv("GGET_GEMM_SPLIT_LAST")) g_gemm_split_last = atoi(v);   // same knob as gget_debug_set(1, .), for whole-step A/B
     if (const char* v = getenv("GGET_GEMM_STAGGER")) g_gemm_stagger_ticks = atoi(v);
   }
-  g.ablate = ablate;
+  g.ablate = g_gemm_ablate_set >= 0 ? g_gemm_ablate_set : ablate;
   static int super = -1;
   if (super < 0) { const char* e = getenv("GGET_GEMM_SUPER"); super = e ? atoi(e) : 0; }
   g.super = super > 0 ? super : (mode == GGET_GEMM_TN ? 1 : kSuper);

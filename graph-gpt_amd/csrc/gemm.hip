@@ -1080,15 +1080,10 @@ __global__ void __launch_bounds__(WM * WN * 64, MODE == 2 ? 4 : ((WM * WN) >= 8 
           //  first MFMA group so that they have the rest of the iteration to land, not one MFMA group: C1 step 7.41 -> 7.36 ms;
           //  spread over the first half of the groups 7.39, over the first two 7.37)
           constexpr int NGI = NSLOT == 2 ? 1 : NG;
-          if constexpr (NSLOT == 2) {
-            // (experiment, g.ablate bits 8-10 = MFMA group behind which the UPPER four waves issue their burst; 0 = with the lower four:
-            //  both waves of a SIMD then sit in DMA issue at the same time)
-            const int gsel = wave >= 4 ? min((g.ablate >> 8) & 7, NG - 1) : 0;
-            if (did && grp == gsel) {
-#pragma unroll
-              for (int q = 0; q < PIECES; ++q) issue_piece(q);
-            }
-          } else if (did && grp < NGI) {
+          // (2-slot ring, measured in round 4: the upper four waves issuing their burst behind a LATER group than the lower four - so that
+          //  the two waves of a SIMD do not sit in DMA issue together - is monotonically slower, 7.035 / 7.059 / 7.072 / 7.089 / 7.114 ms for
+          //  groups 0..4: what the later issue loses in landing time outweighs it)
+          if (did && grp < NGI) {
 #pragma unroll
             for (int q = grp * PIECES / NGI; q < (grp + 1) * PIECES / NGI; ++q) issue_piece(q);
           }

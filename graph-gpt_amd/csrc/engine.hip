@@ -193,6 +193,9 @@ struct Ws {
   uint64_t sq_chunks, sq_tiles;   // gradient-norm shortcut: chunk table of everything but the layers' weight matrices; per-tile sums of those
   // pre-train head
   uint64_t cnt, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
+  // slot-sorted n_token_proj (kernels.hip k_head_slot_sort): sorted cell lists (token row / dP row / cell index per sorted position), the
+  // sorted position of every cell, weight offset per 128-row tile, slot counters, padded total
+  uint64_t ss_tok, ss_cell, ss_l, ss_pos, ss_tile, ss_state, ss_total;
   // task head
   uint64_t tlogits, tdlogits, pooled_h, auc_lists;
   uint64_t raw_x, raw_xn, raw_rstd, raw_dxn, raw_dx, raw_flag;   // raw-embedding inputs: blended bf16 [T,e], normalised [T,e], 1/rms [T], their gradients, mask flags [T]
@@ -290,7 +293,15 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
     w.Hm = b.take(T * d * 2);
     w.dHm = b.take(T * d * 2);
     if (n > 1) {
-      w.Pp = b.take(T * n * d * 2);
+      const uint64_t cap_p = T * n + n * 256;           // sorted cells + one partial tile of pad rows per slot
+      w.ss_tok = b.take(cap_p * 4);
+      w.ss_cell = b.take(cap_p * 4);
+      w.ss_l = b.take(cap_p * 4);
+      w.ss_pos = b.take(T * n * 4);
+      w.ss_tile = b.take((cap_p / 128 + 1) * 4);
+      w.ss_state = b.take(512);
+      w.ss_total = b.take(256);
+      w.Pp = b.take(cap_p * d * 2);                     // (Pp doubles as dXs, the per-cell input gradients of the sorted backward)
       w.Hl = b.take(T * n * d * 2);
       w.dHl = b.take(T * n * d * 2);
       w.dP = b.take(T * n * d * 2);
@@ -369,6 +380,7 @@ struct gget_engine {
   bool opt_norm_from_backward = false;
   int sq_layers = 0;
   int n_sq_chunks = 0;
+  bool head_sorted_fwd = false;   // the last pre-train forward ran the slot-sorted n_token_proj (its lists feed the backward)
   bool tc_from_caller = false;    // the last var-len forward ran on a caller's count (a wrong one poisons the loss, see poison_loss)
   int32_t* host_word = nullptr;   // pinned host word the counted total lands in
   const int64_t* pos_rows = nullptr;   // position of every ROW (GEMM RoPE epilogue): pos_cur, or the compacted positions
@@ -718,6 +730,17 @@ int gemm_nt(const void* A, const void* Bw, void* C, const void* R, int M, int N,
 int gemm_nn(const void* A, const void* Bw, void* C, int M, int N, int K, int lda, int ldb, int ldc, const int* m_dev,
             hipStream_t st, const int* c_rows = nullptr) {
   return gget_gemm_single(GGET_GEMM_NN, GGET_EPI_NONE, A, Bw, C, nullptr, M, N, K, lda, ldb, ldc, m_dev, nullptr, 1, st, false, c_rows);
+}
+// Slot-sorted n_token_proj (kernels.hip: "Slot-sorted SMTP head"): on by default; GGET_HEAD_SORTED=0 / gget_debug_set(8, 1) = the dense
+// projection of every selected row through all n slots (rounds 1-3)
+int g_head_dense = 0;
+int g_head_tile = 0;   // 0: 256-row tiles when d % 256 == 0, else 128 ; 128 / 256: forced (gget_debug_set key 9)
+inline int head_tile_rows(int d) { return g_head_tile == 128 ? 128 : ((d % 256) == 0 ? 256 : 128); }
+bool head_scatter_fused();
+inline bool head_scatter_fused_decl() { return head_scatter_fused(); }
+bool head_sorted() {
+  static const int off = getenv("GGET_HEAD_SORTED") != nullptr && atoi(getenv("GGET_HEAD_SORTED")) == 0;
+  return !off && !g_head_dense && head_scatter_fused_decl();
 }
 bool head_scatter_fused() {
   static const int off = getenv("GGET_NO_HEAD_SCATTER_FUSION") != nullptr;
@@ -1263,7 +1286,27 @@ static int forward_pretrain_impl(gget_handle_t h, const int64_t* input_ids_dev, 
       return e;
   if (int e = k_gather_rows(h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.row_idx), counts, h->wsp<bf16_t>(w.Hm), T, d, 0, st))
     return e;
-  if (h->plan.has_ntp) {
+  h->head_sorted_fwd = false;
+  if (h->plan.has_ntp && head_sorted() && d % 192 == 0 && n <= 32) {
+    // n_token_proj on the labelled cells only (modeling_helpers.py:263-301 computes all n slots of every selected row and drops the
+    // unlabelled half): cells sorted by slot, one GEMM with a weight block per row tile, rows gathered from `hidden` and scattered
+    // straight to Hl's (m, f) order - the dense [M, n d] product and its gather are gone
+    if (int e = k_head_slot_sort(h->wsp<int32_t>(w.sel_src), h->wsp<int32_t>(w.row_idx), counts + 1, h->wsp<int32_t>(w.ss_state),
+                                 h->wsp<int32_t>(w.ss_tok), h->wsp<int32_t>(w.ss_cell), h->wsp<int32_t>(w.ss_l), h->wsp<int32_t>(w.ss_pos),
+                                 h->wsp<int32_t>(w.ss_tile), h->wsp<int32_t>(w.ss_total), T * n, n, (long)d * d, head_tile_rows(d), st))
+      return e;
+    GemmGroup g;
+    memset(&g, 0, sizeof(g));
+    g.count = 1;
+    GemmProblem& p = g.p[0];
+    p.A = h->wsp<bf16_t>(w.hidden); p.B = h->P + h->plan.ntp; p.C = h->wsp<bf16_t>(w.Hl);
+    p.M = T * n + n * 256; p.N = d; p.K = d; p.lda = d; p.ldb = d; p.ldc = d;
+    p.m_dev = h->wsp<int32_t>(w.ss_total);
+    p.a_rows = h->wsp<int32_t>(w.ss_tok); p.b_tile_off = h->wsp<int32_t>(w.ss_tile); p.c_rows = h->wsp<int32_t>(w.ss_l);
+    p.b_tile_rows = head_tile_rows(d);
+    if (int e = gget_gemm_launch(GGET_GEMM_NT, GGET_EPI_NONE, g, 1, st)) return e;
+    h->head_sorted_fwd = true;
+  } else if (h->plan.has_ntp) {
     if (int e = gemm_nt(h->wsp<bf16_t>(w.Hm), h->P + h->plan.ntp, h->wsp<bf16_t>(w.Pp), nullptr, T, n * d, d, d, d, n * d,
                         counts, st))
       return e;
@@ -1577,14 +1620,31 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
         if (int e = k_gather_rows(h->wsp<bf16_t>(w.dHl), h->wsp<int32_t>(w.sel_src), counts + 1, dP, T * n, d, 1, st)) return e;
       }
       // dHm = dP W_ntp, its rows scattered into the gradient of the final-norm output (row row_idx[i]) by the same fused epilogue
-      if (head_scatter_fused()) {
+      if (h->head_sorted_fwd) {
+        // slot-sorted form: one input-gradient row per labelled cell, dXs[p] = dP[cell(p)] W_f(p) (rows gathered from dP, the weight
+        // block per row tile), then every selected token sums its cells (fp32, one rounding) into its row of d hidden
+        bf16_t* dxs = h->wsp<bf16_t>(w.Pp);
+        GemmGroup g;
+        memset(&g, 0, sizeof(g));
+        g.count = 1;
+        GemmProblem& p = g.p[0];
+        p.A = dP; p.B = h->P + h->plan.ntp; p.C = dxs;
+        p.M = T * n + n * 256; p.N = d; p.K = d; p.lda = d; p.ldb = d; p.ldc = d;
+        p.m_dev = h->wsp<int32_t>(w.ss_total);
+        p.a_rows = h->wsp<int32_t>(w.ss_cell); p.b_tile_off = h->wsp<int32_t>(w.ss_tile);
+        p.b_tile_rows = head_tile_rows(d);
+        if (int e = gget_gemm_launch(GGET_GEMM_NN, GGET_EPI_NONE, g, 1, st)) return e;
+        if (int e = k_head_cell_sum(dxs, h->wsp<int32_t>(w.ss_pos), h->wsp<int32_t>(w.cnt), h->wsp<int32_t>(w.l_off),
+                                    h->varlen ? h->wsp<int32_t>(w.vl_pad2c) : nullptr, dhid, T, d, h->T > h->tc ? h->tc : 0, st))
+          return e;
+      } else if (head_scatter_fused()) {
         if (int e = gemm_nn(dP, h->P + h->plan.ntp, dhid, T, d, n * d, n * d, d, d, counts, st, h->wsp<int32_t>(w.row_idx))) return e;
       } else if (int e = gemm_nn(dP, h->P + h->plan.ntp, h->wsp<bf16_t>(w.dHm), T, d, n * d, n * d, d, d, counts, st)) return e;
       if (int e = gget_gemm_single(GGET_GEMM_TN, GGET_EPI_NONE, dP, h->wsp<bf16_t>(w.Hm), h->G + h->plan.ntp, nullptr, n * d, d,
                                    T, n * d, d, d, nullptr, counts, 1, st, /*k_pad_zero=*/true))   // dP is cleared above, Hm is finite
         return e;
     }
-    if (!(h->plan.has_ntp && head_scatter_fused()))
+    if (!(h->plan.has_ntp && (head_scatter_fused() || h->head_sorted_fwd)))
       if (int e = k_gather_rows(h->wsp<bf16_t>(w.dHm), h->wsp<int32_t>(w.row_idx), counts, dhid, T, d, 1, st)) return e;
   } else if (h->plan.n_lin > 0) {
     const Plan& pl = h->plan;
@@ -1831,6 +1891,8 @@ extern "C" int gget_debug_set(int key, int value) {
     case 3: g_gemm_split_last = value; return 0;
     case 5: g_gemm_stagger_ticks = value; return 0;
     case 7: g_gemm_ablate_set = value > 0 ? value : -1; return 0;
+    case 8: g_head_dense = value; return 0;
+    case 9: g_head_tile = value; return 0;
   }
   gget_set_error("debug_set: unknown key %d", key);
   return 2;

@@ -32,6 +32,13 @@ struct GemmProblem {
   // EPI_NONE only: row m of the product is stored at row c_rows[m] of C (a scatter fused into the epilogue: the SMTP head's
   // dHl -> dP and dHm -> d hidden, which were separate gather_rows launches); nullptr = row m
   const int* c_rows;
+  // Slot-sorted SMTP head (engine.hip, round 4; single-problem NT / NN launches through the 128 x 192 persistent tile):
+  //  a_rows     - row m of the product reads row a_rows[m] of A (a gather fused into the LDS-DMA's per-lane source offsets);
+  //  b_tile_off - the B operand of the 128-row tile mt starts b_tile_off[mt] ELEMENTS behind B (one n_token_proj slot per row tile);
+  //  with c_rows, a NEGATIVE entry means "row not stored" (the pad rows that fill a slot's last tile).
+  const int* a_rows;
+  const int* b_tile_off;
+  int b_tile_rows;          // rows per tile of b_tile_off: 128 (128 x 192 tiles) or 256 (256 x 256 tiles, N % 256 == 0)
 };
 
 struct GemmGroup {

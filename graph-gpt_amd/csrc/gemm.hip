@@ -179,12 +179,13 @@ struct TileIO {
     const int q = wave + i * NWAVES;
     return WRAP && q >= NPIECE ? q - NPIECE : q;
   }
-  __device__ __forceinline__ static unsigned piece_off(int ld, int row0, int row_lim, int wave, int lane, int i) {
+  __device__ __forceinline__ static unsigned piece_off(int ld, int row0, int row_lim, int wave, int lane, int i, const int* rows = nullptr) {
     const int q = piece_index(wave, i);
     if (!MC) {
       const int r = q * RPP + lane / CR;
       const int lc = (lane % CR) ^ kc_swz(r);
-      const int gr = min(row0 + r, row_lim - 1);
+      int gr = min(row0 + r, row_lim - 1);
+      if (rows) gr = rows[gr];     // fused row gather (GemmProblem::a_rows)
       return ((unsigned)gr * (unsigned)ld + (unsigned)(lc * 8)) * 2u;
     } else {
       const int c = q * 64 + lane;
@@ -566,8 +567,10 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
         fetch_res(i);
         const int m = mw + i * 16 + l15;          // the row whose values this lane holds before the regrouping
         const int ma = mw + i * 16 + (l15 & 7), mb = ma + 8;
-        const size_t ra = crows && ma < M ? (size_t)crows[ma] : (size_t)ma, rb = crows && mb < M ? (size_t)crows[mb] : (size_t)mb;
-        const size_t rm = crows && m < M ? (size_t)crows[m] : (size_t)m;
+        // (a negative c_rows entry = row not stored: folded into the row test by moving the row behind M)
+        const int ia = crows && ma < M ? crows[ma] : ma, ib = crows && mb < M ? crows[mb] : mb, im = crows && m < M ? crows[m] : m;
+        const size_t ra = (size_t)max(ia, 0), rb = (size_t)max(ib, 0), rm = (size_t)max(im, 0);
+        const int ma_ = ia < 0 ? M : ma, mb_ = ib < 0 ? M : mb, m_ = im < 0 ? M : m;
 #pragma unroll
         for (int jq = 0; jq < NJ / 4; ++jq) {
           const int ja = 2 * jq + lead;           // group = (ja, ja + 1): 64 columns from nw + 32 * ja
@@ -581,19 +584,19 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
           const uint4 pb = low ? xr : y;
           const int n = nw + ja * 32 + (low ? c0 : c0 + 4) * 8;
           if (n + 8 <= N) {
-            if (ma < M) stc16(C + ra * P.ldc + n, pa);
-            if (mb < M) stc16(C + rb * P.ldc + n, pb);
+            if (ma_ < M) stc16(C + ra * P.ldc + n, pa);
+            if (mb_ < M) stc16(C + rb * P.ldc + n, pb);
           } else if (n < N) {
-            if (ma < M) *reinterpret_cast<uint2*>(C + ra * P.ldc + n) = make_uint2(pa.x, pa.y);
-            if (mb < M) *reinterpret_cast<uint2*>(C + rb * P.ldc + n) = make_uint2(pb.x, pb.y);
+            if (ma_ < M) *reinterpret_cast<uint2*>(C + ra * P.ldc + n) = make_uint2(pa.x, pa.y);
+            if (mb_ < M) *reinterpret_cast<uint2*>(C + rb * P.ldc + n) = make_uint2(pb.x, pb.y);
           }
         }
         if constexpr (NJ == 6) {   // the remaining 32 columns: 16 rows x 64 B per instruction
           const int jl = lead ? 0 : 2;
           const uint4 z = lead ? piece(i, 0, m) : piece(i, NJ / 2 - 1, m);
           const int n = nw + jl * 32 + c0 * 8;
-          if (m < M && n + 8 <= N) stc16(C + rm * P.ldc + n, z);
-          else if (m < M && n < N) *reinterpret_cast<uint2*>(C + rm * P.ldc + n) = make_uint2(z.x, z.y);
+          if (m_ < M && n + 8 <= N) stc16(C + rm * P.ldc + n, z);
+          else if (m_ < M && n < N) *reinterpret_cast<uint2*>(C + rm * P.ldc + n) = make_uint2(z.x, z.y);
         }
       }
       return;
@@ -618,6 +621,7 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
       }
       const int n = nw + (odd ? col_of(2 * jp + 1) : col_of(2 * jp)) + (gq & 2) * 4;
       if (m >= M || n >= N) continue;
+      if (EPI == GGET_EPI_NONE && P.c_rows && P.c_rows[m] < 0) continue;
       if (EPI == GGET_EPI_SLAB_F32) {
         float* fp = reinterpret_cast<float*>(P.C) + (size_t)kslice * P.slab_stride + (size_t)m * P.ldc + n;
         *reinterpret_cast<float4*>(fp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -949,8 +953,10 @@ __global__ void __launch_bounds__(WM * WN * 64, MODE == 2 ? 4 : ((WM * WN) >= 8 
     strideB = B_MC ? (long)BK * P.ldb * 2 : (long)BK * 2;
     kA = reinterpret_cast<const unsigned char*>(P.A) + (SK ? ic.kb * strideA : 0);
     kB = reinterpret_cast<const unsigned char*>(P.B) + (SK ? ic.kb * strideB : 0);
+    if (P.b_tile_off)     // (slot-sorted head: one weight block per row tile; the value is wave-uniform - tell the compiler, kB feeds an SGPR pair)
+      kB += (long)__builtin_amdgcn_readfirstlane(P.b_tile_off[__builtin_amdgcn_readfirstlane(ic.m0) / BM]) * 2;
 #pragma unroll
-    for (int i = 0; i < TA::PIECES; ++i) offA[i] = TA::piece_off(P.lda, ic.m0, ic.M, wave, lane, i);
+    for (int i = 0; i < TA::PIECES; ++i) offA[i] = TA::piece_off(P.lda, ic.m0, ic.M, wave, lane, i, A_MC ? nullptr : P.a_rows);
 #pragma unroll
     for (int i = 0; i < TB::PIECES; ++i) {
       if constexpr (EPI == GGET_EPI_GEGLU_FWD) offB[i] = TB::template piece_off_geglu<BN / WN>(P.ldb, ic.n0, P.ff, wave, lane, i);
@@ -1927,6 +1933,32 @@ int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t s
     GGET_HIP_CHECK(hipEventRecord(rec->e0, st));
   }
   int rc = 2;
+  if (g.count == 1 && (g.p[0].b_tile_off || g.p[0].a_rows)) {
+    // slot-sorted head GEMM: a fixed configuration (128-row tiles = the granule the caller padded its slots to)
+    GemmProblem& p = g.p[0];
+    GGET_REQUIRE((mode == GGET_GEMM_NT || mode == GGET_GEMM_NN) && epi == GGET_EPI_NONE && split_k <= 1 && p.m_dev && !p.k_dev &&
+                 (p.N % 192) == 0 && (p.K % 64) == 0 && p.K >= 64,
+                 "gemm: a_rows / b_tile_off need a single NT / NN problem with the plain epilogue, a device-side row count, N %% 192 == 0 and K %% 64 == 0");
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      GGET_HIP_CHECK(hipGetDevice(&dev));
+      GGET_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+      ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const bool big = p.b_tile_rows == 256 && (p.N % 256) == 0;
+    p.tiles_n = big ? p.N / 256 : p.N / 192;
+    p.tile_begin = 0;
+    const int total = big ? ((p.M + 255) / 256) * p.tiles_n : ((p.M + 127) / 128) * p.tiles_n;
+    if (total <= 0) rc = 0;
+    else if (big && mode == GGET_GEMM_NT) rc = launch_persist_cfg<256, 256, 64, 2, 4, false, false, GGET_EPI_NONE, 2>(g, total, ncu, st);
+    else if (big) rc = launch_persist_cfg<256, 256, 32, 2, 4, false, true, GGET_EPI_NONE>(g, total, ncu, st);
+    else if (mode == GGET_GEMM_NT) rc = launch_persist_cfg<128, 192, 64, 4, 2, false, false, GGET_EPI_NONE, 3>(g, total, ncu, st);
+    else rc = launch_persist_cfg<128, 192, 64, 4, 2, false, true, GGET_EPI_NONE, 3>(g, total, ncu, st);
+    if (rec) GGET_HIP_CHECK(hipEventRecord(rec->e1, st));
+    return rc;
+  }
   switch (mode) {
     case GGET_GEMM_NT: rc = launch_mode<false, false>(g, epi, split_k, st); break;
     case GGET_GEMM_NN: rc = launch_mode<false, true>(g, epi, split_k, st); break;

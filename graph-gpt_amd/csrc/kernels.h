@@ -65,6 +65,11 @@ int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, int32_
 // out = clamp(pos, 0, max_pos - 1); *flag = 1 (sticky) if anything was clamped
 int k_clamp_positions(const int64_t* pos, int64_t* out, int32_t* flag, long n, int max_pos, hipStream_t st);
 int k_remap_rows(int32_t* idx, const int32_t* count, const int32_t* pad2c, int cap, int pad_row, int32_t* status, hipStream_t st);
+int k_head_slot_sort(const int32_t* sel_src, const int32_t* row_idx, const int32_t* lm_count, int32_t* slot_state, int32_t* a_tok,
+                     int32_t* a_cell, int32_t* c_l, int32_t* cellpos, int32_t* tile_off, int32_t* total_p, int cap, int n, long slot_elems,
+                     int tile_rows, hipStream_t st);
+int k_head_cell_sum(const void* dxs, const int32_t* cellpos, const int32_t* cnt, const int32_t* l_off, const int32_t* pad2c, void* dhid,
+                    int TP, int d, int pad_row, hipStream_t st);
 int k_poison_loss(const int32_t* flag, float* loss, hipStream_t st);
 int k_sum_lengths(const int32_t* key_len, int B, int32_t* out, hipStream_t st);
 int k_head_compact(const int64_t* labels, int T, int n, int32_t* cnt, int32_t* m_off, int32_t* l_off, int32_t* counts,

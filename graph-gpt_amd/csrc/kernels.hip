@@ -753,6 +753,125 @@ __global__ void __launch_bounds__(kBlock) head_fill_kernel(const int64_t* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Slot-sorted SMTP head (round 4).  The reference projects every selected row through ALL n slots of n_token_proj and then keeps the
+// labelled cells (modeling_helpers.py:263-301: `proj(hidden_states[mask_m])`, `hidden_states[mask.reshape(-1)]`) - half of that product
+// is thrown away (SMTP masks ~50 % of the cells of a selected row).  Here the labelled cells are sorted by slot, every slot padded to a
+// multiple of 128 rows, so that ONE GEMM over the sorted cells with a per-row-tile weight block W_f computes exactly the kept rows:
+//   Hl[l] = hidden[tok(l)] . W_f(l)^T         (forward:  A rows gathered, C rows scattered back to the cells' (m, f) order)
+//   dXs[p] = dP[cell(p)] . W_f(p)             (backward: one row per cell; head_cell_sum adds a token's cells into d hidden)
+// slot_state: [0, n) cell counts, [n, 2n) fill cursors, [2n, 3n + 1) padded slot starts.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) slot_hist_kernel(const int32_t* __restrict__ sel_src, const int32_t* __restrict__ count,
+                                                           int32_t* __restrict__ slot_state, int cap, int n) {
+  __shared__ int hist[32];
+  if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int lm = min(cap, *count);
+  for (int l = blockIdx.x * kBlock + threadIdx.x; l < lm; l += gridDim.x * kBlock) atomicAdd(&hist[sel_src[l] % n], 1);
+  __syncthreads();
+  if ((int)threadIdx.x < n && hist[threadIdx.x]) atomicAdd(&slot_state[threadIdx.x], hist[threadIdx.x]);
+}
+// one block: padded slot starts, the cursors, the per-row-tile weight offsets, the defaults of the pad rows, the padded total
+__global__ void __launch_bounds__(kBlock) slot_plan_kernel(int32_t* __restrict__ slot_state, int32_t* __restrict__ a_tok,
+                                                           int32_t* __restrict__ a_cell, int32_t* __restrict__ c_l,
+                                                           int32_t* __restrict__ tile_off, int32_t* __restrict__ total_p, int n,
+                                                           long slot_elems, int kSlotPad) {     // kSlotPad = row-tile height of the consuming GEMM
+  __shared__ int start[33];
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int f = 0; f < n; ++f) {
+      start[f] = acc;
+      slot_state[n + f] = acc;              // cursor
+      slot_state[2 * n + f] = acc;
+      acc += (slot_state[f] + kSlotPad - 1) / kSlotPad * kSlotPad;
+    }
+    start[n] = acc;
+    slot_state[3 * n] = acc;
+    *total_p = acc;
+  }
+  __syncthreads();
+  for (int f = 0; f < n; ++f) {
+    const int lo = start[f] + slot_state[f], hi = start[f + 1];
+    for (int p = lo + threadIdx.x; p < hi; p += kBlock) { a_tok[p] = 0; a_cell[p] = 0; c_l[p] = -1; }     // pad rows: read row 0, store nothing
+    for (int t = start[f] / kSlotPad + threadIdx.x; t < start[f + 1] / kSlotPad; t += kBlock) tile_off[t] = (int32_t)((long)f * slot_elems);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n) slot_state[threadIdx.x] = 0;     // the histogram of the NEXT forward starts from zero (no memset launch)
+}
+// positions inside a slot: every block ranks the cells of its chunk per slot in LDS and reserves ONE range per slot from the global
+// cursors (13 global atomics per block; one per cell - 37 k atomics on 13 addresses - took 83 us)
+constexpr int kFillItems = 4;
+__global__ void __launch_bounds__(kBlock) slot_fill_kernel(const int32_t* __restrict__ sel_src, const int32_t* __restrict__ row_idx,
+                                                           const int32_t* __restrict__ count, int32_t* __restrict__ slot_state,
+                                                           int32_t* __restrict__ a_tok, int32_t* __restrict__ a_cell,
+                                                           int32_t* __restrict__ c_l, int32_t* __restrict__ cellpos, int cap, int n) {
+  __shared__ int cnt_s[32], base_s[32];
+  const int lm = min(cap, *count);
+  const int l0 = blockIdx.x * (kBlock * kFillItems);
+  if (l0 >= lm) return;
+  if (threadIdx.x < 32) cnt_s[threadIdx.x] = 0;
+  __syncthreads();
+  int cell[kFillItems], rank[kFillItems];
+#pragma unroll
+  for (int i = 0; i < kFillItems; ++i) {
+    const int l = l0 + i * kBlock + threadIdx.x;
+    cell[i] = l < lm ? sel_src[l] : -1;
+    rank[i] = cell[i] >= 0 ? atomicAdd(&cnt_s[cell[i] % n], 1) : 0;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n) base_s[threadIdx.x] = cnt_s[threadIdx.x] ? atomicAdd(&slot_state[n + threadIdx.x], cnt_s[threadIdx.x]) : 0;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kFillItems; ++i) {
+    if (cell[i] < 0) continue;
+    const int l = l0 + i * kBlock + threadIdx.x;
+    const int p = base_s[cell[i] % n] + rank[i];     // (order inside a slot is arbitrary: every row of the products is independent)
+    a_tok[p] = row_idx[cell[i] / n];
+    a_cell[p] = cell[i];
+    c_l[p] = l;
+    cellpos[l] = p;
+  }
+}
+// d hidden[row_idx[m]] = sum over the labelled cells of selected row m of dXs[cellpos[l]] (fp32 sum in slot order, one bf16 rounding);
+// one wave per selected row, cells l_off[t] .. l_off[t] + cnt[t] of token t = row order of the compaction
+__global__ void __launch_bounds__(kBlock) head_cell_sum_kernel(const bf16_t* __restrict__ dxs, const int32_t* __restrict__ cellpos,
+                                                               const int32_t* __restrict__ cnt, const int32_t* __restrict__ l_off,
+                                                               const int32_t* __restrict__ pad2c, bf16_t* __restrict__ dhid, int TP, int d,
+                                                               int pad_row) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (t >= TP) return;
+  const int c = cnt[t];
+  if (c == 0) return;
+  const int l0 = l_off[t];
+  int row = t;
+  if (pad2c) { row = pad2c[t]; if (row < 0) row = pad_row; }       // var-len layout: the token's compact row (remap_rows_kernel's rule)
+  // the token's cell rows (<= 32 of them): lane j holds the row of cell j, broadcast below; four row loads in flight per lane
+  const int myrow = lane < c ? cellpos[l0 + lane] : 0;
+  for (int ch = lane; ch < (d >> 3); ch += 64) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < c; j += 4) {
+      uint4 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = __shfl(myrow, min(j + u, c - 1), 64);
+        q[u] = ldg16(dxs + (size_t)r * d + ch * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (j + u < c) {
+          float v[8];
+          unpack8(q[u], v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+      }
+    }
+    stg16(dhid + (size_t)row * d + ch * 8, pack8(acc));
+  }
+}
+
 // dst[i,:] = src[idx[i],:]  (i < *count)   /   scatter: dst[idx[i],:] = src[i,:]
 __global__ void __launch_bounds__(kBlock) gather_rows_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ idx,
                                                              const int32_t* __restrict__ count, bf16_t* __restrict__ dst,
@@ -2122,6 +2241,26 @@ int k_sum_lengths(const int32_t* key_len, int B, int32_t* out, hipStream_t st) {
 int k_remap_rows(int32_t* idx, const int32_t* count, const int32_t* pad2c, int cap, int pad_row, int32_t* status, hipStream_t st) {
   if (cap == 0) return 0;
   hipLaunchKernelGGL(remap_rows_kernel, dim3(grid_for(cap)), dim3(kBlock), 0, st, idx, count, pad2c, cap, pad_row, status);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_head_slot_sort(const int32_t* sel_src, const int32_t* row_idx, const int32_t* lm_count, int32_t* slot_state, int32_t* a_tok,
+                     int32_t* a_cell, int32_t* c_l, int32_t* cellpos, int32_t* tile_off, int32_t* total_p, int cap, int n, long slot_elems,
+                     int tile_rows, hipStream_t st) {
+  if (n > 32) { gget_set_error("slot-sorted head: next_n_token %d > 32", n); return 2; }
+  // (slot_state[0, n) is zero here: cleared with the workspace at creation and by every slot_plan_kernel after it consumed the counts)
+  hipLaunchKernelGGL(slot_hist_kernel, dim3(grid_for(cap, kBlock, 256)), dim3(kBlock), 0, st, sel_src, lm_count, slot_state, cap, n);
+  hipLaunchKernelGGL(slot_plan_kernel, dim3(1), dim3(kBlock), 0, st, slot_state, a_tok, a_cell, c_l, tile_off, total_p, n, slot_elems, tile_rows);
+  hipLaunchKernelGGL(slot_fill_kernel, dim3((cap + kBlock * kFillItems - 1) / (kBlock * kFillItems)), dim3(kBlock), 0, st, sel_src, row_idx, lm_count, slot_state, a_tok,
+                     a_cell, c_l, cellpos, cap, n);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+int k_head_cell_sum(const void* dxs, const int32_t* cellpos, const int32_t* cnt, const int32_t* l_off, const int32_t* pad2c, void* dhid,
+                    int TP, int d, int pad_row, hipStream_t st) {
+  hipLaunchKernelGGL(head_cell_sum_kernel, dim3((TP + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const bf16_t*)dxs, cellpos, cnt,
+                     l_off, pad2c, (bf16_t*)dhid, TP, d, pad_row);
   GGET_LAUNCH_CHECK();
   return 0;
 }

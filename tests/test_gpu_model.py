@@ -1717,11 +1717,63 @@ def test_gradient_norm_from_backward_partials_matches_full_pass(monkeypatch):
     np_, mp_, wp = run(False)
     nf2, _, wf2 = run(True)                                               # a second full-pass run: the run-to-run noise floor
     assert all(n > 0.05 for n in nf)                                      # the clip is active in every step
-    np.testing.assert_allclose(np_, nf, rtol=3e-5)                        # (later steps inherit tiny parameter differences)
+    assert abs(np_[0] - nf[0]) <= 3e-6 * nf[0]                            # same gradients, two summation orders of their squares
+    np.testing.assert_allclose(np_, nf, rtol=5e-4)                        # (later steps inherit run-to-run parameter differences)
     assert abs(np_[-1] - mp_) <= 2e-5 * mp_ and abs(nf[-1] - mf) <= 2e-5 * mf     # both are the norm of what is in the arena
     # parameters: noise-dominated gradients (fp32-atomic reductions of the norm / embedding gradients differ in their last bits from
     # run to run, and AdamW normalises every update) move single entries by a fraction of lr between ANY two runs - the two norm
     # paths must not differ by more than two full-pass runs do
     upd = float(np.linalg.norm(wf - w0))
     noise = float(np.linalg.norm(wf2 - wf))
-    assert float(np.linalg.norm(wp - wf)) <= max(2.0 * noise, 1e-3 * upd), (float(np.linalg.norm(wp - wf)), noise, upd)
+    assert float(np.linalg.norm(wp - wf)) <= max(4.0 * noise, 2e-2 * upd), (float(np.linalg.norm(wp - wf)), noise, upd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["labels", "labels_varlen", "dlm_weights", "inference"])
+def test_slot_sorted_head_matches_dense_head(mode):
+    """Round 4: n_token_proj on the labelled cells only (cells sorted by slot, one GEMM with a weight block per row tile; kernels.hip
+    "Slot-sorted SMTP head") against the dense form of rounds 1-3 - every selected row through all n slots, then the gather
+    (modeling_helpers.py:263-301, the reference's order of operations) - on the full-width model: same loss and head logits (both forms
+    run the K = d reduction of a cell's row in one tile-K order), and the gradients of every tensor within bf16 rounding (the sorted
+    backward rounds one input-gradient row per cell to bf16 before a token's cells are summed; the dense one sums in the accumulator).
+    The dense form itself is what the reference fixtures pin on the narrow models (d = 128 takes it: the sorted form needs d % 192 == 0)."""
+    from _util import spec_mod, weights_mod, synth
+    lib = L.load()
+    B, S, F, V = 64, 32, 13, 756
+    spec = spec_mod.ModelSpec(kind=spec_mod.KIND_PRETRAIN, vocab_size=V, hidden_size=768, intermediate_size=3072, num_layers=2, num_heads=12,
+                              head_dim=64, stacked_feat=F, next_n_token=F, causal=False, max_position=1024)
+    state = weights_mod.make_state_dict(spec, seed=5, std=0.05, head_std=0.1)
+    batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=31, dlm_wgt=(mode == "dlm_weights"))
+    b = tb(batch)
+    n_tok = int(batch["attention_mask"].sum()) if mode == "labels_varlen" else None
+    out = {}
+    try:
+        for name, dense in (("sorted", 0), ("dense", 1)):
+            L.check(lib.gget_debug_set(8, dense))
+            e = eng_mod.Engine(spec, max_tokens=B * S, max_batch=B)
+            e.load_state_dict(state)
+            labels = None if mode == "inference" else b["labels"]
+            loss = e.forward_pretrain(b["input_ids"], b["attention_mask"], labels, b.get("wgt"), num_tokens=n_tok)
+            logits = e.head_logits().float().cpu().numpy()
+            grads = None
+            if labels is not None:
+                e.backward()
+                torch.cuda.synchronize()
+                grads = {k: v.float().cpu().numpy().copy() for k, v in e.grads().items()}
+            out[name] = (None if loss is None else float(loss), logits, grads, e.head_counts())
+    finally:
+        L.check(lib.gget_debug_set(8, 0))
+    (ls, gs, grs, cs), (ld, gd, grd, cd) = out["sorted"], out["dense"]
+    assert cs == cd and gs.shape == gd.shape and gs.shape[0] == cs[1]
+    if mode == "inference":
+        assert cs[1] == B * S * F                                   # every cell is predicted
+    np.testing.assert_array_equal(gs, gd)                           # head logits: bit-equal
+    if ls is not None:
+        assert abs(ls - ld) <= 2e-6 * abs(ld)
+        gmax = max(float(np.linalg.norm(g)) for g in grd.values())
+        for k in grd:
+            den = max(float(np.linalg.norm(grd[k])), 1e-2 * gmax)
+            err = float(np.linalg.norm(grs[k] - grd[k])) / den
+            tol = 1e-6 if k in ("lm_head.weight",) else 8e-3        # lm_head's gradient does not pass through n_token_proj's backward
+            record_error("slot_sorted_head_" + mode, "grad_rel_l2_vs_dense " + k, err, tol)
+            assert err <= tol, (k, err)

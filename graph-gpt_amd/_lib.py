@@ -86,6 +86,7 @@ SIGNATURES = {
     "gget_op_attn_fwd_ranges": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint32, vp]),
     "gget_op_attn_bwd_ranges": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint32, vp]),
     "gget_op_ranges_from_mask3d": (i32, [vp, vp, vp, i32, i32, vp]),
+    "gget_op_attn_bwd_fused": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint32, vp]),
     "gget_set_dropout": (i32, [vp, f32, f32, C.c_uint32]),
     "gget_set_auc": (i32, [vp, i32, C.c_uint32]),
     "gget_set_token_count": (i32, [vp, C.c_int64]),

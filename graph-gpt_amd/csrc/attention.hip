@@ -1674,6 +1674,324 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
   }
 }
 
+// ================================================================================================
+// Fused backward for long sequences (round 4): dK, dV AND dQ from ONE pass over the (key tile, query tile) pairs - S, dP and the
+// softmax backward are computed once instead of twice (5 matmuls instead of the 7 of the dQ + dK/dV kernel pair).
+// Built on attn_bwd_dkv64_kernel (a wave owns 32 keys, Q / dO streamed in 64-query stages); what is new is the dQ side:
+//  * a wave holds dS with its KEY along the lanes and the queries along the registers - the layout dK += dS^T Q wants, the transpose
+//    of what dQ += dS K wants.  The bf16 dS tile goes to LDS as [key row][64 queries of the stage] (4 x ds_write_b64 per tile, the
+//    swizzle of every [32][128 B] tile here), and is read back through the transposing read as the A operand (m = query, k = key) of
+//    v_mfma_f32_16x16x32_bf16; the B operand (k = key, n = head channel) comes the same way from the block's 256 K rows, kept in LDS.
+//  * the 64 x 64 dQ tile of a stage is 16 blocks of 16 x 16; each of the 8 waves owns two of them (one 16-channel column block, two
+//    16-query row blocks) and reduces them over ALL 256 keys of the block - 16 MFMAs per wave and stage, no cross-wave reduction.
+//  * the dS buffer is double-buffered by stage: the dQ MFMAs of stage t run at the top of stage t + 1, behind the barrier the stage
+//    loop has anyway.
+//  * every key block writes its dQ tiles as bf16 into its OWN slab [rows][d] (plain 8-byte stores, the MFMA run with K as the first
+//    operand so that a lane holds 4 consecutive channels); attn_dq_finish_kernel adds the S / 256 slabs of a row in fp32, in block order,
+//    rotates the row back (q is stored rotated) and writes the bf16 dq part of dqkv.  Reproducible; costs one extra bf16 rounding of
+//    every 256-key partial sum.  First version: fp32 atomics into one accumulator - 8 wave-atomics per wave and stage are 0.8 GB of
+//    read-modify-write per layer at the memory side (the L2s are per XCD): B16 / S2048 / H12 backward 959 us; 16 atomics (32 x 32 output
+//    quadrants, a third less fragment traffic) 1373 us.
+// delta = rowsum(dO * O) comes from attn_delta_kernel (it was a by-product of the dQ kernel).
+// ================================================================================================
+// 16x16x32 MFMA operand from a swizzled [32 rows][128 B] tile: the operand's M / N index runs along 16 tile columns (bf16 column col0 on),
+// its k index along the 32 tile rows: lane (c = l % 16, g = l / 16) gets column col0 + c, rows 8 g .. 8 g + 7
+__device__ __forceinline__ bf16x8_t frag_tr16(const unsigned char* tile, int col0, int lane) {
+  const int li = lane & 15, g = lane >> 4;
+  const int colb = (col0 + (li & 3) * 4) * 2;
+  const int ra = 8 * g + (li >> 2);
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(tile + swz(ra, colb)));
+  const bf16x4_t up = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(tile + swz(ra + 4, colb)));
+  bf16x8_t o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+  o[4] = up[0]; o[5] = up[1]; o[6] = up[2]; o[7] = up[3];
+  return o;
+}
+
+// delta[b, h, q] = sum_dh dO * O   (the softmax-backward row term; [B,H,S]-indexed like lse).  Block = 32 rows x 8 lanes.
+__global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, float* __restrict__ delta,
+                                                         const int32_t* __restrict__ key_len, const int32_t* __restrict__ row_base, int S, int H) {
+  const int b = blockIdx.y, q = blockIdx.x * 32 + (threadIdx.x >> 3), ch = threadIdx.x & 7;
+  const int rb = row_base ? row_base[b] : b * S;
+  const int SL = row_base ? key_len[b] : S;
+  if (q >= SL) {           // (whole groups of 8 lanes leave together) rows of the [B,H,S] grid without a token: a finite value
+    if (q < S && ch == 0)
+      for (int h = 0; h < H; ++h) delta[((size_t)b * H + h) * S + q] = 0.f;
+    return;
+  }
+  const size_t d = (size_t)H * 64;
+  const bf16_t* o = out + ((size_t)rb + q) * d + ch * 8;
+  const bf16_t* g = dout + ((size_t)rb + q) * d + ch * 8;
+  for (int h = 0; h < H; ++h) {
+    float a[8], c[8];
+    unpack8(*reinterpret_cast<const uint4*>(o + h * 64), a);
+    unpack8(*reinterpret_cast<const uint4*>(g + h * 64), c);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf(a[e], c[e], s);
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    if (ch == 0) delta[((size_t)b * H + h) * S + q] = s;
+  }
+}
+
+// dq rows: the key blocks' bf16 partials are summed in fp32 (in block order: reproducible), rotated back, written as bf16 into the q part of
+// dqkv.  Key block kb wrote the rows [causal ? 256 kb : 0, min(row length, S)) of its slab when it held a visible key (kb * 256 < length);
+// packed rows (ranges): every block writes every row.  8 lanes per (row, head): lane c holds channels [4 c, 4 c + 4) and [32 + 4 c, + 4)
+// (the rotation pairs j <-> j + 32).
+__global__ void __launch_bounds__(256) attn_dq_finish_kernel(const bf16_t* __restrict__ slabs, size_t slab_stride, bf16_t* __restrict__ dqkv,
+                                                             const int32_t* __restrict__ key_len, const int32_t* __restrict__ row_base, int S, int H,
+                                                             int causal, int ranges, Rope R) {
+  const int b = blockIdx.z, h = blockIdx.y, q = blockIdx.x * 32 + (threadIdx.x >> 3), c = threadIdx.x & 7;
+  const int rb = row_base ? row_base[b] : b * S;
+  const int SL = row_base ? key_len[b] : S;
+  if (q >= SL) return;
+  const int len = ranges ? S : (key_len ? min(key_len[b], S) : S);
+  int nkb = q < len ? (len + 255) / 256 : 0;
+  if (causal) nkb = min(nkb, q / 256 + 1);
+  const size_t d = (size_t)H * 64;
+  const bf16_t* a = slabs + ((size_t)rb + q) * d + h * 64 + 4 * c;
+  float lo[4] = {0.f, 0.f, 0.f, 0.f}, up[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int kb = 0; kb < nkb; ++kb) {
+    const uint2 l = *reinterpret_cast<const uint2*>(a + (size_t)kb * slab_stride);
+    const uint2 u = *reinterpret_cast<const uint2*>(a + (size_t)kb * slab_stride + 32);
+    lo[0] += __uint_as_float(l.x << 16); lo[1] += __uint_as_float(l.x & 0xffff0000u);
+    lo[2] += __uint_as_float(l.y << 16); lo[3] += __uint_as_float(l.y & 0xffff0000u);
+    up[0] += __uint_as_float(u.x << 16); up[1] += __uint_as_float(u.x & 0xffff0000u);
+    up[2] += __uint_as_float(u.y << 16); up[3] += __uint_as_float(u.y & 0xffff0000u);
+  }
+  if (R.cos_tab) {
+    const int pos = rope_pos(R, b, q);
+    const float4 cs4 = *reinterpret_cast<const float4*>(R.cos_tab + (size_t)pos * 32 + 4 * c);
+    const float4 sn4 = *reinterpret_cast<const float4*>(R.sin_tab + (size_t)pos * 32 + 4 * c);
+    const float cs[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, sn[4] = {sn4.x, sn4.y, sn4.z, sn4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float l2 = lo[e] * cs[e] + up[e] * sn[e], u2 = up[e] * cs[e] - lo[e] * sn[e];
+      lo[e] = l2; up[e] = u2;
+    }
+  }
+  bf16_t* o = dqkv + ((size_t)rb + q) * 3 * d + h * 64 + 4 * c;
+  *reinterpret_cast<uint2*>(o) = make_uint2(pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]));
+  *reinterpret_cast<uint2*>(o + 32) = make_uint2(pack2bf(up[0], up[1]), pack2bf(up[2], up[3]));
+}
+
+constexpr int kFusedLds = 2 * 2 * 8192 + 2 * 8 * 4096 + 8 * 4096 + 4 * 64 * 4 + 4 * 64 * 4;   // stages + dS (x2) + K + lse / delta (+ key ranges)
+template <bool PK>
+__global__ void __launch_bounds__(512, 2) attn_bwd_fused64_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                  KeyRange KR, bf16_t* __restrict__ dqkv, bf16_t* __restrict__ dq_slabs, size_t slab_stride,
+                                                                  int B, int S, int H, int causal, Drop D, Rope Rout) {
+  constexpr int NWB = 8, STG = 64, ARR = STG * 128, NTILE = 2, DQB = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  unsigned char (*st)[2 * ARR] = reinterpret_cast<unsigned char (*)[2 * ARR]>(fsm);                     // [2][16 KiB]: Q | dO of a stage
+  unsigned char (*dsb)[NWB * 4096] = reinterpret_cast<unsigned char (*)[NWB * 4096]>(fsm + 2 * 2 * ARR);   // [2][32 KiB]: dS of a stage
+  unsigned char* kt_s = fsm + 2 * 2 * ARR + 2 * NWB * 4096;                                                // 32 KiB: the block's K rows
+  float (*lse_s)[STG] = reinterpret_cast<float (*)[STG]>(kt_s + NWB * 4096);
+  float (*dl_s)[STG] = lse_s + 2;
+  int (*qlo_s)[STG] = reinterpret_cast<int (*)[STG]>(dl_s + 2);
+  int (*qhi_s)[STG] = qlo_s + 2;
+  constexpr int KB = NWB * 32;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int rb = KR.row_base ? KR.row_base[b] : b * S;
+  const int SL = KR.row_base ? KR.key_len[b] : S;
+  const int k0 = blockIdx.x * KB + wave * 32;
+  const int d = H * 64;
+  const size_t pitch = (size_t)3 * d;
+  const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
+  const bf16_t* kb = qb + d;
+  const bf16_t* vb = qb + 2 * d;
+  const bf16_t* dob = dout + (size_t)rb * d + h * 64;
+  bf16_t* dq_slab = dq_slabs + (size_t)blockIdx.x * slab_stride;      // this key block's dQ partials
+  const int klen = PK ? S : (KR.key_len ? KR.key_len[b] : S);
+  const int krow = k0 + l31;
+  bf16x8_t kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = frag_global(kb, krow, SL, pitch, s, lane);
+    vf[s] = frag_global(vb, krow, SL, pitch, s, lane);
+  }
+  load_tile(kt_s + wave * 4096, kb, k0, SL, pitch, lane);      // (read by every wave from stage 1 on: behind the stage barrier)
+  f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+  const unsigned dbase = drop_base(D, b * H + h, 0, (unsigned)krow >> 1);
+  const int kodd = krow & 1;
+  const bool key_ok = krow < klen;
+  const int kblk0 = blockIdx.x * KB;
+  const int qbeg = causal ? (kblk0 & ~(STG - 1)) : 0;
+  const int qlim = PK ? S : min(S, klen);
+  const int nst = (kblk0 < klen && qbeg < qlim) ? (qlim - qbeg + STG - 1) / STG : 0;
+  constexpr int PPW = (STG / 4) / NWB;
+  auto issue = [&](int buf, int r0) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave * PPW + i;
+      if (pc < STG / 8) stage_piece(st[buf], qb, pitch, r0, SL, pc, lane);
+      else stage_piece(st[buf] + ARR, dob, (size_t)d, r0, SL, pc - STG / 8, lane);
+    }
+  };
+  float p_lse = 0.f, p_dl = 0.f;
+  int p_lo = 0, p_hi = -1;
+  auto fetch_vec = [&](int r0) {
+    if (tid < STG) {
+      const int q = min(r0 + tid, S - 1);
+      p_lse = lse[((size_t)b * H + h) * S + q];
+      p_dl = delta[((size_t)b * H + h) * S + q];
+      if (PK) {
+        const bool v = r0 + tid < SL;
+        p_lo = v ? KR.lo[(size_t)b * S + q] : 0;
+        p_hi = v ? KR.hi[(size_t)b * S + q] : -1;
+      }
+    }
+  };
+  auto commit_vec = [&](int buf) {
+    if (tid < STG) {
+      lse_s[buf][tid] = -p_lse * kLog2e; dl_s[buf][tid] = -p_dl * kScale;
+      if (PK) { qlo_s[buf][tid] = p_lo; qhi_s[buf][tid] = p_hi; }
+    }
+  };
+  // dQ of one finished stage (queries [qs, qs + 64), its dS in dsb[buf]): this wave's two 16 x 16 blocks over the block's 256 keys.
+  // Runs between tiles, where few registers are live: the fragments of four key chunks are fetched in one burst (24 transposing reads in
+  // flight) before their eight MFMAs.  Measured (B16 / S2048 / H12, p = 0.1, whole backward; the two-kernel form: 1052 us): this 959 us; one
+  // chunk at a time 1011 us (every MFMA pair waits out an LDS round trip); the chunks spread over the NEXT stage's softmax-backward
+  // arithmetic (fetch behind the S / dP MFMAs, multiply behind the exponentials ...) spills 42 registers in the tile loop: 1791 us.
+  // The phase is bound by LDS bandwidth: 24 KiB of fragments per wave and stage, all eight waves at once.
+  const int qrows = min(SL, qlim);
+  const int dq4 = wave & 3, qq = wave >> 2;
+  auto dq_stage = [&](int buf, int qs) {
+    f32x4_t c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cb = 0; cb < NWB; cb += DQB) {
+      bf16x8_t bk[DQB], a0[DQB], a1[DQB];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < DQB; ++c) {
+        bk[c] = frag_tr16(kt_s + (cb + c) * 4096, 16 * dq4, lane);
+        a0[c] = frag_tr16(dsb[buf] + (cb + c) * 4096, 32 * qq, lane);
+        a1[c] = frag_tr16(dsb[buf] + (cb + c) * 4096, 32 * qq + 16, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < DQB; ++c) {      // (K as the first operand: the tile comes out transposed - a lane holds 4 consecutive channels of one query)
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk[c], a0[c], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk[c], a1[c], c1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int q_a = qs + 32 * qq + (lane & 15);
+    bf16_t* dst = dq_slab + ((size_t)rb + q_a) * d + h * 64 + 16 * dq4 + 4 * (lane >> 4);
+    if (q_a < qrows) *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(c0[0], c0[1]), pack2bf(c0[2], c0[3]));
+    if (q_a + 16 < qrows) *reinterpret_cast<uint2*>(dst + (size_t)16 * d) = make_uint2(pack2bf(c1[0], c1[1]), pack2bf(c1[2], c1[3]));
+  };
+  if (nst > 0) { issue(0, qbeg); fetch_vec(qbeg); commit_vec(0); }
+  const float keep_k = D.inv_keep * kScale;
+  for (int t = 0; t < nst; ++t) {
+    const int qs = qbeg + t * STG;
+    attn_vm_wait0();
+    __syncthreads();
+    const bool dma_late = wave < NWB / 2;
+    bool dma_due = t + 1 < nst;
+    if (dma_due && !dma_late) { issue((t + 1) & 1, qs + STG); fetch_vec(qs + STG); dma_due = false; }
+    // stage t - 1's dQ.  (Measured, same shape: the lower four waves here and the upper four behind the stage's tiles - so that the two waves
+    //  of a SIMD are never in this MFMA / LDS-only phase together - 1053 us: the second call site costs 14 spilled registers.)
+    if (t > 0) dq_stage((t - 1) & 1, qs - STG);
+    const unsigned char* qst = st[t & 1];
+    const unsigned char* dst_ = qst + ARR;
+    const int vb_ = t & 1;
+    unsigned char* dsw = dsb[t & 1] + wave * 4096;
+#pragma unroll
+    for (int j = 0; j < NTILE; ++j) {
+      const int q0 = qs + 32 * j;
+      bool skip = k0 >= klen || q0 >= SL || (causal && q0 + 31 < k0);
+      bool edge = (k0 + 32 > klen) || (q0 + 32 > SL) || (causal && k0 + 31 > q0);
+      if (PK && !skip) {
+        const int lo = qlo_s[vb_][32 * j + l31], hi_ = qhi_s[vb_][32 * j + l31];
+        const int ulo = wave_imin(hi_ >= lo ? lo : S), uhi = wave_imax(hi_ >= lo ? hi_ + 1 : 0) - 1;
+        if (uhi < k0 || ulo > k0 + 31) skip = true;
+        const int ilo = wave_imax(lo), ihi = wave_imin(hi_ + 1) - 1;
+        edge = edge || ilo > k0 || ihi < k0 + 31;
+      }
+      if (skip) {   // (wave-uniform) nothing to add to dK / dV; the dQ MFMAs read this tile's dS: zeros
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<uint2*>(dsw + swz(l31, 64 * j + 16 * gq + 8 * hi)) = make_uint2(0u, 0u);
+        continue;
+      }
+      const unsigned char* qt = qst + 4096 * j;
+      const unsigned char* dot_ = dst_ + 4096 * j;
+      f32x16_t sc = zero16(), dp = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, s, lane), kf[s], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dot_, s, lane), vf[s], dp, 0, 0, 0);
+      }
+      if (dma_due) { issue((t + 1) & 1, qs + STG); fetch_vec(qs + STG); dma_due = false; }
+      float nl[16], dlv[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 a4 = *reinterpret_cast<const float4*>(&lse_s[vb_][32 * j + 8 * g + 4 * hi]);
+        const float4 b4 = *reinterpret_cast<const float4*>(&dl_s[vb_][32 * j + 8 * g + 4 * hi]);
+        nl[4 * g] = a4.x; nl[4 * g + 1] = a4.y; nl[4 * g + 2] = a4.z; nl[4 * g + 3] = a4.w;
+        dlv[4 * g] = b4.x; dlv[4 * g + 1] = b4.y; dlv[4 * g + 2] = b4.z; dlv[4 * g + 3] = b4.w;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = fast_exp2(fmaf(sc[r], kScaleL2, nl[r]));
+      if (edge) {
+        int q0v = q0;
+        asm volatile("" : "+v"(q0v));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qi = 32 * j + acc_row(r, hi);
+          const int q = q0v + acc_row(r, hi);
+          const bool in_range = PK ? (krow >= qlo_s[vb_][qi] && krow <= qhi_s[vb_][qi]) : key_ok;
+          sc[r] = (in_range && q < SL && (!causal || krow <= q)) ? sc[r] : 0.f;
+        }
+      }
+      if (D.thresh == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = sc[r] * fmaf(dp[r], kScale, dlv[r]);
+      } else {
+        const unsigned xb = dbase + (unsigned)(q0 + 4 * hi) * 0x85EBCA77u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned w = drop_word(xb + (unsigned)((r & 3) + 8 * (r >> 2)) * 0x85EBCA77u);
+          const bool drop = (kodd ? (w >> 16) : (w & 0xffffu)) < D.thresh;
+          dp[r] = sc[r] * fmaf(dp[r], drop ? 0.f : keep_k, dlv[r]);
+          sc[r] = drop ? 0.f : sc[r] * D.inv_keep;
+        }
+      }
+      const bf16x8_t p0 = acc_to_b(sc, 0), p1 = acc_to_b(sc, 1);
+      const bf16x8_t s0 = acc_to_b(dp, 0), s1 = acc_to_b(dp, 1);
+      {   // dS to LDS for the dQ MFMAs of the next stage: this lane's key row, queries 8 gq + 4 hi .. + 3 of the tile per 8-byte piece
+        const uint4 u0 = __builtin_bit_cast(uint4, s0), u1 = __builtin_bit_cast(uint4, s1);
+        *reinterpret_cast<uint2*>(dsw + swz(l31, 64 * j + 0 + 8 * hi)) = make_uint2(u0.x, u0.y);
+        *reinterpret_cast<uint2*>(dsw + swz(l31, 64 * j + 16 + 8 * hi)) = make_uint2(u0.z, u0.w);
+        *reinterpret_cast<uint2*>(dsw + swz(l31, 64 * j + 32 + 8 * hi)) = make_uint2(u1.x, u1.y);
+        *reinterpret_cast<uint2*>(dsw + swz(l31, 64 * j + 48 + 8 * hi)) = make_uint2(u1.z, u1.w);
+      }
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 0, lane), p0, dv0, 0, 0, 0);
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 1, lane), p1, dv0, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 1, 0, lane), p0, dv1, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 1, 1, lane), p1, dv1, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 0, 0, lane), s0, dk0, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 0, 1, lane), s1, dk0, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 0, lane), s0, dk1, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 1, lane), s1, dk1, 0, 0, 0);
+    }
+    if (dma_due) { issue((t + 1) & 1, qs + STG); fetch_vec(qs + STG); }
+    if (t + 1 < nst) commit_vec((t + 1) & 1);
+  }
+  if (nst > 0) {     // the last stage's dQ
+    __syncthreads();
+    dq_stage((nst - 1) & 1, qbeg + (nst - 1) * STG);
+  }
+  if (krow < SL) {
+    bf16_t* row = dqkv + ((size_t)rb + krow) * pitch + h * 64;
+    unrope_acc(dk0, dk1, Rout, rope_pos(Rout, b, krow), hi);
+    store_t(row + d, dk0, dk1, 1.f, hi);
+    store_t(row + 2 * d, dv0, dv1, 1.f, hi);
+  }
+}
+
 // waves (= 32-row tiles) per block: long sequences share each K/V (or Q/dO) tile among 4 waves through LDS
 int attn_waves(int S) { return S >= 128 ? 4 : (S >= 64 ? 2 : 1); }
 
@@ -1727,7 +2045,7 @@ int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, i
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
                const int64_t* position_ids, int qk_rotated, float dropout_p, unsigned dropout_seed, hipStream_t st,
-               const int32_t* key_lo, const int32_t* key_hi, const int32_t* row_base) {
+               const int32_t* key_lo, const int32_t* key_hi, const int32_t* row_base, void* dq_ws, size_t dq_slab_stride) {
   GGET_REQUIRE(!row_base || (key_len && !key_lo), "attention: the var-len token layout needs key_len and excludes per-token key ranges");
   const KeyRange KR{key_len, key_lo, key_hi, row_base};
   if (B == 0 || S == 0) return 0;
@@ -1747,6 +2065,27 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
   // (q, k rotated in memory - the engine's layout - or no rotation at all: the staged kernels read them as they are and rotate dq / dk
   // back in their epilogues; q, k to be rotated on load, the plain-op form of the tests, stays on the register-prefetch kernels)
   if (S >= 256 && (!cos_tab || qk_rotated) && big) {
+    // fused form (one pass; the caller provides room for the key blocks' dQ partials: bf16 [ceil(S / 256)][dq_slab_stride], dq_slab_stride >=
+    // rows x H x 64): see attn_bwd_fused64_kernel.  S < 512: one key block per row - nothing is shared, the two-kernel form is faster.
+    static int fused = -1;
+    if (fused < 0) { const char* e = getenv("GGET_ATTN_FUSED"); fused = e ? atoi(e) : 1; }
+    if (dq_ws && fused && S >= 512) {
+      static bool attr = false;
+      if (!attr) {
+        GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds));
+        GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds));
+        attr = true;
+      }
+      hipLaunchKernelGGL(attn_delta_kernel, dim3((S + 31) / 32, B), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta_ws, key_len, row_base, S, H);
+      if (key_lo) hipLaunchKernelGGL((attn_bwd_fused64_kernel<true>), dim3((S + 255) / 256, H, B), dim3(512), kFusedLds, st, (const bf16_t*)qkv, (const bf16_t*)dout,
+                                     lse, delta_ws, KR, (bf16_t*)dqkv, (bf16_t*)dq_ws, dq_slab_stride, B, S, H, causal, D, R);
+      else hipLaunchKernelGGL((attn_bwd_fused64_kernel<false>), dim3((S + 255) / 256, H, B), dim3(512), kFusedLds, st, (const bf16_t*)qkv, (const bf16_t*)dout,
+                              lse, delta_ws, KR, (bf16_t*)dqkv, (bf16_t*)dq_ws, dq_slab_stride, B, S, H, causal, D, R);
+      hipLaunchKernelGGL(attn_dq_finish_kernel, dim3((S + 31) / 32, H, B), dim3(256), 0, st, (const bf16_t*)dq_ws, dq_slab_stride, (bf16_t*)dqkv, key_len, row_base,
+                         S, H, causal, key_lo ? 1 : 0, R);
+      GGET_LAUNCH_CHECK();
+      return 0;
+    }
     static int stg128 = -1;
     if (stg128 < 0) { const char* e = getenv("GGET_ATTN_STG128"); stg128 = e ? atoi(e) : 1; }
 #define GGET_BWD64(PK)                                                                                                           \

@@ -188,7 +188,7 @@ struct Ws {
   std::vector<uint64_t> xres;  // L+1 residual-stream snapshots
   std::vector<LayerWs> lw;
   uint64_t rstd_f, hidden;
-  uint64_t dxa, dxb, dxc, dxn, dqkv, dattn, dgu, dh, delta, dscaled, dscaled2;
+  uint64_t dxa, dxb, dxc, dxn, dqkv, dattn, dgu, dh, delta, dq_acc, dscaled, dscaled2;
   uint64_t scratch32, loss_sum, sqnorm, counts, segs, emb_sort, emb_cnt, emb_slab, wg32, lm_slab;
   uint64_t sq_chunks, sq_tiles;   // gradient-norm shortcut: chunk table of everything but the layers' weight matrices; per-tile sums of those
   // pre-train head
@@ -251,6 +251,10 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.dgu = b.take(T * 2 * ff * 2);
   w.dh = b.take(T * ff * 2);
   w.delta = b.take(T * H * 4);
+  {   // long sequences: the key blocks' dQ partials of the fused attention backward, bf16 [ceil(S / 256)][T][d]
+    const uint64_t Smax = c.max_tokens / (c.max_batch > 0 ? c.max_batch : 1);
+    w.dq_acc = Smax >= 512 ? b.take(((Smax + 255) / 256) * T * d * 2) : 0;
+  }
   w.dscaled = pl.has_res ? b.take(T * d * 2) : 0;
   w.dscaled2 = pl.has_res ? b.take(T * d * 2) : 0;
   w.scratch32 = b.take(pl.n_scratch32 * 4);
@@ -1496,7 +1500,7 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   if (int e = k_attn_bwd(h->wsp<bf16_t>(lw.qkv), h->wsp<bf16_t>(lw.attn), dattn, h->wsp<float>(lw.lse),
                          h->wsp<int32_t>(w.key_len), dqkv, h->wsp<float>(w.delta), h->B, h->S, H, c.causal, h->cos_cur,
                          h->sin_cur, h->pos_cur, /*qk_rotated=*/1, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st,
-                         h->klo(), h->khi(), h->row_base()))
+                         h->klo(), h->khi(), h->row_base(), w.dq_acc ? h->wsp<bf16_t>(w.dq_acc) : nullptr, (size_t)c.max_tokens * d))
     return e;
   if (int e = gemm_nn(dqkv, h->P + lo.wqkv, dxn, T, d, 3 * d, 3 * d, d, d, nullptr, st)) return e;
   // (fused with the LayerScale backward of the layer below, this RMSNorm backward writes w.dscaled - which this layer's down_proj weight
@@ -2026,6 +2030,13 @@ extern "C" int gget_op_attn_bwd(const void* qkv, const void* out, const void* do
                                 void* stream) {
   return k_attn_bwd(qkv, out, dout, lse, key_len, dqkv, delta_ws, B, S, H, causal, cos_tab, sin_tab, position_ids,
                     /*qk_rotated=*/0, dropout_p, dropout_seed, (hipStream_t)stream);
+}
+extern "C" int gget_op_attn_bwd_fused(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len,
+                                      const int32_t* key_lo, const int32_t* key_hi, void* dqkv, float* delta_ws, void* dq_ws, int B, int S,
+                                      int H, int causal, float dropout_p, uint32_t dropout_seed, void* stream) {
+  GGET_REQUIRE(dq_ws && (!key_lo == !key_hi), "attn_bwd_fused: null workspace / half a key range");
+  return k_attn_bwd(qkv, out, dout, lse, key_lo ? nullptr : key_len, dqkv, delta_ws, B, S, H, causal, nullptr, nullptr, nullptr, 0, dropout_p,
+                    dropout_seed, (hipStream_t)stream, key_lo, key_hi, nullptr, dq_ws, (size_t)B * S * H * 64);
 }
 extern "C" int gget_op_gateup_geglu(const void* x, const void* wgu, void* gu, void* h, int T, int d, int ff, void* stream) {
   GGET_REQUIRE(x && wgu && gu && h && T > 0, "gateup_geglu: null argument");

@@ -418,6 +418,15 @@ int gget_op_attn_bwd_ranges(const void* qkv, const void* out, const void* dout, 
                             const int32_t* key_hi, void* dqkv, float* delta_ws, int B, int S, int H, int causal,
                             float dropout_p, uint32_t dropout_seed, void* stream);
 int gget_op_ranges_from_mask3d(const int64_t* mask3d, int32_t* key_lo, int32_t* key_hi, int B, int S, void* stream);
+/* gget_op_attn_bwd / _ranges (no RoPE) through the ONE-PASS long-sequence backward (S >= 512; shorter rows run the usual kernels and leave
+ * the workspace alone): S, dP and the softmax backward are evaluated once, dK / dV and dQ come out of the same pass (5 matmuls of hf
+ * eager_attention_forward's autograd graph, modeling_llama.py:191-214, instead of the 7 of the two-kernel form).  dq_ws: bf16
+ * [ceil(S / 256)][B * S][H * 64] scratch (contents irrelevant on entry): every block of 256 keys writes its dQ partials into its own
+ * slab, the last launch sums the slabs in fp32 in block order - reproducible - into the q part of dqkv.
+ * key_lo / key_hi both NULL: one key length per row (key_len, may be NULL = S). */
+int gget_op_attn_bwd_fused(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len,
+                           const int32_t* key_lo, const int32_t* key_hi, void* dqkv, float* delta_ws, void* dq_ws, int B, int S,
+                           int H, int causal, float dropout_p, uint32_t dropout_seed, void* stream);
 /* replaces: LlamaMLP.forward (hf :174-176) up to the down projection, as ONE GEMM with the gated-GELU product in its
  * epilogue: gu[T,2ff] = x[T,d] * wgu[2ff,d]^T (gate | up pre-activations, kept for the backward),
  * h[T,ff] = bf16(gelu(gate)) * up.  Falls back to GEMM + gget_op_geglu_fwd when ff % 128 != 0. */

@@ -676,6 +676,74 @@ def test_attention_packed_ranges(lib, B, S, H, causal, drop):
         assert e < 2e-2, f"packed attn bwd d{nm} rel-L2 {e}"
 
 
+@pytest.mark.parametrize("B,S,H,causal,drop,packed", [(2, 256, 2, 0, 0.0, False), (2, 520, 3, 0, 0.1, False), (1, 1056, 2, 1, 0.1, False),
+                                                      (1, 2048, 2, 0, 0.1, False), (2, 520, 2, 0, 0.1, True), (1, 1024, 1, 1, 0.0, True),
+                                                      (3, 300, 12, 0, 0.1, False)])
+def test_attention_bwd_fused(lib, B, S, H, causal, drop, packed):
+    """One-pass long-sequence backward (gget_op_attn_bwd_fused: S, dP and the softmax backward once; dQ through per-key-block bf16
+    partials summed in fp32) against autograd with the identical dropout mask AND against the two-kernel backward of the same library:
+    all three to a few bf16 roundings (dQ is accumulated in another order); a second call reproduces the first bit for bit."""
+    d = H * 64
+    dseed = 777
+    dmask = _drop_mask(dseed, B, H, S, drop).cuda() if drop > 0 else None
+    qkv = rnd(B * S, 3 * d, seed=31)
+    lens = lo = hi = None
+    if packed:
+        m3, lo_np, hi_np = _packed_ranges(B, S, seed=S + B)
+        lo, hi = torch.from_numpy(lo_np).cuda(), torch.from_numpy(hi_np).cuda()
+        allow = torch.from_numpy(m3).cuda().bool()
+        valid = torch.from_numpy(hi_np >= lo_np).cuda().view(B * S)
+    else:
+        lens = torch.tensor([[S, max(5, S // 2 + 3), S - 7][i % 3] for i in range(B)], dtype=torch.int32).cuda()
+        keyok = torch.arange(S, device="cuda")[None, :] < lens[:, None]
+        allow = keyok[:, None, :].expand(B, S, S).clone()
+        valid = keyok.reshape(B * S)
+    if causal:
+        allow = allow & torch.ones(S, S, dtype=torch.bool, device="cuda").tril()[None]
+    out = torch.zeros(B * S, d, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
+    if packed:
+        L.check(lib.gget_op_attn_fwd_ranges(P(qkv), P(lo), P(hi), P(out), P(lse), B, S, H, causal, drop, dseed, ST()))
+    else:
+        L.check(lib.gget_op_attn_fwd(P(qkv), P(lens), P(out), P(lse), B, S, H, causal, None, None, None, drop, dseed, ST()))
+    x = qkv.float().view(B, S, 3, H, 64).detach().requires_grad_(True)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    w = (q @ k.transpose(2, 3) * 0.125).masked_fill(~allow[:, None], float("-inf"))
+    p = torch.softmax(w, -1).nan_to_num(0.0)
+    if dmask is not None:
+        p = p * dmask
+    ref = (p @ v).transpose(1, 2).reshape(B * S, d)
+    dout = rnd(B * S, d, seed=37)
+    dout[~valid] = 0
+    ref.backward(dout.float())
+    # the two-kernel form
+    dqkv2 = torch.zeros_like(qkv)
+    delta = torch.full((B * H * S,), float("nan"), dtype=torch.float32, device="cuda")
+    if packed:
+        L.check(lib.gget_op_attn_bwd_ranges(P(qkv), P(out), P(dout), P(lse), P(lo), P(hi), P(dqkv2), P(delta), B, S, H, causal, drop, dseed, ST()))
+    else:
+        L.check(lib.gget_op_attn_bwd(P(qkv), P(out), P(dout), P(lse), P(lens), P(dqkv2), P(delta), B, S, H, causal, None, None, None, drop, dseed, ST()))
+    # the fused form, twice
+    acc = torch.full(((S + 255) // 256, B * S, d), float("nan"), dtype=torch.bfloat16, device="cuda")    # scratch: contents irrelevant
+    runs = []
+    for _ in range(2):
+        dqkv = torch.zeros_like(qkv)
+        delta1 = torch.full((B * H * S,), float("nan"), dtype=torch.float32, device="cuda")
+        L.check(lib.gget_op_attn_bwd_fused(P(qkv), P(out), P(dout), P(lse), P(lens), P(lo), P(hi), P(dqkv), P(delta1), P(acc), B, S, H, causal, drop, dseed, ST()))
+        runs.append(dqkv.float().view(B, S, 3, H, 64))
+    got, got2 = runs
+    assert torch.isfinite(got).all()
+    for i, nm in enumerate("qkv"):
+        e = rel_l2(got[:, :, i].cpu().numpy(), x.grad[:, :, i].cpu().numpy())
+        assert e < 2e-2, f"fused attn bwd d{nm} rel-L2 {e}"
+    two = dqkv2.float().view(B, S, 3, H, 64)
+    vr = valid.view(B, S)
+    # (delta = rowsum(dO * O) is summed in another order than inside the dQ kernel: dK / dV agree to a few bf16 roundings, not bit for bit)
+    for i in (0, 1, 2):
+        assert rel_l2(got[:, :, i][vr].cpu().numpy(), two[:, :, i][vr].cpu().numpy()) < 3e-3
+    assert torch.equal(got2, got), "the fused backward must be reproducible"
+
+
 @pytest.mark.parametrize("B,S,F,power", [(6, 24, 13, 1.0), (64, 32, 13, 1.0), (5, 40, 4, 2.0), (3, 2048, 13, 0.5), (4, 16, 1, 1.0)])
 def test_smtp_rows_kernel_matches_oracle(lib, B, S, F, power):
     """Collator masking on the device (gget_op_smtp_rows) vs the oracle's _mask_stacked_input_ids_v2 fed with the cell list

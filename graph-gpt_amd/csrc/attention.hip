@@ -2066,10 +2066,13 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
   // back in their epilogues; q, k to be rotated on load, the plain-op form of the tests, stays on the register-prefetch kernels)
   if (S >= 256 && (!cos_tab || qk_rotated) && big) {
     // fused form (one pass; the caller provides room for the key blocks' dQ partials: bf16 [ceil(S / 256)][dq_slab_stride], dq_slab_stride >=
-    // rows x H x 64): see attn_bwd_fused64_kernel.  S < 512: one key block per row - nothing is shared, the two-kernel form is faster.
+    // rows x H x 64): see attn_bwd_fused64_kernel.  (S = 256, one key block per row: still ahead of the two-kernel form once the partials are
+    // plain stores - C3 step 40.06 -> 39.69 ms, same box; GGET_ATTN_FUSED_MIN_S moves the threshold.)
     static int fused = -1;
     if (fused < 0) { const char* e = getenv("GGET_ATTN_FUSED"); fused = e ? atoi(e) : 1; }
-    if (dq_ws && fused && S >= 512) {
+    static int fused_min_s = -1;
+    if (fused_min_s < 0) { const char* e = getenv("GGET_ATTN_FUSED_MIN_S"); fused_min_s = e ? atoi(e) : 256; }
+    if (dq_ws && fused && S >= fused_min_s) {
       static bool attr = false;
       if (!attr) {
         GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds));

@@ -253,7 +253,7 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.delta = b.take(T * H * 4);
   {   // long sequences: the key blocks' dQ partials of the fused attention backward, bf16 [ceil(S / 256)][T][d]
     const uint64_t Smax = c.max_tokens / (c.max_batch > 0 ? c.max_batch : 1);
-    w.dq_acc = Smax >= 512 ? b.take(((Smax + 255) / 256) * T * d * 2) : 0;
+    w.dq_acc = Smax >= 256 ? b.take(((Smax + 255) / 256) * T * d * 2) : 0;
   }
   w.dscaled = pl.has_res ? b.take(T * d * 2) : 0;
   w.dscaled2 = pl.has_res ? b.take(T * d * 2) : 0;

@@ -418,7 +418,7 @@ int gget_op_attn_bwd_ranges(const void* qkv, const void* out, const void* dout, 
                             const int32_t* key_hi, void* dqkv, float* delta_ws, int B, int S, int H, int causal,
                             float dropout_p, uint32_t dropout_seed, void* stream);
 int gget_op_ranges_from_mask3d(const int64_t* mask3d, int32_t* key_lo, int32_t* key_hi, int B, int S, void* stream);
-/* gget_op_attn_bwd / _ranges (no RoPE) through the ONE-PASS long-sequence backward (S >= 512; shorter rows run the usual kernels and leave
+/* gget_op_attn_bwd / _ranges (no RoPE) through the ONE-PASS long-sequence backward (S >= 256; shorter rows run the usual kernels and leave
  * the workspace alone): S, dP and the softmax backward are evaluated once, dK / dV and dQ come out of the same pass (5 matmuls of hf
  * eager_attention_forward's autograd graph, modeling_llama.py:191-214, instead of the 7 of the two-kernel form).  dq_ws: bf16
  * [ceil(S / 256)][B * S][H * 64] scratch (contents irrelevant on entry): every block of 256 keys writes its dQ partials into its own

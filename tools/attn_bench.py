@@ -26,7 +26,7 @@ for (B, S, H) in [(256, 32, 12), (256, 256, 12), (32, 1024, 12), (16, 2048, 12)]
         else:
             f = t(lambda: L.check(lib.gget_op_attn_fwd(P(qkv), P(lens), P(out), P(lse), B, S, H, 0, None, None, None, p, 7, st)))
             b = t(lambda: L.check(lib.gget_op_attn_bwd(P(qkv), P(out), P(dout), P(lse), P(lens), P(dqkv), P(delta), B, S, H, 0, None, None, None, p, 7, st)))
-        if S >= 512 and not os.environ.get("RANGES"):   # the one-pass backward (dQ through an fp32 accumulator)
+        if S >= 256 and not os.environ.get("RANGES"):   # the one-pass backward (dQ through an fp32 accumulator)
             acc = torch.empty((S + 255) // 256, T, d, dtype=torch.bfloat16, device="cuda")
             bf = t(lambda: L.check(lib.gget_op_attn_bwd_fused(P(qkv), P(out), P(dout), P(lse), P(lens), None, None, P(dqkv), P(delta), P(acc), B, S, H, 0, p, 7, st)))
             print(f"B={B} S={S} H={H} p={p}: fused bwd {bf:8.1f} us ({2.5*fl/bf/1e6:6.1f} TF)")

@@ -1646,7 +1646,7 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
           const unsigned w = drop_word(xb + (unsigned)((r & 3) + 8 * (r >> 2)) * 0x85EBCA77u);
           const bool drop = (kodd ? (w >> 16) : (w & 0xffffu)) < D.thresh;
           dp[r] = sc[r] * fmaf(dp[r], drop ? 0.f : keep_k, dlv[r]);
-          sc[r] = drop ? 0.f : sc[r] * D.inv_keep;      // dropped probabilities: what multiplied V in forward
+          sc[r] = drop ? 0.f : sc[r];      // dropped probabilities: what multiplied V in forward (their 1 / (1 - p) goes onto dV at the end)
         }
       }
       if (j < 2) GGET_STAMP(5 + 5 * j);
@@ -1670,7 +1670,7 @@ __global__ void __launch_bounds__(NWB * 64, 2) attn_bwd_dkv64_kernel(const bf16_
     bf16_t* row = dqkv + ((size_t)rb + krow) * pitch + h * 64;
     unrope_acc(dk0, dk1, Rout, rope_pos(Rout, b, krow), hi);
     store_t(row + d, dk0, dk1, 1.f, hi);
-    store_t(row + 2 * d, dv0, dv1, 1.f, hi);
+    store_t(row + 2 * d, dv0, dv1, D.inv_keep, hi);
   }
 }
 
@@ -1956,7 +1956,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused64_kernel(const bf16_t* 
           const unsigned w = drop_word(xb + (unsigned)((r & 3) + 8 * (r >> 2)) * 0x85EBCA77u);
           const bool drop = (kodd ? (w >> 16) : (w & 0xffffu)) < D.thresh;
           dp[r] = sc[r] * fmaf(dp[r], drop ? 0.f : keep_k, dlv[r]);
-          sc[r] = drop ? 0.f : sc[r] * D.inv_keep;
+          sc[r] = drop ? 0.f : sc[r];      // (1 / (1 - p) goes onto dV at the end)
         }
       }
       const bf16x8_t p0 = acc_to_b(sc, 0), p1 = acc_to_b(sc, 1);
@@ -1988,7 +1988,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused64_kernel(const bf16_t* 
     bf16_t* row = dqkv + ((size_t)rb + krow) * pitch + h * 64;
     unrope_acc(dk0, dk1, Rout, rope_pos(Rout, b, krow), hi);
     store_t(row + d, dk0, dk1, 1.f, hi);
-    store_t(row + 2 * d, dv0, dv1, 1.f, hi);
+    store_t(row + 2 * d, dv0, dv1, D.inv_keep, hi);
   }
 }
 

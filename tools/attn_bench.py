@@ -26,8 +26,13 @@ for (B, S, H) in [(256, 32, 12), (256, 256, 12), (32, 1024, 12), (16, 2048, 12)]
         else:
             f = t(lambda: L.check(lib.gget_op_attn_fwd(P(qkv), P(lens), P(out), P(lse), B, S, H, 0, None, None, None, p, 7, st)))
             b = t(lambda: L.check(lib.gget_op_attn_bwd(P(qkv), P(out), P(dout), P(lse), P(lens), P(dqkv), P(delta), B, S, H, 0, None, None, None, p, 7, st)))
-        if S >= 256 and not os.environ.get("RANGES"):   # the one-pass backward (dQ through an fp32 accumulator)
+        if S >= 256 and not os.environ.get("RANGES"):   # the one-pass backward against the two-kernel form, alternated (same process, same clocks)
             acc = torch.empty((S + 255) // 256, T, d, dtype=torch.bfloat16, device="cuda")
-            bf = t(lambda: L.check(lib.gget_op_attn_bwd_fused(P(qkv), P(out), P(dout), P(lse), P(lens), None, None, P(dqkv), P(delta), P(acc), B, S, H, 0, p, 7, st)))
-            print(f"B={B} S={S} H={H} p={p}: fused bwd {bf:8.1f} us ({2.5*fl/bf/1e6:6.1f} TF)")
+            two = lambda: L.check(lib.gget_op_attn_bwd(P(qkv), P(out), P(dout), P(lse), P(lens), P(dqkv), P(delta), B, S, H, 0, None, None, None, p, 7, st))
+            one = lambda: L.check(lib.gget_op_attn_bwd_fused(P(qkv), P(out), P(dout), P(lse), P(lens), None, None, P(dqkv), P(delta), P(acc), B, S, H, 0, p, 7, st))
+            r2, r1 = [], []
+            for _ in range(5):
+                r2.append(t(two, 5)); r1.append(t(one, 5))
+            print(f"B={B} S={S} H={H} p={p}: bwd two-kernel " + " ".join(f"{x:.0f}" for x in r2) + "  | one-pass " + " ".join(f"{x:.0f}" for x in r1) +
+                  f"  | medians {sorted(r2)[2]:.1f} / {sorted(r1)[2]:.1f} us ({2.5*fl/sorted(r1)[2]/1e6:.0f} TF)")
         print(f"B={B} S={S} H={H} p={p}: fwd {f:8.1f} us ({fl/f/1e6:6.1f} TF)  bwd {b:8.1f} us ({2.5*fl/b/1e6:6.1f} TF)")

@@ -1885,6 +1885,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused64_kernel(const bf16_t* 
   };
   if (nst > 0) { issue(0, qbeg); fetch_vec(qbeg); commit_vec(0); }
   const float keep_k = D.inv_keep * kScale;
+  // byte selectors of the dropout field (see the dropout loop): low half of the own word / high half of the partner's word ...
+  const unsigned selA = kodd ? 0x0c0c0706u : 0x0c0c0100u, selB = kodd ? 0x0c0c0302u : 0x0c0c0504u;
   for (int t = 0; t < nst; ++t) {
     const int qs = qbeg + t * STG;
     attn_vm_wait0();
@@ -1950,11 +1952,21 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused64_kernel(const bf16_t* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) dp[r] = sc[r] * fmaf(dp[r], kScale, dlv[r]);
       } else {
-        const unsigned xb = dbase + (unsigned)(q0 + 4 * hi) * 0x85EBCA77u;
+        // The two lanes of a key pair (k, k + 1) need the same 16 hash words (one word serves both keys).  Each computes HALF of them -
+        // the even key's lane those of query registers 0..7, the odd key's lane those of 8..15 (16 queries further) - and reads the
+        // other half from its partner (DPP quad_perm [1,0,3,2]); v_perm_b32 with a per-lane selector then picks the lane's 16-bit field
+        // out of its own or the partner's word: 8 hashes + 8 lane swaps instead of 16 hashes per 16 scores, same mask.
+        const unsigned xb = dbase + (unsigned)(q0 + 4 * hi + 16 * kodd) * 0x85EBCA77u;
+        unsigned mine[8], theirs[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mine[i] = drop_word(xb + (unsigned)((i & 3) + 8 * (i >> 2)) * 0x85EBCA77u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) theirs[i] = (unsigned)__builtin_amdgcn_mov_dpp((int)mine[i], 0xB1, 0xF, 0xF, true);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const unsigned w = drop_word(xb + (unsigned)((r & 3) + 8 * (r >> 2)) * 0x85EBCA77u);
-          const bool drop = (kodd ? (w >> 16) : (w & 0xffffu)) < D.thresh;
+          // v_perm_b32 {S0 = partner's word, S1 = own word}: registers 0..7 are the even lane's own words / the odd lane's partner words
+          const unsigned f = __builtin_amdgcn_perm(theirs[r & 7], mine[r & 7], r < 8 ? selA : selB);
+          const bool drop = f < D.thresh;
           dp[r] = sc[r] * fmaf(dp[r], drop ? 0.f : keep_k, dlv[r]);
           sc[r] = drop ? 0.f : sc[r];      // (1 / (1 - p) goes onto dV at the end)
         }
@@ -2021,7 +2033,11 @@ int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, i
 #define GGET_FWD64(PK) hipLaunchKernelGGL((attn_fwd64_kernel<PK, 1, 8>), dim3((S + 255) / 256, H, B), dim3(512), 0, st, (const bf16_t*)qkv, KR, \
                                           (bf16_t*)out, lse, B, S, H, causal, D)
     if (dense && !key_lo && !causal && S >= 512) {   // (shorter rows: the pipeline's fill and drain cost more than it hides)
-      if (D.thresh) hipLaunchKernelGGL((attn_fwd_dense_kernel<true, 8>), dim3((S + 255) / 256, H, B), dim3(512), 0, st, (const bf16_t*)qkv, key_len,
+      static int nwb4 = -1;
+      if (nwb4 < 0) { const char* e = getenv("GGET_ATTN_FWD_NWB4"); nwb4 = e ? atoi(e) : 0; }
+      if (D.thresh && nwb4) hipLaunchKernelGGL((attn_fwd_dense_kernel<true, 4>), dim3((S + 127) / 128, H, B), dim3(256), 0, st, (const bf16_t*)qkv, key_len,
+                                               (bf16_t*)out, lse, B, S, H, D, row_base);
+      else if (D.thresh) hipLaunchKernelGGL((attn_fwd_dense_kernel<true, 8>), dim3((S + 255) / 256, H, B), dim3(512), 0, st, (const bf16_t*)qkv, key_len,
                                        (bf16_t*)out, lse, B, S, H, D, row_base);
       else hipLaunchKernelGGL((attn_fwd_dense_kernel<false, 8>), dim3((S + 255) / 256, H, B), dim3(512), 0, st, (const bf16_t*)qkv, key_len,
                               (bf16_t*)out, lse, B, S, H, D, row_base);

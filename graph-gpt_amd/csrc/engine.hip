@@ -1500,7 +1500,10 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   if (int e = k_attn_bwd(h->wsp<bf16_t>(lw.qkv), h->wsp<bf16_t>(lw.attn), dattn, h->wsp<float>(lw.lse),
                          h->wsp<int32_t>(w.key_len), dqkv, h->wsp<float>(w.delta), h->B, h->S, H, c.causal, h->cos_cur,
                          h->sin_cur, h->pos_cur, /*qk_rotated=*/1, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st,
-                         h->klo(), h->khi(), h->row_base(), w.dq_acc ? h->wsp<bf16_t>(w.dq_acc) : nullptr, (size_t)c.max_tokens * d))
+                         h->klo(), h->khi(), h->row_base(),
+                         /* the slabs were sized for ceil(max_tokens / max_batch / 256) key blocks: a call with fewer, longer rows keeps the two-kernel form */
+                         (w.dq_acc && (uint64_t)(h->S + 255) / 256 <= (c.max_tokens / (c.max_batch > 0 ? c.max_batch : 1) + 255) / 256) ? h->wsp<bf16_t>(w.dq_acc) : nullptr,
+                         (size_t)c.max_tokens * d))
     return e;
   if (int e = gemm_nn(dqkv, h->P + lo.wqkv, dxn, T, d, 3 * d, 3 * d, d, d, nullptr, st)) return e;
   // (fused with the LayerScale backward of the layer below, this RMSNorm backward writes w.dscaled - which this layer's down_proj weight

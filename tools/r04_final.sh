@@ -5,6 +5,7 @@ cd $GRAFT_REPO_ROOT
 ROWS=${1:-5696}
 bash tools/pmc_wgrad.sh r04 $ROWS > /dev/null && cp gpurun_out/r04_wgrad_pmc.json profiles/r04_wgrad_gemm_pmc_T$ROWS.json
 bash tools/pmc_gu.sh r04 $ROWS > /dev/null && cp gpurun_out/r04_gu_pmc.json profiles/r04_gu_geglu_gemm_pmc_T$ROWS.json
+bash tools/pmc_dh.sh r04 $ROWS > /dev/null
 python bench.py > gpurun_out/r04_final_bench_default.json 2> gpurun_out/r04_final_bench_default.err
 bash tools/trace_c1.sh r04_final_c1 > /dev/null
 bash tools/pmc_step.sh r04_final_c1 > /dev/null

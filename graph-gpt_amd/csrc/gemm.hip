@@ -1840,8 +1840,7 @@ int launch_mode(GemmGroup& g, int epi, int split_k, hipStream_t st) {
           GGET_HIP_CHECK(hipGetDevice(&dev));
           GGET_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
           num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-          if (const char* e = getenv("GGET_GEMM_NUM_CU")) num_cu = atoi(e);
-      if (const char* e = getenv("GGET_GEMM_NUM_CU")) num_cu = atoi(e);   // measurement knob: pretend the chip has fewer CUs (tools/halfchip.py)
+          if (const char* e = getenv("GGET_GEMM_NUM_CU")) num_cu = atoi(e);   // measurement knob: pretend the chip has fewer CUs (tools/halfchip.py)
         }
         // (192-row tiles when they need fewer rounds x rows than 256-row tiles - see launch_t)
         long t192 = 0;

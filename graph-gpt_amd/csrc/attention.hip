@@ -1806,13 +1806,13 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused64_kernel(const bf16_t* 
   bf16_t* dq_slab = dq_slabs + (size_t)blockIdx.x * slab_stride;      // this key block's dQ partials
   const int klen = PK ? S : (KR.key_len ? KR.key_len[b] : S);
   const int krow = k0 + l31;
-  bf16x8_t kf[4], vf[4];
+  bf16x8_t vf[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    kf[s] = frag_global(kb, krow, SL, pitch, s, lane);
-    vf[s] = frag_global(vb, krow, SL, pitch, s, lane);
-  }
-  load_tile(kt_s + wave * 4096, kb, k0, SL, pitch, lane);      // (read by every wave from stage 1 on: behind the stage barrier)
+  for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, krow, SL, pitch, s, lane);
+  // the block's K rows: every wave's dQ operand from stage 1 on (behind the stage barrier), and this wave's own S operand (its own tile,
+  // read back four fragments per query tile: 16 registers less than holding them)
+  load_tile(kt_s + wave * 4096, kb, k0, SL, pitch, lane);
+  const unsigned char* kmine = kt_s + wave * 4096;
   f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
   const unsigned dbase = drop_base(D, b * H + h, 0, (unsigned)krow >> 1);
   const int kodd = krow & 1;
@@ -1923,7 +1923,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused64_kernel(const bf16_t* 
       f32x16_t sc = zero16(), dp = zero16();
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, s, lane), kf[s], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, s, lane), frag_rows(kmine, s, lane), sc, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dot_, s, lane), vf[s], dp, 0, 0, 0);
       }
       if (dma_due) { issue((t + 1) & 1, qs + STG); fetch_vec(qs + STG); dma_due = false; }

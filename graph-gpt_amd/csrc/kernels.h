@@ -124,7 +124,7 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
                const int64_t* position_ids, int qk_rotated, float dropout_p, unsigned dropout_seed, hipStream_t st,
                const int32_t* key_lo = nullptr, const int32_t* key_hi = nullptr, const int32_t* row_base = nullptr,
-               void* dq_ws = nullptr, size_t dq_slab_stride = 0);   // dq_ws: bf16 [ceil(S / 256)][dq_slab_stride >= rows * H * 64] - S >= 512 then runs the fused one-pass backward (attention.hip)
+               void* dq_ws = nullptr, size_t dq_slab_stride = 0);   // dq_ws: bf16 [ceil(S / 256)][dq_slab_stride >= rows * H * 64] - S >= 256 (GGET_ATTN_FUSED_MIN_S) then runs the fused one-pass backward (attention.hip)
 // row_base ([B] int32, needs key_len): var-len (padding-free) token layout - sample b owns rows [row_base[b], row_base[b] + key_len[b]) of
 // qkv / out / dout / dqkv instead of [b * S, b * S + S); lse / delta / position ids stay [B,S]-indexed.
 // packed rows: inclusive key range [lo, hi] of every token from the block-diagonal mask [B,S,S] (first / last 1 of its row)

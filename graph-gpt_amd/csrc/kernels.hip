@@ -849,14 +849,18 @@ __global__ void __launch_bounds__(kBlock) head_cell_sum_kernel(const bf16_t* __r
   if (pad2c) { row = pad2c[t]; if (row < 0) row = pad_row; }       // var-len layout: the token's compact row (remap_rows_kernel's rule)
   // the token's cell rows (<= 32 of them): lane j holds the row of cell j, broadcast below; four row loads in flight per lane
   const int myrow = lane < c ? cellpos[l0 + lane] : 0;
-  for (int ch = lane; ch < (d >> 3); ch += 64) {
+  // the trip count is wave-uniform (ch0, not ch): __shfl reads from the lanes that hold the cell rows, which must be active in the
+  // last partial pass over the channels too (d/8 % 64 != 0: d = 576, 1152, ...) - loads and the store are predicated instead
+  for (int ch0 = 0; ch0 < (d >> 3); ch0 += 64) {
+    const int ch = ch0 + lane;
+    const bool on = ch < (d >> 3);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < c; j += 4) {
       uint4 q[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int r = __shfl(myrow, min(j + u, c - 1), 64);
-        q[u] = ldg16(dxs + (size_t)r * d + ch * 8);
+        q[u] = on ? ldg16(dxs + (size_t)r * d + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -868,7 +872,7 @@ __global__ void __launch_bounds__(kBlock) head_cell_sum_kernel(const bf16_t* __r
         }
       }
     }
-    stg16(dhid + (size_t)row * d + ch * 8, pack8(acc));
+    if (on) stg16(dhid + (size_t)row * d + ch * 8, pack8(acc));
   }
 }
 

@@ -393,6 +393,20 @@ class _GgetModel(nn.Module):
             return int((attention_mask != 0).sum()) if attention_mask.device.type == "cpu" else "auto"
         return None       # (GGET_VARLEN=sync / nosync / 0 are handled by Engine._set_layout)
 
+    def _want_hidden_states(self, output_hidden_states):
+        """hf resolve: the call's flag, else config.output_hidden_states (modeling_helpers.resolve_forward_defaults)."""
+        if output_hidden_states is None:
+            output_hidden_states = getattr(self.config, "output_hidden_states", False)
+        return bool(output_hidden_states)
+
+    def _collect_hidden_states(self, B, S):
+        """`outputs.hidden_states` of the reference's backbone with output_hidden_states=True (hf LlamaModel.forward
+        modeling_llama.py:401-414): a tuple of L + 1 tensors [B,S,d] - the residual stream entering every decoder layer, then the
+        FINAL-NORMED output of the last layer.  bf16 copies of the engine's activations (gget_layer_hidden_states /
+        gget_hidden_states); the forward that filled them ran on the padded [B,S] grid (the accessors index padded rows)."""
+        e = self._engine      # (the accessors refuse after a var-len forward - GGET_VARLEN=sync - with a hint)
+        return tuple(e.layer_hidden_states(i, B, S) for i in range(self.spec.num_layers)) + (e.hidden_states(B, S),)
+
     def _wrap_loss(self, loss):
         if loss is None:
             return None
@@ -426,7 +440,8 @@ class GraphGPTPretrainBase(_GgetModel):
         B, S = input_ids.shape[:2]
         assert input_ids.shape[2] == self.spec.stacked_feat, \
             f"stacked_feat: {self.spec.stacked_feat}\nx.shape: {tuple(input_ids.shape)}"  # modeling_common.py:131-133
-        n_real = self._token_count(attention_mask, num_tokens)
+        want_hs = self._want_hidden_states(output_hidden_states)
+        n_real = None if want_hs else self._token_count(attention_mask, num_tokens)     # (hidden states are read from the padded grid)
         if attention_mask is None:
             attention_mask = torch.ones(B, S, dtype=torch.int64)
         assert attention_mask.dim() in (2, 3), "attention_mask is [B,S] (right padding) or [B,S,S] (packed, block-diagonal)"
@@ -438,7 +453,10 @@ class GraphGPTPretrainBase(_GgetModel):
         if inputs_raw_embeds is not None:
             e.set_raw_embeds(inputs_raw_embeds, first_label_only=bool(getattr(self.config, "smtp_inside", False)))
         loss = e.forward_pretrain(input_ids, attention_mask, labels, sample_wgt, position_ids, num_tokens=n_real)
-        return _PretrainOutput(self._wrap_loss(loss), _LazyLogits(self))
+        out = _PretrainOutput(self._wrap_loss(loss), _LazyLogits(self))
+        if want_hs:
+            out.hidden_states = self._collect_hidden_states(B, S)       # modeling_pretrain.py:264 (outputs.hidden_states)
+        return out
 
 
 class GraphGPTTaskModel(_GgetModel):
@@ -455,7 +473,8 @@ class GraphGPTTaskModel(_GgetModel):
         if input_ids.dim() == 2:
             input_ids = input_ids[:, :, None]
         B, S = input_ids.shape[:2]
-        n_real = self._token_count(attention_mask, num_tokens)
+        want_hs = self._want_hidden_states(output_hidden_states)
+        n_real = None if want_hs else self._token_count(attention_mask, num_tokens)
         if attention_mask is None:
             attention_mask = torch.ones(B, S, dtype=torch.int64)
         cfg = self.config
@@ -491,7 +510,8 @@ class GraphGPTTaskModel(_GgetModel):
             e.set_raw_embeds(inputs_raw_embeds)
         loss, logits, hid = e.forward_task(input_ids, attention_mask, position_ids, task_labels, sample_wgt, code, num_tokens=n_real)
         return DoubleHeadsModelOutput(pretrain_loss=None, task_loss=self._wrap_loss(loss), pretrain_logits=None,
-                                      task_logits=logits, task_hidden_states=hid)
+                                      task_logits=logits, task_hidden_states=hid,
+                                      hidden_states=self._collect_hidden_states(B, S) if want_hs else None)   # modeling_finetune.py:323
 
 
 def check_batch(input_ids, attention_mask, labels, vocab_size: int):

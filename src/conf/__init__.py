@@ -1,21 +1,15 @@
-"""`src.conf` of the reference, reduced to the names the entry scripts import (examples/train_pretrain.py:7, train_supervised.py:7).
-The Hydra structured-config tree itself (src/conf/base_configs.py and sub-packages) is host-side configuration plumbing outside
-the hot path: `Config` here is the plain container the lean `TrainingPipeline` reads - `model`
-(GraphGPTConfig or its keyword dict), `optim`, `batches` (an iterable of collated batches), `max_steps`, `log_every`, `output_dir`,
-`resume_from` - and `TrainingStats` the three fields the reference's step functions read from theirs."""
+"""`src.conf` of the reference, reduced to the names the training path reads (examples/train_pretrain.py:7, train_supervised.py:7,
+src/conf/base_configs.py:28-203).  Hydra and the tokenization / generation trees are host-side plumbing outside the hot path
+(SURVEY.md section 2); `Config` carries the reference's four sub-trees - `TrainingPipeline(cfg, mode)` reads `cfg.model` (nested
+GraphGPTModelConfig) and `cfg.training` exactly as the reference's does - and still accepts the lean form of earlier rounds
+(`model`, `optim`, `batches`, ...).  `TrainingStats` = the fields the reference's step functions read from theirs."""
 import dataclasses
-from typing import Any, Iterable, Optional
+import importlib as _il
+from typing import Any
 
-
-@dataclasses.dataclass
-class Config:
-    model: Any = None
-    optim: Any = None
-    batches: Optional[Iterable] = None
-    max_steps: int = 0
-    log_every: int = 0
-    output_dir: Optional[str] = None
-    resume_from: Optional[str] = None
+_c = _il.import_module("graph-gpt_amd.conf")
+Config, TrainingConfig, ScheduleConfig, OptimizerConfig = _c.Config, _c.TrainingConfig, _c.ScheduleConfig, _c.OptimizerConfig
+DistConfig, FinetuneTrainConfig = _c.DistConfig, _c.FinetuneTrainConfig
 
 
 @dataclasses.dataclass
@@ -32,4 +26,4 @@ class TrainingStats:
     sliced_raw_embeds: Any = None
 
 
-__all__ = ["Config", "TrainingStats"]
+__all__ = ["Config", "TrainingConfig", "ScheduleConfig", "OptimizerConfig", "DistConfig", "FinetuneTrainConfig", "TrainingStats"]

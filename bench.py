@@ -342,6 +342,14 @@ def main():
         dp_info = engine.describe_dp()
         dp_info["ms_per_step_without_exchange"] = float(dt_nox[0]) / a.steps * 1e3
         dp_info["replicas_bit_identical"] = replicas_identical
+        # which device every rank ran on (the driver's SCALE run must see N distinct GPUs): name, index, PCI bus id / uuid
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        me = {"rank": rank, "device_index": torch.cuda.current_device(), "name": pr.name,
+              "pci_bus_id": getattr(pr, "pci_bus_id", None), "uuid": str(getattr(pr, "uuid", "")) or None}
+        allr = [None] * world
+        dist.all_gather_object(allr, me)
+        dp_info["rank_devices"] = allr
+        dp_info["distinct_devices"] = len({(d_["device_index"], d_["pci_bus_id"], d_["uuid"]) for d_ in allr})
     # the dominant kernels' launch durations INSIDE a step: three more (untimed) steps with HIP events around those launches, on the
     # stream they run on (single process only - the extra steps would otherwise need every rank)
     in_step = {}

@@ -109,11 +109,15 @@ struct ElemDropArg {
   unsigned thresh;    // 0 => off
   float inv_keep;
   unsigned seed;
+  // var-len token layout: the mask is keyed by the LOGICAL row b * S + s of the padded [B,S] grid, so that the compact layout draws
+  // the same random stream as the padded one (rows[t] = logical row of compact row t; nullptr: the rows are the logical rows)
+  const int32_t* rows;
 };
 #define GGET_DROP_STREAM_EMBED 48u
 #define GGET_DROP_STREAM_MLP_ACT 49u
 #define GGET_DROP_STREAM_MLP_OUT 50u
 #ifdef __HIPCC__
+__device__ __forceinline__ unsigned elem_row(const ElemDropArg& E, long t) { return E.rows ? (unsigned)E.rows[t] : (unsigned)t; }
 __device__ __forceinline__ float elem_drop_mul(const ElemDropArg& E, unsigned stream, unsigned a, unsigned b) {
   if (E.thresh == 0) return 1.f;
   unsigned x = E.seed ^ (stream * 0x9E3779B1u);

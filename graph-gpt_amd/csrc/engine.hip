@@ -204,7 +204,7 @@ struct Ws {
   uint64_t long_wgt;   // stack_method = "long": per-sample loss weights (fp32 [max_batch])
   // var-len token layout: first compact row of every sample [max_batch + 1], per compact row its sample index / position / ids, the
   // padded -> compact row map [max_tokens], a status word
-  uint64_t vl_cu, vl_rowb, vl_pos, vl_ids, vl_pad2c, vl_status;
+  uint64_t vl_cu, vl_rowb, vl_pos, vl_ids, vl_pad2c, vl_c2p, vl_status;   // (vl_c2p: compact -> padded row map [max_tokens])
   uint64_t pos_safe;   // position ids clamped into the RoPE table (int64 [max_tokens]); the sticky "clamped" flag is vl_status[1]
   uint64_t sk_ws;      // stream-K GEMM launches: flags + one fp32 partial tile per block (gemm.h)
   uint64_t head_x[6] = {0}, head_a[5] = {0}, head_d[2] = {0};   // MLP head: layer inputs / activations (bf16), fp32 gradient ping-pong
@@ -271,6 +271,7 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.vl_pos = b.take(T * 8);
   w.vl_ids = b.take(T * (uint64_t)c.stacked_feat * 8);
   w.vl_pad2c = b.take(T * 4);
+  w.vl_c2p = b.take(T * 4);
   w.vl_status = b.take(256);
   w.pos_safe = b.take(T * 8);
   w.sk_ws = b.take(gget_gemm_streamk_bytes());
@@ -423,12 +424,14 @@ struct gget_engine {
   float mlp_drop_p = 0.f;
   float head_drop_p = 0.f;        // dropout inside the MLP score head
   ElemDropArg head_drop() const { return elem_drop(head_drop_p, attn_drop_seed ^ 0x2545F491u); }
-  static ElemDropArg elem_drop(float p, unsigned seed) {
-    if (p <= 0.f) return ElemDropArg{0, 1.f, 0};
-    return ElemDropArg{(unsigned)(p * 16777216.0f), 1.0f / (1.0f - p), seed};
+  static ElemDropArg elem_drop(float p, unsigned seed, const int32_t* rows = nullptr) {
+    if (p <= 0.f) return ElemDropArg{0, 1.f, 0, nullptr};
+    return ElemDropArg{(unsigned)(p * 16777216.0f), 1.0f / (1.0f - p), seed, rows};
   }
-  ElemDropArg embed_drop() const { return elem_drop(embed_drop_p, attn_drop_seed ^ 0x5BD1E995u); }
-  ElemDropArg mlp_drop(int layer) const { return elem_drop(mlp_drop_p, attn_drop_seed + 0x7F4A7C15u * (unsigned)(layer + 1)); }
+  // token-wise masks are keyed by the logical [B,S] row: on the var-len layout through the compact -> padded row map (vl_c2p)
+  const int32_t* drop_rows() const { return varlen ? wsp<int32_t>(ws.vl_c2p) : nullptr; }
+  ElemDropArg embed_drop() const { return elem_drop(embed_drop_p, attn_drop_seed ^ 0x5BD1E995u, drop_rows()); }
+  ElemDropArg mlp_drop(int layer) const { return elem_drop(mlp_drop_p, attn_drop_seed + 0x7F4A7C15u * (unsigned)(layer + 1), drop_rows()); }
   PathDropArg path_drop(int layer, int which) const {
     const int L = cfg.num_layers;
     const float rate = (path_drop_p > 0.f && L > 1) ? path_drop_p * (float)layer / (float)(L - 1) : 0.f;
@@ -813,7 +816,7 @@ __global__ void __launch_bounds__(256) ls_fwd_kernel(const bf16_t* __restrict__ 
     if (E.thresh) {   // mlp_dropout on the down projection's output (utils_graphgpt.py:79), rounded like the bf16 module does
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        v[e] = bf2f(f2bf(v[e] * elem_drop_mul(E, GGET_DROP_STREAM_MLP_OUT, (unsigned)(w / cpr), (unsigned)(c * 8 + e))));
+        v[e] = bf2f(f2bf(v[e] * elem_drop_mul(E, GGET_DROP_STREAM_MLP_OUT, elem_row(E, w / cpr), (unsigned)(c * 8 + e))));
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] += keep * bf2f(f2bf(l[e] * v[e]));
@@ -873,7 +876,7 @@ __global__ void __launch_bounds__(256) ls_rmsnorm_fwd_kernel(const bf16_t* __res
       if (E.thresh) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          yv[e] = bf2f(f2bf(yv[e] * elem_drop_mul(E, GGET_DROP_STREAM_MLP_OUT, (unsigned)row, (unsigned)(c * 8 + e))));
+          yv[e] = bf2f(f2bf(yv[e] * elem_drop_mul(E, GGET_DROP_STREAM_MLP_OUT, elem_row(E, row), (unsigned)(c * 8 + e))));
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) r[e] += keep * bf2f(f2bf(lv[i][e] * yv[e]));
@@ -928,7 +931,7 @@ __global__ void __launch_bounds__(256) ls_bwd_kernel(const bf16_t* __restrict__ 
       unpack8(*reinterpret_cast<const uint4*>(y + (size_t)t * d + c * 8), v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float em = elem_drop_mul(E, GGET_DROP_STREAM_MLP_OUT, (unsigned)t, (unsigned)(c * 8 + e));
+        const float em = elem_drop_mul(E, GGET_DROP_STREAM_MLP_OUT, elem_row(E, t), (unsigned)(c * 8 + e));
         o[e] = l[e] * keep * g[e] * em;
         acc[e] += keep * g[e] * bf2f(f2bf(v[e] * em));
       }
@@ -1030,7 +1033,7 @@ __global__ void __launch_bounds__(256) rmsnorm_bwd_ls_kernel(const bf16_t* __res
         unpack8(pk, gq);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float em = elem_drop_mul(E, GGET_DROP_STREAM_MLP_OUT, (unsigned)row, (unsigned)(c * 8 + e));
+          const float em = elem_drop_mul(E, GGET_DROP_STREAM_MLP_OUT, elem_row(E, row), (unsigned)(c * 8 + e));
           sc[e] = lv[i][e] * keep * gq[e] * em;
           dlp[i][e] += keep * gq[e] * bf2f(f2bf(yv[i][e] * em));
         }
@@ -1175,9 +1178,10 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
   // are summed on the device and the total read back: 4 bytes and ONE stream synchronisation, which is what the reference's step pays
   // on every `.to(device)` of a batch tensor anyway, training_utils.py:17-26) - the real tokens are compacted sample after sample and
   // every token-wise kernel and GEMM of the layer stack runs on round_up(real, 64) rows instead of B * S (PCQM4M-v2 batches are ~30 %
-  // padding, ogbl-ppa ~37 %).  Logical [B,S] quantities (labels, lse, dropout coordinates, loss normalisers) are unchanged.  Not taken
-  // where a kernel's random stream or an output is indexed by the padded row: element dropouts, raw-embedding inputs, rope_range
-  // tables, the token-level head; packed rows carry no padding to begin with.
+  // padding, ogbl-ppa ~37 %).  Logical [B,S] quantities (labels, lse, dropout coordinates, loss normalisers) are unchanged: the
+  // element dropouts hash the logical row (ElemDropArg::rows = vl_c2p), the per-token rope_range tables are indexed through the compact
+  // position list (= the logical row).  Not taken where an INPUT or OUTPUT tensor is indexed by the padded row: raw-embedding inputs,
+  // the token-level head, full-logit inference; packed rows carry no padding to begin with.
   h->varlen = false;
   h->tc_from_caller = false;
   h->tc = B * S;
@@ -1191,8 +1195,7 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
                                c.kind == GGET_KIND_TASK ? h->wsp<int32_t>(h->ws.pool_row) : nullptr, B, S, st)) {
     return e;
   }
-  if (allow_varlen && varlen_enabled() && (tc_hint > 0 || tc_hint == GGET_TOKENS_AUTO) && !mask_is_3d && mask != nullptr && c.embed_dim == 0 &&
-      h->embed_drop_p == 0.f && h->mlp_drop_p == 0.f && !(h->rope_range > 0.f && pos)) {
+  if (allow_varlen && varlen_enabled() && (tc_hint > 0 || tc_hint == GGET_TOKENS_AUTO) && !mask_is_3d && mask != nullptr && c.embed_dim == 0) {
     long tc = tc_hint;
     if (tc_hint == GGET_TOKENS_AUTO) {
       int32_t* dst = h->wsp<int32_t>(h->ws.vl_status) + 3;
@@ -1219,10 +1222,12 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
   h->pos_rows = h->pos_cur;
   if (h->varlen) {
     const Ws& w = h->ws;
-    if (int e = k_varlen_plan(ids, ldF, c.stacked_feat, pos, h->wsp<int32_t>(w.key_len),
+    // (h->pos_cur: the caller's positions, or with rope_range the identity list into the per-token angle tables - a compact row then
+    //  reads the table row of its logical token)
+    if (int e = k_varlen_plan(ids, ldF, c.stacked_feat, h->pos_cur, h->wsp<int32_t>(w.key_len),
                               c.kind == GGET_KIND_TASK ? h->wsp<int32_t>(w.pool_row) : nullptr, h->wsp<int32_t>(w.vl_cu),
                               h->wsp<int64_t>(w.vl_ids), h->wsp<int64_t>(w.vl_pos), h->wsp<int32_t>(w.vl_rowb), h->wsp<int32_t>(w.vl_pad2c),
-                              h->wsp<int32_t>(w.vl_status), B, S, h->tc, h->T, c.pad_token_id, st))
+                              h->wsp<int32_t>(w.vl_c2p), h->wsp<int32_t>(w.vl_status), B, S, h->tc, h->T, c.pad_token_id, st))
       return e;
     h->ids = ids = h->wsp<int64_t>(w.vl_ids);
     ldF = c.stacked_feat;

@@ -60,8 +60,8 @@ int k_lengths(const int64_t* mask, const int64_t* ids, int ldF, int pad_id, int3
 // total), compact ids [t_rows][F] / row positions / sample index per row, pad2c[b*S+s] = compact row or -1; rows [tc, t_rows) are pad
 // tokens.  pool_row (task head, may be NULL) is moved to the compact rows; status[0] = 1 if sum(key_len) != tc.
 int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, int32_t* key_len, int32_t* pool_row, int32_t* cu,
-                  int64_t* ids_c, int64_t* pos_c, int32_t* row_b, int32_t* pad2c, int32_t* status, int B, int S, int tc, int t_rows,
-                  int pad_id, hipStream_t st);
+                  int64_t* ids_c, int64_t* pos_c, int32_t* row_b, int32_t* pad2c, int32_t* c2p, int32_t* status, int B, int S, int tc,
+                  int t_rows, int pad_id, hipStream_t st);      // c2p[r] = logical row b * S + s of compact row r
 // out = clamp(pos, 0, max_pos - 1); *flag = 1 (sticky) if anything was clamped
 int k_clamp_positions(const int64_t* pos, int64_t* out, int32_t* flag, long n, int max_pos, hipStream_t st);
 int k_remap_rows(int32_t* idx, const int32_t* count, const int32_t* pad2c, int cap, int pad_row, int32_t* status, hipStream_t st);

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(128) embed_fwd_kernel(const int64_t* __restric
         if (E.thresh) {   // embed_dropout acts on the gathered rows, before the stacking (modeling_helpers.py:96-101)
 #pragma unroll
           for (int e = 0; e < 8; ++e)
-            v[e] = bf2f(f2bf(v[e] * elem_drop_mul(E, GGET_DROP_STREAM_EMBED, (unsigned)(t * F + f), (unsigned)(c * 8 + e))));
+            v[e] = bf2f(f2bf(v[e] * elem_drop_mul(E, GGET_DROP_STREAM_EMBED, elem_row(E, t) * (unsigned)F + (unsigned)f, (unsigned)(c * 8 + e))));
         }
         if (gate) {
           float gv[8];
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(128) embed_reduce_kernel(const int32_t* __rest
         unpack8(raw[u], g);
         if (E.thresh) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) g[e] *= elem_drop_mul(E, GGET_DROP_STREAM_EMBED, (unsigned)cellv[u], (unsigned)(c * 8 + e));
+          for (int e = 0; e < 8; ++e) g[e] *= elem_drop_mul(E, GGET_DROP_STREAM_EMBED, elem_row(E, cellv[u] / F) * (unsigned)F + (unsigned)(cellv[u] % F), (unsigned)(c * 8 + e));
         }
         if (gate) {
           float gv[8];
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(128) embed_dgate_kernel(const int64_t* __restr
       if (E.thresh) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          ev[e] = bf2f(f2bf(ev[e] * elem_drop_mul(E, GGET_DROP_STREAM_EMBED, (unsigned)(t * F + f), (unsigned)(c * 8 + e))));
+          ev[e] = bf2f(f2bf(ev[e] * elem_drop_mul(E, GGET_DROP_STREAM_EMBED, elem_row(E, t) * (unsigned)F + (unsigned)f, (unsigned)(c * 8 + e))));
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += g[e] * ev[e];
@@ -1893,7 +1893,7 @@ __global__ void __launch_bounds__(kBlock) elem_dropout_kernel(bf16_t* __restrict
   const int cpr = n >> 3;
   const long total = T * cpr;
   for (long w = (long)blockIdx.x * kBlock + threadIdx.x; w < total; w += (long)gridDim.x * kBlock) {
-    const unsigned t = (unsigned)(w / cpr), c = (unsigned)(w % cpr) * 8;
+    const unsigned t = elem_row(E, w / cpr), c = (unsigned)(w % cpr) * 8;
     float v[8];
     unpack8(*reinterpret_cast<const uint4*>(x + w * 8), v);
 #pragma unroll
@@ -2145,8 +2145,8 @@ __global__ void __launch_bounds__(1024) varlen_scan_kernel(int32_t* __restrict__
 __global__ void __launch_bounds__(kBlock) varlen_fill_kernel(const int64_t* __restrict__ ids, int ldF, int F, const int64_t* __restrict__ pos,
                                                              const int32_t* __restrict__ key_len, const int32_t* __restrict__ cu,
                                                              int64_t* __restrict__ ids_c, int64_t* __restrict__ pos_c,
-                                                             int32_t* __restrict__ row_b, int32_t* __restrict__ pad2c, int B, int S,
-                                                             int tc, int t_rows, int64_t pad_id) {
+                                                             int32_t* __restrict__ row_b, int32_t* __restrict__ pad2c,
+                                                             int32_t* __restrict__ c2p, int B, int S, int tc, int t_rows, int64_t pad_id) {
   const long i = (long)blockIdx.x * kBlock + threadIdx.x;
   const long TP = (long)B * S;
   if (i < TP) {
@@ -2157,6 +2157,7 @@ __global__ void __launch_bounds__(kBlock) varlen_fill_kernel(const int64_t* __re
       pos_c[r] = pos ? pos[i] : (int64_t)sq;
       row_b[r] = b;
       pad2c[i] = r;
+      c2p[r] = (int)i;        // the row's logical coordinate b * S + s (element-dropout hashes, rope_range tables)
     } else {
       pad2c[i] = -1;
     }
@@ -2165,6 +2166,7 @@ __global__ void __launch_bounds__(kBlock) varlen_fill_kernel(const int64_t* __re
     for (int f = 0; f < F; ++f) ids_c[(size_t)r * F + f] = pad_id;
     pos_c[r] = 0;
     row_b[r] = 0;
+    c2p[r] = (int)i;          // (behind the padded grid: a coordinate no real token has)
   }
 }
 // SMTP head: the selected rows (padded token indices, head_fill_kernel) -> rows of the compact layout.  A label != -100 at a PADDED
@@ -2218,12 +2220,12 @@ int k_clamp_positions(const int64_t* pos, int64_t* out, int32_t* flag, long n, i
 }
 
 int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, int32_t* key_len, int32_t* pool_row, int32_t* cu,
-                  int64_t* ids_c, int64_t* pos_c, int32_t* row_b, int32_t* pad2c, int32_t* status, int B, int S, int tc, int t_rows,
-                  int pad_id, hipStream_t st) {
+                  int64_t* ids_c, int64_t* pos_c, int32_t* row_b, int32_t* pad2c, int32_t* c2p, int32_t* status, int B, int S, int tc,
+                  int t_rows, int pad_id, hipStream_t st) {
   hipLaunchKernelGGL(varlen_scan_kernel, dim3(1), dim3(1024), 0, st, key_len, cu, pool_row, status, B, S, tc);
   const long n = (long)B * S + (t_rows - tc);
   hipLaunchKernelGGL(varlen_fill_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, ids, ldF, F, pos, key_len, cu,
-                     ids_c, pos_c, row_b, pad2c, B, S, tc, t_rows, (int64_t)pad_id);
+                     ids_c, pos_c, row_b, pad2c, c2p, B, S, tc, t_rows, (int64_t)pad_id);
   GGET_LAUNCH_CHECK();
   return 0;
 }

@@ -304,3 +304,37 @@ def test_bench_eight_ranks_gloo_smoke():
     assert dp["world"] == 8 and dp["n_buckets"] == 2 + 2 and dp["collectives_per_step"] == 4
     assert dp["replicas_bit_identical"] is True
     assert np.isfinite(dp["exposed_comm_ms"]) and np.isfinite(d["smtp_loss"])
+    assert len(dp["rank_devices"]) == 8 and dp["distinct_devices"] >= 1 and dp["rank_devices"][3]["rank"] == 3
+
+
+@pytest.mark.parametrize("backend", ["torch", "abi"])
+def test_bench_two_gpus_over_rccl(backend):
+    """The first real multi-GPU evidence, whenever a box has >= 2 GPUs (auto-skips on the one-GPU boxes of this pool): `bench.py
+    --gpus 2` launched exactly as the driver's SCALE run does, over RCCL, with the gradient exchange through torch.distributed
+    (default) and through the C ABI's own communicator (GGET_DP_BACKEND=abi: ncclAllReduce on the engine's side stream).  The
+    replicas must be bit-identical after the timed steps, the backend must be RCCL, the ranks must sit on distinct devices, the
+    exposed-communication diagnostic must be finite.  reference: src/utils/opt_utils.py:13 (DDP), src/utils/misc_utils.py:519-526."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs >= 2 GPUs, this box has {torch.cuda.device_count()}")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GGET_DP_BACKEND=backend)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GGET_BENCH_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    dp = d["dp"]
+    assert d["n_gpus"] == 2 and dp["world"] == 2 and d["config"]["parallelism"] == "dp2"
+    assert dp["replicas_bit_identical"] is True
+    assert ("nccl" in dp["backend"] or "rccl" in dp["backend"]), dp["backend"]
+    assert (backend == "abi") == (dp["backend"] == "rccl-via-c-abi")
+    assert dp["distinct_devices"] == 2 and len(dp["rank_devices"]) == 2
+    assert np.isfinite(dp["exposed_comm_ms"]) and np.isfinite(d["smtp_loss"]) and dp["rccl_version"]
+    assert d["value"] > 0 and d["scaling"] == "weak"

@@ -674,9 +674,9 @@ def _c1_engine_and_batch(seed=77, size="base"):
 @pytest.mark.parametrize("size", ["base", "base24"])
 def test_c1_full_size_loss_matches_oracle(size, layout):
     """BASELINE configs[1] (base d768/L12) and configs[2] (base24, 24 layers) at full size (B=256, S=32, F=13, V=756): SMTP loss of the HIP forward against the
-    oracle forward on the same bf16-rounded weights (tolerance: north_star's 1e-4 relative is for same-cast-point fp32
-    arithmetic; the 12-layer bf16 path is held to 3e-4, the reference's own bf16-vs-fp32 gap on the full-width fixtures is 1e-5 ...
-    1.3e-4), on the padded grid and on the var-len token layout the bench runs (include/gget.h: gget_set_token_count)."""
+    oracle forward on the same bf16-rounded weights, held to 5e-5 relative - inside north_star's 1e-4 and ~10 x what four rounds have
+    measured (2e-6 ... 4e-6: a mean over ~37 k masked cells averages the bf16 rounding away) - on the padded grid and on the var-len
+    token layout the bench runs (include/gget.h: gget_set_token_count)."""
     spec, state, batch, e = _c1_engine_and_batch(size=size)
     b = tb(batch)
     n_tok = int(batch["attention_mask"].sum()) if layout == "varlen" else None
@@ -686,16 +686,19 @@ def test_c1_full_size_loss_matches_oracle(size, layout):
     p = O.to_params(st_bf, torch.float32, requires_grad=False)
     with torch.no_grad():
         want = O.pretrain_forward(spec, p, b["input_ids"], b["attention_mask"], b["labels"])["head1_loss"].item()
-    record_error(f"c1_full_size_{size}_{layout}", "loss_rel_vs_oracle (B=256, S=32)", abs(float(loss) - want) / abs(want), 3e-4)
-    assert abs(float(loss) - want) <= 3e-4 * abs(want), (float(loss), want)
+    record_error(f"c1_full_size_{size}_{layout}", "loss_rel_vs_oracle (B=256, S=32)", abs(float(loss) - want) / abs(want), 5e-5)
+    assert abs(float(loss) - want) <= 5e-5 * abs(want), (float(loss), want)
 
 
-@pytest.mark.parametrize("layout", ["padded", "varlen"])
-def test_c1_full_size_backward_matches_oracle(layout):
+@pytest.mark.parametrize("size,layout", [("base", "padded"), ("base", "varlen"), ("base24", "varlen")])
+def test_c1_full_size_backward_matches_oracle(size, layout):
     """The headline configuration at FULL size (base d768 / L12, B = 256, S = 32, F = 13, V = 756: one oracle fwd + bwd, ~6 s on the
-    box's host cores): loss and the gradients of ten tensors spread over the stack - embedding, first / middle / last layer
-    attention and MLP projections, a norm weight, n_token_proj and lm_head - against the oracle, on both token layouts."""
-    spec, state, batch, e = _c1_engine_and_batch(size="base", seed=79)
+    box's host cores): loss and the gradients of eleven tensors spread over the stack - embedding, first / middle / last layer
+    attention and MLP projections, a norm weight, n_token_proj and lm_head - against the oracle, on both token layouts; and
+    BASELINE configs[2] (base24: the same width, 24 layers) on the layout the bench runs.  Tolerances: loss 5e-5 (measured 2.5e-6),
+    gradients 3e-2 rel-L2 (measured 4e-3 ... 1.4e-2 on the 12-layer model)."""
+    spec, state, batch, e = _c1_engine_and_batch(size=size, seed=79)
+    Lm, Ll = spec.num_layers // 2 - 1, spec.num_layers - 1
     b = tb(batch)
     n_tok = int(batch["attention_mask"].sum()) if layout == "varlen" else None
     loss = e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], b.get("wgt"), num_tokens=n_tok)
@@ -706,21 +709,21 @@ def test_c1_full_size_backward_matches_oracle(layout):
     fn, lk, _ = oracle_fn(spec, b, "pt")
     out, grads = O.loss_and_grads(fn, p, lk)
     want = out[lk].item()
-    tag = f"c1_full_size_backward_{layout}"
-    record_error(tag, "loss_rel_vs_oracle", abs(float(loss) - want) / abs(want), 3e-4)
-    assert abs(float(loss) - want) <= 3e-4 * abs(want), (float(loss), want)
+    tag = f"c1_full_size_backward_{layout}" if size == "base" else f"c2_full_size_backward_{size}_{layout}"
+    record_error(tag, "loss_rel_vs_oracle", abs(float(loss) - want) / abs(want), 5e-5)
+    assert abs(float(loss) - want) <= 5e-5 * abs(want), (float(loss), want)
     got = e.grads()
     gmax = max(float(g.norm()) for g in grads.values())
     for k in ("model.embed_tokens.weight", "model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.v_proj.weight",
-              "model.layers.0.mlp.gate_proj.weight", "model.layers.5.self_attn.o_proj.weight", "model.layers.5.mlp.down_proj.weight",
-              "model.layers.5.post_attention_layernorm.weight", "model.layers.11.self_attn.k_proj.weight",
-              "model.layers.11.mlp.up_proj.weight", "n_token_proj.weight", "lm_head.weight"):
+              "model.layers.0.mlp.gate_proj.weight", f"model.layers.{Lm}.self_attn.o_proj.weight", f"model.layers.{Lm}.mlp.down_proj.weight",
+              f"model.layers.{Lm}.post_attention_layernorm.weight", f"model.layers.{Ll}.self_attn.k_proj.weight",
+              f"model.layers.{Ll}.mlp.up_proj.weight", "n_token_proj.weight", "lm_head.weight"):
         w = grads[k].numpy()
         # (standard init: q / k gradients are ~1e-3 of the largest - near-uniform attention - and sit at the bf16 noise floor of the
         #  signal that feeds them: tensors below 1 % of the largest norm are judged on that scale, like test_backward_matches_oracle)
         err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
-        record_error(tag, "grad_rel_l2 " + k, err, 6e-2)
-        assert err < 6e-2, f"{k}: {err}"
+        record_error(tag, "grad_rel_l2 " + k, err, 3e-2)
+        assert err < 3e-2, f"{k}: {err}"
 
 
 def test_c1_full_size_properties():
@@ -1729,18 +1732,21 @@ def test_gradient_norm_from_backward_partials_matches_full_pass(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["labels", "labels_varlen", "dlm_weights", "inference"])
-def test_slot_sorted_head_matches_dense_head(mode):
+@pytest.mark.parametrize("mode,d", [("labels", 768), ("labels_varlen", 768), ("dlm_weights", 768), ("inference", 768),
+                                    ("labels", 576), ("labels_varlen", 576)])
+def test_slot_sorted_head_matches_dense_head(mode, d):
     """Round 4: n_token_proj on the labelled cells only (cells sorted by slot, one GEMM with a weight block per row tile; kernels.hip
     "Slot-sorted SMTP head") against the dense form of rounds 1-3 - every selected row through all n slots, then the gather
     (modeling_helpers.py:263-301, the reference's order of operations) - on the full-width model: same loss and head logits (both forms
     run the K = d reduction of a cell's row in one tile-K order), and the gradients of every tensor within bf16 rounding (the sorted
     backward rounds one input-gradient row per cell to bf16 before a token's cells are summed; the dense one sums in the accumulator).
-    The dense form itself is what the reference fixtures pin on the narrow models (d = 128 takes it: the sorted form needs d % 192 == 0)."""
+    The dense form itself is what the reference fixtures pin on the narrow models (d = 128 takes it: the sorted form needs d % 192 == 0).
+    d = 576: d / 8 = 72 channels, so head_cell_sum_kernel's last pass over the channels has 8 live lanes while tokens carry up
+    to 13 labelled cells - the cell rows must still come from all 13 lanes."""
     from _util import spec_mod, weights_mod, synth
     lib = L.load()
     B, S, F, V = 64, 32, 13, 756
-    spec = spec_mod.ModelSpec(kind=spec_mod.KIND_PRETRAIN, vocab_size=V, hidden_size=768, intermediate_size=3072, num_layers=2, num_heads=12,
+    spec = spec_mod.ModelSpec(kind=spec_mod.KIND_PRETRAIN, vocab_size=V, hidden_size=d, intermediate_size=4 * d, num_layers=2, num_heads=d // 64,
                               head_dim=64, stacked_feat=F, next_n_token=F, causal=False, max_position=1024)
     state = weights_mod.make_state_dict(spec, seed=5, std=0.05, head_std=0.1)
     batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=31, dlm_wgt=(mode == "dlm_weights"))
@@ -1775,5 +1781,5 @@ def test_slot_sorted_head_matches_dense_head(mode):
             den = max(float(np.linalg.norm(grd[k])), 1e-2 * gmax)
             err = float(np.linalg.norm(grs[k] - grd[k])) / den
             tol = 1e-6 if k in ("lm_head.weight",) else 8e-3        # lm_head's gradient does not pass through n_token_proj's backward
-            record_error("slot_sorted_head_" + mode, "grad_rel_l2_vs_dense " + k, err, tol)
+            record_error("slot_sorted_head_" + mode + ("" if d == 768 else f"_d{d}"), "grad_rel_l2_vs_dense " + k, err, tol)
             assert err <= tol, (k, err)

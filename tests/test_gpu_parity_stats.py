@@ -1,0 +1,173 @@
+"""Is the fine-tune loss deviation of the bf16 engine NOISE or BIAS?  (VERDICT r4 "What's weak" 1, "Next round" 3.)
+
+The fine-tune fixtures are means over 2-32 pooled rows and sit 1e-3 ... 1.4e-2 from the fp32 loss under tolerances derived from the
+reference's own bf16-vs-fp32 gap.  That argument needs evidence that the deviation is zero-mean rounding noise - it must shrink like
+1/sqrt(rows) and carry no sign:
+
+  (i)   C3 (BASELINE configs[3]: base model + LayerScale, S = 256, F = 4, V = 41245) at B = 64 and B = 128, forward, HIP vs oracle:
+        loss held to 1e-3 / 7e-4 - a mean over 64 / 128 pooled rows must beat the 4-row fixture (1.05e-3 reference gap, 2.1e-3 measured at
+        B = 8) if the deviation is noise;
+  (ii)  a 16-seed sign test of (HIP loss - fp32 oracle loss) on ft_tiny_f4-shaped batches (and the 32-row shape): |mean| <= 2 sigma/sqrt(16);
+  (iii) the same C3 rows split into groups of 4: the group errors scatter around zero with the spread the small fixtures show;
+  (iv)  C3 in TRAINING mode (DropPath 0.2 + attention dropout 0.1, identical masks through the Python twins) at B = 32 next to its eval-mode
+        twin on the same weights: the 2.3e-2 of the B = 4 check (std-0.04 weights) is the few-row scatter of that weight scale, not the dropouts.
+Reference: /root/reference/src/models/graphgpt/modeling_finetune.py:167-234 (calculate_task_loss), :236-326 (forward)."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fnn
+
+from _util import ROOT, record_error, spec_mod, synth, tb, weights_mod
+from oracle import gget_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+eng_mod = importlib.import_module("graph-gpt_amd.engine")
+L = importlib.import_module("graph-gpt_amd._lib")
+
+
+def _bf16_weights(state):
+    return {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in state.items()}
+
+
+def _dump(name, rec):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", name), "w") as fh:
+        json.dump(rec, fh, indent=1)
+
+
+def _c3(B, seed_w=9, seed_b=192, std=0.02, head_std=None, path_pdrop=0.0):
+    S, F, V = 256, 4, 41245
+    spec = spec_mod.spec_from_size("base", kind=spec_mod.KIND_TASK, vocab_size=V, stacked_feat=F, next_n_token=1, num_labels=2,
+                                   max_position=1024, layer_scale_init=1.0, path_pdrop=path_pdrop)
+    state = weights_mod.make_state_dict(spec, seed=seed_w, std=std, head_std=head_std)
+    batch = synth.make_task_batch(B=B, S=S, F=F, V=V, seed=seed_b, lengths="uniform", min_len=S // 4)
+    return spec, state, batch
+
+
+def _oracle_task(spec, state_bf, b, chunk=16, **kw):
+    """fp32 oracle forward in chunks of `chunk` samples (memory: [chunk,H,S,S] score tensors); logits [B, num_labels]"""
+    p = O.to_params(state_bf, torch.float32, requires_grad=False)
+    B = b["input_ids"].shape[0]
+    outs = []
+    with torch.no_grad():
+        for a in range(0, B, chunk):
+            sl = slice(a, min(B, a + chunk))
+            kk = {k: (lambda f, sl: (lambda *args: f(*args)[sl]))(f, sl) for k, f in kw.items()}      # per-sample masks: this chunk's rows
+            out = O.task_forward(spec, p, b["input_ids"][sl], b["attention_mask"][sl], b["position_ids"][sl], b["task_labels"][sl], **kk)
+            outs.append(out["task_logits"].float())
+    return torch.cat(outs)
+
+
+@pytest.mark.parametrize("B,tol", [(64, 1e-3), (128, 7e-4)])
+def test_c3_large_batch_loss_deviation_shrinks_like_noise(B, tol):
+    spec, state, batch = _c3(B)
+    b = tb(batch)
+    e = eng_mod.Engine(spec, max_tokens=B * 256, max_batch=B)
+    e.load_state_dict(state)
+    loss, logits, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], None, L.PROBLEM_SINGLE_LABEL,
+                                     num_tokens=int(batch["attention_mask"].sum()))
+    torch.cuda.synchronize()
+    want_logits = _oracle_task(spec, _bf16_weights(state), b)
+    y = b["task_labels"]
+    want = float(Fnn.cross_entropy(want_logits, y))
+    got = float(loss)
+    rel = abs(got - want) / abs(want)
+    lg = logits.float().cpu()
+    dlogit = float((lg - want_logits).abs().max())
+    # per-row CE of both, groups of 4 rows = the size of the small fixtures
+    ce_g, ce_w = Fnn.cross_entropy(lg, y, reduction="none"), Fnn.cross_entropy(want_logits, y, reduction="none")
+    assert abs(float(ce_g.mean()) - got) <= 2e-5 * abs(got)          # the engine's loss IS the mean CE of its logits
+    grp = ((ce_g - ce_w).view(-1, 4).mean(1) / ce_w.view(-1, 4).mean(1)).numpy()
+    n = len(grp)
+    mean, sd = float(grp.mean()), float(grp.std(ddof=1))
+    rec = {"B": B, "loss_engine": got, "loss_oracle_fp32_on_bf16_weights": want, "loss_rel": rel, "logits_max_abs_dev": dlogit,
+           "groups_of_4_rows": {"n": n, "mean_rel_err": mean, "std_rel_err": sd, "stderr_of_mean": sd / np.sqrt(n),
+                                "max_abs_rel_err": float(np.abs(grp).max()), "positive_fraction": float((grp > 0).mean())}}
+    _dump(f"parity_stats_c3_B{B}.json", rec)
+    record_error(f"c3_S256_B{B}_forward", "loss_rel_vs_oracle", rel, tol)
+    record_error(f"c3_S256_B{B}_forward", "task_logits_max_abs_vs_oracle", dlogit, 3e-2)
+    record_error(f"c3_S256_B{B}_forward", f"groups_of_4_rows mean_rel_err (std {sd:.2e}, n {n})", abs(mean), 2.5 * sd / np.sqrt(n) + 1e-5)
+    assert rel <= tol, rec
+    assert dlogit <= 3e-2, rec
+    assert abs(mean) <= 2.5 * sd / np.sqrt(n) + 1e-5, rec            # no sign: the group errors scatter around zero
+
+
+@pytest.mark.parametrize("shape", ["f4", "f4_b32"])
+def test_sixteen_seed_sign_test_of_finetune_loss_deviation(shape):
+    """16 independent (weights, batch) draws of the fixture shape (tiny d128 / L2, F = 4, S = 24; B = 4 with standard init like ft_tiny_f4, B = 32 with the
+    wide init of ft_tiny_f4_b32): d_i = (HIP loss - oracle loss) / oracle loss, oracle = fp32 arithmetic on the same bf16-rounded weights.
+    Fail if |mean d| > 2 sigma / sqrt(16) (a bias would show as a mean that does not shrink with the number of draws)."""
+    B, std, head_std = (4, 0.02, None) if shape == "f4" else (32, 0.06, 0.15)
+    S, F, V = 24, 4, 1000
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=V, stacked_feat=F, next_n_token=1, num_labels=2)
+    e = eng_mod.Engine(spec, max_tokens=B * S, max_batch=B)
+    ds, dl = [], []
+    for i in range(16):
+        state = weights_mod.make_state_dict(spec, seed=1000 + i, std=std, head_std=head_std)
+        batch = synth.make_task_batch(B=B, S=S, F=F, V=V, seed=2000 + i)
+        b = tb(batch)
+        e.load_state_dict(state)
+        loss, logits, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], None, L.PROBLEM_SINGLE_LABEL)
+        want_logits = _oracle_task(spec, _bf16_weights(state), b, chunk=B)
+        want = float(Fnn.cross_entropy(want_logits, b["task_labels"]))
+        ds.append((float(loss) - want) / want)
+        dl.append(float((logits.float().cpu() - want_logits).abs().max()))
+    ds = np.asarray(ds)
+    mean, sd = float(ds.mean()), float(ds.std(ddof=1))
+    rec = {"shape": shape, "B": B, "rel_dev_by_seed": ds.tolist(), "mean": mean, "std": sd, "two_sigma_over_sqrt_n": 2 * sd / 4.0,
+           "max_abs": float(np.abs(ds).max()), "positive": int((ds > 0).sum()), "logits_max_abs_dev_max": max(dl)}
+    _dump(f"parity_stats_sign_test_{shape}.json", rec)
+    record_error(f"ft_tiny_{shape}_16_seed_sign_test", f"abs_mean_rel_loss_dev (std {sd:.2e}, +{rec['positive']}/16)", abs(mean), 2 * sd / 4.0)
+    record_error(f"ft_tiny_{shape}_16_seed_sign_test", "max_abs_rel_loss_dev", float(np.abs(ds).max()), 2e-2)
+    assert abs(mean) <= 2 * sd / 4.0, rec
+    assert np.abs(ds).max() <= 2e-2, rec
+
+
+def test_c3_training_mode_dropouts_large_batch_and_eval_twin():
+    """The B = 4 check of test_gpu_model.py::test_c3_training_mode_dropouts_exact_mask measures 2.3e-2 with identical masks.  Same weights
+    (std 0.04, head 0.1: twice the standard init, logits of +-3), B = 32: (a) eval mode, (b) training mode with both masks handed to
+    the oracle.  Both means over 32 rows must come in under 8e-3, the training-mode one no worse than 2 x the eval one + 2e-3 -
+    the dropouts add nothing beyond the few-row scatter of this weight scale; the first 4 rows alone reproduce the B = 4 magnitude."""
+    from test_gpu_model import _attn_drop_keep, _path_keep
+    B, S, seed, p_attn, p_path = 32, 256, 4242, 0.1, 0.2
+    spec, state, batch = _c3(B, seed_w=9, seed_b=94, std=0.04, head_std=0.1, path_pdrop=p_path)
+    b = tb(batch)
+    y = b["task_labels"]
+    e = eng_mod.Engine(spec, max_tokens=B * S, max_batch=B)
+    e.load_state_dict(state)
+    sb = _bf16_weights(state)
+    res = {}
+    for mode in ("eval", "train"):
+        e.set_dropout(p_attn if mode == "train" else 0.0, p_path if mode == "train" else 0.0, seed)
+        loss, logits, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], y, None, L.PROBLEM_SINGLE_LABEL)
+        torch.cuda.synchronize()
+        kw = {}
+        if mode == "train":
+            L_, H = spec.num_layers, spec.num_heads
+            cache = {}
+
+            def attn_keep(l):
+                if l not in cache:
+                    cache.clear()           # (one layer's [B,H,S,S] mask at a time)
+                    cache[l] = _attn_drop_keep((seed + 0x9E37 * l) & 0xFFFFFFFF, B, H, S, p_attn)
+                return cache[l]
+            kw = dict(path_mult=lambda l, w: _path_keep(seed, l, w, B, p_path * l / (L_ - 1)), attn_keep=attn_keep)
+        want_logits = _oracle_task(spec, sb, b, chunk=8, **kw)
+        want = float(Fnn.cross_entropy(want_logits, y))
+        lg = logits.float().cpu()
+        ce_g, ce_w = Fnn.cross_entropy(lg, y, reduction="none"), Fnn.cross_entropy(want_logits, y, reduction="none")
+        grp = ((ce_g - ce_w).view(-1, 4).mean(1) / ce_w.view(-1, 4).mean(1)).numpy()
+        res[mode] = {"loss_engine": float(loss), "loss_oracle": want, "rel": abs(float(loss) - want) / want,
+                     "logits_max_abs_dev": float((lg - want_logits).abs().max()), "logits_abs_max": float(want_logits.abs().max()),
+                     "groups_of_4_rel_err": grp.tolist()}
+    _dump("parity_stats_c3_train_vs_eval_B32.json", res)
+    record_error("c3_train_mode_dropouts_B32", "eval loss_rel_vs_oracle", res["eval"]["rel"], 8e-3)
+    record_error("c3_train_mode_dropouts_B32", "train loss_rel_vs_oracle_same_masks", res["train"]["rel"], 8e-3)
+    record_error("c3_train_mode_dropouts_B32", "max |rel err| of a 4-row group (train)", float(np.abs(res["train"]["groups_of_4_rel_err"]).max()), 6e-2)
+    assert res["eval"]["rel"] <= 8e-3 and res["train"]["rel"] <= 8e-3, res
+    assert res["train"]["rel"] <= 2 * res["eval"]["rel"] + 2e-3, res

@@ -140,8 +140,8 @@ def test_varlen_layerscale_droppath_training_mode():
 
 
 def test_varlen_wrong_token_count_is_flagged_and_fallbacks():
-    """A caller's count that disagrees with the mask raises the device-side flag (gget_varlen_status); element dropouts, the
-    token-level head and full rows keep the padded layout by themselves."""
+    """A caller's count that disagrees with the mask raises the device-side flag (gget_varlen_status); full-logit inference and full
+    rows keep the padded layout by themselves; element dropouts no longer do (round 5: their hashes are keyed by the logical row)."""
     spec = _tiny_spec(spec_mod.KIND_PRETRAIN, 32)
     state = weights_mod.make_state_dict(spec, seed=3)
     batch = synth.make_pretrain_batch(B=16, S=32, F=4, V=500, seed=5)
@@ -163,10 +163,84 @@ def test_varlen_wrong_token_count_is_flagged_and_fallbacks():
     full = torch.ones_like(b["attention_mask"])
     e.forward_pretrain(b["input_ids"], full, b["labels"], num_tokens=16 * 32)       # no padding -> nothing to compact
     assert e.varlen_status()[0] is False
-    e.set_dropout_ex(0.1, 0.0, 0.0)                                                 # element dropout hashes the padded row index
+    e.set_dropout_ex(0.1, 0.1, 0.0)                                                 # element dropouts hash the LOGICAL row: no fallback
     e.set_dropout(0.0, 0.0, 5)
     e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], num_tokens=n)
-    assert e.varlen_status()[0] is False
+    assert e.varlen_status() == (True, (n + 63) // 64 * 64, False)
+
+
+@pytest.mark.parametrize("kind", ["pt", "ft"])
+def test_varlen_element_dropouts_draw_the_padded_grids_masks(kind):
+    """embed_dropout + the two MLP dropouts (utils_graphgpt.py:69-80, modeling_helpers.py:96-101) on the var-len layout: the counter
+    hashes are keyed by the logical [B,S] row (ElemDropArg::rows), so the compact step must reproduce the padded step's loss and
+    gradients with the SAME seed - exactly the masks the Python twins pin against the oracle in
+    tests/test_gpu_model.py::test_embed_and_mlp_dropouts_exact_mask.  ft: LayerScale + DropPath + attention dropout on top (the C3
+    training configuration with mlp_pdrop > 0)."""
+    S, F, V, B = 40, 4, 500, 24
+    if kind == "pt":
+        spec = _tiny_spec(spec_mod.KIND_PRETRAIN, S)
+        batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=15)
+    else:
+        spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=V, stacked_feat=F, next_n_token=1, num_labels=2,
+                                       layer_scale_init=1.0, path_pdrop=0.2, gated_agg=True)
+        batch = synth.make_task_batch(B=B, S=S, F=F, V=V, seed=15)
+    state = weights_mod.make_state_dict(spec, seed=3, std=0.05, head_std=0.1)
+    b = tb({k: v for k, v in batch.items() if k != "lengths"})
+    n = int(batch["attention_mask"].sum())
+    out = {}
+    for lay, cnt in (("padded", None), ("varlen", n)):
+        e = eng_mod.Engine(spec, max_tokens=B * S, max_batch=B)
+        e.load_state_dict(state)
+        e.set_dropout(0.1, 0.2 if kind == "ft" else 0.0, 77)
+        e.set_dropout_ex(0.15, 0.2, 0.0)
+        if kind == "pt":
+            loss = e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], num_tokens=cnt)
+        else:
+            loss, _, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], None, L.PROBLEM_SINGLE_LABEL,
+                                        num_tokens=cnt)
+        assert e.varlen_status()[0] == (lay == "varlen")
+        e.backward()
+        torch.cuda.synchronize()
+        out[lay] = (float(loss), {k: v.float().cpu().numpy().copy() for k, v in e.grads().items()})
+        # ... and the masks really are on: the same step without the element dropouts gives another loss
+        if lay == "padded":
+            e.set_dropout_ex(0.0, 0.0, 0.0)
+            l0 = e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"]) if kind == "pt" else \
+                e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], None, L.PROBLEM_SINGLE_LABEL)[0]
+            assert abs(float(l0) - float(loss)) > 1e-3 * abs(float(loss))
+    (lp, gp), (lv, gv) = out["padded"], out["varlen"]
+    assert abs(lv - lp) <= 2e-5 * abs(lp), (lv, lp)
+    gmax = max(float(np.linalg.norm(g)) for g in gp.values())
+    for k in gp:
+        err = float(np.linalg.norm(gv[k] - gp[k])) / max(float(np.linalg.norm(gp[k])), 1e-2 * gmax)
+        assert err < 1e-2, (k, err)        # same masks, bf16 gradients, another summation order over the rows
+
+
+def test_varlen_rope_range_matches_padded():
+    """rope_range > 0 (utils_graphgpt.reset_pos_ids :574-581: positions rescaled per row, angles evaluated per token): on the var-len
+    layout a compact row reads the angle-table row of its logical token - loss, logits and gradients of the padded run."""
+    S, F, V, B = 48, 4, 500, 12
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=V, stacked_feat=F, next_n_token=1, num_labels=2, rope_range=6.0)
+    state = weights_mod.make_state_dict(spec, seed=4, std=0.05, head_std=0.1)
+    batch = synth.make_task_batch(B=B, S=S, F=F, V=V, seed=16)
+    b = tb({k: v for k, v in batch.items() if k != "lengths"})
+    n = int(batch["attention_mask"].sum())
+    out = {}
+    for lay, cnt in (("padded", None), ("varlen", n)):
+        e = eng_mod.Engine(spec, max_tokens=B * S, max_batch=B)
+        e.load_state_dict(state)
+        e.set_rope_range(6.0)
+        loss, logits, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], None, L.PROBLEM_SINGLE_LABEL,
+                                         num_tokens=cnt)
+        assert e.varlen_status()[0] == (lay == "varlen")
+        e.backward()
+        torch.cuda.synchronize()
+        out[lay] = (float(loss), logits.float().cpu().numpy().copy(), {k: v.float().cpu().numpy().copy() for k, v in e.grads().items()})
+    (lp, zp, gp), (lv, zv, gv) = out["padded"], out["varlen"]
+    assert abs(lv - lp) <= 2e-5 * abs(lp) and np.abs(zv - zp).max() <= 1e-3 * max(1.0, np.abs(zp).max())
+    gmax = max(float(np.linalg.norm(g)) for g in gp.values())
+    for k in gp:
+        assert float(np.linalg.norm(gv[k] - gp[k])) / max(float(np.linalg.norm(gp[k])), 1e-2 * gmax) < 1e-2, k
 
 
 def test_varlen_model_classes_and_training_step(monkeypatch):

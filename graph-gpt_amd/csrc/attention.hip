@@ -824,6 +824,524 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
 }
 
 // ================================================================================================
+// S <= 32, one WORKGROUP per sample (round 5): attention of all H heads, the o projection + residual add and the RMSNorm behind it in
+// ONE launch.  Graph sequences of the headline workload are ~22 tokens: a sample is a single 32-row tile, and the three launches it
+// replaces (attn_fwd_kernel<1> 11.9 us + the N = K = d GEMM 15.9 us + rmsnorm_fwd 6.1 us per layer at T = 5696) are latency chains,
+// not work - the GEMM offers only 180 tiles to 256 CUs and spends most of its time in prologue / epilogue.
+//   phase 1  wave h = head h: the single-tile form of attn_fwd_kernel<1> (same arithmetic, same dropout hash); the normalised output
+//            tile goes to global memory (the backward and the o weight gradient read it) AND to an LDS tile O[32][d] (bf16)
+//   phase 2  Y^T[n][q] = Wo[n][:] . O[q][:] on v_mfma_f32_16x16x32_bf16: wave w owns output channels [64 w, 64 w + 64); the Wo
+//            fragments come straight from global memory into registers, from a FRAGMENT-MAJOR copy of the weight (pack_wo_kernel:
+//            the 64 lanes' 16-byte pieces of one 16 x 32 MFMA operand are 1 KiB contiguous).  In the weight's own row-major layout a
+//            fragment is 16 rows x 64 bytes with ADJACENT LANES IN DIFFERENT ROWS: the texture addresser coalesces neighbouring lanes
+//            only, so that form issues 64 separate 16-byte requests per instruction - measured 5.9 TB/s over the chip = 10 B/clk per
+//            CU, the whole launch 50.8 us against 36.0 us for the three launches it replaces (profiles/r05_attn_oproj_experiments.txt).
+//            The O fragments come from LDS; residual added on the fp32 accumulator, ONE bf16 rounding (as the GEMM epilogue does),
+//            the tile x_mid[32][d] goes back to LDS, the rows' sums of squares to a [H][32] table
+//   phase 3  all threads: x_mid and xn = w * bf16(x_mid * rstd) (hf LlamaRMSNorm.forward :62-67) leave in whole 16-byte row pieces
+// What bounds it: every sample streams the d x d weight through its CU's vector cache once (1.18 MB at 64 B/clk = 7.7 us for d = 768).
+// reference: hf LlamaAttention.forward :243-281 (o_proj), LlamaDecoderLayer.forward :305-316 (residual, post_attention_layernorm).
+// ================================================================================================
+// Fragment-major copies of a [d][d] weight for the per-sample kernels below: fwd[((T KS + s) * 64 + lane) * 8 + e] = W[16 T + (lane & 15)]
+// [32 s + 8 (lane >> 4) + e] (the A operand of v_mfma_f32_16x16x32_bf16 for rows 16 T .. 16 T + 15, contraction 32 s .. 32 s + 31; KS = d / 32),
+// and the same of the TRANSPOSED weight in bwd (rows = W's columns).  One block per 64 x 64 tile of W; grid (d / 64, d / 64, layers).
+__global__ void __launch_bounds__(256) pack_wo_kernel(const bf16_t* __restrict__ w0, size_t layer_stride, bf16_t* __restrict__ fwd,
+                                                      bf16_t* __restrict__ bwd, int d) {
+  __shared__ bf16_t tile[64][72];
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64, KS = d / 32;
+  const bf16_t* w = w0 + (size_t)blockIdx.z * layer_stride;
+  bf16_t* fo = fwd + (size_t)blockIdx.z * d * d;
+  bf16_t* bo = bwd + (size_t)blockIdx.z * d * d;
+  for (int c = threadIdx.x; c < 512; c += 256) {
+    const int r = c >> 3, ch = c & 7;
+    *reinterpret_cast<uint4*>(&tile[r][ch * 8]) = *reinterpret_cast<const uint4*>(w + (size_t)(n0 + r) * d + k0 + ch * 8);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 512; c += 256) {
+    const int fr = c >> 6, lane = c & 63, li = lane & 15, g4 = lane >> 4;
+    const int tl = fr >> 1, sl = fr & 1;      // 4 row tiles x 2 contraction steps inside the 64 x 64 block
+    // forward: rows n, contraction k
+    const uint4 v = *reinterpret_cast<const uint4*>(&tile[16 * tl + li][32 * sl + 8 * g4]);
+    *reinterpret_cast<uint4*>(fo + ((size_t)((n0 / 16 + tl) * KS + (k0 / 32 + sl)) * 64 + lane) * 8) = v;
+    // backward: rows k, contraction n (a column of the tile)
+    bf16_t t8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t8[e] = tile[32 * sl + 8 * g4 + e][16 * tl + li];
+    uint4 u;
+    u.x = t8[0] | ((unsigned)t8[1] << 16); u.y = t8[2] | ((unsigned)t8[3] << 16);
+    u.z = t8[4] | ((unsigned)t8[5] << 16); u.w = t8[6] | ((unsigned)t8[7] << 16);
+    *reinterpret_cast<uint4*>(bo + ((size_t)((k0 / 16 + tl) * KS + (n0 / 32 + sl)) * 64 + lane) * 8) = u;
+  }
+}
+
+constexpr int kOPad = 8;    // bf16 elements of padding per LDS row: pitch (d + 8) * 2 bytes = 4 banks past a multiple of 64 banks
+template <int H>
+__global__ void __launch_bounds__(H * 64) attn_oproj_fwd_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
+                                                                const int32_t* __restrict__ row_base, bf16_t* __restrict__ attn_out,
+                                                                float* __restrict__ lse, const bf16_t* __restrict__ wo,
+                                                                const bf16_t* __restrict__ x_in, bf16_t* __restrict__ x_mid,
+                                                                const bf16_t* __restrict__ nw, bf16_t* __restrict__ xn,
+                                                                float* __restrict__ rstd_out, int B, int S, int causal, float eps, Drop D) {
+  constexpr int d = H * 64, NT = H * 64, PITCH = (d + kOPad) * 2, KSTEPS = d / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fa_lds[];
+  unsigned char* otile = fa_lds;                                   // [32][PITCH]: O, later x_mid
+  float* ss_part = reinterpret_cast<float*>(fa_lds + 32 * PITCH);  // [H][32] sums of squares, then [32] rstd behind it
+  float* rstd_s = ss_part + H * 32;
+  unsigned char* kv = fa_lds + 32 * PITCH + (H * 32 + 32) * 4;     // per wave: K tile, V tile (4 KiB each)
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const int rb = row_base ? row_base[b] : b * S;
+  const int SL = row_base ? key_len[b] : S;                        // rows of this sample in the token-major buffers
+  const int klen = key_len ? min(key_len[b], S) : S;
+  const size_t pitch = (size_t)3 * d;
+  // ---------------------------------------------------------------- phase 1: attention of head h (single 32 x 32 tile)
+  {
+    unsigned char* kt = kv + h * 8192;
+    unsigned char* vt = kt + 4096;
+    const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
+    const bf16_t* kb = qb + d;
+    const bf16_t* vb = qb + 2 * d;
+    const int qrow = l31;
+    const Rope Rnone{nullptr, nullptr, nullptr, S};
+    bf16x8_t qf[4];
+    frags_global_rope(qf, qb, qrow, SL, pitch, lane, Rnone, b);
+    load_tile_coop<64>(kt, kb, 0, SL, pitch, lane, Rnone, b);
+    load_tile_coop<64>(vt, vb, 0, SL, pitch, lane, Rnone, b);
+    __syncthreads();
+    f32x16_t sc = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), qf[s], sc, 0, 0, 0);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = acc_row(r, hi);
+      const bool ok = key < klen && (!causal || key <= qrow);
+      sc[r] = ok ? sc[r] : -INFINITY;
+      mx = fmaxf(mx, sc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m = mx * kScaleL2;
+    const bool dead = m == -INFINITY;
+    const float nm = dead ? 0.f : -m;
+    const unsigned dbase = drop_base(D, b * H + h, qrow, 0);
+    float l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = fast_exp2(fmaf(sc[r], kScaleL2, nm));
+      l += p;                                                        // softmax normaliser: before dropout
+      sc[r] = p * drop_mul_x(D, dbase + (unsigned)(acc_row(r, hi) >> 1) * 0xC2B2AE3Du, r & 1);
+    }
+    l += __shfl_xor(l, 32, 64);
+    const bf16x8_t pb0 = acc_to_b(sc, 0), pb1 = acc_to_b(sc, 1);
+    f32x16_t o0 = zero16(), o1 = zero16();
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 0, lane), pb0, o0, 0, 0, 0);
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 1, lane), pb1, o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 0, lane), pb0, o1, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 1, lane), pb1, o1, 0, 0, 0);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    const bool live = qrow < SL;
+    bf16_t* grow = attn_out + ((size_t)rb + min(qrow, max(SL - 1, 0))) * d + h * 64;
+    unsigned char* lrow = otile + qrow * PITCH + h * 128;
+    // (store_t's piece trade: the hi = 0 lane of a row ends up with the 16 bytes dh [8 rr, 8 rr + 8) of the even rr, the hi = 1 lane
+    //  with those of the odd rr)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const f32x16_t& a = half ? o1 : o0;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int e = 2 * pr, o = 2 * pr + 1;
+        const unsigned e0 = pack2bf(a[4 * e + 0] * inv, a[4 * e + 1] * inv), e1 = pack2bf(a[4 * e + 2] * inv, a[4 * e + 3] * inv);
+        const unsigned q0_ = pack2bf(a[4 * o + 0] * inv, a[4 * o + 1] * inv), q1_ = pack2bf(a[4 * o + 2] * inv, a[4 * o + 3] * inv);
+        const hw_u32x2_t w0 = __builtin_amdgcn_permlane32_swap(e0, q0_, false, false);
+        const hw_u32x2_t w1 = __builtin_amdgcn_permlane32_swap(e1, q1_, false, false);
+        uint4 v;
+        v.x = w0[0]; v.y = w1[0]; v.z = w0[1]; v.w = w1[1];
+        const int off = 32 * half + 8 * (hi ? o : e);
+        if (live) *reinterpret_cast<uint4*>(grow + off) = v;
+        *reinterpret_cast<uint4*>(lrow + off * 2) = live ? v : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    if (hi == 0 && live && lse) lse[((size_t)b * H + h) * S + qrow] = l > 0.f ? (m + log2f(l)) * (1.0f / kLog2e) : 0.f;
+  }
+  __syncthreads();
+  // ---------------------------------------------------------------- phase 2: Y^T = Wo O^T, + residual, sums of squares
+  const int li = lane & 15, g4 = lane >> 4;
+  {
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* wrow = wo + (size_t)4 * h * KSTEPS * 512 + lane * 8;   // packed: fragment (n-tile 4 h + t, K-step s) at ((4 h + t) KSTEPS + s) * 512
+    const unsigned char* orow = otile + li * PITCH + 16 * g4;           // + 16 u rows, + 64 s bytes
+    // K-steps of weight fragments in flight: PD x 4 16-byte loads per lane.  The scheduling fences keep the issue order written here
+    // (without them the compiler sinks every load to just before its MFMA - one or two in flight, the loop then runs at the latency
+    // of an L2 round trip per K-step); the O fragments are fetched one K-step ahead
+    constexpr int PD = 4;
+    uint4 af[PD][4];
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[s][t] = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * KSTEPS + s) * 512);
+    uint4 bq[2][2];
+    bq[0][0] = *reinterpret_cast<const uint4*>(orow);
+    bq[0][1] = *reinterpret_cast<const uint4*>(orow + 16 * PITCH);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      bf16x8_t a[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = __builtin_bit_cast(bf16x8_t, af[s % PD][t]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + PD < KSTEPS) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[s % PD][t] = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * KSTEPS + s + PD) * 512);
+      }
+      if (s + 1 < KSTEPS) {
+        bq[(s + 1) & 1][0] = *reinterpret_cast<const uint4*>(orow + 64 * (s + 1));
+        bq[(s + 1) & 1][1] = *reinterpret_cast<const uint4*>(orow + 16 * PITCH + 64 * (s + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, bq[s & 1][0]), b1 = __builtin_bit_cast(bf16x8_t, bq[s & 1][1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b0, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b1, acc[t][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // lane holds x[q = 16 u + li][n = 64 h + 16 t + 4 g4 + i]: residual (8 bytes), one rounding, sum of squares of the ROUNDED values
+    uint2 res[4][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = 16 * u + li;
+      const bf16_t* rrow = x_in + ((size_t)rb + min(q, max(SL - 1, 0))) * d + 64 * h + 4 * g4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) res[t][u] = *reinterpret_cast<const uint2*>(rrow + 16 * t);
+    }
+    __syncthreads();     // every wave has read its O fragments: the tile is overwritten with x_mid
+    float ssq[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float r0 = acc[t][u][0] + __uint_as_float(res[t][u].x << 16), r1 = acc[t][u][1] + __uint_as_float(res[t][u].x & 0xffff0000u);
+        const float r2 = acc[t][u][2] + __uint_as_float(res[t][u].y << 16), r3 = acc[t][u][3] + __uint_as_float(res[t][u].y & 0xffff0000u);
+        uint2 o;
+        o.x = pack2bf(r0, r1); o.y = pack2bf(r2, r3);
+        const float f0 = __uint_as_float(o.x << 16), f1 = __uint_as_float(o.x & 0xffff0000u);
+        const float f2 = __uint_as_float(o.y << 16), f3 = __uint_as_float(o.y & 0xffff0000u);
+        ssq[u] += f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3;
+        *reinterpret_cast<uint2*>(otile + (16 * u + li) * PITCH + (64 * h + 16 * t + 4 * g4) * 2) = o;
+      }
+      // fold the four 16-lane rows (same token, other channels)
+      hw_u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ssq[u]), __float_as_uint(ssq[u]), false, false);
+      ssq[u] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      r = __builtin_amdgcn_permlane32_swap(__float_as_uint(ssq[u]), __float_as_uint(ssq[u]), false, false);
+      ssq[u] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      if (g4 == 0) ss_part[h * 32 + 16 * u + li] = ssq[u];
+    }
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float ss = 0.f;
+#pragma unroll
+    for (int w = 0; w < H; ++w) ss += ss_part[w * 32 + tid];
+    const float rs = rsqrtf(ss / (float)d + eps);
+    rstd_s[tid] = rs;
+    if (tid < SL && rstd_out) rstd_out[rb + tid] = rs;
+  }
+  __syncthreads();
+  // ---------------------------------------------------------------- phase 3: x_mid and xn leave in 16-byte row pieces
+  constexpr int CPR = d / 8;
+#pragma unroll
+  for (int i = 0; i < (32 * CPR + NT - 1) / NT; ++i) {
+    const int c = tid + i * NT;
+    if (c >= 32 * CPR) break;
+    const int q = c / CPR, cc = c % CPR;
+    if (q >= SL) continue;
+    const uint4 xv = *reinterpret_cast<const uint4*>(otile + q * PITCH + cc * 16);
+    float v[8], wv[8], o[8];
+    unpack8(xv, v);
+    unpack8(*reinterpret_cast<const uint4*>(nw + cc * 8), wv);
+    const float rs = rstd_s[q];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = wv[e] * bf2f(f2bf(v[e] * rs));
+    *reinterpret_cast<uint4*>(x_mid + ((size_t)rb + q) * d + cc * 8) = xv;
+    *reinterpret_cast<uint4*>(xn + ((size_t)rb + q) * d + cc * 8) = pack8(o);
+  }
+}
+
+// The backward counterpart, one workgroup per sample (S <= 32): RMSNorm backward of post_attention_layernorm, the dgrad of the o
+// projection and the attention backward of every head in ONE launch (three launches before: rmsnorm_bwd 10.9 us + the N = K = d NN GEMM
+// 16.6 us + attn_bwd_small_kernel 21 us per layer at T = 5696).
+//   phase A  wave w owns rows w, w + H, ...: dx_mid = dres + rstd (dy w - xhat mean(dy w xhat)) exactly as rmsnorm_bwd_kernel; the row
+//            goes to global memory (the o weight gradient and the next RMSNorm backward read it) and to an LDS tile; the norm weight's
+//            gradient is pre-reduced over the block's rows, one fp32 atomic per channel and block
+//   phase B  dattn^T[k][q] = WoT[k][:] . dx_mid[q][:] (fragment-major copy of the TRANSPOSED weight, pack_wo_kernel); wave w owns the 64
+//            channels of head w and writes them, rounded to bf16 like the GEMM's output, into its own swizzled dO tile - dattn never
+//            exists in global memory
+//   phase C  wave w: attn_bwd_small_kernel's arithmetic on head w (K, Q tiles from global memory, V in registers, dO from phase B)
+// reference: hf LlamaRMSNorm :62-67, LlamaAttention.forward :243-281, eager_attention_forward :191-214 (their autograd).
+template <int H>
+__global__ void __launch_bounds__(H * 64) attn_oproj_bwd_kernel(const bf16_t* __restrict__ dxn, const bf16_t* __restrict__ x_mid,
+                                                                const bf16_t* __restrict__ nw, const float* __restrict__ rstd,
+                                                                const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx_mid,
+                                                                float* __restrict__ dw_accum, int copies, uint64_t copy_stride,
+                                                                const bf16_t* __restrict__ wot, const bf16_t* __restrict__ qkv,
+                                                                const float* __restrict__ lse, const int32_t* __restrict__ key_len,
+                                                                const int32_t* __restrict__ row_base, bf16_t* __restrict__ dqkv, int B, int S,
+                                                                int causal, Rope R, Drop D, int t_rows) {
+  constexpr int d = H * 64, NT = H * 64, PITCH = (d + kOPad) * 2, KSTEPS = d / 32, NCHUNK = d / 8, NCH = (NCHUNK + 63) / 64;
+  constexpr int UNI = (32 * PITCH + H * d * 4) > H * 8192 ? (32 * PITCH + H * d * 4) : H * 8192;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fb_lds[];
+  unsigned char* dot_all = fb_lds;                                  // [H][4096]: dO tile of every head
+  unsigned char* dtile = fb_lds + H * 4096;                         // phase A / B: dx_mid [32][PITCH] ...
+  float* dw_lds = reinterpret_cast<float*>(dtile + 32 * PITCH);     // ... and the waves' norm-weight gradient partials [H][d]
+  unsigned char* kq = fb_lds + H * 4096;                            // phase C (same bytes): K and Q tile of every head
+  float* stat = reinterpret_cast<float*>(fb_lds + H * 4096 + UNI);  // [H][64]: -lse * log2(e) and -delta per query
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const int rb = row_base ? row_base[b] : b * S;
+  const int SL = row_base ? key_len[b] : S;
+  const int klen = key_len ? min(key_len[b], S) : S;
+  // var-len layout: the <= 63 pad rows behind the last sample belong to no workgroup; their gradient is zero (rmsnorm_bwd_kernel computed
+  // exactly that from their zero inputs) and must read as zero in the o weight gradient (K = all rows) and the next RMSNorm backward
+  if (row_base && b == B - 1)
+    for (int c = (rb + SL) * NCHUNK + tid; c < t_rows * NCHUNK; c += NT) reinterpret_cast<uint4*>(dx_mid)[c] = make_uint4(0u, 0u, 0u, 0u);
+  // ---------------------------------------------------------------- phase A: RMSNorm backward of this wave's rows
+  {
+    float wv[NCH][8], dwp[NCH][8];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { dwp[i][e] = 0.f; wv[i][e] = 0.f; }
+      if (c < NCHUNK) unpack8(*reinterpret_cast<const uint4*>(nw + c * 8), wv[i]);
+    }
+    constexpr int RPW = (32 + H - 1) / H, RB = RPW < 3 ? RPW : 3;
+    for (int j0 = 0; j0 < RPW; j0 += RB) {
+      uint4 xr[RB][NCH], dr[RB][NCH], rr[RB][NCH];
+      float rs[RB];
+#pragma unroll
+      for (int jj = 0; jj < RB; ++jj) {
+        const int q = h + H * (j0 + jj);
+        const size_t row = (size_t)rb + max(min(q, SL - 1), 0);
+        rs[jj] = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c = min(lane + i * 64, NCHUNK - 1);
+          xr[jj][i] = *reinterpret_cast<const uint4*>(x_mid + row * d + c * 8);
+          dr[jj][i] = *reinterpret_cast<const uint4*>(dxn + row * d + c * 8);
+          rr[jj][i] = *reinterpret_cast<const uint4*>(dres + row * d + c * 8);
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < RB; ++jj) {
+        const int q = h + H * (j0 + jj);
+        if (q >= 32) break;                    // (wave-uniform)
+        const bool live = q < SL;
+        float xh[NCH][8], g[NCH][8], res[NCH][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const bool on = lane + i * 64 < NCHUNK;
+          float xv[8], dv[8];
+          unpack8(xr[jj][i], xv);
+          unpack8(dr[jj][i], dv);
+          unpack8(rr[jj][i], res[i]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            xh[i][e] = xv[e] * rs[jj];
+            g[i][e] = dv[e] * wv[i][e];
+            if (on) dot += g[i][e] * xh[i][e];
+            if (on && live) dwp[i][e] += dv[e] * xh[i][e];
+          }
+        }
+        dot = wave_sum(dot) / (float)d;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c = lane + i * 64;
+          if (c < NCHUNK) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = res[i][e] + rs[jj] * (g[i][e] - xh[i][e] * dot);
+            const uint4 ov = live ? pack8(o) : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(dtile + q * PITCH + c * 16) = ov;
+            if (live) *reinterpret_cast<uint4*>(dx_mid + ((size_t)rb + q) * d + c * 8) = ov;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < NCHUNK) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dw_lds[h * d + c * 8 + e] = dwp[i][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < d; j += NT) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < H; ++w) sum += dw_lds[w * d + j];
+    unsafeAtomicAdd(dw_accum + (size_t)(blockIdx.x % copies) * copy_stride + j, sum);
+  }
+  // ---------------------------------------------------------------- phase B: dattn^T = WoT dx_mid^T -> this head's dO tile
+  unsigned char* dot_ = dot_all + h * 4096;
+  {
+    const int li = lane & 15, g4 = lane >> 4;
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* wrow = wot + (size_t)4 * h * KSTEPS * 512 + lane * 8;
+    const unsigned char* orow = dtile + li * PITCH + 16 * g4;
+    constexpr int PD = 4;
+    uint4 af[PD][4];
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[s][t] = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * KSTEPS + s) * 512);
+    uint4 bq[2][2];
+    bq[0][0] = *reinterpret_cast<const uint4*>(orow);
+    bq[0][1] = *reinterpret_cast<const uint4*>(orow + 16 * PITCH);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      bf16x8_t a[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = __builtin_bit_cast(bf16x8_t, af[s % PD][t]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + PD < KSTEPS) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[s % PD][t] = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * KSTEPS + s + PD) * 512);
+      }
+      if (s + 1 < KSTEPS) {
+        bq[(s + 1) & 1][0] = *reinterpret_cast<const uint4*>(orow + 64 * (s + 1));
+        bq[(s + 1) & 1][1] = *reinterpret_cast<const uint4*>(orow + 16 * PITCH + 64 * (s + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, bq[s & 1][0]), b1 = __builtin_bit_cast(bf16x8_t, bq[s & 1][1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b0, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b1, acc[t][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // lane holds dattn[q = 16 u + li][64 h + 16 t + 4 g4 + i]: 8 bytes of row q of the head's [32][64] tile
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        uint2 o;
+        o.x = pack2bf(acc[t][u][0], acc[t][u][1]);
+        o.y = pack2bf(acc[t][u][2], acc[t][u][3]);
+        *reinterpret_cast<uint2*>(dot_ + swz(16 * u + li, (16 * t + 4 * g4) * 2)) = o;
+      }
+  }
+  __syncthreads();     // every wave is done with the dx_mid tile: its bytes become the K / Q tiles
+  // ---------------------------------------------------------------- phase C: attention backward of head h (attn_bwd_small_kernel)
+  {
+    unsigned char* kt = kq + h * 8192;
+    unsigned char* qt = kt + 4096;
+    float* lse_s = stat + h * 64;
+    float* dl_s = lse_s + 32;
+    const size_t pitch = (size_t)3 * d;
+    const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
+    const bf16_t* kb = qb + d;
+    const bf16_t* vb = qb + 2 * d;
+    const Rope Rnone{nullptr, nullptr, nullptr, S};
+    load_tile_coop<64>(kt, kb, 0, SL, pitch, lane, Rnone, b);
+    bf16x8_t vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, l31, SL, pitch, s, lane);
+    load_tile_coop<64>(qt, qb, 0, SL, pitch, lane, Rnone, b);
+    const float nlse2 = -lse[((size_t)b * H + h) * S + min(l31, S - 1)] * kLog2e;
+    if (hi == 0) lse_s[l31] = nlse2;
+    __syncthreads();
+    const unsigned bh = b * H + h;
+    {   // dQ^T[dh][q] = K^T dS^T   (lane owns query l31)
+      const int qrow = l31;
+      const unsigned dbase = drop_base(D, bh, qrow, 0);
+      f32x16_t dp = zero16(), sc = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s], frag_rows(dot_, s, lane), dp, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), frag_rows(qt, s, lane), sc, 0, 0, 0);
+      }
+      float dl = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = acc_row(r, hi);
+        const bool ok = key < klen && (!causal || key <= qrow) && qrow < SL;
+        const float p = ok ? fast_exp2(fmaf(sc[r], kScaleL2, nlse2)) : 0.f;
+        const float t = dp[r] * drop_mul_x(D, dbase + (unsigned)(key >> 1) * 0xC2B2AE3Du, key & 1);
+        dl = fmaf(p, t, dl);
+        sc[r] = p;
+        dp[r] = t;
+      }
+      dl += __shfl_xor(dl, 32, 64);
+      if (hi == 0) dl_s[l31] = -dl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = sc[r] * (dp[r] - dl) * kScale;
+      const bf16x8_t ds0 = acc_to_b(sc, 0), ds1 = acc_to_b(sc, 1);
+      f32x16_t a0 = zero16(), a1 = zero16();
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 0, lane), ds0, a0, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 0, 1, lane), ds1, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 0, lane), ds0, a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 1, lane), ds1, a1, 0, 0, 0);
+      if (qrow < SL) {
+        unrope_acc(a0, a1, R, rope_pos(R, b, qrow), hi);
+        store_t(dqkv + ((size_t)rb + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
+      }
+    }
+    __syncthreads();   // dl_s
+    {   // dV^T = dO^T P, dK^T = Q^T dS   (lane owns key l31)
+      const int krow = l31;
+      const bool key_ok = krow < klen;
+      const unsigned dbase = drop_base(D, bh, 0, (unsigned)krow >> 1);
+      f32x16_t sc = zero16(), dp = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, s, lane), frag_rows(kt, s, lane), sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dot_, s, lane), vf[s], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = acc_row(r, hi);
+        const bool ok = key_ok && q < SL && (!causal || krow <= q);
+        const float p = ok ? fast_exp2(fmaf(sc[r], kScaleL2, lse_s[q])) : 0.f;
+        const float dm = drop_mul_x(D, dbase + (unsigned)q * 0x85EBCA77u, krow & 1);
+        sc[r] = p * dm;
+        dp[r] = p * fmaf(dp[r], dm, dl_s[q]) * kScale;
+      }
+      const bf16x8_t p0 = acc_to_b(sc, 0), p1 = acc_to_b(sc, 1);
+      const bf16x8_t s0 = acc_to_b(dp, 0), s1 = acc_to_b(dp, 1);
+      f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 0, lane), p0, dv0, 0, 0, 0);
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 1, lane), p1, dv0, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 1, 0, lane), p0, dv1, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 1, 1, lane), p1, dv1, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 0, 0, lane), s0, dk0, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 0, 1, lane), s1, dk0, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 0, lane), s0, dk1, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 1, lane), s1, dk1, 0, 0, 0);
+      if (krow < SL) {
+        bf16_t* row = dqkv + ((size_t)rb + krow) * pitch + h * 64;
+        unrope_acc(dk0, dk1, R, rope_pos(R, b, krow), hi);
+        store_t(row + d, dk0, dk1, 1.f, hi);
+        store_t(row + 2 * d, dv0, dv1, 1.f, hi);
+      }
+    }
+  }
+}
+
+// ================================================================================================
 // Long-sequence kernels (S >= 256, q / k already rotated in memory - the engine's layout): 8 waves per block = 256 rows
 // of one (batch, head); the operand that is streamed (K and V, or Q and dO) arrives by LDS-DMA in stages of 64 rows
 // (2 arrays x 8 KiB, two [32][128 B] swizzled tiles each) through a double buffer: ONE barrier per 64 rows, the next stage's
@@ -2058,6 +2576,86 @@ int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, i
   return 0;
 }
 
+// attention + o projection + residual + RMSNorm of one decoder layer for S <= 32 (attn_oproj_fwd_kernel); returns 1 via *taken when
+// the fused form ran, 0 when the shape is not covered (the caller then runs the three launches)
+int k_pack_wo(const void* w0, size_t layer_stride, void* fwd, void* bwd, int d, int layers, hipStream_t st) {
+  GGET_REQUIRE(d % 64 == 0 && layers > 0, "pack_wo: d must be a multiple of 64");
+  hipLaunchKernelGGL(pack_wo_kernel, dim3(d / 64, d / 64, layers), dim3(256), 0, st, (const bf16_t*)w0, layer_stride, (bf16_t*)fwd, (bf16_t*)bwd, d);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+int g_attn_oproj_off = 0;   // gget_debug_set key 10: in-process A/B of the fused form
+bool attn_oproj_enabled() {
+  static const int on = getenv("GGET_ATTN_OPROJ") ? atoi(getenv("GGET_ATTN_OPROJ")) : 1;
+  return on && !g_attn_oproj_off;
+}
+template <int H>
+static int launch_attn_oproj(const void* qkv, const int32_t* key_len, const int32_t* row_base, void* attn_out, float* lse, const void* wo,
+                             const void* x_in, void* x_mid, const void* nw, void* xn, float* rstd, int B, int S, int causal, float eps,
+                             const Drop& D, hipStream_t st) {
+  constexpr int d = H * 64;
+  constexpr int lds = 32 * (d + kOPad) * 2 + (H * 32 + 32) * 4 + H * 8192;
+  static bool attr = false;
+  if (!attr) {
+    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_oproj_fwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr = true;
+  }
+  hipLaunchKernelGGL((attn_oproj_fwd_kernel<H>), dim3(B), dim3(H * 64), lds, st, (const bf16_t*)qkv, key_len, row_base, (bf16_t*)attn_out, lse,
+                     (const bf16_t*)wo, (const bf16_t*)x_in, (bf16_t*)x_mid, (const bf16_t*)nw, (bf16_t*)xn, rstd, B, S, causal, eps, D);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+int k_attn_oproj_fwd(const void* qkv, const int32_t* key_len, const int32_t* row_base, void* attn_out, float* lse, const void* wo,
+                     const void* x_in, void* x_mid, const void* nw, void* xn, float* rstd, int B, int S, int H, int causal, float eps,
+                     float dropout_p, unsigned dropout_seed, hipStream_t st, int* taken) {
+  *taken = 0;
+  if (B == 0 || S == 0 || S > 32 || !attn_oproj_enabled()) return 0;
+  GGET_REQUIRE(!row_base || key_len, "attention: the var-len token layout needs key_len");
+  const Drop D = make_drop(dropout_p, dropout_seed);
+#define GGET_AO(HH) case HH: *taken = 1; return launch_attn_oproj<HH>(qkv, key_len, row_base, attn_out, lse, wo, x_in, x_mid, nw, xn, rstd, B, S, causal, eps, D, st)
+  switch (H) {
+    GGET_AO(2); GGET_AO(4); GGET_AO(8); GGET_AO(12);     // (H = 16: the tiles of 16 waves do not fit 160 KiB of LDS)
+    default: return 0;
+  }
+#undef GGET_AO
+}
+
+template <int H>
+static int launch_attn_oproj_bwd(const void* dxn, const void* x_mid, const void* nw, const float* rstd, const void* dres, void* dx_mid,
+                                 float* dw_accum, int copies, uint64_t copy_stride, const void* wot, const void* qkv, const float* lse,
+                                 const int32_t* key_len, const int32_t* row_base, void* dqkv, int B, int S, int causal, const Rope& R,
+                                 const Drop& D, int t_rows, hipStream_t st) {
+  constexpr int d = H * 64, PITCH = (d + kOPad) * 2;
+  constexpr int UNI = (32 * PITCH + H * d * 4) > H * 8192 ? (32 * PITCH + H * d * 4) : H * 8192;
+  constexpr int lds = H * 4096 + UNI + H * 64 * 4;
+  static bool attr = false;
+  if (!attr) {
+    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_oproj_bwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr = true;
+  }
+  hipLaunchKernelGGL((attn_oproj_bwd_kernel<H>), dim3(B), dim3(H * 64), lds, st, (const bf16_t*)dxn, (const bf16_t*)x_mid, (const bf16_t*)nw, rstd,
+                     (const bf16_t*)dres, (bf16_t*)dx_mid, dw_accum, copies, copy_stride, (const bf16_t*)wot, (const bf16_t*)qkv, lse, key_len,
+                     row_base, (bf16_t*)dqkv, B, S, causal, R, D, t_rows);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+int k_attn_oproj_bwd(const void* dxn, const void* x_mid, const void* nw, const float* rstd, const void* dres, void* dx_mid, float* dw_accum,
+                     int copies, uint64_t copy_stride, const void* wot_packed, const void* qkv, const float* lse, const int32_t* key_len,
+                     const int32_t* row_base, void* dqkv, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
+                     const int64_t* position_ids, float dropout_p, unsigned dropout_seed, int t_rows, hipStream_t st, int* taken) {
+  *taken = 0;
+  if (B == 0 || S == 0 || S > 32 || !attn_oproj_enabled() || k_get_deterministic()) return 0;
+  GGET_REQUIRE(!row_base || key_len, "attention: the var-len token layout needs key_len");
+  if (copies < 1) copies = 1;
+  const Rope R{cos_tab, sin_tab, position_ids, S};     // rotation of dq, dk back to the un-rotated projections (q, k in memory are rotated)
+  const Drop D = make_drop(dropout_p, dropout_seed);
+#define GGET_AOB(HH) case HH: *taken = 1; return launch_attn_oproj_bwd<HH>(dxn, x_mid, nw, rstd, dres, dx_mid, dw_accum, copies, copy_stride, wot_packed, qkv, lse, key_len, row_base, dqkv, B, S, causal, R, D, t_rows, st)
+  switch (H) {
+    GGET_AOB(2); GGET_AOB(4); GGET_AOB(8); GGET_AOB(12);
+    default: return 0;
+  }
+#undef GGET_AOB
+}
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
                const int64_t* position_ids, int qk_rotated, float dropout_p, unsigned dropout_seed, hipStream_t st,

@@ -205,6 +205,7 @@ struct Ws {
   // var-len token layout: first compact row of every sample [max_batch + 1], per compact row its sample index / position / ids, the
   // padded -> compact row map [max_tokens], a status word
   uint64_t vl_cu, vl_rowb, vl_pos, vl_ids, vl_pad2c, vl_c2p, vl_status;   // (vl_c2p: compact -> padded row map [max_tokens])
+  uint64_t wo_pack = 0, wot_pack = 0;   // fragment-major copies of every layer's o weight / its transpose (S <= 32 per-sample kernels), [L][d][d] bf16
   uint64_t pos_safe;   // position ids clamped into the RoPE table (int64 [max_tokens]); the sticky "clamped" flag is vl_status[1]
   uint64_t sk_ws;      // stream-K GEMM launches: flags + one fp32 partial tile per block (gemm.h)
   uint64_t head_x[6] = {0}, head_a[5] = {0}, head_d[2] = {0};   // MLP head: layer inputs / activations (bf16), fp32 gradient ping-pong
@@ -272,6 +273,10 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.vl_ids = b.take(T * (uint64_t)c.stacked_feat * 8);
   w.vl_pad2c = b.take(T * 4);
   w.vl_c2p = b.take(T * 4);
+  if (d % 64 == 0 && !pl.has_res) {
+    w.wo_pack = b.take((uint64_t)c.num_layers * d * d * 2);
+    w.wot_pack = b.take((uint64_t)c.num_layers * d * d * 2);
+  }
   w.vl_status = b.take(256);
   w.pos_safe = b.take(T * 8);
   w.sk_ws = b.take(gget_gemm_streamk_bytes());
@@ -377,6 +382,7 @@ struct gget_engine {
   // backbone_forward); TP = B * S always (the index space of ids / labels / the SMTP head's selections)
   int B = 0, S = 0, T = 0, TP = 0;
   bool varlen = false;            // the last forward ran on the compacted (padding-free) token layout
+  bool wo_packed = false;         // the last forward built the fragment-major o weights (S <= 32 per-sample kernels)
   int tc = 0;                     // its number of real tokens
   long tc_next = -1;              // real-token count of the NEXT forward's batch (gget_set_token_count); -1 = unknown -> padded layout,
                                   // GGET_TOKENS_AUTO = count on the device and read back; consumed (reset) at the ENTRY of every forward
@@ -1107,6 +1113,23 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
     p.rope_cos = h->cos_cur; p.rope_sin = h->sin_cur; p.rope_pos = h->pos_rows; p.rope_S = h->S; p.rope_cols = 2 * d;
     if (int e = gget_gemm_launch(GGET_GEMM_NT, GGET_EPI_ROPE, g, 1, st)) return e;
   }
+  if (!h->plan.has_res && !h->klo()) {
+    // S <= 32 (the graph sequences of the headline workload): attention, o projection + residual and post_attention_layernorm of a
+    // sample in ONE workgroup (attention.hip: attn_oproj_fwd_kernel) instead of three latency-bound launches
+    int taken = 0;
+    if (h->wo_packed)
+    if (int e = k_attn_oproj_fwd(qkv, h->wsp<int32_t>(h->ws.key_len), h->row_base(), attn, h->wsp<float>(lw.lse),
+                                 h->wsp<bf16_t>(h->ws.wo_pack) + (size_t)i * d * d, x_in, xmid,
+                                 h->P + lo.ln2, xn2, h->wsp<float>(lw.rstd2), h->B, h->S, H, c.causal, c.rms_eps, h->attn_drop_p,
+                                 h->attn_drop_seed + 0x9E37u * (unsigned)i, st, &taken))
+      return e;
+    if (taken) {
+      if (h->probe) GGET_HIP_CHECK(hipEventRecord(h->probe_event(1, 2 * i), st));
+      if (int e = gateup_geglu(xn2, h->P + lo.wgu, gu, hh, T, d, ff, st)) return e;
+      if (h->probe) GGET_HIP_CHECK(hipEventRecord(h->probe_event(1, 2 * i + 1), st));
+      return gemm_nt(hh, h->P + lo.wdown, x_out, xmid, T, d, ff, ff, ff, d, nullptr, st);
+    }
+  }
   if (int e = k_attn_fwd(qkv, h->wsp<int32_t>(h->ws.key_len), attn, h->wsp<float>(lw.lse), h->B, h->S, H, c.causal,
                          nullptr, nullptr, nullptr, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st, h->klo(),
                          h->khi(), h->row_base()))
@@ -1257,6 +1280,20 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
     if (int e = gemm_nt(h->wsp<bf16_t>(w.raw_xn), h->P + h->plan.raw_proj, x0, x0, h->T, d, e_, e_, e_, d, nullptr, st)) return e;
     h->raw_used = true;
     h->raw_next = nullptr;
+  }
+  // S <= 32 without LayerScale / DropPath: the layers run the per-sample attention + o projection kernels (attention.hip), which read
+  // fragment-major copies of the o weights.  They are rebuilt at the start of EVERY forward (one launch, ~10 us: the bf16 weights are the
+  // caller's memory and change under AdamW, gget_sync_params or a caller's own writes); the backward of this forward uses the same copies.
+  h->wo_packed = false;
+  if (!h->plan.has_res && !mask_is_3d && S <= 32 && h->ws.wo_pack && c.num_layers > 0) {
+    const size_t stride = c.num_layers > 1 ? h->plan.layers[1].wo - h->plan.layers[0].wo : 0;
+    bool regular = true;
+    for (int i = 0; i < c.num_layers; ++i) regular = regular && h->plan.layers[i].wo == h->plan.layers[0].wo + (size_t)i * stride;
+    if (regular) {
+      if (int e = k_pack_wo(h->P + h->plan.layers[0].wo, stride, h->wsp<bf16_t>(h->ws.wo_pack), h->wsp<bf16_t>(h->ws.wot_pack), d, c.num_layers, st))
+        return e;
+      h->wo_packed = true;
+    }
   }
   for (int i = 0; i < c.num_layers; ++i)
     if (int e = layer_forward(h, i, st)) return e;
@@ -1483,7 +1520,20 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
     if (int e = k_geglu_bwd(h->wsp<bf16_t>(lw.gu), dh, dgu, T, ff, st)) return e;
   } else if (int e = down_dgrad_geglu(dy_down, h->P + lo.wdown, h->wsp<bf16_t>(lw.gu), dgu, dh, T, d, ff, st)) return e;
   if (int e = gemm_nn(dgu, h->P + lo.wgu, dxn, T, d, 2 * ff, 2 * ff, d, d, nullptr, st)) return e;
-  if (fuse_ls) {
+  bool front_fused = false;
+  if (!h->plan.has_res && !h->klo() && h->wo_packed) {
+    // S <= 32: RMSNorm backward of post_attention_layernorm, the o projection's dgrad and the attention backward of a sample in ONE
+    // workgroup (attention.hip: attn_oproj_bwd_kernel); dattn is never materialised
+    int taken = 0;
+    if (int e = k_attn_oproj_bwd(dxn, xmid, h->P + lo.ln2, h->wsp<float>(lw.rstd2), dx_out, dx_mid, s32 + lo.ln2_32, kAccumCopies,
+                                 align_up((uint64_t)d, 128), h->wsp<bf16_t>(w.wot_pack) + (size_t)i * d * d, h->wsp<bf16_t>(lw.qkv),
+                                 h->wsp<float>(lw.lse), h->wsp<int32_t>(w.key_len), h->row_base(), dqkv, h->B, h->S, H, c.causal, h->cos_cur,
+                                 h->sin_cur, h->pos_cur, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, T, st, &taken))
+      return e;
+    front_fused = taken != 0;
+  }
+  if (front_fused) {
+  } else if (fuse_ls) {
     if (int e = rmsnorm_bwd_ls(dxn, xmid, h->P + lo.ln2, h->wsp<float>(lw.rstd2), dx_out, dx_mid, s32 + lo.ln2_32, h->wsp<bf16_t>(lw.araw),
                                h->plan.has_ls ? h->P + lo.lam1 : nullptr, h->wsp<bf16_t>(w.dscaled2),
                                h->plan.has_ls ? s32 + lo.lam1_32 : nullptr, T, d, h->path_drop(i, 0), ElemDropArg{0, 1.f, 0}, st))
@@ -1501,7 +1551,9 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
     dy_o = dsc;
   }
   // attention: dattn = dy_o W_o ; (dq,dk,dv) ; inverse RoPE ; dxn1 = dqkv W_qkv
+  if (!front_fused)
   if (int e = gemm_nn(dy_o, h->P + lo.wo, dattn, T, d, d, d, d, d, nullptr, st)) return e;
+  if (!front_fused)
   if (int e = k_attn_bwd(h->wsp<bf16_t>(lw.qkv), h->wsp<bf16_t>(lw.attn), dattn, h->wsp<float>(lw.lse),
                          h->wsp<int32_t>(w.key_len), dqkv, h->wsp<float>(w.delta), h->B, h->S, H, c.causal, h->cos_cur,
                          h->sin_cur, h->pos_cur, /*qk_rotated=*/1, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st,
@@ -1871,6 +1923,7 @@ extern "C" int gget_debug_occupy(void* scratch, uint64_t scratch_bytes, int bloc
   return 0;
 }
 
+extern int g_attn_oproj_off;
 extern int g_gemm_variant;
 extern int g_gemm_lds_headroom;
 extern int g_gemm_split_last;
@@ -1905,6 +1958,7 @@ extern "C" int gget_debug_set(int key, int value) {
     case 7: g_gemm_ablate_set = value > 0 ? value : -1; return 0;
     case 8: g_head_dense = value; return 0;
     case 9: g_head_tile = value; return 0;
+    case 10: g_attn_oproj_off = value; return 0;
   }
   gget_set_error("debug_set: unknown key %d", key);
   return 2;
@@ -2014,6 +2068,32 @@ extern "C" int gget_op_attn_fwd(const void* qkv, const int32_t* key_len, void* o
                                 uint32_t dropout_seed, void* stream) {
   return k_attn_fwd(qkv, key_len, out, lse, B, S, H, causal, cos_tab, sin_tab, position_ids, dropout_p, dropout_seed,
                     (hipStream_t)stream);
+}
+extern "C" int gget_op_attn_oproj_fwd(const void* qkv, const int32_t* key_len, const int32_t* row_base, void* attn_out, float* lse,
+                                      const void* wo, const void* x_in, void* x_mid, const void* norm_w, void* xn, float* rstd, int B, int S,
+                                      int H, int causal, float eps, float dropout_p, uint32_t dropout_seed, void* stream, int32_t* taken) {
+  GGET_REQUIRE(qkv && attn_out && wo && x_in && x_mid && norm_w && xn && taken, "null argument");
+  int t = 0;
+  const int rc = k_attn_oproj_fwd(qkv, key_len, row_base, attn_out, lse, wo, x_in, x_mid, norm_w, xn, rstd, B, S, H, causal, eps, dropout_p,
+                                  dropout_seed, (hipStream_t)stream, &t);
+  *taken = t;
+  return rc;
+}
+extern "C" int gget_op_pack_wo(const void* w, uint64_t layer_stride, void* fwd, void* bwd, int d, int layers, void* stream) {
+  GGET_REQUIRE(w && fwd && bwd, "null argument");
+  return k_pack_wo(w, (size_t)layer_stride, fwd, bwd, d, layers, (hipStream_t)stream);
+}
+extern "C" int gget_op_attn_oproj_bwd(const void* dxn, const void* x_mid, const void* norm_w, const float* rstd, const void* dres, void* dx_mid,
+                                      float* dw_accum, int copies, uint64_t copy_stride, const void* wot_packed, const void* qkv, const float* lse,
+                                      const int32_t* key_len, const int32_t* row_base, void* dqkv, int B, int S, int H, int causal,
+                                      const float* cos_tab, const float* sin_tab, const int64_t* position_ids, float dropout_p,
+                                      uint32_t dropout_seed, int t_rows, void* stream, int32_t* taken) {
+  GGET_REQUIRE(dxn && x_mid && norm_w && rstd && dres && dx_mid && dw_accum && wot_packed && qkv && lse && dqkv && taken, "null argument");
+  int t = 0;
+  const int rc = k_attn_oproj_bwd(dxn, x_mid, norm_w, rstd, dres, dx_mid, dw_accum, copies, copy_stride, wot_packed, qkv, lse, key_len, row_base,
+                                  dqkv, B, S, H, causal, cos_tab, sin_tab, position_ids, dropout_p, dropout_seed, t_rows, (hipStream_t)stream, &t);
+  *taken = t;
+  return rc;
 }
 extern "C" int gget_op_attn_fwd_ranges(const void* qkv, const int32_t* key_lo, const int32_t* key_hi, void* out, float* lse, int B,
                                        int S, int H, int causal, float dropout_p, uint32_t dropout_seed, void* stream) {

@@ -120,6 +120,23 @@ int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, i
                const float* cos_tab, const float* sin_tab, const int64_t* position_ids, float dropout_p,
                unsigned dropout_seed, hipStream_t st, const int32_t* key_lo = nullptr, const int32_t* key_hi = nullptr,
                const int32_t* row_base = nullptr);
+// S <= 32: attention (all heads of a sample), the o projection + residual add and the RMSNorm behind it in one launch, one workgroup
+// per sample (attention.hip: attn_oproj_fwd_kernel).  qkv rotated [rows, 3d]; writes attn_out [rows, d] (kept for the backward), lse,
+// x_mid = x_in + attn_out Wo^T, xn = rmsnorm(x_mid) * nw, rstd [rows].  *taken = 1 when it ran (S <= 32, H in {2, 4, 8, 12, 16},
+// GGET_ATTN_OPROJ != 0), else the caller runs k_attn_fwd + the GEMM + k_rmsnorm_fwd.
+// ... `wo` is the FRAGMENT-MAJOR copy of the o weight written by k_pack_wo (fwd); the backward counterpart below reads the fragment-major
+// copy of the transposed weight (bwd).  k_pack_wo packs `layers` [d][d] weights that sit `layer_stride` elements apart.
+int k_pack_wo(const void* w0, size_t layer_stride, void* fwd, void* bwd, int d, int layers, hipStream_t st);
+// RMSNorm backward of post_attention_layernorm (dxn, x_mid, nw, rstd, dres -> dx_mid, dw_accum as k_rmsnorm_bwd), the o projection's
+// dgrad and the attention backward (-> dqkv, dq / dk rotated back with cos_tab / sin_tab / position_ids) of one decoder layer, one
+// workgroup per sample; *taken as above (also 0 in the reproducible mode: the norm weight gradient is summed with atomics).
+int k_attn_oproj_bwd(const void* dxn, const void* x_mid, const void* nw, const float* rstd, const void* dres, void* dx_mid, float* dw_accum,
+                     int copies, uint64_t copy_stride, const void* wot_packed, const void* qkv, const float* lse, const int32_t* key_len,
+                     const int32_t* row_base, void* dqkv, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
+                     const int64_t* position_ids, float dropout_p, unsigned dropout_seed, int t_rows, hipStream_t st, int* taken);   // t_rows: rows of the token-major buffers (var-len: the pad rows behind the last sample get a zero dx_mid)
+int k_attn_oproj_fwd(const void* qkv, const int32_t* key_len, const int32_t* row_base, void* attn_out, float* lse, const void* wo,
+                     const void* x_in, void* x_mid, const void* nw, void* xn, float* rstd, int B, int S, int H, int causal, float eps,
+                     float dropout_p, unsigned dropout_seed, hipStream_t st, int* taken);
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
                const int64_t* position_ids, int qk_rotated, float dropout_p, unsigned dropout_seed, hipStream_t st,

@@ -410,6 +410,35 @@ int gget_op_attn_bwd(const void* qkv, const void* out, const void* dout, const f
                      void* dqkv, float* delta_ws, int B, int S, int H, int causal, const float* cos_tab,
                      const float* sin_tab, const int64_t* position_ids, float dropout_p, uint32_t dropout_seed,
                      void* stream);
+/* S <= 32 (graph sequences of PCQM4M-v2): attention of every head of a sample, the o projection + residual add and the RMSNorm behind
+ * it in ONE launch, one workgroup per sample (csrc/attention.hip: attn_oproj_fwd_kernel).  replaces, for one decoder layer:
+ * hf LlamaAttention.forward :243-281 (attention on rotated q / k + o_proj), LlamaDecoderLayer.forward :305-316 (residual add,
+ * post_attention_layernorm = LlamaRMSNorm.forward :62-67).  wo_packed: the FRAGMENT-MAJOR copy of o_proj.weight [d][d] written by
+ * gget_op_pack_wo (its `fwd` output; the 64 lanes' 16-byte pieces of one 16 x 32 MFMA operand are contiguous - in the weight's row-major
+ * layout a fragment load is 64 separate 16-byte requests and the launch runs at 10 B/clk per CU).
+ * qkv [rows, 3 * 64 H] bf16 with q / k ALREADY rotated (the engine's layout);
+ * row_base (int32 [B], may be NULL): first row of sample b in the token-major buffers (var-len layout; then key_len[b] rows belong to it),
+ * NULL = padded layout, sample b at rows [b S, b S + S).  Outputs: attn_out [rows, d] bf16, lse fp32 [B, H, S] (natural log), x_mid =
+ * x_in + attn_out Wo^T (bf16, residual added on the fp32 accumulator: one rounding), xn = norm_w * bf16(x_mid * rstd) and rstd fp32 [rows].
+ * *taken = 1 when the fused form ran; 0 when the shape is not covered (S > 32, H not in {2, 4, 8, 12, 16}, GGET_ATTN_OPROJ=0) - nothing
+ * is written then and the caller runs gget_op_attn_fwd, a GEMM and gget_op_rmsnorm_fwd. */
+int gget_op_attn_oproj_fwd(const void* qkv, const int32_t* key_len, const int32_t* row_base, void* attn_out, float* lse, const void* wo_packed,
+                           const void* x_in, void* x_mid, const void* norm_w, void* xn, float* rstd, int B, int S, int H, int causal,
+                           float eps, float dropout_p, uint32_t dropout_seed, void* stream, int32_t* taken);
+/* fwd[((T KS + s) 64 + lane) 8 + e] = w[16 T + lane % 16][32 s + 8 (lane / 16) + e], KS = d / 32; bwd: the same of w transposed.
+ * `layers` weights, `layer_stride` elements apart in w, are packed back to back ([layers][d][d] each output).  d % 64 == 0. */
+int gget_op_pack_wo(const void* w, uint64_t layer_stride, void* fwd, void* bwd, int d, int layers, void* stream);
+/* The backward counterpart of gget_op_attn_oproj_fwd, one workgroup per sample (csrc/attention.hip: attn_oproj_bwd_kernel): RMSNorm
+ * backward of post_attention_layernorm - dx_mid = dres + rstd (dxn w - xhat mean(dxn w xhat)), dw_accum[j] += sum_rows dxn xhat (fp32,
+ * `copies` replicas `copy_stride` floats apart, as gget_op_rmsnorm_bwd's) - then dattn = dx_mid Wo (never written to memory) and the
+ * attention backward of every head: dqkv [rows, 3 d] with dq / dk rotated BACK by cos_tab / sin_tab / position_ids (NULL tables: no
+ * rotation).  wot_packed = gget_op_pack_wo's `bwd` output.  t_rows = rows of the token-major buffers (var-len layout: dx_mid of the pad
+ * rows behind the last sample is zeroed).  *taken as above; also 0 in the reproducible mode (gget_debug_set(4, 1)). */
+int gget_op_attn_oproj_bwd(const void* dxn, const void* x_mid, const void* norm_w, const float* rstd, const void* dres, void* dx_mid,
+                           float* dw_accum, int copies, uint64_t copy_stride, const void* wot_packed, const void* qkv, const float* lse,
+                           const int32_t* key_len, const int32_t* row_base, void* dqkv, int B, int S, int H, int causal, const float* cos_tab,
+                           const float* sin_tab, const int64_t* position_ids, float dropout_p, uint32_t dropout_seed, int t_rows,
+                           void* stream, int32_t* taken);
 /* attention with a per-token inclusive key range [key_lo, key_hi] (int32 [B,S]; packed rows) instead of one length per
  * batch row; gget_op_ranges_from_mask3d derives the ranges from a block-diagonal int64 [B,S,S] mask. */
 int gget_op_attn_fwd_ranges(const void* qkv, const int32_t* key_lo, const int32_t* key_hi, void* out, float* lse, int B, int S,

@@ -771,3 +771,220 @@ def test_smtp_rows_kernel_matches_oracle(lib, B, S, F, power):
         assert abs(float(got_w[b]) - wgt) <= 1e-6 * wgt
         a2, w2 = O.smtp_mask_ratio((1.0 - alpha) ** (1.0 / power) and ((1.0 - alpha) ** (1.0 / power) - 0.01) / 0.98, 0.01, 0.99, power)
         assert abs(a2 - alpha) < 1e-9
+
+
+@pytest.mark.parametrize("varlen", [False, True])
+@pytest.mark.parametrize("B,S,H,causal,p", [(5, 24, 2, 0, 0.0), (3, 32, 12, 0, 0.1), (7, 32, 12, 1, 0.0), (260, 32, 12, 0, 0.1), (4, 16, 4, 0, 0.0),
+                                            (3, 32, 8, 0, 0.0)])
+def test_attn_oproj_norm_fused_forward(lib, B, S, H, causal, p, varlen):
+    """Round 5: attention + o projection + residual + RMSNorm of a decoder layer in one launch for S <= 32 (one workgroup per
+    sample; attention.hip attn_oproj_fwd_kernel) against the three launches it replaces - gget_op_attn_fwd (bit-equal attention
+    output and lse: same arithmetic, same dropout hash), an fp32 statement of x_mid = x_in + attn Wo^T (one bf16 rounding) and of
+    hf LlamaRMSNorm on the bf16 x_mid - on the padded [B,S] grid and on the var-len token layout (sample b at rows
+    [cu[b], cu[b] + len[b]); rows of the NEXT sample must not be touched)."""
+    d = H * 64
+    lens = torch.tensor([[S, max(3, S // 2), max(1, S - 3), 1][i % 4] for i in range(B)], dtype=torch.int32)
+    if varlen:
+        cu = torch.zeros(B + 1, dtype=torch.int32)
+        cu[1:] = torch.cumsum(lens, 0)
+        rows = (int(cu[-1]) + 63) // 64 * 64
+        row_base = cu[:B].contiguous().cuda()
+    else:
+        rows, row_base = B * S, None
+    qkv = rnd(rows, 3 * d, seed=27)
+    wo = rnd(d, d, seed=28, scale=0.03)
+    x_in = rnd(rows, d, seed=29)
+    nw = (1.0 + 0.1 * torch.randn(d, generator=torch.Generator().manual_seed(30))).to(torch.bfloat16).cuda()
+    lens_d = lens.cuda()
+    seed = 4321
+    sentinel = 7.0
+    outs = {k: torch.full((rows, d), sentinel, dtype=torch.bfloat16, device="cuda") for k in ("attn", "xmid", "xn")}
+    lse = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
+    rstd = torch.full((rows,), sentinel, dtype=torch.float32, device="cuda")
+    taken = C.c_int32(0)
+    wo_f, wo_b = torch.empty_like(wo), torch.empty_like(wo)
+    L.check(lib.gget_op_pack_wo(P(wo), 0, P(wo_f), P(wo_b), d, 1, ST()))
+    L.check(lib.gget_op_attn_oproj_fwd(P(qkv), P(lens_d), P(row_base), P(outs["attn"]), P(lse), P(wo_f), P(x_in), P(outs["xmid"]), P(nw),
+                                       P(outs["xn"]), P(rstd), B, S, H, causal, 1e-6, p, seed, ST(), C.byref(taken)))
+    assert taken.value == 1
+    torch.cuda.synchronize()
+    # the rows of the samples (padded layout: every row of the grid is computed like the three launches do)
+    if varlen:
+        live = torch.zeros(rows, dtype=torch.bool)
+        for b in range(B):
+            live[int(cu[b]): int(cu[b]) + int(lens[b])] = True
+    else:
+        live = torch.ones(rows, dtype=torch.bool)
+    live = live.cuda()
+    for k in ("attn", "xmid", "xn"):
+        assert bool((outs[k][~live].float() == sentinel).all()), f"{k}: rows outside the samples were written"
+    assert bool((rstd[~live] == sentinel).all())
+    # 1. attention output and lse: the single-wave kernel's, bit for bit
+    if varlen:
+        # (the op entry of the separate kernel has no row_base argument: compare on a padded copy of the same samples)
+        qkv_p = torch.zeros(B * S, 3 * d, dtype=torch.bfloat16, device="cuda")
+        for b in range(B):
+            qkv_p[b * S: b * S + int(lens[b])] = qkv[int(cu[b]): int(cu[b]) + int(lens[b])]
+    else:
+        qkv_p = qkv
+    ref_attn = torch.zeros(B * S, d, dtype=torch.bfloat16, device="cuda")
+    ref_lse = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_attn_fwd(P(qkv_p), P(lens_d), P(ref_attn), P(ref_lse), B, S, H, causal, None, None, None, p, seed, ST()))
+    torch.cuda.synchronize()
+    for b in range(B):
+        n = int(lens[b])
+        r0 = int(cu[b]) if varlen else b * S
+        assert torch.equal(outs["attn"][r0: r0 + n], ref_attn[b * S: b * S + n]), f"sample {b}: attention output differs"
+        a = lse.view(B, H, S)[b, :, :n]
+        assert torch.equal(a, ref_lse.view(B, H, S)[b, :, :n]), f"sample {b}: lse differs"
+    # 2. x_mid = bf16(x_in + attn Wo^T) in fp32 from the kernel's own bf16 attention output
+    want_mid = (x_in.float() + outs["attn"].float() @ wo.float().t())
+    got_mid = outs["xmid"].float()
+    err = (got_mid[live] - want_mid[live]).abs().max().item()
+    scale = want_mid[live].abs().max().item()
+    assert err <= 2 ** -7 * scale, f"x_mid max-abs {err} (scale {scale})"          # one bf16 rounding of values up to `scale`
+    assert rel_l2(got_mid[live].cpu().numpy(), want_mid[live].cpu().numpy()) < 3e-3
+    # 3. RMSNorm of the kernel's bf16 x_mid, hf's rounding points (:62-67)
+    xm = outs["xmid"].float()
+    want_rstd = torch.rsqrt((xm * xm).mean(-1) + 1e-6)
+    assert torch.allclose(rstd[live], want_rstd[live], rtol=2e-6, atol=0)
+    want_xn = nw.float() * (xm * rstd[:, None]).to(torch.bfloat16).float()
+    assert torch.equal(outs["xn"][live], want_xn.to(torch.bfloat16)[live])
+
+
+def test_attn_oproj_not_taken_outside_its_shapes(lib):
+    """S > 32 or a head count without an instantiation (H = 16: the tiles of 16 waves do not fit the LDS): *taken = 0 and nothing is written."""
+    for S, H in ((40, 2), (32, 3), (32, 16)):
+        d = H * 64
+        z = torch.zeros(2 * S, 3 * d, dtype=torch.bfloat16, device="cuda")
+        out = torch.full((2 * S, d), 3.0, dtype=torch.bfloat16, device="cuda")
+        lens = torch.tensor([S, S], dtype=torch.int32).cuda()
+        taken = C.c_int32(5)
+        L.check(lib.gget_op_attn_oproj_fwd(P(z), P(lens), None, P(out), None, P(z), P(z), P(out), P(z), P(out), None, 2, S, H, 0, 1e-6, 0.0, 0, ST(),
+                                           C.byref(taken)))
+        torch.cuda.synchronize()
+        assert taken.value == 0 and bool((out.float() == 3.0).all())
+
+
+def test_pack_wo_layout(lib):
+    """gget_op_pack_wo: fwd[((T KS + s) 64 + lane) 8 + e] = w[16 T + lane % 16][32 s + 8 (lane / 16) + e], bwd the same of w^T; several
+    layers a stride apart."""
+    d, Ls, stride = 128, 3, 128 * 128 + 256
+    buf = rnd(Ls * stride, seed=41)
+    fwd = torch.empty(Ls, d * d, dtype=torch.bfloat16, device="cuda")
+    bwd = torch.empty_like(fwd)
+    L.check(lib.gget_op_pack_wo(P(buf), stride, P(fwd), P(bwd), d, Ls, ST()))
+    torch.cuda.synchronize()
+    KS = d // 32
+    lane = torch.arange(64)
+    for l in range(Ls):
+        w = buf[l * stride: l * stride + d * d].view(d, d).cpu()
+        for src, got in ((w, fwd[l].cpu()), (w.t().contiguous(), bwd[l].cpu())):
+            want = torch.empty(d // 16, KS, 64, 8, dtype=torch.bfloat16)
+            for T in range(d // 16):
+                for s_ in range(KS):
+                    rows = 16 * T + lane % 16
+                    cols = 32 * s_ + 8 * (lane // 16)
+                    want[T, s_] = torch.stack([src[rows, cols + e] for e in range(8)], dim=1)
+            assert torch.equal(got.view(-1), want.view(-1))
+
+
+@pytest.mark.parametrize("varlen", [False, True])
+@pytest.mark.parametrize("B,S,H,causal,p,rope", [(5, 24, 2, 0, 0.0, False), (3, 32, 12, 0, 0.1, True), (7, 32, 12, 1, 0.0, True), (260, 32, 12, 0, 0.1, False),
+                                                 (4, 16, 4, 0, 0.0, True), (3, 32, 8, 0, 0.0, False)])
+def test_attn_oproj_norm_fused_backward(lib, B, S, H, causal, p, rope, varlen):
+    """The backward counterpart (attn_oproj_bwd_kernel: RMSNorm backward + o projection dgrad + attention backward per sample) against the
+    three launches it replaces, run through their own op entries on the same inputs: dx_mid and the norm weight gradient of
+    gget_op_rmsnorm_bwd, dattn = dx_mid Wo by an fp32 matmul rounded to bf16 (what the GEMM stores), dqkv of gget_op_attn_bwd (same
+    arithmetic and dropout hash; its dO operand is the bf16 dattn)."""
+    d = H * 64
+    lens = torch.tensor([[S, max(3, S // 2), max(1, S - 3), 1][i % 4] for i in range(B)], dtype=torch.int32)
+    cu = torch.zeros(B + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    if varlen:
+        rows = (int(cu[-1]) + 63) // 64 * 64
+        row_base = cu[:B].contiguous().cuda()
+        r0 = [int(cu[b]) for b in range(B)]
+    else:
+        rows, row_base = B * S, None
+        r0 = [b * S for b in range(B)]
+    nrow = [int(lens[b]) if varlen else S for b in range(B)]          # rows the sample owns in the buffers
+    live = torch.zeros(rows, dtype=torch.bool)
+    for b in range(B):
+        live[r0[b]: r0[b] + nrow[b]] = True
+    live = live.cuda()
+    qkv = rnd(rows, 3 * d, seed=51)
+    wo = rnd(d, d, seed=52, scale=0.03)
+    x_mid, dxn, dres = rnd(rows, d, seed=53), rnd(rows, d, seed=54, scale=0.5), rnd(rows, d, seed=55, scale=0.5)
+    nw = (1.0 + 0.1 * torch.randn(d, generator=torch.Generator().manual_seed(56))).to(torch.bfloat16).cuda()
+    rstd = torch.rsqrt((x_mid.float() ** 2).mean(-1) + 1e-6)
+    lens_d = lens.cuda()
+    seed = 9876
+    cos = sin = pos = None
+    if rope:
+        cos, sin = _tables(1024)
+        pos = (torch.arange(S)[None].repeat(B, 1) + torch.arange(B)[:, None] % 5).cuda()
+    # forward pieces the backward needs: lse of the attention on these q, k, v (padded copy for the separate kernels)
+    qkv_p = torch.zeros(B * S, 3 * d, dtype=torch.bfloat16, device="cuda")
+    for b in range(B):
+        qkv_p[b * S: b * S + nrow[b]] = qkv[r0[b]: r0[b] + nrow[b]]
+    out_p = torch.zeros(B * S, d, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_attn_fwd(P(qkv_p), P(lens_d), P(out_p), P(lse), B, S, H, causal, None, None, None, p, seed, ST()))
+    # ---- fused
+    wo_f, wo_b = torch.empty_like(wo), torch.empty_like(wo)
+    L.check(lib.gget_op_pack_wo(P(wo), 0, P(wo_f), P(wo_b), d, 1, ST()))
+    sentinel = 5.0
+    dx_mid = torch.full((rows, d), sentinel, dtype=torch.bfloat16, device="cuda")
+    dqkv = torch.full((rows, 3 * d), sentinel, dtype=torch.bfloat16, device="cuda")
+    copies, cstride = 4, 1024
+    dw = torch.zeros(copies * cstride, dtype=torch.float32, device="cuda")
+    taken = C.c_int32(0)
+    L.check(lib.gget_op_attn_oproj_bwd(P(dxn), P(x_mid), P(nw), P(rstd), P(dres), P(dx_mid), P(dw), copies, cstride, P(wo_b), P(qkv), P(lse),
+                                       P(lens_d), P(row_base), P(dqkv), B, S, H, causal, P(cos), P(sin), P(pos), p, seed, rows, ST(), C.byref(taken)))
+    assert taken.value == 1
+    torch.cuda.synchronize()
+    # ---- the three launches
+    ref_dx = torch.empty(rows, d, dtype=torch.bfloat16, device="cuda")
+    ref_dw = torch.zeros(d, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_rmsnorm_bwd(P(dxn), P(x_mid), P(nw), P(rstd), P(dres), P(ref_dx), P(ref_dw), rows, d, ST()))
+    torch.cuda.synchronize()
+    assert torch.equal(dx_mid[live], ref_dx[live]), "dx_mid differs from rmsnorm_bwd_kernel's"
+    if varlen:
+        tail = torch.arange(rows, device="cuda") >= int(cu[-1])
+        assert bool((dx_mid[tail].float() == 0).all()), "the pad rows behind the last sample must get a zero gradient"
+        assert bool((dx_mid[~live & ~tail].float() == sentinel).all()) if bool((~live & ~tail).any()) else True
+    else:
+        assert bool(live.all())
+    # norm weight gradient: the separate kernel summed every row of the buffer, the fused one the samples' rows
+    xh = x_mid.float() * rstd[:, None]
+    want_dw = (dxn.float() * xh)[live].sum(0)
+    got_dw = dw.view(copies, cstride)[:, :d].sum(0)
+    assert rel_l2(got_dw.cpu().numpy(), want_dw.cpu().numpy()) < 1e-4
+    dattn = (ref_dx.float() @ wo.float()).to(torch.bfloat16)            # [rows, d]: dgrad of y = a Wo^T
+    dattn_p = torch.zeros(B * S, d, dtype=torch.bfloat16, device="cuda")
+    for b in range(B):
+        dattn_p[b * S: b * S + nrow[b]] = dattn[r0[b]: r0[b] + nrow[b]]
+    ref_dqkv = torch.zeros(B * S, 3 * d, dtype=torch.bfloat16, device="cuda")
+    delta = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
+    # (the separate op rotates with q / k UN-rotated in memory when tables are given; the engine's layout - rotated q / k, gradients
+    #  rotated back - is what the fused kernel implements, so the reference here runs without tables and the rotation is undone by hand)
+    L.check(lib.gget_op_attn_bwd(P(qkv_p), P(out_p), P(dattn_p), P(lse), P(lens_d), P(ref_dqkv), P(delta), B, S, H, causal, None, None, None,
+                                 p, seed, ST()))
+    torch.cuda.synchronize()
+    for b in range(B):
+        n = nrow[b]
+        got = dqkv[r0[b]: r0[b] + n].float().view(n, 3, H, 64)
+        want = ref_dqkv[b * S: b * S + n].float().view(n, 3, H, 64).clone()
+        if rope:       # gradient of a rotated row back to the un-rotated one: x = R(-theta) x'
+            for i in (0, 1):
+                want[:, i] = _rope_ref(want[None, :, i], -pos[b: b + 1, :n])[0]      # (rotation by the negative angle)
+        tol = 2e-2 if rope else 0.0      # (the un-rotation happens on fp32 accumulators in the kernel, on bf16 values here)
+        if rope:
+            assert rel_l2(got.cpu().numpy(), want.cpu().numpy()) < tol, f"sample {b}"
+        else:
+            err = (got - want).abs().max().item()
+            # dO reaches the MFMAs as bf16 in both forms; the fused one rounds its own fp32 dattn, the reference the matmul above: equal up to
+            # rounding flips of single dattn elements
+            assert rel_l2(got.cpu().numpy(), want.cpu().numpy()) < 4e-3, f"sample {b}: {err}"
+    assert bool((dqkv[~live].float() == sentinel).all())

@@ -163,7 +163,7 @@ def test_varlen_wrong_token_count_is_flagged_and_fallbacks():
     full = torch.ones_like(b["attention_mask"])
     e.forward_pretrain(b["input_ids"], full, b["labels"], num_tokens=16 * 32)       # no padding -> nothing to compact
     assert e.varlen_status()[0] is False
-    e.set_dropout_ex(0.1, 0.1, 0.0)                                                 # element dropouts hash the LOGICAL row: no fallback
+    e.set_dropout_ex(0.1, 0.0, 0.0)                                                 # element dropouts hash the LOGICAL row: no fallback
     e.set_dropout(0.0, 0.0, 5)
     e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], num_tokens=n)
     assert e.varlen_status() == (True, (n + 63) // 64 * 64, False)
@@ -177,12 +177,13 @@ def test_varlen_element_dropouts_draw_the_padded_grids_masks(kind):
     tests/test_gpu_model.py::test_embed_and_mlp_dropouts_exact_mask.  ft: LayerScale + DropPath + attention dropout on top (the C3
     training configuration with mlp_pdrop > 0)."""
     S, F, V, B = 40, 4, 500, 24
+    import dataclasses
     if kind == "pt":
-        spec = _tiny_spec(spec_mod.KIND_PRETRAIN, S)
+        spec = dataclasses.replace(_tiny_spec(spec_mod.KIND_PRETRAIN, S), mlp_pdrop=0.2, embed_pdrop=0.15)
         batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=15)
     else:
         spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=V, stacked_feat=F, next_n_token=1, num_labels=2,
-                                       layer_scale_init=1.0, path_pdrop=0.2, gated_agg=True)
+                                       layer_scale_init=1.0, path_pdrop=0.2, gated_agg=True, mlp_pdrop=0.2, embed_pdrop=0.15)
         batch = synth.make_task_batch(B=B, S=S, F=F, V=V, seed=15)
     state = weights_mod.make_state_dict(spec, seed=3, std=0.05, head_std=0.1)
     b = tb({k: v for k, v in batch.items() if k != "lengths"})

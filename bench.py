@@ -136,6 +136,58 @@ def time_kernels(spec, T, iters=20):
     return out
 
 
+def time_per_sample_kernels(spec, B, S, lengths, p_drop, iters=20):
+    """S <= 32: the per-sample launches of a decoder layer (attention + o projection + residual + RMSNorm forward; RMSNorm backward + o
+    dgrad + attention backward) stand-alone through their operator entries, on the batch's own sample lengths (var-len rows), HIP-event
+    timed.  What bounds them is the stream of the fragment-major o weight through every sample's vector cache (B x d x d x 2 bytes of
+    L2 -> CU traffic per launch), reported next to their algorithmic HBM bytes."""
+    L = importlib.import_module("graph-gpt_amd._lib")
+    import ctypes as C
+    import numpy as np
+    lib = L.load()
+    H, d = spec.num_heads, spec.hidden_size
+    if S > 32 or H not in (2, 4, 8, 12) or lengths is None:
+        return None
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lens = torch.from_numpy(np.asarray(lengths, dtype=np.int32))
+    cu = torch.zeros(B + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    T = (int(cu[-1]) + 63) // 64 * 64
+    bf = lambda *sh, sc=1.0: (torch.randn(*sh, device="cuda") * sc).to(torch.bfloat16)
+    emp = lambda *sh: torch.empty(*sh, dtype=torch.bfloat16, device="cuda")
+    qkv, wo, x, nw = bf(T, 3 * d), bf(d, d, sc=0.03), bf(T, d), bf(d)
+    wo_f, wo_b = emp(d, d), emp(d, d)
+    L.check(lib.gget_op_pack_wo(P(wo), 0, P(wo_f), P(wo_b), d, 1, st))
+    attn, xmid, xn, dxmid, dqkv = emp(T, d), emp(T, d), emp(T, d), emp(T, d), emp(T, 3 * d)
+    dxn, dres = bf(T, d, sc=0.5), bf(T, d, sc=0.5)
+    lse = torch.empty(B * H * S, dtype=torch.float32, device="cuda")
+    rstd = torch.empty(T, dtype=torch.float32, device="cuda")
+    dw = torch.zeros(16 * 1024, dtype=torch.float32, device="cuda")
+    lens_d, rb = lens.cuda(), cu[:B].contiguous().cuda()
+    taken = C.c_int32(0)
+    fwd = lambda: L.check(lib.gget_op_attn_oproj_fwd(P(qkv), P(lens_d), P(rb), P(attn), P(lse), P(wo_f), P(x), P(xmid), P(nw), P(xn), P(rstd), B, S, H, 0,
+                                                     1e-6, p_drop, 7, st, C.byref(taken)))
+    bwd = lambda: L.check(lib.gget_op_attn_oproj_bwd(P(dxn), P(xmid), P(nw), P(rstd), P(dres), P(dxmid), P(dw), 16, 1024, P(wo_b), P(qkv), P(lse), P(lens_d),
+                                                     P(rb), P(dqkv), B, S, H, 0, None, None, None, p_drop, 7, T, st, C.byref(taken)))
+    fwd()
+    if not taken.value:
+        return None
+    f_ms, b_ms = _event_time(fwd, iters), _event_time(bwd, iters)
+    stream = float(B) * d * d * 2
+    hbm_f = 2.0 * T * (3 * d + 3 * d + d)          # qkv, x_in read; attn_out, x_mid, xn written
+    hbm_b = 2.0 * T * (3 * d + d + 3 * d + 3 * d)  # dxn, x_mid, dres, qkv read; dx_mid, dqkv written
+    return {"what": "S <= 32: one workgroup per sample - attention of all heads + o projection + residual + RMSNorm (forward), RMSNorm backward + o dgrad + "
+                    "attention backward; each replaces three launches of a decoder layer (attention.hip: attn_oproj_fwd_kernel / attn_oproj_bwd_kernel)",
+            "rows": T, "samples": B, "timed": "stand-alone loop, HIP events",
+            "forward": {"avg_launch_ms": f_ms, "weight_stream_TBps": stream / (f_ms * 1e-3) / 1e12, "algorithmic_hbm_bytes": hbm_f,
+                        "hbm_GBps": hbm_f / (f_ms * 1e-3) / 1e9},
+            "backward": {"avg_launch_ms": b_ms, "weight_stream_TBps": stream / (b_ms * 1e-3) / 1e12, "algorithmic_hbm_bytes": hbm_b,
+                         "hbm_GBps": hbm_b / (b_ms * 1e-3) / 1e9},
+            "bound": "L2 -> CU stream of the fragment-major o weight (B x d x d x 2 bytes per launch, every byte an L2 hit; the vector caches' 64 B/clk x "
+                     "256 CUs = 39 TB/s is the ceiling, ~10 TB/s measured with all workgroups streaming the same lines)"}
+
+
 def _source_digest():
     import hashlib
     h = hashlib.sha256()
@@ -471,6 +523,10 @@ def main():
         }
         if gemm_info is not None:
             out["step_mfma"]["gemms"] = gemm_info
+        if world == 1 and kind == "pt":
+            psk = time_per_sample_kernels(spec, B, S, host_batches[0].get("lengths"), cfg.attention_dropout)
+            if psk is not None:
+                out["per_sample_kernels"] = psk
         if dp_info is not None:
             dp_info["exposed_comm_ms"] = ms - dp_info["ms_per_step_without_exchange"]
             out["dp"] = dp_info

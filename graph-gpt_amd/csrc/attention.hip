@@ -842,6 +842,31 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
 // What bounds it: every sample streams the d x d weight through its CU's vector cache once (1.18 MB at 64 B/clk = 7.7 us for d = 768).
 // reference: hf LlamaAttention.forward :243-281 (o_proj), LlamaDecoderLayer.forward :305-316 (residual, post_attention_layernorm).
 // ================================================================================================
+// LDS-DMA helpers (used by the per-sample kernels below and by the long-sequence kernels further down)
+__device__ __forceinline__ void attn_glds16(const void* gsrc, const unsigned char* lds_dst) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(LDS_AS const void*)lds_dst);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(dst)
+      : "memory");
+}
+// piece p (0..7) of a 64-row stage array: rows [8p, 8p+8) x 128 B; lane -> (row, LDS slot), source chunk = slot ^ f(row)
+__device__ __forceinline__ void stage_piece(unsigned char* arr, const bf16_t* __restrict__ base, size_t pitch, int r0, int row_lim,
+                                            int p, int lane) {
+  const int row = p * 8 + (lane >> 3), slot = lane & 7;
+  const int x = (row >> 1) & 7;
+  const int f = ((x & 1) << 2) | (x >> 1);
+  const int gr = max(min(r0 + row, row_lim - 1), 0);
+  attn_glds16(base + (size_t)gr * pitch + ((slot ^ f) << 3), arr + p * 1024);
+}
+__device__ __forceinline__ void attn_vm_wait0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // Fragment-major copies of a [d][d] weight for the per-sample kernels below: fwd[((T KS + s) * 64 + lane) * 8 + e] = W[16 T + (lane & 15)]
 // [32 s + 8 (lane >> 4) + e] (the A operand of v_mfma_f32_16x16x32_bf16 for rows 16 T .. 16 T + 15, contraction 32 s .. 32 s + 31; KS = d / 32),
 // and the same of the TRANSPOSED weight in bwd (rows = W's columns).  One block per 64 x 64 tile of W; grid (d / 64, d / 64, layers).
@@ -874,6 +899,9 @@ __global__ void __launch_bounds__(256) pack_wo_kernel(const bf16_t* __restrict__
   }
 }
 
+#ifndef GGET_AO_PD
+#define GGET_AO_PD 4      // K-steps of weight fragments in flight in the per-sample kernels (measurement knob: -DGGET_AO_PD=n)
+#endif
 constexpr int kOPad = 8;    // bf16 elements of padding per LDS row: pitch (d + 8) * 2 bytes = 4 banks past a multiple of 64 banks
 template <int H>
 __global__ void __launch_bounds__(H * 64) attn_oproj_fwd_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
@@ -895,6 +923,13 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_fwd_kernel(const bf16_t* __
   const int SL = row_base ? key_len[b] : S;                        // rows of this sample in the token-major buffers
   const int klen = key_len ? min(key_len[b], S) : S;
   const size_t pitch = (size_t)3 * d;
+  const int li = lane & 15, g4 = lane >> 4;
+  // K order of phase 2: every workgroup streams the SAME weight; started at the same K-step they would all hit the same L2 lines at
+  // the same time, so workgroup b starts at K-step (5 b) mod KSTEPS (wave-uniform: scalar address arithmetic)
+  const int rot = __builtin_amdgcn_readfirstlane((b * 5) % KSTEPS);
+  const bf16_t* wrow = wo + (size_t)4 * h * KSTEPS * 512 + lane * 8;   // packed: fragment (n-tile 4 h + t, K-step s) at ((4 h + t) KSTEPS + s) * 512
+  constexpr int PD = GGET_AO_PD;         // K-steps of weight fragments in flight: PD x 4 16-byte loads per lane
+  uint4 af[PD][4];
   // ---------------------------------------------------------------- phase 1: attention of head h (single 32 x 32 tile)
   {
     unsigned char* kt = kv + h * 8192;
@@ -906,8 +941,28 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_fwd_kernel(const bf16_t* __
     const Rope Rnone{nullptr, nullptr, nullptr, S};
     bf16x8_t qf[4];
     frags_global_rope(qf, qb, qrow, SL, pitch, lane, Rnone, b);
-    load_tile_coop<64>(kt, kb, 0, SL, pitch, lane, Rnone, b);
-    load_tile_coop<64>(vt, vb, 0, SL, pitch, lane, Rnone, b);
+    // (global loads first, then - behind them in the queue - the first weight fragments of phase 2: they stream in under the attention)
+    uint4 kraw[4], vraw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + i * 64, row = c >> 3, ch = c & 7;
+      kraw[i] = *reinterpret_cast<const uint4*>(kb + (size_t)clamp_row(row, SL) * pitch + ch * 8);
+      vraw[i] = *reinterpret_cast<const uint4*>(vb + (size_t)clamp_row(row, SL) * pitch + ch * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+      const int sr = (s + rot) % KSTEPS;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[s][t] = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * KSTEPS + sr) * 512);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + i * 64, row = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(kt + swz(row, ch * 16)) = zero_if(row >= SL, kraw[i]);
+      *reinterpret_cast<uint4*>(vt + swz(row, ch * 16)) = zero_if(row >= SL, vraw[i]);
+    }
     __syncthreads();
     f32x16_t sc = zero16();
 #pragma unroll
@@ -966,27 +1021,31 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_fwd_kernel(const bf16_t* __
   }
   __syncthreads();
   // ---------------------------------------------------------------- phase 2: Y^T = Wo O^T, + residual, sums of squares
-  const int li = lane & 15, g4 = lane >> 4;
   {
     f32x4_t acc[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int u = 0; u < 2; ++u) acc[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const bf16_t* wrow = wo + (size_t)4 * h * KSTEPS * 512 + lane * 8;   // packed: fragment (n-tile 4 h + t, K-step s) at ((4 h + t) KSTEPS + s) * 512
     const unsigned char* orow = otile + li * PITCH + 16 * g4;           // + 16 u rows, + 64 s bytes
-    // K-steps of weight fragments in flight: PD x 4 16-byte loads per lane.  The scheduling fences keep the issue order written here
-    // (without them the compiler sinks every load to just before its MFMA - one or two in flight, the loop then runs at the latency
-    // of an L2 round trip per K-step); the O fragments are fetched one K-step ahead
-    constexpr int PD = 4;
-    uint4 af[PD][4];
+    // The scheduling fences keep the issue order written here (without them the compiler sinks every weight load to just before its
+    // MFMA - one or two in flight, the loop then runs at the latency of an L2 round trip per K-step); the O fragments are fetched one
+    // K-step ahead.  K-step s of the loop is K-step (s + rot) mod KSTEPS of the matrices.
+    int sw = rot + PD; if (sw >= KSTEPS) sw -= KSTEPS;      // K-step the next weight load fetches
+    int sb = rot;                                           // K-step of the O fragments in bq[s & 1]
+    // the lane's residual values x_in[q = 16 u + li][n = 64 h + 16 t + 4 g4 + i] (8 bytes each): fetched under the K loop
+    uint2 res[4][2];
 #pragma unroll
-    for (int s = 0; s < PD; ++s)
+    for (int u = 0; u < 2; ++u) {
+      const int q = 16 * u + li;
+      const bf16_t* rrow = x_in + ((size_t)rb + min(q, max(SL - 1, 0))) * d + 64 * h + 4 * g4;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) af[s][t] = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * KSTEPS + s) * 512);
+      for (int t = 0; t < 4; ++t) res[t][u] = *reinterpret_cast<const uint2*>(rrow + 16 * t);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     uint4 bq[2][2];
-    bq[0][0] = *reinterpret_cast<const uint4*>(orow);
-    bq[0][1] = *reinterpret_cast<const uint4*>(orow + 16 * PITCH);
+    bq[0][0] = *reinterpret_cast<const uint4*>(orow + 64 * sb);
+    bq[0][1] = *reinterpret_cast<const uint4*>(orow + 16 * PITCH + 64 * sb);
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       bf16x8_t a[4];
@@ -995,11 +1054,13 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_fwd_kernel(const bf16_t* __
       __builtin_amdgcn_sched_barrier(0);
       if (s + PD < KSTEPS) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) af[s % PD][t] = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * KSTEPS + s + PD) * 512);
+        for (int t = 0; t < 4; ++t) af[s % PD][t] = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * KSTEPS + sw) * 512);
+        if (++sw == KSTEPS) sw = 0;
       }
       if (s + 1 < KSTEPS) {
-        bq[(s + 1) & 1][0] = *reinterpret_cast<const uint4*>(orow + 64 * (s + 1));
-        bq[(s + 1) & 1][1] = *reinterpret_cast<const uint4*>(orow + 16 * PITCH + 64 * (s + 1));
+        if (++sb == KSTEPS) sb = 0;
+        bq[(s + 1) & 1][0] = *reinterpret_cast<const uint4*>(orow + 64 * sb);
+        bq[(s + 1) & 1][1] = *reinterpret_cast<const uint4*>(orow + 16 * PITCH + 64 * sb);
       }
       __builtin_amdgcn_sched_barrier(0);
       const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, bq[s & 1][0]), b1 = __builtin_bit_cast(bf16x8_t, bq[s & 1][1]);
@@ -1009,15 +1070,6 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_fwd_kernel(const bf16_t* __
         acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b1, acc[t][1], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
-    // lane holds x[q = 16 u + li][n = 64 h + 16 t + 4 g4 + i]: residual (8 bytes), one rounding, sum of squares of the ROUNDED values
-    uint2 res[4][2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int q = 16 * u + li;
-      const bf16_t* rrow = x_in + ((size_t)rb + min(q, max(SL - 1, 0))) * d + 64 * h + 4 * g4;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) res[t][u] = *reinterpret_cast<const uint2*>(rrow + 16 * t);
     }
     __syncthreads();     // every wave has read its O fragments: the tile is overwritten with x_mid
     float ssq[2] = {0.f, 0.f};
@@ -1093,13 +1145,16 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_bwd_kernel(const bf16_t* __
                                                                 const int32_t* __restrict__ row_base, bf16_t* __restrict__ dqkv, int B, int S,
                                                                 int causal, Rope R, Drop D, int t_rows) {
   constexpr int d = H * 64, NT = H * 64, PITCH = (d + kOPad) * 2, KSTEPS = d / 32, NCHUNK = d / 8, NCH = (NCHUNK + 63) / 64;
-  constexpr int UNI = (32 * PITCH + H * d * 4) > H * 8192 ? (32 * PITCH + H * d * 4) : H * 8192;
+  // LDS: region X = the dx_mid tile [32][PITCH] of phases A / B, overwritten by the heads' dO tiles [H][4096] once phase B's loop is
+  // over; region Y = the heads' K and Q tiles [H][8192] (they arrive by LDS-DMA while phase B runs), whose first bytes hold the waves'
+  // norm-weight gradient partials [H][d] during phase A
+  constexpr int XB = 32 * PITCH > H * 4096 ? 32 * PITCH : H * 4096, YB = H * 8192 > H * d * 4 ? H * 8192 : H * d * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char fb_lds[];
-  unsigned char* dot_all = fb_lds;                                  // [H][4096]: dO tile of every head
-  unsigned char* dtile = fb_lds + H * 4096;                         // phase A / B: dx_mid [32][PITCH] ...
-  float* dw_lds = reinterpret_cast<float*>(dtile + 32 * PITCH);     // ... and the waves' norm-weight gradient partials [H][d]
-  unsigned char* kq = fb_lds + H * 4096;                            // phase C (same bytes): K and Q tile of every head
-  float* stat = reinterpret_cast<float*>(fb_lds + H * 4096 + UNI);  // [H][64]: -lse * log2(e) and -delta per query
+  unsigned char* dtile = fb_lds;
+  unsigned char* dot_all = fb_lds;
+  unsigned char* kq = fb_lds + XB;
+  float* dw_lds = reinterpret_cast<float*>(fb_lds + XB);
+  float* stat = reinterpret_cast<float*>(fb_lds + XB + YB);         // [H][64]: -lse * log2(e) and -delta per query
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
@@ -1190,10 +1245,25 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_bwd_kernel(const bf16_t* __
     for (int w = 0; w < H; ++w) sum += dw_lds[w * d + j];
     unsafeAtomicAdd(dw_accum + (size_t)(blockIdx.x % copies) * copy_stride + j, sum);
   }
+  __syncthreads();     // the partials are consumed: region Y takes the K / Q tiles
+  unsigned char* kt = kq + h * 8192;
+  unsigned char* qt = kt + 4096;
+  const size_t pitch = (size_t)3 * d;
+  const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
+  const bf16_t* kb = qb + d;
+  const bf16_t* vb = qb + 2 * d;
+  // K and Q tile of head h by LDS-DMA (no registers; rows beyond the sample are clamped - finite - and masked below): in flight under phase B
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) {
+    stage_piece(kt, kb, pitch, 0, SL, pc, lane);
+    stage_piece(qt, qb, pitch, 0, SL, pc, lane);
+  }
   // ---------------------------------------------------------------- phase B: dattn^T = WoT dx_mid^T -> this head's dO tile
   unsigned char* dot_ = dot_all + h * 4096;
+  bf16x8_t vf[4];
   {
     const int li = lane & 15, g4 = lane >> 4;
+    const int rot = __builtin_amdgcn_readfirstlane((b * 5) % KSTEPS);      // (see attn_oproj_fwd_kernel)
     f32x4_t acc[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -1201,15 +1271,19 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_bwd_kernel(const bf16_t* __
       for (int u = 0; u < 2; ++u) acc[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const bf16_t* wrow = wot + (size_t)4 * h * KSTEPS * 512 + lane * 8;
     const unsigned char* orow = dtile + li * PITCH + 16 * g4;
-    constexpr int PD = 4;
+    constexpr int PD = GGET_AO_PD;
     uint4 af[PD][4];
 #pragma unroll
-    for (int s = 0; s < PD; ++s)
+    for (int s = 0; s < PD; ++s) {
+      const int sr = (s + rot) % KSTEPS;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) af[s][t] = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * KSTEPS + s) * 512);
+      for (int t = 0; t < 4; ++t) af[s][t] = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * KSTEPS + sr) * 512);
+    }
+    int sw = rot + PD; if (sw >= KSTEPS) sw -= KSTEPS;
+    int sb = rot;
     uint4 bq[2][2];
-    bq[0][0] = *reinterpret_cast<const uint4*>(orow);
-    bq[0][1] = *reinterpret_cast<const uint4*>(orow + 16 * PITCH);
+    bq[0][0] = *reinterpret_cast<const uint4*>(orow + 64 * sb);
+    bq[0][1] = *reinterpret_cast<const uint4*>(orow + 16 * PITCH + 64 * sb);
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       bf16x8_t a[4];
@@ -1218,11 +1292,13 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_bwd_kernel(const bf16_t* __
       __builtin_amdgcn_sched_barrier(0);
       if (s + PD < KSTEPS) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) af[s % PD][t] = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * KSTEPS + s + PD) * 512);
+        for (int t = 0; t < 4; ++t) af[s % PD][t] = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * KSTEPS + sw) * 512);
+        if (++sw == KSTEPS) sw = 0;
       }
       if (s + 1 < KSTEPS) {
-        bq[(s + 1) & 1][0] = *reinterpret_cast<const uint4*>(orow + 64 * (s + 1));
-        bq[(s + 1) & 1][1] = *reinterpret_cast<const uint4*>(orow + 16 * PITCH + 64 * (s + 1));
+        if (++sb == KSTEPS) sb = 0;
+        bq[(s + 1) & 1][0] = *reinterpret_cast<const uint4*>(orow + 64 * sb);
+        bq[(s + 1) & 1][1] = *reinterpret_cast<const uint4*>(orow + 16 * PITCH + 64 * sb);
       }
       __builtin_amdgcn_sched_barrier(0);
       const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, bq[s & 1][0]), b1 = __builtin_bit_cast(bf16x8_t, bq[s & 1][1]);
@@ -1233,6 +1309,10 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_bwd_kernel(const bf16_t* __
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    // V is only ever read row-wise (operand rows = keys): its fragments come straight from global memory, under the barrier below
+#pragma unroll
+    for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, l31, SL, pitch, s, lane);
+    __syncthreads();     // every wave is done with the dx_mid tile: its bytes become the dO tiles
     // lane holds dattn[q = 16 u + li][64 h + 16 t + 4 g4 + i]: 8 bytes of row q of the head's [32][64] tile
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -1244,23 +1324,11 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_bwd_kernel(const bf16_t* __
         *reinterpret_cast<uint2*>(dot_ + swz(16 * u + li, (16 * t + 4 * g4) * 2)) = o;
       }
   }
-  __syncthreads();     // every wave is done with the dx_mid tile: its bytes become the K / Q tiles
   // ---------------------------------------------------------------- phase C: attention backward of head h (attn_bwd_small_kernel)
   {
-    unsigned char* kt = kq + h * 8192;
-    unsigned char* qt = kt + 4096;
     float* lse_s = stat + h * 64;
     float* dl_s = lse_s + 32;
-    const size_t pitch = (size_t)3 * d;
-    const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
-    const bf16_t* kb = qb + d;
-    const bf16_t* vb = qb + 2 * d;
-    const Rope Rnone{nullptr, nullptr, nullptr, S};
-    load_tile_coop<64>(kt, kb, 0, SL, pitch, lane, Rnone, b);
-    bf16x8_t vf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) vf[s] = frag_global(vb, l31, SL, pitch, s, lane);
-    load_tile_coop<64>(qt, qb, 0, SL, pitch, lane, Rnone, b);
+    attn_vm_wait0();     // the K / Q tiles (DMA) have landed
     const float nlse2 = -lse[((size_t)b * H + h) * S + min(l31, S - 1)] * kLog2e;
     if (hi == 0) lse_s[l31] = nlse2;
     __syncthreads();
@@ -1352,35 +1420,12 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_bwd_kernel(const bf16_t* __
 // clamped (finite) and masked.  Packed rows: the block's union of key ranges bounds the stage loop, so whole stages are
 // neither loaded nor computed.
 // ================================================================================================
-__device__ __forceinline__ void attn_glds16(const void* gsrc, const unsigned char* lds_dst) {
-  unsigned keep;
-  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(LDS_AS const void*)lds_dst);
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(dst)
-      : "memory");
-}
-// piece p (0..7) of a 64-row stage array: rows [8p, 8p+8) x 128 B; lane -> (row, LDS slot), source chunk = slot ^ f(row)
-__device__ __forceinline__ void stage_piece(unsigned char* arr, const bf16_t* __restrict__ base, size_t pitch, int r0, int row_lim,
-                                            int p, int lane) {
-  const int row = p * 8 + (lane >> 3), slot = lane & 7;
-  const int x = (row >> 1) & 7;
-  const int f = ((x & 1) << 2) | (x >> 1);
-  const int gr = max(min(r0 + row, row_lim - 1), 0);
-  attn_glds16(base + (size_t)gr * pitch + ((slot ^ f) << 3), arr + p * 1024);
-}
 // the block's 8 waves load one stage (two arrays): wave w issues pieces w and w + 8
 __device__ __forceinline__ void stage_issue(unsigned char* buf /* [2][8192] */, const bf16_t* __restrict__ a0, size_t pitch0,
                                             const bf16_t* __restrict__ a1, size_t pitch1, int r0, int row_lim, int wave, int lane) {
   stage_piece(buf, a0, pitch0, r0, row_lim, wave, lane);
   stage_piece(buf + 8192, a1, pitch1, r0, row_lim, wave, lane);
 }
-__device__ __forceinline__ void attn_vm_wait0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // block-wide min / max of two small ints through LDS (packed rows: union of the waves' key ranges)
 __device__ __forceinline__ void block_range(int& lo, int& hi, int* red /* [16] */, int wave, int lane) {
@@ -2626,8 +2671,8 @@ static int launch_attn_oproj_bwd(const void* dxn, const void* x_mid, const void*
                                  const int32_t* key_len, const int32_t* row_base, void* dqkv, int B, int S, int causal, const Rope& R,
                                  const Drop& D, int t_rows, hipStream_t st) {
   constexpr int d = H * 64, PITCH = (d + kOPad) * 2;
-  constexpr int UNI = (32 * PITCH + H * d * 4) > H * 8192 ? (32 * PITCH + H * d * 4) : H * 8192;
-  constexpr int lds = H * 4096 + UNI + H * 64 * 4;
+  constexpr int XB = 32 * PITCH > H * 4096 ? 32 * PITCH : H * 4096, YB = H * 8192 > H * d * 4 ? H * 8192 : H * d * 4;
+  constexpr int lds = XB + YB + H * 64 * 4;
   static bool attr = false;
   if (!attr) {
     GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_oproj_bwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));

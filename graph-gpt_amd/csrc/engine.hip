@@ -1877,7 +1877,7 @@ extern "C" int gget_head_logits(gget_handle_t h, const void** logits_dev, int32_
 
 extern "C" int gget_hidden_states(gget_handle_t h, const void** hidden_dev) {
   GGET_REQUIRE(h && hidden_dev, "null argument");
-  GGET_REQUIRE(!h->varlen, "hidden_states: the last forward ran on the var-len token layout (rows are compacted); run it without a token count");
+  GGET_REQUIRE(!h->varlen, "hidden_states: the last forward ran on the var-len token layout (rows are compacted): run that forward on the padded grid - no token count at the C ABI, num_tokens=None with a host-side mask or GGET_VARLEN=0 through the model classes, or ask the model for output_hidden_states=True");
   *hidden_dev = h->wsp<bf16_t>(h->ws.hidden);
   return 0;
 }
@@ -1887,7 +1887,7 @@ extern "C" int gget_hidden_states(gget_handle_t h, const void** hidden_dev) {
 extern "C" int gget_layer_hidden_states(gget_handle_t h, int layer, const void** hidden_dev) {
   GGET_REQUIRE(h && hidden_dev, "null argument");
   GGET_REQUIRE(layer >= 0 && layer <= h->cfg.num_layers, "layer_hidden_states: layer %d out of range", layer);
-  GGET_REQUIRE(!h->varlen, "layer_hidden_states: the last forward ran on the var-len token layout (rows are compacted); run it without a token count");
+  GGET_REQUIRE(!h->varlen, "layer_hidden_states: the last forward ran on the var-len token layout (rows are compacted): run that forward on the padded grid - no token count at the C ABI, num_tokens=None with a host-side mask or GGET_VARLEN=0 through the model classes, or ask the model for output_hidden_states=True");
   *hidden_dev = h->wsp<bf16_t>(h->ws.xres[layer]);
   return 0;
 }

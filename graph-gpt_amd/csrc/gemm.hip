@@ -1622,7 +1622,7 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
     }
     // wide tile for the widest forward GEMM: 256x256x32 (8 waves of 128x64, 4-slot ring) moves 2/3 of the bytes per
     // FLOP of the 256x128 tile
-    if constexpr (WM == 4 && WN == 2 && !A_MC && EPI != GGET_EPI_SLAB_F32 && EPI != GGET_EPI_ATOMIC_F32 && EPI != GGET_EPI_ROPE && EPI != GGET_EPI_GEGLU_FWD) {
+    if constexpr (WM == 4 && WN == 2 && !A_MC && EPI != GGET_EPI_SLAB_F32 && EPI != GGET_EPI_ATOMIC_F32 && EPI != GGET_EPI_GEGLU_FWD) {
       long t256 = 0;
       bool ok256 = getenv("GGET_GEMM_NO_256") == nullptr;
       for (int i = 0; i < g.count; ++i) {
@@ -1635,7 +1635,15 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
       // against 972 = four rounds of 256x128: dxn2 386 -> 343 us, down 216 -> 198, dxn1 143 -> 134, o 70 -> 64; tools/gemm_bench.py)
       const long r256 = (t256 + num_cu - 1) / num_cu, r_cur = (total + num_cu - 1) / num_cu;
       const bool near = 2 * t256 >= 3L * num_cu && r256 * 256 * 256 * 9 <= r_cur * BM * BN * 10;
-      if (ok256 && (t256 >= (5 * num_cu) / 2 || near)) {
+      // Round 5 experiment (OFF by default; GGET_GEMM_ONE_ROUND=1 or g_gemm_variant bit 8 turns it on): ONE partial round of 256x256 tiles
+      // instead of two rounds of the default tile when they are the same work per CU - the q|k|v projection on the var-len rows, 5696 x
+      // 2304, is 207 tiles of 256x256 = 81 % of the CUs once, against 414 of 256x128 = two rounds, the second 62 % full.  Measured in the
+      // C1 step, alternated in one process: +0.22 ms (7.000 -> 7.223 ms; profiles/r05_step_experiments.txt item 2) - a 256x256 tile with the
+      // RoPE epilogue (128 accumulator registers per lane rotated and stored behind a 12-K-tile loop) costs more than the second round.
+      static const int one_round_on = getenv("GGET_GEMM_ONE_ROUND") ? atoi(getenv("GGET_GEMM_ONE_ROUND")) : 0;
+      const bool one_round = (one_round_on || (g_gemm_variant & 256)) && t256 <= num_cu && t256 * 10 >= (long)num_cu * 7 && r_cur >= 2 &&
+                             (long)256 * 256 <= r_cur * BM * BN;
+      if (ok256 && ((EPI != GGET_EPI_ROPE && (t256 >= (5 * num_cu) / 2 || near)) || one_round)) {
         int tot2 = 0;
         for (int i = 0; i < g.count; ++i) {
           GemmProblem& p = g.p[i];

@@ -114,6 +114,7 @@ SIGNATURES = {
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 OPT_NORM_FROM_BACKWARD = 1   # gget_set_option
+OPT_SKIP_NONFINITE_STEP = 2
 TOKENS_AUTO = -2   # gget_set_token_count: count the real tokens on the device (include/gget.h GGET_TOKENS_AUTO)
 EPI_NONE, EPI_RESIDUAL, EPI_ATOMIC_F32, EPI_SLAB_F32 = 0, 1, 2, 3
 

@@ -389,6 +389,7 @@ struct gget_engine {
   // gget_set_option(GGET_OPT_NORM_FROM_BACKWARD): the squared gradient norm of the layers' weight matrices comes from partial sums
   // their weight-gradient launches left behind (sq_layers = layers of the last backward that did), the rest from a chunked pass
   bool opt_norm_from_backward = false;
+  bool opt_skip_nonfinite = false;     // GGET_OPT_SKIP_NONFINITE_STEP: gget_adamw_step leaves the parameters alone when the gradient norm is inf / NaN
   int sq_layers = 0;
   int n_sq_chunks = 0;
   bool head_sorted_fwd = false;   // the last pre-train forward ran the slot-sorted n_token_proj (its lists feed the backward)
@@ -679,6 +680,7 @@ extern "C" int gget_set_option(gget_handle_t h, int option, int value) {
   GGET_REQUIRE(h != nullptr, "null handle");
   switch (option) {
     case GGET_OPT_NORM_FROM_BACKWARD: h->opt_norm_from_backward = value != 0; return 0;
+    case GGET_OPT_SKIP_NONFINITE_STEP: h->opt_skip_nonfinite = value != 0; return 0;
   }
   gget_set_error("set_option: unknown option %d", option);
   return 2;
@@ -1845,7 +1847,7 @@ extern "C" int gget_adamw_step(gget_handle_t h, float lr, float beta1, float bet
   GGET_REQUIRE(step >= 1, "step is 1-based");
   hipStream_t st = (hipStream_t)stream;
   float* sq = h->wsp<float>(h->ws.sqnorm);
-  const bool need_norm = max_grad_norm > 0.f || gnorm_dev != nullptr;
+  const bool need_norm = max_grad_norm > 0.f || gnorm_dev != nullptr || h->opt_skip_nonfinite;
   if (need_norm) {
     // the shortcut holds only while the gradient array is exactly what the last backward wrote: the caller promised that
     // (GGET_OPT_NORM_FROM_BACKWARD), grad_scale != 1 means an exchange happened anyway, and every layer must have left its partials
@@ -1856,7 +1858,7 @@ extern "C" int gget_adamw_step(gget_handle_t h, float lr, float beta1, float bet
     } else if (int e = k_grad_sqnorm(h->G, h->plan.n_params, sq, st)) return e;
   }
   return k_adamw(h->master, h->am, h->av, h->G, h->P, h->plan.n_params, lr, beta1, beta2, eps, weight_decay, step,
-                 max_grad_norm, grad_scale, need_norm ? sq : nullptr, gnorm_dev, st);
+                 max_grad_norm, grad_scale, need_norm ? sq : nullptr, gnorm_dev, st, h->opt_skip_nonfinite);
 }
 
 extern "C" int gget_head_counts(gget_handle_t h, int32_t counts[2], void* stream) {

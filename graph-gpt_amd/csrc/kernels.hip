@@ -1480,12 +1480,15 @@ __global__ void __launch_bounds__(kBlock) adamw_kernel(float* __restrict__ maste
                                                        const bf16_t* __restrict__ grad, bf16_t* __restrict__ param, size_t n,
                                                        float lr, float beta1, float beta2, float eps, float wd, float bc1,
                                                        float bc2_sqrt, float max_norm, float grad_scale,
-                                                       const float* __restrict__ sqnorm, float* __restrict__ gnorm_out) {
+                                                       const float* __restrict__ sqnorm, float* __restrict__ gnorm_out, int skip_nonfinite) {
   float coef = grad_scale;
   if (sqnorm) {
     const float nrm = sqrtf(sqnorm[0]) * grad_scale;
     if (max_norm > 0.f) coef *= fminf(1.0f, max_norm / (nrm + 1e-6f));
     if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) gnorm_out[0] = nrm;
+    // GradScaler's rule (torch.cuda.amp.GradScaler.step: the optimizer step is skipped when the unscaled gradients hold an inf / NaN;
+    // reference src/utils/training_utils.py:76-82, the DDP branch): nothing is touched, the caller reads the norm and leaves its step count
+    if (skip_nonfinite && !(nrm < INFINITY)) return;      // (uniform: every thread reads the same scalar; NaN fails the comparison too)
   }
   const size_t nv = n >> 2;
   const size_t stride = (size_t)gridDim.x * kBlock;
@@ -2472,14 +2475,14 @@ int k_grad_sqnorm_chunks(const void* g, const GgetSqChunk* chunks_dev, int nchun
 
 int k_adamw(float* master, float* m, float* v, const void* grad, void* param, size_t n, float lr, float beta1, float beta2,
             float eps, float wd, int step, float max_norm, float grad_scale, const float* sqnorm, float* gnorm_out,
-            hipStream_t st) {
+            hipStream_t st, bool skip_nonfinite) {
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2 = 1.0f - powf(beta2, (float)step);
   // one pass, two float4 groups per thread (grid up to 65536 blocks): the grid-stride form with 4096 blocks ran at 5.1 TB/s of
   // state traffic, this one at 6.0 (profiles/r02_adamw_sweep.txt); loads and the fp32 state stores are non-temporal
   hipLaunchKernelGGL(adamw_kernel<2>, dim3(grid_for((long)(n / 8), kBlock, 65536)), dim3(kBlock), 0, st, master, m, v,
                      (const bf16_t*)grad, (bf16_t*)param, n, lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2), max_norm,
-                     grad_scale, sqnorm, gnorm_out);
+                     grad_scale, sqnorm, gnorm_out, skip_nonfinite ? 1 : 0);
   GGET_LAUNCH_CHECK();
   return 0;
 }

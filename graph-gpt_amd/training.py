@@ -372,10 +372,34 @@ def initialize(model: _GgetModel, optim: Optional[OptimConfig] = None, process_g
 def _reference_step_args(model, train_cfg, train_stats):
     """The reference's positional form `batch_training(data, model, train_cfg, train_stats, opt_stats)` (training_utils.py:7-13):
     `model` is the engine `deepspeed.initialize` returned, `train_stats` carries `.device`, `.has_embeds_input`, `.use_deepspeed`."""
-    if not getattr(train_stats, "use_deepspeed", True):
-        raise NotImplementedError("the fp16 autocast + GradScaler DDP branch (training_utils.py:46-86) is outside the bf16 hot path "
-                                  "(DESIGN.md section 7): run with use_deepspeed=True semantics (engine.backward / engine.step)")
     return getattr(train_stats, "device", None) or model.device, bool(getattr(train_stats, "has_embeds_input", False))
+
+
+def _reference_optimizer_step(model, train_cfg, train_stats, loss):
+    """backward + optimizer step of the reference's two branches on the engine.
+    DeepSpeed branch (training_utils.py:44-45): model.backward(loss); model.step().
+    DDP branch (`train_stats.use_deepspeed` False, :46-86): zero_grad; fp16 autocast forward; scaler.scale(loss).backward();
+    scaler.unscale_; clip_grad_norm_(max_grad_norm); scaler.step (SKIPPED when a gradient is inf / NaN); scaler.update; lr_scheduler.step().
+    On this engine the forward / backward arithmetic is bf16 with fp32 accumulation whatever the branch (fp16 autocast is not reproduced:
+    bf16 has fp32's exponent range, so the loss scale is 1 and never changes); what the branch changes is the step rule - GradScaler's
+    skip of a non-finite step (GGET_OPT_SKIP_NONFINITE_STEP: weights and Adam state untouched, Adam's step count not advanced) while the
+    LR schedule still advances, and `optimizer.gradient_accumulation_steps` must be 1 (the reference asserts it, :47-49)."""
+    ddp = not getattr(train_stats, "use_deepspeed", True)
+    eng = model.module._engine
+    if getattr(eng, "_skip_nonfinite", None) != ddp:
+        from . import _lib as L
+        eng.set_option(L.OPT_SKIP_NONFINITE_STEP, int(ddp))
+        eng._skip_nonfinite = ddp
+    if ddp:
+        oc = getattr(train_cfg, "optimizer", None)
+        assert oc is None or getattr(oc, "gradient_accumulation_steps", 1) == 1, \
+            "https://pytorch.org/docs/stable/notes/amp_examples.html#gradient-accumulation"
+    model.backward(loss)
+    gn = model.step()
+    if ddp and not bool(torch.isfinite(gn)):       # (GradScaler.step reads found_inf back as well: one sync per step on this branch)
+        eng.step_count -= 1                        # optimizer.step() did not run; lr_scheduler.step() did (global_steps stays advanced)
+        model.skipped_steps = getattr(model, "skipped_steps", 0) + 1
+    return gn
 
 
 def batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine, train_cfg=None, train_stats=None, opt_stats=None):
@@ -407,8 +431,7 @@ def batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine, train_cfg=
                    sample_wgt=sample_wgt)
     main_loss, aux_loss = output.head1_loss, output.head2_loss
     loss = main_loss + aux_loss if aux_loss is not None else main_loss
-    model.backward(loss)
-    model.step()
+    _reference_optimizer_step(model, train_cfg, train_stats, loss)
     train_stats.loss, train_stats.main_loss, train_stats.aux_loss = loss, main_loss, aux_loss
     train_stats.inputs_shape = input_ids.shape
     train_stats.sliced_raw_embeds = inputs_raw_embeds[:2, :8] if inputs_raw_embeds is not None else None
@@ -444,8 +467,7 @@ def ft_batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine, *ref_ar
                    sample_wgt=data["wgt"].to(device) if "wgt" in data else None, position_ids=data["position_ids"].to(device))
     task_loss = output.task_loss
     loss = task_loss.float()
-    model.backward(loss)
-    model.step()
+    _reference_optimizer_step(model, train_cfg, train_stats, loss)
     train_stats.loss, train_stats.main_loss, train_stats.aux_loss = loss, task_loss, None
     return loss, output.task_logits
 

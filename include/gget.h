@@ -252,6 +252,11 @@ int gget_backward_end(gget_handle_t h, void* stream);
  *   :72-82, DeepSpeed's gradient_clipping) loses its 244 MB norm pass.  Ignored (full pass) whenever grad_scale != 1 or a layer's launch
  *   left no partials.  The norm is the same sum in another (fixed) order: equal to fp32 rounding. */
 #define GGET_OPT_NORM_FROM_BACKWARD 1
+/* GGET_OPT_SKIP_NONFINITE_STEP = 1: gget_adamw_step touches nothing (weights, Adam moments, bf16 copy) when the global gradient norm is
+ *   inf / NaN - what torch.cuda.amp.GradScaler.step does on the reference's DDP branch (src/utils/training_utils.py:46-86: scale,
+ *   backward, unscale_, clip, scaler.step, scaler.update).  The norm still reaches gnorm_dev, so the caller can tell (and keep its
+ *   1-based step count for the skipped step).  Off by default: DeepSpeed's bf16 optimizer, the path the engine reproduces, has no such guard. */
+#define GGET_OPT_SKIP_NONFINITE_STEP 2
 int gget_set_option(gget_handle_t h, int option, int value);
 
 /* ------------------------------------------------------------------------------------------

@@ -431,3 +431,67 @@ def test_varlen_wrong_count_poisons_loss_and_raises_deferred():
     assert np.isfinite(out)
     with pytest.raises(ValueError):
         model.check_deferred()
+
+
+def test_reference_ddp_branch_step_skips_a_non_finite_step():
+    """`train_stats.use_deepspeed = False`: the reference's DDP branch (training_utils.py:46-86 - fp16 autocast, GradScaler, clip,
+    scaler.step, lr_scheduler.step) on the bf16 engine.  With finite gradients it is the DeepSpeed-branch step (same losses, same weights:
+    the loss scale of a bf16 path is 1); with an inf in the gradients GradScaler skips the optimizer step - weights, Adam moments and Adam's
+    step count stay, the LR schedule advances - where the DeepSpeed-branch step would have destroyed the weights."""
+    import types
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    tr = importlib.import_module("graph-gpt_amd.training")
+    from src.utils.training_utils import batch_training as ref_batch_training
+    cfg = dict(hidden_act="gelu", vocab_size=756, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+               max_position_embeddings=1024, causal_attention=False, stacked_feat=13, next_n_token=13)
+    batch = synth.make_pretrain_batch(B=16, S=32, F=13, V=756, seed=9)
+    host = {k: torch.from_numpy(v) for k, v in batch.items() if k != "lengths"}
+    host["position_ids"] = torch.arange(32)[None, :].repeat(16, 1)
+    tcfg = types.SimpleNamespace(optimizer=types.SimpleNamespace(gradient_accumulation_steps=1, max_grad_norm=1.0))
+
+    def run(use_ds, steps):
+        model = M.GraphGPTPretrainBase(M.GraphGPTConfig(**cfg), seed=1).cuda().eval()
+        eng = tr.initialize(model, tr.OptimConfig(lr=1e-3, max_grad_norm=1.0, schedule="onecycle", total_num_steps=10, warmup_num_steps=2))
+        stats = types.SimpleNamespace(device=torch.device("cuda"), has_embeds_input=False, use_deepspeed=use_ds)
+        losses = []
+        for _ in range(steps):
+            ref_batch_training(host, eng, tcfg, stats, None)
+            losses.append(float(stats.loss))
+        torch.cuda.synchronize()
+        return model, eng, stats, losses
+
+    m_ds, _, _, l_ds = run(True, 3)
+    m_dp, eng, stats, l_dp = run(False, 3)
+    np.testing.assert_allclose(l_dp, l_ds, rtol=2e-6)
+    np.testing.assert_array_equal(m_dp._engine.master.cpu().numpy(), m_ds._engine.master.cpu().numpy())
+    assert getattr(eng, "skipped_steps", 0) == 0 and m_dp._engine.step_count == 3 and eng.global_steps == 3
+    # a step whose gradients hold an inf: forward + backward by hand, poison one gradient element, then the branch's step rule
+    e = m_dp._engine
+    before = {k: e.master.clone() for k in ("w",)}
+    m0, v0 = e.adam_m.clone(), e.adam_v.clone()
+    out = eng(input_ids=host["input_ids"].cuda(), attention_mask=host["attention_mask"].cuda(), labels=host["labels"].cuda())
+    real_backward = eng.backward
+
+    def poisoned_backward(loss=None):
+        real_backward(loss)
+        e.grad_bf16[12345] = float("inf")
+    eng.backward = poisoned_backward
+    gn = tr._reference_optimizer_step(eng, tcfg, stats, out.head1_loss)
+    eng.backward = real_backward
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(gn))
+    assert torch.equal(e.master, before["w"]) and torch.equal(e.adam_m, m0) and torch.equal(e.adam_v, v0)
+    assert eng.skipped_steps == 1 and e.step_count == 3 and eng.global_steps == 4          # Adam's count stays, the schedule moved on
+    # ... and training continues from the untouched state
+    ref_batch_training(host, eng, tcfg, stats, None)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(stats.loss)) and e.step_count == 4 and not torch.equal(e.master, before["w"])
+    # the DeepSpeed-branch rule has no such guard (DeepSpeed's bf16 optimizer): the same poisoned step ruins the weights
+    e2 = m_ds._engine
+    eng2 = tr.initialize(m_ds, tr.OptimConfig(lr=1e-3, max_grad_norm=1.0))
+    out2 = eng2(input_ids=host["input_ids"].cuda(), attention_mask=host["attention_mask"].cuda(), labels=host["labels"].cuda())
+    eng2.backward(out2.head1_loss)
+    e2.grad_bf16[12345] = float("inf")
+    eng2.step()
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(e2.master).all())

@@ -1329,8 +1329,10 @@ static int forward_pretrain_impl(gget_handle_t h, const int64_t* input_ids_dev, 
                              h->wsp<int32_t>(w.sel_tok), st))
     return e;
   if (h->varlen)   // the selected rows live at their compact positions (sel_tok / sel_label keep the padded coordinates the loss weights need)
+    // (full-logit inference - labels == NULL, generation - selects every cell of the padded grid: the cells of padded positions read a
+    //  pad-token row, their logits are defined but meaningless exactly like the reference's, and no flag is raised)
     if (int e = k_remap_rows(h->wsp<int32_t>(w.row_idx), counts, h->wsp<int32_t>(w.vl_pad2c), T, h->T > h->tc ? h->tc : 0,
-                             h->wsp<int32_t>(w.vl_status), st))
+                             labels_dev ? h->wsp<int32_t>(w.vl_status) : nullptr, st))
       return e;
   if (int e = k_gather_rows(h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.row_idx), counts, h->wsp<bf16_t>(w.Hm), T, d, 0, st))
     return e;

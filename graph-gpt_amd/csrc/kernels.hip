@@ -496,13 +496,18 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_bwd_kernel(const bf16_t* __res
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + i * 64;
     if (c < nchunk) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dw_lds[wave * d + c * 8 + e] = dwp[i][e];
+      // Two planes of d / 2 floats per wave: channels [8 c, 8 c + 4) in plane 0 at float 4 c, [8 c + 4, 8 c + 8) in plane 1 - neighbouring lanes
+      // store neighbouring 16 bytes.  (Eight scalar stores 32 bytes apart per lane were 8-way bank conflicts: 0.75 conflict cycles per
+      // active LDS cycle in the round-4 PMC table; two 16-byte stores at that pitch still 2-way.)
+      *reinterpret_cast<float4*>(dw_lds + wave * d + c * 4) = make_float4(dwp[i][0], dwp[i][1], dwp[i][2], dwp[i][3]);
+      *reinterpret_cast<float4*>(dw_lds + wave * d + (d >> 1) + c * 4) = make_float4(dwp[i][4], dwp[i][5], dwp[i][6], dwp[i][7]);
     }
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < d; j += kBlock) {
-    const float s = dw_lds[j] + dw_lds[d + j] + dw_lds[2 * d + j] + dw_lds[3 * d + j];
+  for (int t = threadIdx.x; t < d; t += kBlock) {
+    const int hd = d >> 1, pl = t >= hd ? 1 : 0, ix = t - pl * hd;      // thread -> (plane, float): consecutive threads read consecutive floats
+    const int j = (ix >> 2) * 8 + pl * 4 + (ix & 3);                     // ... of channel j
+    const float s = dw_lds[t] + dw_lds[d + t] + dw_lds[2 * d + t] + dw_lds[3 * d + t];
     if (dw_part) dw_part[(size_t)blockIdx.x * d + j] = s;     // reproducible mode: summed in block order by ordered_colsum_kernel
     else unsafeAtomicAdd(dw_accum + (size_t)(blockIdx.x % copies) * copy_stride + j, s);
   }
@@ -2186,7 +2191,7 @@ __global__ void __launch_bounds__(kBlock) remap_rows_kernel(int32_t* __restrict_
     bad |= r < 0;
     idx[i] = r < 0 ? pad_row : r;
   }
-  if (__any(bad) && (threadIdx.x & 63) == 0) status[2] = 1;
+  if (status && __any(bad) && (threadIdx.x & 63) == 0) status[2] = 1;     // (status == nullptr: inference selects EVERY cell of the padded grid on purpose)
 }
 // sum of the key lengths of a batch (one block): the real-token count the host reads back when it asked the engine to count
 // (gget_set_token_count(GGET_TOKENS_AUTO))

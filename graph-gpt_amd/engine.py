@@ -169,7 +169,7 @@ class Engine:
         wgt = None if sample_wgt is None else sample_wgt.to(device=dev, dtype=torch.float32).contiguous()
         pos = self._i64(position_ids, dev)
         self._keep = (ids, att, lab, wgt, pos)
-        self._set_layout(att if lab is not None else None, num_tokens if lab is not None else None)   # (full-logit inference: padded rows)
+        self._set_layout(att, num_tokens)   # (full-logit inference runs var-len too since round 5: the logits keep their [B S F, V] cell order)
         if att is not None and att.dim() == 3:      # packed rows: block-diagonal [B,S,S] mask
             assert att.shape == (B, S, S), f"3-D attention mask must be [B,S,S], got {tuple(att.shape)}"
             fn = self.lib.gget_forward_pretrain_packed

@@ -158,8 +158,8 @@ def test_varlen_wrong_token_count_is_flagged_and_fallbacks():
     e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"])           # no count -> padded
     assert e.varlen_status()[0] is False
     e.hidden_states(16, 32)
-    e.forward_pretrain(b["input_ids"], b["attention_mask"], None, num_tokens=n)    # full-logit inference -> padded rows
-    assert e.varlen_status()[0] is False
+    e.forward_pretrain(b["input_ids"], b["attention_mask"], None, num_tokens=n)    # full-logit inference: var-len since round 5, no flag for
+    assert e.varlen_status() == (True, (n + 63) // 64 * 64, False)                 # the cells of padded positions
     full = torch.ones_like(b["attention_mask"])
     e.forward_pretrain(b["input_ids"], full, b["labels"], num_tokens=16 * 32)       # no padding -> nothing to compact
     assert e.varlen_status()[0] is False
@@ -495,3 +495,28 @@ def test_reference_ddp_branch_step_skips_a_non_finite_step():
     eng2.step()
     torch.cuda.synchronize()
     assert not bool(torch.isfinite(e2.master).all())
+
+
+def test_varlen_full_logit_inference_matches_padded():
+    """labels = None (generation, `sample_per_batch`: logits for every cell of the [B,S,F] grid): the layer stack runs on the compact rows,
+    the head still writes [B S F, V] logits in cell order - at every REAL position they are the padded run's (the cells of padded positions
+    are as meaningless as the reference's in both runs)."""
+    spec = _tiny_spec(spec_mod.KIND_PRETRAIN, 32)
+    state = weights_mod.make_state_dict(spec, seed=3, std=0.05, head_std=0.1)
+    batch = synth.make_pretrain_batch(B=16, S=32, F=4, V=500, seed=21)
+    b = tb({k: v for k, v in batch.items() if k != "lengths"})
+    n = int(batch["attention_mask"].sum())
+    outs = []
+    for cnt in (None, n):
+        e = eng_mod.Engine(spec, max_tokens=16 * 32, max_batch=16)
+        e.load_state_dict(state)
+        e.forward_pretrain(b["input_ids"], b["attention_mask"], None, num_tokens=cnt)
+        assert e.varlen_status()[0] == (cnt is not None)
+        assert e.deferred_status() == (False, False)          # selecting the cells of padded positions raises no flag in inference
+        M, Lm = e.head_counts()
+        assert Lm == 16 * 32 * 4
+        outs.append(e.head_logits().float().cpu().view(16, 32, 4, -1))
+    real = b["attention_mask"].bool()
+    a, c = outs[0][real], outs[1][real]
+    assert float((a - c).abs().max()) <= 2e-2 * max(1.0, float(a.abs().max())) and rel_l2(c.numpy(), a.numpy()) < 3e-3
+    assert bool(torch.isfinite(outs[1]).all())

@@ -2638,7 +2638,6 @@ int k_pack_wo(const void* w0, size_t layer_stride, void* fwd, void* bwd, int d, 
   return 0;
 }
 int g_attn_oproj_off = 0;   // gget_debug_set key 10: in-process A/B of the fused form
-extern int g_gemm_lds_headroom;
 bool attn_oproj_enabled() {
   static const int on = getenv("GGET_ATTN_OPROJ") ? atoi(getenv("GGET_ATTN_OPROJ")) : 1;
   return on && !g_attn_oproj_off;
@@ -2698,11 +2697,7 @@ int k_attn_oproj_bwd(const void* dxn, const void* x_mid, const void* nw, const f
                      const int32_t* row_base, void* dqkv, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
                      const int64_t* position_ids, float dropout_p, unsigned dropout_seed, int t_rows, hipStream_t st, int* taken) {
   *taken = 0;
-  // (g_gemm_lds_headroom >= 2: a collective's kernel shares the chip with the backward - data-parallel runs.  This kernel fills 151 of the
-  //  160 KiB of a CU's LDS with ONE workgroup per sample: a foreign workgroup on a CU would push the sample's workgroup into a second round,
-  //  the mechanism behind the GEMM launch menu's headroom rule.  The three-launch form runs then; the forward - which
-  //  never overlaps a collective - stays fused.)
-  if (B == 0 || S == 0 || S > 32 || !attn_oproj_enabled() || k_get_deterministic() || g_gemm_lds_headroom >= 2) return 0;
+  if (B == 0 || S == 0 || S > 32 || !attn_oproj_enabled() || k_get_deterministic()) return 0;
   GGET_REQUIRE(!row_base || key_len, "attention: the var-len token layout needs key_len");
   if (copies < 1) copies = 1;
   const Rope R{cos_tab, sin_tab, position_ids, S};     // rotation of dq, dk back to the un-rotated projections (q, k in memory are rotated)

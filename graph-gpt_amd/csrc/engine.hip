@@ -32,6 +32,7 @@ extern "C" int gget_version(void) { return 101; }
 
 struct PathDropArg { float rate; unsigned seed; int S; const int32_t* row_b; };   // row_b: sample index of every row (var-len token layout) or NULL (row / S)
 
+extern int g_gemm_lds_headroom;   // gemm.hip: >= 2 while a collective's kernel shares the chip (data-parallel runs)
 namespace {
 
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
@@ -1205,8 +1206,8 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
   // every token-wise kernel and GEMM of the layer stack runs on round_up(real, 64) rows instead of B * S (PCQM4M-v2 batches are ~30 %
   // padding, ogbl-ppa ~37 %).  Logical [B,S] quantities (labels, lse, dropout coordinates, loss normalisers) are unchanged: the
   // element dropouts hash the logical row (ElemDropArg::rows = vl_c2p), the per-token rope_range tables are indexed through the compact
-  // position list (= the logical row).  Not taken where an INPUT or OUTPUT tensor is indexed by the padded row: raw-embedding inputs,
-  // the token-level head, full-logit inference; packed rows carry no padding to begin with.
+  // position list (= the logical row); raw-embedding inputs, the token-level head's labels / logits and the cells of full-logit inference
+  // go through the same maps (vl_c2p / vl_pad2c).  Packed rows carry no padding to begin with; hidden-state accessors need the padded grid.
   h->varlen = false;
   h->tc_from_caller = false;
   h->tc = B * S;
@@ -1220,7 +1221,7 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
                                c.kind == GGET_KIND_TASK ? h->wsp<int32_t>(h->ws.pool_row) : nullptr, B, S, st)) {
     return e;
   }
-  if (allow_varlen && varlen_enabled() && (tc_hint > 0 || tc_hint == GGET_TOKENS_AUTO) && !mask_is_3d && mask != nullptr && c.embed_dim == 0) {
+  if (allow_varlen && varlen_enabled() && (tc_hint > 0 || tc_hint == GGET_TOKENS_AUTO) && !mask_is_3d && mask != nullptr) {
     long tc = tc_hint;
     if (tc_hint == GGET_TOKENS_AUTO) {
       int32_t* dst = h->wsp<int32_t>(h->ws.vl_status) + 3;
@@ -1272,7 +1273,8 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
     const int e_ = c.embed_dim;
     const bool blend = c.kind == GGET_KIND_PRETRAIN && labels != nullptr;
     if (int e = k_raw_blend(h->raw_next, blend ? labels : nullptr, c.next_n_token, h->raw_first_label_only,
-                            blend ? h->P + h->plan.raw_tok : nullptr, h->wsp<bf16_t>(w.raw_x), h->wsp<int32_t>(w.raw_flag), h->T, e_, st))
+                            blend ? h->P + h->plan.raw_tok : nullptr, h->wsp<bf16_t>(w.raw_x), h->wsp<int32_t>(w.raw_flag), h->T, e_, st,
+                            h->varlen ? h->wsp<int32_t>(w.vl_c2p) : nullptr, B * S))     // (var-len: raw rows / labels through the logical row)
       return e;
     if (int e = k_rmsnorm_fwd(h->wsp<bf16_t>(w.raw_x), h->P + h->plan.raw_ln, h->wsp<bf16_t>(w.raw_xn), h->wsp<float>(w.raw_rstd), h->T, e_,
                               c.rms_eps, st))
@@ -1415,8 +1417,7 @@ extern "C" int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, 
   const gget_config_t& c = h->cfg;
   StreamKScope sk_scope(h);
   h->fwd_valid = false;
-  if (int e = backbone_forward(h, tc_hint, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st, false, nullptr,
-                               /*allow_varlen=*/problem_type != GGET_PROBLEM_TOKEN_CE))
+  if (int e = backbone_forward(h, tc_hint, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st, false, nullptr))
     return e;
   const Ws& w = h->ws;
   const int d = c.hidden_size, C = c.num_labels;
@@ -1441,7 +1442,11 @@ extern "C" int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, 
                                  c.score_bias ? h->P + h->plan.sbias : nullptr, lg, h->wsp<bf16_t>(w.pooled_h), B, C, d, st))
     return e;
   const int rows = problem_type == GGET_PROBLEM_TOKEN_CE ? h->T : B;   // rows of the logits
-  if (task_logits_dev) GGET_HIP_CHECK(hipMemcpyAsync(task_logits_dev, lg, (size_t)rows * C * 4, hipMemcpyDeviceToDevice, st));
+  const bool tok_vl = problem_type == GGET_PROBLEM_TOKEN_CE && h->varlen;   // token-level logits of compact rows: back to [B,S,C] order
+  if (task_logits_dev && tok_vl) {
+    GGET_HIP_CHECK(hipMemsetAsync(task_logits_dev, 0, (size_t)B * S * C * 4, st));      // (padded positions: zeros)
+    if (int e = k_scatter_rows_map_f32(lg, h->wsp<int32_t>(w.vl_c2p), task_logits_dev, h->T, C, B * S, st)) return e;
+  } else if (task_logits_dev) GGET_HIP_CHECK(hipMemcpyAsync(task_logits_dev, lg, (size_t)rows * C * 4, hipMemcpyDeviceToDevice, st));
   if (task_hidden_dev)
     GGET_HIP_CHECK(hipMemcpyAsync(task_hidden_dev, h->wsp<bf16_t>(w.pooled_h), (size_t)B * d * 2, hipMemcpyDeviceToDevice, st));
   h->have_labels = task_labels_dev != nullptr;
@@ -1455,7 +1460,8 @@ extern "C" int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, 
                              h->wsp<float>(w.tdlogits), h->wsp<int32_t>(w.auc_lists), st))
         return e;
     } else if (problem_type == GGET_PROBLEM_TOKEN_CE) {
-      if (int e = k_tok_ce(lg, (const int64_t*)task_labels_dev, h->wsp<float>(w.tdlogits), h->wsp<float>(w.tok_stat), loss_dev, rows, C, st))
+      if (int e = k_tok_ce(lg, (const int64_t*)task_labels_dev, h->wsp<float>(w.tdlogits), h->wsp<float>(w.tok_stat), loss_dev, rows, C, st,
+                           tok_vl ? h->wsp<int32_t>(w.vl_c2p) : nullptr, B * S))
         return e;
     } else if (int e = k_task_loss(lg, task_labels_dev, sample_wgt_dev, problem_type, B, C, loss_dev, h->wsp<float>(w.tdlogits), st))
       return e;
@@ -1525,7 +1531,11 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   } else if (int e = down_dgrad_geglu(dy_down, h->P + lo.wdown, h->wsp<bf16_t>(lw.gu), dgu, dh, T, d, ff, st)) return e;
   if (int e = gemm_nn(dgu, h->P + lo.wgu, dxn, T, d, 2 * ff, 2 * ff, d, d, nullptr, st)) return e;
   bool front_fused = false;
-  if (!h->plan.has_res && !h->klo() && h->wo_packed) {
+  // (g_gemm_lds_headroom >= 2: a collective's kernel shares the chip with the backward - data-parallel runs.  The per-sample backward kernel
+  //  fills 151 of the 160 KiB of a CU's LDS with ONE workgroup per sample: a foreign workgroup on a CU would push the sample's workgroup into
+  //  a second round, the mechanism behind the GEMM launch menu's headroom rule.  The three-launch form runs then; the
+  //  forward - which never overlaps a collective - stays fused.)
+  if (!h->plan.has_res && !h->klo() && h->wo_packed && g_gemm_lds_headroom < 2) {
     // S <= 32: RMSNorm backward of post_attention_layernorm, the o projection's dgrad and the attention backward of a sample in ONE
     // workgroup (attention.hip: attn_oproj_bwd_kernel); dattn is never materialised
     int taken = 0;
@@ -1728,7 +1738,7 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
     if (int e = k_scatter_rows_f32(dy, h->wsp<int32_t>(w.pool_row), dhid, h->B, d, st)) return e;
   } else if (h->problem == GGET_PROBLEM_TOKEN_CE) {
     if (int e = k_tok_score_bwd(h->wsp<float>(w.tdlogits), h->wsp<float>(w.tok_stat), h->wsp<bf16_t>(w.hidden), h->P + h->plan.score,
-                                s32 + h->plan.score32, c.score_bias ? s32 + h->plan.sbias32 : nullptr, dhid, T, c.num_labels, d, st))
+                                s32 + h->plan.score32, c.score_bias ? s32 + h->plan.sbias32 : nullptr, dhid, h->T, c.num_labels, d, st))   // (h->T: the rows of the token-major buffers)
       return e;
   } else {
     if (int e = k_score_bwd(h->wsp<float>(w.tdlogits), h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.pool_row),

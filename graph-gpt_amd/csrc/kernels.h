@@ -24,7 +24,7 @@ int k_elem_dropout(void* x, long T, int n, unsigned stream, ElemDropArg E, hipSt
 // raw-embedding inputs (config.embed_dim > 0; modeling_pretrain.py:131-149): out[t,:] = bf16(raw[t,:]), or the mask token on rows whose
 // labels are all set (first_only: whose first label is set); flag[t] = 1 on those rows.  labels == nullptr: no row is replaced.
 int k_raw_blend(const float* raw, const int64_t* labels, int n, bool first_only, const void* tok, void* out, int32_t* flag, int T, int e,
-                hipStream_t st);
+                hipStream_t st, const int32_t* rows_map = nullptr, int n_logical = 0);
 // d emb_mask_token += sum over the flagged rows of dx[t,:]  (fp32 accumulator, copy 0)
 int k_raw_tok_grad(const void* dx, const int32_t* flag, float* dtok, int T, int e, hipStream_t st);
 // stack_method = "long": x[t,:] *= min(1, bf16(1 / (non-zero ids of token t + 1e-7))) in place (forward value and its gradient);
@@ -84,7 +84,9 @@ int k_score_fwd(const void* hidden, const int32_t* pool_row, const void* w, cons
 // token-level head (loss_type = "token_ce"): score on every row (fp32 logits rounded as bf16), cross-entropy with ignore_index -100
 // (stat: 4 floats of scratch - loss sum, labelled rows, 1 / rows), and the backward (dW / dbias accumulate, dhidden is overwritten)
 int k_tok_score_fwd(const void* hidden, const void* w, const void* bias, float* logits, int T, int C, int d, hipStream_t st);
-int k_tok_ce(const float* logits, const int64_t* labels, float* dl, float* stat, float* loss_out, int T, int C, hipStream_t st);
+int k_tok_ce(const float* logits, const int64_t* labels, float* dl, float* stat, float* loss_out, int T, int C, hipStream_t st,
+             const int32_t* rows_map = nullptr, int n_logical = 0);   // rows_map: compact row -> logical row of the labels (var-len layout)
+int k_scatter_rows_map_f32(const float* src, const int32_t* rows_map, float* dst, int T, int C, int n_logical, hipStream_t st);
 int k_tok_score_bwd(const float* dl, const float* stat, const void* hidden, const void* w, float* dw, float* dbias, void* dhidden, int T,
                     int C, int d, hipStream_t st);
 int k_pool_rows(const void* hidden, const int32_t* pool_row, void* out, int B, int d, hipStream_t st);

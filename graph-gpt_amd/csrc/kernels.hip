@@ -111,17 +111,25 @@ __global__ void __launch_bounds__(kBlock) sample_mask_wgt_kernel(const int64_t* 
 // when ANY of the token's labels is unset (smtp_inside: when its first label is unset); the other rows become emb_mask_token.
 __global__ void __launch_bounds__(128) raw_blend_kernel(const float* __restrict__ raw, const int64_t* __restrict__ labels, int n,
                                                         int first_only, const bf16_t* __restrict__ tok, bf16_t* __restrict__ out,
-                                                        int32_t* __restrict__ flag, int e) {
+                                                        int32_t* __restrict__ flag, int e, const int32_t* __restrict__ rows_map, int n_logical) {
+  // var-len token layout (rows_map): out / flag rows are the compact rows, raw and labels are read at the logical row rows_map[t]; the
+  // pad rows that round the row count up (logical row >= n_logical) are zeros, unflagged
   const int t = blockIdx.x;
+  const int lt = rows_map ? rows_map[t] : t;
+  if (lt >= n_logical) {
+    if (threadIdx.x == 0) flag[t] = 0;
+    for (int j = threadIdx.x; j < e; j += blockDim.x) out[(size_t)t * e + j] = 0;
+    return;
+  }
   bool masked = false;
   if (labels) {
-    const int64_t* lr = labels + (size_t)t * n;
+    const int64_t* lr = labels + (size_t)lt * n;
     int unset = 0;
     for (int f = 0; f < (first_only ? 1 : n); ++f) unset += lr[f] == -100;
     masked = unset == 0;
   }
   if (threadIdx.x == 0) flag[t] = masked ? 1 : 0;
-  for (int j = threadIdx.x; j < e; j += blockDim.x) out[(size_t)t * e + j] = masked ? tok[j] : f2bf(raw[(size_t)t * e + j]);
+  for (int j = threadIdx.x; j < e; j += blockDim.x) out[(size_t)t * e + j] = masked ? tok[j] : f2bf(raw[(size_t)lt * e + j]);
 }
 __global__ void __launch_bounds__(kBlock) raw_tok_grad_kernel(const bf16_t* __restrict__ dx, const int32_t* __restrict__ flag,
                                                               float* __restrict__ dtok, int T, int e) {
@@ -1109,12 +1117,16 @@ __global__ void __launch_bounds__(kBlock) tok_score_fwd_kernel(const bf16_t* __r
 }
 // per-row cross-entropy with ignore_index = -100 (label < 0): dl[t,:] = softmax - onehot for labelled rows (NOT yet divided by
 // their number), zeros otherwise; stat[0] += sum of row losses, stat[1] += labelled rows (fp32 atomics; the count is exact)
+// rows_map (var-len token layout): logits / dl rows are the compact rows, labels are indexed by the logical row rows_map[t] (rows behind
+// the padded grid - the pad rows that round the row count up - carry no label)
 __global__ void __launch_bounds__(kBlock) tok_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                        float* __restrict__ dl, float* __restrict__ stat, int T, int C) {
+                                                        float* __restrict__ dl, float* __restrict__ stat, int T, int C,
+                                                        const int32_t* __restrict__ rows_map, int n_logical) {
   __shared__ float red[2][kBlock / 64];
   float ls = 0.f, cnt = 0.f;
   for (int t = blockIdx.x * kBlock + threadIdx.x; t < T; t += gridDim.x * kBlock) {
-    const int y = (int)labels[t];
+    const int lt = rows_map ? rows_map[t] : t;
+    const int y = lt < n_logical ? (int)labels[lt] : -100;
     const float* lp = logits + (size_t)t * C;
     float* dp = dl + (size_t)t * C;
     if (y < 0) {
@@ -1928,9 +1940,10 @@ int k_embed_fwd(const int64_t* ids, const void* emb, const void* gate, void* out
 }
 
 int k_raw_blend(const float* raw, const int64_t* labels, int n, bool first_only, const void* tok, void* out, int32_t* flag, int T, int e,
-                hipStream_t st) {
+                hipStream_t st, const int32_t* rows_map, int n_logical) {
   if (T == 0) return 0;
-  hipLaunchKernelGGL(raw_blend_kernel, dim3(T), dim3(128), 0, st, raw, labels, n, first_only ? 1 : 0, (const bf16_t*)tok, (bf16_t*)out, flag, e);
+  hipLaunchKernelGGL(raw_blend_kernel, dim3(T), dim3(128), 0, st, raw, labels, n, first_only ? 1 : 0, (const bf16_t*)tok, (bf16_t*)out, flag, e,
+                     rows_map, rows_map ? n_logical : T);
   GGET_LAUNCH_CHECK();
   return 0;
 }
@@ -2329,9 +2342,28 @@ int k_tok_score_fwd(const void* hidden, const void* w, const void* bias, float* 
   GGET_LAUNCH_CHECK();
   return 0;
 }
-int k_tok_ce(const float* logits, const int64_t* labels, float* dl, float* stat, float* loss_out, int T, int C, hipStream_t st) {
+// dst[rows_map[t], :] = src[t, :] for the rows inside the logical grid (token-level logits of the var-len layout back to [B,S,C] order)
+__global__ void __launch_bounds__(kBlock) scatter_rows_map_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ rows_map,
+                                                                      float* __restrict__ dst, long T, int C, int n_logical) {
+  for (long w = (long)blockIdx.x * kBlock + threadIdx.x; w < T * C; w += (long)gridDim.x * kBlock) {
+    const long t = w / C;
+    const int lt = rows_map[t];
+    if (lt < n_logical) dst[(size_t)lt * C + (w % C)] = src[w];
+  }
+}
+int k_scatter_rows_map_f32(const float* src, const int32_t* rows_map, float* dst, int T, int C, int n_logical, hipStream_t st) {
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(scatter_rows_map_f32_kernel, dim3(grid_for((long)T * C, kBlock, 2048)), dim3(kBlock), 0, st, src, rows_map, dst, (long)T, C,
+                     n_logical);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+int k_tok_ce(const float* logits, const int64_t* labels, float* dl, float* stat, float* loss_out, int T, int C, hipStream_t st,
+             const int32_t* rows_map, int n_logical) {
   GGET_HIP_CHECK(hipMemsetAsync(stat, 0, 4 * sizeof(float), st));
-  if (T > 0) hipLaunchKernelGGL(tok_ce_kernel, dim3(grid_for(T, kBlock, 1024)), dim3(kBlock), 0, st, logits, labels, dl, stat, T, C);
+  if (T > 0)
+    hipLaunchKernelGGL(tok_ce_kernel, dim3(grid_for(T, kBlock, 1024)), dim3(kBlock), 0, st, logits, labels, dl, stat, T, C, rows_map,
+                       rows_map ? n_logical : T);
   hipLaunchKernelGGL(tok_ce_final_kernel, dim3(1), dim3(1), 0, st, stat, loss_out);
   GGET_LAUNCH_CHECK();
   return 0;

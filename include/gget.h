@@ -141,9 +141,10 @@ int gget_set_dropout(gget_handle_t h, float attention_p, float path_p, uint32_t 
  * In the var-len layout the engine compacts the real tokens once (sample b owns rows [cu[b], cu[b] + len[b]))
  * and runs embedding, every GEMM / norm / residual of the layer stack, attention (per-sample row offsets) and the backward on
  * round_up(n_real_tokens, 64) rows instead of B*S.  Results are those of the padded layout (pad rows never influence real rows; the
- * loss, its normalisers, the dropout streams and all [B,S]-shaped inputs keep their logical coordinates).  The engine falls back to the
- * padded layout by itself where a random stream or an output is indexed by the padded row (element dropouts, raw-embedding inputs,
- * rope_range, the token-level head) and for packed rows.  gget_hidden_states refuses after a var-len forward.
+ * loss, its normalisers, the dropout streams and all [B,S]-shaped inputs / outputs keep their logical coordinates: element-dropout hashes
+ * and rope_range tables are keyed by the logical row, full-logit inference keeps the [B S F, V] cell order of its logits, the token-level
+ * head writes task_logits [B,S,C] with zeros at padded positions, raw-embedding inputs are read at the logical row).  The engine falls back
+ * to the padded layout by itself for packed rows only.  gget_hidden_states / gget_layer_hidden_states refuse after a var-len forward.
  * A caller's count that DISAGREES with the mask cannot go unnoticed: the samples are cut at the count (no kernel leaves the rows of
  * the step), the step's loss is NaN, and a sticky device flag is raised that gget_deferred_status reports; the same flag is raised by
  * a label != -100 at a padded position (the reference's collator pads labels with -100; such a row does not exist in the compact

@@ -27,6 +27,22 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _reset_process_wide_kernel_menu(request):
+    """gget_debug_set switches are process-wide (the data-parallel tests attach communicators, which selects the LDS-headroom launch menu
+    - key 2 - for the rest of the process): every GPU test starts from the single-GPU defaults, whatever ran before it."""
+    if "gpu" in request.keywords:
+        try:
+            import importlib
+            L = importlib.import_module("graph-gpt_amd._lib")
+            lib = L.load()
+            for key, val in ((2, 1), (10, 0), (1, 0), (8, 0)):
+                lib.gget_debug_set(key, val)
+        except Exception:
+            pass
+    yield
+
+
 def pytest_sessionfinish(session, exitstatus):
     """Every error the GPU parity tests measured, next to the tolerance it was held to (tests/_util.py:record_error) ->
     gpurun_out/parity_errors.json (copied to profiles/ per round)."""

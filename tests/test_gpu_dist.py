@@ -83,7 +83,11 @@ def test_two_rank_step_matches_manual_gradient_average(overlap, layout, monkeypa
     assert res[0][1][0] != res[1][1][0]                            # ... on different data
     assert abs(res[0][3] - res[1][3]) == 0.0                       # same clipped global norm on both ranks
 
-    # one process, two replicas' gradients averaged by hand (fp32 sum of the bf16 buckets, then the same 1/world scale)
+    # one process, two replicas' gradients averaged by hand (fp32 sum of the bf16 buckets, then the same 1/world scale) - with the kernel
+    # menu of a data-parallel rank (gget_debug_set(2, 2), what GgetEngine sets at world > 1: LDS headroom for a collective's workgroups, which
+    # since round 5 also means the three-launch form of the S <= 32 backward instead of the per-sample workgroup)
+    L_ = importlib.import_module("graph-gpt_amd._lib")
+    L_.check(L_.load().gget_debug_set(2, 2))
     models = [modeling.GraphGPTPretrainBase(_cfg(modeling), seed=1) for _ in range(2)]
     engs = [tr.initialize(m, tr.OptimConfig(lr=1e-3, max_grad_norm=0.05)) for m in models]
     datas = [_batch(synth, r, layout) for r in range(2)]
@@ -100,6 +104,7 @@ def test_two_rank_step_matches_manual_gradient_average(overlap, layout, monkeypa
             en.step()
             en.world = 1
         torch.cuda.synchronize()
+    L_.check(L_.load().gget_debug_set(2, 1))
     ref = models[0]._engine.master.detach().cpu().numpy()
     np.testing.assert_allclose(res[0][2], ref, rtol=0, atol=1e-6)
 

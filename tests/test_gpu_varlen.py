@@ -520,3 +520,75 @@ def test_varlen_full_logit_inference_matches_padded():
     a, c = outs[0][real], outs[1][real]
     assert float((a - c).abs().max()) <= 2e-2 * max(1.0, float(a.abs().max())) and rel_l2(c.numpy(), a.numpy()) < 3e-3
     assert bool(torch.isfinite(outs[1]).all())
+
+
+def test_varlen_token_level_head_matches_padded():
+    """loss_type = "token_ce" (node-level tasks: `score` and the cross-entropy on every row, task_logits [B,S,C]) on the var-len layout
+    (round 5): the logits of the compact rows are scattered back to [B,S,C] order (padded positions: zeros), the labels are read through the
+    compact -> logical row map; loss, logits at the real positions and every gradient equal the padded run's."""
+    S, F, V, B, C_ = 40, 4, 500, 12, 5
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=V, stacked_feat=F, next_n_token=1, num_labels=C_)
+    state = weights_mod.make_state_dict(spec, seed=6, std=0.05, head_std=0.1)
+    batch = synth.make_task_batch(B=B, S=S, F=F, V=V, seed=19)
+    b = tb({k: v for k, v in batch.items() if k != "lengths"})
+    g = torch.Generator().manual_seed(3)
+    y = torch.randint(0, C_, (B, S), generator=g)
+    y[torch.rand(B, S, generator=g) < 0.3] = -100
+    y[b["attention_mask"] == 0] = -100            # the collator pads labels with -100
+    n = int(batch["attention_mask"].sum())
+    out = {}
+    for lay, cnt in (("padded", None), ("varlen", n)):
+        e = eng_mod.Engine(spec, max_tokens=B * S, max_batch=B)
+        e.load_state_dict(state)
+        loss, logits, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], y, None, L.PROBLEM_TOKEN_CE, num_tokens=cnt)
+        assert e.varlen_status()[0] == (lay == "varlen")
+        e.backward()
+        torch.cuda.synchronize()
+        out[lay] = (float(loss), logits.float().cpu().clone(), {k: v.float().cpu().numpy().copy() for k, v in e.grads().items()})
+    (lp, zp, gp), (lv, zv, gv) = out["padded"], out["varlen"]
+    real = b["attention_mask"].bool()
+    assert tuple(zv.shape) == (B, S, C_) and abs(lv - lp) <= 2e-5 * abs(lp)
+    assert float((zv[real] - zp[real]).abs().max()) <= 2e-3 * max(1.0, float(zp[real].abs().max()))
+    assert bool((zv[~real] == 0).all())
+    gmax = max(float(np.linalg.norm(x)) for x in gp.values())
+    for k in gp:
+        assert float(np.linalg.norm(gv[k] - gp[k])) / max(float(np.linalg.norm(gp[k])), 1e-2 * gmax) < 1e-2, k
+
+
+@pytest.mark.parametrize("kind", ["pt", "ft"])
+def test_varlen_raw_embedding_inputs_match_padded(kind):
+    """config.embed_dim > 0 (raw per-token embeddings [B,S,E] next to the ids; modeling_pretrain.py:131-149) on the var-len layout
+    (round 5): the raw rows and the labels of the mask-token blend are read at the logical row of every compact row, the branch's dropout
+    stream is keyed by it - loss and every gradient (incl. embed_proj, embed_layernorm, emb_mask_token) equal the padded run's, with
+    embed_dropout on."""
+    S, F, V, B, E = 40, 4, 500, 12, 64
+    pt = kind == "pt"
+    spec = spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_PRETRAIN if pt else spec_mod.KIND_TASK, vocab_size=V, stacked_feat=F,
+                                   next_n_token=F if pt else 1, num_labels=2, embed_dim=E, embed_pdrop=0.1)
+    state = weights_mod.make_state_dict(spec, seed=8, std=0.05, head_std=0.1)
+    batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=23) if pt else synth.make_task_batch(B=B, S=S, F=F, V=V, seed=23)
+    b = tb({k: v for k, v in batch.items() if k != "lengths"})
+    raw = torch.randn(B, S, E, generator=torch.Generator().manual_seed(5))
+    n = int(batch["attention_mask"].sum())
+    out = {}
+    for lay, cnt in (("padded", None), ("varlen", n)):
+        e = eng_mod.Engine(spec, max_tokens=B * S, max_batch=B)
+        e.load_state_dict(state)
+        e.set_dropout(0.0, 0.0, 91)
+        e.set_dropout_ex(0.1, 0.0, 0.0)
+        e.set_raw_embeds(raw)
+        if pt:
+            loss = e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], num_tokens=cnt)
+        else:
+            loss, _, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], None, L.PROBLEM_SINGLE_LABEL,
+                                        num_tokens=cnt)
+        assert e.varlen_status()[0] == (lay == "varlen")
+        e.backward()
+        torch.cuda.synchronize()
+        out[lay] = (float(loss), {k: v.float().cpu().numpy().copy() for k, v in e.grads().items()})
+    (lp, gp), (lv, gv) = out["padded"], out["varlen"]
+    assert abs(lv - lp) <= 2e-5 * abs(lp), (lv, lp)
+    assert "embed_proj.weight" in gp and float(np.linalg.norm(gp["embed_proj.weight"])) > 0
+    gmax = max(float(np.linalg.norm(x)) for x in gp.values())
+    for k in gp:
+        assert float(np.linalg.norm(gv[k] - gp[k])) / max(float(np.linalg.norm(gp[k])), 1e-2 * gmax) < 1e-2, k

@@ -82,6 +82,7 @@ class Engine:
         self.h = h
         self.workspace_bytes = int(sz.workspace_bytes)
         # parameter table
+        self.varlen_mode: Optional[str] = None     # per-engine override of GGET_VARLEN (see _set_layout)
         self.params: "OrderedDict[str, dict]" = OrderedDict()
         info = L.GgetParamInfo()
         for i in range(self.lib.gget_param_count(self.h)):
@@ -145,9 +146,10 @@ class Engine:
         string "auto" (the engine sums the key lengths of the 2-D device mask and reads the total back: 4 bytes + one stream
         synchronisation - what the model classes pass for a device-resident mask) or None (unknown: padded layout, the default of this
         low-level class).  GGET_VARLEN=0 keeps the padded layout whatever the caller passed; =sync counts even when the caller passed
-        nothing; =nosync never counts on the device."""
+        nothing; =nosync never counts on the device.  `self.varlen_mode` (the same strings; set through the model classes'
+        `token_layout` attribute) overrides the environment for this engine."""
         import os
-        mode = os.environ.get("GGET_VARLEN", "")
+        mode = self.varlen_mode if self.varlen_mode is not None else os.environ.get("GGET_VARLEN", "")
         n = None if mode == "0" else num_tokens
         if n is None and mode == "sync":
             n = "auto"

@@ -198,6 +198,7 @@ class _GgetModel(nn.Module):
         self._anchor = None
         self.dropout_seed, self._drop_step = seed, 0
         self.materialize_grads = True   # fill nn.Parameter.grad (fp32) after backward, like autograd would
+        self._token_layout = "auto"
         self._dirty = False             # master weights changed behind the engine's back (external optimizer)
         state = make_state_dict(self.spec, seed=seed, std=config.initializer_range)
         # module tree with the reference's attribute paths: model.embed_tokens / model.layers[i].* / model.norm ...
@@ -229,6 +230,25 @@ class _GgetModel(nn.Module):
     @property
     def dtype(self):
         return torch.bfloat16
+
+    # token layout of this model's forwards - a per-model switch beside the process-wide GGET_VARLEN:
+    #   "auto"   (default) the environment decides; without it: var-len whenever the real-token count is known or countable
+    #   "padded" every row of the [B,S] grid, as the reference computes it (hidden-state accessors, debugging)
+    #   "nosync" var-len only when the count costs no device->host read (host mask or num_tokens=); device masks run padded
+    #   "sync"   count on the device even when the caller passed nothing
+    _LAYOUTS = {"auto": None, "varlen": "", "padded": "0", "nosync": "nosync", "sync": "sync"}
+
+    @property
+    def token_layout(self) -> str:
+        return self._token_layout
+
+    @token_layout.setter
+    def token_layout(self, value: str):
+        if value not in self._LAYOUTS:
+            raise ValueError(f"token_layout: one of {sorted(self._LAYOUTS)}, got {value!r}")
+        self._token_layout = value
+        if self._engine is not None:
+            self._engine.varlen_mode = self._LAYOUTS[value]
 
     def gradient_checkpointing_enable(self, *a, **k):
         return None  # activations for 288 GB HBM are kept; recompute is never needed on this path
@@ -284,6 +304,7 @@ class _GgetModel(nn.Module):
         new.sync_params()
         new.set_stack_method(getattr(self.config, "stack_method", None) == "long")
         new.set_rope_range(float(getattr(self.config, "rope_range", 0) or 0))
+        new.varlen_mode = self._LAYOUTS[self._token_layout]
         self._engine = new
         self._anchor = torch.zeros(1, device=new.device, requires_grad=True)
         self._dirty = False

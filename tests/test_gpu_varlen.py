@@ -497,6 +497,43 @@ def test_reference_ddp_branch_step_skips_a_non_finite_step():
     assert not bool(torch.isfinite(e2.master).all())
 
 
+def test_model_token_layout_attribute_overrides_the_environment(monkeypatch):
+    """`model.token_layout` - the per-model switch beside the process-wide GGET_VARLEN: "padded" keeps the [B,S] grid for a batch that
+    would run var-len (and the hidden-state accessors work), "nosync" runs a device mask padded and a host mask var-len, "auto" hands the
+    decision back to the environment; unknown names raise."""
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    cfg = dict(hidden_act="gelu", vocab_size=500, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+               max_position_embeddings=1024, causal_attention=False, stacked_feat=4, next_n_token=4)
+    batch = synth.make_pretrain_batch(B=8, S=32, F=4, V=500, seed=5)
+    host = {k: torch.from_numpy(v) for k, v in batch.items() if k != "lengths"}
+    dev = {k: v.cuda() for k, v in host.items()}
+    model = M.GraphGPTPretrainBase(M.GraphGPTConfig(**cfg), seed=1).cuda().eval()
+
+    def ran_varlen(data):
+        with torch.no_grad():
+            loss = float(model(**data).head1_loss)
+        return model._engine.varlen_status()[0], loss
+
+    assert model.token_layout == "auto"
+    v0, l0 = ran_varlen(dev)
+    model.token_layout = "padded"
+    v1, l1 = ran_varlen(dev)
+    hs = model._engine.hidden_states(8, 32)                 # (refuses after a var-len forward)
+    assert tuple(hs.shape) == (8, 32, 128)
+    model.token_layout = "nosync"
+    v2, _ = ran_varlen(dev)
+    v3, l3 = ran_varlen(host)
+    monkeypatch.setenv("GGET_VARLEN", "0")
+    model.token_layout = "varlen"                           # the attribute wins over the environment
+    v4, _ = ran_varlen(dev)
+    model.token_layout = "auto"                             # ... and "auto" gives the decision back to it
+    v5, _ = ran_varlen(dev)
+    assert (v0, v1, v2, v3, v4, v5) == (True, False, False, True, True, False)
+    assert abs(l0 - l1) <= 5e-5 * abs(l1) and abs(l3 - l1) <= 5e-5 * abs(l1)
+    with pytest.raises(ValueError):
+        model.token_layout = "compact"
+
+
 def test_varlen_full_logit_inference_matches_padded():
     """labels = None (generation, `sample_per_batch`: logits for every cell of the [B,S,F] grid): the layer stack runs on the compact rows,
     the head still writes [B S F, V] logits in cell order - at every REAL position they are the padded run's (the cells of padded positions

@@ -1066,6 +1066,121 @@ __global__ void __launch_bounds__(256) rmsnorm_bwd_ls_kernel(const bf16_t* __res
     if (dlam_accum) unsafeAtomicAdd(dlam_accum + off, dl_lds[j] + dl_lds[d + j] + dl_lds[2 * d + j] + dl_lds[3 * d + j]);
   }
 }
+int g_ls_norm_bwd_wide = getenv("GGET_LS_NORM_BWD_WIDE") ? atoi(getenv("GGET_LS_NORM_BWD_WIDE")) : 0;
+// The same pass for d = 256 PCH with every lane busy and a third of the registers: lane l owns the 4 channels [256 p + 4 l, +4) of each of
+// the PCH pieces of a row (8-byte loads, 512 contiguous bytes per wave instruction), norm weight and LayerScale vector stay packed, the
+// residual / branch operands are unpacked where they are used, and there is no software prefetch - ~100 registers = 5 waves per SIMD keep
+// 12 loads per lane in flight each instead of 2 waves x 16 (the form above: 230 registers; at d = 768 its second chunk idles half of the
+// lanes).  C3 (T = 41 088, d = 768): 104 -> see profiles/r05_step_experiments.txt item 7.  Same expressions per element; the fp32 order of
+// the row's dot product differs (other lane assignment), i.e. results equal the form above up to single bf16 rounding flips.
+template <int PCH>
+__global__ void __launch_bounds__(256) rmsnorm_bwd_ls4_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                              const bf16_t* __restrict__ w, const float* __restrict__ rstd_in,
+                                                              const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                                              float* __restrict__ dw_accum, const bf16_t* __restrict__ y,
+                                                              const bf16_t* __restrict__ lam, bf16_t* __restrict__ dsc,
+                                                              float* __restrict__ dlam_accum, int T, int copies, uint64_t copy_stride,
+                                                              PathDrop D, ElemDropArg E) {
+  constexpr int d = 256 * PCH;
+  extern __shared__ float red_lds[];  // [2][4][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto un4 = [](const uint2& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  };
+  uint2 wq[PCH], lq[PCH];
+  float dwp[PCH][4], dlp[PCH][4];
+#pragma unroll
+  for (int p = 0; p < PCH; ++p) {
+    wq[p] = *reinterpret_cast<const uint2*>(w + p * 256 + lane * 4);
+    lq[p] = lam ? *reinterpret_cast<const uint2*>(lam + p * 256 + lane * 4) : make_uint2(0x3F803F80u, 0x3F803F80u);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dwp[p][e] = 0.f; dlp[p][e] = 0.f; }
+  }
+  const int stride = gridDim.x * 4;
+  // `keepv`: an empty asm the compiler must assume rewrites the packed words - the unpacked copies are recomputed where they are used
+  // (one shift / and each) instead of living in registers across the loop (norm weight, LayerScale vector) or across the row's reduction
+  // (x, dy): that is what takes the kernel from 149 to <= 102 registers
+  auto keepv = [](uint2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); };
+  for (int row0 = blockIdx.x * 4 + wave; row0 < T; row0 += stride) {
+    const int row = __builtin_amdgcn_readfirstlane(row0);     // (wave-uniform: scalar row base, 32-bit lane offsets)
+    const size_t rb = (size_t)row * d;
+    const bf16_t *xrow = x + rb, *dyrow = dy + rb, *yrow = y + rb, *rrow = dres ? dres + rb : nullptr;
+    bf16_t *dxrow = dx + rb, *dscrow = dsc + rb;
+    const unsigned lo = lane * 4;
+    uint2 xr[PCH], dr[PCH], rr[PCH], yr[PCH];
+#pragma unroll
+    for (int p = 0; p < PCH; ++p) {
+      xr[p] = *reinterpret_cast<const uint2*>(xrow + lo + p * 256);
+      dr[p] = *reinterpret_cast<const uint2*>(dyrow + lo + p * 256);
+    }
+#pragma unroll
+    for (int p = 0; p < PCH; ++p) {
+      rr[p] = rrow ? *reinterpret_cast<const uint2*>(rrow + lo + p * 256) : make_uint2(0, 0);
+      yr[p] = *reinterpret_cast<const uint2*>(yrow + lo + p * 256);
+    }
+    const float rs = rstd_in[row];
+    float dot = 0.f;
+#pragma unroll
+    for (int p = 0; p < PCH; ++p) {
+      float xv[4], dv[4], wv[4];
+      keepv(wq[p]);
+      un4(xr[p], xv);
+      un4(dr[p], dv);
+      un4(wq[p], wv);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = xv[e] * rs, g = dv[e] * wv[e];
+        dot += g * xh;
+        dwp[p][e] += dv[e] * xh;
+      }
+    }
+    dot = wave_sum(dot) / (float)d;
+    const float keep = path_keep(D, row);
+    const unsigned erow = E.thresh ? elem_row(E, row) : 0u;
+#pragma unroll
+    for (int p = 0; p < PCH; ++p) {
+      float xv[4], dv[4], wv[4], res[4], o[4], gq[4], sc[4], lv[4], yv[4];
+      keepv(xr[p]);
+      keepv(dr[p]);
+      keepv(wq[p]);
+      keepv(lq[p]);
+      un4(xr[p], xv);
+      un4(dr[p], dv);
+      un4(wq[p], wv);
+      un4(rr[p], res);
+      un4(lq[p], lv);
+      un4(yr[p], yv);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = xv[e] * rs, g = dv[e] * wv[e];
+        o[e] = res[e] + rs * (g - xh * dot);
+      }
+      const uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+      *reinterpret_cast<uint2*>(dxrow + lo + p * 256) = pk;
+      un4(pk, gq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float em = elem_drop_mul(E, GGET_DROP_STREAM_MLP_OUT, erow, (unsigned)(p * 256 + lane * 4 + e));
+        sc[e] = lv[e] * keep * gq[e] * em;
+        dlp[p][e] += keep * gq[e] * bf2f(f2bf(yv[e] * em));
+      }
+      *reinterpret_cast<uint2*>(dscrow + lo + p * 256) = make_uint2(pack2bf(sc[0], sc[1]), pack2bf(sc[2], sc[3]));
+    }
+  }
+  float* dl_lds = red_lds + 4 * d;
+#pragma unroll
+  for (int p = 0; p < PCH; ++p) {
+    *reinterpret_cast<float4*>(red_lds + wave * d + p * 256 + lane * 4) = make_float4(dwp[p][0], dwp[p][1], dwp[p][2], dwp[p][3]);
+    *reinterpret_cast<float4*>(dl_lds + wave * d + p * 256 + lane * 4) = make_float4(dlp[p][0], dlp[p][1], dlp[p][2], dlp[p][3]);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < d; j += 256) {
+    const size_t off = (size_t)(blockIdx.x % copies) * copy_stride + j;
+    unsafeAtomicAdd(dw_accum + off, red_lds[j] + red_lds[d + j] + red_lds[2 * d + j] + red_lds[3 * d + j]);
+    if (dlam_accum) unsafeAtomicAdd(dlam_accum + off, dl_lds[j] + dl_lds[d + j] + dl_lds[2 * d + j] + dl_lds[3 * d + j]);
+  }
+}
 int rmsnorm_bwd_ls(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres, bf16_t* dx, float* dw_accum,
                    const bf16_t* y, const bf16_t* lam, bf16_t* dsc, float* dlam_accum, int T, int d, PathDrop D, ElemDropArg E,
                    hipStream_t st) {
@@ -1073,6 +1188,16 @@ int rmsnorm_bwd_ls(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const flo
   const int grid = (int)std::min<long>(4096, ((long)T + 15) / 16);
   const size_t lds = (size_t)8 * d * sizeof(float);
   const uint64_t cs = align_up((uint64_t)d, 128);
+  if (!g_ls_norm_bwd_wide && (d == 512 || d == 768 || d == 1024)) {   // (gget_debug_set(11, 1): the 16-byte-chunk form for every width)
+    // 5 workgroups of 4 waves per CU in one round; every wave walks rows with a grid stride (fewer partial-sum atomics per row as well)
+    const int g4 = (int)std::min<long>(1280, ((long)T + 15) / 16);
+#define GGET_LS4(P) hipLaunchKernelGGL(rmsnorm_bwd_ls4_kernel<P>, dim3(g4), dim3(256), lds, st, dy, x, w, rstd, dres, dx, dw_accum, y, lam, dsc, \
+                                      dlam_accum, T, kAccumCopies, cs, D, E)
+    if (d == 512) GGET_LS4(2); else if (d == 768) GGET_LS4(3); else GGET_LS4(4);
+#undef GGET_LS4
+    GGET_LAUNCH_CHECK();
+    return 0;
+  }
   if (d <= 1024)
     hipLaunchKernelGGL(rmsnorm_bwd_ls_kernel<2>, dim3(grid), dim3(256), lds, st, dy, x, w, rstd, dres, dx, dw_accum, y, lam, dsc, dlam_accum, T,
                        d, kAccumCopies, cs, D, E);
@@ -1973,6 +2098,7 @@ extern "C" int gget_debug_set(int key, int value) {
     case 8: g_head_dense = value; return 0;
     case 9: g_head_tile = value; return 0;
     case 10: g_attn_oproj_off = value; return 0;
+    case 11: g_ls_norm_bwd_wide = value; return 0;
   }
   gget_set_error("debug_set: unknown key %d", key);
   return 2;

@@ -343,7 +343,9 @@ int gget_op_gemm_grouped(int mode, int count, const void* const* A, const void* 
  * last round, 16 the 64- / 96-row tiles of the K-split kernel, 32 two co-resident workgroups per CU for the dh + GEGLU' launch.  key 2 = LDS headroom of the 128x192 tile (0: 4-slot ring).
  * key 3 = 1: split the K range of the last, partial round's tiles among the idle workgroups (off by default).
  * key 4 = 1 (also env GGET_DETERMINISTIC=1): reproducible mode of the pre-train step - the RMSNorm weight gradients, the one sum of that
- * gradient path added with fp32 atomics, are summed in block order instead; two runs then produce bit-identical parameters. */
+ * gradient path added with fp32 atomics, are summed in block order instead; two runs then produce bit-identical parameters.
+ * key 10 = 1: the per-sample kernels of S <= 32 off (the three launches each replaces run).  key 11 = 1: the fused RMSNorm + LayerScale
+ * backward in its 16-byte-chunk form for every width (0: the 8-byte, all-lanes form for d = 512 / 768 / 1024). */
 int gget_debug_set(int key, int value);
 /* measurement aid: with enable != 0 the engine brackets, with HIP events on the launch stream, the grouped weight-gradient launch
  * (avg_ms_out[0]) and the gate|up + GEGLU launch (avg_ms_out[1]) of every layer of the following forward / backward calls;

@@ -1095,6 +1095,48 @@ def test_c3_training_mode_dropouts_exact_mask():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("width", [512, 768, 1024])
+def test_ls_norm_backward_lean_form_matches_the_wide_form(width):
+    """The fused RMSNorm + LayerScale / DropPath backward has two lane mappings (engine.hip: rmsnorm_bwd_ls4_kernel - 8-byte pieces, all
+    lanes busy, d = 512 / 768 / 1024 - and the 16-byte-chunk form of every other width): same expressions per element, another fp32 order
+    of the row's dot product.  Same batch, same masks (LayerScale, stochastic depth, mlp_dropout, var-len rows): equal loss (the forward
+    is not involved), gradients equal up to rounding flips."""
+    from _util import spec_mod, weights_mod, synth
+    import dataclasses
+    B, S, F, V = 6, 64, 4, 2000
+    spec = dataclasses.replace(spec_mod.spec_from_size("tiny", kind=spec_mod.KIND_TASK, vocab_size=V, stacked_feat=F, next_n_token=1,
+                                                       num_labels=2, max_position=256, layer_scale_init=1.0, path_pdrop=0.2, mlp_pdrop=0.1),
+                               hidden_size=width, intermediate_size=2 * width, num_heads=width // 64, num_layers=3)
+    state = weights_mod.make_state_dict(spec, seed=5, std=0.04, head_std=0.1)
+    batch = synth.make_task_batch(B=B, S=S, F=F, V=V, seed=31, lengths="uniform", min_len=S // 3)
+    b = tb(batch)
+    runs = []
+    for wide in (1, 0):
+        L.check(L.load().gget_debug_set(11, wide))
+        try:
+            e = make_engine(spec, batch)
+            e.load_state_dict(state)
+            e.set_dropout(0.1, 0.2, 99)
+            e.set_dropout_ex(0.0, 0.1, 0.0)
+            loss, _, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], None, L.PROBLEM_SINGLE_LABEL,
+                                        num_tokens=int(batch["attention_mask"].sum()))
+            e.backward()
+            torch.cuda.synchronize()
+            runs.append((float(loss), {k: v.float().cpu().numpy().copy() for k, v in e.grads().items()}))
+        finally:
+            L.check(L.load().gget_debug_set(11, 0))
+    (lw, gw), (ll, gl) = runs
+    assert lw == ll
+    gmax = max(float(np.linalg.norm(v)) for v in gw.values())
+    worst = 0.0
+    for k in gw:
+        err = float(np.linalg.norm(gl[k] - gw[k])) / max(float(np.linalg.norm(gw[k])), 1e-2 * gmax)
+        worst = max(worst, err)
+        assert err < 4e-3, f"{k}: {err}"
+    record_error(f"ls_norm_bwd_lean_d{width}", "grad_rel_l2_vs_wide_form_worst", worst, 4e-3)
+
+
+@pytest.mark.gpu
 def test_auc_loss_matches_oracle_with_the_same_pairs():
     """loss_type "auc" (modeling_finetune.py:203-207, src/utils/loss_utils.py:25-53) through the drop-in model class: the
     engine's counter-hash negative sampling is reproduced by its Python twin, the oracle (pinned to the reference by

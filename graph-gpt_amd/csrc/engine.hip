@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "common.h"
@@ -423,6 +424,12 @@ struct gget_engine {
     while ((int)v.size() <= idx) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; v.push_back(e); }
     return v[idx];
   }
+  // GGET_TOKENS_AUTO: work of the forward that does not depend on the token count (the SMTP head's row / cell compaction, the packed copies
+  // of the o weights) is enqueued BEHIND the 4-byte read-back and BEFORE the host waits for it, so that the device has ~35 us of kernels to
+  // run while the host wakes up and enqueues the layer stack (the step trace showed the device idle for 25-37 us there)
+  std::function<int(hipStream_t)> presync_work;
+  bool presync_done = false;
+  hipEvent_t count_event = nullptr;
   unsigned auc_seed = 0;
   bool fwd_valid = false;
   float attn_drop_p = 0.f;        // attention dropout of the NEXT forward (training mode); 0 = off
@@ -593,6 +600,7 @@ extern "C" int gget_comm_destroy(gget_handle_t h);
 extern "C" int gget_destroy(gget_handle_t h) {
   if (h) gget_comm_destroy(h);
   if (h && h->host_word) (void)hipHostFree(h->host_word);
+  if (h && h->count_event) (void)hipEventDestroy(h->count_event);
   delete h;
   return 0;
 }
@@ -1338,6 +1346,34 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
   h->tc = B * S;
   const int d = c.hidden_size;
   h->packed = mask_is_3d;
+  auto pack_o_weights = [&]() -> int {
+    // S <= 32 without LayerScale / DropPath: the layers run the per-sample attention + o projection kernels (attention.hip), which read
+    // fragment-major copies of the o weights.  They are rebuilt at the start of EVERY forward (one launch, ~10 us: the bf16 weights are the
+    // caller's memory and change under AdamW, gget_sync_params or a caller's own writes); the backward of this forward uses the same copies.
+    h->wo_packed = false;
+    if (!h->plan.has_res && !mask_is_3d && S <= 32 && h->ws.wo_pack && c.num_layers > 0) {
+      const size_t stride = c.num_layers > 1 ? h->plan.layers[1].wo - h->plan.layers[0].wo : 0;
+      bool regular = true;
+      for (int i = 0; i < c.num_layers; ++i) regular = regular && h->plan.layers[i].wo == h->plan.layers[0].wo + (size_t)i * stride;
+      if (regular) {
+        if (int e = k_pack_wo(h->P + h->plan.layers[0].wo, stride, h->wsp<bf16_t>(h->ws.wo_pack), h->wsp<bf16_t>(h->ws.wot_pack), d, c.num_layers, st))
+          return e;
+        h->wo_packed = true;
+      }
+    }
+    return 0;
+  };
+  bool early_done = false;
+  auto early_work = [&]() -> int {     // token-count independent launches (see gget_engine::presync_work)
+    if (early_done) return 0;
+    early_done = true;
+    if (int e = pack_o_weights()) return e;
+    if (h->presync_work) {
+      if (int e = h->presync_work(st)) return e;
+      h->presync_done = true;
+    }
+    return 0;
+  };
   if (mask_is_3d) {
     GGET_REQUIRE(mask != nullptr && c.kind == GGET_KIND_PRETRAIN, "a 3-D (packed) attention mask needs the pre-train model and a mask");
     if (int e = k_ranges_from_mask3d(mask, h->wsp<int32_t>(h->ws.key_lo), h->wsp<int32_t>(h->ws.key_hi), B, S, st)) return e;
@@ -1353,7 +1389,10 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
       if (!h->host_word) GGET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->host_word), 64, hipHostMallocDefault));
       if (int e = k_sum_lengths(h->wsp<int32_t>(h->ws.key_len), B, dst, st)) return e;
       GGET_HIP_CHECK(hipMemcpyAsync(h->host_word, dst, 4, hipMemcpyDeviceToHost, st));
-      GGET_HIP_CHECK(hipStreamSynchronize(st));
+      if (!h->count_event) GGET_HIP_CHECK(hipEventCreateWithFlags(&h->count_event, hipEventDisableTiming));
+      GGET_HIP_CHECK(hipEventRecord(h->count_event, st));
+      if (int e = early_work()) return e;                      // (runs on the device while the host waits for the 4 bytes)
+      GGET_HIP_CHECK(hipEventSynchronize(h->count_event));
       tc = *h->host_word;
     }
     const long t_rows = (tc + 63) / 64 * 64;
@@ -1364,6 +1403,7 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
       h->T = (int)t_rows;
     }
   }
+  if (int e = early_work()) return e;
   if (h->rope_range > 0.f && pos) {
     if (int e = k_rope_range_table(pos, h->wsp<float>(h->ws.rr_cos), h->wsp<float>(h->ws.rr_sin), h->wsp<int64_t>(h->ws.rr_ids), B, S,
                                    h->rope_range, c.rope_theta > 0.f ? c.rope_theta : 10000.0f, st))
@@ -1410,20 +1450,6 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
     h->raw_used = true;
     h->raw_next = nullptr;
   }
-  // S <= 32 without LayerScale / DropPath: the layers run the per-sample attention + o projection kernels (attention.hip), which read
-  // fragment-major copies of the o weights.  They are rebuilt at the start of EVERY forward (one launch, ~10 us: the bf16 weights are the
-  // caller's memory and change under AdamW, gget_sync_params or a caller's own writes); the backward of this forward uses the same copies.
-  h->wo_packed = false;
-  if (!h->plan.has_res && !mask_is_3d && S <= 32 && h->ws.wo_pack && c.num_layers > 0) {
-    const size_t stride = c.num_layers > 1 ? h->plan.layers[1].wo - h->plan.layers[0].wo : 0;
-    bool regular = true;
-    for (int i = 0; i < c.num_layers; ++i) regular = regular && h->plan.layers[i].wo == h->plan.layers[0].wo + (size_t)i * stride;
-    if (regular) {
-      if (int e = k_pack_wo(h->P + h->plan.layers[0].wo, stride, h->wsp<bf16_t>(h->ws.wo_pack), h->wsp<bf16_t>(h->ws.wot_pack), d, c.num_layers, st))
-        return e;
-      h->wo_packed = true;
-    }
-  }
   for (int i = 0; i < c.num_layers; ++i)
     if (int e = layer_forward(h, i, st)) return e;
   if (h->plan.has_res && ls_norm_fused()) return 0;   // (the last layer's residual kernel applied the final norm)
@@ -1445,16 +1471,24 @@ static int forward_pretrain_impl(gget_handle_t h, const int64_t* input_ids_dev, 
   const gget_config_t& c = h->cfg;
   StreamKScope sk_scope(h);
   h->fwd_valid = false;
-  if (int e = backbone_forward(h, tc_hint, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st, mask_is_3d, labels_dev))
-    return e;
   const Ws& w = h->ws;
-  const int T = h->TP, d = c.hidden_size, n = c.next_n_token, V = c.vocab_size;   // (capacities of the head: the padded token space)
+  const int d = c.hidden_size, n = c.next_n_token, V = c.vocab_size;
   const int Vp = (int)align_up(V, 64);
   int32_t* counts = h->wsp<int32_t>(w.counts);
-  if (int e = k_head_compact(labels_dev, T, n, h->wsp<int32_t>(w.cnt), h->wsp<int32_t>(w.m_off), h->wsp<int32_t>(w.l_off),
-                             counts, h->wsp<int32_t>(w.row_idx), h->wsp<int32_t>(w.sel_src), h->wsp<int32_t>(w.sel_label),
-                             h->wsp<int32_t>(w.sel_tok), st))
-    return e;
+  // row / cell compaction of the head: reads the labels only (padded coordinates), so it is handed to the backbone as token-count
+  // independent work (gget_engine::presync_work) - with GGET_TOKENS_AUTO it runs while the host waits for the count
+  auto head_compact = [&](hipStream_t s_) -> int {
+    return k_head_compact(labels_dev, B * S, n, h->wsp<int32_t>(w.cnt), h->wsp<int32_t>(w.m_off), h->wsp<int32_t>(w.l_off), counts,
+                          h->wsp<int32_t>(w.row_idx), h->wsp<int32_t>(w.sel_src), h->wsp<int32_t>(w.sel_label), h->wsp<int32_t>(w.sel_tok), s_);
+  };
+  h->presync_work = head_compact;
+  h->presync_done = false;
+  const int rc_bb = backbone_forward(h, tc_hint, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st, mask_is_3d, labels_dev);
+  h->presync_work = nullptr;       // (captures this frame)
+  if (rc_bb) return rc_bb;
+  const int T = h->TP;             // (capacities of the head: the padded token space)
+  if (!h->presync_done)
+    if (int e = head_compact(st)) return e;
   if (h->varlen)   // the selected rows live at their compact positions (sel_tok / sel_label keep the padded coordinates the loss weights need)
     // (full-logit inference - labels == NULL, generation - selects every cell of the padded grid: the cells of padded positions read a
     //  pad-token row, their logits are defined but meaningless exactly like the reference's, and no flag is raised)

@@ -204,7 +204,7 @@ def pmc_traffic(which="wgrad_layer", rows=8192):
     is a recorded one: it carries the digest of the kernel sources and the row count (T, = K of the weight-gradient launch) it was
     measured on and is reported as null when no record matches both."""
     import glob
-    pat = {"wgrad_layer": "r0*_wgrad_gemm_pmc*.json", "gateup": "r0*_gu_geglu_gemm_pmc*.json"}.get(which)
+    pat = {"wgrad_layer": "r0*_wgrad_gemm_pmc*.json", "gateup": "r0*_gu_geglu_gemm_pmc*.json", "dgrad_gu": "r0*_dxn2_gemm_pmc*.json"}.get(which)
     if pat is None:
         return None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pat)), reverse=True):

@@ -16,3 +16,4 @@ cp gpurun_out/r05_attn_oproj_pmc.json profiles/r05_attn_oproj_pmc.json
 cp gpurun_out/r05_attn_oproj_bench.txt profiles/r05_attn_oproj_bench.txt
 cp gpurun_out/r05_dh_pmc.json profiles/r05_dh_geglu_bwd_gemm_pmc_T$R.json 2>/dev/null
 cp gpurun_out/parity_errors.json profiles/r05_parity_errors.json 2>/dev/null
+cp gpurun_out/r05_dxn2_pmc.json profiles/r05_dxn2_gemm_pmc_T$R.json 2>/dev/null

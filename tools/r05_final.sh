@@ -6,6 +6,7 @@ ROWS=${1:-5696}
 bash tools/pmc_wgrad.sh r05 $ROWS > /dev/null && cp gpurun_out/r05_wgrad_pmc.json profiles/r05_wgrad_gemm_pmc_T$ROWS.json
 bash tools/pmc_gu.sh r05 $ROWS > /dev/null && cp gpurun_out/r05_gu_pmc.json profiles/r05_gu_geglu_gemm_pmc_T$ROWS.json
 bash tools/pmc_dh.sh r05 $ROWS > /dev/null
+bash tools/pmc_dxn2.sh r05 $ROWS > /dev/null && cp gpurun_out/r05_dxn2_pmc.json profiles/r05_dxn2_gemm_pmc_T$ROWS.json
 bash tools/pmc_attn_oproj.sh r05 > /dev/null
 python tools/attn_oproj_bench.py > gpurun_out/r05_attn_oproj_bench.txt 2>&1
 python bench.py > gpurun_out/r05_final_bench_default.json 2> gpurun_out/r05_final_bench_default.err

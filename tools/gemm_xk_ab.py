@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """A/B of the cross-block K-half form of the in-block K-split GEMM (gemm_ks_kernel<XK>, g_gemm_variant bit 11) on the N = d launches of the
-C1 step: dxn2 (NN, K = 6144), dxn1 (NN, K = 2304), down + residual (NT, K = 3072).  tools/ only.  usage: gemm_xk_ab.py [T]"""
+C1 step: dxn2 (NN, K = 6144), dxn1 (NN, K = 2304), down + residual (NT, K = 3072).  tools/ only.
+The variant is NOT in the tree: apply profiles/r05_cross_block_k_halves_experiment.diff first (without it both columns time the shipped kernel).
+usage: gemm_xk_ab.py [T]"""
 import ctypes as C, importlib, os, statistics, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -183,3 +183,67 @@ def test_c3_training_mode_dropouts_large_batch_and_eval_twin():
         record_error("c3_train_mode_dropouts_B32", f"{mode}: std of the 4-row group errors (max |err| {np.abs(g_).max():.2e})", float(g_.std(ddof=1)), float("nan"))
     assert res["eval"]["rel"] <= 1.5e-2 and res["train"]["rel"] <= 1.5e-2, res
     assert res["train"]["rel"] <= 2 * res["eval"]["rel"] + 2e-3, res
+
+
+def test_training_curve_tracks_the_oracle_over_many_steps():
+    """The SMTP loss CURVE, not single steps: 40 clip + AdamW steps (GGET_CURVE_STEPS) of the small pre-train model (d 256 / L 4, F = 13, V = 756,
+    the C1 tokenisation) over eight batches in rotation, HIP engine (bf16 compute copy, fp32 master, var-len rows) against the oracle's
+    fp32 training with the same AdamW restatement (bf16-rounded weights in its forward: the engine's cast point).  The two trajectories
+    see different rounding (activations, gradients) at every step, so they separate slowly; held: every step's loss within 1 % of the
+    oracle's to 2e-3 (measured 3.6e-4 at the worst step), the mean signed gap within 3 standard errors of zero (no drift), and the weight UPDATE
+    (final - initial master weights) of the two runs pointing the same way (cosine >= 0.95; element-wise Adam amplifies gradient rounding,
+    see the comment at the assert)."""
+    steps = int(os.environ.get("GGET_CURVE_STEPS", "40"))
+    B, S, F, V = 32, 32, 13, 756
+    spec = spec_mod.spec_from_size("mini", kind=spec_mod.KIND_PRETRAIN, vocab_size=V, stacked_feat=F, next_n_token=F)
+    state = weights_mod.make_state_dict(spec, seed=11, std=0.02)
+    batches = [synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=500 + i) for i in range(8)]
+    lr, b1, b2, eps, wd, clip = 1e-3, 0.9, 0.95, 1e-8, 0.1, 1.0
+    e = eng_mod.Engine(spec, max_tokens=B * S, max_batch=B)
+    e.load_state_dict(state)
+    p = O.to_params(state, torch.float32)
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(x) for k, x in p.items()}
+    got, want = [], []
+    for it in range(steps):
+        batch = batches[it % len(batches)]
+        b = tb({k: x for k, x in batch.items() if k != "lengths"})
+        loss = e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], num_tokens=int(batch["attention_mask"].sum()))
+        e.backward()
+        e.adamw_step(lr, b1, b2, eps, wd, clip)
+        got.append(float(loss))
+
+        def fn(q):
+            qb = {k: (x.detach().to(torch.bfloat16).float() - x.detach() + x) for k, x in q.items()}     # bf16 compute copy, straight-through
+            return O.pretrain_forward(spec, qb, b["input_ids"], b["attention_mask"], b["labels"])
+        out, grads = O.loss_and_grads(fn, p, "head1_loss")
+        with torch.no_grad():
+            O.adamw_step(p, grads, m, v, it + 1, lr, b1, b2, eps, wd, clip)
+        want.append(float(out["head1_loss"].detach()))
+    got, want = np.asarray(got), np.asarray(want)
+    rel = (got - want) / want
+    mean, sd = float(rel.mean()), float(rel.std(ddof=1))
+    # where the weights went: update = final - initial master weights, engine vs oracle (whole model and the worst tensor; tensors whose
+    # update is tiny against the model's largest are measured against that floor)
+    upd_g = {k: e.view(k, "master").float().cpu().numpy().ravel() - np.asarray(state[k], np.float32).ravel() for k in state}
+    upd_w = {k: p[k].detach().numpy().ravel() - np.asarray(state[k], np.float32).ravel() for k in state}
+    umax = max(float(np.linalg.norm(x)) for x in upd_w.values())
+    per = {k: float(np.linalg.norm(upd_g[k] - upd_w[k])) / max(float(np.linalg.norm(upd_w[k])), 1e-2 * umax) for k in state}
+    worst = max(per, key=per.get)
+    tot = float(np.sqrt(sum(float(np.sum((upd_g[k] - upd_w[k]) ** 2)) for k in state)) / np.sqrt(sum(float(np.sum(upd_w[k] ** 2)) for k in state)))
+    dot = sum(float(np.dot(upd_g[k], upd_w[k])) for k in state)
+    cos = dot / np.sqrt(sum(float(np.sum(upd_g[k] ** 2)) for k in state) * sum(float(np.sum(upd_w[k] ** 2)) for k in state))
+    rec = {"steps": steps, "loss_engine": got.tolist(), "loss_oracle": want.tolist(), "rel_gap_max_abs": float(np.abs(rel).max()),
+           "rel_gap_mean": mean, "rel_gap_std": sd, "loss_first": float(want[0]), "loss_last": float(want[-1]),
+           "weight_update_cosine_whole_model": float(cos), "weight_update_rel_l2_whole_model": tot, "weight_update_rel_l2_worst_tensor": per[worst], "worst_tensor": worst}
+    _dump("parity_stats_training_curve.json", rec)
+    record_error("pt_mini_training_curve", f"max_abs_rel_loss_gap_over_{steps}_steps", rec["rel_gap_max_abs"], 1e-2)
+    record_error("pt_mini_training_curve", "abs_mean_rel_loss_gap", abs(mean), 3 * sd / np.sqrt(steps) + 1e-5)
+    record_error("pt_mini_training_curve", "one_minus_weight_update_cosine", 1.0 - float(cos), 5e-2)
+    assert want[-1] < want[0] - 0.1, rec                         # the curve actually goes somewhere
+    assert rec["rel_gap_max_abs"] <= 2e-3, rec                   # (measured 3.6e-4)
+    assert abs(mean) <= 3 * sd / np.sqrt(steps) + 1e-5, rec
+    # Adam normalises every element's step to ~lr whatever the size of its gradient: elements whose gradient is at the level of the bf16
+    # rounding of the gradient array move in rounding-decided directions in BOTH runs (the reference's bf16 training has the same property
+    # against fp32), so the element-wise update differs by ~0.18 rel-L2 after 40 steps while the direction of the whole update agrees
+    assert cos >= 0.95 and tot <= 0.35, rec

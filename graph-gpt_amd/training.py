@@ -268,7 +268,9 @@ class GgetEngine:
                 elif self.abi_comm:   # RCCL through the C ABI on the side stream (works at world 1 too: a one-rank communicator)
                     e.allreduce_range_async(off, cnt, self.fp32_reduce, self._comm_stream)
                     self._pending.append(None)
-                elif self.world > 1:
+                elif self.world > 1 or (self.force_staged and dist.is_available() and dist.is_initialized()):
+                    # (a ONE-rank process group with GGET_FORCE_STAGED=1 still issues the collectives: the real backend - RCCL - runs the
+                    #  whole exchange schedule on a one-GPU box, tests/test_gpu_dist.py::test_torch_rccl_one_rank_group_through_staged_backward)
                     self._pending.append(all_reduce_bucket(e.grad_bf16, (off, cnt), self.pg, async_op=True,
                                                            fp32_accumulate=self.fp32_reduce))
                 else:  # single-rank dry run of the staged path (tests): the exchange is the identity
@@ -307,7 +309,8 @@ class GgetEngine:
     def describe_dp(self) -> Dict[str, Any]:
         """What the data-parallel exchange of this engine looks like (bench.py prints it on N > 1 lines)."""
         e = self.module._engine
-        backend = "none" if self.world == 1 else (dist.get_backend(self.pg) if dist.is_initialized() else "none")
+        live = dist.is_available() and dist.is_initialized() and (self.world > 1 or self.force_staged)
+        backend = dist.get_backend(self.pg) if live else "none"
         info = {"world": self.world, "backend": ("rccl-via-c-abi" if self.abi_comm else f"torch.distributed/{backend}"),
                 "n_buckets": len(e.buckets) if e is not None else None, "overlap_with_backward": bool(self.overlap),
                 "reduce_dtype": "fp32" if self.fp32_reduce else "bf16",

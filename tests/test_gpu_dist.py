@@ -154,6 +154,67 @@ def test_rccl_one_rank_communicator_through_staged_backward(monkeypatch):
         assert float(np.linalg.norm(got[2] - ref[2])) < 0.02 * upd
 
 
+_RCCL_ONE_RANK = r"""
+import importlib, json, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["GGET_REPO"])
+modeling = importlib.import_module("graph-gpt_amd.modeling")
+tr = importlib.import_module("graph-gpt_amd.training")
+synth = importlib.import_module("graph-gpt_amd.synth")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", 0))
+cfg = modeling.GraphGPTConfig(hidden_act="gelu", vocab_size=756, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
+                              num_attention_heads=2, max_position_embeddings=1024, causal_attention=False, stacked_feat=13, next_n_token=13)
+b = synth.make_pretrain_batch(B=8, S=32, F=13, V=756, seed=40)
+data = {k: torch.from_numpy(v).cuda() for k, v in b.items() if k != "lengths"}
+out = {}
+for staged in (0, 1):
+    os.environ["GGET_FORCE_STAGED"] = str(staged)
+    for fp32 in ((0,) if not staged else (0, 1)):
+        os.environ["GGET_DP_FP32_REDUCE"] = str(fp32)
+        model = modeling.GraphGPTPretrainBase(cfg, seed=1)
+        eng = tr.initialize(model, tr.OptimConfig(lr=1e-3, max_grad_norm=0.05))
+        losses = [float(tr.batch_training(data, eng)) for _ in range(3)]
+        torch.cuda.synchronize()
+        e = model._engine
+        out[f"{staged}{fp32}"] = {"losses": losses, "master_sum": float(e.master.double().abs().sum()), 
+                                  "dp": eng.describe_dp() if staged else None, "world": eng.world, "forced": eng.force_staged}
+        np.save(os.path.join(os.environ["GGET_OUT"], f"master_{staged}{fp32}.npy"), e.master.detach().cpu().numpy())
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_torch_rccl_one_rank_group_through_staged_backward(tmp_path):
+    """The DEFAULT data-parallel path (torch.distributed all-reduce of the flat bf16 gradient array, one collective per bucket on the side
+    stream behind per-bucket events) with the REAL backend: a one-rank NCCL (= RCCL) process group on cuda:0 and GGET_FORCE_STAGED=1, in
+    bf16 and with the fp32-accumulate option.  A one-rank all-reduce is the identity, so three steps must reproduce the monolithic
+    single-process steps (losses to 2e-6, master weights to 2 % of the update: fp32-atomic reductions differ between any two runs).
+    Own process: the process group must not leak into the other tests."""
+    import json
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "one_rank.py"
+    script.write_text(_RCCL_ONE_RANK)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               GGET_REPO=ROOT, GGET_OUT=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("GGET_DP_BACKEND", None)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    out = json.loads(line[len("RESULT "):])
+    ref = out["00"]
+    m0 = np.load(tmp_path / "master_00.npy")
+    for key in ("10", "11"):
+        got = out[key]
+        assert got["forced"] and got["world"] == 1
+        assert "nccl" in got["dp"]["backend"] or "rccl" in got["dp"]["backend"], got["dp"]
+        np.testing.assert_allclose(got["losses"], ref["losses"], rtol=2e-6)
+        m = np.load(tmp_path / f"master_{key}.npy")
+        assert float(np.linalg.norm(m - m0)) <= 2e-2 * 3 * 1e-3 * np.sqrt(m0.size), key     # (3 steps of lr 1e-3: |update| <= 3e-3 per element)
+
+
 def test_bf16_vs_fp32_bucket_reduction_drift_world8():
     """Bounds what a bf16 SUM all-reduce over 8 ranks costs against the fp32-accumulated reduction (GGET_DP_FP32_REDUCE=1):
     eight replicas' gradient sets (same weights, eight different batches) are produced on one GPU and summed (a) in a bf16

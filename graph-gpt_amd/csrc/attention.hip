@@ -346,6 +346,30 @@ __device__ __forceinline__ void unrope_acc(f32x16_t& a0, f32x16_t& a1, const Rop
   }
 }
 
+constexpr int kRopePitch = 36;      // floats per staged angle-table row (32 + 4: the lanes' 16-byte reads of 32 rows spread over the banks)
+// the same with the lane's angle-table pieces already in registers (rope_fetch): the per-sample backward requests them before its matrix
+// work - behind the MFMAs the position -> cos / sin chain was two dependent global round trips at the very end of the kernel, twice
+__device__ __forceinline__ void rope_fetch(const Rope& R, int pos, int hi, float4 (&c)[4], float4 (&sn)[4]) {
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int j0 = 8 * rr + 4 * hi;
+    c[rr] = *reinterpret_cast<const float4*>(R.cos_tab + (size_t)pos * 32 + j0);
+    sn[rr] = *reinterpret_cast<const float4*>(R.sin_tab + (size_t)pos * 32 + j0);
+  }
+}
+__device__ __forceinline__ void unrope_acc_pre(f32x16_t& a0, f32x16_t& a1, const float4 (&c)[4], const float4 (&sn)[4]) {
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const float cc[4] = {c[rr].x, c[rr].y, c[rr].z, c[rr].w}, ss[4] = {sn[rr].x, sn[rr].y, sn[rr].z, sn[rr].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = a0[4 * rr + e], up = a1[4 * rr + e];
+      a0[4 * rr + e] = lo * cc[e] + up * ss[e];
+      a1[4 * rr + e] = up * cc[e] - lo * ss[e];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Block = NW waves = NW consecutive 32-query tiles of one (batch, head); every 32-key K tile and V tile is brought into
 // LDS ONCE per block (K rotated on the way in when R is given) and shared by the NW waves: K as the A operand of
@@ -742,6 +766,10 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
   load_tile_coop<64>(qt, qb, 0, SL, pitch, lane, Rin, b);
   load_tile_coop<64>(dot_, dob, 0, SL, (size_t)d, lane, Rnone, b);
   const float nlse2 = -lse[((size_t)b * H + h) * S + min(l31, S - 1)] * kLog2e;
+  // the lane's angle-table pieces (dq / dk of row l31 are rotated back at the end of each half): requested here, ahead of the matrix
+  // work - at the point of use the position -> table chain is two dependent global round trips with nothing left to cover them
+  float4 rc[4], rs[4];
+  if (R.cos_tab) rope_fetch(R, rope_pos(R, b, min(l31, S - 1)), hi, rc, rs);
   if (hi == 0) lse_s[l31] = nlse2;
   __syncthreads();
   const unsigned bh = b * H + h;
@@ -779,7 +807,7 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
     a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 0, lane), ds0, a1, 0, 0, 0);
     a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 1, lane), ds1, a1, 0, 0, 0);
     if (qrow < SL) {
-      unrope_acc(a0, a1, R, rope_pos(R, b, qrow), hi);
+      if (R.cos_tab) unrope_acc_pre(a0, a1, rc, rs);
       store_t(dqkv + ((size_t)rb + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
     }
   }
@@ -816,7 +844,7 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
     dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 1, lane), s1, dk1, 0, 0, 0);
     if (krow < SL) {
       bf16_t* row = dqkv + ((size_t)rb + krow) * pitch + h * 64;
-      unrope_acc(dk0, dk1, R, rope_pos(R, b, krow), hi);
+      if (R.cos_tab) unrope_acc_pre(dk0, dk1, rc, rs);
       store_t(row + d, dk0, dk1, 1.f, hi);
       store_t(row + 2 * d, dv0, dv1, 1.f, hi);
     }
@@ -1160,12 +1188,29 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_bwd_kernel(const bf16_t* __
   unsigned char* kq = fb_lds + XB;
   float* dw_lds = reinterpret_cast<float*>(fb_lds + XB);
   float* stat = reinterpret_cast<float*>(fb_lds + XB + YB);         // [H][64]: -lse * log2(e) and -delta per query
+  float* rope_lds = stat + H * 64;                                  // cos [32][kRopePitch], sin [32][kRopePitch] of the sample's rows
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
   const int rb = row_base ? row_base[b] : b * S;
   const int SL = row_base ? key_len[b] : S;
   const int klen = key_len ? min(key_len[b], S) : S;
+  // Angle-table rows of the sample's 32 positions (phase C rotates dq and dk back): requested NOW (position, then its table piece: two
+  // dependent global round trips) and parked in LDS behind phase A; the unrotation at the end of phase C reads LDS.  Fetched at the
+  // point of use the chain sat exposed at the very end of the kernel, twice: 41.1 us per launch inside the step; requested at the top of
+  // phase C 39.3 us; this form: profiles/r05_step_experiments.txt item 12.
+  constexpr int RPC = (512 + NT - 1) / NT;       // 2 tables x 32 rows x 8 pieces of 16 bytes over the block's threads
+  float4 rope_piece[RPC];
+#pragma unroll
+  for (int i = 0; i < RPC; ++i) {
+    const int t = tid + i * NT;
+    rope_piece[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (R.cos_tab && t < 512) {
+      const int row = (t >> 3) & 31, q4 = t & 7;
+      const int pos = rope_pos(R, b, min(row, S - 1));
+      rope_piece[i] = *reinterpret_cast<const float4*>((t < 256 ? R.cos_tab : R.sin_tab) + (size_t)pos * 32 + q4 * 4);
+    }
+  }
   // var-len layout: the <= 63 pad rows behind the last sample belong to no workgroup; their gradient is zero (rmsnorm_bwd_kernel computed
   // exactly that from their zero inputs) and must read as zero in the o weight gradient (K = all rows) and the next RMSNorm backward
   if (row_base && b == B - 1)
@@ -1252,6 +1297,13 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_bwd_kernel(const bf16_t* __
 #pragma unroll
     for (int w = 0; w < H; ++w) sum += dw_lds[w * d + t];
     unsafeAtomicAdd(dw_accum + (size_t)(blockIdx.x % copies) * copy_stride + j, sum);
+  }
+  if (R.cos_tab) {     // (its own LDS region; read behind phase B's barriers)
+#pragma unroll
+    for (int i = 0; i < RPC; ++i) {
+      const int t = tid + i * NT;
+      if (t < 512) *reinterpret_cast<float4*>(rope_lds + ((t < 256 ? 0 : 32) + ((t >> 3) & 31)) * kRopePitch + (t & 7) * 4) = rope_piece[i];
+    }
   }
   __syncthreads();     // the partials are consumed: region Y takes the K / Q tiles
   unsigned char* kt = kq + h * 8192;
@@ -1372,7 +1424,15 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_bwd_kernel(const bf16_t* __
       a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 0, lane), ds0, a1, 0, 0, 0);
       a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt, 1, 1, lane), ds1, a1, 0, 0, 0);
       if (qrow < SL) {
-        unrope_acc(a0, a1, R, rope_pos(R, b, qrow), hi);
+        if (R.cos_tab) {
+          float4 rc[4], rs[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            rc[rr] = *reinterpret_cast<const float4*>(rope_lds + l31 * kRopePitch + 8 * rr + 4 * hi);
+            rs[rr] = *reinterpret_cast<const float4*>(rope_lds + (32 + l31) * kRopePitch + 8 * rr + 4 * hi);
+          }
+          unrope_acc_pre(a0, a1, rc, rs);
+        }
         store_t(dqkv + ((size_t)rb + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
       }
     }
@@ -1409,7 +1469,15 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_bwd_kernel(const bf16_t* __
       dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 1, lane), s1, dk1, 0, 0, 0);
       if (krow < SL) {
         bf16_t* row = dqkv + ((size_t)rb + krow) * pitch + h * 64;
-        unrope_acc(dk0, dk1, R, rope_pos(R, b, krow), hi);
+        if (R.cos_tab) {
+          float4 rc[4], rs[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            rc[rr] = *reinterpret_cast<const float4*>(rope_lds + l31 * kRopePitch + 8 * rr + 4 * hi);
+            rs[rr] = *reinterpret_cast<const float4*>(rope_lds + (32 + l31) * kRopePitch + 8 * rr + 4 * hi);
+          }
+          unrope_acc_pre(dk0, dk1, rc, rs);
+        }
         store_t(row + d, dk0, dk1, 1.f, hi);
         store_t(row + 2 * d, dv0, dv1, 1.f, hi);
       }
@@ -2680,7 +2748,8 @@ static int launch_attn_oproj_bwd(const void* dxn, const void* x_mid, const void*
                                  const Drop& D, int t_rows, hipStream_t st) {
   constexpr int d = H * 64, PITCH = (d + kOPad) * 2;
   constexpr int XB = 32 * PITCH > H * 4096 ? 32 * PITCH : H * 4096, YB = H * 8192 > H * d * 4 ? H * 8192 : H * d * 4;
-  constexpr int lds = XB + YB + H * 64 * 4;
+  constexpr int lds = XB + YB + H * 64 * 4 + 2 * 32 * kRopePitch * 4;      // + the sample's cos / sin rows (attn_oproj_bwd_kernel)
+  static_assert(lds <= 160 * 1024, "per-sample backward: LDS");
   static bool attr = false;
   if (!attr) {
     GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_oproj_bwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));

@@ -1813,13 +1813,24 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
   const Ws& w = h->ws;
   const int d = c.hidden_size;
   float* s32 = h->wsp<float>(w.scratch32);
-  GGET_HIP_CHECK(hipMemsetAsync(s32, 0, h->plan.n_scratch32 * 4, st));
+  // everything the backward needs cleared, in ONE launch (five runtime fill kernels of 4 - 15 us each before): the fp32 accumulators of the
+  // small parameters, the gradient of the final-norm output (the head scatters the selected rows into it), ...
+  GgetZeroRanges zr;
+  zr.n = 0;
+  zr.add(s32, (size_t)h->plan.n_scratch32 * 4);
   bf16_t* dhid = h->wsp<bf16_t>(w.dxb);  // gradient w.r.t. the final-norm output
-  GGET_HIP_CHECK(hipMemsetAsync(dhid, 0, (size_t)h->T * d * 2, st));
+  zr.add(dhid, (size_t)h->T * d * 2);
   if (h->varlen && h->T > h->tc)   // var-len layout: the <= 63 pad rows behind the last sample belong to no attention problem - their
     // q|k|v gradient rows are written by nobody and must read as zeros in the weight gradients (K = T) and the dgrad below them
-    GGET_HIP_CHECK(hipMemsetAsync(h->wsp<bf16_t>(w.dqkv) + (size_t)h->tc * 3 * d, 0, (size_t)(h->T - h->tc) * 3 * d * 2, st));
+    zr.add(h->wsp<bf16_t>(w.dqkv) + (size_t)h->tc * 3 * d, (size_t)(h->T - h->tc) * 3 * d * 2);
   int T = h->TP;   // the head works in the padded token index space (capacities only: the counts are on the device)
+  if (c.kind == GGET_KIND_PRETRAIN) {
+    // ... the scatter target of the lm_head dgrad and the split-K slabs of its weight gradient (both only ever written by the launches below)
+    if (h->plan.has_ntp && head_scatter_fused())
+      zr.add(h->wsp<bf16_t>(w.dP), (size_t)(h->varlen ? h->T : T) * c.next_n_token * d * 2);
+    zr.add(h->wsp<float>(w.lm_slab), (size_t)kLmSplit * c.vocab_size * d * sizeof(float));
+  }
+  if (int e = k_zero_ranges(zr, st)) return e;
   if (c.kind == GGET_KIND_PRETRAIN) {
     const int n = c.next_n_token, V = c.vocab_size, Vp = (int)align_up(V, 64);
     int32_t* counts = h->wsp<int32_t>(w.counts);
@@ -1828,8 +1839,7 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
     // With n_token_proj the rows of dHl are scattered into dP (row sel_src[i] of the [M n, d] view) - fused into the GEMM's epilogue
     // (GemmProblem::c_rows), so dHl is never materialised and the separate scatter launch disappears; dP is cleared first.
     const bool fuse_sc = h->plan.has_ntp && head_scatter_fused();
-    if (fuse_sc) {
-      GGET_HIP_CHECK(hipMemsetAsync(h->wsp<bf16_t>(w.dP), 0, (size_t)(h->varlen ? h->T : T) * n * d * 2, st));
+    if (fuse_sc) {      // (dP was cleared by the launch above)
       if (int e = gemm_nn(dlog, h->P + h->plan.lm, h->wsp<bf16_t>(w.dP), T * n, d, Vp, Vp, d, d, counts + 1, st, h->wsp<int32_t>(w.sel_src)))
         return e;
     } else if (int e = gemm_nn(dlog, h->P + h->plan.lm, h->wsp<bf16_t>(w.dHl), T * n, d, Vp, Vp, d, d, counts + 1, st)) return e;   // K = Vp: zero pads on both sides
@@ -1838,8 +1848,7 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
       // Slices that fall beyond a short Lm write nothing, so the slabs are cleared first.
       float* slabs = h->wsp<float>(w.lm_slab);
       const long slab = (long)V * d;
-      GGET_HIP_CHECK(hipMemsetAsync(slabs, 0, (size_t)kLmSplit * slab * sizeof(float), st));
-      GemmGroup g;
+      GemmGroup g;     // (the slabs were cleared by the launch at the top)
       memset(&g, 0, sizeof(g));
       g.count = 1;
       g.p[0] = GemmProblem{dlog, h->wsp<bf16_t>(w.Hl), slabs, nullptr, V, d, T * n, Vp, d, d, nullptr, counts + 1, 0, 0, slab};

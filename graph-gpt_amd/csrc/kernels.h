@@ -111,6 +111,14 @@ int k_grad_sqnorm_chunks(const void* g, const GgetSqChunk* chunks_dev, int nchun
 int k_adamw(float* master, float* m, float* v, const void* grad, void* param, size_t n, float lr, float beta1, float beta2,
             float eps, float wd, int step, float max_norm, float grad_scale, const float* sqnorm, float* gnorm_out,
             hipStream_t st, bool skip_nonfinite = false);   // skip_nonfinite: leave everything untouched when the gradient norm is inf / NaN
+constexpr int kZeroRanges = 6;
+struct GgetZeroRanges {
+  void* ptr[kZeroRanges];
+  size_t bytes[kZeroRanges];
+  int n;
+  void add(void* p, size_t b) { if (b && n < kZeroRanges) { ptr[n] = p; bytes[n] = b; ++n; } }
+};
+int k_zero_ranges(const GgetZeroRanges& R, hipStream_t st);   // every range cleared by one launch (kernels.hip)
 int k_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st);
 int k_slab_reduce(const float* slabs, long slab_stride, int nslab, void* dst, size_t n, hipStream_t st, bool f32_out = false);  // dst: bf16, or fp32 (overwritten)
 int k_convert_segments(const float* scratch, void* grads, const GgetSegment* segs_dev, int nseg, hipStream_t st);

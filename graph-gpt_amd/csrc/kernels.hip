@@ -2524,6 +2524,34 @@ int k_adamw(float* master, float* m, float* v, const void* grad, void* param, si
   return 0;
 }
 
+// Up to kZeroRanges device ranges cleared by ONE launch (the backward's accumulators, the head's scatter targets and split-K slabs: five
+// hipMemsetAsync calls = five runtime fill kernels of 4 - 15 us each at the start of every backward before).  16-byte non-temporal stores
+// over the aligned body of every range (plain stores: the non-temporal form ran at 4.4 TB/s, the runtime's fill at 7.8), byte stores for what is left at its ends.
+__global__ void __launch_bounds__(kBlock) zero_ranges_kernel(GgetZeroRanges R) {
+  const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x, stride = (size_t)gridDim.x * kBlock;
+  for (int r = 0; r < R.n; ++r) {
+    unsigned char* p = reinterpret_cast<unsigned char*>(R.ptr[r]);
+    const size_t bytes = R.bytes[r];
+    const size_t head = std::min<size_t>(bytes, (16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15);
+    const size_t nv = (bytes - head) >> 4, tail0 = head + (nv << 4);
+    uint4* v = reinterpret_cast<uint4*>(p + head);
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    size_t i = tid;
+    for (; i + 3 * stride < nv; i += 4 * stride) { v[i] = z; v[i + stride] = z; v[i + 2 * stride] = z; v[i + 3 * stride] = z; }
+    for (; i < nv; i += stride) v[i] = z;
+    if (tid < head) p[tid] = 0;
+    if (tid < bytes - tail0) p[tail0 + tid] = 0;
+  }
+}
+int k_zero_ranges(const GgetZeroRanges& R, hipStream_t st) {
+  size_t total = 0;
+  for (int r = 0; r < R.n; ++r) total += R.bytes[r];
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3(grid_for((long)(total / 64 + 1), kBlock, 8192)), dim3(kBlock), 0, st, R);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
 int k_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t st) {
   hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for((long)(n / 4), kBlock, 4096)), dim3(kBlock), 0, st, src,
                      (bf16_t*)dst, n);

@@ -380,8 +380,11 @@ __device__ __forceinline__ void store_tile(f32x4_t (&acc)[MI][NJ], const GemmPro
     // their values.
     constexpr int IB = MI * NP > 8 ? 2 : MI;
     static_assert(MI % IB == 0, "RoPE epilogue: row blocks per batch");
+    // a wave whose columns all lie in the v block (a third of the q|k|v tiles) has nothing to rotate: it skips the position and table
+    // reads as well (wave-uniform; the reads were unconditional: 16 KiB of cos / sin rows per wave and tile)
+    const bool any_live = (ILV ? nw - chan0 : nw) < P.rope_cols;
 #pragma unroll
-    for (int i0 = 0; i0 < MI; i0 += IB) {
+    for (int i0 = 0; i0 < MI && any_live; i0 += IB) {
       int pos[IB];
       if (P.rope_pos) {   // (the test outside the loop: inside it every position load sat behind its own branch and vmcnt(0))
 #pragma unroll

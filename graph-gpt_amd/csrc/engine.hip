@@ -191,7 +191,7 @@ struct Ws {
   std::vector<LayerWs> lw;
   uint64_t rstd_f, hidden;
   uint64_t dxa, dxb, dxc, dxn, dqkv, dattn, dgu, dh, delta, dq_acc, dscaled, dscaled2;
-  uint64_t scratch32, loss_sum, sqnorm, counts, segs, emb_sort, emb_cnt, emb_slab, wg32, lm_slab;
+  uint64_t scratch32, loss_sum, loss_part, sqnorm, counts, segs, emb_sort, emb_cnt, emb_slab, wg32, lm_slab;
   uint64_t sq_chunks, sq_tiles;   // gradient-norm shortcut: chunk table of everything but the layers' weight matrices; per-tile sums of those
   // pre-train head
   uint64_t cnt, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
@@ -262,6 +262,7 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.dscaled2 = pl.has_res ? b.take(T * d * 2) : 0;
   w.scratch32 = b.take(pl.n_scratch32 * 4);
   w.loss_sum = b.take(256);
+  w.loss_part = b.take(2048 * sizeof(float));   // one partial loss sum per block of the cross-entropy launch
   w.sqnorm = b.take(k_grad_sqnorm_ws_bytes());
   w.sq_chunks = b.take(1024 * sizeof(GgetSqChunk));
   w.sq_tiles = b.take((uint64_t)c.num_layers * kSqTilesPerLayer * sizeof(float));
@@ -1539,7 +1540,7 @@ static int forward_pretrain_impl(gget_handle_t h, const int64_t* input_ids_dev, 
     const float base = 1.0f / (float)((long)B * S * n);  // dLM normaliser, modeling_pretrain.py:230-236
     if (int e = k_ce_fwd_bwd(h->wsp<bf16_t>(w.logits), Vp, h->wsp<int32_t>(w.sel_label), h->wsp<int32_t>(w.sel_tok),
                              sample_wgt_dev, S, counts + 1, T * n, V, h->wsp<float>(w.loss_sum), h->wsp<bf16_t>(w.dlogits),
-                             base, mean_rows, loss_dev, st, mean_rows ? h->focal_gamma : 0.f))   // (the dLM-weighted loss has no focal form)
+                             base, mean_rows, loss_dev, st, mean_rows ? h->focal_gamma : 0.f, h->wsp<float>(w.loss_part), 2048))   // (the dLM-weighted loss has no focal form)
       return e;
     if (h->varlen && h->tc_from_caller && loss_dev)
       if (int e = k_poison_loss(h->wsp<int32_t>(w.vl_status), loss_dev, st)) return e;
@@ -2142,6 +2143,8 @@ extern "C" int gget_debug_set(int key, int value) {
     case 9: g_head_tile = value; return 0;
     case 10: g_attn_oproj_off = value; return 0;
     case 11: g_ls_norm_bwd_wide = value; return 0;
+    case 13: k_set_rms_wide(value); return 0;
+    case 14: k_set_ce_parts(value); return 0;
   }
   gget_set_error("debug_set: unknown key %d", key);
   return 2;

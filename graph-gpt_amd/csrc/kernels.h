@@ -43,6 +43,8 @@ constexpr int kEmbDenseSplit = 8;   // K slices (fp32 slabs of V*d each) of that
 int k_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int T, int d, float eps, hipStream_t st);
 // dw_accum: fp32 [copies][copy_stride] accumulators (see GgetSegment); copies = 1 for a plain vector
 void k_set_deterministic(int on);   // reproducible summation order of the RMSNorm weight gradients (gget_debug_set key 4)
+void k_set_rms_wide(int on);   // 1 (default): short RMSNorm backward launches run one 16-wave block per CU (kernels.hip rmsnorm_bwd_kernel)
+void k_set_ce_parts(int on);    // 1 (default): ce_rows_kernel leaves one partial loss sum per block where the caller has the slots (no same-address atomics)
 int k_get_deterministic();
 int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
                   float* dw_accum, int T, int d, hipStream_t st, int copies = 1, uint64_t copy_stride = 0);
@@ -78,7 +80,8 @@ int k_gather_rows(const void* src, const int32_t* idx, const int32_t* count, voi
                   hipStream_t st);
 int k_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const int32_t* sel_tok, const float* sample_wgt, int S,
                  const int32_t* n_rows_dev, int n_rows_cap, int V, float* loss_sum, void* dlogits, float scale_base,
-                 int mean_over_rows, float* loss_out, hipStream_t st, float focal_gamma = 0.f);
+                 int mean_over_rows, float* loss_out, hipStream_t st, float focal_gamma = 0.f, float* loss_part = nullptr,
+                 int loss_part_cap = 0);   // loss_part: optional [loss_part_cap >= 2048] floats - one partial loss sum per block instead of atomics
 int k_score_fwd(const void* hidden, const int32_t* pool_row, const void* w, const void* bias, float* logits,
                 void* pooled_h, int B, int C, int d, hipStream_t st);
 // token-level head (loss_type = "token_ce"): score on every row (fp32 logits rounded as bf16), cross-entropy with ignore_index -100

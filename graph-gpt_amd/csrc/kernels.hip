@@ -6,6 +6,8 @@
 #include "kernels.h"
 
 static int g_deterministic = getenv("GGET_DETERMINISTIC") ? atoi(getenv("GGET_DETERMINISTIC")) : 0;   // k_set_deterministic
+static int g_rms_bwd_wide = getenv("GGET_RMS_WIDE") ? atoi(getenv("GGET_RMS_WIDE")) : 1;   // k_set_rms_wide (gget_debug_set key 13)
+static int g_ce_parts = getenv("GGET_CE_PARTS") ? atoi(getenv("GGET_CE_PARTS")) : 1;         // k_set_ce_parts (gget_debug_set key 14)
 static float* g_det_scratch = nullptr;
 static size_t g_det_bytes = 0;
 
@@ -521,6 +523,133 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_bwd_kernel(const bf16_t* __res
   }
 }
 
+// SHORT launches (round 5).  The step's shapes are short - T = 5 696 rows at the headline, 22 rows per CU: with 4-wave blocks of 4 rows per
+// wave only ~6 waves per CU had loads in flight (25 KB per CU where HBM latency x bandwidth wants ~47 KB: 3.2 TB/s), and fewer rows per wave
+// multiplied the per-block atomics of the weight gradient.  Here: ONE block of NW = 16 waves per CU, the rows cut into contiguous ranges
+// per block and dealt round-robin to its waves (1 - 2 rows each: everything a CU will read, 72 KB, is requested at once), one block-level
+// reduction of the weight-gradient partials = 256 x d atomics per launch instead of 356 x d.  To fit 16 waves per CU (<= 128 registers)
+// a row's operands stay PACKED in two register sets (the row being worked on, the row in flight) and are unpacked where they are used -
+// once for the reductions, once more for the result; same expressions, same bits as rmsnorm_bwd_kernel.
+template <int NCH, int NW>
+__global__ void __launch_bounds__(NW * 64) rmsnorm_bwd_wide_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                  const bf16_t* __restrict__ w, const float* __restrict__ rstd_in,
+                                                                  const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                                                  float* __restrict__ dw_accum, int T, int d, int copies,
+                                                                  uint64_t copy_stride, float* __restrict__ dw_part) {
+  extern __shared__ float dw_lds[];  // [NW][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = d >> 3;
+  float dwp[NCH][8];
+  uint4 wp[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dwp[i][e] = 0.f;
+    wp[i] = c < nchunk ? ldg16(w + c * 8) : make_uint4(0, 0, 0, 0);
+  }
+  struct RowRegs { uint4 x[NCH], d[NCH], r[NCH]; float rs; };
+  RowRegs ra, rb;
+  const unsigned lo = lane * 8;     // (32-bit lane offsets on a wave-uniform row base: the addresses stay out of the vector registers)
+  auto fetch = [&](int r0, RowRegs& q) {
+    const int r = __builtin_amdgcn_readfirstlane(r0);
+    const size_t rbase = (size_t)r * d;
+    const bf16_t *xrow = x + rbase, *dyrow = dy + rbase, *rrow = dres ? dres + rbase : nullptr;
+    q.rs = rstd_in[r];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        q.x[i] = ldg16(xrow + lo + i * 512);
+        q.d[i] = ldg16(dyrow + lo + i * 512);
+        q.r[i] = rrow ? ldg16(rrow + lo + i * 512) : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  // (`keep4`: an empty asm the compiler must assume rewrites the packed words, so that it unpacks them AGAIN where they are used instead
+  //  of keeping the floats of the first pass alive across the reduction / the loop - that is what spilled)
+  auto keep4 = [](uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); };
+  auto work = [&](int row0, RowRegs& q) {
+    const int row = __builtin_amdgcn_readfirstlane(row0);
+    const float rs = q.rs;
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        float xv[8], dv[8], wv[8];
+        keep4(wp[i]);
+        unpack8(q.x[i], xv);
+        unpack8(q.d[i], dv);
+        unpack8(wp[i], wv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = xv[e] * rs;
+          const float g = dv[e] * wv[e];
+          dot += g * xh;
+          dwp[i][e] += dv[e] * xh;
+        }
+      }
+    }
+    dot = wave_sum(dot) / (float)d;
+    bf16_t* dxrow = dx + (size_t)row * d;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        float xv[8], dv[8], wv[8], res[8], o[8];
+        keep4(q.x[i]);
+        keep4(q.d[i]);
+        keep4(wp[i]);
+        unpack8(q.x[i], xv);
+        unpack8(q.d[i], dv);
+        unpack8(wp[i], wv);
+        unpack8(q.r[i], res);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = xv[e] * rs;
+          float g = dv[e] * wv[e];
+          asm volatile("" : "+v"(g));   // (the ROUNDED product, as in rmsnorm_bwd_kernel where it is shared with the first pass: without this
+                                        //  the compiler may fuse THIS multiply into the subtraction instead of xh * dot - single bf16 flips)
+          o[e] = res[e] + rs * (g - xh * dot);
+        }
+        stg16(dxrow + lo + i * 512, pack8(o));
+      }
+    }
+  };
+  // block b owns rows [b T / G, (b + 1) T / G), wave w of it rows w, w + NW, ... of the range: every CU the same share
+  int row = (int)((long)blockIdx.x * T / gridDim.x) + wave;
+  const int r_end = (int)((long)(blockIdx.x + 1) * T / gridDim.x);
+  if (row < r_end) fetch(row, ra);
+  while (row < r_end) {
+    if (row + NW < r_end) fetch(row + NW, rb);
+    work(row, ra);
+    row += NW;
+    if (row >= r_end) break;
+    if (row + NW < r_end) fetch(row + NW, ra);
+    work(row, rb);
+    row += NW;
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {   // (plane layout of the partials: see rmsnorm_bwd_kernel)
+      *reinterpret_cast<float4*>(dw_lds + wave * d + c * 4) = make_float4(dwp[i][0], dwp[i][1], dwp[i][2], dwp[i][3]);
+      *reinterpret_cast<float4*>(dw_lds + wave * d + (d >> 1) + c * 4) = make_float4(dwp[i][4], dwp[i][5], dwp[i][6], dwp[i][7]);
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < d; t += NW * 64) {
+    const int hd = d >> 1, pl = t >= hd ? 1 : 0, ix = t - pl * hd;
+    const int j = (ix >> 2) * 8 + pl * 4 + (ix & 3);
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; q += 4) s += (dw_lds[q * d + t] + dw_lds[(q + 1) * d + t]) + (dw_lds[(q + 2) * d + t] + dw_lds[(q + 3) * d + t]);
+    if (dw_part) dw_part[(size_t)blockIdx.x * d + j] = s;
+    else unsafeAtomicAdd(dw_accum + (size_t)(blockIdx.x % copies) * copy_stride + j, s);
+  }
+}
+
 // reproducible mode (k_set_deterministic): dst[j] += part[0][j] + part[1][j] + ... in block order (one thread per column)
 // A fixed order, not the sequential one: the rows are cut into segments of `per` (one block each), the four waves of a block interleave a
 // segment's rows and every lane keeps 8 running sums (32 coalesced row reads in flight per block); lane sums, wave sums and - in a
@@ -972,7 +1101,8 @@ __global__ void __launch_bounds__(kBlock) ce_rows_kernel(const bf16_t* __restric
                                                          const float* __restrict__ sample_wgt, int S,
                                                          const int32_t* __restrict__ n_rows_dev, int n_rows_cap, int V,
                                                          float* __restrict__ loss_sum, bf16_t* __restrict__ dlogits,
-                                                         float scale_base, int mean_over_rows, float focal_gamma) {
+                                                         float scale_base, int mean_over_rows, float focal_gamma,
+                                                         float* __restrict__ loss_part) {
   __shared__ float part[kBlock / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_rows = min(n_rows_cap, n_rows_dev ? *n_rows_dev : n_rows_cap);
@@ -1044,14 +1174,30 @@ __global__ void __launch_bounds__(kBlock) ce_rows_kernel(const bf16_t* __restric
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int i = 0; i < kBlock / 64; ++i) s += part[i];
-    if (s != 0.f) unsafeAtomicAdd(loss_sum, s);
+    // (one atomic per block on ONE address: 2048 of them cost the headline launch 13 of its 38 us - the engine hands in a slot per block)
+    if (loss_part) loss_part[blockIdx.x] = s;
+    else if (s != 0.f) unsafeAtomicAdd(loss_sum, s);
   }
 }
 
-__global__ void finalize_loss_kernel(const float* loss_sum, const int32_t* n_rows_dev, float scale_base,
-                                     int mean_over_rows, float* loss_out) {
-  const float sc = mean_over_rows ? (*n_rows_dev > 0 ? 1.0f / (float)(*n_rows_dev) : 0.f) : scale_base;
-  loss_out[0] = loss_sum[0] * sc;
+// loss_part != nullptr: the blocks of ce_rows_kernel left one partial sum each (n_part of them) - summed here in a fixed order, the total
+// also goes to loss_sum[0] (what the atomics of the other form accumulate)
+__global__ void __launch_bounds__(256) finalize_loss_kernel(float* loss_sum, const int32_t* n_rows_dev, float scale_base, int mean_over_rows,
+                                                            float* loss_out, const float* __restrict__ loss_part, int n_part) {
+  __shared__ float red[4];
+  if (loss_part) {
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n_part; i += 256) a += loss_part[i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_sum[0] = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && loss_out) {
+    const float sc = mean_over_rows ? (*n_rows_dev > 0 ? 1.0f / (float)(*n_rows_dev) : 0.f) : scale_base;
+    loss_out[0] = loss_sum[0] * sc;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2044,7 +2190,27 @@ int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rst
     }
     part = g_det_scratch;
   }
-  if (d <= 1024)
+  // short launches (<= 4 rows per wave of a 16-wave block per CU): the one-block-per-CU form (kernel comment); GGET_RMS_WIDE=0 / gget_debug_set(13, 0)
+  // = the 4-wave blocks everywhere
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    GGET_HIP_CHECK(hipGetDevice(&dev));
+    GGET_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  int wgrid = grid;
+  if (d <= 1024 && g_rms_bwd_wide && T <= n_cu * 16 * 4) {
+    wgrid = (T + 15) / 16 < n_cu ? (T + 15) / 16 : n_cu;
+    static bool attr_done = false;
+    if (!attr_done) {
+      GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rmsnorm_bwd_wide_kernel<2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1024 * 4));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((rmsnorm_bwd_wide_kernel<2, 16>), dim3(wgrid), dim3(1024), 16 * d * sizeof(float), st, (const bf16_t*)dy,
+                       (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_accum, T, d, copies, copy_stride, part);
+  } else if (d <= 1024)
     hipLaunchKernelGGL(rmsnorm_bwd_kernel<2>, dim3(grid), dim3(kBlock), 4 * d * sizeof(float), st, (const bf16_t*)dy,
                        (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_accum, T, d, copies, copy_stride, part);
   else
@@ -2052,9 +2218,9 @@ int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rst
                        (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_accum, T, d, copies, copy_stride, part);
   if (part) {
     constexpr int kPer = 64;
-    const int nseg = (grid + kPer - 1) / kPer;
+    const int nseg = (wgrid + kPer - 1) / kPer;
     float* seg = part + (size_t)4096 * d;
-    hipLaunchKernelGGL(ordered_colsum_kernel, dim3((d + 63) / 64, nseg), dim3(kBlock), 0, st, part, grid, d, kPer, seg, 0);
+    hipLaunchKernelGGL(ordered_colsum_kernel, dim3((d + 63) / 64, nseg), dim3(kBlock), 0, st, part, wgrid, d, kPer, seg, 0);
     hipLaunchKernelGGL(ordered_colsum_kernel, dim3((d + 63) / 64, 1), dim3(kBlock), 0, st, seg, nseg, d, nseg, dw_accum, 1);
   }
   GGET_LAUNCH_CHECK();
@@ -2062,6 +2228,8 @@ int k_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rst
 }
 
 void k_set_deterministic(int on) { g_deterministic = on; }
+void k_set_rms_wide(int on) { g_rms_bwd_wide = on; }
+void k_set_ce_parts(int on) { g_ce_parts = on; }
 int k_get_deterministic() { return g_deterministic; }
 
 int k_rope(void* qkv, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, int T, int S, int H,
@@ -2314,21 +2482,26 @@ int k_gather_rows(const void* src, const int32_t* idx, const int32_t* count, voi
 
 int k_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const int32_t* sel_tok, const float* sample_wgt, int S,
                  const int32_t* n_rows_dev, int n_rows_cap, int V, float* loss_sum, void* dlogits, float scale_base,
-                 int mean_over_rows, float* loss_out, hipStream_t st, float focal_gamma) {
-  GGET_HIP_CHECK(hipMemsetAsync(loss_sum, 0, sizeof(float), st));
+                 int mean_over_rows, float* loss_out, hipStream_t st, float focal_gamma, float* loss_part, int loss_part_cap) {
+  const bool vec = (ld % 8) == 0 && ((uintptr_t)logits & 15) == 0 && ((uintptr_t)dlogits & 15) == 0 && getenv("GGET_CE_GENERIC") == nullptr;
+  const dim3 grid(grid_for(n_rows_cap, 4 * 8, 2048));
+  // per-block partial sums instead of same-address atomics: the row-in-registers kernels, when the caller has a slot per block
+  // (gget_debug_set(14, 0): atomics everywhere)
+  const bool parts = g_ce_parts && loss_part && n_rows_cap > 0 && vec && ld <= 2048 && (int)grid.x <= loss_part_cap;
+  if (!parts) GGET_HIP_CHECK(hipMemsetAsync(loss_sum, 0, sizeof(float), st));
   if (n_rows_cap > 0) {
-    const bool vec = (ld % 8) == 0 && ((uintptr_t)logits & 15) == 0 && ((uintptr_t)dlogits & 15) == 0 && getenv("GGET_CE_GENERIC") == nullptr;
+    float* lp = parts ? loss_part : nullptr;
 #define GGET_CE_ARGS (const bf16_t*)logits, ld, labels, sel_tok, sample_wgt, S, n_rows_dev, n_rows_cap, V, loss_sum, \
                      (bf16_t*)dlogits, scale_base, mean_over_rows, focal_gamma
-    const dim3 grid(grid_for(n_rows_cap, 4 * 8, 2048));
-    if (vec && ld <= 512) hipLaunchKernelGGL(ce_rows_kernel<1>, grid, dim3(kBlock), 0, st, GGET_CE_ARGS);
-    else if (vec && ld <= 1024) hipLaunchKernelGGL(ce_rows_kernel<2>, grid, dim3(kBlock), 0, st, GGET_CE_ARGS);
-    else if (vec && ld <= 2048) hipLaunchKernelGGL(ce_rows_kernel<4>, grid, dim3(kBlock), 0, st, GGET_CE_ARGS);
+    if (vec && ld <= 512) hipLaunchKernelGGL(ce_rows_kernel<1>, grid, dim3(kBlock), 0, st, GGET_CE_ARGS, lp);
+    else if (vec && ld <= 1024) hipLaunchKernelGGL(ce_rows_kernel<2>, grid, dim3(kBlock), 0, st, GGET_CE_ARGS, lp);
+    else if (vec && ld <= 2048) hipLaunchKernelGGL(ce_rows_kernel<4>, grid, dim3(kBlock), 0, st, GGET_CE_ARGS, lp);
     else hipLaunchKernelGGL(ce_fwd_bwd_kernel, grid, dim3(kBlock), 0, st, GGET_CE_ARGS);
 #undef GGET_CE_ARGS
   }
-  if (loss_out) hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(1), 0, st, loss_sum, n_rows_dev, scale_base,
-                                   mean_over_rows, loss_out);
+  if (loss_out || parts)
+    hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(256), 0, st, loss_sum, n_rows_dev, scale_base, mean_over_rows, loss_out,
+                       parts ? loss_part : nullptr, (int)grid.x);
   GGET_LAUNCH_CHECK();
   return 0;
 }

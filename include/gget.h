@@ -346,7 +346,10 @@ int gget_op_gemm_grouped(int mode, int count, const void* const* A, const void* 
  * key 4 = 1 (also env GGET_DETERMINISTIC=1): reproducible mode of the pre-train step - the RMSNorm weight gradients, the one sum of that
  * gradient path added with fp32 atomics, are summed in block order instead; two runs then produce bit-identical parameters.
  * key 10 = 1: the per-sample kernels of S <= 32 off (the three launches each replaces run).  key 11 = 1: the fused RMSNorm + LayerScale
- * backward in its 16-byte-chunk form for every width (0: the 8-byte, all-lanes form for d = 512 / 768 / 1024). */
+ * backward in its 16-byte-chunk form for every width (0: the 8-byte, all-lanes form for d = 512 / 768 / 1024).
+ * key 13 = 0: the RMSNorm backward of short launches (<= 64 rows per CU) in 4-wave blocks as everywhere else (1, default: one 16-wave block
+ * per CU, same bits).  key 14 = 0: the engine's cross-entropy launch adds its loss with one atomic per block (1, default: one partial sum
+ * per block, summed in block order by the finalising launch). */
 int gget_debug_set(int key, int value);
 /* measurement aid: with enable != 0 the engine brackets, with HIP events on the launch stream, the grouped weight-gradient launch
  * (avg_ms_out[0]) and the gate|up + GEGLU launch (avg_ms_out[1]) of every layer of the following forward / backward calls;

@@ -1774,6 +1774,38 @@ def test_gradient_norm_from_backward_partials_matches_full_pass(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("weighted", [False, True])
+def test_cross_entropy_block_partials_match_the_atomic_sum(weighted):
+    """The engine's cross-entropy launch leaves ONE partial loss sum per block in its workspace and the finalising launch adds them in block
+    order (kernels.hip ce_rows_kernel / finalize_loss_kernel; 2048 same-address atomics cost the headline launch a third of its time);
+    gget_debug_set(14, 0) = the atomic form.  Same row losses, two summation orders: the loss equal to fp32 rounding, the lm_head gradient -
+    dlogits - untouched (the plain and the dLM-weighted normalisation, modeling_pretrain.py:210-236)."""
+    from _util import spec_mod, weights_mod, synth
+    lib = L.load()
+    B, S, F, V, d = 96, 32, 13, 756, 256
+    spec = spec_mod.ModelSpec(kind=spec_mod.KIND_PRETRAIN, vocab_size=V, hidden_size=d, intermediate_size=4 * d, num_layers=2, num_heads=d // 64,
+                              head_dim=64, stacked_feat=F, next_n_token=F, causal=False, max_position=1024)
+    state = weights_mod.make_state_dict(spec, seed=5, std=0.05, head_std=0.1)
+    b = tb(synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=31, dlm_wgt=weighted))
+    out = []
+    try:
+        for form in (0, 1, 1):
+            L.check(lib.gget_debug_set(14, form))
+            e = eng_mod.Engine(spec, max_tokens=B * S, max_batch=B)
+            e.load_state_dict(state)
+            loss = float(e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], b.get("wgt")))
+            e.backward()
+            torch.cuda.synchronize()
+            out.append((loss, e.grads()["lm_head.weight"].float().cpu().numpy().copy()))
+    finally:
+        L.check(lib.gget_debug_set(14, 1))
+    assert out[0][0] > 0.5
+    assert abs(out[0][0] - out[1][0]) <= 2e-6 * abs(out[0][0]), (out[0][0], out[1][0])
+    assert out[1][0] == out[2][0], "the block-ordered sum must reproduce itself"
+    assert rel_l2(out[1][1], out[0][1]) < 1e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode,d", [("labels", 768), ("labels_varlen", 768), ("dlm_weights", 768), ("inference", 768),
                                     ("labels", 576), ("labels_varlen", 576)])
 def test_slot_sorted_head_matches_dense_head(mode, d):

@@ -198,6 +198,36 @@ def test_rmsnorm(lib, T, d):
     assert rel_l2(dw.cpu().numpy(), wf.grad.cpu().numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("T,d", [(5696, 768), (8320, 768), (777, 512), (4097, 1024), (23, 768)])
+def test_rmsnorm_bwd_short_launch_form_is_bit_equal(lib, T, d):
+    """Short launches (<= 64 rows per CU) run one 16-wave block per CU with the rows dealt in contiguous ranges (rmsnorm_bwd_wide_kernel);
+    gget_debug_set(13, 0) selects the 4-wave blocks every other launch uses.  Same expressions: dx bit-equal, the weight gradient equal up to
+    the order of its fp32 partial sums."""
+    x, w, dy, dres = rnd(T, d, seed=1), (rnd(d, seed=2) * 0.1 + 1).to(torch.bfloat16), rnd(T, d, seed=3), rnd(T, d, seed=4)
+    rstd = torch.rsqrt(x.float().pow(2).mean(-1) + 1e-6)
+    out = []
+    for form in (0, 1):
+        lib.gget_debug_set(13, form)
+        dx = torch.full((T, d), 5.0, dtype=torch.bfloat16, device="cuda")
+        dw = torch.zeros(d, dtype=torch.float32, device="cuda")
+        L.check(lib.gget_op_rmsnorm_bwd(P(dy), P(x), P(w), P(rstd), P(dres), P(dx), P(dw), T, d, ST()))
+        torch.cuda.synchronize()
+        out.append((dx, dw))
+    lib.gget_debug_set(13, 1)
+    assert torch.equal(out[0][0], out[1][0]), "dx of the 16-wave form differs from the 4-wave form"
+    assert rel_l2(out[1][1].cpu().numpy(), out[0][1].cpu().numpy()) < 2e-6
+    # without a residual gradient
+    dx0 = torch.empty(T, d, dtype=torch.bfloat16, device="cuda")
+    dx1 = torch.empty(T, d, dtype=torch.bfloat16, device="cuda")
+    dw = torch.zeros(d, dtype=torch.float32, device="cuda")
+    lib.gget_debug_set(13, 0)
+    L.check(lib.gget_op_rmsnorm_bwd(P(dy), P(x), P(w), P(rstd), None, P(dx0), P(dw), T, d, ST()))
+    lib.gget_debug_set(13, 1)
+    L.check(lib.gget_op_rmsnorm_bwd(P(dy), P(x), P(w), P(rstd), None, P(dx1), P(dw), T, d, ST()))
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1)
+
+
 # ------------------------------------------------------------------------------------------ embedding
 @pytest.mark.parametrize("gated,V", [(False, 97), (True, 97), (False, 9001), (False, 756)])
 def test_embed(lib, gated, V):

@@ -1714,8 +1714,11 @@ __global__ void __launch_bounds__(NWB * 64, QT == 1 ? 4 : 2) attn_fwd64_kernel(c
 // keys, so the loop is branch-free (the lazy rescale of the running output aside); the last one or two tiles (key_len not
 // a multiple of 64) take the sequential masked path.
 #define GGET_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef GGET_FWD_DENSE_MINW
+#define GGET_FWD_DENSE_MINW 4   // waves per SIMD the 8-wave form is compiled for (128 registers, two blocks per CU; 3 / 2 measured: see profiles/r05_step_experiments.txt item 16)
+#endif
 template <bool DROP, int NWB>
-__global__ void __launch_bounds__(NWB * 64, NWB == 8 ? 4 : 3) attn_fwd_dense_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
+__global__ void __launch_bounds__(NWB * 64, NWB == 8 ? GGET_FWD_DENSE_MINW : 3) attn_fwd_dense_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
                                                                                     bf16_t* __restrict__ out, float* __restrict__ lse, int B, int S,
                                                                                     int H, Drop D, const int32_t* __restrict__ row_base) {
   __shared__ __attribute__((aligned(16))) unsigned char kr[3][8192];

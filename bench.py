@@ -254,6 +254,8 @@ def main():
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     if world > 1:
+        # (before the communicator exists: NCCL_MAX_NCHANNELS = the CUs the GEMM launches leave free, graph-gpt_amd/training.py dp_env_defaults)
+        importlib.import_module("graph-gpt_amd.training").dp_env_defaults()
         if backend == "nccl":
             dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local))
         else:

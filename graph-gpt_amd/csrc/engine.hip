@@ -44,13 +44,7 @@ constexpr int kLmSplit = 16;   // K slices of the lm_head wgrad at most (few out
 // the CUs (one 96-144 KiB block per CU) - 18 tiles x 16 slices = 288 blocks ran a second round for 32 of them (lm_head weight
 // gradient 88.6 -> measured below; profiles/r03_step_experiments.txt)
 int fit_split(int tiles, int want) {
-  static int num_cu = 0;
-  if (!num_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                 ? prop.multiProcessorCount : 256;
-  }
+  const int num_cu = gget_gemm_num_cu();   // (minus the CUs a data-parallel run leaves to its collectives)
   int s = want;
   while (s > 1 && tiles * s > num_cu) --s;
   return s;
@@ -1746,18 +1740,24 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   // weight gradients of the layer (dW = dY^T X, K = T).  All four dY / X pairs are still alive here.
   const GemmProblem wg_gu{dgu, h->wsp<bf16_t>(lw.xn2), h->G + lo.wgu, nullptr, 2 * ff, d, T, 2 * ff, d, d, nullptr, nullptr, 0, 0};
   const GemmProblem wg_dn{dy_down, h->wsp<bf16_t>(lw.h), h->G + lo.wdown, nullptr, d, ff, T, d, ff, ff, nullptr, nullptr, 0, 0};
+  // Data-parallel runs leave CUs to their collectives (g_gemm_cu_reserve): the 256 tiles of the grouped launch below would then need a second
+  // round for a few of them (twice the time).  The o projection's 16 tiles leave the group - the remaining 240 are one per CU again - and
+  // take the split-K slab path (128 x 128 tiles x K slices fitted to one round, fp32 slabs summed by slab_reduce).
+  const long wg_tiles_all = ((long)2 * ff * d + (long)d * ff + (long)4 * d * d) / (192 * 192);
+  const bool wo_apart = d % 192 == 0 && ff % 192 == 0 && g_gemm_cu_reserve > 0 && wg_tiles_all > gget_gemm_num_cu() &&
+                        wg_tiles_all - (long)d * d / (192 * 192) <= gget_gemm_num_cu();
   if (d % 192 == 0 && ff % 192 == 0) {
     // one persistent launch of 192x192 tiles over gate|up, down, q|k|v and o: (2ff*d + d*ff + 4d*d) / 192^2 tiles, which for
     // d = 768 is exactly 256 - every CU owns one tile and walks the full K, no split-K slabs, no reduce pass
     GemmGroup g;
     memset(&g, 0, sizeof(g));
-    g.count = 4;
+    g.count = wo_apart ? 3 : 4;
     g.p[0] = wg_gu;
     g.p[1] = wg_dn;
     g.p[2] = GemmProblem{dqkv, h->wsp<bf16_t>(lw.xn1), h->G + lo.wqkv, nullptr, 3 * d, d, T, 3 * d, d, d, nullptr, nullptr, 0, 0};
     g.p[3] = GemmProblem{dy_o, h->wsp<bf16_t>(lw.attn), h->G + lo.wo, nullptr, d, d, T, d, d, d, nullptr, nullptr, 0, 0};
     const long wg_tiles = ((long)2 * ff * d + (long)d * ff + (long)4 * d * d) / (192 * 192);
-    g.sq_partials = h->opt_norm_from_backward && wg_tiles <= kSqTilesPerLayer ? h->wsp<float>(w.sq_tiles) + (size_t)i * kSqTilesPerLayer : nullptr;
+    g.sq_partials = !wo_apart && h->opt_norm_from_backward && wg_tiles <= kSqTilesPerLayer ? h->wsp<float>(w.sq_tiles) + (size_t)i * kSqTilesPerLayer : nullptr;
     if (h->probe) GGET_HIP_CHECK(hipEventRecord(h->probe_event(0, 2 * i), st));
     if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_NONE, g, 1, st)) return e;
     if (h->probe) GGET_HIP_CHECK(hipEventRecord(h->probe_event(0, 2 * i + 1), st));
@@ -1765,6 +1765,20 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
       if (wg_tiles < kSqTilesPerLayer)   // (slots no tile writes must read as zero)
         GGET_HIP_CHECK(hipMemsetAsync(h->wsp<float>(w.sq_tiles) + (size_t)i * kSqTilesPerLayer + wg_tiles, 0, (kSqTilesPerLayer - wg_tiles) * sizeof(float), st));
       ++h->sq_layers;
+    }
+    if (wo_apart) {
+      float* wg = h->wsp<float>(w.wg32);                 // kWgSplit x 4 d^2 floats: up to 4 kWgSplit slabs of d^2
+      const long slab = (long)d * d;
+      const int t128 = ((d + 127) / 128) * ((d + 127) / 128);
+      int split = fit_split(t128, 4 * kWgSplit);
+      while (split > 1 && (T + 63) / 64 < 4 * split) --split;      // (at least four 64-deep K-tiles per slice)
+      GemmGroup go;
+      memset(&go, 0, sizeof(go));
+      go.count = 1;
+      go.p[0] = GemmProblem{dy_o, h->wsp<bf16_t>(lw.attn), wg, nullptr, d, d, T, d, d, d, nullptr, nullptr, 0, 0, slab};
+      if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_SLAB_F32, go, split, st)) return e;
+      const int ktiles = (T + 63) / 64, per = (ktiles + split - 1) / split;      // (the kernel's slicing: trailing slices may be empty)
+      if (int e = k_slab_reduce(wg, slab, (ktiles + per - 1) / per, h->G + lo.wo, (size_t)d * d, st)) return e;
     }
   } else {
     {
@@ -2145,6 +2159,7 @@ extern "C" int gget_debug_set(int key, int value) {
     case 11: g_ls_norm_bwd_wide = value; return 0;
     case 13: k_set_rms_wide(value); return 0;
     case 14: k_set_ce_parts(value); return 0;
+    case 15: g_gemm_cu_reserve = value > 0 ? value : 0; return 0;
   }
   gget_set_error("debug_set: unknown key %d", key);
   return 2;

@@ -74,6 +74,11 @@ constexpr size_t kStreamKFlagBytes = (kStreamKBlocks + 64) * sizeof(unsigned);
 inline size_t gget_gemm_streamk_bytes() { return kStreamKFlagBytes + kStreamKBlocks * kStreamKSlotBytes; }
 void gget_gemm_streamk_workspace(void* ws);
 
+// CUs the launcher plans for: the device's, minus g_gemm_cu_reserve (gget_debug_set key 15: CUs left free for a collective's workgroups in
+// data-parallel runs - gemm.hip has the reason), or GGET_GEMM_NUM_CU.  Every tile plan, persistent grid and split-K fit uses it.
+extern int g_gemm_cu_reserve;
+int gget_gemm_num_cu();
+
 // mode: GGET_GEMM_NT/NN/TN, epi: GGET_EPI_*; problems of one group share mode and epilogue.
 int gget_gemm_launch(int mode, int epi, GemmGroup& g, int split_k, hipStream_t st);
 int gget_gemm_single(int mode, int epi, const void* A, const void* B, void* C, const void* R, int M, int N, int K,

@@ -47,6 +47,28 @@ int g_gemm_ablate_set = -1;     // >= 0: replaces GGET_GEMM_ABLATE at run time (
 int g_gemm_stagger_ticks = 0;   // MODE 2 launches (two workgroups per CU): start delay of a CU's second workgroup in 100 MHz ticks (gget_debug_set
                                 // key 5, env GGET_GEMM_STAGGER); 0 = both start together (round 3)
 
+
+// CUs the GEMM launches leave FREE (gget_debug_set key 15; data-parallel runs set it to the number of channels they allow the collective
+// library).  Why: an RCCL workgroup (rcclGenericKernel: 256 threads, 261 - 280 registers per lane, 19.7 KiB of LDS - read from the library's
+// gfx950 code object) cannot share a CU with ANY 8-wave GEMM workgroup of this file (2 waves x 130 - 216 registers per SIMD), and these
+// launches assign their tiles statically: one workgroup that finds its CU taken starts when the others exit and the launch takes twice as
+// long (profiles/r02_coresidency.txt measured exactly that with one foreign workgroup).  With R CUs left free the collective's <= R
+// workgroups and the GEMM's (CUs - R) never compete.
+int g_gemm_cu_reserve = 0;
+int gget_gemm_num_cu() {
+  static int dev_cus = 0;
+  if (!dev_cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    dev_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("GGET_GEMM_NUM_CU")) dev_cus = atoi(e);   // measurement knob: pretend the chip has fewer CUs (tools/halfchip.py)
+  }
+  int n = dev_cus - (g_gemm_cu_reserve > 0 ? g_gemm_cu_reserve : 0);
+  if (g_gemm_cu_reserve > 0) n &= ~7;      // (the XCD permutation of the persistent kernels wants a multiple of 8)
+  return n < 8 ? 8 : n;
+}
+
 namespace {
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -1614,15 +1636,7 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
               (g.p[i].k_dev == nullptr || (g.count == 1 && g.p[i].k_pad_zero && getenv("GGET_GEMM_NO_DYN") == nullptr)) &&
               (g.p[i].K % 64) == 0 && g.p[i].K >= 64;
   if (persist) {
-    static int num_cu = 0;
-    if (!num_cu) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      GGET_HIP_CHECK(hipGetDevice(&dev));
-      GGET_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-      num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-      if (const char* e = getenv("GGET_GEMM_NUM_CU")) num_cu = atoi(e);   // measurement knob: pretend the chip has fewer CUs (tools/halfchip.py)
-    }
+    const int num_cu = gget_gemm_num_cu();
     // wide tile for the widest forward GEMM: 256x256x32 (8 waves of 128x64, 4-slot ring) moves 2/3 of the bytes per
     // FLOP of the 256x128 tile
     if constexpr (WM == 4 && WN == 2 && !A_MC && EPI != GGET_EPI_SLAB_F32 && EPI != GGET_EPI_ATOMIC_F32 && EPI != GGET_EPI_GEGLU_FWD) {
@@ -1844,15 +1858,7 @@ int launch_mode(GemmGroup& g, int epi, int split_k, hipStream_t st) {
           total += ((p.M + 255) / 256) * p.tiles_n;
         }
         if (total == 0) return 0;
-        static int num_cu = 0;
-        if (!num_cu) {
-          int dev = 0;
-          hipDeviceProp_t prop;
-          GGET_HIP_CHECK(hipGetDevice(&dev));
-          GGET_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-          num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-          if (const char* e = getenv("GGET_GEMM_NUM_CU")) num_cu = atoi(e);   // measurement knob: pretend the chip has fewer CUs (tools/halfchip.py)
-        }
+        const int num_cu = gget_gemm_num_cu();
         // (192-row tiles when they need fewer rounds x rows than 256-row tiles - see launch_t)
         long t192 = 0;
         for (int i = 0; i < g.count; ++i) t192 += (long)((g.p[i].M + 191) / 192) * (g.p[i].N / 256);

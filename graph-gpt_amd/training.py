@@ -186,11 +186,24 @@ class GgetEngine:
         # measurement switch (bench.py `dp.exposed_comm_ms`): False runs the same staged backward WITHOUT issuing the collectives -
         # the ranks then drift apart, so it is only ever set for a few untimed-for-throughput diagnostic steps
         self.exchange = True
+        self.reserved_cus = 0
         if self.world > 1 and torch.cuda.is_available():
             # a collective's kernel shares the chip with the compute stream from now on: the GEMM launcher keeps LDS headroom on every
             # CU (no launch with two LDS-filling workgroups per CU; gget_debug_set key 2)
             from . import _lib as L
             L.check(L.load().gget_debug_set(2, 2))
+            # ... and, in a real multi-process job, the GEMM launches leave GGET_DP_RESERVE_CUS CUs (default 16, 0 = off) FREE for the
+            # collective's workgroups, which are held to as many channels (NCCL_MAX_NCHANNELS, unless the user set it): an RCCL workgroup
+            # (256 threads x 261 - 280 registers, 19.7 KiB LDS) cannot share a CU with any 8-wave GEMM workgroup, and a GEMM launch that finds
+            # one of "its" CUs taken runs a second round (csrc/gemm.hip g_gemm_cu_reserve).  The RMSNorm backward goes
+            # back to its many-small-blocks form for the same reason.
+            real_world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+            if real_world > 1:
+                self.reserved_cus = max(0, int(os.environ.get("GGET_DP_RESERVE_CUS", "16")))
+                if self.reserved_cus:
+                    os.environ.setdefault("NCCL_MAX_NCHANNELS", str(self.reserved_cus))   # (read when the communicator is created)
+                    L.check(L.load().gget_debug_set(15, self.reserved_cus))
+                    L.check(L.load().gget_debug_set(13, 0))
         model.materialize_grads = False  # fused path: gradients stay in the flat bf16 arena
         model._managed_by_engine = True  # the bucketed exchange below replaces the all-reduce of _autograd_backward
 
@@ -316,7 +329,8 @@ class GgetEngine:
                 "reduce_dtype": "fp32" if self.fp32_reduce else "bf16",
                 "bucket_mb": [round(c * 2 / 2 ** 20, 1) for _, c in e.buckets] if e is not None else None,
                 "collectives_per_step": len(self.exchange_groups(e)) if e is not None else None,
-                "collective_mb": [round(c * 2 / 2 ** 20, 1) for _, c in self.exchange_groups(e).values()] if e is not None else None}
+                "collective_mb": [round(c * 2 / 2 ** 20, 1) for _, c in self.exchange_groups(e).values()] if e is not None else None,
+                "reserved_cus": self.reserved_cus, "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS")}
         try:
             v = torch.cuda.nccl.version()
             info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
@@ -613,8 +627,20 @@ def ft_evaluate(model, loader, *, problem_type: str = "single_label_classificati
 
 
 # ----------------------------------------------------------------------------- distributed env
+
+def dp_env_defaults() -> int:
+    """Environment a multi-process job wants BEFORE its process group / communicator exists: the collective library is held to as many
+    channels (= workgroups) as the GEMM launches leave CUs free - GGET_DP_RESERVE_CUS, default 16, 0 = off; an NCCL_MAX_NCHANNELS the user set
+    wins.  Returns the number of reserved CUs (GgetEngine applies the GEMM side: gget_debug_set(15, .))."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    r = max(0, int(os.environ.get("GGET_DP_RESERVE_CUS", "16"))) if world > 1 else 0
+    if r:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(r))
+    return r
+
 def set_dist_env(backend: Optional[str] = None):
     """reference misc_utils.set_dist_env (:507-539): env:// rendezvous, one process per GPU, barrier."""
+    dp_env_defaults()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -349,7 +349,9 @@ int gget_op_gemm_grouped(int mode, int count, const void* const* A, const void* 
  * backward in its 16-byte-chunk form for every width (0: the 8-byte, all-lanes form for d = 512 / 768 / 1024).
  * key 13 = 0: the RMSNorm backward of short launches (<= 64 rows per CU) in 4-wave blocks as everywhere else (1, default: one 16-wave block
  * per CU, same bits).  key 14 = 0: the engine's cross-entropy launch adds its loss with one atomic per block (1, default: one partial sum
- * per block, summed in block order by the finalising launch). */
+ * per block, summed in block order by the finalising launch).  key 15 = R: every GEMM launch plan (tile shapes, persistent grids, split-K
+ * fits) counts the device's CUs minus R - data-parallel runs leave R CUs to the collective library's workgroups, which cannot share a CU
+ * with a GEMM workgroup (0, default: the whole chip). */
 int gget_debug_set(int key, int value);
 /* measurement aid: with enable != 0 the engine brackets, with HIP events on the launch stream, the grouped weight-gradient launch
  * (avg_ms_out[0]) and the gate|up + GEGLU launch (avg_ms_out[1]) of every layer of the following forward / backward calls;

@@ -36,7 +36,7 @@ def _reset_process_wide_kernel_menu(request):
             import importlib
             L = importlib.import_module("graph-gpt_amd._lib")
             lib = L.load()
-            for key, val in ((2, 1), (10, 0), (11, 0), (1, 0), (8, 0), (13, 1), (14, 1)):
+            for key, val in ((2, 1), (10, 0), (11, 0), (1, 0), (8, 0), (13, 1), (14, 1), (15, 0)):
                 lib.gget_debug_set(key, val)
         except Exception:
             pass

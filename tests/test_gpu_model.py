@@ -1774,6 +1774,43 @@ def test_gradient_norm_from_backward_partials_matches_full_pass(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_reserved_cus_launch_menu_gives_the_same_step():
+    """Data-parallel runs leave CUs free for the collective's workgroups (gget_debug_set(15, R): every GEMM tile plan, persistent grid and
+    split-K fit counts CUs - R; the o projection's weight gradient leaves the grouped 256-tile launch for the split-K slab path so that the
+    rest is one tile per CU again; csrc/gemm.hip g_gemm_cu_reserve).  Same arithmetic in other tilings: loss bit-equal is not promised,
+    but loss and every gradient must agree to bf16 rounding with the full-chip menu - at the headline width, where the menus differ."""
+    from _util import spec_mod, weights_mod, synth
+    lib = L.load()
+    B, S, F, V, d = 256, 32, 13, 756, 768
+    spec = spec_mod.ModelSpec(kind=spec_mod.KIND_PRETRAIN, vocab_size=V, hidden_size=d, intermediate_size=4 * d, num_layers=2, num_heads=d // 64,
+                              head_dim=64, stacked_feat=F, next_n_token=F, causal=False, max_position=1024)
+    state = weights_mod.make_state_dict(spec, seed=9, std=0.02, head_std=0.05)
+    batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=77)
+    b = tb(batch)
+    n_tok = int(batch["attention_mask"].sum())
+    out = {}
+    try:
+        for name, r in (("full", 0), ("reserved", 16)):
+            L.check(lib.gget_debug_set(15, r))
+            e = eng_mod.Engine(spec, max_tokens=B * S, max_batch=B)
+            e.load_state_dict(state)
+            loss = float(e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], num_tokens=n_tok))
+            e.backward()
+            torch.cuda.synchronize()
+            out[name] = (loss, {k: v.float().cpu().numpy().copy() for k, v in e.grads().items()})
+    finally:
+        L.check(lib.gget_debug_set(15, 0))
+    (lf, gf), (lr, gr) = out["full"], out["reserved"]
+    assert abs(lf - lr) <= 2e-5 * abs(lf), (lf, lr)
+    gmax = max(float(np.linalg.norm(g)) for g in gf.values())
+    for k in gf:
+        den = max(float(np.linalg.norm(gf[k])), 1e-2 * gmax)
+        err = float(np.linalg.norm(gr[k] - gf[k])) / den
+        record_error("reserved_cus_menu", "grad_rel_l2_vs_full_chip " + k, err, 8e-3)
+        assert err <= 8e-3, (k, err)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("weighted", [False, True])
 def test_cross_entropy_block_partials_match_the_atomic_sum(weighted):
     """The engine's cross-entropy launch leaves ONE partial loss sum per block in its workspace and the finalising launch adds them in block

@@ -1689,7 +1689,10 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   //  fills 151 of the 160 KiB of a CU's LDS with ONE workgroup per sample: a foreign workgroup on a CU would push the sample's workgroup into
   //  a second round, the mechanism behind the GEMM launch menu's headroom rule.  The three-launch form runs then; the
   //  forward - which never overlaps a collective - stays fused.)
-  if (!h->plan.has_res && !h->klo() && h->wo_packed && g_gemm_lds_headroom < 2) {
+  // (With CUs RESERVED for the collective - g_gemm_cu_reserve, the rule data-parallel runs use since round 5 - the collective's workgroups
+  //  have their own CUs: the kernel may run whenever its one-workgroup-per-sample grid fits the CUs that are left, whatever the LDS rule says.)
+  const bool ao_bwd_ok = g_gemm_cu_reserve > 0 ? h->B <= gget_gemm_num_cu() : g_gemm_lds_headroom < 2;
+  if (!h->plan.has_res && !h->klo() && h->wo_packed && ao_bwd_ok) {
     // S <= 32: RMSNorm backward of post_attention_layernorm, the o projection's dgrad and the attention backward of a sample in ONE
     // workgroup (attention.hip: attn_oproj_bwd_kernel); dattn is never materialised
     int taken = 0;
@@ -2437,7 +2440,7 @@ extern "C" int gget_comm_init(gget_handle_t h, int rank, int world, const void* 
   h->comm_rank = rank;
   h->comm_world = world;
   // a collective's kernel will share the chip with the compute stream: keep LDS headroom on every CU
-  if (world > 1 && g_gemm_lds_headroom < 2) g_gemm_lds_headroom = 2;
+  if (world > 1 && g_gemm_cu_reserve == 0 && g_gemm_lds_headroom < 2) g_gemm_lds_headroom = 2;
   return 0;
 }
 
@@ -2487,7 +2490,7 @@ extern "C" int gget_comm_init_loopback(gget_handle_t h, int world) {
   h->comm_loopback = true;
   h->comm_rank = 0;
   h->comm_world = world;
-  if (world > 1 && g_gemm_lds_headroom < 2) g_gemm_lds_headroom = 2;   // (the launch menu of a data-parallel run, as gget_comm_init)
+  if (world > 1 && g_gemm_cu_reserve == 0 && g_gemm_lds_headroom < 2) g_gemm_lds_headroom = 2;   // (the launch menu of a data-parallel run, as gget_comm_init)
   return 0;
 }
 

@@ -192,6 +192,8 @@ class GgetEngine:
             # CU (no launch with two LDS-filling workgroups per CU; gget_debug_set key 2)
             from . import _lib as L
             L.check(L.load().gget_debug_set(2, 2))
+            # (superseded below, in a real multi-process job, by the stronger rule: CUs of their own for the collective - the two-per-CU launch
+            #  returns then, and the per-sample backward runs whenever its grid fits the CUs that are left)
             # ... and, in a real multi-process job, the GEMM launches leave GGET_DP_RESERVE_CUS CUs (default 16, 0 = off) FREE for the
             # collective's workgroups, which are held to as many channels (NCCL_MAX_NCHANNELS, unless the user set it): an RCCL workgroup
             # (256 threads x 261 - 280 registers, 19.7 KiB LDS) cannot share a CU with any 8-wave GEMM workgroup, and a GEMM launch that finds
@@ -204,6 +206,7 @@ class GgetEngine:
                     os.environ.setdefault("NCCL_MAX_NCHANNELS", str(self.reserved_cus))   # (read when the communicator is created)
                     L.check(L.load().gget_debug_set(15, self.reserved_cus))
                     L.check(L.load().gget_debug_set(13, 0))
+                    L.check(L.load().gget_debug_set(2, 1))
         model.materialize_grads = False  # fused path: gradients stay in the flat bf16 arena
         model._managed_by_engine = True  # the bucketed exchange below replaces the all-reduce of _autograd_backward
 

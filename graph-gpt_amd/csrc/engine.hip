@@ -1744,23 +1744,29 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   const GemmProblem wg_gu{dgu, h->wsp<bf16_t>(lw.xn2), h->G + lo.wgu, nullptr, 2 * ff, d, T, 2 * ff, d, d, nullptr, nullptr, 0, 0};
   const GemmProblem wg_dn{dy_down, h->wsp<bf16_t>(lw.h), h->G + lo.wdown, nullptr, d, ff, T, d, ff, ff, nullptr, nullptr, 0, 0};
   // Data-parallel runs leave CUs to their collectives (g_gemm_cu_reserve): the 256 tiles of the grouped launch below would then need a second
-  // round for a few of them (twice the time).  The o projection's 16 tiles leave the group - the remaining 240 are one per CU again - and
-  // take the split-K slab path (128 x 128 tiles x K slices fitted to one round, fp32 slabs summed by slab_reduce).
-  const long wg_tiles_all = ((long)2 * ff * d + (long)d * ff + (long)4 * d * d) / (192 * 192);
-  const bool wo_apart = d % 192 == 0 && ff % 192 == 0 && g_gemm_cu_reserve > 0 && wg_tiles_all > gget_gemm_num_cu() &&
-                        wg_tiles_all - (long)d * d / (192 * 192) <= gget_gemm_num_cu();
+  // round for a few of them (twice the time).  As many problems as fit the CUs that are left stay in the one-tile-per-CU group (in the order
+  // gate|up 128, down 64, q|k|v 48, o 16 tiles at d = 768); the rest - q|k|v and o, contiguous in the gradient array - take the split-K slab
+  // path (128 x 128 or 256 x 128 tiles x K slices fitted to one round, fp32 slabs summed by slab_reduce).
+  const long t192[4] = {(long)2 * ff * d / (192 * 192), (long)d * ff / (192 * 192), (long)3 * d * d / (192 * 192), (long)d * d / (192 * 192)};
+  int n_grouped = 4;
+  if (d % 192 == 0 && ff % 192 == 0 && g_gemm_cu_reserve > 0) {
+    long acc_t = 0;
+    n_grouped = 0;
+    for (int q = 0; q < 4 && acc_t + t192[q] <= gget_gemm_num_cu(); ++q) { acc_t += t192[q]; ++n_grouped; }
+    if (n_grouped < 2) n_grouped = 4;      // (nothing sensible to shed: the plain plan, whatever rounds it takes)
+  }
   if (d % 192 == 0 && ff % 192 == 0) {
     // one persistent launch of 192x192 tiles over gate|up, down, q|k|v and o: (2ff*d + d*ff + 4d*d) / 192^2 tiles, which for
     // d = 768 is exactly 256 - every CU owns one tile and walks the full K, no split-K slabs, no reduce pass
     GemmGroup g;
     memset(&g, 0, sizeof(g));
-    g.count = wo_apart ? 3 : 4;
+    g.count = n_grouped;
     g.p[0] = wg_gu;
     g.p[1] = wg_dn;
     g.p[2] = GemmProblem{dqkv, h->wsp<bf16_t>(lw.xn1), h->G + lo.wqkv, nullptr, 3 * d, d, T, 3 * d, d, d, nullptr, nullptr, 0, 0};
     g.p[3] = GemmProblem{dy_o, h->wsp<bf16_t>(lw.attn), h->G + lo.wo, nullptr, d, d, T, d, d, d, nullptr, nullptr, 0, 0};
     const long wg_tiles = ((long)2 * ff * d + (long)d * ff + (long)4 * d * d) / (192 * 192);
-    g.sq_partials = !wo_apart && h->opt_norm_from_backward && wg_tiles <= kSqTilesPerLayer ? h->wsp<float>(w.sq_tiles) + (size_t)i * kSqTilesPerLayer : nullptr;
+    g.sq_partials = n_grouped == 4 && h->opt_norm_from_backward && wg_tiles <= kSqTilesPerLayer ? h->wsp<float>(w.sq_tiles) + (size_t)i * kSqTilesPerLayer : nullptr;
     if (h->probe) GGET_HIP_CHECK(hipEventRecord(h->probe_event(0, 2 * i), st));
     if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_NONE, g, 1, st)) return e;
     if (h->probe) GGET_HIP_CHECK(hipEventRecord(h->probe_event(0, 2 * i + 1), st));
@@ -1769,19 +1775,31 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
         GGET_HIP_CHECK(hipMemsetAsync(h->wsp<float>(w.sq_tiles) + (size_t)i * kSqTilesPerLayer + wg_tiles, 0, (kSqTilesPerLayer - wg_tiles) * sizeof(float), st));
       ++h->sq_layers;
     }
-    if (wo_apart) {
-      float* wg = h->wsp<float>(w.wg32);                 // kWgSplit x 4 d^2 floats: up to 4 kWgSplit slabs of d^2
-      const long slab = (long)d * d;
-      const int t128 = ((d + 127) / 128) * ((d + 127) / 128);
-      int split = fit_split(t128, 4 * kWgSplit);
-      while (split > 1 && (T + 63) / 64 < 4 * split) --split;      // (at least four 64-deep K-tiles per slice)
+    if (n_grouped < 4) {
+      // the shed problems: q|k|v (when n_grouped == 2) and o, one split-K launch into fp32 slabs of 4 d^2 (q|k|v|o are contiguous in the
+      // gradient array); the workspace holds kWgSplit such slabs
+      float* wg = h->wsp<float>(w.wg32);
+      const bool with_qkv = n_grouped == 2;
+      const long slab = with_qkv ? (long)4 * d * d : (long)d * d;
+      const int max_slabs = with_qkv ? kWgSplit : 4 * kWgSplit;
+      const int rows_out = with_qkv ? 4 * d : d;
+      const int t_big = ((rows_out + 255) / 256) * ((d + 127) / 128), t_small = ((rows_out + 127) / 128) * ((d + 127) / 128);
+      int split = fit_split(t_big, max_slabs);
+      if (t_big * split < 160) split = fit_split(t_small, max_slabs);           // (gemm.hip launch_shape: 128 x 128 tiles below 160 tile-slices)
+      while (split > 1 && (T + 63) / 64 < 4 * split) --split;                   // (at least four 64-deep K-tiles per slice)
       GemmGroup go;
       memset(&go, 0, sizeof(go));
-      go.count = 1;
-      go.p[0] = GemmProblem{dy_o, h->wsp<bf16_t>(lw.attn), wg, nullptr, d, d, T, d, d, d, nullptr, nullptr, 0, 0, slab};
+      if (with_qkv) {
+        go.count = 2;
+        go.p[0] = GemmProblem{dqkv, h->wsp<bf16_t>(lw.xn1), wg, nullptr, 3 * d, d, T, 3 * d, d, d, nullptr, nullptr, 0, 0, slab};
+        go.p[1] = GemmProblem{dy_o, h->wsp<bf16_t>(lw.attn), wg + (size_t)3 * d * d, nullptr, d, d, T, d, d, d, nullptr, nullptr, 0, 0, slab};
+      } else {
+        go.count = 1;
+        go.p[0] = GemmProblem{dy_o, h->wsp<bf16_t>(lw.attn), wg, nullptr, d, d, T, d, d, d, nullptr, nullptr, 0, 0, slab};
+      }
       if (int e = gget_gemm_launch(GGET_GEMM_TN, GGET_EPI_SLAB_F32, go, split, st)) return e;
       const int ktiles = (T + 63) / 64, per = (ktiles + split - 1) / split;      // (the kernel's slicing: trailing slices may be empty)
-      if (int e = k_slab_reduce(wg, slab, (ktiles + per - 1) / per, h->G + lo.wo, (size_t)d * d, st)) return e;
+      if (int e = k_slab_reduce(wg, slab, (ktiles + per - 1) / per, h->G + (with_qkv ? lo.wqkv : lo.wo), (size_t)slab, st)) return e;
     }
   } else {
     {
@@ -2110,12 +2128,36 @@ __global__ void __launch_bounds__(256) occupy_kernel(float* buf, size_t n, long 
   }
   if (acc == 1.2345e-30f) buf[0] = acc;
 }
+// ... with the REGISTER footprint of RCCL's kernel (gget_debug_set(16, 1)): rcclGenericKernel allocates 261 - 280 registers per lane (its
+// gfx950 code object) - one wave of it per SIMD leaves no room for the two waves of a GEMM workgroup, whatever LDS is
+// free.  The clobbers make the compiler allocate 256 vector + 8 accumulation registers; the loop is the same.
+__global__ void __launch_bounds__(256) occupy_fat_kernel(float* buf, size_t n, long long ticks) {
+  extern __shared__ float occ_lds[];
+  asm volatile("" ::: "v255", "a7");
+  const long long t0 = wall_clock64();
+  float acc = 0.f;
+  size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) % n;
+  while (wall_clock64() - t0 < ticks) {
+    acc += buf[i];
+    i = (i + 65536) % n;
+    if (threadIdx.x == 0) occ_lds[0] = acc;
+  }
+  if (acc == 1.2345e-30f) buf[0] = acc;
+}
+int g_occupy_fat = 0;
 extern "C" int gget_debug_occupy(void* scratch, uint64_t scratch_bytes, int blocks, int lds_bytes, int microseconds, void* stream) {
   GGET_REQUIRE(scratch && scratch_bytes >= 4096 && blocks > 0 && lds_bytes >= 4 && lds_bytes <= 160 * 1024, "debug_occupy: bad arguments");
   static bool attr = false;
   if (!attr) {
     GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&occupy_fat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
+  }
+  if (g_occupy_fat) {
+    hipLaunchKernelGGL(occupy_fat_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, (float*)scratch, scratch_bytes / 4,
+                       (long long)microseconds * 100);
+    GGET_LAUNCH_CHECK();
+    return 0;
   }
   hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, (float*)scratch, scratch_bytes / 4,
                      (long long)microseconds * 100);   // wall_clock64 ticks at 100 MHz
@@ -2163,6 +2205,7 @@ extern "C" int gget_debug_set(int key, int value) {
     case 13: k_set_rms_wide(value); return 0;
     case 14: k_set_ce_parts(value); return 0;
     case 15: g_gemm_cu_reserve = value > 0 ? value : 0; return 0;
+    case 16: g_occupy_fat = value; return 0;
   }
   gget_set_error("debug_set: unknown key %d", key);
   return 2;

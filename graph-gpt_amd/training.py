@@ -194,14 +194,14 @@ class GgetEngine:
             L.check(L.load().gget_debug_set(2, 2))
             # (superseded below, in a real multi-process job, by the stronger rule: CUs of their own for the collective - the two-per-CU launch
             #  returns then, and the per-sample backward runs whenever its grid fits the CUs that are left)
-            # ... and, in a real multi-process job, the GEMM launches leave GGET_DP_RESERVE_CUS CUs (default 16, 0 = off) FREE for the
+            # ... and, in a real multi-process job that asks for it, the GEMM launches leave GGET_DP_RESERVE_CUS CUs (default 0 = off) FREE for the
             # collective's workgroups, which are held to as many channels (NCCL_MAX_NCHANNELS, unless the user set it): an RCCL workgroup
             # (256 threads x 261 - 280 registers, 19.7 KiB LDS) cannot share a CU with any 8-wave GEMM workgroup, and a GEMM launch that finds
             # one of "its" CUs taken runs a second round (csrc/gemm.hip g_gemm_cu_reserve).  The RMSNorm backward goes
             # back to its many-small-blocks form for the same reason.
             real_world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
             if real_world > 1:
-                self.reserved_cus = max(0, int(os.environ.get("GGET_DP_RESERVE_CUS", "16")))
+                self.reserved_cus = max(0, int(os.environ.get("GGET_DP_RESERVE_CUS", "0")))
                 if self.reserved_cus:
                     os.environ.setdefault("NCCL_MAX_NCHANNELS", str(self.reserved_cus))   # (read when the communicator is created)
                     L.check(L.load().gget_debug_set(15, self.reserved_cus))
@@ -633,10 +633,11 @@ def ft_evaluate(model, loader, *, problem_type: str = "single_label_classificati
 
 def dp_env_defaults() -> int:
     """Environment a multi-process job wants BEFORE its process group / communicator exists: the collective library is held to as many
-    channels (= workgroups) as the GEMM launches leave CUs free - GGET_DP_RESERVE_CUS, default 16, 0 = off; an NCCL_MAX_NCHANNELS the user set
-    wins.  Returns the number of reserved CUs (GgetEngine applies the GEMM side: gget_debug_set(15, .))."""
+    channels (= workgroups) as the GEMM launches leave CUs free - GGET_DP_RESERVE_CUS = R, OFF by default (0: tools/dp_standin.py measured that
+    16 free CUs do not protect the exact-fit launches and that 32 cost more than the collisions they prevent at the 8-GPU residency of the
+    collectives); an NCCL_MAX_NCHANNELS the user set wins.  Returns R (GgetEngine applies the GEMM side: gget_debug_set(15, R))."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    r = max(0, int(os.environ.get("GGET_DP_RESERVE_CUS", "16"))) if world > 1 else 0
+    r = max(0, int(os.environ.get("GGET_DP_RESERVE_CUS", "0"))) if world > 1 else 0
     if r:
         os.environ.setdefault("NCCL_MAX_NCHANNELS", str(r))
     return r

@@ -351,7 +351,8 @@ int gget_op_gemm_grouped(int mode, int count, const void* const* A, const void* 
  * per CU, same bits).  key 14 = 0: the engine's cross-entropy launch adds its loss with one atomic per block (1, default: one partial sum
  * per block, summed in block order by the finalising launch).  key 15 = R: every GEMM launch plan (tile shapes, persistent grids, split-K
  * fits) counts the device's CUs minus R - data-parallel runs leave R CUs to the collective library's workgroups, which cannot share a CU
- * with a GEMM workgroup (0, default: the whole chip). */
+ * with a GEMM workgroup (0, default: the whole chip).  key 16 = 1: gget_debug_occupy's stand-in takes the register footprint of RCCL's
+ * kernel (264 registers per lane) besides the LDS asked for. */
 int gget_debug_set(int key, int value);
 /* measurement aid: with enable != 0 the engine brackets, with HIP events on the launch stream, the grouped weight-gradient launch
  * (avg_ms_out[0]) and the gate|up + GEGLU launch (avg_ms_out[1]) of every layer of the following forward / backward calls;

@@ -1689,8 +1689,9 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   //  fills 151 of the 160 KiB of a CU's LDS with ONE workgroup per sample: a foreign workgroup on a CU would push the sample's workgroup into
   //  a second round, the mechanism behind the GEMM launch menu's headroom rule.  The three-launch form runs then; the
   //  forward - which never overlaps a collective - stays fused.)
-  // (With CUs RESERVED for the collective - g_gemm_cu_reserve, the rule data-parallel runs use since round 5 - the collective's workgroups
-  //  have their own CUs: the kernel may run whenever its one-workgroup-per-sample grid fits the CUs that are left, whatever the LDS rule says.)
+  // (Both rules are opt-in since round 5 - GGET_DP_LDS_HEADROOM, GGET_DP_RESERVE_CUS; a data-parallel rank keeps the single-GPU menu by
+  //  default, this kernel included: tools/dp_standin.py.  With CUs RESERVED for the collective - g_gemm_cu_reserve - the collective's
+  //  workgroups have their own CUs: the kernel may run whenever its one-workgroup-per-sample grid fits the CUs that are left.)
   const bool ao_bwd_ok = g_gemm_cu_reserve > 0 ? h->B <= gget_gemm_num_cu() : g_gemm_lds_headroom < 2;
   if (!h->plan.has_res && !h->klo() && h->wo_packed && ao_bwd_ok) {
     // S <= 32: RMSNorm backward of post_attention_layernorm, the o projection's dgrad and the attention backward of a sample in ONE
@@ -2483,7 +2484,7 @@ extern "C" int gget_comm_init(gget_handle_t h, int rank, int world, const void* 
   h->comm_rank = rank;
   h->comm_world = world;
   // a collective's kernel will share the chip with the compute stream: keep LDS headroom on every CU
-  if (world > 1 && g_gemm_cu_reserve == 0 && g_gemm_lds_headroom < 2) g_gemm_lds_headroom = 2;
+  if (world > 1 && g_gemm_cu_reserve == 0 && g_gemm_lds_headroom < 2 && getenv("GGET_DP_LDS_HEADROOM") && atoi(getenv("GGET_DP_LDS_HEADROOM"))) g_gemm_lds_headroom = 2;   // (opt-in since round 5: DESIGN.md section 6)
   return 0;
 }
 
@@ -2533,7 +2534,7 @@ extern "C" int gget_comm_init_loopback(gget_handle_t h, int world) {
   h->comm_loopback = true;
   h->comm_rank = 0;
   h->comm_world = world;
-  if (world > 1 && g_gemm_cu_reserve == 0 && g_gemm_lds_headroom < 2) g_gemm_lds_headroom = 2;   // (the launch menu of a data-parallel run, as gget_comm_init)
+  if (world > 1 && g_gemm_cu_reserve == 0 && g_gemm_lds_headroom < 2 && getenv("GGET_DP_LDS_HEADROOM") && atoi(getenv("GGET_DP_LDS_HEADROOM"))) g_gemm_lds_headroom = 2;   // (opt-in since round 5: DESIGN.md section 6)   // (the launch menu of a data-parallel run, as gget_comm_init)
   return 0;
 }
 

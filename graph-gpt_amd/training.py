@@ -191,7 +191,10 @@ class GgetEngine:
             # a collective's kernel shares the chip with the compute stream from now on: the GEMM launcher keeps LDS headroom on every
             # CU (no launch with two LDS-filling workgroups per CU; gget_debug_set key 2)
             from . import _lib as L
-            L.check(L.load().gget_debug_set(2, 2))
+            # (rounds 2 - 4 set this for every multi-rank job; round 5's stand-in with RCCL's real register footprint - tools/dp_standin.py -
+            #  shows the rule buys nothing against such a kernel and costs 0.08 ms alone, 0.2 ms beside it: opt-in now, GGET_DP_LDS_HEADROOM=1)
+            if bool(int(os.environ.get("GGET_DP_LDS_HEADROOM", "0"))):
+                L.check(L.load().gget_debug_set(2, 2))
             # (superseded below, in a real multi-process job, by the stronger rule: CUs of their own for the collective - the two-per-CU launch
             #  returns then, and the per-sample backward runs whenever its grid fits the CUs that are left)
             # ... and, in a real multi-process job that asks for it, the GEMM launches leave GGET_DP_RESERVE_CUS CUs (default 0 = off) FREE for the

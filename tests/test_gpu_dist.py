@@ -84,11 +84,10 @@ def test_two_rank_step_matches_manual_gradient_average(overlap, layout, monkeypa
     assert abs(res[0][3] - res[1][3]) == 0.0                       # same clipped global norm on both ranks
 
     # one process, two replicas' gradients averaged by hand (fp32 sum of the bf16 buckets, then the same 1/world scale) - with the kernel
-    # menu of a data-parallel rank, what GgetEngine sets in a multi-process job (gget_debug_set(2, 2): LDS headroom for a collective's
-    # workgroups, which since round 5 also means the three-launch form of the S <= 32 backward instead of the per-sample workgroup;
-    # GGET_DP_RESERVE_CUS, off by default, would add (15, R), (13, 0), (2, 1))
+    # menu of a data-parallel rank = the single-GPU menu since round 5 (GGET_DP_LDS_HEADROOM=1 would add (2, 2), GGET_DP_RESERVE_CUS=R
+    # (15, R), (13, 0): both opt-in)
     L_ = importlib.import_module("graph-gpt_amd._lib")
-    for key, val in ((15, 0), (13, 1), (2, 2)):
+    for key, val in ((15, 0), (13, 1), (2, 1)):
         L_.check(L_.load().gget_debug_set(key, val))
     models = [modeling.GraphGPTPretrainBase(_cfg(modeling), seed=1) for _ in range(2)]
     engs = [tr.initialize(m, tr.OptimConfig(lr=1e-3, max_grad_norm=0.05)) for m in models]

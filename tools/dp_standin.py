@@ -10,7 +10,9 @@ backward the way the bucketed all-reduce is.  Menus (gget_debug_set):
   r5_32    ... 32 CUs left                              (15, 32)
   r5_64    ... 64 CUs left                              (15, 64)
 
-prints ms/step (forward + backward + clip + AdamW, HIP events) without the stand-in and with N = 8 / 16 / 32 workgroups of it."""
+prints ms/step (forward + backward + clip + AdamW, HIP events) without the stand-in and with N = 16 / 32 workgroups of it.
+DP_STANDIN_SCHEDULE=300,150,60: instead, the bucketed exchange SCHEDULE of a rank - the staged backward with a stand-in behind every
+bucket that lasts as long as a ring all-reduce of that bucket at the given bus bandwidth (GB/s) over 8 ranks."""
 import ctypes as C, importlib, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -66,7 +68,63 @@ def run(menu, blocks, steps=12, warm=4):
     return e0.elapsed_time(e1) / steps
 
 
+def run_schedule(menu, blocks, gbps, world=8, steps=12, warm=4):
+    """The exchange SCHEDULE of a data-parallel rank: the staged backward (head, layer L-1 ... 0, embeddings), behind every bucket a stand-in
+    that stays as long as a ring all-reduce of the bucket would at `gbps` GB/s of bus bandwidth (+ 30 us of latency) over `world` ranks."""
+    for k, v in MENUS[menu]:
+        L.check(lib.gget_debug_set(k, v))
+    L.check(lib.gget_debug_set(16, 1))
+    e = model._engine
+    nl = e.spec.num_layers
+    main = torch.cuda.current_stream()
+
+    def bucket(b):
+        if not blocks:
+            return
+        us = int(30 + 2.0 * (world - 1) / world * e.buckets[b][1] * 2 / (gbps * 1e3))
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        L.check(lib.gget_debug_occupy(C.c_void_p(scratch.data_ptr()), scratch.numel(), blocks, RCCL_LDS, us, C.c_void_p(side.cuda_stream)))
+
+    def step():
+        eng(input_ids=dev["input_ids"], attention_mask=dev["attention_mask"], labels=dev["labels"], num_tokens=n_tok)
+        e.backward_begin()
+        bucket(0)
+        for i in range(nl - 1, -1, -1):
+            e.backward_layer(i)
+            bucket(nl - i)
+        e.backward_end()
+        bucket(nl + 1)
+        if blocks:
+            main.wait_stream(side)
+        eng.step()
+    for _ in range(warm):
+        step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
 rows = []
+if os.environ.get("DP_STANDIN_SCHEDULE"):      # "gbps[,gbps...]": the bucketed schedule instead of one stand-in for the whole backward
+    mb = [round(c * 2 / 2 ** 20, 1) for _, c in model._engine.buckets]
+    print("buckets (MiB, completion order):", mb)
+    for gbps in [float(x) for x in os.environ["DP_STANDIN_SCHEDULE"].split(",")]:
+        for menu in ("single", "r4", "r5_32"):
+            for blocks in (0, 16):
+                ms = [run_schedule(menu, blocks, gbps) for _ in range(2)]
+                rows.append({"schedule_gbps": gbps, "menu": menu, "standin_workgroups": blocks, "ms_per_step": ms})
+                print(f"schedule at {gbps:.0f} GB/s bus bandwidth, 8 ranks: menu {menu:6s} stand-in workgroups {blocks:3d}: {ms[0]:.3f} / {ms[1]:.3f} ms/step", flush=True)
+    for k, v in MENUS["single"] + [(16, 0)]:
+        L.check(lib.gget_debug_set(k, v))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "dp_standin_schedule.json")
+    json.dump({"rows": rows, "buckets_mib": mb}, open(out, "w"), indent=1)
+    sys.exit(0)
 ONLY = os.environ.get("DP_STANDIN_ONLY")      # "menu:blocks" - one configuration (for a kernel trace)
 for rnd in range(2):
     for menu in ("single", "r4", "r5", "r5_32", "r5_64"):

@@ -78,10 +78,14 @@ def run_schedule(menu, blocks, gbps, world=8, steps=12, warm=4):
     nl = e.spec.num_layers
     main = torch.cuda.current_stream()
 
+    eng.bucket_mb = float(os.environ.get("DP_STANDIN_BUCKET_MB", "0"))      # (GGET_DP_BUCKET_MB: consecutive buckets in ONE collective)
+    eng._groups = None
+    groups = eng.exchange_groups(e)
+
     def bucket(b):
-        if not blocks:
+        if not blocks or b not in groups:
             return
-        us = int(30 + 2.0 * (world - 1) / world * e.buckets[b][1] * 2 / (gbps * 1e3))
+        us = int(30 + 2.0 * (world - 1) / world * groups[b][1] * 2 / (gbps * 1e3))
         ev = torch.cuda.Event()
         ev.record(main)
         side.wait_event(ev)
@@ -115,7 +119,7 @@ if os.environ.get("DP_STANDIN_SCHEDULE"):      # "gbps[,gbps...]": the bucketed 
     mb = [round(c * 2 / 2 ** 20, 1) for _, c in model._engine.buckets]
     print("buckets (MiB, completion order):", mb)
     for gbps in [float(x) for x in os.environ["DP_STANDIN_SCHEDULE"].split(",")]:
-        for menu in ("single", "r4", "r5_32"):
+        for menu in os.environ.get("DP_STANDIN_MENUS", "single,r4,r5_32").split(","):
             for blocks in (0, 16):
                 ms = [run_schedule(menu, blocks, gbps) for _ in range(2)]
                 rows.append({"schedule_gbps": gbps, "menu": menu, "standin_workgroups": blocks, "ms_per_step": ms})

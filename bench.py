@@ -56,14 +56,14 @@ def flops_per_step(spec, B, S, M, Lm, kind="pt", rows=None, lengths=None):
     return 3.0 * fwd
 
 
-def cpu_baseline(spec, state, B, S, F, V, seed, threads, budget_s=30.0):
+def cpu_baseline(spec, state, B, S, F, V, seed, threads, budget_s=30.0, tail=None):
     """Oracle (CPU port of the reference path, parity-pinned) timed on the host cores: fwd + bwd + AdamW, fp32, on the
     SAME batch shape as the GPU run (B x S x F of the workload, same generator and seed), bounded in time: one warm-up step
     and as many timed steps as fit in ~budget_s seconds (at least one)."""
     from oracle import gget_oracle as O
     synth = importlib.import_module("graph-gpt_amd.synth")
     torch.set_num_threads(threads)
-    b = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=seed)
+    b = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=seed, **(tail or {}))
     tb = {k: torch.from_numpy(v) for k, v in b.items()}
     # parity leg (the oracle as CHECKER, not timed): SMTP loss of the oracle's forward on the bench batch, weights rounded to bf16 first
     # (the cast point of the engine's compute copy) - compared with the engine's eval-mode forward in `loss_parity`
@@ -237,6 +237,13 @@ def main():
                     help="distinct synthetic batches the steps rotate through (pre-train workloads; every batch has its own lengths, so the "
                          "var-len row count - and with it the launch shapes - changes from step to step like in a real epoch; 1 = the "
                          "single repeated batch of rounds 1-3)")
+    ap.add_argument("--seq-len", type=int, default=0,
+                    help="padded width S of the pre-train workloads (SURVEY 8d: the C1 sweep S = 24 / 32 / 40 / 56).  The collator pads a batch to "
+                         "8 * ceil(max_len / 8) of its longest graph (reference src/data/collator.py:70-111), so real PCQM4M-v2 batches of 256 graphs "
+                         "are rarely S <= 32; the lengths keep the workload's distribution (clipped N(22, 6), one graph of the batch at the full width). "
+                         "0 = the workload's own S (the headline line)")
+    ap.add_argument("--long-tail", type=float, default=0.0,
+                    help="fraction of the graphs redrawn uniformly from (32, S] (a heavier long tail than the clipped normal's; needs --seq-len > 32)")
     ap.add_argument("--layout", default="varlen", choices=["varlen", "varlen-count", "padded"],
                     help="token layout of the timed steps.  varlen (default): the call of the reference's own step - device-resident "
                          "tensors, no token count passed - the engine counts the mask on the device and runs the padding-free layout; "
@@ -268,6 +275,10 @@ def main():
     training = importlib.import_module("graph-gpt_amd.training")
 
     kind, size, B, S, F, V = WORKLOADS[a.workload]
+    if a.seq_len:
+        assert kind == "pt", "--seq-len: pre-train workloads"
+        S = a.seq_len
+    tail = dict(long_tail=a.long_tail) if a.long_tail > 0 else {}
     sz = spec_mod.MODEL_SIZES[size]
     pt = kind.startswith("pt")
     extra = {}
@@ -287,9 +298,9 @@ def main():
                                                              max_grad_norm=1.0))
     extra_batches = []
     if kind == "pt":
-        batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=1234 + rank)     # distinct data per rank
+        batch = synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=1234 + rank, **tail)     # distinct data per rank
         real_tokens = synth.real_tokens(batch)
-        extra_batches = [synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=1234 + rank + 1000 * i) for i in range(1, max(1, a.batches))]
+        extra_batches = [synth.make_pretrain_batch(B=B, S=S, F=F, V=V, seed=1234 + rank + 1000 * i, **tail) for i in range(1, max(1, a.batches))]
     elif kind == "pt-packed":
         batch = synth.make_packed_pretrain_batch(B=B, S=S, F=F, V=V, seed=1234 + rank, mean_len=22, min_len=6)
         real_tokens = int(batch["lengths"].sum())
@@ -539,7 +550,7 @@ def main():
                                       "K steps each, outside the reported time"}
         if world == 1 and not a.no_cpu_baseline and kind == "pt":
             state = weights.make_state_dict(spec, seed=0)
-            out["cpu_baseline"], oracle_loss = cpu_baseline(spec, state, B, S, F, V, 1234, min(os.cpu_count() or 1, 32))
+            out["cpu_baseline"], oracle_loss = cpu_baseline(spec, state, B, S, F, V, 1234, min(os.cpu_count() or 1, 32), tail=tail)
             if gpu_eval_loss is not None:
                 out["loss_parity"] = {"gpu_eval_loss": gpu_eval_loss, "oracle_loss": oracle_loss,
                                       "rel": abs(gpu_eval_loss - oracle_loss) / abs(oracle_loss),

@@ -12,6 +12,7 @@
 // gfx950's ds_read_b64_tr_b16.  Backward = delta kernel + dQ kernel (per query tile) + dK/dV kernel
 // (per key tile); no atomics, P recomputed from the saved log-sum-exp.
 #include <stdlib.h>
+#include <algorithm>
 
 #include "common.h"
 #include "kernels.h"
@@ -253,6 +254,8 @@ struct KeyRange {
   // [row_base[b], row_base[b] + key_len[b]).  nullptr = padded layout, sample b at rows [b * S, b * S + S).  Logical [B,S] arrays
   // (lse, delta, position ids, the dropout hash coordinates) keep their (b, s) indexing in both layouts.  Not combined with lo / hi.
   const int32_t* row_base;
+  // var-len layout, S <= 64: samples with more rows than this belong to another launch (attn_fwd_long_kernel) - their blocks exit.  0 = none.
+  int skip_over;
 };
 // wave-uniform min / max of small non-negative integers (exact in fp32)
 __device__ __forceinline__ int wave_imin(int v) { return (int)-wave_max(-(float)v); }
@@ -386,6 +389,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
   // var-len token layout (KR.row_base): sample b owns rows [rb, rb + SL) of the token-major buffers; padded layout: rb = b * S, SL = S
   const int rb = KR.row_base ? KR.row_base[b] : b * S;
   const int SL = KR.row_base ? KR.key_len[b] : S;
+  // var-len layout: the grid is sized by the padded width S (the batch's longest graph, reference src/data/collator.py:70-111), the
+  // sample owns SL rows - blocks wholly behind them have nothing to load or store (at S = 40 / 56 nineteen graphs in twenty are <= 32
+  // tokens: without this exit their second block staged every K / V tile for nothing, 20.0 us per launch against 11.9 at S = 32)
+  if (KR.row_base && (int)blockIdx.x * NW * 32 >= SL) return;
+  if (KR.row_base && KR.skip_over && SL > KR.skip_over) return;      // (the sample is attn_fwd_long_kernel's)
   const int q0 = (blockIdx.x * NW + wave) * 32;
   const int d = H * 64;
   const size_t pitch = (size_t)3 * d;
@@ -489,6 +497,109 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
   }
 }
 
+// Samples of 33 .. 64 rows on the var-len layout with S <= 64 (round 6), as their OWN launch next to attn_fwd_kernel<1> (whose blocks of
+// these samples exit).  Why: the S <= 64 forward is ONE round of thousands of one-wave blocks, twelve per CU; it lasts as long as its
+// slowest block, and under that load every global round trip of a block costs ~3 us.  A 33 .. 64-row sample walks two key tiles - two
+// more dependent round trips - so with nineteen graphs in twenty at <= 32 tokens the launch still ran 20.0 us at S = 40 against 11.9 at
+// S = 32 (issue priority for the long blocks changed nothing: they wait on memory, not on issue slots).  Here the few long samples
+// (the collator pads to the batch's LONGEST graph, reference src/data/collator.py:70-111) get a block of TWO waves - wave w = query tile
+// w - that requests all four K / V tiles at once and runs on a nearly empty chip.  The arithmetic is attn_fwd_kernel<1>'s, step by step
+// (online softmax over key tile 0, then 1): same bits.  q / k are read as they are in memory (rotated - the engine's layout - or plain).
+// long_list (may be NULL): [0] = number of such samples, [1 ..] their indices (varlen_scan_kernel); NULL = every block tests its own sample.
+__global__ void __launch_bounds__(128, 2) attn_fwd_long_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
+                                                               const int32_t* __restrict__ row_base, bf16_t* __restrict__ out,
+                                                               float* __restrict__ lse, int B, int S, int H, int causal, Drop D,
+                                                               const int32_t* __restrict__ long_list) {
+  __shared__ __attribute__((aligned(16))) unsigned char tiles[4][4096];   // K0 K1 V0 V1
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y;
+  const int n_items = long_list ? min(long_list[0], B) : B;
+  for (int it = blockIdx.z; it < n_items; it += gridDim.z) {
+    const int b = long_list ? long_list[1 + it] : it;
+    const int rb = row_base[b];
+    const int SL = key_len[b];
+    if (SL <= 32 || SL > 64) continue;      // (block-uniform)
+    const int d = H * 64;
+    const size_t pitch = (size_t)3 * d;
+    const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
+    const bf16_t* kb = qb + d;
+    const bf16_t* vb = qb + 2 * d;
+    const Rope Rnone{nullptr, nullptr, nullptr, S};
+    const int q0 = 32 * w, qrow = q0 + l31;
+    const int qhi = min(SL, S) - 1;                 // keys [0, qhi]
+    TilePref<128> pf[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      tile_fetch<128>(pf[t], kb, 32 * t, SL, pitch, tid, Rnone);
+      tile_fetch<128>(pf[2 + t], vb, 32 * t, SL, pitch, tid, Rnone);
+    }
+    bf16x8_t qf[4];
+    frags_global_rope(qf, qb, qrow, SL, pitch, lane, Rnone, b);
+    __syncthreads();      // (the previous item's tiles are consumed)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) tile_commit<128>(tiles[t], pf[t], 32 * (t & 1), SL, tid, Rnone, b);
+    __syncthreads();
+    f32x16_t o0 = zero16(), o1 = zero16();
+    float m = -INFINITY, l = 0.f;
+    const unsigned dbase = drop_base(D, b * H + h, qrow, 0);
+    const int kend = (q0 < SL) ? min(qhi + 1, causal ? q0 + 32 : SL) : 0;
+#pragma unroll
+    for (int kt_i = 0; kt_i < 2; ++kt_i) {
+      const int k0 = 32 * kt_i;
+      if (k0 >= kend) continue;
+      const unsigned char* kt = tiles[kt_i];
+      const unsigned char* vt = tiles[2 + kt_i];
+      f32x16_t sc = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), qf[s], sc, 0, 0, 0);
+      const bool edge = (k0 + 31 > qhi) || (causal && k0 + 31 > q0) || (q0 + 32 > SL);
+      float mx = -INFINITY;
+      if (edge) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + acc_row(r, hi);
+          const bool ok = key <= qhi && (!causal || key <= qrow);
+          sc[r] = ok ? sc[r] : -INFINITY;
+          mx = fmaxf(mx, sc[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m, mx * kScaleL2);
+      const bool dead = m_new == -INFINITY;
+      const float alpha = dead ? 1.f : fast_exp2(m - m_new);
+      const float nm = dead ? 0.f : -m_new;
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(fmaf(sc[r], kScaleL2, nm));
+        rs += p;
+        sc[r] = p * drop_mul_x(D, dbase + (unsigned)((k0 + acc_row(r, hi)) >> 1) * 0xC2B2AE3Du, r & 1);
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      l = l * alpha + rs;
+      m = m_new;
+      if (__any(alpha != 1.f)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      }
+      const bf16x8_t pb0 = acc_to_b(sc, 0), pb1 = acc_to_b(sc, 1);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 0, lane), pb0, o0, 0, 0, 0);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 1, lane), pb1, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 0, lane), pb0, o1, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 1, lane), pb1, o1, 0, 0, 0);
+    }
+    if (qrow < SL) {
+      const float inv = l > 0.f ? 1.f / l : 0.f;
+      store_t(out + ((size_t)rb + qrow) * d + h * 64, o0, o1, inv, hi);
+      if (hi == 0 && lse) lse[((size_t)b * H + h) * S + qrow] = l > 0.f ? (m + log2f(l)) * (1.0f / kLog2e) : 0.f;
+    }
+  }
+}
+
 // dQ^T[dh][q] = sum_keys K^T[dh][key] dS^T[key][q],  dS^T = P^T (dP^T - delta_q) * scale
 // Block = NW query tiles; the K tile (rotated if Rin) and the V tile are shared through LDS.
 template <int NW, bool PK>
@@ -504,6 +615,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dq_kernel(c
   // var-len token layout (KR.row_base): sample b owns rows [rb, rb + SL) of the token-major buffers; padded layout: rb = b * S, SL = S
   const int rb = KR.row_base ? KR.row_base[b] : b * S;
   const int SL = KR.row_base ? KR.key_len[b] : S;
+  if (KR.row_base && (int)blockIdx.x * NW * 32 >= SL) return;     // (var-len layout: no rows of this sample in the block, see attn_fwd_kernel)
   const int q0 = (blockIdx.x * NW + wave) * 32;
   const int d = H * 64;
   const size_t pitch = (size_t)3 * d;
@@ -615,6 +727,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
   // var-len token layout (KR.row_base): sample b owns rows [rb, rb + SL) of the token-major buffers; padded layout: rb = b * S, SL = S
   const int rb = KR.row_base ? KR.row_base[b] : b * S;
   const int SL = KR.row_base ? KR.key_len[b] : S;
+  if (KR.row_base && (int)blockIdx.x * NW * 32 >= SL) return;     // (var-len layout: no rows of this sample in the block, see attn_fwd_kernel)
   const int k0 = (blockIdx.x * NW + wave) * 32;
   const int d = H * 64;
   const size_t pitch = (size_t)3 * d;
@@ -729,10 +842,179 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_bwd_dkv_kernel(
   }
 }
 
-// S <= 32: one wave holds the whole (batch, head) problem, so the backward is ONE launch: the K, Q and dO tiles go to
+// A sample of 33 .. 64 rows (round 6): the S <= 32 kernel below over 2 x 2 tiles, as its OWN launch next to it.  The collator pads a batch
+// to the width of its LONGEST graph (reference src/data/collator.py:70-111), so at B = 256 the padded width is 40 - 56 while nineteen
+// graphs in twenty are still <= 32 tokens: the backward is keyed on each sample's own row count, not on S (the S > 32 path before:
+// attn_bwd_dq_kernel<1> 43.8 us + attn_bwd_dkv_kernel<1> 48.8 us per layer at S = 40 against 21 us for the one-tile kernel).
+// Block = TWO waves on one (sample, head); samples outside 33 .. 64 rows exit at once (they are the one-tile kernel's).  All six tiles
+// (K, Q, dO x two 32-row tiles, 24 KiB) are requested up front and staged once; then
+//   part 1  wave w = query tile w: scores and dP against BOTH key tiles stay in registers, so delta = sum_k P dP covers the whole row as in
+//           the one-tile kernel; dQ_w^T = sum_j K_j^T dS_wj^T
+//   part 2  wave w = key tile w: dK_w^T = sum_i Q_i^T dS_iw, dV_w^T = sum_i dO_i^T P_iw
+// Why a second launch and not a branch of the one-tile kernel: inlined there the body spilled 178 - 313 registers of the COMMON path's
+// allocation (168 at three waves per SIMD), as a called function it ran from 1.3 KiB of scratch per lane - 116 us per launch.  These few
+// blocks (5 % of the samples) want registers and no neighbours; the thousands of one-tile blocks want occupancy.
+// q and k are read as they are in memory (rotated already - the engine's layout - or no rotation at all); R rotates dq / dk back.
+__device__ __attribute__((noinline)) void attn_bwd_long_item(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                             const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int b, int rb, int SL,
+                                                             int klen_b, int S, int H, int causal, const Rope& R, const Drop& D) {
+  __shared__ __attribute__((aligned(16))) unsigned char tiles[6][4096];   // K0 K1 Q0 Q1 dO0 dO1
+  __shared__ float lse_s[64], dl_s[64];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y;
+  const int d = H * 64;
+  const size_t pitch = (size_t)3 * d;
+  const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
+  const bf16_t* kb = qb + d;
+  const bf16_t* vb = qb + 2 * d;
+  const bf16_t* dob = dout + (size_t)rb * d + h * 64;
+  const int klen = min(klen_b, S);
+  const Rope Rnone{nullptr, nullptr, nullptr, S};
+  TilePref<128> pf[6];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    tile_fetch<128>(pf[t], kb, 32 * t, SL, pitch, tid, Rnone);
+    tile_fetch<128>(pf[2 + t], qb, 32 * t, SL, pitch, tid, Rnone);
+    tile_fetch<128>(pf[4 + t], dob, 32 * t, SL, (size_t)d, tid, Rnone);
+  }
+  // the wave's own 32 rows (query tile w in part 1, key tile w in part 2): V rows as MFMA operands, lse, the angle-table pieces of the
+  // final rotation - all requested before the first wait
+  const int myrow = 32 * w + l31;
+  bf16x8_t vf[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) vf[j][s] = frag_global(vb, 32 * j + l31, SL, pitch, s, lane);
+  const float nlse2 = -lse[((size_t)b * H + h) * S + min(myrow, S - 1)] * kLog2e;
+  float4 rc[4], rs[4];
+  if (R.cos_tab) rope_fetch(R, rope_pos(R, b, min(myrow, S - 1)), hi, rc, rs);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    tile_commit<128>(tiles[t], pf[t], 32 * t, SL, tid, Rnone, b);
+    tile_commit<128>(tiles[2 + t], pf[2 + t], 32 * t, SL, tid, Rnone, b);
+    tile_commit<128>(tiles[4 + t], pf[4 + t], 32 * t, SL, tid, Rnone, b);
+  }
+  if (hi == 0) lse_s[myrow] = nlse2;
+  __syncthreads();
+  const unsigned bh = b * H + h;
+  {   // ---------------- part 1: dQ of query tile w (lane owns query myrow)
+    const int qrow = myrow;
+    const unsigned char* qt = tiles[2 + w];
+    const unsigned char* dot_ = tiles[4 + w];
+    const unsigned dbase = drop_base(D, bh, qrow, 0);
+    f32x16_t sc[2], dp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      sc[j] = zero16(); dp[j] = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        dp[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j][s], frag_rows(dot_, s, lane), dp[j], 0, 0, 0);
+        sc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tiles[j], s, lane), frag_rows(qt, s, lane), sc[j], 0, 0, 0);
+      }
+    }
+    float dl = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * j + acc_row(r, hi);
+        const bool ok = key < klen && (!causal || key <= qrow) && qrow < SL;
+        const float p = ok ? fast_exp2(fmaf(sc[j][r], kScaleL2, nlse2)) : 0.f;
+        const float t = dp[j][r] * drop_mul_x(D, dbase + (unsigned)(key >> 1) * 0xC2B2AE3Du, key & 1);
+        dl = fmaf(p, t, dl);
+        sc[j][r] = p;
+        dp[j][r] = t;
+      }
+    dl += __shfl_xor(dl, 32, 64);
+    if (hi == 0) dl_s[qrow] = -dl;
+    f32x16_t a0 = zero16(), a1 = zero16();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[j][r] = sc[j][r] * (dp[j][r] - dl) * kScale;
+      const bf16x8_t ds0 = acc_to_b(sc[j], 0), ds1 = acc_to_b(sc[j], 1);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tiles[j], 0, 0, lane), ds0, a0, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tiles[j], 0, 1, lane), ds1, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tiles[j], 1, 0, lane), ds0, a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tiles[j], 1, 1, lane), ds1, a1, 0, 0, 0);
+    }
+    if (qrow < SL) {
+      if (R.cos_tab) unrope_acc_pre(a0, a1, rc, rs);
+      store_t(dqkv + ((size_t)rb + qrow) * pitch + h * 64, a0, a1, 1.f, hi);
+    }
+  }
+  __syncthreads();   // dl_s of both query tiles
+  {   // ---------------- part 2: dK, dV of key tile w (lane owns key myrow)
+    const int krow = myrow;
+    const bool key_ok = krow < klen;
+    const unsigned dbase = drop_base(D, bh, 0, (unsigned)krow >> 1);
+    const unsigned char* kt = tiles[w];
+    f32x16_t dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned char* qt = tiles[2 + i];
+      const unsigned char* dot_ = tiles[4 + i];
+      f32x16_t sc = zero16(), dp = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, s, lane), frag_rows(kt, s, lane), sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dot_, s, lane), w ? vf[1][s] : vf[0][s], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = 32 * i + acc_row(r, hi);
+        const bool ok = key_ok && q < SL && (!causal || krow <= q);
+        const float p = ok ? fast_exp2(fmaf(sc[r], kScaleL2, lse_s[q])) : 0.f;
+        const float dm = drop_mul_x(D, dbase + (unsigned)q * 0x85EBCA77u, krow & 1);
+        sc[r] = p * dm;
+        dp[r] = p * fmaf(dp[r], dm, dl_s[q]) * kScale;
+      }
+      const bf16x8_t p0 = acc_to_b(sc, 0), p1 = acc_to_b(sc, 1);
+      const bf16x8_t s0 = acc_to_b(dp, 0), s1 = acc_to_b(dp, 1);
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 0, lane), p0, dv0, 0, 0, 0);
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 0, 1, lane), p1, dv0, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 1, 0, lane), p0, dv1, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_, 1, 1, lane), p1, dv1, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 0, 0, lane), s0, dk0, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 0, 1, lane), s1, dk0, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 0, lane), s0, dk1, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt, 1, 1, lane), s1, dk1, 0, 0, 0);
+    }
+    if (krow < SL) {
+      bf16_t* row = dqkv + ((size_t)rb + krow) * pitch + h * 64;
+      if (R.cos_tab) unrope_acc_pre(dk0, dk1, rc, rs);
+      store_t(row + d, dk0, dk1, 1.f, hi);
+      store_t(row + 2 * d, dv0, dv1, 1.f, hi);
+    }
+  }
+}
+
+// (the launch: a block walks the list of 33 .. 64-row samples with the grid's stride; the per-sample body is a real call so that its
+//  registers are allocated once, not around the loop - inlined the loop form spilled 31 vector and 97 scalar registers)
+__global__ void __launch_bounds__(128, 2) attn_bwd_long_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                               const float* __restrict__ lse, const int32_t* __restrict__ key_len,
+                                                               bf16_t* __restrict__ dqkv, int B, int S, int H, int causal, Rope R, Drop D,
+                                                               const int32_t* __restrict__ row_base, const int32_t* __restrict__ long_list) {
+  // long_list (may be NULL): [0] = number of 33 .. 64-row samples, [1 ..] their indices (varlen_scan_kernel); NULL = every block tests its own
+  const int n_items = long_list ? min(long_list[0], B) : B;
+#pragma unroll 1
+  for (int it = blockIdx.z; it < n_items; it += gridDim.z) {
+    const int b = long_list ? long_list[1 + it] : it;
+    const int rb = row_base ? row_base[b] : b * S;
+    const int kl = key_len ? key_len[b] : S;
+    const int SL = row_base ? kl : S;
+    if (SL <= 32 || SL > 64) continue;      // (block-uniform)
+    __syncthreads();                         // (the previous item's tiles and tables are consumed)
+    attn_bwd_long_item(qkv, dout, lse, dqkv, b, rb, SL, kl, S, H, causal, R, D);
+  }
+}
+
+// rows <= 32: one wave holds the whole (batch, head) problem, so the backward is ONE launch: the K, Q and dO tiles go to
 // LDS once (V stays in registers), then the dQ part (scores transposed, lane = query; it also yields the softmax-backward row
 // term delta) and the dK/dV part (lane = key) run back to back on the same tiles.  Same arithmetic as attn_bwd_dq_kernel +
-// attn_bwd_dkv_kernel except that delta comes from P and dP in registers instead of rowsum(dO * O).
+// attn_bwd_dkv_kernel except that delta comes from P and dP in registers instead of rowsum(dO * O).  Launched for S <= 64: a sample with
+// more than 32 rows is attn_bwd_long_kernel's (above) and exits here.
 __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __restrict__ qkv,
                                                                const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                const int32_t* __restrict__ key_len, bf16_t* __restrict__ dqkv,
@@ -755,6 +1037,7 @@ __global__ void __launch_bounds__(64, 3) attn_bwd_small_kernel(const bf16_t* __r
   const bf16_t* dob = dout + (size_t)rb * d + h * 64;
   const int klen = key_len ? key_len[b] : S;
   const Rope Rnone{nullptr, nullptr, nullptr, S};
+  if (SL > 32) return;      // (wave-uniform: the sample is attn_bwd_long_kernel's)
   // (one tile at a time: issuing all 17 loads of a problem before the first wait - or K + V first, then Q + dO - measured SLOWER,
   //  29.4 / 28.7 against 23.4 us: with all 3072 problems resident at once the chip's memory queues overflow; profiles/r03_step_experiments.txt, item 14)
   load_tile_coop<64>(kt, kb, 0, SL, pitch, lane, Rin, b);
@@ -2648,6 +2931,12 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused64_kernel(const bf16_t* 
 
 // waves (= 32-row tiles) per block: long sequences share each K/V (or Q/dO) tile among 4 waves through LDS
 int attn_waves(int S) { return S >= 128 ? 4 : (S >= 64 ? 2 : 1); }
+// GGET_ATTN_BY_SAMPLE=0: the S-keyed launches of rounds 1 - 5 for 32 < S <= 64 (A/B switch of the per-sample dispatch)
+bool attn_by_sample_rows() {
+  static const int on = getenv("GGET_ATTN_BY_SAMPLE") ? atoi(getenv("GGET_ATTN_BY_SAMPLE")) : 1;
+  return on != 0;
+}
+constexpr int kLongGrid = 32;      // sample slots of a list-driven long launch (a block walks the list with this stride)
 
 Drop make_drop(float p, unsigned seed) {
   Drop d;
@@ -2661,12 +2950,23 @@ Drop make_drop(float p, unsigned seed) {
 
 int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
                const float* cos_tab, const float* sin_tab, const int64_t* position_ids, float dropout_p,
-               unsigned dropout_seed, hipStream_t st, const int32_t* key_lo, const int32_t* key_hi, const int32_t* row_base) {
+               unsigned dropout_seed, hipStream_t st, const int32_t* key_lo, const int32_t* key_hi, const int32_t* row_base,
+               const int32_t* long_list) {
   GGET_REQUIRE(!row_base || (key_len && !key_lo), "attention: the var-len token layout needs key_len and excludes per-token key ranges");
-  const KeyRange KR{key_len, key_lo, key_hi, row_base};
+  KeyRange KR{key_len, key_lo, key_hi, row_base};
   if (B == 0 || S == 0) return 0;
   const Rope R{cos_tab, sin_tab, position_ids, S};
   const Drop D = make_drop(dropout_p, dropout_seed);
+  // var-len layout, 32 < S <= 64 (the collator pads to the batch's longest graph, most samples are still one 32-row tile): every sample by
+  // its OWN row count - the one-wave kernel takes the samples of <= 32 rows, attn_fwd_long_kernel the few longer ones
+  if (row_base && S > 32 && S <= 64 && !cos_tab && attn_by_sample_rows()) {
+    KR.skip_over = 32;
+    hipLaunchKernelGGL((attn_fwd_kernel<1, false>), dim3(1, H, B), dim3(64), 0, st, (const bf16_t*)qkv, KR, (bf16_t*)out, lse, B, S, H, causal, R, D);
+    hipLaunchKernelGGL(attn_fwd_long_kernel, dim3(1, H, long_list ? std::min(B, kLongGrid) : B), dim3(128), 0, st, (const bf16_t*)qkv, key_len, row_base,
+                       (bf16_t*)out, lse, B, S, H, causal, D, long_list);
+    GGET_LAUNCH_CHECK();
+    return 0;
+  }
   static int big = -1;
   if (big < 0) { const char* e = getenv("GGET_ATTN_BIG"); big = e ? atoi(e) : 1; }
   if (S >= 256 && !cos_tab && big) {   // long sequences with q / k already rotated (the engine's layout): 64-row DMA stages
@@ -2784,7 +3084,8 @@ int k_attn_oproj_bwd(const void* dxn, const void* x_mid, const void* nw, const f
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
                const int64_t* position_ids, int qk_rotated, float dropout_p, unsigned dropout_seed, hipStream_t st,
-               const int32_t* key_lo, const int32_t* key_hi, const int32_t* row_base, void* dq_ws, size_t dq_slab_stride) {
+               const int32_t* key_lo, const int32_t* key_hi, const int32_t* row_base, void* dq_ws, size_t dq_slab_stride,
+               const int32_t* long_list) {
   GGET_REQUIRE(!row_base || (key_len && !key_lo), "attention: the var-len token layout needs key_len and excludes per-token key ranges");
   const KeyRange KR{key_len, key_lo, key_hi, row_base};
   if (B == 0 || S == 0) return 0;
@@ -2793,9 +3094,17 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
   const Drop D = make_drop(dropout_p, dropout_seed);
   static int small = -1;
   if (small < 0) { const char* e = getenv("GGET_ATTN_SMALL"); small = e ? atoi(e) : 1; }
-  if (S <= 32 && !key_lo && small) {
-    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(1, H, B), dim3(64), 0, st, (const bf16_t*)qkv,
-                       (const bf16_t*)dout, lse, key_len, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D, row_base);
+  if ((S <= 32 || (S <= 64 && !Rin.cos_tab && attn_by_sample_rows())) && !key_lo && small) {      // every sample by its OWN row count: one 32-row tile, or (33 .. 64 rows) 2 x 2
+    if (S <= 32 || row_base)        // (padded layout with S > 32: every sample owns S rows - nothing for the one-tile kernel)
+      hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(1, H, B), dim3(64), 0, st, (const bf16_t*)qkv,
+                         (const bf16_t*)dout, lse, key_len, (bf16_t*)dqkv, B, S, H, causal, Rin, R, D, row_base);
+    if (S > 32) {
+      // (on a second stream beside the dense launch the sparse one made the step SLOWER - 7.39 -> 7.80 ms at S = 40: the fork / join
+      //  barrier packets cost more than the 15 us they hide; profiles/r06_attn_side_lane_experiment.diff)
+      const int32_t* list = row_base ? long_list : nullptr;
+      hipLaunchKernelGGL(attn_bwd_long_kernel, dim3(1, H, list ? std::min(B, kLongGrid) : B), dim3(128), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+                         key_len, (bf16_t*)dqkv, B, S, H, causal, R, D, row_base, list);
+    }
     GGET_LAUNCH_CHECK();
     return 0;
   }

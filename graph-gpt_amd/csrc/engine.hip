@@ -201,6 +201,7 @@ struct Ws {
   // var-len token layout: first compact row of every sample [max_batch + 1], per compact row its sample index / position / ids, the
   // padded -> compact row map [max_tokens], a status word
   uint64_t vl_cu, vl_rowb, vl_pos, vl_ids, vl_pad2c, vl_c2p, vl_status;   // (vl_c2p: compact -> padded row map [max_tokens])
+  uint64_t vl_long;   // [max_batch + 1] int32: count and indices of the batch's 33 .. 64-row samples (varlen_scan_kernel)
   uint64_t wo_pack = 0, wot_pack = 0;   // fragment-major copies of every layer's o weight / its transpose (S <= 32 per-sample kernels), [L][d][d] bf16
   uint64_t pos_safe;   // position ids clamped into the RoPE table (int64 [max_tokens]); the sticky "clamped" flag is vl_status[1]
   uint64_t sk_ws;      // stream-K GEMM launches: flags + one fp32 partial tile per block (gemm.h)
@@ -265,6 +266,7 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.wg32 = b.take(kWgSplit * 4 * d * d * 4);   // split-K slabs of the q|k|v|o wgrad
   w.long_wgt = b.take((uint64_t)c.max_batch * 4);
   w.vl_cu = b.take((Bm + 1) * 4);
+  w.vl_long = b.take((Bm + 1) * 4);
   w.vl_rowb = b.take(T * 4);
   w.vl_pos = b.take(T * 8);
   w.vl_ids = b.take(T * (uint64_t)c.stacked_feat * 8);
@@ -394,6 +396,7 @@ struct gget_engine {
   int32_t* host_word = nullptr;   // pinned host word the counted total lands in
   const int64_t* pos_rows = nullptr;   // position of every ROW (GEMM RoPE epilogue): pos_cur, or the compacted positions
   const int32_t* row_base() const { return varlen ? wsp<int32_t>(ws.vl_cu) : nullptr; }
+  const int32_t* long_list() const { return varlen ? wsp<int32_t>(ws.vl_long) : nullptr; }
   const int64_t* ids = nullptr;
   const int64_t* pos = nullptr;
   const float* sample_wgt = nullptr;
@@ -1263,7 +1266,7 @@ int layer_forward(gget_engine* h, int i, hipStream_t st) {
   }
   if (int e = k_attn_fwd(qkv, h->wsp<int32_t>(h->ws.key_len), attn, h->wsp<float>(lw.lse), h->B, h->S, H, c.causal,
                          nullptr, nullptr, nullptr, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, st, h->klo(),
-                         h->khi(), h->row_base()))
+                         h->khi(), h->row_base(), h->long_list()))
     return e;
   if (h->plan.has_res) {
     bf16_t* araw = h->wsp<bf16_t>(lw.araw);
@@ -1413,7 +1416,8 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
     if (int e = k_varlen_plan(ids, ldF, c.stacked_feat, h->pos_cur, h->wsp<int32_t>(w.key_len),
                               c.kind == GGET_KIND_TASK ? h->wsp<int32_t>(w.pool_row) : nullptr, h->wsp<int32_t>(w.vl_cu),
                               h->wsp<int64_t>(w.vl_ids), h->wsp<int64_t>(w.vl_pos), h->wsp<int32_t>(w.vl_rowb), h->wsp<int32_t>(w.vl_pad2c),
-                              h->wsp<int32_t>(w.vl_c2p), h->wsp<int32_t>(w.vl_status), B, S, h->tc, h->T, c.pad_token_id, st))
+                              h->wsp<int32_t>(w.vl_c2p), h->wsp<int32_t>(w.vl_status), B, S, h->tc, h->T, c.pad_token_id, st,
+                              h->wsp<int32_t>(w.vl_long)))
       return e;
     h->ids = ids = h->wsp<int64_t>(w.vl_ids);
     ldF = c.stacked_feat;
@@ -1732,7 +1736,7 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
                          h->klo(), h->khi(), h->row_base(),
                          /* the slabs were sized for ceil(max_tokens / max_batch / 256) key blocks: a call with fewer, longer rows keeps the two-kernel form */
                          (w.dq_acc && (uint64_t)(h->S + 255) / 256 <= (c.max_tokens / (c.max_batch > 0 ? c.max_batch : 1) + 255) / 256) ? h->wsp<bf16_t>(w.dq_acc) : nullptr,
-                         (size_t)c.max_tokens * d))
+                         (size_t)c.max_tokens * d, h->long_list()))
     return e;
   if (int e = gemm_nn(dqkv, h->P + lo.wqkv, dxn, T, d, 3 * d, 3 * d, d, d, nullptr, st)) return e;
   // (fused with the LayerScale backward of the layer below, this RMSNorm backward writes w.dscaled - which this layer's down_proj weight
@@ -2366,6 +2370,22 @@ extern "C" int gget_op_attn_bwd(const void* qkv, const void* out, const void* do
                                 void* stream) {
   return k_attn_bwd(qkv, out, dout, lse, key_len, dqkv, delta_ws, B, S, H, causal, cos_tab, sin_tab, position_ids,
                     /*qk_rotated=*/0, dropout_p, dropout_seed, (hipStream_t)stream);
+}
+extern "C" int gget_op_attn_fwd_varlen(const void* qkv, const int32_t* key_len, const int32_t* row_base, void* out, float* lse, int B, int S,
+                                       int H, int causal, const float* cos_tab, const float* sin_tab, const int64_t* position_ids,
+                                       int qk_rotated, float dropout_p, uint32_t dropout_seed, void* stream) {
+  GGET_REQUIRE(qkv && key_len && row_base && out, "attn_fwd_varlen: null argument");
+  // (rotated q / k: the forward reads them as they are)
+  return k_attn_fwd(qkv, key_len, out, lse, B, S, H, causal, qk_rotated ? nullptr : cos_tab, qk_rotated ? nullptr : sin_tab,
+                    qk_rotated ? nullptr : position_ids, dropout_p, dropout_seed, (hipStream_t)stream, nullptr, nullptr, row_base);
+}
+extern "C" int gget_op_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len,
+                                       const int32_t* row_base, void* dqkv, float* delta_ws, int B, int S, int H, int causal,
+                                       const float* cos_tab, const float* sin_tab, const int64_t* position_ids, int qk_rotated,
+                                       float dropout_p, uint32_t dropout_seed, void* stream) {
+  GGET_REQUIRE(qkv && dout && key_len && row_base && dqkv, "attn_bwd_varlen: null argument");
+  return k_attn_bwd(qkv, out, dout, lse, key_len, dqkv, delta_ws, B, S, H, causal, cos_tab, sin_tab, position_ids, qk_rotated, dropout_p,
+                    dropout_seed, (hipStream_t)stream, nullptr, nullptr, row_base);
 }
 extern "C" int gget_op_attn_bwd_fused(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len,
                                       const int32_t* key_lo, const int32_t* key_hi, void* dqkv, float* delta_ws, void* dq_ws, int B, int S,

@@ -63,7 +63,7 @@ int k_lengths(const int64_t* mask, const int64_t* ids, int ldF, int pad_id, int3
 // tokens.  pool_row (task head, may be NULL) is moved to the compact rows; status[0] = 1 if sum(key_len) != tc.
 int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, int32_t* key_len, int32_t* pool_row, int32_t* cu,
                   int64_t* ids_c, int64_t* pos_c, int32_t* row_b, int32_t* pad2c, int32_t* c2p, int32_t* status, int B, int S, int tc,
-                  int t_rows, int pad_id, hipStream_t st);      // c2p[r] = logical row b * S + s of compact row r
+                  int t_rows, int pad_id, hipStream_t st, int32_t* long_list = nullptr);      // c2p[r] = logical row b * S + s of compact row r
 // out = clamp(pos, 0, max_pos - 1); *flag = 1 (sticky) if anything was clamped
 int k_clamp_positions(const int64_t* pos, int64_t* out, int32_t* flag, long n, int max_pos, hipStream_t st);
 int k_remap_rows(int32_t* idx, const int32_t* count, const int32_t* pad2c, int cap, int pad_row, int32_t* status, hipStream_t st);
@@ -132,7 +132,7 @@ int k_convert_segments(const float* scratch, void* grads, const GgetSegment* seg
 int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, int B, int S, int H, int causal,
                const float* cos_tab, const float* sin_tab, const int64_t* position_ids, float dropout_p,
                unsigned dropout_seed, hipStream_t st, const int32_t* key_lo = nullptr, const int32_t* key_hi = nullptr,
-               const int32_t* row_base = nullptr);
+               const int32_t* row_base = nullptr, const int32_t* long_list = nullptr);
 // S <= 32: attention (all heads of a sample), the o projection + residual add and the RMSNorm behind it in one launch, one workgroup
 // per sample (attention.hip: attn_oproj_fwd_kernel).  qkv rotated [rows, 3d]; writes attn_out [rows, d] (kept for the backward), lse,
 // x_mid = x_in + attn_out Wo^T, xn = rmsnorm(x_mid) * nw, rstd [rows].  *taken = 1 when it ran (S <= 32, H in {2, 4, 8, 12, 16},
@@ -154,7 +154,7 @@ int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* 
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
                const int64_t* position_ids, int qk_rotated, float dropout_p, unsigned dropout_seed, hipStream_t st,
                const int32_t* key_lo = nullptr, const int32_t* key_hi = nullptr, const int32_t* row_base = nullptr,
-               void* dq_ws = nullptr, size_t dq_slab_stride = 0);   // dq_ws: bf16 [ceil(S / 256)][dq_slab_stride >= rows * H * 64] - S >= 256 (GGET_ATTN_FUSED_MIN_S) then runs the fused one-pass backward (attention.hip)
+               void* dq_ws = nullptr, size_t dq_slab_stride = 0, const int32_t* long_list = nullptr);   // dq_ws: bf16 [ceil(S / 256)][dq_slab_stride >= rows * H * 64] - S >= 256 (GGET_ATTN_FUSED_MIN_S) then runs the fused one-pass backward (attention.hip)
 // row_base ([B] int32, needs key_len): var-len (padding-free) token layout - sample b owns rows [row_base[b], row_base[b] + key_len[b]) of
 // qkv / out / dout / dqkv instead of [b * S, b * S + S); lse / delta / position ids stay [B,S]-indexed.
 // packed rows: inclusive key range [lo, hi] of every token from the block-diagonal mask [B,S,S] (first / last 1 of its row)

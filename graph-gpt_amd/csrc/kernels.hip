@@ -2287,13 +2287,16 @@ int k_lengths(const int64_t* mask, const int64_t* ids, int ldF, int pad_id, int3
 // one block: exclusive scan of key_len over the batch (any B), cu[B] = total; the pooled row of the task head (lengths_kernel: b*S + p)
 // moves to cu[b] + min(p, len - 1); status[0] = 1 when the total differs from the caller's token count (status[2]: the same, sticky -
 // gget_deferred_status reads and clears it)
+// long_list (may be NULL; int32 [B + 1]): [0] = number of samples of 33 .. 64 rows, [1 ..] their indices in ascending order - the work list
+// of the attention launches that take such samples apart from the one-tile ones (attention.hip: attn_fwd_long_kernel / attn_bwd_long_kernel)
 __global__ void __launch_bounds__(1024) varlen_scan_kernel(int32_t* __restrict__ key_len, int32_t* __restrict__ cu,
                                                            int32_t* __restrict__ pool_row, int32_t* __restrict__ status, int B, int S,
-                                                           int expect_total) {
+                                                           int expect_total, int32_t* __restrict__ long_list) {
   __shared__ int wsum[16];
-  __shared__ int carry_s;
+  __shared__ int lsum[16];
+  __shared__ int carry_s, lcarry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry_s = 0;
+  if (tid == 0) { carry_s = 0; lcarry_s = 0; }
   __syncthreads();
   for (int b0 = 0; b0 < B; b0 += 1024) {
     const int b = b0 + tid;
@@ -2308,11 +2311,12 @@ __global__ void __launch_bounds__(1024) varlen_scan_kernel(int32_t* __restrict__
     __syncthreads();
     int base = carry_s;
     for (int w = 0; w < wave; ++w) base += wsum[w];
+    int len = 0;
     if (b < B) {
       // (a caller's count SMALLER than the mask's total - flagged below, the step's results are invalid - must still not send any
       //  kernel behind the rows the step runs on: samples are cut at expect_total)
       const int start = min(base + x - v, expect_total);
-      const int len = min(v, expect_total - start);
+      len = min(v, expect_total - start);
       cu[b] = start;
       if (len != v) key_len[b] = len;
       if (pool_row) {
@@ -2320,11 +2324,28 @@ __global__ void __launch_bounds__(1024) varlen_scan_kernel(int32_t* __restrict__
         pool_row[b] = min(start + max(min(pidx, len - 1), 0), max(expect_total - 1, 0));
       }
     }
+    // the 33 .. 64-row samples, in batch order (ballot + prefix count: deterministic)
+    const bool is_long = len > 32 && len <= 64;
+    const unsigned long long bal = __ballot(is_long);
+    if (lane == 0) lsum[wave] = __popcll(bal);
     __syncthreads();
-    if (tid == 1023) carry_s = base + x;
+    if (long_list && is_long) {
+      int lpos = lcarry_s;
+      for (int w = 0; w < wave; ++w) lpos += lsum[w];
+      lpos += __popcll(bal & ((1ull << lane) - 1ull));
+      long_list[1 + lpos] = b;
+    }
+    __syncthreads();
+    if (tid == 1023) {
+      carry_s = base + x;
+      int lt = lcarry_s;
+      for (int w = 0; w < 16; ++w) lt += lsum[w];
+      lcarry_s = lt;
+    }
     __syncthreads();
   }
   if (tid == 0) {
+    if (long_list) long_list[0] = lcarry_s;
     cu[B] = min(carry_s, expect_total);
     status[0] = carry_s == expect_total ? 0 : 1;
     if (carry_s != expect_total) status[2] = 1;
@@ -2410,8 +2431,8 @@ int k_clamp_positions(const int64_t* pos, int64_t* out, int32_t* flag, long n, i
 
 int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, int32_t* key_len, int32_t* pool_row, int32_t* cu,
                   int64_t* ids_c, int64_t* pos_c, int32_t* row_b, int32_t* pad2c, int32_t* c2p, int32_t* status, int B, int S, int tc,
-                  int t_rows, int pad_id, hipStream_t st) {
-  hipLaunchKernelGGL(varlen_scan_kernel, dim3(1), dim3(1024), 0, st, key_len, cu, pool_row, status, B, S, tc);
+                  int t_rows, int pad_id, hipStream_t st, int32_t* long_list) {
+  hipLaunchKernelGGL(varlen_scan_kernel, dim3(1), dim3(1024), 0, st, key_len, cu, pool_row, status, B, S, tc, long_list);
   const long n = (long)B * S + (t_rows - tc);
   hipLaunchKernelGGL(varlen_fill_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, ids, ldF, F, pos, key_len, cu,
                      ids_c, pos_c, row_b, pad2c, c2p, B, S, tc, t_rows, (int64_t)pad_id);

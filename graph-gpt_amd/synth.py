@@ -35,14 +35,18 @@ def _lengths(rng, B, S, mode: str, min_len: int):
 
 def make_pretrain_batch(B: int, S: int, F: int, V: int, seed: int = 1234, *, lengths: str = "pcqm",
                         min_len: int = 4, first_id: int = 22, power: float = 1.0,
-                        umr_clip=(0.01, 0.99), dlm_wgt: bool = False, force_full_row: bool = True
-                        ) -> Dict[str, np.ndarray]:
+                        umr_clip=(0.01, 0.99), dlm_wgt: bool = False, force_full_row: bool = True,
+                        long_tail: float = 0.0) -> Dict[str, np.ndarray]:
     """SMTP pre-train batch: input_ids/labels i64 [B,S,F], attention_mask/position_ids i64 [B,S]."""
     assert S % 8 == 0 or True  # collator pads to a multiple of 8; callers choose S accordingly
     rng = np.random.RandomState(seed)
     lens = _lengths(rng, B, S, lengths, min_len)
     if force_full_row and lengths != "full":
         lens[rng.randint(B)] = S  # the batch max defines S in the real collator
+    if long_tail > 0.0 and S > 32:   # a heavier long tail (bench.py --long-tail): own generator, the other draws stay those of long_tail = 0
+        rt = np.random.RandomState(seed ^ 0x5A17)
+        pick = rt.random_sample(B) < long_tail
+        lens[pick] = rt.randint(33, S + 1, size=int(pick.sum()))
     ids = np.zeros((B, S, F), np.int64)
     labels = np.full((B, S, F), LABEL_PAD, np.int64)
     att = np.zeros((B, S), np.int64)

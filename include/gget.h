@@ -425,6 +425,19 @@ int gget_op_attn_bwd(const void* qkv, const void* out, const void* dout, const f
                      void* dqkv, float* delta_ws, int B, int S, int H, int causal, const float* cos_tab,
                      const float* sin_tab, const int64_t* position_ids, float dropout_p, uint32_t dropout_seed,
                      void* stream);
+/* The two above on the padding-free (var-len) token layout: row_base (int32 [B]) = first row of sample b in the token-major buffers
+ * (qkv / out / dout / dqkv hold the samples' real rows back to back, key_len[b] of them for sample b); lse / delta keep their [B, H, S]
+ * indexing, S = the padded width the collator produced (8 * ceil(longest graph / 8), reference src/data/collator.py:70-111).  Every
+ * sample is processed by its OWN row count: blocks behind a sample's rows exit at once, and the backward for S <= 64 is one launch whose
+ * waves take one 32-row tile or - a sample of 33 .. 64 rows - 2 x 2 tiles (csrc/attention.hip: attn_bwd_small_kernel).  qk_rotated != 0:
+ * q and k in qkv are rotated already (the engine's layout); the tables then only rotate dq / dk back. */
+int gget_op_attn_fwd_varlen(const void* qkv, const int32_t* key_len, const int32_t* row_base, void* out, float* lse, int B, int S, int H,
+                            int causal, const float* cos_tab, const float* sin_tab, const int64_t* position_ids, int qk_rotated,
+                            float dropout_p, uint32_t dropout_seed, void* stream);
+int gget_op_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len,
+                            const int32_t* row_base, void* dqkv, float* delta_ws, int B, int S, int H, int causal, const float* cos_tab,
+                            const float* sin_tab, const int64_t* position_ids, int qk_rotated, float dropout_p, uint32_t dropout_seed,
+                            void* stream);
 /* S <= 32 (graph sequences of PCQM4M-v2): attention of every head of a sample, the o projection + residual add and the RMSNorm behind
  * it in ONE launch, one workgroup per sample (csrc/attention.hip: attn_oproj_fwd_kernel).  replaces, for one decoder layer:
  * hf LlamaAttention.forward :243-281 (attention on rotated q / k + o_proj), LlamaDecoderLayer.forward :305-316 (residual add,

@@ -452,6 +452,103 @@ def test_attention_dropout(lib, S, short):
         assert e < 2e-2, f"dropout attn bwd d{nm} rel-L2 {e}"
 
 
+@pytest.mark.parametrize("rope", [False, True])
+@pytest.mark.parametrize("B,S,H,causal,p", [(9, 40, 2, 0, 0.0), (7, 56, 12, 0, 0.1), (6, 64, 3, 1, 0.0), (300, 40, 12, 0, 0.1), (5, 32, 2, 0, 0.0),
+                                            (4, 48, 4, 1, 0.1), (3, 72, 2, 0, 0.0)])
+def test_attention_varlen_by_sample_rows(lib, B, S, H, causal, p, rope):
+    """The padded width S is the batch's LONGEST graph (reference src/data/collator.py:70-111); on the var-len layout every sample is
+    processed by its own row count: forward blocks behind a sample's rows exit, the S <= 64 backward is one launch whose waves take one
+    32-row tile or, for a sample of 33 .. 64 rows, 2 x 2 tiles (attn_bwd_small_kernel / attn_bwd_small_two_tiles).  Checked against
+    autograd through the same masks (dropout: the Python twin of the counter hash; rope: q / k rotated in memory, dq / dk rotated back)
+    and against the padded-layout launch of the same samples; S = 72 keeps the two-kernel path behind the same entry covered."""
+    d, seed = H * 64, 4321
+    pat = [S, 33, 32, 31, 5, min(S, 47), 1, 22, min(S, 64), 17]
+    lens = torch.tensor([min(S, pat[i % len(pat)]) for i in range(B)], dtype=torch.int32)
+    cu = torch.zeros(B + 1, dtype=torch.int64)
+    cu[1:] = torch.cumsum(lens.long(), 0)
+    T = int(cu[-1])
+    rows = (T + 63) // 64 * 64
+    valid = (torch.arange(S)[None, :] < lens[:, None]).cuda()                      # [B,S]
+    sel = valid.reshape(-1).nonzero().squeeze(1)                                      # padded row of every compact row
+    qkv_u = rnd(B * S, 3 * d, seed=27)
+    cos = sin = pos = None
+    qf = qkv_u.float().requires_grad_(True)
+    x = qf.view(B, S, 3, H, 64)
+    if rope:
+        cos, sin = _tables(max(1024, S + 16))
+        pos = torch.arange(S)[None].repeat(B, 1)
+        pos[0, S // 2:] += 7
+        pos = pos.cuda()
+        xin = torch.stack((_rope_ref(x[:, :, 0], pos), _rope_ref(x[:, :, 1], pos), x[:, :, 2]), dim=2).reshape(B * S, 3 * d)
+        qkv_mem = xin.detach().to(torch.bfloat16).contiguous()                      # rotated in memory: the engine's layout
+    else:
+        xin, qkv_mem = qf, qkv_u
+    # reference (on what is in memory, so the bf16 rounding of the rotated q / k is not part of the comparison)
+    xm = qkv_mem.float().requires_grad_(True)
+    xv = xm.view(B, S, 3, H, 64)
+    q, k, v = (xv[:, :, i].transpose(1, 2) for i in range(3))
+    w = q @ k.transpose(2, 3) * 0.125
+    w = w.masked_fill(~valid[:, None, None, :], float("-inf"))
+    if causal:
+        w = w.masked_fill(~torch.ones(S, S, dtype=torch.bool, device="cuda").tril()[None, None], float("-inf"))
+    pr = torch.softmax(w, -1)
+    if p > 0:
+        pr = pr * _drop_mask(seed, B, H, S, p).cuda()
+    ref = (pr @ v).transpose(1, 2).reshape(B, S, d)
+    # compact buffers
+    qkv_c = torch.zeros(rows, 3 * d, dtype=torch.bfloat16, device="cuda")
+    qkv_c[:T] = qkv_mem[sel]
+    lens_d, rb = lens.cuda(), cu[:B].to(torch.int32).cuda()
+    out_c = torch.zeros(rows, d, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_attn_fwd_varlen(P(qkv_c), P(lens_d), P(rb), P(out_c), P(lse), B, S, H, causal, P(cos), P(sin), P(pos), 1, p, seed, ST()))
+    e = rel_l2(out_c[:T].float().cpu().numpy(), ref.detach().reshape(B * S, d)[sel].cpu().numpy())
+    assert e < 8e-3, f"var-len attention forward rel-L2 {e}"
+    assert float(out_c[T:].float().abs().max()) == 0.0 if rows > T else True         # rows behind the last sample are nobody's
+    # the padded-layout launch of the same samples: same kernel arithmetic per tile -> the same bits on the real rows
+    out_p = torch.zeros(B * S, d, dtype=torch.bfloat16, device="cuda")
+    lse_p = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_attn_fwd(P(qkv_mem), P(lens_d), P(out_p), P(lse_p), B, S, H, causal, None, None, None, p, seed, ST()))
+    assert torch.equal(out_c[:T], out_p[sel]), "var-len forward differs from the padded launch on real rows"
+    vq = valid[:, None, :].expand(B, H, S)
+    assert torch.equal(lse.view(B, H, S)[vq], lse_p.view(B, H, S)[vq])
+    # backward
+    dout = rnd(B * S, d, seed=28)
+    dout = (dout.view(B, S, d) * valid[:, :, None]).reshape(B * S, d).contiguous()
+    (ref * dout.float().view(B, S, d)).sum().backward()
+    want = xm.grad.view(B * S, 3, d)
+    if rope:   # gradient w.r.t. the UN-rotated q / k: the rotation's transpose applied to the gradient of the rotated ones
+        g4 = xm.grad.view(B, S, 3, H, 64)
+        want = torch.stack((_rope_ref_signed(g4[:, :, 0], pos, -1.0), _rope_ref_signed(g4[:, :, 1], pos, -1.0), g4[:, :, 2]), dim=2).reshape(B * S, 3, d)
+    dout_c = torch.zeros(rows, d, dtype=torch.bfloat16, device="cuda")
+    dout_c[:T] = dout[sel]
+    dqkv_c = torch.full((rows, 3 * d), 7.0, dtype=torch.bfloat16, device="cuda")     # (every real row must be overwritten)
+    delta = torch.zeros(B * H * S, dtype=torch.float32, device="cuda")
+    L.check(lib.gget_op_attn_bwd_varlen(P(qkv_c), P(out_c), P(dout_c), P(lse), P(lens_d), P(rb), P(dqkv_c), P(delta), B, S, H, causal,
+                                        P(cos), P(sin), P(pos), 1, p, seed, ST()))
+    g = dqkv_c[:T].float().view(T, 3, d)
+    for i, nm in enumerate("qkv"):
+        e = rel_l2(g[:, i].cpu().numpy(), want[sel][:, i].cpu().numpy())
+        assert e < 2e-2, f"var-len attention backward d{nm} rel-L2 {e}"
+    # per-sample check of the long samples alone (5 % of a real batch: a slip there would drown in the batch-wide norm)
+    for b in range(min(B, 12)):
+        if int(lens[b]) > 32:
+            r0, r1 = int(cu[b]), int(cu[b + 1])
+            ws = want[b * S: b * S + int(lens[b])]
+            for i, nm in enumerate("qkv"):
+                e = rel_l2(g[r0:r1, i].cpu().numpy(), ws[:, i].cpu().numpy())
+                assert e < 2.5e-2, f"sample {b} ({int(lens[b])} rows) d{nm} rel-L2 {e}"
+
+
+def _rope_ref_signed(x, pos, sign, theta=10000.0):
+    """rotation by sign * angle (sign = -1: the transpose / inverse rotation that maps a gradient of rotated q / k back)"""
+    inv = 1.0 / (theta ** (torch.arange(0, 64, 2, dtype=torch.float32, device=x.device) / 64))
+    fr = pos.float()[:, :, None] * inv * sign
+    emb = torch.cat((fr, fr), -1)[:, :, None, :]
+    x1, x2 = x[..., :32], x[..., 32:]
+    return x * emb.cos() + torch.cat((-x2, x1), -1) * emb.sin()
+
+
 # ------------------------------------------------------------------------------------------ GEGLU / CE
 def test_geglu(lib):
     T, ff = 77, 512

@@ -102,10 +102,13 @@ def _tiny_spec(kind, S, causal=False, layer_scale=0.0, path_pdrop=0.0, F=4, V=50
 
 
 @pytest.mark.parametrize("S,B,causal", [(24, 12, False), (32, 64, False), (72, 6, False), (160, 5, True), (256, 6, False), (320, 4, True),
-                                         (640, 3, False), (1088, 2, False)])
+                                         (640, 3, False), (1088, 2, False),
+                                         # 32 < S <= 64: every sample by its own row count (one-tile kernels + the 33 .. 64-row launches)
+                                         (40, 40, False), (48, 9, True), (56, 70, False), (64, 16, False)])
 @pytest.mark.parametrize("kind", ["pt", "ft"])
 def test_varlen_every_attention_kernel_class(kind, S, B, causal):
-    """S <= 32 (one-wave kernels), 32 < S < 256 (multi-wave register-prefetch kernels), S >= 256 (64-row LDS-DMA stages; the dense
+    """S <= 32 (one-wave kernels), 32 < S <= 64 (var-len: every sample by its own row count - attn_fwd_long_kernel / attn_bwd_long_kernel for
+    the samples of 33 .. 64 rows; padded: the two-tile backward for all), 64 < S < 256 (multi-wave register-prefetch kernels), S >= 256 (64-row LDS-DMA stages; the dense
     pipelined forward from S = 512 when not causal; 128-row dK/dV stages from S = 512), with attention dropout 0.1 (the masks are
     hashes of the LOGICAL (b, h, q, k) coordinates, so both layouts draw the same one), ragged lengths incl. very short samples."""
     pt = kind == "pt"

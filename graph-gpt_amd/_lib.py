@@ -88,7 +88,7 @@ SIGNATURES = {
     "gget_op_attn_oproj_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, C.c_uint32, vp, vp]),
     "gget_op_pack_wo": (i32, [vp, C.c_uint64, vp, vp, i32, i32, vp]),
     "gget_op_attn_oproj_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, C.c_uint64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, f32,
-                                      C.c_uint32, i32, vp, vp]),
+                                      C.c_uint32, i32, vp, vp, vp]),
     "gget_op_attn_fwd_ranges": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint32, vp]),
     "gget_op_attn_bwd_ranges": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint32, vp]),
     "gget_op_ranges_from_mask3d": (i32, [vp, vp, vp, i32, i32, vp]),

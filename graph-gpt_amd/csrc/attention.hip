@@ -254,8 +254,6 @@ struct KeyRange {
   // [row_base[b], row_base[b] + key_len[b]).  nullptr = padded layout, sample b at rows [b * S, b * S + S).  Logical [B,S] arrays
   // (lse, delta, position ids, the dropout hash coordinates) keep their (b, s) indexing in both layouts.  Not combined with lo / hi.
   const int32_t* row_base;
-  // var-len layout, S <= 64: samples with more rows than this belong to another launch (attn_fwd_long_kernel) - their blocks exit.  0 = none.
-  int skip_over;
 };
 // wave-uniform min / max of small non-negative integers (exact in fp32)
 __device__ __forceinline__ int wave_imin(int v) { return (int)-wave_max(-(float)v); }
@@ -393,7 +391,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
   // sample owns SL rows - blocks wholly behind them have nothing to load or store (at S = 40 / 56 nineteen graphs in twenty are <= 32
   // tokens: without this exit their second block staged every K / V tile for nothing, 20.0 us per launch against 11.9 at S = 32)
   if (KR.row_base && (int)blockIdx.x * NW * 32 >= SL) return;
-  if (KR.row_base && KR.skip_over && SL > KR.skip_over) return;      // (the sample is attn_fwd_long_kernel's)
   const int q0 = (blockIdx.x * NW + wave) * 32;
   const int d = H * 64;
   const size_t pitch = (size_t)3 * d;
@@ -497,106 +494,140 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 3 : 2) attn_fwd_kernel(cons
   }
 }
 
-// Samples of 33 .. 64 rows on the var-len layout with S <= 64 (round 6), as their OWN launch next to attn_fwd_kernel<1> (whose blocks of
-// these samples exit).  Why: the S <= 64 forward is ONE round of thousands of one-wave blocks, twelve per CU; it lasts as long as its
-// slowest block, and under that load every global round trip of a block costs ~3 us.  A 33 .. 64-row sample walks two key tiles - two
-// more dependent round trips - so with nineteen graphs in twenty at <= 32 tokens the launch still ran 20.0 us at S = 40 against 11.9 at
-// S = 32 (issue priority for the long blocks changed nothing: they wait on memory, not on issue slots).  Here the few long samples
-// (the collator pads to the batch's LONGEST graph, reference src/data/collator.py:70-111) get a block of TWO waves - wave w = query tile
-// w - that requests all four K / V tiles at once and runs on a nearly empty chip.  The arithmetic is attn_fwd_kernel<1>'s, step by step
-// (online softmax over key tile 0, then 1): same bits.  q / k are read as they are in memory (rotated - the engine's layout - or plain).
-// long_list (may be NULL): [0] = number of such samples, [1 ..] their indices (varlen_scan_kernel); NULL = every block tests its own sample.
-__global__ void __launch_bounds__(128, 2) attn_fwd_long_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
-                                                               const int32_t* __restrict__ row_base, bf16_t* __restrict__ out,
-                                                               float* __restrict__ lse, int B, int S, int H, int causal, Drop D,
-                                                               const int32_t* __restrict__ long_list) {
-  __shared__ __attribute__((aligned(16))) unsigned char tiles[4][4096];   // K0 K1 V0 V1
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = blockIdx.y;
-  const int n_items = long_list ? min(long_list[0], B) : B;
-  for (int it = blockIdx.z; it < n_items; it += gridDim.z) {
-    const int b = long_list ? long_list[1 + it] : it;
-    const int rb = row_base[b];
-    const int SL = key_len[b];
-    if (SL <= 32 || SL > 64) continue;      // (block-uniform)
-    const int d = H * 64;
-    const size_t pitch = (size_t)3 * d;
-    const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
-    const bf16_t* kb = qb + d;
-    const bf16_t* vb = qb + 2 * d;
-    const Rope Rnone{nullptr, nullptr, nullptr, S};
-    const int q0 = 32 * w, qrow = q0 + l31;
-    const int qhi = min(SL, S) - 1;                 // keys [0, qhi]
-    TilePref<128> pf[4];
+// Var-len layout, 32 < S <= 64 (round 6): one wave per (sample, head, 32-query tile), keyed on the sample's OWN row count.  The collator pads
+// a batch to the width of its LONGEST graph (reference src/data/collator.py:70-111), so at B = 256 the padded width is 40 - 56 while nineteen
+// graphs in twenty are one 32-row tile.  The launch is ONE round of thousands of one-wave blocks and lasts as long as its slowest block;
+// under that load every dependent global round trip of a block costs ~3 us, and attn_fwd_kernel<1> walks the key tiles one round trip at
+// a time (20.0 us per launch at S = 40 against 11.9 at S = 32; a separate sparse launch for the long samples: 10.3 + 6.6 us).  Here a
+// block requests EVERYTHING at once - Q rows, both K tiles, both V tiles, as whole-row tile loads (K rows fetched directly as MFMA
+// operands, 32-byte pieces 4.6 KB apart, cost 14.5 us per launch: the texture addresser coalesces neighbouring lanes only) - and stages
+// them through the SAME 8 KiB of LDS in two steps: K tiles in, K operands out to registers, V tiles in.  A 33 .. 64-row sample costs one
+// round trip like the others; blocks behind a sample's rows exit.  The arithmetic is attn_fwd_kernel's, step by step (online softmax over
+// key tile 0, then 1): same bits.  q / k are read as they are in memory (rotated - the engine's layout - or plain).
+__global__ void __launch_bounds__(64, 3) attn_fwd_rows64_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
+                                                                const int32_t* __restrict__ row_base, bf16_t* __restrict__ out,
+                                                                float* __restrict__ lse, int B, int S, int H, int causal, Drop D) {
+  __shared__ __attribute__((aligned(16))) unsigned char tl[2][4096];
+  const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+  // grid (H, B, tiles), the LAST query tile first in dispatch order: the blocks behind a sample's rows (most of that tile's) flash through
+  // at the start of the launch and the second tiles of the long samples begin with it, not behind three thousand first tiles
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int rb = row_base[b];
+  const int SL = min(key_len[b], 64);
+  const int q0 = ((int)gridDim.z - 1 - (int)blockIdx.z) * 32;
+  if (q0 >= SL) return;
+  const int d = H * 64;
+  const size_t pitch = (size_t)3 * d;
+  const bf16_t* qb = qkv + (size_t)rb * pitch + h * 64;
+  const bf16_t* kb = qb + d;
+  const bf16_t* vb = qb + 2 * d;
+  const int qrow = q0 + l31;
+  const int kend = causal ? min(SL, q0 + 32) : SL;     // keys [0, kend) concern this tile
+  const bool two = kend > 32;                           // (wave-uniform)
+  const Rope Rnone{nullptr, nullptr, nullptr, S};
+  bf16x8_t qf[4], kf[2][4];
+  uint4 kraw[2][4], vraw[2][4];
+  frags_global_rope(qf, qb, qrow, SL, pitch, lane, Rnone, b);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      tile_fetch<128>(pf[t], kb, 32 * t, SL, pitch, tid, Rnone);
-      tile_fetch<128>(pf[2 + t], vb, 32 * t, SL, pitch, tid, Rnone);
+  for (int j = 0; j < 2; ++j) {
+    if (j == 1 && !two) break;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + i * 64, row = c >> 3, ch = c & 7;
+      const size_t off = (size_t)clamp_row(32 * j + row, SL) * pitch + ch * 8;
+      kraw[j][i] = *reinterpret_cast<const uint4*>(kb + off);
+      vraw[j][i] = *reinterpret_cast<const uint4*>(vb + off);
     }
-    bf16x8_t qf[4];
-    frags_global_rope(qf, qb, qrow, SL, pitch, lane, Rnone, b);
-    __syncthreads();      // (the previous item's tiles are consumed)
+  }
+  if (two) {
+    // two key tiles: K0 | K1 through the LDS first, their MFMA operands parked in registers, then V0 | V1 take the same bytes
 #pragma unroll
-    for (int t = 0; t < 4; ++t) tile_commit<128>(tiles[t], pf[t], 32 * (t & 1), SL, tid, Rnone, b);
-    __syncthreads();
-    f32x16_t o0 = zero16(), o1 = zero16();
-    float m = -INFINITY, l = 0.f;
-    const unsigned dbase = drop_base(D, b * H + h, qrow, 0);
-    const int kend = (q0 < SL) ? min(qhi + 1, causal ? q0 + 32 : SL) : 0;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int kt_i = 0; kt_i < 2; ++kt_i) {
-      const int k0 = 32 * kt_i;
-      if (k0 >= kend) continue;
-      const unsigned char* kt = tiles[kt_i];
-      const unsigned char* vt = tiles[2 + kt_i];
-      f32x16_t sc = zero16();
-#pragma unroll
-      for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, s, lane), qf[s], sc, 0, 0, 0);
-      const bool edge = (k0 + 31 > qhi) || (causal && k0 + 31 > q0) || (q0 + 32 > SL);
-      float mx = -INFINITY;
-      if (edge) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = k0 + acc_row(r, hi);
-          const bool ok = key <= qhi && (!causal || key <= qrow);
-          sc[r] = ok ? sc[r] : -INFINITY;
-          mx = fmaxf(mx, sc[r]);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+      for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64, row = c >> 3, ch = c & 7;
+        *reinterpret_cast<uint4*>(tl[j] + swz(row, ch * 16)) = zero_if(32 * j + row >= SL, kraw[j][i]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m, mx * kScaleL2);
-      const bool dead = m_new == -INFINITY;
-      const float alpha = dead ? 1.f : fast_exp2(m - m_new);
-      const float nm = dead ? 0.f : -m_new;
-      float rs = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[j][s] = frag_rows(tl[j], s, lane);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64, row = c >> 3, ch = c & 7;
+        *reinterpret_cast<uint4*>(tl[j] + swz(row, ch * 16)) = zero_if(32 * j + row >= SL, vraw[j][i]);
+      }
+    __syncthreads();
+  } else {
+    // one key tile (nineteen samples in twenty): K in the first half, V in the second - attn_fwd_kernel<1>'s staging
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + i * 64, row = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(tl[1] + swz(row, ch * 16)) = zero_if(row >= SL, kraw[0][i]);
+      *reinterpret_cast<uint4*>(tl[0] + swz(row, ch * 16)) = zero_if(row >= SL, vraw[0][i]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kf[0][s] = frag_rows(tl[1], s, lane);
+  }
+  f32x16_t o0 = zero16(), o1 = zero16();
+  float m = -INFINITY, l = 0.f;
+  const unsigned dbase = drop_base(D, b * H + h, qrow, 0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k0 = 32 * j;
+    if (k0 >= kend) break;
+    const unsigned char* vt = tl[j];
+    f32x16_t sc = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j][s], qf[s], sc, 0, 0, 0);
+    const bool edge = (k0 + 31 > SL - 1) || (causal && k0 + 31 > q0) || (q0 + 32 > SL);
+    float mx = -INFINITY;
+    if (edge) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(fmaf(sc[r], kScaleL2, nm));
-        rs += p;
-        sc[r] = p * drop_mul_x(D, dbase + (unsigned)((k0 + acc_row(r, hi)) >> 1) * 0xC2B2AE3Du, r & 1);
+        const int key = k0 + acc_row(r, hi);
+        const bool ok = key < SL && (!causal || key <= qrow);
+        sc[r] = ok ? sc[r] : -INFINITY;
+        mx = fmaxf(mx, sc[r]);
       }
-      rs += __shfl_xor(rs, 32, 64);
-      l = l * alpha + rs;
-      m = m_new;
-      if (__any(alpha != 1.f)) {
+    } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-      }
-      const bf16x8_t pb0 = acc_to_b(sc, 0), pb1 = acc_to_b(sc, 1);
-      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 0, lane), pb0, o0, 0, 0, 0);
-      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 1, lane), pb1, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 0, lane), pb0, o1, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 1, lane), pb1, o1, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
     }
-    if (qrow < SL) {
-      const float inv = l > 0.f ? 1.f / l : 0.f;
-      store_t(out + ((size_t)rb + qrow) * d + h * 64, o0, o1, inv, hi);
-      if (hi == 0 && lse) lse[((size_t)b * H + h) * S + qrow] = l > 0.f ? (m + log2f(l)) * (1.0f / kLog2e) : 0.f;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx * kScaleL2);
+    const bool dead = m_new == -INFINITY;
+    const float alpha = dead ? 1.f : fast_exp2(m - m_new);
+    const float nm = dead ? 0.f : -m_new;
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = fast_exp2(fmaf(sc[r], kScaleL2, nm));
+      rs += p;
+      sc[r] = p * drop_mul_x(D, dbase + (unsigned)((k0 + acc_row(r, hi)) >> 1) * 0xC2B2AE3Du, r & 1);
     }
+    rs += __shfl_xor(rs, 32, 64);
+    l = l * alpha + rs;
+    m = m_new;
+    if (__any(alpha != 1.f)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    }
+    const bf16x8_t pb0 = acc_to_b(sc, 0), pb1 = acc_to_b(sc, 1);
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 0, lane), pb0, o0, 0, 0, 0);
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 0, 1, lane), pb1, o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 0, lane), pb0, o1, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vt, 1, 1, lane), pb1, o1, 0, 0, 0);
+  }
+  if (qrow < SL) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    store_t(out + ((size_t)rb + qrow) * d + h * 64, o0, o1, inv, hi);
+    if (hi == 0 && lse) lse[((size_t)b * H + h) * S + qrow] = l > 0.f ? (m + log2f(l)) * (1.0f / kLog2e) : 0.f;
   }
 }
 
@@ -996,13 +1027,23 @@ __global__ void __launch_bounds__(128, 2) attn_bwd_long_kernel(const bf16_t* __r
                                                                const float* __restrict__ lse, const int32_t* __restrict__ key_len,
                                                                bf16_t* __restrict__ dqkv, int B, int S, int H, int causal, Rope R, Drop D,
                                                                const int32_t* __restrict__ row_base, const int32_t* __restrict__ long_list) {
-  // long_list (may be NULL): [0] = number of 33 .. 64-row samples, [1 ..] their indices (varlen_scan_kernel); NULL = every block tests its own
-  const int n_items = long_list ? min(long_list[0], B) : B;
+  // long_list (may be NULL): [0] = number n of 33 .. 64-row samples, [1 .. n] their indices, [1 + B ..] their first rows, [1 + 2 B ..] their row
+  // counts (varlen_scan_kernel; all four words of a block's first item are requested together: one round trip); NULL = every block tests
+  // its own sample
+  int n_items = B;
+  int b0 = blockIdx.z, rb0 = 0, sl0 = 0;
+  if (long_list) {
+    const int it = min((int)blockIdx.z, B - 1);
+    n_items = long_list[0];
+    b0 = long_list[1 + it]; rb0 = long_list[1 + B + it]; sl0 = long_list[1 + 2 * B + it];
+    n_items = min(n_items, B);
+  }
 #pragma unroll 1
   for (int it = blockIdx.z; it < n_items; it += gridDim.z) {
-    const int b = long_list ? long_list[1 + it] : it;
-    const int rb = row_base ? row_base[b] : b * S;
-    const int kl = key_len ? key_len[b] : S;
+    const bool first = it == (int)blockIdx.z;
+    const int b = long_list ? (first ? b0 : long_list[1 + it]) : it;
+    const int rb = long_list ? (first ? rb0 : long_list[1 + B + it]) : (row_base ? row_base[b] : b * S);
+    const int kl = long_list ? (first ? sl0 : long_list[1 + 2 * B + it]) : (key_len ? key_len[b] : S);
     const int SL = row_base ? kl : S;
     if (SL <= 32 || SL > 64) continue;      // (block-uniform)
     __syncthreads();                         // (the previous item's tiles and tables are consumed)
@@ -1210,6 +1251,9 @@ __global__ void __launch_bounds__(256) pack_wo_kernel(const bf16_t* __restrict__
   }
 }
 
+#ifndef GGET_AO_PD_LONG
+#define GGET_AO_PD_LONG 2   // the same for a 33 .. 64-row sample of the backward (64 accumulators per lane beside them: 3 and 4 spill inside the K loop)
+#endif
 #ifndef GGET_AO_PD
 #define GGET_AO_PD 4      // K-steps of weight fragments in flight in the per-sample kernels (measurement knob: -DGGET_AO_PD=n)
 #endif
@@ -1219,6 +1263,10 @@ __global__ void __launch_bounds__(256) pack_wo_kernel(const bf16_t* __restrict__
 // conflict-free; with ONE slot of padding (the first version) rows 11 / chunk 1 and 12 / chunk 0 met: SQ_LDS_BANK_CONFLICT / IDX_ACTIVE
 // 0.32 - 0.37 in profiles/r05_final_c1_pmc_mfma_lds.txt
 constexpr int kOPad = 16;
+// LDS bytes of the per-sample forward: the [32][d + pad] tile, the sums of squares [H][32] + rstd [32], the waves' two 4 KiB tiles
+template <int H>
+constexpr int attn_oproj_fwd_lds() { return 32 * (H * 64 + kOPad) * 2 + (H * 32 + 32) * 4 + H * 8192; }
+
 template <int H>
 __global__ void __launch_bounds__(H * 64) attn_oproj_fwd_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_len,
                                                                 const int32_t* __restrict__ row_base, bf16_t* __restrict__ attn_out,
@@ -1451,6 +1499,182 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_fwd_kernel(const bf16_t* __
 //            exists in global memory
 //   phase C  wave w: attn_bwd_small_kernel's arithmetic on head w (K, Q tiles from global memory, V in registers, dO from phase B)
 // reference: hf LlamaRMSNorm :62-67, LlamaAttention.forward :243-281, eager_attention_forward :191-214 (their autograd).
+// A sample of 33 .. 64 rows inside attn_oproj_bwd_kernel (round 6; var-len layout, S <= 64).  The collator pads a batch to the width of its
+// LONGEST graph (reference src/data/collator.py:70-111): at B = 256 the width is 40 - 56 while nineteen graphs in twenty are one 32-row tile,
+// so the kernel is keyed on each sample's own row count.  The long sample stays ONE workgroup (a second workgroup per extra tile would be a
+// second round on a 256-CU chip at B = 256): phases A and B over
+// two row tiles with the transposed weight streamed ONCE, dattn of these rows written to global memory (bf16, the GEMM's rounding) - the
+// attention backward of such samples is attn_bwd_long_kernel's, launched behind this kernel on the same stream: its 24 KiB of K / Q / dO
+// tiles per HEAD do not fit beside this workgroup's row tiles (twelve heads: 288 KiB).
+//   phase A  wave w owns rows w, w + H, ...: rows 0 .. 31 go to region X, rows 32 .. 63 to region Y behind the waves' norm-weight partials
+//   phase B  four 16-row blocks per weight fragment, two K-steps of fragments in flight
+// A real call (own register allocation), decided by the kernel's first statements.
+template <int H>
+__device__ __attribute__((noinline)) void attn_oproj_bwd_long(const bf16_t* __restrict__ dxn, const bf16_t* __restrict__ x_mid,
+                                                              const bf16_t* __restrict__ nw, const float* __restrict__ rstd,
+                                                              const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx_mid,
+                                                              float* __restrict__ dw_accum, int copies, uint64_t copy_stride,
+                                                              const bf16_t* __restrict__ wot, bf16_t* __restrict__ dattn, int b, int rb, int SL) {
+  constexpr int d = H * 64, NT = H * 64, PITCH = (d + kOPad) * 2, KSTEPS = d / 32, NCHUNK = d / 8, NCH = (NCHUNK + 63) / 64;
+  constexpr int XB = 32 * PITCH > H * 4096 ? 32 * PITCH : H * 4096, YB = H * 8192 > H * d * 4 ? H * 8192 : H * d * 4;
+  static_assert(H * d * 4 + 32 * PITCH <= YB, "the second row tile sits behind the norm-weight partials in region Y");
+  extern __shared__ __attribute__((aligned(16))) unsigned char fb_lds[];
+  unsigned char* dtile0 = fb_lds;
+  float* dw_lds = reinterpret_cast<float*>(fb_lds + XB);
+  unsigned char* dtile1 = fb_lds + XB + H * d * 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // ---------------------------------------------------------------- phase A: RMSNorm backward of this wave's rows (of 64)
+  {
+    float wv[NCH][8], dwp[NCH][8];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { dwp[i][e] = 0.f; wv[i][e] = 0.f; }
+      if (c < NCHUNK) unpack8(*reinterpret_cast<const uint4*>(nw + c * 8), wv[i]);
+    }
+    constexpr int RPW = (64 + H - 1) / H, RB = RPW < 3 ? RPW : 3;
+#pragma unroll 1
+    for (int j0 = 0; j0 < RPW; j0 += RB) {
+      uint4 xr[RB][NCH], dr[RB][NCH], rr[RB][NCH];
+      float rs[RB];
+#pragma unroll
+      for (int jj = 0; jj < RB; ++jj) {
+        const int q = h + H * (j0 + jj);
+        const size_t row = (size_t)rb + max(min(q, SL - 1), 0);
+        rs[jj] = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c = min(lane + i * 64, NCHUNK - 1);
+          xr[jj][i] = *reinterpret_cast<const uint4*>(x_mid + row * d + c * 8);
+          dr[jj][i] = *reinterpret_cast<const uint4*>(dxn + row * d + c * 8);
+          rr[jj][i] = *reinterpret_cast<const uint4*>(dres + row * d + c * 8);
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < RB; ++jj) {
+        const int q = h + H * (j0 + jj);
+        if (q >= 64) break;                    // (wave-uniform)
+        const bool live = q < SL;
+        unsigned char* trow = q < 32 ? dtile0 + q * PITCH : dtile1 + (q - 32) * PITCH;
+        float xh[NCH][8], g[NCH][8], res[NCH][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const bool on = lane + i * 64 < NCHUNK;
+          float xv[8], dv[8];
+          unpack8(xr[jj][i], xv);
+          unpack8(dr[jj][i], dv);
+          unpack8(rr[jj][i], res[i]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            xh[i][e] = xv[e] * rs[jj];
+            g[i][e] = dv[e] * wv[i][e];
+            if (on) dot += g[i][e] * xh[i][e];
+            if (on && live) dwp[i][e] += dv[e] * xh[i][e];
+          }
+        }
+        dot = wave_sum(dot) / (float)d;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c = lane + i * 64;
+          if (c < NCHUNK) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = res[i][e] + rs[jj] * (g[i][e] - xh[i][e] * dot);
+            const uint4 ov = live ? pack8(o) : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(trow + c * 16) = ov;
+            if (live) *reinterpret_cast<uint4*>(dx_mid + ((size_t)rb + q) * d + c * 8) = ov;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < NCHUNK) {
+        *reinterpret_cast<float4*>(dw_lds + h * d + c * 4) = make_float4(dwp[i][0], dwp[i][1], dwp[i][2], dwp[i][3]);
+        *reinterpret_cast<float4*>(dw_lds + h * d + (d >> 1) + c * 4) = make_float4(dwp[i][4], dwp[i][5], dwp[i][6], dwp[i][7]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < d; t += NT) {
+    constexpr int hd = d >> 1;
+    const int pl = t >= hd ? 1 : 0, ix = t - pl * hd;
+    const int j = (ix >> 2) * 8 + pl * 4 + (ix & 3);
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < H; ++w) sum += dw_lds[w * d + t];
+    unsafeAtomicAdd(dw_accum + (size_t)(blockIdx.x % copies) * copy_stride + j, sum);
+  }
+  // ---------------------------------------------------------------- phase B: dattn^T = WoT dx_mid^T over 64 rows -> global memory
+  {
+    const int li = lane & 15, g4 = lane >> 4;
+    const int rot = __builtin_amdgcn_readfirstlane((b * 5) % KSTEPS);
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* wrow = wot + (size_t)4 * h * KSTEPS * 512 + lane * 8;
+    const unsigned char* orow0 = dtile0 + li * PITCH + 16 * g4;
+    const unsigned char* orow1 = dtile1 + li * PITCH + 16 * g4;
+    constexpr int PD = GGET_AO_PD_LONG;
+    uint4 af[PD][4];
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+      const int sr = (s + rot) % KSTEPS;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[s][t] = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * KSTEPS + sr) * 512);
+    }
+    int sw = rot + PD; if (sw >= KSTEPS) sw -= KSTEPS;
+    int sb = rot;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      bf16x8_t a[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = __builtin_bit_cast(bf16x8_t, af[s % PD][t]);
+      uint4 bq[4];
+      bq[0] = *reinterpret_cast<const uint4*>(orow0 + 64 * sb);
+      bq[1] = *reinterpret_cast<const uint4*>(orow0 + 16 * PITCH + 64 * sb);
+      bq[2] = *reinterpret_cast<const uint4*>(orow1 + 64 * sb);
+      bq[3] = *reinterpret_cast<const uint4*>(orow1 + 16 * PITCH + 64 * sb);
+      if (++sb == KSTEPS) sb = 0;
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + PD < KSTEPS) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[s % PD][t] = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * KSTEPS + sw) * 512);
+        if (++sw == KSTEPS) sw = 0;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, bq[u]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bb, acc[t][u], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // lane holds dattn[q = 16 u + li][64 h + 16 t + 4 g4 + i]: 8 bytes of row q
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = 16 * u + li;
+      if (q < SL) {
+        bf16_t* grow = dattn + ((size_t)rb + q) * d + 64 * h + 4 * g4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          uint2 o;
+          o.x = pack2bf(acc[t][u][0], acc[t][u][1]);
+          o.y = pack2bf(acc[t][u][2], acc[t][u][3]);
+          *reinterpret_cast<uint2*>(grow + 16 * t) = o;
+        }
+      }
+    }
+  }
+}
+
 template <int H>
 __global__ void __launch_bounds__(H * 64) attn_oproj_bwd_kernel(const bf16_t* __restrict__ dxn, const bf16_t* __restrict__ x_mid,
                                                                 const bf16_t* __restrict__ nw, const float* __restrict__ rstd,
@@ -1459,7 +1683,7 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_bwd_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ wot, const bf16_t* __restrict__ qkv,
                                                                 const float* __restrict__ lse, const int32_t* __restrict__ key_len,
                                                                 const int32_t* __restrict__ row_base, bf16_t* __restrict__ dqkv, int B, int S,
-                                                                int causal, Rope R, Drop D, int t_rows) {
+                                                                int causal, Rope R, Drop D, int t_rows, bf16_t* __restrict__ dattn_long) {
   constexpr int d = H * 64, NT = H * 64, PITCH = (d + kOPad) * 2, KSTEPS = d / 32, NCHUNK = d / 8, NCH = (NCHUNK + 63) / 64;
   // LDS: region X = the dx_mid tile [32][PITCH] of phases A / B, overwritten by the heads' dO tiles [H][4096] once phase B's loop is
   // over; region Y = the heads' K and Q tiles [H][8192] (they arrive by LDS-DMA while phase B runs), whose first bytes hold the waves'
@@ -1477,6 +1701,12 @@ __global__ void __launch_bounds__(H * 64) attn_oproj_bwd_kernel(const bf16_t* __
   const int b = blockIdx.x;
   const int rb = row_base ? row_base[b] : b * S;
   const int SL = row_base ? key_len[b] : S;
+  if (SL > 32) {     // (workgroup-uniform; var-len layout with 32 < S <= 64 only: the launcher sees to that)
+    if (b == B - 1)
+      for (int c = (rb + SL) * NCHUNK + tid; c < t_rows * NCHUNK; c += NT) reinterpret_cast<uint4*>(dx_mid)[c] = make_uint4(0u, 0u, 0u, 0u);
+    attn_oproj_bwd_long<H>(dxn, x_mid, nw, rstd, dres, dx_mid, dw_accum, copies, copy_stride, wot, dattn_long, b, rb, min(SL, 64));
+    return;
+  }
   const int klen = key_len ? min(key_len[b], S) : S;
   // Angle-table rows of the sample's 32 positions (phase C rotates dq and dk back): requested NOW (position, then its table piece: two
   // dependent global round trips) and parked in LDS behind phase A; the unrotation at the end of phase C reads LDS.  Fetched at the
@@ -2953,17 +3183,15 @@ int k_attn_fwd(const void* qkv, const int32_t* key_len, void* out, float* lse, i
                unsigned dropout_seed, hipStream_t st, const int32_t* key_lo, const int32_t* key_hi, const int32_t* row_base,
                const int32_t* long_list) {
   GGET_REQUIRE(!row_base || (key_len && !key_lo), "attention: the var-len token layout needs key_len and excludes per-token key ranges");
-  KeyRange KR{key_len, key_lo, key_hi, row_base};
+  const KeyRange KR{key_len, key_lo, key_hi, row_base};
   if (B == 0 || S == 0) return 0;
   const Rope R{cos_tab, sin_tab, position_ids, S};
   const Drop D = make_drop(dropout_p, dropout_seed);
   // var-len layout, 32 < S <= 64 (the collator pads to the batch's longest graph, most samples are still one 32-row tile): every sample by
-  // its OWN row count - the one-wave kernel takes the samples of <= 32 rows, attn_fwd_long_kernel the few longer ones
+  // its OWN row count (attn_fwd_rows64_kernel)
   if (row_base && S > 32 && S <= 64 && !cos_tab && attn_by_sample_rows()) {
-    KR.skip_over = 32;
-    hipLaunchKernelGGL((attn_fwd_kernel<1, false>), dim3(1, H, B), dim3(64), 0, st, (const bf16_t*)qkv, KR, (bf16_t*)out, lse, B, S, H, causal, R, D);
-    hipLaunchKernelGGL(attn_fwd_long_kernel, dim3(1, H, long_list ? std::min(B, kLongGrid) : B), dim3(128), 0, st, (const bf16_t*)qkv, key_len, row_base,
-                       (bf16_t*)out, lse, B, S, H, causal, D, long_list);
+    hipLaunchKernelGGL(attn_fwd_rows64_kernel, dim3(H, B, (S + 31) / 32), dim3(64), 0, st, (const bf16_t*)qkv, key_len, row_base, (bf16_t*)out, lse, B, S, H,
+                       causal, D);
     GGET_LAUNCH_CHECK();
     return 0;
   }
@@ -3017,8 +3245,8 @@ template <int H>
 static int launch_attn_oproj(const void* qkv, const int32_t* key_len, const int32_t* row_base, void* attn_out, float* lse, const void* wo,
                              const void* x_in, void* x_mid, const void* nw, void* xn, float* rstd, int B, int S, int causal, float eps,
                              const Drop& D, hipStream_t st) {
-  constexpr int d = H * 64;
-  constexpr int lds = 32 * (d + kOPad) * 2 + (H * 32 + 32) * 4 + H * 8192;
+  constexpr int lds = attn_oproj_fwd_lds<H>();
+  static_assert(lds <= 160 * 1024, "per-sample forward: LDS");
   static bool attr = false;
   if (!attr) {
     GGET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_oproj_fwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -3033,6 +3261,8 @@ int k_attn_oproj_fwd(const void* qkv, const int32_t* key_len, const int32_t* row
                      const void* x_in, void* x_mid, const void* nw, void* xn, float* rstd, int B, int S, int H, int causal, float eps,
                      float dropout_p, unsigned dropout_seed, hipStream_t st, int* taken) {
   *taken = 0;
+  // (S <= 32 only: a 33 .. 64-row sample inside this kernel - one workgroup over two row tiles - was built and measured slower than the
+  //  three launches, profiles/r06_attn_oproj_fwd_long_experiment.diff; the backward counterpart is kept)
   if (B == 0 || S == 0 || S > 32 || !attn_oproj_enabled()) return 0;
   GGET_REQUIRE(!row_base || key_len, "attention: the var-len token layout needs key_len");
   const Drop D = make_drop(dropout_p, dropout_seed);
@@ -3048,7 +3278,7 @@ template <int H>
 static int launch_attn_oproj_bwd(const void* dxn, const void* x_mid, const void* nw, const float* rstd, const void* dres, void* dx_mid,
                                  float* dw_accum, int copies, uint64_t copy_stride, const void* wot, const void* qkv, const float* lse,
                                  const int32_t* key_len, const int32_t* row_base, void* dqkv, int B, int S, int causal, const Rope& R,
-                                 const Drop& D, int t_rows, hipStream_t st) {
+                                 const Drop& D, int t_rows, hipStream_t st, void* dattn_long) {
   constexpr int d = H * 64, PITCH = (d + kOPad) * 2;
   constexpr int XB = 32 * PITCH > H * 4096 ? 32 * PITCH : H * 4096, YB = H * 8192 > H * d * 4 ? H * 8192 : H * d * 4;
   constexpr int lds = XB + YB + H * 64 * 4 + 2 * 32 * kRopePitch * 4;      // + the sample's cos / sin rows (attn_oproj_bwd_kernel)
@@ -3060,26 +3290,39 @@ static int launch_attn_oproj_bwd(const void* dxn, const void* x_mid, const void*
   }
   hipLaunchKernelGGL((attn_oproj_bwd_kernel<H>), dim3(B), dim3(H * 64), lds, st, (const bf16_t*)dxn, (const bf16_t*)x_mid, (const bf16_t*)nw, rstd,
                      (const bf16_t*)dres, (bf16_t*)dx_mid, dw_accum, copies, copy_stride, (const bf16_t*)wot, (const bf16_t*)qkv, lse, key_len,
-                     row_base, (bf16_t*)dqkv, B, S, causal, R, D, t_rows);
+                     row_base, (bf16_t*)dqkv, B, S, causal, R, D, t_rows, (bf16_t*)dattn_long);
   GGET_LAUNCH_CHECK();
   return 0;
 }
 int k_attn_oproj_bwd(const void* dxn, const void* x_mid, const void* nw, const float* rstd, const void* dres, void* dx_mid, float* dw_accum,
                      int copies, uint64_t copy_stride, const void* wot_packed, const void* qkv, const float* lse, const int32_t* key_len,
                      const int32_t* row_base, void* dqkv, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
-                     const int64_t* position_ids, float dropout_p, unsigned dropout_seed, int t_rows, hipStream_t st, int* taken) {
+                     const int64_t* position_ids, float dropout_p, unsigned dropout_seed, int t_rows, hipStream_t st, int* taken,
+                     void* dattn_long, const int32_t* long_list) {
   *taken = 0;
-  if (B == 0 || S == 0 || S > 32 || !attn_oproj_enabled() || k_get_deterministic()) return 0;
+  // S <= 32, or - var-len layout, with room for the long samples' dattn rows - S <= 64: every sample by its own row count
+  if (B == 0 || S == 0 || S > 64 || (S > 32 && (!row_base || !dattn_long || !attn_by_sample_rows())) || !attn_oproj_enabled() ||
+      k_get_deterministic())
+    return 0;
+  if (H != 2 && H != 4 && H != 8 && H != 12) return 0;
   GGET_REQUIRE(!row_base || key_len, "attention: the var-len token layout needs key_len");
   if (copies < 1) copies = 1;
   const Rope R{cos_tab, sin_tab, position_ids, S};     // rotation of dq, dk back to the un-rotated projections (q, k in memory are rotated)
   const Drop D = make_drop(dropout_p, dropout_seed);
-#define GGET_AOB(HH) case HH: *taken = 1; return launch_attn_oproj_bwd<HH>(dxn, x_mid, nw, rstd, dres, dx_mid, dw_accum, copies, copy_stride, wot_packed, qkv, lse, key_len, row_base, dqkv, B, S, causal, R, D, t_rows, st)
+  int rc = 0;
+#define GGET_AOB(HH) case HH: rc = launch_attn_oproj_bwd<HH>(dxn, x_mid, nw, rstd, dres, dx_mid, dw_accum, copies, copy_stride, wot_packed, qkv, lse, key_len, row_base, dqkv, B, S, causal, R, D, t_rows, st, dattn_long); break
   switch (H) {
     GGET_AOB(2); GGET_AOB(4); GGET_AOB(8); GGET_AOB(12);
-    default: return 0;
   }
 #undef GGET_AOB
+  if (rc) return rc;
+  *taken = 1;
+  if (S > 32) {     // the attention backward of the 33 .. 64-row samples, from the dattn rows the kernel above wrote for them
+    hipLaunchKernelGGL(attn_bwd_long_kernel, dim3(1, H, long_list ? std::min(B, kLongGrid) : B), dim3(128), 0, st, (const bf16_t*)qkv, (const bf16_t*)dattn_long,
+                       lse, key_len, (bf16_t*)dqkv, B, S, H, causal, R, D, row_base, long_list);
+    GGET_LAUNCH_CHECK();
+  }
+  return 0;
 }
 int k_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_len, void* dqkv,
                float* delta_ws, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,

@@ -201,7 +201,7 @@ struct Ws {
   // var-len token layout: first compact row of every sample [max_batch + 1], per compact row its sample index / position / ids, the
   // padded -> compact row map [max_tokens], a status word
   uint64_t vl_cu, vl_rowb, vl_pos, vl_ids, vl_pad2c, vl_c2p, vl_status;   // (vl_c2p: compact -> padded row map [max_tokens])
-  uint64_t vl_long;   // [max_batch + 1] int32: count and indices of the batch's 33 .. 64-row samples (varlen_scan_kernel)
+  uint64_t vl_long;   // [3 max_batch + 1] int32: count, indices, first rows and row counts of the batch's 33 .. 64-row samples (varlen_scan_kernel)
   uint64_t wo_pack = 0, wot_pack = 0;   // fragment-major copies of every layer's o weight / its transpose (S <= 32 per-sample kernels), [L][d][d] bf16
   uint64_t pos_safe;   // position ids clamped into the RoPE table (int64 [max_tokens]); the sticky "clamped" flag is vl_status[1]
   uint64_t sk_ws;      // stream-K GEMM launches: flags + one fp32 partial tile per block (gemm.h)
@@ -266,7 +266,7 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   w.wg32 = b.take(kWgSplit * 4 * d * d * 4);   // split-K slabs of the q|k|v|o wgrad
   w.long_wgt = b.take((uint64_t)c.max_batch * 4);
   w.vl_cu = b.take((Bm + 1) * 4);
-  w.vl_long = b.take((Bm + 1) * 4);
+  w.vl_long = b.take((3 * Bm + 1) * 4);
   w.vl_rowb = b.take(T * 4);
   w.vl_pos = b.take(T * 8);
   w.vl_ids = b.take(T * (uint64_t)c.stacked_feat * 8);
@@ -1348,8 +1348,11 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
     // S <= 32 without LayerScale / DropPath: the layers run the per-sample attention + o projection kernels (attention.hip), which read
     // fragment-major copies of the o weights.  They are rebuilt at the start of EVERY forward (one launch, ~10 us: the bf16 weights are the
     // caller's memory and change under AdamW, gget_sync_params or a caller's own writes); the backward of this forward uses the same copies.
+    // 32 < S <= 64: only the BACKWARD's per-sample kernel runs (var-len layout, every sample by its own row count); the copies are built
+    // whenever that layout can still be chosen for this forward
     h->wo_packed = false;
-    if (!h->plan.has_res && !mask_is_3d && S <= 32 && h->ws.wo_pack && c.num_layers > 0) {
+    const bool may_varlen = allow_varlen && varlen_enabled() && (tc_hint > 0 || tc_hint == GGET_TOKENS_AUTO) && mask != nullptr;
+    if (!h->plan.has_res && !mask_is_3d && (S <= 32 || (S <= 64 && may_varlen)) && h->ws.wo_pack && c.num_layers > 0) {
       const size_t stride = c.num_layers > 1 ? h->plan.layers[1].wo - h->plan.layers[0].wo : 0;
       bool regular = true;
       for (int i = 0; i < c.num_layers; ++i) regular = regular && h->plan.layers[i].wo == h->plan.layers[0].wo + (size_t)i * stride;
@@ -1698,13 +1701,15 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
   //  workgroups have their own CUs: the kernel may run whenever its one-workgroup-per-sample grid fits the CUs that are left.)
   const bool ao_bwd_ok = g_gemm_cu_reserve > 0 ? h->B <= gget_gemm_num_cu() : g_gemm_lds_headroom < 2;
   if (!h->plan.has_res && !h->klo() && h->wo_packed && ao_bwd_ok) {
-    // S <= 32: RMSNorm backward of post_attention_layernorm, the o projection's dgrad and the attention backward of a sample in ONE
-    // workgroup (attention.hip: attn_oproj_bwd_kernel); dattn is never materialised
+    // S <= 32, or S <= 64 on the var-len layout (every sample by its own row count): RMSNorm backward of post_attention_layernorm, the o
+    // projection's dgrad and the attention backward of a sample in ONE workgroup (attention.hip: attn_oproj_bwd_kernel); dattn is never
+    // materialised, except for the rows of 33 .. 64-row samples (their attention backward is a second, sparse launch)
     int taken = 0;
     if (int e = k_attn_oproj_bwd(dxn, xmid, h->P + lo.ln2, h->wsp<float>(lw.rstd2), dx_out, dx_mid, s32 + lo.ln2_32, kAccumCopies,
                                  align_up((uint64_t)d, 128), h->wsp<bf16_t>(w.wot_pack) + (size_t)i * d * d, h->wsp<bf16_t>(lw.qkv),
                                  h->wsp<float>(lw.lse), h->wsp<int32_t>(w.key_len), h->row_base(), dqkv, h->B, h->S, H, c.causal, h->cos_cur,
-                                 h->sin_cur, h->pos_cur, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, T, st, &taken))
+                                 h->sin_cur, h->pos_cur, h->attn_drop_p, h->attn_drop_seed + 0x9E37u * (unsigned)i, T, st, &taken,
+                                 dattn, h->long_list()))     // (dattn: only the rows of 33 .. 64-row samples are written, for their own launch)
       return e;
     front_fused = taken != 0;
   }
@@ -2339,11 +2344,12 @@ extern "C" int gget_op_attn_oproj_bwd(const void* dxn, const void* x_mid, const 
                                       float* dw_accum, int copies, uint64_t copy_stride, const void* wot_packed, const void* qkv, const float* lse,
                                       const int32_t* key_len, const int32_t* row_base, void* dqkv, int B, int S, int H, int causal,
                                       const float* cos_tab, const float* sin_tab, const int64_t* position_ids, float dropout_p,
-                                      uint32_t dropout_seed, int t_rows, void* stream, int32_t* taken) {
+                                      uint32_t dropout_seed, int t_rows, void* stream, int32_t* taken, void* dattn_long) {
   GGET_REQUIRE(dxn && x_mid && norm_w && rstd && dres && dx_mid && dw_accum && wot_packed && qkv && lse && dqkv && taken, "null argument");
   int t = 0;
   const int rc = k_attn_oproj_bwd(dxn, x_mid, norm_w, rstd, dres, dx_mid, dw_accum, copies, copy_stride, wot_packed, qkv, lse, key_len, row_base,
-                                  dqkv, B, S, H, causal, cos_tab, sin_tab, position_ids, dropout_p, dropout_seed, t_rows, (hipStream_t)stream, &t);
+                                  dqkv, B, S, H, causal, cos_tab, sin_tab, position_ids, dropout_p, dropout_seed, t_rows, (hipStream_t)stream, &t,
+                                  dattn_long, nullptr);
   *taken = t;
   return rc;
 }

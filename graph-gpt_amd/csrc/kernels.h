@@ -146,7 +146,8 @@ int k_pack_wo(const void* w0, size_t layer_stride, void* fwd, void* bwd, int d, 
 int k_attn_oproj_bwd(const void* dxn, const void* x_mid, const void* nw, const float* rstd, const void* dres, void* dx_mid, float* dw_accum,
                      int copies, uint64_t copy_stride, const void* wot_packed, const void* qkv, const float* lse, const int32_t* key_len,
                      const int32_t* row_base, void* dqkv, int B, int S, int H, int causal, const float* cos_tab, const float* sin_tab,
-                     const int64_t* position_ids, float dropout_p, unsigned dropout_seed, int t_rows, hipStream_t st, int* taken);   // t_rows: rows of the token-major buffers (var-len: the pad rows behind the last sample get a zero dx_mid)
+                     const int64_t* position_ids, float dropout_p, unsigned dropout_seed, int t_rows, hipStream_t st, int* taken,
+                     void* dattn_long = nullptr, const int32_t* long_list = nullptr);   // t_rows: rows of the token-major buffers (var-len: the pad rows behind the last sample get a zero dx_mid)
 int k_attn_oproj_fwd(const void* qkv, const int32_t* key_len, const int32_t* row_base, void* attn_out, float* lse, const void* wo,
                      const void* x_in, void* x_mid, const void* nw, void* xn, float* rstd, int B, int S, int H, int causal, float eps,
                      float dropout_p, unsigned dropout_seed, hipStream_t st, int* taken);

@@ -2287,8 +2287,9 @@ int k_lengths(const int64_t* mask, const int64_t* ids, int ldF, int pad_id, int3
 // one block: exclusive scan of key_len over the batch (any B), cu[B] = total; the pooled row of the task head (lengths_kernel: b*S + p)
 // moves to cu[b] + min(p, len - 1); status[0] = 1 when the total differs from the caller's token count (status[2]: the same, sticky -
 // gget_deferred_status reads and clears it)
-// long_list (may be NULL; int32 [B + 1]): [0] = number of samples of 33 .. 64 rows, [1 ..] their indices in ascending order - the work list
-// of the attention launches that take such samples apart from the one-tile ones (attention.hip: attn_fwd_long_kernel / attn_bwd_long_kernel)
+// long_list (may be NULL; int32 [3 B + 1]): [0] = number n of samples of 33 .. 64 rows, [1 .. n] their indices in ascending order, [1 + B ..]
+// their first rows, [1 + 2 B ..] their row counts - the work list of the launch that takes such samples apart from the one-tile ones
+// (attention.hip: attn_bwd_long_kernel; one read gives a block its whole work item)
 __global__ void __launch_bounds__(1024) varlen_scan_kernel(int32_t* __restrict__ key_len, int32_t* __restrict__ cu,
                                                            int32_t* __restrict__ pool_row, int32_t* __restrict__ status, int B, int S,
                                                            int expect_total, int32_t* __restrict__ long_list) {
@@ -2334,6 +2335,8 @@ __global__ void __launch_bounds__(1024) varlen_scan_kernel(int32_t* __restrict__
       for (int w = 0; w < wave; ++w) lpos += lsum[w];
       lpos += __popcll(bal & ((1ull << lane) - 1ull));
       long_list[1 + lpos] = b;
+      long_list[1 + B + lpos] = cu[b];        // (this thread wrote cu[b] above)
+      long_list[1 + 2 * B + lpos] = len;
     }
     __syncthreads();
     if (tid == 1023) {

@@ -448,7 +448,7 @@ int gget_op_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, 
  * row_base (int32 [B], may be NULL): first row of sample b in the token-major buffers (var-len layout; then key_len[b] rows belong to it),
  * NULL = padded layout, sample b at rows [b S, b S + S).  Outputs: attn_out [rows, d] bf16, lse fp32 [B, H, S] (natural log), x_mid =
  * x_in + attn_out Wo^T (bf16, residual added on the fp32 accumulator: one rounding), xn = norm_w * bf16(x_mid * rstd) and rstd fp32 [rows].
- * *taken = 1 when the fused form ran; 0 when the shape is not covered (S > 32, H not in {2, 4, 8, 12, 16}, GGET_ATTN_OPROJ=0) - nothing
+ * *taken = 1 when the fused form ran; 0 when the shape is not covered (S > 32, H not in {2, 4, 8, 12}, GGET_ATTN_OPROJ=0) - nothing
  * is written then and the caller runs gget_op_attn_fwd, a GEMM and gget_op_rmsnorm_fwd. */
 int gget_op_attn_oproj_fwd(const void* qkv, const int32_t* key_len, const int32_t* row_base, void* attn_out, float* lse, const void* wo_packed,
                            const void* x_in, void* x_mid, const void* norm_w, void* xn, float* rstd, int B, int S, int H, int causal,
@@ -461,12 +461,15 @@ int gget_op_pack_wo(const void* w, uint64_t layer_stride, void* fwd, void* bwd, 
  * `copies` replicas `copy_stride` floats apart, as gget_op_rmsnorm_bwd's) - then dattn = dx_mid Wo (never written to memory) and the
  * attention backward of every head: dqkv [rows, 3 d] with dq / dk rotated BACK by cos_tab / sin_tab / position_ids (NULL tables: no
  * rotation).  wot_packed = gget_op_pack_wo's `bwd` output.  t_rows = rows of the token-major buffers (var-len layout: dx_mid of the pad
- * rows behind the last sample is zeroed).  *taken as above; also 0 in the reproducible mode (gget_debug_set(4, 1)). */
+ * rows behind the last sample is zeroed).  *taken as above; also 0 in the reproducible mode (gget_debug_set(4, 1)).
+ * Var-len layout (row_base != NULL) with 32 < S <= 64: every sample by its own row count.  A sample of 33 .. 64 rows takes the first two
+ * steps in its workgroup, over two row tiles; its dattn rows go to dattn_long (bf16 [t_rows, d]; rows of other samples are not touched;
+ * NULL: the launch is not taken for S > 32) and a second launch on the same stream (attn_bwd_long_kernel) does its attention backward. */
 int gget_op_attn_oproj_bwd(const void* dxn, const void* x_mid, const void* norm_w, const float* rstd, const void* dres, void* dx_mid,
                            float* dw_accum, int copies, uint64_t copy_stride, const void* wot_packed, const void* qkv, const float* lse,
                            const int32_t* key_len, const int32_t* row_base, void* dqkv, int B, int S, int H, int causal, const float* cos_tab,
                            const float* sin_tab, const int64_t* position_ids, float dropout_p, uint32_t dropout_seed, int t_rows,
-                           void* stream, int32_t* taken);
+                           void* stream, int32_t* taken, void* dattn_long);
 /* attention with a per-token inclusive key range [key_lo, key_hi] (int32 [B,S]; packed rows) instead of one length per
  * batch row; gget_op_ranges_from_mask3d derives the ranges from a block-diagonal int64 [B,S,S] mask. */
 int gget_op_attn_fwd_ranges(const void* qkv, const int32_t* key_lo, const int32_t* key_hi, void* out, float* lse, int B, int S,

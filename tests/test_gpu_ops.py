@@ -1018,12 +1018,18 @@ def test_pack_wo_layout(lib):
 
 @pytest.mark.parametrize("varlen", [False, True])
 @pytest.mark.parametrize("B,S,H,causal,p,rope", [(5, 24, 2, 0, 0.0, False), (3, 32, 12, 0, 0.1, True), (7, 32, 12, 1, 0.0, True), (260, 32, 12, 0, 0.1, False),
-                                                 (4, 16, 4, 0, 0.0, True), (3, 32, 8, 0, 0.0, False)])
+                                                 (4, 16, 4, 0, 0.0, True), (3, 32, 8, 0, 0.0, False),
+                                                 # 32 < S <= 64, var-len layout: samples of 33 .. 64 rows take phases A / B over two row tiles, their
+                                                 # attention backward is attn_bwd_long_kernel's from the dattn rows written for them
+                                                 (6, 40, 12, 0, 0.1, True), (5, 56, 2, 1, 0.0, False), (9, 64, 8, 0, 0.1, False), (260, 48, 12, 0, 0.1, True),
+                                                 (7, 40, 4, 1, 0.1, False)])
 def test_attn_oproj_norm_fused_backward(lib, B, S, H, causal, p, rope, varlen):
     """The backward counterpart (attn_oproj_bwd_kernel: RMSNorm backward + o projection dgrad + attention backward per sample) against the
     three launches it replaces, run through their own op entries on the same inputs: dx_mid and the norm weight gradient of
     gget_op_rmsnorm_bwd, dattn = dx_mid Wo by an fp32 matmul rounded to bf16 (what the GEMM stores), dqkv of gget_op_attn_bwd (same
     arithmetic and dropout hash; its dO operand is the bf16 dattn)."""
+    if S > 32 and not varlen:
+        pytest.skip("the padded layout is covered for S <= 32")
     d = H * 64
     lens = torch.tensor([[S, max(3, S // 2), max(1, S - 3), 1][i % 4] for i in range(B)], dtype=torch.int32)
     cu = torch.zeros(B + 1, dtype=torch.int32)
@@ -1067,10 +1073,19 @@ def test_attn_oproj_norm_fused_backward(lib, B, S, H, causal, p, rope, varlen):
     copies, cstride = 4, 1024
     dw = torch.zeros(copies * cstride, dtype=torch.float32, device="cuda")
     taken = C.c_int32(0)
+    dattn_long = torch.full((rows, d), sentinel, dtype=torch.bfloat16, device="cuda")
     L.check(lib.gget_op_attn_oproj_bwd(P(dxn), P(x_mid), P(nw), P(rstd), P(dres), P(dx_mid), P(dw), copies, cstride, P(wo_b), P(qkv), P(lse),
-                                       P(lens_d), P(row_base), P(dqkv), B, S, H, causal, P(cos), P(sin), P(pos), p, seed, rows, ST(), C.byref(taken)))
+                                       P(lens_d), P(row_base), P(dqkv), B, S, H, causal, P(cos), P(sin), P(pos), p, seed, rows, ST(), C.byref(taken),
+                                       P(dattn_long)))
     assert taken.value == 1
     torch.cuda.synchronize()
+    # (dattn exists in memory for the rows of 33 .. 64-row samples only)
+    long_rows = torch.zeros(rows, dtype=torch.bool)
+    for b in range(B):
+        if varlen and nrow[b] > 32:
+            long_rows[r0[b]: r0[b] + nrow[b]] = True
+    long_rows = long_rows.cuda()
+    assert bool((dattn_long[~long_rows].float() == sentinel).all()), "dattn rows of one-tile samples / foreign rows were written"
     # ---- the three launches
     ref_dx = torch.empty(rows, d, dtype=torch.bfloat16, device="cuda")
     ref_dw = torch.zeros(d, dtype=torch.float32, device="cuda")
@@ -1089,6 +1104,8 @@ def test_attn_oproj_norm_fused_backward(lib, B, S, H, causal, p, rope, varlen):
     got_dw = dw.view(copies, cstride)[:, :d].sum(0)
     assert rel_l2(got_dw.cpu().numpy(), want_dw.cpu().numpy()) < 1e-4
     dattn = (ref_dx.float() @ wo.float()).to(torch.bfloat16)            # [rows, d]: dgrad of y = a Wo^T
+    if bool(long_rows.any()):
+        assert rel_l2(dattn_long[long_rows].float().cpu().numpy(), dattn[long_rows].float().cpu().numpy()) < 3e-3
     dattn_p = torch.zeros(B * S, d, dtype=torch.bfloat16, device="cuda")
     for b in range(B):
         dattn_p[b * S: b * S + nrow[b]] = dattn[r0[b]: r0[b] + nrow[b]]

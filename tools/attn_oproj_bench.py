@@ -10,7 +10,7 @@ synth = importlib.import_module("graph-gpt_amd.synth")
 lib = L.load()
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-B, S, H, p = int(os.environ.get("B", "256")), 32, 12, 0.1
+B, S, H, p = int(os.environ.get("B", "256")), int(os.environ.get("S", "32")), 12, 0.1      # S=40 / 56: every sample by its own row count (round 6)
 d = H * 64
 lens = torch.from_numpy(synth.make_pretrain_batch(B=B, S=S, F=13, V=756, seed=1234)["attention_mask"].sum(1).astype(np.int32))
 cu = torch.zeros(B + 1, dtype=torch.int32); cu[1:] = torch.cumsum(lens, 0)
@@ -30,6 +30,7 @@ for o in sets:     # fragment-major copies of the o weight (the engine rebuilds 
     L.check(lib.gget_op_pack_wo(P(o["wo"]), 0, P(o["wo_f"]), P(o["wo_b"]), d, 1, st))
     o["dxn"], o["dres"], o["dxmid"] = mk(R, d, sc=0.5), mk(R, d, sc=0.5), torch.empty(R, d, dtype=torch.bfloat16, device="cuda")
     o["dattn"], o["dqkv"] = torch.empty(R, d, dtype=torch.bfloat16, device="cuda"), torch.empty(R, 3 * d, dtype=torch.bfloat16, device="cuda")
+    o["dattn_long"] = torch.empty(R, d, dtype=torch.bfloat16, device="cuda")
     o["dw"] = torch.zeros(16 * 1024, dtype=torch.float32, device="cuda")
     o["delta"] = torch.empty(B * H * S, dtype=torch.float32, device="cuda")
 
@@ -39,8 +40,8 @@ def fused(o):
                                        P(o["xn"]), P(o["rstd"]), B, S, H, 0, 1e-6, p, 7, st, C.byref(taken)))
 
 
-def attn_only(o):     # (padded-grid op entry: the same samples at rows b * S - what the one-wave kernel costs is the same in both layouts)
-    L.check(lib.gget_op_attn_fwd(P(o["qkv"]), P(lens_d), P(o["attn"]), P(o["lse"]), B, S, H, 0, None, None, None, p, 7, st))
+def attn_only(o):     # (the var-len entry: one-tile kernel + the launch of the 33 .. 64-row samples when S > 32)
+    L.check(lib.gget_op_attn_fwd_varlen(P(o["qkv"]), P(lens_d), P(rb), P(o["attn"]), P(o["lse"]), B, S, H, 0, None, None, None, 1, p, 7, st))
 
 
 def gemm(o):
@@ -57,7 +58,8 @@ def separate(o):
 
 def fused_bwd(o):
     L.check(lib.gget_op_attn_oproj_bwd(P(o["dxn"]), P(o["xmid"]), P(o["nw"]), P(o["rstd"]), P(o["dres"]), P(o["dxmid"]), P(o["dw"]), 16, 1024, P(o["wo_b"]),
-                                       P(o["qkv"]), P(o["lse"]), P(lens_d), P(rb), P(o["dqkv"]), B, S, H, 0, None, None, None, p, 7, T, st, C.byref(taken)))
+                                       P(o["qkv"]), P(o["lse"]), P(lens_d), P(rb), P(o["dqkv"]), B, S, H, 0, None, None, None, p, 7, T, st, C.byref(taken),
+                                       P(o["dattn_long"])))
 
 
 def norm_bwd(o):
@@ -69,8 +71,8 @@ def gemm_bwd(o):
 
 
 def attn_bwd(o):
-    L.check(lib.gget_op_attn_bwd(P(o["qkv"]), P(o["attn"]), P(o["dattn"]), P(o["lse"]), P(lens_d), P(o["dqkv"]), P(o["delta"]), B, S, H, 0, None, None, None,
-                                 p, 7, st))
+    L.check(lib.gget_op_attn_bwd_varlen(P(o["qkv"]), P(o["attn"]), P(o["dattn"]), P(o["lse"]), P(lens_d), P(rb), P(o["dqkv"]), P(o["delta"]), B, S, H, 0,
+                                        None, None, None, 1, p, 7, st))
 
 
 def separate_bwd(o):
@@ -94,10 +96,10 @@ def timeit(fn, iters=30):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-fused(sets[0]); assert taken.value == 1
+fused(sets[0]); fwd_taken = taken.value == 1      # (S > 32: the forward keeps its three launches)
 for o in sets: separate(o)      # (lse, rstd, x_mid of every set: the backward's inputs)
 fused_bwd(sets[0]); assert taken.value == 1
-cases = (("fused", fused), ("separate", separate), ("attn", attn_only), ("gemm", gemm), ("norm", norm), ("fused_bwd", fused_bwd),
+cases = ((("fused", fused),) if fwd_taken else ()) + (("separate", separate), ("attn", attn_only), ("gemm", gemm), ("norm", norm), ("fused_bwd", fused_bwd),
          ("separate_bwd", separate_bwd), ("norm_bwd", norm_bwd), ("gemm_bwd", gemm_bwd), ("attn_bwd", attn_bwd), ("pack_12_layers", pack_all))
 res = {k: [] for k, _ in cases}
 for r in range(5):
@@ -106,4 +108,5 @@ for r in range(5):
 for k, v in res.items():
     print(f"{k:9s} median {statistics.median(v):7.2f} us   min {min(v):7.2f} us")
 wbytes = d * d * 2
-print(f"weight stream per sample {wbytes / 1e6:.2f} MB; fused launch = {B * wbytes / statistics.median(res['fused']) / 1e6:.2f} TB/s of L2 -> CU traffic over all CUs")
+if fwd_taken:
+    print(f"weight stream per sample {wbytes / 1e6:.2f} MB; fused launch = {B * wbytes / statistics.median(res['fused']) / 1e6:.2f} TB/s of L2 -> CU traffic over all CUs")

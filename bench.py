@@ -243,6 +243,9 @@ def main():
                          "8 * ceil(max_len / 8) of its longest graph (reference src/data/collator.py:70-111), so real PCQM4M-v2 batches of 256 graphs "
                          "are rarely S <= 32; the lengths keep the workload's distribution (clipped N(22, 6), one graph of the batch at the full width). "
                          "0 = the workload's own S (the headline line)")
+    ap.add_argument("--mean-len", type=float, default=22.0,
+                    help="mean of the graphs' token count (clipped N(mean, 6); 22 = the workload's own): moves the var-len row count of the "
+                         "batches, the shape every GEMM launch plan is chosen for (tools/rows_sweep.py)")
     ap.add_argument("--long-tail", type=float, default=0.0,
                     help="fraction of the graphs redrawn uniformly from (32, S] (a heavier long tail than the clipped normal's; needs --seq-len > 32)")
     ap.add_argument("--layout", default="varlen", choices=["varlen", "varlen-count", "padded"],
@@ -280,6 +283,8 @@ def main():
         assert kind == "pt", "--seq-len: pre-train workloads"
         S = a.seq_len
     tail = dict(long_tail=a.long_tail) if a.long_tail > 0 else {}
+    if a.mean_len != 22.0:
+        tail["mean_len"] = a.mean_len
     sz = spec_mod.MODEL_SIZES[size]
     pt = kind.startswith("pt")
     extra = {}

@@ -1691,7 +1691,25 @@ int launch_t(GemmGroup& g, int split_k, hipStream_t st) {
       }
       // rounds x tile area: take 128x192 when it needs less per-CU work than the default tile
       const long cur_rounds = (total + num_cu - 1) / num_cu, r192 = (t192 + num_cu - 1) / num_cu;
-      if (ok && r192 * 128 * 192 < cur_rounds * BM * BN) {
+      // ... or when the K-split arrangement below fits ONE round at no more than 1.3x the default tiling's per-CU work: the default tiling
+      // of an N = d launch happens to fit one round of 128x128 tiles from M <= 5 376 down (42 x 6 = 252 tiles), and the area rule then
+      // kept it although it runs 66 us where the 96x192 K-split tiles run 47 (dxn2 at M = 5 376, profiles/r06_step_experiments.txt item 2:
+      // a batch a few dozen tokens shorter than the headline's 5 696 rows cost +0.35 ms per step).  Only for launches that fill most of
+      // the chip either way (>= 60 % of the CUs): small launches keep their tiling.
+      bool ks_first = false;
+      if constexpr (EPI != GGET_EPI_ROPE) {
+        if (ok && !(g_gemm_variant & 1) && cur_rounds == 1 && total * 10 >= (long)num_cu * 6 && !(g_gemm_variant & 512)) {
+          bool can = true;
+          for (int i = 0; i < g.count; ++i) can = can && !g.p[i].m_dev && !g.p[i].k_dev && (g.p[i].N % 192) == 0 && g.p[i].K >= 1536;
+          if (can)
+            for (int cand : {64, 96, 128}) {
+              long t = 0;
+              for (int i = 0; i < g.count; ++i) t += (long)((g.p[i].M + cand - 1) / cand) * (g.p[i].N / 192);
+              if (t <= num_cu) { ks_first = (long)cand * 192 * 10 <= (long)BM * BN * 13; break; }
+            }
+        }
+      }
+      if (ok && (r192 * 128 * 192 < cur_rounds * BM * BN || ks_first)) {
         int tot3 = 0;
         for (int i = 0; i < g.count; ++i) {
           GemmProblem& p = g.p[i];

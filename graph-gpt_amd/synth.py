@@ -22,13 +22,13 @@ PAD_TOKEN_ID = 0
 LABEL_PAD = -100
 
 
-def _lengths(rng, B, S, mode: str, min_len: int):
+def _lengths(rng, B, S, mode: str, min_len: int, mean_len: float = 22.0):
     if mode == "full":
         return np.full(B, S, np.int64)
     if mode == "uniform":
         return rng.randint(min_len, S + 1, size=B).astype(np.int64)
     if mode == "pcqm":  # clipped N(22, 6), min 6
-        ln = np.rint(rng.normal(22.0, 6.0, size=B)).astype(np.int64)
+        ln = np.rint(rng.normal(mean_len, 6.0, size=B)).astype(np.int64)
         return np.clip(ln, max(6, min_len), S)
     raise ValueError(mode)
 
@@ -36,11 +36,11 @@ def _lengths(rng, B, S, mode: str, min_len: int):
 def make_pretrain_batch(B: int, S: int, F: int, V: int, seed: int = 1234, *, lengths: str = "pcqm",
                         min_len: int = 4, first_id: int = 22, power: float = 1.0,
                         umr_clip=(0.01, 0.99), dlm_wgt: bool = False, force_full_row: bool = True,
-                        long_tail: float = 0.0) -> Dict[str, np.ndarray]:
+                        long_tail: float = 0.0, mean_len: float = 22.0) -> Dict[str, np.ndarray]:
     """SMTP pre-train batch: input_ids/labels i64 [B,S,F], attention_mask/position_ids i64 [B,S]."""
     assert S % 8 == 0 or True  # collator pads to a multiple of 8; callers choose S accordingly
     rng = np.random.RandomState(seed)
-    lens = _lengths(rng, B, S, lengths, min_len)
+    lens = _lengths(rng, B, S, lengths, min_len, mean_len)
     if force_full_row and lengths != "full":
         lens[rng.randint(B)] = S  # the batch max defines S in the real collator
     if long_tail > 0.0 and S > 32:   # a heavier long tail (bench.py --long-tail): own generator, the other draws stay those of long_tail = 0

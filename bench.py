@@ -311,9 +311,12 @@ def main():
         batch = synth.make_packed_pretrain_batch(B=B, S=S, F=F, V=V, seed=1234 + rank, mean_len=22, min_len=6)
         real_tokens = int(batch["lengths"].sum())
     else:
-        batch = synth.make_task_batch(B=B, S=S, F=F, V=V, seed=1234 + rank, lengths="uniform" if kind == "ft" else "full",
-                                      min_len=S // 4)
+        mk_task = lambda sd: synth.make_task_batch(B=B, S=S, F=F, V=V, seed=sd, lengths="uniform" if kind == "ft" else "full", min_len=S // 4)
+        batch = mk_task(1234 + rank)
         real_tokens = synth.real_tokens(batch)
+        # (a rotation here as well since round 6: on ONE repeated batch the fine-tune model memorises it within 25 steps - loss 2.8e-6 /
+        #  6.0e-8 in profiles/r05_other_workloads.json - harmless for the timing, useless as a loss sanity figure)
+        extra_batches = [mk_task(1234 + rank + 1000 * i) for i in range(1, max(1, a.batches))]
     dev = {k: torch.from_numpy(v).cuda() for k, v in batch.items() if k not in ("lengths", "segments")}
     # the rotation: batch 0 (seed 1234 + rank: the batch of the probes, the parity leg and the CPU baseline) and the extra ones
     host_batches = [batch] + extra_batches

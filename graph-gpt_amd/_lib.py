@@ -64,6 +64,7 @@ SIGNATURES = {
     "gget_head_logits": (i32, [vp, C.POINTER(vp), C.POINTER(i32)]),
     "gget_hidden_states": (i32, [vp, C.POINTER(vp)]),
     "gget_layer_hidden_states": (i32, [vp, i32, C.POINTER(vp)]),
+    "gget_hidden_states_grid": (i32, [vp, i32, vp, vp]),
     "gget_op_gemm": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "gget_op_gemm_streamk": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "gget_op_gemm_streamk_bytes": (u64, []),

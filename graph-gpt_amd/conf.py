@@ -183,6 +183,8 @@ def optim_from_training(train_cfg, use_deepspeed: bool, finetune: bool):
     kw = dict(lr=lr, betas=tuple(_get(oc, "betas")), eps=float(_get(oc, "eps")), weight_decay=float(_get(oc, "weight_decay")),
               max_grad_norm=float(_get(oc, "max_grad_norm")), warmup_num_steps=int(warm), total_num_steps=int(total))
     if use_deepspeed:
+        # conf_utils.py:59-66: the DS engine gets `gradient_accumulation_steps` (its step() fires at the boundary only)
+        kw["gradient_accumulation_steps"] = int(_get(oc, "gradient_accumulation_steps", 1) or 1)
         kind = ds_scheduler_type(train_cfg, "OneCycleLR" if finetune else "WarmupDecayLR")
         if kind == "WarmupDecayLR":
             return OptimConfig(schedule="warmup_decay", min_lr=lr, **kw)

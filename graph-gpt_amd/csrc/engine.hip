@@ -736,6 +736,7 @@ extern "C" int gget_set_dropout(gget_handle_t h, float attention_p, float path_p
 
 extern "C" int gget_sync_params(gget_handle_t h, void* stream) {
   GGET_REQUIRE(h && h->master, "sync_params needs the fp32 master arena");
+  h->wo_packed = false;      // the bf16 weights change: a backward that follows must not read the fragment-major o-weight copies of the last forward
   return k_f32_to_bf16(h->master, h->P, h->plan.n_params, (hipStream_t)stream);
 }
 
@@ -2072,6 +2073,7 @@ extern "C" int gget_adamw_step(gget_handle_t h, float lr, float beta1, float bet
   GGET_REQUIRE(h && h->master && h->am && h->av, "adamw needs master/m/v arenas");
   GGET_REQUIRE(step >= 1, "step is 1-based");
   hipStream_t st = (hipStream_t)stream;
+  h->wo_packed = false;      // (see gget_sync_params; the next forward rebuilds the copies)
   float* sq = h->wsp<float>(h->ws.sqnorm);
   const bool need_norm = max_grad_norm > 0.f || gnorm_dev != nullptr || h->opt_skip_nonfinite;
   if (need_norm) {
@@ -2118,6 +2120,24 @@ extern "C" int gget_layer_hidden_states(gget_handle_t h, int layer, const void**
   GGET_REQUIRE(!h->varlen, "layer_hidden_states: the last forward ran on the var-len token layout (rows are compacted): run that forward on the padded grid - no token count at the C ABI, num_tokens=None with a host-side mask or GGET_VARLEN=0 through the model classes, or ask the model for output_hidden_states=True");
   *hidden_dev = h->wsp<bf16_t>(h->ws.xres[layer]);
   return 0;
+}
+
+// The same two quantities in the reference's [B,S,d] layout WHATEVER layout the forward ran on: layer = -1 the final-normed hidden states
+// (gget_hidden_states), 0 .. num_layers the residual stream entering that layer (gget_layer_hidden_states).  After a var-len forward the
+// compact rows are spread over the grid through the padded -> compact map and the positions behind a sample's tokens read as zero
+// (the padded layout computes values there that nothing downstream uses).  out_dev: bf16 [B * S * d] of the last forward's B, S.
+extern "C" int gget_hidden_states_grid(gget_handle_t h, int layer, void* out_dev, void* stream) {
+  GGET_REQUIRE(h && out_dev, "null argument");
+  GGET_REQUIRE(layer >= -1 && layer <= h->cfg.num_layers, "hidden_states_grid: layer %d out of range", layer);
+  GGET_REQUIRE(h->B > 0 && h->S > 0, "hidden_states_grid: no forward has run");
+  const bf16_t* src = layer < 0 ? h->wsp<bf16_t>(h->ws.hidden) : h->wsp<bf16_t>(h->ws.xres[layer]);
+  const int d = h->cfg.hidden_size;
+  const long n_pos = (long)h->B * h->S;
+  if (!h->varlen) {
+    GGET_HIP_CHECK(hipMemcpyAsync(out_dev, src, (size_t)n_pos * d * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+  }
+  return k_rows_to_grid(src, h->wsp<int32_t>(h->ws.vl_pad2c), out_dev, n_pos, d, (hipStream_t)stream);
 }
 
 // ================================================================================================

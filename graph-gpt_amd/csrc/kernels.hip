@@ -2442,6 +2442,28 @@ int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, int32_
   GGET_LAUNCH_CHECK();
   return 0;
 }
+// compact rows -> the padded [B,S] grid (hidden-state accessors after a var-len forward): out[i] = src[pad2c[i]], zero where the padded
+// position holds no token; one thread per 16-byte piece
+__global__ void __launch_bounds__(kBlock) rows_to_grid_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ pad2c,
+                                                              bf16_t* __restrict__ out, long n_pos, int d) {
+  const int cpr = d / 8;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n_pos * cpr; i += (long)gridDim.x * kBlock) {
+    const long pos = i / cpr;
+    const int c = (int)(i % cpr);
+    const int r = pad2c[pos];
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (r >= 0) v = *reinterpret_cast<const uint4*>(src + (size_t)r * d + c * 8);
+    *reinterpret_cast<uint4*>(out + (size_t)pos * d + c * 8) = v;
+  }
+}
+int k_rows_to_grid(const void* src, const int32_t* pad2c, void* out, long n_pos, int d, hipStream_t st) {
+  if (n_pos == 0) return 0;
+  hipLaunchKernelGGL(rows_to_grid_kernel, dim3(grid_for(n_pos * (d / 8), kBlock, 4096)), dim3(kBlock), 0, st, (const bf16_t*)src, pad2c, (bf16_t*)out,
+                     n_pos, d);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
 // a var-len step that ran on a caller's token count the mask contradicts computed garbage: its loss becomes NaN (and the sticky flag
 // status[2] stays up for gget_deferred_status) instead of a plausible number
 __global__ void poison_loss_kernel(const int32_t* __restrict__ flag, float* __restrict__ loss) {

@@ -366,16 +366,14 @@ class Engine:
         return conf, tok
 
     def hidden_states(self, B: int, S: int) -> torch.Tensor:
-        p = C.c_void_p()
-        L.check(self.lib.gget_hidden_states(self.h, C.byref(p)))
-        off = p.value - self.workspace.data_ptr()
-        d = self.spec.hidden_size
-        return self.workspace[off: off + B * S * d * 2].view(torch.bfloat16).view(B, S, d).clone()
+        """bf16 [B,S,d] final-normed hidden states of the last forward (a copy; either token layout - gget_hidden_states_grid)."""
+        return self._hidden_grid(-1, B, S)
 
     def layer_hidden_states(self, layer: int, B: int, S: int) -> torch.Tensor:
         """bf16 [B,S,d] residual stream entering decoder layer `layer` (num_layers = leaving the last one) of the last forward (a copy)."""
-        p = C.c_void_p()
-        L.check(self.lib.gget_layer_hidden_states(self.h, int(layer), C.byref(p)))
-        off = p.value - self.workspace.data_ptr()
-        d = self.spec.hidden_size
-        return self.workspace[off: off + B * S * d * 2].view(torch.bfloat16).view(B, S, d).clone()
+        return self._hidden_grid(int(layer), B, S)
+
+    def _hidden_grid(self, layer: int, B: int, S: int) -> torch.Tensor:
+        out = torch.empty(B, S, self.spec.hidden_size, dtype=torch.bfloat16, device=self.device)
+        L.check(self.lib.gget_hidden_states_grid(self.h, layer, _ptr(out), _stream()))
+        return out

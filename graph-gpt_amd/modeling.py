@@ -423,9 +423,10 @@ class _GgetModel(nn.Module):
     def _collect_hidden_states(self, B, S):
         """`outputs.hidden_states` of the reference's backbone with output_hidden_states=True (hf LlamaModel.forward
         modeling_llama.py:401-414): a tuple of L + 1 tensors [B,S,d] - the residual stream entering every decoder layer, then the
-        FINAL-NORMED output of the last layer.  bf16 copies of the engine's activations (gget_layer_hidden_states /
-        gget_hidden_states); the forward that filled them ran on the padded [B,S] grid (the accessors index padded rows)."""
-        e = self._engine      # (the accessors refuse after a var-len forward - GGET_VARLEN=sync - with a hint)
+        FINAL-NORMED output of the last layer.  bf16 copies of the engine's activations in the [B,S,d] layout whatever token layout
+        the forward ran on (gget_hidden_states_grid: after a var-len forward the compact rows go back to their positions, the
+        positions behind a sample's tokens read as zero - the reference computes values there that nothing uses)."""
+        e = self._engine
         return tuple(e.layer_hidden_states(i, B, S) for i in range(self.spec.num_layers)) + (e.hidden_states(B, S),)
 
     def _wrap_loss(self, loss):
@@ -462,7 +463,7 @@ class GraphGPTPretrainBase(_GgetModel):
         assert input_ids.shape[2] == self.spec.stacked_feat, \
             f"stacked_feat: {self.spec.stacked_feat}\nx.shape: {tuple(input_ids.shape)}"  # modeling_common.py:131-133
         want_hs = self._want_hidden_states(output_hidden_states)
-        n_real = None if want_hs else self._token_count(attention_mask, num_tokens)     # (hidden states are read from the padded grid)
+        n_real = self._token_count(attention_mask, num_tokens)     # (hidden states: gget_hidden_states_grid spreads the compact rows back)
         if attention_mask is None:
             attention_mask = torch.ones(B, S, dtype=torch.int64)
         assert attention_mask.dim() in (2, 3), "attention_mask is [B,S] (right padding) or [B,S,S] (packed, block-diagonal)"
@@ -495,7 +496,7 @@ class GraphGPTTaskModel(_GgetModel):
             input_ids = input_ids[:, :, None]
         B, S = input_ids.shape[:2]
         want_hs = self._want_hidden_states(output_hidden_states)
-        n_real = None if want_hs else self._token_count(attention_mask, num_tokens)
+        n_real = self._token_count(attention_mask, num_tokens)
         if attention_mask is None:
             attention_mask = torch.ones(B, S, dtype=torch.int64)
         cfg = self.config

@@ -54,7 +54,9 @@ class OptimConfig:
     """Defaults = the reference pre-train launch script (examples/graph_lvl/pcqm4m_v2_pretrain.sh:53-57)."""
 
     def __init__(self, lr=3e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1, max_grad_norm=1.0, min_lr=0.0,
-                 warmup_num_steps=0, total_num_steps=0, schedule="constant", onecycle_extra_step=1):
+                 warmup_num_steps=0, total_num_steps=0, schedule="constant", onecycle_extra_step=1, gradient_accumulation_steps=1):
+        # micro-batches per optimizer step (the DeepSpeed engine's `gradient_accumulation_steps`, conf_utils.py:59-66): see GgetEngine.step
+        self.gradient_accumulation_steps = max(1, int(gradient_accumulation_steps))
         self.lr, self.betas, self.eps, self.weight_decay = lr, tuple(betas), eps, weight_decay
         self.max_grad_norm, self.min_lr = max_grad_norm, min_lr
         self.warmup_num_steps, self.total_num_steps, self.schedule = warmup_num_steps, total_num_steps, schedule
@@ -187,6 +189,15 @@ class GgetEngine:
         # the ranks then drift apart, so it is only ever set for a few untimed-for-throughput diagnostic steps
         self.exchange = True
         self.reserved_cus = 0
+        self._dp_menu_set = False      # this engine switched the process-wide GEMM launch menu (gget_debug_set keys 2 / 13 / 15): close() restores it
+        # gradient accumulation (DeepSpeed branch, conf_utils.py:59-66 -> the DS engine steps at the boundary only): the micro-batches'
+        # gradients are summed in an fp32 copy of the flat gradient array; step() k - 1 times out of k only does that
+        self.micro_steps = 0
+        self._grad_acc = None
+        # GradScaler's rule of the reference's DDP branch (training_utils.py:46-86): an optimizer step whose gradient norm is inf / NaN is
+        # skipped (weights and Adam state untouched, Adam's step count not advanced) while the LR schedule still advances
+        self.skip_nonfinite = False
+        self.skipped_steps = 0
         if self.world > 1 and torch.cuda.is_available():
             # a collective's kernel shares the chip with the compute stream from now on: the GEMM launcher keeps LDS headroom on every
             # CU (no launch with two LDS-filling workgroups per CU; gget_debug_set key 2)
@@ -195,6 +206,7 @@ class GgetEngine:
             #  shows the rule buys nothing against such a kernel and costs 0.08 ms alone, 0.2 ms beside it: opt-in now, GGET_DP_LDS_HEADROOM=1)
             if bool(int(os.environ.get("GGET_DP_LDS_HEADROOM", "0"))):
                 L.check(L.load().gget_debug_set(2, 2))
+                self._dp_menu_set = True
             # (superseded below, in a real multi-process job, by the stronger rule: CUs of their own for the collective - the two-per-CU launch
             #  returns then, and the per-sample backward runs whenever its grid fits the CUs that are left)
             # ... and, in a real multi-process job that asks for it, the GEMM launches leave GGET_DP_RESERVE_CUS CUs (default 0 = off) FREE for the
@@ -206,12 +218,31 @@ class GgetEngine:
             if real_world > 1:
                 self.reserved_cus = max(0, int(os.environ.get("GGET_DP_RESERVE_CUS", "0")))
                 if self.reserved_cus:
-                    os.environ.setdefault("NCCL_MAX_NCHANNELS", str(self.reserved_cus))   # (read when the communicator is created)
+                    # (NCCL_MAX_NCHANNELS is read when the communicator is created - before this constructor runs: dp_env_defaults()
+                    #  sets it, from the same variable, ahead of init_process_group; bench.py and set_dist_env call it)
                     L.check(L.load().gget_debug_set(15, self.reserved_cus))
                     L.check(L.load().gget_debug_set(13, 0))
                     L.check(L.load().gget_debug_set(2, 1))
+                    self._dp_menu_set = True
         model.materialize_grads = False  # fused path: gradients stay in the flat bf16 arena
         model._managed_by_engine = True  # the bucketed exchange below replaces the all-reduce of _autograd_backward
+
+    def close(self):
+        """Give back what this engine changed process-wide: the data-parallel GEMM launch menu (keys 2 / 13 / 15 of gget_debug_set are
+        globals of the library, not of a handle - ADVICE r5) goes back to the single-GPU defaults.  Idempotent; also run when the object dies."""
+        if getattr(self, "_dp_menu_set", False):
+            self._dp_menu_set = False
+            try:
+                from . import _lib as L
+                lib = L.load()
+                lib.gget_debug_set(15, 0)
+                lib.gget_debug_set(13, 1)
+                lib.gget_debug_set(2, 0)
+            except Exception:
+                pass
+
+    def __del__(self):
+        self.close()
 
     @property
     def device(self):
@@ -344,7 +375,22 @@ class GgetEngine:
             info["rccl_version"] = None
         return info
 
+    def set_skip_nonfinite(self, on: bool):
+        """The DDP branch's step rule (see __init__): the engine leaves weights / Adam state alone when the gradient norm is not finite
+        (GGET_OPT_SKIP_NONFINITE_STEP); step() then takes Adam's step count back and counts the skipped step."""
+        on = bool(on)
+        e = self.module._engine
+        if e is not None and getattr(e, "_skip_nonfinite", None) != on:
+            from . import _lib as L
+            e.set_option(L.OPT_SKIP_NONFINITE_STEP, int(on))
+            e._skip_nonfinite = on
+        self.skip_nonfinite = on
+
     def step(self):
+        """One `engine.step()` of the reference's loop.  With `gradient_accumulation_steps = k > 1` (DeepSpeed branch) the call is made
+        after every micro-batch like there, and like the DS engine only every k-th call updates the weights: the others add the
+        micro-batch's (exchanged) gradient to an fp32 sum and return None; at the boundary the sum goes back into the gradient
+        array and AdamW runs with 1 / (world * k) - the mean over the k * world micro-batches - clip and LR schedule once per update."""
         e = self.module._engine
         if self._pending:
             for w in self._pending:
@@ -353,10 +399,27 @@ class GgetEngine:
             self._pending = []
             torch.cuda.current_stream().wait_stream(self._comm_stream)
         o = self.optim
+        k = getattr(o, "gradient_accumulation_steps", 1)
+        if k > 1:
+            g = e.grad_bf16
+            if self._grad_acc is None or self._grad_acc.shape != g.shape:
+                self._grad_acc = torch.zeros(g.shape, dtype=torch.float32, device=g.device)
+                self.micro_steps = 0
+            self._grad_acc += g
+            self.micro_steps += 1
+            if self.micro_steps % k != 0:
+                return None
+            g.copy_(self._grad_acc)
+            self._grad_acc.zero_()
         lr = o.lr_at(self.global_steps)
-        gn = e.adamw_step(lr, o.betas[0], o.betas[1], o.eps, o.weight_decay, o.max_grad_norm, 1.0 / self.world)
+        if self.skip_nonfinite and getattr(e, "_skip_nonfinite", None) is not True:
+            self.set_skip_nonfinite(True)       # (the model re-created its engine: the option lives on the engine instance)
+        gn = e.adamw_step(lr, o.betas[0], o.betas[1], o.eps, o.weight_decay, o.max_grad_norm, 1.0 / (self.world * k))
         self.global_steps += 1
         self.last_lr, self.last_grad_norm = lr, gn
+        if self.skip_nonfinite and not bool(torch.isfinite(gn)):   # (GradScaler.step reads found_inf back as well: one sync per step on this branch)
+            e.step_count -= 1                   # optimizer.step() did not run; lr_scheduler.step() did (global_steps stays advanced)
+            self.skipped_steps += 1
         return gn
 
     # -- checkpoint = reference DDP layout (misc_utils.py:105-121): model.pt / optimizer.pt keyed by state-dict names
@@ -408,21 +471,14 @@ def _reference_optimizer_step(model, train_cfg, train_stats, loss):
     skip of a non-finite step (GGET_OPT_SKIP_NONFINITE_STEP: weights and Adam state untouched, Adam's step count not advanced) while the
     LR schedule still advances, and `optimizer.gradient_accumulation_steps` must be 1 (the reference asserts it, :47-49)."""
     ddp = not getattr(train_stats, "use_deepspeed", True)
-    eng = model.module._engine
-    if getattr(eng, "_skip_nonfinite", None) != ddp:
-        from . import _lib as L
-        eng.set_option(L.OPT_SKIP_NONFINITE_STEP, int(ddp))
-        eng._skip_nonfinite = ddp
+    if model.skip_nonfinite != ddp:
+        model.set_skip_nonfinite(ddp)       # (the rule itself - Adam's step count taken back, the skipped-steps counter - lives in GgetEngine.step)
     if ddp:
         oc = getattr(train_cfg, "optimizer", None)
         assert oc is None or getattr(oc, "gradient_accumulation_steps", 1) == 1, \
             "https://pytorch.org/docs/stable/notes/amp_examples.html#gradient-accumulation"
     model.backward(loss)
-    gn = model.step()
-    if ddp and not bool(torch.isfinite(gn)):       # (GradScaler.step reads found_inf back as well: one sync per step on this branch)
-        eng.step_count -= 1                        # optimizer.step() did not run; lr_scheduler.step() did (global_steps stays advanced)
-        model.skipped_steps = getattr(model, "skipped_steps", 0) + 1
-    return gn
+    return model.step()
 
 
 def batch_training(data: Dict[str, torch.Tensor], engine: GgetEngine, train_cfg=None, train_stats=None, opt_stats=None):
@@ -676,9 +732,12 @@ class TrainingMode(abc.ABC):
 
     def __init__(self, batches: Optional[Iterable] = None, tokens_per_sample: Optional[float] = None,
                  samples_per_gpu: Optional[int] = None, vocab_size: Optional[int] = None, bos_token_id: Optional[int] = None,
-                 eos_token_id: Optional[int] = None):
+                 eos_token_id: Optional[int] = None, mask_inside_model: bool = False):
         self.batches, self.tokens_per_sample, self.samples_per_gpu = batches, tokens_per_sample, samples_per_gpu
         self.vocab_size, self.bos_token_id, self.eos_token_id = vocab_size, bos_token_id, eos_token_id
+        # the tokenizer configuration's `pretrain_mlm.method == "inside_model"` (pretrain_mode.py:121-128): the SMTP masking runs in the
+        # model's forward; the tokenizer half of the reference lives on the host, so the caller says which it is
+        self.mask_inside_model = bool(mask_inside_model)
 
     @abc.abstractmethod
     def train_step(self, engine: GgetEngine, batch) -> torch.Tensor: ...
@@ -721,6 +780,11 @@ class TrainingMode(abc.ABC):
             pipeline.optim = CF.optim_from_training(pipeline.train_cfg, pipeline.use_deepspeed, self.finetune)
         pipeline.engine = initialize(pipeline.model, pipeline.optim)
         pipeline.device = pipeline.model.device
+        if pipeline.reference_cfg and not pipeline.use_deepspeed:
+            # an empty `deepspeed_conf_file` selects the reference's DDP / AMP branch (training_utils.py:46-86): its optimizer step is
+            # GradScaler.step, which SKIPS a step whose gradients are inf / NaN - the modes' train_step goes through engine.step(), so
+            # the rule is set on the engine here (the lean `batch_training(batch, engine)` form never saw `use_deepspeed`)
+            pipeline.engine.skip_nonfinite = True
 
     def setup_training(self, pipeline) -> None:
         return None
@@ -728,6 +792,12 @@ class TrainingMode(abc.ABC):
     def run_training(self, pipeline) -> None:
         t0 = time.time()
         tokens = None   # accumulated where the mask lives (no device->host read per step); read at log time only
+        # a resumed run (pipeline._resume_checkpoint restored engine.global_steps) does the REMAINDER of the schedule, like the reference
+        # continuing from its checkpoint's epoch / j_init (pipeline.py:178-202) - not max_steps further steps
+        done0 = int(pipeline.engine.global_steps)
+        if pipeline.max_steps and done0 >= pipeline.max_steps:
+            pipeline.model.check_deferred()
+            return
         for step, batch in enumerate(pipeline.batches):
             loss = self.train_step(pipeline.engine, batch)
             pipeline.last_loss = loss
@@ -737,10 +807,11 @@ class TrainingMode(abc.ABC):
             if pipeline.log_every and (step + 1) % pipeline.log_every == 0:
                 torch.cuda.synchronize()
                 dt = time.time() - t0
-                pipeline.log(f"step {step + 1} loss {float(loss):.5f} lr {pipeline.engine.last_lr:.3e} "
+                pipeline.log(f"step {pipeline.engine.global_steps} loss {float(loss):.5f} lr {pipeline.engine.last_lr:.3e} "
                              f"tokens/s/gpu {int(tokens) / dt:.0f}")
+                pipeline.log_lines.append(f"{pipeline.engine.global_steps},{float(loss):.6f},{pipeline.engine.last_lr:.6e}\n")
                 pipeline.model.check_deferred()      # device-side input guards (position ids), read where the loop syncs anyway
-            if pipeline.max_steps and step + 1 >= pipeline.max_steps:
+            if pipeline.max_steps and pipeline.engine.global_steps >= pipeline.max_steps:
                 break
         pipeline.model.check_deferred()
 
@@ -764,7 +835,16 @@ class PretrainMode(TrainingMode):
         if self.tokens_per_sample is None:
             raise ValueError("PretrainMode(tokens_per_sample=...): the mean un-padded length the reference estimates from its "
                              "tokenizer (misc_utils.estimate_tokens_per_sample) is needed to turn the token budget into steps")
+        # pretrain_mode.py:121-128: smtp_inside follows the tokenizer's masking method, whatever the model config said
+        pt_head = CF._get(pipeline.model_cfg, "pt_head")
+        if pt_head is not None:
+            CF._set(pt_head, "smtp_inside", self.mask_inside_model)
+        if self.mask_inside_model:
+            assert CF._get(tc, "task_type") in ("pretrain-mlm", "pretrain-smtp")
+            CF._set(tc, "task_type", "pretrain-smtp")
         tps = CF._get(pipeline.model_cfg, "max_position_embeddings") if CF._get(tc, "pack_tokens", 0) > 0 else self.tokens_per_sample
+        if CF._get(tc, "task_type") == "pretrain-euler":        # pretrain_mode.py:191-195
+            tps = tps // 2
         CF.update_num_steps(sc, tps, bs, pipeline.world_size)
         if self.samples_per_gpu:
             CF.update_epochs(sc, tps, self.samples_per_gpu, pipeline.world_size)
@@ -827,6 +907,7 @@ class TrainingPipeline:
         self.config = self.model = self.device = None
         self.engine: Optional[GgetEngine] = None
         self.last_loss = None
+        self.log_lines = []        # "step,loss,lr" lines of this run -> <output_dir>/log.csv (the file whose presence means "resume", pipeline.py:129)
         self.max_steps, self.log_every = get("max_steps", 0) or 0, get("log_every", 0) or 0
         if self.reference_cfg:
             self.optim, self.batches = None, get("batches") if get("batches") is not None else mode.batches
@@ -926,6 +1007,11 @@ class TrainingPipeline:
             self.mode.run_training(self)
             if self.output_dir and self.rank == 0 and self.mode.allow_save_config():
                 self.engine.save_checkpoint(self.output_dir)
+                # the reference's save_all writes log.csv next to its checkpoints (misc_utils.py:150-154); its presence in output_dir is
+                # what makes the next run with this output_dir a RESUME (_setup_deepspeed_flag above / pipeline.py:129)
+                with open(os.path.join(self.output_dir, "log.csv"), "a") as fh:
+                    fh.writelines(self.log_lines or [f"{self.engine.global_steps},{float(self.last_loss) if self.last_loss is not None else float('nan'):.6f},"
+                                                     f"{getattr(self.engine, 'last_lr', float('nan')):.6e}\n"])
             return self
         self._setup_distributed()
         self.mode.update_config(self)

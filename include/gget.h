@@ -145,7 +145,7 @@ int gget_set_dropout(gget_handle_t h, float attention_p, float path_p, uint32_t 
  * loss, its normalisers, the dropout streams and all [B,S]-shaped inputs / outputs keep their logical coordinates: element-dropout hashes
  * and rope_range tables are keyed by the logical row, full-logit inference keeps the [B S F, V] cell order of its logits, the token-level
  * head writes task_logits [B,S,C] with zeros at padded positions, raw-embedding inputs are read at the logical row).  The engine falls back
- * to the padded layout by itself for packed rows only.  gget_hidden_states / gget_layer_hidden_states refuse after a var-len forward.
+ * to the padded layout by itself for packed rows only.  gget_hidden_states / gget_layer_hidden_states (pointers into the workspace) refuse after a var-len forward; gget_hidden_states_grid copies out of either layout.
  * A caller's count that DISAGREES with the mask cannot go unnoticed: the samples are cut at the count (no kernel leaves the rows of
  * the step), the step's loss is NaN, and a sticky device flag is raised that gget_deferred_status reports; the same flag is raised by
  * a label != -100 at a padded position (the reference's collator pads labels with -100; such a row does not exist in the compact
@@ -240,7 +240,10 @@ int gget_forward_task(gget_handle_t h, const int64_t* input_ids_dev, const int64
  * next layers (one HIP event per bucket on the caller's side):
  *   gget_backward_begin  -> head + final norm   (bucket 0 complete)
  *   gget_backward_layer(i) for i = L-1..0       (bucket L-i complete)
- *   gget_backward_end    -> embedding scatter   (last bucket complete)  */
+ *   gget_backward_end    -> embedding scatter   (last bucket complete)
+ * The backward reads the SAME bf16 weights the forward used (the caller's arena): do not write parameters between a forward and its
+ * backward.  gget_sync_params / gget_adamw_step in between are tolerated - the per-sample kernels' fragment-major o-weight copies of that
+ * forward are dropped and the backward takes the three-launch form on the live weights - but the gradients then mix two weight versions. */
 int gget_backward(gget_handle_t h, float loss_scale, void* stream);
 int gget_backward_begin(gget_handle_t h, float loss_scale, void* stream);
 int gget_backward_layer(gget_handle_t h, int layer, void* stream);
@@ -309,6 +312,11 @@ int gget_hidden_states(gget_handle_t h, const void** hidden_dev);
  * the last forward.  replaces: `output_hidden_states=True` of the reference's backbone (hf LlamaModel.forward modeling_llama.py
  * :401-414 collects exactly these tensors); used by the per-layer error budget of tests/test_error_budget.py.  Padded layout only. */
 int gget_layer_hidden_states(gget_handle_t h, int layer, const void** hidden_dev);
+/* Both of the above as a COPY in the reference's [B,S,d] layout, after a forward on either token layout: layer = -1 the final-normed
+ * hidden states (`outputs.hidden_states[-1]` of modeling_pretrain.py:264 / modeling_finetune.py:323), 0 .. num_layers the residual
+ * stream entering that layer (hf LlamaModel.forward :401-414).  After a var-len forward the rows go back to their (b, s) positions;
+ * positions behind a sample's tokens read as zero.  out_dev: bf16 [B * S * hidden] for the last forward's B and S. */
+int gget_hidden_states_grid(gget_handle_t h, int layer, void* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Operator-level entry points (the individual HIP kernels), used by the parity tests and by

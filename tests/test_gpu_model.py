@@ -122,23 +122,23 @@ def test_backward_matches_oracle(name):
             err = float(np.linalg.norm(got[k] - w)) / (1e-2 * gmax)
         worst.append((err, k))
     worst.sort(reverse=True)
-    # bf16 activations/gradients through L layers: a few 1e-2 relative per tensor
-    record_error(name, "worst_gradient_rel_l2_vs_oracle (" + worst[0][1] + ")", worst[0][0], 6e-2)
-    assert worst[0][0] < 6e-2, f"{name}: worst gradient rel-L2 {worst[:4]}"
+    # bf16 activations/gradients through L layers: a few 1e-2 relative per tensor (measured: <= 2.1e-2 on every fixture, profiles/r06_parity_errors.json; 6e-2 until round 5)
+    record_error(name, "worst_gradient_rel_l2_vs_oracle (" + worst[0][1] + ")", worst[0][0], 3e-2)
+    assert worst[0][0] < 3e-2, f"{name}: worst gradient rel-L2 {worst[:4]}"
     # q / k projections judged on their OWN norm wherever it is not negligible (big-weight cases: attention far from uniform)
     for k in ("model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.k_proj.weight",
               "model.layers.1.self_attn.q_proj.weight", "model.layers.1.self_attn.k_proj.weight"):
         w = grads[k].numpy()
         if np.linalg.norm(w) >= 2e-3 * gmax:
             err = rel_l2(got[k], w)
-            record_error(name, "grad_rel_l2_own_norm " + k, err, 6e-2)
-            assert err < 6e-2, f"{name}: {k} rel-L2 {err} on its own norm ({np.linalg.norm(w) / gmax:.1e} of the largest)"
+            record_error(name, "grad_rel_l2_own_norm " + k, err, 3e-2)
+            assert err < 3e-2, f"{name}: {k} rel-L2 {err} on its own norm ({np.linalg.norm(w) / gmax:.1e} of the largest)"
     # the three tensors the fixtures keep from the REAL reference
     for key, arr in (("model.embed_tokens.weight", "grad_embed"), ("model.layers.0.self_attn.q_proj.weight", "grad_l0_q"),
                      ("model.layers.1.mlp.down_proj.weight", "grad_l1_down")):
         err = rel_l2(got[key], z[arr])
-        record_error(name, "grad_rel_l2_vs_reference " + key, err, 6e-2)
-        assert err < 6e-2, f"{name}: {key} vs reference gradient rel-L2 {err}"
+        record_error(name, "grad_rel_l2_vs_reference " + key, err, 3e-2)
+        assert err < 3e-2, f"{name}: {key} vs reference gradient rel-L2 {err}"
 
 
 @pytest.mark.parametrize("name", ["pt_tiny_f13_a", "pt_tiny_bigw", "pt_tiny_wgt", "ft_tiny_f4", "ft_tiny_mse", "ft_tiny_wce"])
@@ -236,7 +236,7 @@ def test_medium_batch_matches_oracle(kind):
         w = grads[k].numpy()
         gk = got[k].float().cpu().numpy()
         err = float(np.linalg.norm(gk - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
-        assert err < 6e-2, f"{k}: {err}"
+        assert err < 3e-2, f"{k}: {err}"
 
 
 def test_staged_backward_equals_monolithic():
@@ -321,7 +321,7 @@ def test_drop_path_matches_oracle_with_same_mask(layer_scale):
     for k in state:
         w = grads[k].numpy()
         err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
-        assert err < 6e-2, f"{k}: {err}"
+        assert err < 3e-2, f"{k}: {err}"
 
 
 @pytest.mark.gpu
@@ -558,7 +558,7 @@ def test_base_width_two_layers_matches_oracle():
         w = grads[k].numpy()
         gk = got[k].float().cpu().numpy()
         err = float(np.linalg.norm(gk - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
-        assert err < 6e-2, f"{k}: {err}"
+        assert err < 3e-2, f"{k}: {err}"
 
 
 def test_degenerate_batches():
@@ -1181,8 +1181,8 @@ def test_auc_loss_matches_oracle_with_the_same_pairs():
               "model.embed_tokens.weight"):
         w = grads[k].numpy()
         err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
-        record_error("ft_tiny_auc", "grad_rel_l2 " + k, err, 6e-2)
-        assert err < 6e-2, f"{k}: {err}"
+        record_error("ft_tiny_auc", "grad_rel_l2 " + k, err, 3e-2)
+        assert err < 3e-2, f"{k}: {err}"
     # another call draws other pairs (the reference draws a fresh randperm every call)
     out2 = model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], position_ids=b["position_ids"],
                  task_labels=b["task_labels"])
@@ -1238,8 +1238,8 @@ def test_embed_and_mlp_dropouts_exact_mask(gated, layer_scale):
     for k in keys:
         w = grads[k].numpy()
         err = float(np.linalg.norm(got[k].float().cpu().numpy() - w)) / max(float(np.linalg.norm(w)), 1e-2 * gmax)
-        record_error(name, "grad_rel_l2 " + k, err, 6e-2)
-        assert err < 6e-2, f"{k}: {err}"
+        record_error(name, "grad_rel_l2 " + k, err, 3e-2)
+        assert err < 3e-2, f"{k}: {err}"
     # evaluation mode again: same loss as before the training step
     e.set_dropout(0.0, 0.0, 0)
     e.set_dropout_ex(0.0, 0.0)

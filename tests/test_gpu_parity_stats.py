@@ -136,6 +136,58 @@ def test_sign_test_of_finetune_loss_deviation(shape):
     assert np.abs(ds).max() <= 2e-2, rec
 
 
+def test_sign_test_of_s2048_loss_deviation():
+    """`ft_base_s2048` (base model, S = 2048, a TWO-row mean) sits at 95 % of its derived tolerance, and the sign tests
+    above cover the tiny model only.  Here: NSEED = 32 independent (weights, batch) draws of that fixture's shape - base d768 / L12, F = 4,
+    V = 41245, B = 2 full-length rows - forward, HIP loss against the fp32 oracle on the same bf16-rounded weights.  The deviation must
+    carry no sign (|mean d| <= 3 sigma / sqrt(NSEED)), and the fixture's own 1.4e-2 must be an ordinary draw of the measured scatter
+    (<= 3.5 sigma): it is a two-row coin flip, not a bias of the long-sequence kernels.  The per-seed logits are held to the fixtures' bound."""
+    # (the 32-draw pass with both oracle passes takes 12 minutes of host time - 64 fp32 forwards of the base model at S = 2048 - and is on file:
+    #  profiles/r06_parity_stats_sign_test_s2048_n32.json: mean -1.3e-3 +- 1.2e-3 (14 / 32 positive) against bf16-rounded weights, -1.2e-3 +-
+    #  1.4e-3 (15 / 32) against fp32 weights, sigma 6.8e-3 / 7.9e-3, the fixture's 1.4e-2 = 1.8 sigma.  The suite's default is 8 draws, one pass.)
+    NSEED = int(os.environ.get("GGET_S2048_SIGN_TEST_SEEDS", "8"))
+    both = NSEED >= 32
+    B, S, F, V = 2, 2048, 4, 41245
+    spec = spec_mod.spec_from_size("base", kind=spec_mod.KIND_TASK, vocab_size=V, stacked_feat=F, next_n_token=1, num_labels=2, max_position=2048)
+    e = eng_mod.Engine(spec, max_tokens=B * S, max_batch=B)
+    ds, dl, df = [], [], []
+    for i in range(NSEED):
+        state = weights_mod.make_state_dict(spec, seed=3000 + i)
+        batch = synth.make_task_batch(B=B, S=S, F=F, V=V, seed=4000 + i, lengths="full")
+        b = tb(batch)
+        e.load_state_dict(state)
+        loss, logits, _ = e.forward_task(b["input_ids"], b["attention_mask"], b["position_ids"], b["task_labels"], None, L.PROBLEM_SINGLE_LABEL)
+        want_logits = _oracle_task(spec, _bf16_weights(state), b, chunk=1)
+        want = float(Fnn.cross_entropy(want_logits, b["task_labels"]))
+        ds.append((float(loss) - want) / want)
+        dl.append(float((logits.float().cpu() - want_logits).abs().max()))
+        # ... and against fp32 arithmetic on the UN-rounded weights - what the fixture compares with (the reference's fp32 run): the bf16
+        # rounding of the weights is half of the deviation there (DESIGN.md section 2, cast-point model)
+        full = float(Fnn.cross_entropy(_oracle_task(spec, state, b, chunk=1), b["task_labels"])) if both else want
+        df.append((float(loss) - full) / full)
+    ds, df = np.asarray(ds), np.asarray(df)
+    mean, sd = float(ds.mean()), float(ds.std(ddof=1))
+    mean_f, sd_f = float(df.mean()), float(df.std(ddof=1))
+    bound, bound_f = 3 * sd / np.sqrt(NSEED), 3 * sd_f / np.sqrt(NSEED)
+    fixture_dev = 1.404e-2          # ft_base_s2048: |HIP - reference fp32| / reference fp32 (profiles/r05_parity_errors.json)
+    rec = {"shape": "base d768 / L12, S 2048, B 2, F 4, V 41245", "n_seeds": NSEED,
+           "vs_fp32_on_bf16_rounded_weights": {"rel_dev_by_seed": ds.tolist(), "mean": mean, "std": sd, "stderr_of_mean": sd / np.sqrt(NSEED),
+                                               "three_sigma_over_sqrt_n": bound, "max_abs": float(np.abs(ds).max()), "positive": int((ds > 0).sum())},
+           "vs_fp32_on_fp32_weights": {"rel_dev_by_seed": df.tolist(), "mean": mean_f, "std": sd_f, "stderr_of_mean": sd_f / np.sqrt(NSEED),
+                                       "three_sigma_over_sqrt_n": bound_f, "max_abs": float(np.abs(df).max()), "positive": int((df > 0).sum())},
+           "logits_max_abs_dev_max": max(dl), "fixture_ft_base_s2048_dev": fixture_dev, "fixture_dev_in_sigmas": fixture_dev / sd_f}
+    rec["second_oracle_pass_on_fp32_weights"] = both
+    _dump("parity_stats_sign_test_s2048.json" if NSEED == 8 else f"parity_stats_sign_test_s2048_n{NSEED}.json", rec)
+    tag = f"ft_base_s2048_{NSEED}_seed_sign_test"
+    record_error(tag, f"abs_mean_rel_loss_dev vs fp32 on bf16-rounded weights (std {sd:.2e}, +{int((ds > 0).sum())}/{NSEED})", abs(mean), bound)
+    record_error(tag, f"abs_mean_rel_loss_dev vs fp32 on fp32 weights (std {sd_f:.2e}, +{int((df > 0).sum())}/{NSEED})", abs(mean_f), bound_f)
+    record_error(tag, "fixture_dev_in_sigmas_of_the_two_row_scatter", fixture_dev / sd_f, 3.5)
+    record_error(tag, "task_logits_max_abs_vs_oracle (max over seeds)", max(dl), 5e-2)
+    assert abs(mean) <= bound and abs(mean_f) <= bound_f, rec
+    assert fixture_dev <= (3.5 if both else 5.0) * sd_f, rec      # (8 draws estimate sigma to +-25 %)
+    assert max(dl) <= 5e-2, rec
+
+
 def test_c3_training_mode_dropouts_large_batch_and_eval_twin():
     """The B = 4 check of test_gpu_model.py::test_c3_training_mode_dropouts_exact_mask measures 2.3e-2 with identical masks.  Same weights
     (std 0.04, head 0.1: twice the standard init, logits of +-3), B = 32: (a) eval mode, (b) training mode with both masks handed to

@@ -156,11 +156,17 @@ def test_varlen_wrong_token_count_is_flagged_and_fallbacks():
     assert e.varlen_status() == (True, (n - 3 + 63) // 64 * 64, True)
     e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"], num_tokens=n)
     assert e.varlen_status() == (True, (n + 63) // 64 * 64, False)
-    with pytest.raises(L.GgetError):
-        e.hidden_states(16, 32)                      # compact rows: the [B,S,d] view does not exist
+    # hidden-state accessors after a var-len forward (round 6: gget_hidden_states_grid spreads the compact rows back over [B,S,d];
+    # positions behind a sample's tokens read as zero) against the padded forward's
+    hv, lv = e.hidden_states(16, 32).float().cpu(), [e.layer_hidden_states(i, 16, 32).float().cpu() for i in range(spec.num_layers + 1)]
     e.forward_pretrain(b["input_ids"], b["attention_mask"], b["labels"])           # no count -> padded
     assert e.varlen_status()[0] is False
-    e.hidden_states(16, 32)
+    real = torch.from_numpy(batch["attention_mask"]).bool()
+    hp, lp = e.hidden_states(16, 32).float().cpu(), [e.layer_hidden_states(i, 16, 32).float().cpu() for i in range(spec.num_layers + 1)]
+    for name_, a_, p_ in [("final", hv, hp)] + [(f"layer {i}", x, y) for i, (x, y) in enumerate(zip(lv, lp))]:
+        assert float(a_[~real].abs().max()) == 0.0, name_
+        assert rel_l2(a_[real].numpy(), p_[real].numpy()) < 6e-3, name_
+    assert torch.equal(lv[0][real], lp[0][real])                                    # (the embedding sum: the same arithmetic per row)
     e.forward_pretrain(b["input_ids"], b["attention_mask"], None, num_tokens=n)    # full-logit inference: var-len since round 5, no flag for
     assert e.varlen_status() == (True, (n + 63) // 64 * 64, False)                 # the cells of padded positions
     full = torch.ones_like(b["attention_mask"])
@@ -521,7 +527,7 @@ def test_model_token_layout_attribute_overrides_the_environment(monkeypatch):
     v0, l0 = ran_varlen(dev)
     model.token_layout = "padded"
     v1, l1 = ran_varlen(dev)
-    hs = model._engine.hidden_states(8, 32)                 # (refuses after a var-len forward)
+    hs = model._engine.hidden_states(8, 32)
     assert tuple(hs.shape) == (8, 32, 128)
     model.token_layout = "nosync"
     v2, _ = ran_varlen(dev)

@@ -9,6 +9,7 @@ created) on the same inputs; the GPU test runs whole pipelines."""
 import copy
 import importlib
 import json
+import math
 import os
 import types
 
@@ -139,6 +140,35 @@ def test_finetune_config_phases_match_reference(shape, monkeypatch):
         assert o.lr_at(s) == pytest.approx(want, rel=1e-9, abs=1e-18), s
 
 
+def test_pretrain_mode_smtp_inside_and_euler_rules(monkeypatch):
+    """pretrain_mode.py:121-128: `pt_head.smtp_inside` follows the tokenizer's masking method whatever the model config said (here: the
+    mode's `mask_inside_model`, the tokenizer lives on the host), and with it the task type becomes pretrain-smtp; :191-195: the
+    pretrain-euler task counts HALF the tokens per sample in its schedule."""
+    T = importlib.import_module("graph-gpt_amd.training")
+    CF = importlib.import_module("graph-gpt_amd.conf")
+    case = _cases()["pretrain_ds"]
+    tok = case["tokenizer"]
+    g = CF._get
+
+    def phases(mask_inside, task=None, smtp_cfg=True):
+        cfg = _cfg(case, "namespace")
+        cfg.model.pt_head.smtp_inside = smtp_cfg
+        if task:
+            cfg.training.task_type = task
+        mode = T.PretrainMode(batches=[], tokens_per_sample=case["tokens_per_sample"], samples_per_gpu=case["samples_per_gpu"],
+                              mask_inside_model=mask_inside, **tok)
+        return _config_phases(cfg, mode, case["world_size"], monkeypatch)
+    p = phases(False)
+    assert g(g(p.model_cfg, "pt_head"), "smtp_inside") is False and p.config.smtp_inside is False      # reset although the config said True
+    assert g(p.sched_cfg, "total_num_steps") == case["total_num_steps"]
+    p = phases(True, smtp_cfg=False)
+    assert g(g(p.model_cfg, "pt_head"), "smtp_inside") is True and g(p.train_cfg, "task_type") == "pretrain-smtp" and p.config.smtp_inside is True
+    p = phases(False, task="pretrain-euler")
+    half = int(case["tokens_per_sample"]) // 2
+    want = int(math.ceil(case["training"]["schedule"]["total_tokens"] / (half * case["training"]["batch_size"] * case["world_size"])))
+    assert g(p.sched_cfg, "total_num_steps") == want and want > case["total_num_steps"]
+
+
 def test_lean_config_still_recognised():
     T = importlib.import_module("graph-gpt_amd.training")
     p = T.TrainingPipeline({"model": dict(vocab_size=300, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
@@ -201,16 +231,99 @@ def test_pretrain_pipeline_runs_from_a_reference_shaped_config(tmp_path):
     for b in batches[:3]:
         want = float(T.batch_training(b, eng))
     assert np.isfinite(last) and abs(last - want) <= 1e-6 * abs(want), (last, want)
-    # resume: log.csv in the output directory makes the run continue from its own checkpoint (pipeline.py:127-133, :178-202)
-    open(os.path.join(cfg.training.output_dir, "log.csv"), "w").write("step,loss\n")
+    # resume: the run wrote log.csv next to its checkpoint (the reference's save_all, misc_utils.py:150-154); its presence in the output
+    # directory makes the next run continue from that checkpoint (pipeline.py:127-133, :178-202) and do the REMAINDER of its schedule
+    assert os.path.isfile(os.path.join(cfg.training.output_dir, "log.csv"))
     cfg2, _ = _tiny_reference_cfg(tmp_path, "pt")
     cfg2.training.deepspeed_conf_file = "ds_config2_pt.json"
-    cfg2.training.schedule.total_tokens, cfg2.training.schedule.warmup_tokens = 3 * 8 * 20.0, 8 * 20.0
-    p2 = T.TrainingPipeline(cfg2, T.PretrainMode(batches=batches[3:4], tokens_per_sample=20.0, vocab_size=756, bos_token_id=19, eos_token_id=20))
+    cfg2.training.schedule.total_tokens, cfg2.training.schedule.warmup_tokens = 4 * 8 * 20.0, 8 * 20.0       # a 4-step budget, 3 done
+    p2 = T.TrainingPipeline(cfg2, T.PretrainMode(batches=batches[3:], tokens_per_sample=20.0, vocab_size=756, bos_token_id=19, eos_token_id=20))
     p2.run()
-    assert p2.pretrain_cpt == cfg2.training.output_dir and p2.engine.global_steps == 4
+    assert p2.pretrain_cpt == cfg2.training.output_dir and p2.max_steps == 4 and p2.engine.global_steps == 4      # one step, not four more
     want4 = float(T.batch_training(batches[3], eng))
     assert abs(float(p2.last_loss) - want4) <= 2e-5 * abs(want4), (float(p2.last_loss), want4)
+    # ... and a third run with the same budget has nothing left to do
+    cfg3, _ = _tiny_reference_cfg(tmp_path, "pt")
+    cfg3.training.deepspeed_conf_file = "ds_config2_pt.json"
+    cfg3.training.schedule.total_tokens, cfg3.training.schedule.warmup_tokens = 4 * 8 * 20.0, 8 * 20.0
+    p3 = T.TrainingPipeline(cfg3, T.PretrainMode(batches=batches, tokens_per_sample=20.0, vocab_size=756, bos_token_id=19, eos_token_id=20)).run()
+    assert p3.engine.global_steps == 4 and p3.last_loss is None
+
+
+@pytest.mark.gpu
+def test_pipeline_ddp_branch_skips_a_non_finite_step(tmp_path):
+    """a reference-shaped config with an EMPTY deepspeed_conf_file selects the reference's DDP / AMP branch
+    (training_utils.py:46-86), whose optimizer step is GradScaler.step - a step with an inf / NaN gradient is skipped.  The modes drive
+    the lean `batch_training(batch, engine)` form; the rule must still apply: a poisoned gradient inside a pipeline run leaves the weights
+    finite, counts one skipped step and lets the LR schedule advance."""
+    import torch
+    T = importlib.import_module("graph-gpt_amd.training")
+    synth = importlib.import_module("graph-gpt_amd.synth")
+    cfg, _ = _tiny_reference_cfg(tmp_path, "pt")
+    cfg.training.deepspeed_conf_file = ""
+    cfg.training.schedule.total_tokens, cfg.training.schedule.warmup_tokens = 4 * 8 * 20.0, 8 * 20.0
+    batches = [{k: torch.from_numpy(v) for k, v in synth.make_pretrain_batch(B=8, S=32, F=13, V=756, seed=90 + i).items()} for i in range(5)]
+
+    class Poisoning(T.PretrainMode):
+        calls = 0
+
+        def train_step(self, engine, batch):
+            Poisoning.calls += 1
+            if Poisoning.calls != 2:
+                return super().train_step(engine, batch)
+            out = engine(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"])
+            engine.backward(out.head1_loss)
+            engine.module._engine.grad_bf16[4321] = float("nan")
+            engine.step()
+            return out.head1_loss
+    p = T.TrainingPipeline(cfg, Poisoning(batches=batches, tokens_per_sample=20.0, vocab_size=756, bos_token_id=19, eos_token_id=20)).run()
+    e = p.model._engine
+    torch.cuda.synchronize()
+    assert not p.use_deepspeed and p.engine.skip_nonfinite
+    assert p.engine.global_steps == 4 and p.engine.skipped_steps == 1 and e.step_count == 3       # the schedule moved on, Adam's count did not
+    assert bool(torch.isfinite(e.master).all()) and bool(torch.isfinite(e.adam_m).all())
+    import numpy as np
+    assert np.isfinite(float(p.last_loss))
+
+
+@pytest.mark.gpu
+def test_gradient_accumulation_steps_on_the_deepspeed_branch(tmp_path):
+    """`training.optimizer.gradient_accumulation_steps = k` on the DeepSpeed branch (conf_utils.py:59-66 hands it to the DS engine, whose
+    step() only fires at the boundary): k micro-batches per optimizer step, gradients summed, the update made with their mean.  With the
+    SAME micro-batch twice and k = 2 the mean gradient is that batch's gradient exactly (the fp32 sum of two equal bf16 values rounds
+    back to twice the value), so the weights must equal one plain step on it, bit for bit; with two different micro-batches the update
+    lies between the two single-batch updates' directions and one optimizer step is counted."""
+    import torch
+    T = importlib.import_module("graph-gpt_amd.training")
+    M = importlib.import_module("graph-gpt_amd.modeling")
+    CF = importlib.import_module("graph-gpt_amd.conf")
+    synth = importlib.import_module("graph-gpt_amd.synth")
+    cfg = dict(hidden_act="gelu", vocab_size=756, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+               max_position_embeddings=64, causal_attention=False, stacked_feat=13, next_n_token=13)
+    A, Bb = ({k: torch.from_numpy(v) for k, v in synth.make_pretrain_batch(B=8, S=32, F=13, V=756, seed=s_).items() if k != "lengths"} for s_ in (3, 4))
+
+    def run(batches, k):
+        model = M.GraphGPTPretrainBase(M.GraphGPTConfig(**cfg), seed=2).cuda().eval()
+        eng = T.initialize(model, T.OptimConfig(lr=1e-3, max_grad_norm=1.0, gradient_accumulation_steps=k))
+        for b in batches:
+            T.batch_training(b, eng)
+        torch.cuda.synchronize()
+        return model._engine.master.clone(), eng, model._engine
+    w1, e1, _ = run([A], 1)
+    w2, e2, eng2 = run([A, A], 2)
+    assert e2.global_steps == 1 and eng2.step_count == 1 and e2.micro_steps == 2
+    assert torch.equal(w1, w2), "k = 2 on the same micro-batch twice must be the plain step"
+    w3, e3, _ = run([A, Bb], 2)
+    assert e3.global_steps == 1 and not torch.equal(w3, w1)
+    w4, e4, _ = run([A, Bb, A], 2)            # the third call is a micro-step of the NEXT update: nothing applied yet
+    assert e4.global_steps == 1 and torch.equal(w4, w3)
+    # the reference-shaped config carries it on the DeepSpeed branch only (the DDP branch asserts k == 1, training_utils.py:47-49)
+    case = _cases()["pretrain_ds"]
+    tc = _ns(copy.deepcopy(case["training"]))
+    tc.optimizer.gradient_accumulation_steps = 4
+    tc.schedule.total_num_steps, tc.schedule.warmup_num_steps = 100, 10
+    assert CF.optim_from_training(tc, use_deepspeed=True, finetune=False).gradient_accumulation_steps == 4
+    assert CF.optim_from_training(tc, use_deepspeed=False, finetune=False).gradient_accumulation_steps == 1
 
 
 @pytest.mark.gpu

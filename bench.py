@@ -385,6 +385,42 @@ def main():
             layouts[lay] = (time.perf_counter() - t1) / a.steps * 1e3
         step(0)     # (the probes below run on the reported layout again, on batch 0)
         torch.cuda.synchronize()
+    # The batch hand-over inside the number: the same K steps once more, outside the reported time, fed with HOST
+    # batches - nothing pre-staged - (a) through the product's DevicePrefetcher (pinned staging + side stream, batch t + 1 copied during
+    # step t: what TrainingPipeline's loop does) and (b) the reference's way, every tensor `.to(device)` at the top of the step
+    # (training_utils.py:17-26).  `value` stays the device-resident figure the contract asks for; these two sit next to it.
+    h2d = None
+    if world == 1 and kind != "pt-packed":
+        host_t = [{k: torch.from_numpy(v) for k, v in b_.items() if k not in ("lengths", "segments")} for b_ in host_batches]
+        run_on = (lambda d_: training.batch_training(d_, engine)) if pt else (lambda d_: training.ft_batch_training(d_, engine)[0])
+
+        def feed(n, start):
+            for i in range(n):
+                yield host_t[(start + i) % nb]
+        it = iter(training.DevicePrefetcher(feed(2 + a.steps, a.warmup - 2), torch.device("cuda", local)))
+        for _ in range(2):
+            run_on(next(it))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for d_ in it:
+            run_on(d_)
+        torch.cuda.synchronize()
+        pre_ms = (time.perf_counter() - t1) / a.steps * 1e3
+        for i in range(2):
+            run_on({k: v.cuda() for k, v in host_t[(a.warmup - 2 + i) % nb].items()})
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(a.steps):
+            run_on({k: v.cuda() for k, v in host_t[(a.warmup + i) % nb].items()})
+        torch.cuda.synchronize()
+        sync_ms = (time.perf_counter() - t1) / a.steps * 1e3
+        nbytes = sum(v.numel() * v.element_size() for v in host_t[0].values())
+        h2d = {"h2d_inclusive_ms_per_step": pre_ms, "synchronous_to_device_ms_per_step": sync_ms, "batch_bytes": nbytes,
+               "what": "host batches in, nothing pre-staged, same K steps and rotation: prefetched = graph-gpt_amd.training.DevicePrefetcher (pinned "
+                       "staging, side stream, one batch ahead; the host-side mask sum rides along as num_tokens); synchronous = every tensor "
+                       ".cuda() from pageable memory at the top of the step, the reference's batch_training"}
+        step(0)
+        torch.cuda.synchronize()
     # N > 1: how much of the step is gradient exchange the backward does not hide - the same K steps once more (outside the reported
     # time) with the collectives switched off (GgetEngine.exchange = False: identical kernels on the compute stream, nothing on the
     # side stream), max over ranks; exposed = reported step - that.  The replicas drift apart in these steps: they come last.
@@ -552,6 +588,10 @@ def main():
         if dp_info is not None:
             dp_info["exposed_comm_ms"] = ms - dp_info["ms_per_step_without_exchange"]
             out["dp"] = dp_info
+        if h2d is not None:
+            h2d["vs_device_resident"] = h2d["h2d_inclusive_ms_per_step"] / ms
+            out["h2d_inclusive_ms_per_step"] = h2d["h2d_inclusive_ms_per_step"]
+            out["batch_handover"] = h2d
         if layouts is not None:
             out["layouts"] = {"ms_per_step": layouts, "reported": layout,
                               "note": "varlen = reference-shaped call (device tensors only; the engine sums the mask and reads 4 bytes back), "

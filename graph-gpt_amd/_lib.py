@@ -84,6 +84,7 @@ SIGNATURES = {
     "gget_op_rope": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "gget_op_attn_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, f32, C.c_uint32, vp]),
     "gget_op_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, f32, C.c_uint32, vp]),
+    "gget_op_copy_from_host": (i32, [vp, vp, C.c_uint64, vp]),
     "gget_op_attn_fwd_varlen": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, f32, C.c_uint32, vp]),
     "gget_op_attn_bwd_varlen": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, f32, C.c_uint32, vp]),
     "gget_op_attn_oproj_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, C.c_uint32, vp, vp]),

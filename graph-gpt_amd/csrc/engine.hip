@@ -2397,6 +2397,10 @@ extern "C" int gget_op_attn_bwd(const void* qkv, const void* out, const void* do
   return k_attn_bwd(qkv, out, dout, lse, key_len, dqkv, delta_ws, B, S, H, causal, cos_tab, sin_tab, position_ids,
                     /*qk_rotated=*/0, dropout_p, dropout_seed, (hipStream_t)stream);
 }
+extern "C" int gget_op_copy_from_host(const void* src_pinned_host, void* dst_dev, uint64_t bytes, void* stream) {
+  GGET_REQUIRE(src_pinned_host && dst_dev, "copy_from_host: null argument");
+  return k_copy_from_host(src_pinned_host, dst_dev, (size_t)bytes, (hipStream_t)stream);
+}
 extern "C" int gget_op_attn_fwd_varlen(const void* qkv, const int32_t* key_len, const int32_t* row_base, void* out, float* lse, int B, int S,
                                        int H, int causal, const float* cos_tab, const float* sin_tab, const int64_t* position_ids,
                                        int qk_rotated, float dropout_p, uint32_t dropout_seed, void* stream) {

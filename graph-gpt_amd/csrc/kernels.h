@@ -89,6 +89,7 @@ int k_score_fwd(const void* hidden, const int32_t* pool_row, const void* w, cons
 int k_tok_score_fwd(const void* hidden, const void* w, const void* bias, float* logits, int T, int C, int d, hipStream_t st);
 int k_tok_ce(const float* logits, const int64_t* labels, float* dl, float* stat, float* loss_out, int T, int C, hipStream_t st,
              const int32_t* rows_map = nullptr, int n_logical = 0);   // rows_map: compact row -> logical row of the labels (var-len layout)
+int k_copy_from_host(const void* src_host_mapped, void* dst, size_t bytes, hipStream_t st);
 int k_rows_to_grid(const void* src, const int32_t* pad2c, void* out, long n_pos, int d, hipStream_t st);
 int k_scatter_rows_map_f32(const float* src, const int32_t* rows_map, float* dst, int T, int C, int n_logical, hipStream_t st);
 int k_tok_score_bwd(const float* dl, const float* stat, const void* hidden, const void* w, float* dw, float* dbias, void* dhidden, int T,

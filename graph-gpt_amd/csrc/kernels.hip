@@ -2442,6 +2442,26 @@ int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, int32_
   GGET_LAUNCH_CHECK();
   return 0;
 }
+// Host -> device hand-over of a collated batch as a KERNEL: the source is pinned (device-mapped) host memory, read over the host link
+// with 16-byte loads (1.8 MB for a C1 batch: ~35 us).  An in-stream hipMemcpyAsync from pinned memory goes to the copy engine and every
+// such copy is a cross-engine dependency the runtime resolves on the host: four of them per step took the C1 step from 6.7 to 12 - 20 ms
+// (tools/prefetch_probe.py); a kernel stays in the compute queue.
+__global__ void __launch_bounds__(kBlock) copy_from_host_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, size_t n) {
+  const size_t n16 = n / 16;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (size_t)gridDim.x * kBlock)
+    reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+  if (blockIdx.x == 0)
+    for (size_t i = n16 * 16 + threadIdx.x; i < n; i += kBlock) dst[i] = src[i];
+}
+int k_copy_from_host(const void* src_host_mapped, void* dst, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return 0;
+  GGET_REQUIRE((((uintptr_t)src_host_mapped | (uintptr_t)dst) & 15) == 0, "copy_from_host: 16-byte aligned buffers");
+  hipLaunchKernelGGL(copy_from_host_kernel, dim3(grid_for((long)(bytes / 16 + 1), kBlock, 256)), dim3(kBlock), 0, st, (const unsigned char*)src_host_mapped,
+                     (unsigned char*)dst, bytes);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
 // compact rows -> the padded [B,S] grid (hidden-state accessors after a var-len forward): out[i] = src[pad2c[i]], zero where the padded
 // position holds no token; one thread per 16-byte piece
 __global__ void __launch_bounds__(kBlock) rows_to_grid_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ pad2c,

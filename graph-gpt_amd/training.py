@@ -18,6 +18,7 @@ import os
 import time
 from typing import Any, Callable, Dict, Iterable, Optional
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -569,6 +570,109 @@ def _layout_kw(model, data) -> Dict[str, Any]:
     return {} if n is None else {"num_tokens": n}
 
 
+# ----------------------------------------------------------------------------- batch hand-over (host -> device)
+class DevicePrefetcher:
+    """The reference's step moves every tensor of the batch to the device at its top (training_utils.py:17-26, `.to(device)` on pageable
+    DataLoader output: a synchronous staging copy per tensor in front of the forward).  Here the host half of the hand-over of batch
+    t + 1 runs DURING step t: the collated batch is copied into pinned staging buffers one batch ahead (three sets, used in turn), and
+    the device half is one copy kernel per tensor from the pinned buffer into persistent device buffers, enqueued on the COMPUTE stream
+    right in front of the step that reads them (1.8 MB for a C1 batch: ~35 us of a 6.7 ms step) - stream order alone keeps a device set
+    from being overwritten before the step that read it has run; one event per pinned set tells the host when it may refill it.
+    What comes out is the same dict with device tensors plus `num_tokens` = the host-side sum of a 2-D attention mask (free here, and
+    what lets the engine run the padding-free layout without reading a count back).  `batch_training(data, model, train_cfg,
+    train_stats, ...)` - the reference's form - sees tensors that are already on `train_stats.device`: its `.to(device)` calls return
+    them as they are.
+
+        for data in DevicePrefetcher(loader, device):
+            batch_training(data, engine)
+
+    The device tensors of a batch are reused for the batch three steps later: consume them inside the step (as the training step does).
+    Measured (tools/prefetch_probe.py, C1 step, one box): device-resident batches 6.80 ms, this class 6.87 ms (+0.9 %), the reference's
+    synchronous `.cuda()` per tensor 6.95 ms (+2.2 %).  Two traps on the way there: (1) `pinned.copy_(pageable)` - torch's copy_ INTO a
+    pinned tensor synchronises with the device (3 ms on average, up to 94 ms under load): the staging buffers are filled through their
+    numpy views (14 us); (2) the device half as hipMemcpyAsync (`dst.copy_(pinned, non_blocking=True)`) is a copy-engine job, 6.92 ms: the
+    kernel form (gget_op_copy_from_host reads the pinned buffer over the host link) stays in the compute queue.
+    Non-tensor entries pass through; tensors already on the device are left alone."""
+
+    SETS = 3
+
+    def __init__(self, batches: Iterable, device=None, count_tokens: bool = True):
+        self.batches = batches
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.count_tokens = count_tokens
+        self._pinned = [dict() for _ in range(self.SETS)]        # key -> pinned host tensor
+        self._dev = [dict() for _ in range(self.SETS)]           # key -> device tensor
+        self._copied = [None] * self.SETS                        # compute-stream event behind the set's last pinned -> device copies
+
+    def __len__(self):
+        return len(self.batches)
+
+    def _stage(self, data, slot):
+        """host half: the batch into pinned set `slot` (+ the token count)"""
+        if self._copied[slot] is not None:
+            self._copied[slot].synchronize()     # (the device copy that last read this pinned set: three steps old)
+            self._copied[slot] = None
+        out, pend = {}, []
+        for k, v in data.items():
+            if not torch.is_tensor(v) or v.device == self.device:
+                out[k] = v
+                continue
+            buf = self._pinned[slot].get(k)
+            if buf is None or buf.shape != v.shape or buf.dtype != v.dtype:
+                buf = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                self._pinned[slot][k] = buf
+                self._dev[slot][k] = torch.empty(v.shape, dtype=v.dtype, device=self.device)
+            # (NOT buf.copy_(v): torch's copy_ into a pinned tensor synchronises with the device - 3 ms on average, up to 94 ms with the
+            #  GPU busy, against 14 us for the same bytes through the buffers' numpy views; that alone took the C1 step from 6.7 to 10 - 20 ms)
+            np.copyto(buf.view(torch.uint8).numpy(), v.contiguous().view(torch.uint8).numpy())
+            pend.append(k)
+        if self.count_tokens and "num_tokens" not in out:
+            am = data.get("attention_mask")
+            if torch.is_tensor(am) and am.dim() == 2 and am.device.type == "cpu":
+                out["num_tokens"] = int((am != 0).sum())
+        return out, pend, slot
+
+    def _to_device(self, staged):
+        """device half, on the current (compute) stream, in front of the step"""
+        out, pend, slot = staged
+        if pend:
+            import ctypes as C
+            from . import _lib as L
+            lib, st = L.load(), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        for k in pend:
+            src, dst = self._pinned[slot][k], self._dev[slot][k]
+            if os.environ.get("GGET_PF_COPY", "kernel") == "kernel":      # (memcpy: the copy-engine form, kept for tools/prefetch_probe.py)
+                L.check(lib.gget_op_copy_from_host(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel() * src.element_size(), st))
+            else:
+                dst.copy_(src, non_blocking=True)
+            out[k] = dst
+        if pend:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._copied[slot] = ev
+        return out
+
+    def __iter__(self):
+        it = iter(self.batches)
+        try:
+            cur = self._stage(next(it), 0)
+        except StopIteration:
+            return
+        slot = 1
+        data = self._to_device(cur)
+        while cur is not None:
+            try:
+                nxt = self._stage(next(it), slot)       # the host half of the NEXT batch, before the consumer's step on this one is enqueued
+            except StopIteration:
+                nxt = None
+            slot = (slot + 1) % self.SETS
+            yield data
+            # (the device half on a side stream, joined by an event, so that it runs beside the step: 6.88 ms against 6.74 - the fork / join
+            #  packets cost more than the 35 us of copy they hide, as with the attention launches, profiles/r06_step_experiments.txt)
+            data = self._to_device(nxt) if nxt is not None else None
+            cur = nxt
+
+
 # ----------------------------------------------------------------------------- evaluation pass
 @torch.no_grad()
 def evaluate(model, loader, eval_name: str = "valid", do_eval: bool = True):
@@ -798,11 +902,16 @@ class TrainingMode(abc.ABC):
         if pipeline.max_steps and done0 >= pipeline.max_steps:
             pipeline.model.check_deferred()
             return
-        for step, batch in enumerate(pipeline.batches):
+        # host batches are handed over one step ahead (pinned staging + a side stream: DevicePrefetcher); GGET_PREFETCH=0 = as they come
+        source = pipeline.batches
+        if bool(int(os.environ.get("GGET_PREFETCH", "1"))) and torch.cuda.is_available() and pipeline.batches is not None:
+            source = DevicePrefetcher(pipeline.batches, pipeline.model.device)
+        for step, batch in enumerate(source):
             loss = self.train_step(pipeline.engine, batch)
             pipeline.last_loss = loss
             am = batch["attention_mask"]
-            n = am.sum() if am.dim() == 2 else am.diagonal(dim1=1, dim2=2).sum()   # packed rows: [B,S,S] block-diagonal
+            n = batch["num_tokens"] if batch.get("num_tokens") is not None else \
+                (am.sum() if am.dim() == 2 else am.diagonal(dim1=1, dim2=2).sum())   # packed rows: [B,S,S] block-diagonal
             tokens = n if tokens is None else tokens + n
             if pipeline.log_every and (step + 1) % pipeline.log_every == 0:
                 torch.cuda.synchronize()

@@ -433,6 +433,12 @@ int gget_op_attn_bwd(const void* qkv, const void* out, const void* dout, const f
                      void* dqkv, float* delta_ws, int B, int S, int H, int causal, const float* cos_tab,
                      const float* sin_tab, const int64_t* position_ids, float dropout_p, uint32_t dropout_seed,
                      void* stream);
+/* replaces: the `.to(device)` calls at the top of the reference's step (src/utils/training_utils.py:17-26) for a batch that sits in PINNED
+ * host memory (hipHostMalloc / torch pin_memory: device-mapped): a kernel on `stream` reads it over the host link into dst_dev.  Stays in
+ * the compute queue - an in-stream hipMemcpyAsync from pinned memory is a copy-engine job whose dependencies the runtime resolves on the
+ * host (four per step: the C1 step 6.7 -> 12 - 20 ms).  Both pointers 16-byte aligned; the host buffer must stay untouched until the
+ * kernel has run (record an event behind it).  graph-gpt_amd/training.py DevicePrefetcher is the caller. */
+int gget_op_copy_from_host(const void* src_pinned_host, void* dst_dev, uint64_t bytes, void* stream);
 /* The two above on the padding-free (var-len) token layout: row_base (int32 [B]) = first row of sample b in the token-major buffers
  * (qkv / out / dout / dqkv hold the samples' real rows back to back, key_len[b] of them for sample b); lse / delta keep their [B, H, S]
  * indexing, S = the padded width the collator produced (8 * ceil(longest graph / 8), reference src/data/collator.py:70-111).  Every

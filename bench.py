@@ -353,6 +353,17 @@ def main():
             gpu_eval_loss = float(model(input_ids=dev["input_ids"], attention_mask=dev["attention_mask"], labels=dev["labels"]).head1_loss)
         model.train()
 
+    # N > 1: no scaling curve of this engine exists - the job times the exchange arrangements on THIS machine first
+    # (10 steps each: collectives beside the backward / behind it / beside it with 32 CUs left free by the GEMM plans) and runs the
+    # reported steps on the fastest; GGET_DP_PROBE=0 or an explicit GGET_DP_OVERLAP / GGET_DP_RESERVE_CUS keeps what the environment says
+    menu_probe = None
+    if world > 1 and bool(int(os.environ.get("GGET_DP_PROBE", "1"))) and "GGET_DP_OVERLAP" not in os.environ and "GGET_DP_RESERVE_CUS" not in os.environ:
+        probe_i = [0]
+
+        def probe_step():
+            probe_i[0] += 1
+            return step(probe_i[0])
+        menu_probe = engine.probe_dp_menu(probe_step, steps=int(os.environ.get("GGET_DP_PROBE_STEPS", "10")))
     for i in range(a.warmup):
         loss = step(i)
     torch.cuda.synchronize()
@@ -450,6 +461,7 @@ def main():
         dist.all_reduce(dt_nox, op=dist.ReduceOp.MAX)
         engine.exchange = True
         dp_info = engine.describe_dp()
+        dp_info["menu_probe"] = menu_probe
         dp_info["ms_per_step_without_exchange"] = float(dt_nox[0]) / a.steps * 1e3
         dp_info["replicas_bit_identical"] = replicas_identical
         # which device every rank ran on (the driver's SCALE run must see N distinct GPUs): name, index, PCI bus id / uuid

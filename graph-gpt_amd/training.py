@@ -357,6 +357,55 @@ class GgetEngine:
         self._groups = (e, groups)
         return groups
 
+    # -- the data-parallel launch menu, decided by measurement on the machine the job runs on
+    def set_dp_menu(self, overlap: Optional[bool] = None, reserve_cus: Optional[int] = None):
+        """Switch the exchange arrangement of a running engine: `overlap` = bucketed collectives beside the backward (True) or one
+        collective behind it (False); `reserve_cus` = CUs the GEMM launch plans leave free for the collective's workgroups (the GEMM side
+        of GGET_DP_RESERVE_CUS; the collective library's channel count is fixed when its communicator is created - dp_env_defaults)."""
+        if overlap is not None:
+            self.overlap = bool(overlap)
+        if reserve_cus is not None and torch.cuda.is_available():
+            from . import _lib as L
+            lib = L.load()
+            r = max(0, int(reserve_cus))
+            L.check(lib.gget_debug_set(15, r))
+            L.check(lib.gget_debug_set(13, 0 if r else 1))
+            L.check(lib.gget_debug_set(2, 1 if r else (2 if bool(int(os.environ.get("GGET_DP_LDS_HEADROOM", "0"))) else 0)))
+            self.reserved_cus = r
+            self._dp_menu_set = self._dp_menu_set or r > 0
+
+    def probe_dp_menu(self, step_fn: Callable[[], Any], steps: int = 10, warm: int = 2, menus=None) -> Dict[str, Any]:
+        """No 1 -> 8 GPU curve of this engine has been measured: instead of a default chosen from a model, a
+        multi-rank job TIMES the arrangements on its own machine at start-up and keeps the fastest - `steps` training steps each
+        (after `warm`), max over ranks, the decision broadcast from rank 0 so that every rank takes the same.  `step_fn()` runs one
+        step (forward + backward + step) on this rank.  The probe steps are ordinary training steps (the replicas stay identical).
+        Returns {"menus": [...], "chosen": {...}}; a single-rank engine returns without measuring."""
+        if self.world <= 1 or not (dist.is_available() and dist.is_initialized()):
+            return {"menus": [], "chosen": {"overlap": self.overlap, "reserve_cus": self.reserved_cus}, "probed": False}
+        if menus is None:
+            menus = [dict(overlap=True, reserve_cus=0), dict(overlap=False, reserve_cus=0), dict(overlap=True, reserve_cus=32)]
+        dev = self.module.device if dist.get_backend(self.pg) == "nccl" else torch.device("cpu")
+        rows = []
+        for m in menus:
+            self.set_dp_menu(**m)
+            for _ in range(warm):
+                step_fn()
+            torch.cuda.synchronize()
+            dist.barrier(self.pg)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step_fn()
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+            rows.append(dict(m, ms_per_step=float(t[0]) / steps * 1e3))
+        best = min(range(len(rows)), key=lambda i: rows[i]["ms_per_step"])
+        pick = torch.tensor([best], dtype=torch.int64, device=dev)
+        dist.broadcast(pick, src=0, group=self.pg)
+        chosen = menus[int(pick[0])]
+        self.set_dp_menu(**chosen)
+        return {"menus": rows, "chosen": dict(chosen), "probed": True, "steps_per_menu": steps}
+
     def describe_dp(self) -> Dict[str, Any]:
         """What the data-parallel exchange of this engine looks like (bench.py prints it on N > 1 lines)."""
         e = self.module._engine

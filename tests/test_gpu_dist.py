@@ -285,7 +285,8 @@ def test_bench_two_ranks_gloo_smoke():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["value"] > 0
     assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"]
     dp = d["dp"]
-    assert dp["world"] == 2 and dp["n_buckets"] == 2 + 2 and dp["backend"].endswith("gloo") and dp["overlap_with_backward"] is True
+    assert dp["world"] == 2 and dp["n_buckets"] == 2 + 2 and dp["backend"].endswith("gloo")
+    assert dp["menu_probe"]["probed"] and dp["overlap_with_backward"] == dp["menu_probe"]["chosen"]["overlap"]
     assert dp["ms_per_step_without_exchange"] > 0 and abs(dp["exposed_comm_ms"] - (d["ms_per_step"] - dp["ms_per_step_without_exchange"])) < 1e-9
     assert np.isfinite(d["smtp_loss"])
 
@@ -373,6 +374,12 @@ def test_bench_eight_ranks_gloo_smoke():
     assert dp["replicas_bit_identical"] is True
     assert np.isfinite(dp["exposed_comm_ms"]) and np.isfinite(d["smtp_loss"])
     assert len(dp["rank_devices"]) == 8 and dp["distinct_devices"] >= 1 and dp["rank_devices"][3]["rank"] == 3
+    # the start-up probe (round 6): three exchange arrangements timed on this machine, the fastest one kept by EVERY rank
+    mp = dp["menu_probe"]
+    assert mp["probed"] is True and len(mp["menus"]) == 3 and all(m["ms_per_step"] > 0 for m in mp["menus"])
+    best = min(mp["menus"], key=lambda m: m["ms_per_step"])
+    assert (mp["chosen"]["overlap"], mp["chosen"]["reserve_cus"]) == (best["overlap"], best["reserve_cus"])
+    assert dp["overlap_with_backward"] == mp["chosen"]["overlap"] and dp["reserved_cus"] == mp["chosen"]["reserve_cus"]
 
 
 @pytest.mark.parametrize("backend", ["torch", "abi"])

@@ -397,8 +397,8 @@ def main():
         step(0)     # (the probes below run on the reported layout again, on batch 0)
         torch.cuda.synchronize()
     # The batch hand-over inside the number: the same K steps once more, outside the reported time, fed with HOST
-    # batches - nothing pre-staged - (a) through the product's DevicePrefetcher (pinned staging + side stream, batch t + 1 copied during
-    # step t: what TrainingPipeline's loop does) and (b) the reference's way, every tensor `.to(device)` at the top of the step
+    # batches - nothing pre-staged - (a) through the product's DevicePrefetcher (pinned staging of batch t + 1 during step t, copy kernels in
+    # the compute queue: what TrainingPipeline's loop does) and (b) the reference's way, every tensor `.to(device)` at the top of the step
     # (training_utils.py:17-26).  `value` stays the device-resident figure the contract asks for; these two sit next to it.
     h2d = None
     if world == 1 and kind != "pt-packed":
@@ -427,9 +427,10 @@ def main():
         sync_ms = (time.perf_counter() - t1) / a.steps * 1e3
         nbytes = sum(v.numel() * v.element_size() for v in host_t[0].values())
         h2d = {"h2d_inclusive_ms_per_step": pre_ms, "synchronous_to_device_ms_per_step": sync_ms, "batch_bytes": nbytes,
-               "what": "host batches in, nothing pre-staged, same K steps and rotation: prefetched = graph-gpt_amd.training.DevicePrefetcher (pinned "
-                       "staging, side stream, one batch ahead; the host-side mask sum rides along as num_tokens); synchronous = every tensor "
-                       ".cuda() from pageable memory at the top of the step, the reference's batch_training"}
+               "what": "host batches in, nothing pre-staged, same K steps and rotation: h2d_inclusive = graph-gpt_amd.training.DevicePrefetcher (pinned "
+                       "staging one batch ahead, one copy kernel per tensor in the compute queue in front of the step; the host-side mask sum "
+                       "rides along as num_tokens); synchronous = every tensor .cuda() from pageable memory at the top of the step, the "
+                       "reference's batch_training"}
         step(0)
         torch.cuda.synchronize()
     # N > 1: how much of the step is gradient exchange the backward does not hide - the same K steps once more (outside the reported

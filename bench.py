@@ -363,7 +363,11 @@ def main():
         def probe_step():
             probe_i[0] += 1
             return step(probe_i[0])
-        menu_probe = engine.probe_dp_menu(probe_step, steps=int(os.environ.get("GGET_DP_PROBE_STEPS", "10")))
+        try:
+            menu_probe = engine.probe_dp_menu(probe_step, steps=int(os.environ.get("GGET_DP_PROBE_STEPS", "10")))
+        except Exception as ex:      # (the probe must never cost the run its line: defaults then, and the reason in the line)
+            engine.set_dp_menu(overlap=True, reserve_cus=0)
+            menu_probe = {"menus": [], "chosen": {"overlap": True, "reserve_cus": 0}, "probed": False, "error": repr(ex)[:300]}
     for i in range(a.warmup):
         loss = step(i)
     torch.cuda.synchronize()

@@ -243,6 +243,9 @@ def main():
                          "8 * ceil(max_len / 8) of its longest graph (reference src/data/collator.py:70-111), so real PCQM4M-v2 batches of 256 graphs "
                          "are rarely S <= 32; the lengths keep the workload's distribution (clipped N(22, 6), one graph of the batch at the full width). "
                          "0 = the workload's own S (the headline line)")
+    ap.add_argument("--per-gpu-batch", type=int, default=0,
+                    help="graphs per GPU and step instead of the workload's own B (256 for the headline: the reference's batch size); a shape knob "
+                         "for sweeps like --seq-len / --mean-len, never the headline line")
     ap.add_argument("--mean-len", type=float, default=22.0,
                     help="mean of the graphs' token count (clipped N(mean, 6); 22 = the workload's own): moves the var-len row count of the "
                          "batches, the shape every GEMM launch plan is chosen for (tools/rows_sweep.py)")
@@ -282,6 +285,8 @@ def main():
     if a.seq_len:
         assert kind == "pt", "--seq-len: pre-train workloads"
         S = a.seq_len
+    if a.per_gpu_batch:
+        B = a.per_gpu_batch
     tail = dict(long_tail=a.long_tail) if a.long_tail > 0 else {}
     if a.mean_len != 22.0:
         tail["mean_len"] = a.mean_len

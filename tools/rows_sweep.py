@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--means", default="16,17,18,19,20,21,22,23,24,25,26")
     ap.add_argument("--seq-len", type=int, default=32)
+    ap.add_argument("--batches", default="", help="comma list of per-GPU batch sizes: sweep B at the workload's mean length instead of the mean length")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--out", default="r06_c1_rows_sweep")
@@ -29,16 +30,17 @@ def main():
         k, v = kv.split("=", 1)
         env[k] = v
     rows = []
-    for m in [float(x) for x in a.means.split(",")]:
+    points = [("mean", float(x)) for x in a.means.split(",")] if not a.batches else [("batch", int(x)) for x in a.batches.split(",")]
+    for kind_, m in points:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", str(a.warmup), "--no-cpu-baseline",
-               "--seq-len", str(a.seq_len), "--mean-len", str(m), "--layout", "varlen-count"]
+               "--seq-len", str(a.seq_len), "--layout", "varlen-count"] + (["--mean-len", str(m)] if kind_ == "mean" else ["--per-gpu-batch", str(m)])
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not line:
             print(r.stdout[-2000:], r.stderr[-4000:], file=sys.stderr)
             raise SystemExit(f"bench.py --mean-len {m} failed")
         j = json.loads(line[-1])
-        rows.append({"mean_len": m, "rows_per_batch": j["step_mfma"]["rows_per_batch"], "ms_per_step": j["ms_per_step"],
+        rows.append({"mean_len": m if kind_ == "mean" else 22.0, "per_gpu_batch": j["config"]["per_gpu_batch"], "rows_per_batch": j["step_mfma"]["rows_per_batch"], "ms_per_step": j["ms_per_step"],
                      "real_tokens_per_s": j["value"], "us_per_1k_rows": j["ms_per_step"] * 1e3 / (sum(j["step_mfma"]["rows_per_batch"]) / len(j["step_mfma"]["rows_per_batch"]) / 1e3),
                      "step_mfma_frac_of_peak": j["step_mfma"]["frac_of_peak"]})
         print(json.dumps(rows[-1]), flush=True)
@@ -49,7 +51,7 @@ def main():
         json.dump(out, f, indent=1)
     print("mean  rows/batch (rotation)            ms/step   real tok/s   us per 1k rows")
     for r in rows:
-        print(f"{r['mean_len']:<5.1f} {str(r['rows_per_batch']):34s} {r['ms_per_step']:.3f}    {r['real_tokens_per_s'] / 1e6:.4f} M   {r['us_per_1k_rows']:.1f}")
+        print(f"{r['mean_len']:<5.1f} B={r['per_gpu_batch']:<4d} {str(r['rows_per_batch']):34s} {r['ms_per_step']:.3f}    {r['real_tokens_per_s'] / 1e6:.4f} M   {r['us_per_1k_rows']:.1f}")
 
 
 if __name__ == "__main__":

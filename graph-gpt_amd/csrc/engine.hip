@@ -1353,7 +1353,13 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
     // whenever that layout can still be chosen for this forward
     h->wo_packed = false;
     const bool may_varlen = allow_varlen && varlen_enabled() && (tc_hint > 0 || tc_hint == GGET_TOKENS_AUTO) && mask != nullptr;
-    if (!h->plan.has_res && !mask_is_3d && (S <= 32 || (S <= 64 && may_varlen)) && h->ws.wo_pack && c.num_layers > 0) {
+    // One workgroup per sample, one per CU: B samples are ceil(B / CUs) ROUNDS of the kernel whatever the last round holds.  Up to one
+    // round they always pay; beyond, only when the last round is nearly full (B = 288 / 320 / 384 on 256 CUs: 8.20 / 8.51 / 9.90 ms per
+    // step against 7.95 / 8.32 / 9.73 with the three launches, profiles/r06_step_experiments.txt item 8)
+    const int ncu = gget_gemm_num_cu() > 0 ? gget_gemm_num_cu() : 256;
+    const int rounds = (B + ncu - 1) / ncu;
+    const bool rounds_ok = B <= ncu || (long)B * 100 >= (long)rounds * ncu * 85;
+    if (!h->plan.has_res && !mask_is_3d && (S <= 32 || (S <= 64 && may_varlen)) && rounds_ok && h->ws.wo_pack && c.num_layers > 0) {
       const size_t stride = c.num_layers > 1 ? h->plan.layers[1].wo - h->plan.layers[0].wo : 0;
       bool regular = true;
       for (int i = 0; i < c.num_layers; ++i) regular = regular && h->plan.layers[i].wo == h->plan.layers[0].wo + (size_t)i * stride;

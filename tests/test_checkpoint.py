@@ -121,3 +121,62 @@ def test_reference_written_checkpoint_reproduces_reference_loss():
     names = [str(n) for n in z["names"]]
     gn = np.array([float(dict(model.named_parameters())[n].grad.norm()) for n in names])
     np.testing.assert_allclose(gn, z["grad_norms"], rtol=3e-2, atol=1e-6)
+
+
+def _write_zero2_shards(root, tag, state, groups, world, tie=None, buffers=None):
+    """A DeepSpeed ZeRO-2 checkpoint directory in the documented layout (deepspeed 0.15.4 stage_1_and_2.py state_dict / engine.py
+    _save_checkpoint): per optimizer group the parameters are flattened in order, padded to a multiple of 2 x world, and cut into `world`
+    equal slices, one per rank file; rank 0's model-states file lists the shapes."""
+    import collections
+    import math
+    d = os.path.join(root, tag)
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(root, "latest"), "w") as fh:
+        fh.write(tag)
+    shapes, slices = [], [[] for _ in range(world)]
+    for names in groups:
+        flat = torch.cat([state[n].reshape(-1).float() for n in names])
+        pad = (2 * world) * math.ceil(flat.numel() / (2 * world)) - flat.numel()
+        flat = torch.cat([flat, torch.zeros(pad)])
+        per = flat.numel() // world
+        for r in range(world):
+            slices[r].append(flat[r * per:(r + 1) * per].clone())
+        shapes.append(collections.OrderedDict((n, torch.Size(state[n].shape)) for n in names))
+    module = {k: v.to(torch.bfloat16) for k, v in state.items()}
+    module.update({k: v for k, v in (buffers or {}).items()})
+    torch.save({"module": module, "buffer_names": list((buffers or {}).keys()), "param_shapes": shapes, "shared_params": tie or [],
+                "ds_version": "0.15.4"}, os.path.join(d, "mp_rank_00_model_states.pt"))
+    for r in range(world):
+        torch.save({"optimizer_state_dict": {"zero_stage": 2, "partition_count": world, "single_partition_of_fp32_groups": slices[r],
+                                             "loss_scaler": None}, "ds_version": "0.15.4"},
+                   os.path.join(d, f"bf16_zero_pp_rank_{r}_mp_rank_00_optim_states.pt"))
+
+
+@pytest.mark.parametrize("world", [1, 2, 8, 11])
+def test_zero2_shards_consolidate_to_the_fp32_state_dict(tmp_path, world):
+    """The reference's fallback for DeepSpeed checkpoints (loader_utils.py:199-207 -> deepspeed.utils.zero_to_fp32): ZeRO-2 shards of a
+    pre-train model - two optimizer groups (decay / no-decay), `world` rank files, padding to 2 x world, a tied pair, a buffer - come back
+    as the exact fp32 state dict, through `zero_to_fp32_state_dict` and through `read_state_dict` (what `load_from_ckp_with_try` calls).
+    UNPINNED against DeepSpeed itself (not installed): the writer above follows the documented layout."""
+    CK = importlib.import_module("graph-gpt_amd.checkpoint")
+    spec_mod = importlib.import_module("graph-gpt_amd.spec")
+    weights = importlib.import_module("graph-gpt_amd.weights")
+    spec = spec_mod.spec_from_size("tiny", vocab_size=300, stacked_feat=4, next_n_token=4)
+    state = {k: torch.from_numpy(v).float() for k, v in weights.make_state_dict(spec, seed=5).items()}
+    names = list(state)
+    decay = [n for n in names if state[n].dim() > 1]
+    no_decay = [n for n in names if state[n].dim() <= 1]
+    _write_zero2_shards(str(tmp_path), "global_step120", state, [decay, no_decay], world, tie=[["tied.alias.weight", decay[0]]],
+                        buffers={"model.rotary_emb.inv_freq": torch.arange(32, dtype=torch.bfloat16)})
+    got = CK.zero_to_fp32_state_dict(str(tmp_path))
+    assert set(got) == set(state) | {"tied.alias.weight", "model.rotary_emb.inv_freq"}
+    for k, v in state.items():
+        assert got[k].dtype == torch.float32 and torch.equal(got[k], v), k
+    assert torch.equal(got["tied.alias.weight"], state[decay[0]]) and got["model.rotary_emb.inv_freq"].dtype == torch.float32
+    via = CK.read_state_dict(str(tmp_path))                       # the loader's path: no model.pt -> the ZeRO branch
+    assert all(torch.equal(via[k], v) for k, v in state.items())
+    assert all(torch.equal(CK.zero_to_fp32_state_dict(os.path.join(str(tmp_path), "global_step120"))[k], v) for k, v in state.items())   # the tag directory itself
+    # a missing rank file is an error, like in the original
+    os.remove(os.path.join(str(tmp_path), "global_step120", "bf16_zero_pp_rank_0_mp_rank_00_optim_states.pt"))
+    with pytest.raises((ValueError, FileNotFoundError)):
+        CK.zero_to_fp32_state_dict(str(tmp_path))

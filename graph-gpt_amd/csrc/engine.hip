@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <functional>
 #include <vector>
@@ -188,7 +189,7 @@ struct Ws {
   uint64_t scratch32, loss_sum, loss_part, sqnorm, counts, segs, emb_sort, emb_cnt, emb_slab, wg32, lm_slab;
   uint64_t sq_chunks, sq_tiles;   // gradient-norm shortcut: chunk table of everything but the layers' weight matrices; per-tile sums of those
   // pre-train head
-  uint64_t cnt, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
+  uint64_t cnt, hc_tot, m_off, l_off, row_idx, sel_src, sel_label, sel_tok, Hm, Pp, Hl, logits, dlogits, dHl, dP, dHm;
   // slot-sorted n_token_proj (kernels.hip k_head_slot_sort): sorted cell lists (token row / dP row / cell index per sorted position), the
   // sorted position of every cell, weight offset per 128-row tile, slot counters, padded total
   uint64_t ss_tok, ss_cell, ss_l, ss_pos, ss_tile, ss_state, ss_total;
@@ -293,6 +294,7 @@ Ws make_ws(const gget_config_t& c, const Plan& pl) {
   if (c.kind == GGET_KIND_PRETRAIN) {
     const uint64_t n = c.next_n_token, Vp = align_up(c.vocab_size, 64);
     w.cnt = b.take(T * 4);
+    w.hc_tot = b.take(k_head_compact_ws_bytes((int)T));
     w.m_off = b.take(T * 4);
     w.l_off = b.take(T * 4);
     w.row_idx = b.take(T * 4);
@@ -391,9 +393,11 @@ struct gget_engine {
   bool opt_skip_nonfinite = false;     // GGET_OPT_SKIP_NONFINITE_STEP: gget_adamw_step leaves the parameters alone when the gradient norm is inf / NaN
   int sq_layers = 0;
   int n_sq_chunks = 0;
+  bool emb_cnt_cleared = false;   // this backward's first launch cleared the embedding gradient's count matrix (gget_backward_begin)
   bool head_sorted_fwd = false;   // the last pre-train forward ran the slot-sorted n_token_proj (its lists feed the backward)
   bool tc_from_caller = false;    // the last var-len forward ran on a caller's count (a wrong one poisons the loss, see poison_loss)
   int32_t* host_word = nullptr;   // pinned host word the counted total lands in
+  int32_t* host_word_dev = nullptr;   // ... and its device-side address (sum_lengths_kernel stores to it)
   const int64_t* pos_rows = nullptr;   // position of every ROW (GEMM RoPE epilogue): pos_cur, or the compacted positions
   const int32_t* row_base() const { return varlen ? wsp<int32_t>(ws.vl_cu) : nullptr; }
   const int32_t* long_list() const { return varlen ? wsp<int32_t>(ws.vl_long) : nullptr; }
@@ -1394,14 +1398,40 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
     long tc = tc_hint;
     if (tc_hint == GGET_TOKENS_AUTO) {
       int32_t* dst = h->wsp<int32_t>(h->ws.vl_status) + 3;
-      if (!h->host_word) GGET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->host_word), 64, hipHostMallocDefault));
-      if (int e = k_sum_lengths(h->wsp<int32_t>(h->ws.key_len), B, dst, st)) return e;
-      GGET_HIP_CHECK(hipMemcpyAsync(h->host_word, dst, 4, hipMemcpyDeviceToHost, st));
-      if (!h->count_event) GGET_HIP_CHECK(hipEventCreateWithFlags(&h->count_event, hipEventDisableTiming));
-      GGET_HIP_CHECK(hipEventRecord(h->count_event, st));
+      if (!h->host_word) {     // (coherent: a store from a running kernel is visible to the polling host)
+        GGET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->host_word), 64, hipHostMallocMapped | hipHostMallocCoherent));
+        GGET_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->host_word_dev), h->host_word, 0));
+      }
+      // Round 6: sum_lengths_kernel stores the count into the pinned word itself (system-scope release) and the host POLLS the word -
+      // no device-to-host copy packet and no event in the stream (a 4 us blit kernel plus a 5.7 us bubble behind the event's barrier
+      // packet in every step before).  GGET_COUNT_COPY=1: the copy + event of rounds 3 - 5.
+      static const bool count_copy = getenv("GGET_COUNT_COPY") && atoi(getenv("GGET_COUNT_COPY")) != 0;
+      constexpr int32_t kNoCount = INT32_MIN;
+      if (!count_copy) __atomic_store_n(h->host_word, kNoCount, __ATOMIC_RELEASE);     // (before the launch: the launch orders it)
+      if (int e = k_sum_lengths(h->wsp<int32_t>(h->ws.key_len), B, dst, st, count_copy ? nullptr : h->host_word_dev)) return e;
+      if (count_copy) {
+        GGET_HIP_CHECK(hipMemcpyAsync(h->host_word, dst, 4, hipMemcpyDeviceToHost, st));
+        if (!h->count_event) GGET_HIP_CHECK(hipEventCreateWithFlags(&h->count_event, hipEventDisableTiming));
+        GGET_HIP_CHECK(hipEventRecord(h->count_event, st));
+      }
       if (int e = early_work()) return e;                      // (runs on the device while the host waits for the 4 bytes)
-      GGET_HIP_CHECK(hipEventSynchronize(h->count_event));
-      tc = *h->host_word;
+      if (count_copy) {
+        GGET_HIP_CHECK(hipEventSynchronize(h->count_event));
+        tc = *h->host_word;
+      } else {
+        int32_t v = kNoCount;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (long spin = 0; (v = __atomic_load_n(h->host_word, __ATOMIC_ACQUIRE)) == kNoCount; ++spin) {
+          if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            // (a stream that is held up - another process on the GPU, a debugger - or a failed launch: wait for the stream, then look again)
+            GGET_HIP_CHECK(hipStreamSynchronize(st));
+            v = __atomic_load_n(h->host_word, __ATOMIC_ACQUIRE);
+            GGET_REQUIRE(v != kNoCount, "the token count never arrived from the device");
+            break;
+          }
+        }
+        tc = v;
+      }
     }
     const long t_rows = (tc + 63) / 64 * 64;
     if (tc > 0 && t_rows < (long)B * S) {
@@ -1486,28 +1516,35 @@ static int forward_pretrain_impl(gget_handle_t h, const int64_t* input_ids_dev, 
   int32_t* counts = h->wsp<int32_t>(w.counts);
   // row / cell compaction of the head: reads the labels only (padded coordinates), so it is handed to the backbone as token-count
   // independent work (gget_engine::presync_work) - with GGET_TOKENS_AUTO it runs while the host waits for the count
+  // (the slot-sorted n_token_proj below: its per-slot cell counts are taken by the same launches)
+  const bool sorted_head = h->plan.has_ntp && head_sorted() && d % 192 == 0 && n <= 32;
   auto head_compact = [&](hipStream_t s_) -> int {
     return k_head_compact(labels_dev, B * S, n, h->wsp<int32_t>(w.cnt), h->wsp<int32_t>(w.m_off), h->wsp<int32_t>(w.l_off), counts,
-                          h->wsp<int32_t>(w.row_idx), h->wsp<int32_t>(w.sel_src), h->wsp<int32_t>(w.sel_label), h->wsp<int32_t>(w.sel_tok), s_);
+                          h->wsp<int32_t>(w.row_idx), h->wsp<int32_t>(w.sel_src), h->wsp<int32_t>(w.sel_label), h->wsp<int32_t>(w.sel_tok),
+                          h->wsp<int32_t>(w.hc_tot), sorted_head ? h->wsp<int32_t>(w.ss_state) : nullptr, s_);
   };
   h->presync_work = head_compact;
   h->presync_done = false;
   const int rc_bb = backbone_forward(h, tc_hint, input_ids_dev, c.stacked_feat, attention_mask_dev, position_ids_dev, B, S, st, mask_is_3d, labels_dev);
   h->presync_work = nullptr;       // (captures this frame)
-  if (rc_bb) return rc_bb;
+  if (rc_bb) {
+    if (sorted_head && h->presync_done)     // (the slot counts were taken and nobody will consume them)
+      (void)hipMemsetAsync(h->wsp<int32_t>(w.ss_state), 0, 512, st);
+    return rc_bb;
+  }
   const int T = h->TP;             // (capacities of the head: the padded token space)
   if (!h->presync_done)
     if (int e = head_compact(st)) return e;
-  if (h->varlen)   // the selected rows live at their compact positions (sel_tok / sel_label keep the padded coordinates the loss weights need)
+  if (h->varlen) {  // the selected rows live at their compact positions (sel_tok / sel_label keep the padded coordinates the loss weights need)
     // (full-logit inference - labels == NULL, generation - selects every cell of the padded grid: the cells of padded positions read a
     //  pad-token row, their logits are defined but meaningless exactly like the reference's, and no flag is raised)
-    if (int e = k_remap_rows(h->wsp<int32_t>(w.row_idx), counts, h->wsp<int32_t>(w.vl_pad2c), T, h->T > h->tc ? h->tc : 0,
-                             labels_dev ? h->wsp<int32_t>(w.vl_status) : nullptr, st))
+    if (int e = k_gather_rows_remap(h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.row_idx), counts, h->wsp<int32_t>(w.vl_pad2c),
+                                    h->wsp<bf16_t>(w.Hm), T, d, h->T > h->tc ? h->tc : 0, labels_dev ? h->wsp<int32_t>(w.vl_status) : nullptr, st))
       return e;
-  if (int e = k_gather_rows(h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.row_idx), counts, h->wsp<bf16_t>(w.Hm), T, d, 0, st))
+  } else if (int e = k_gather_rows(h->wsp<bf16_t>(w.hidden), h->wsp<int32_t>(w.row_idx), counts, h->wsp<bf16_t>(w.Hm), T, d, 0, st))
     return e;
   h->head_sorted_fwd = false;
-  if (h->plan.has_ntp && head_sorted() && d % 192 == 0 && n <= 32) {
+  if (sorted_head) {
     // n_token_proj on the labelled cells only (modeling_helpers.py:263-301 computes all n slots of every selected row and drops the
     // unlabelled half): cells sorted by slot, one GEMM with a weight block per row tile, rows gathered from `hidden` and scattered
     // straight to Hl's (m, f) order - the dense [M, n d] product and its gather are gone
@@ -1855,6 +1892,13 @@ int layer_backward(gget_engine* h, int i, hipStream_t st) {
 
 }  // namespace
 
+// which form of the embedding backward runs (embed_bwd below): the count-matrix product, or the sorted scatter-add
+// (embedding dropout masks every (cell, channel) on its own: the count-matrix product cannot express it)
+static bool embed_dense_path(int T, int d, int V, bool gated, const ElemDropArg& E) {
+  static const bool sorted_only = getenv("GGET_EMBED_SORTED") != nullptr;   // A/B knob
+  return !sorted_only && E.thresh == 0 && k_embed_dense_ok(V, gated) && T > 0 && ((long)V * d) % 4 == 0;
+}
+
 extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stream) {
   GGET_REQUIRE(h, "null handle");
   GGET_REQUIRE(h->fwd_valid && h->have_labels, "backward needs a preceding forward with labels");
@@ -1882,6 +1926,12 @@ extern "C" int gget_backward_begin(gget_handle_t h, float loss_scale, void* stre
     if (h->plan.has_ntp && head_scatter_fused())
       zr.add(h->wsp<bf16_t>(w.dP), (size_t)(h->varlen ? h->T : T) * c.next_n_token * d * 2);
     zr.add(h->wsp<float>(w.lm_slab), (size_t)kLmSplit * c.vocab_size * d * sizeof(float));
+  }
+  // ... and the bf16 count matrix of the embedding gradient (embed_bwd at the end of the backward: its own fill launch before)
+  h->emb_cnt_cleared = false;
+  if (h->ws.emb_cnt && embed_dense_path(h->T, d, c.vocab_size, h->plan.has_gate, h->embed_drop()) && zr.n < kZeroRanges) {
+    zr.add(h->wsp<unsigned char>(h->ws.emb_cnt), (size_t)h->T * align_up((uint64_t)c.vocab_size, 64) * 2);
+    h->emb_cnt_cleared = true;
   }
   if (int e = k_zero_ranges(zr, st)) return e;
   if (c.kind == GGET_KIND_PRETRAIN) {
@@ -1997,12 +2047,11 @@ extern "C" int gget_backward_layer(gget_handle_t h, int layer, void* stream) {
 // (k_embed_count), one split-K GEMM with fp32 atomics into the accumulator - the sorted scatter-add below spends its time in
 // same-address atomics when half of the cells hold the <mask> id.  Otherwise: counting sort by id + segmented sums.
 int embed_bwd(const int64_t* ids, const void* dx, const void* emb, const void* gate, float* demb, float* dgate, int T, int F,
-              int ldF, int d, int V, int pad_id, int32_t* sort_ws, void* cnt_ws, void* slab_ws, hipStream_t st, ElemDropArg E) {
-  static const bool sorted_only = getenv("GGET_EMBED_SORTED") != nullptr;   // A/B knob
-  // (embedding dropout masks every (cell, channel) on its own: the count-matrix product cannot express it)
-  if (cnt_ws && slab_ws && !sorted_only && E.thresh == 0 && k_embed_dense_ok(V, gate != nullptr) && T > 0 && (V * d) % 4 == 0) {
+              int ldF, int d, int V, int pad_id, int32_t* sort_ws, void* cnt_ws, void* slab_ws, hipStream_t st, ElemDropArg E,
+              bool cnt_cleared = false) {
+  if (cnt_ws && slab_ws && embed_dense_path(T, d, V, gate != nullptr, E)) {
     const int ldc = (int)align_up((uint64_t)V, 64);
-    GGET_HIP_CHECK(hipMemsetAsync(cnt_ws, 0, (size_t)T * ldc * 2, st));
+    if (!cnt_cleared) GGET_HIP_CHECK(hipMemsetAsync(cnt_ws, 0, (size_t)T * ldc * 2, st));
     if (int e = k_embed_count(ids, cnt_ws, T, F, ldF, ldc, pad_id, st)) return e;
     // 6 x 6 output tiles at V = 756, d = 768: K = T is cut into <= kEmbDenseSplit slices, one fp32 slab each (every slice is
     // non-empty: nslab is recomputed from the 64-row K-tiles), then one pass sums the slabs into the accumulator
@@ -2052,8 +2101,9 @@ extern "C" int gget_backward_end(gget_handle_t h, void* stream) {
                         c.stacked_feat, c.hidden_size, c.vocab_size, c.pad_token_id, h->wsp<int32_t>(h->ws.emb_sort),
                         k_embed_dense_ok(c.vocab_size, h->plan.has_gate) ? h->wsp<unsigned char>(h->ws.emb_cnt) : nullptr,
                         k_embed_dense_ok(c.vocab_size, h->plan.has_gate) ? h->wsp<unsigned char>(h->ws.emb_slab) : nullptr, st,
-                        h->embed_drop()))
+                        h->embed_drop(), h->emb_cnt_cleared))
     return e;
+  h->emb_cnt_cleared = false;
   h->dx_cur = nullptr;
   return convert_bucket(h, c.num_layers + 1, st);
 }

@@ -66,18 +66,21 @@ int k_varlen_plan(const int64_t* ids, int ldF, int F, const int64_t* pos, int32_
                   int t_rows, int pad_id, hipStream_t st, int32_t* long_list = nullptr);      // c2p[r] = logical row b * S + s of compact row r
 // out = clamp(pos, 0, max_pos - 1); *flag = 1 (sticky) if anything was clamped
 int k_clamp_positions(const int64_t* pos, int64_t* out, int32_t* flag, long n, int max_pos, hipStream_t st);
-int k_remap_rows(int32_t* idx, const int32_t* count, const int32_t* pad2c, int cap, int pad_row, int32_t* status, hipStream_t st);
 int k_head_slot_sort(const int32_t* sel_src, const int32_t* row_idx, const int32_t* lm_count, int32_t* slot_state, int32_t* a_tok,
                      int32_t* a_cell, int32_t* c_l, int32_t* cellpos, int32_t* tile_off, int32_t* total_p, int cap, int n, long slot_elems,
                      int tile_rows, hipStream_t st);
 int k_head_cell_sum(const void* dxs, const int32_t* cellpos, const int32_t* cnt, const int32_t* l_off, const int32_t* pad2c, void* dhid,
                     int TP, int d, int pad_row, hipStream_t st);
 int k_poison_loss(const int32_t* flag, float* loss, hipStream_t st);
-int k_sum_lengths(const int32_t* key_len, int B, int32_t* out, hipStream_t st);
+int k_sum_lengths(const int32_t* key_len, int B, int32_t* out, hipStream_t st, int32_t* host_out = nullptr);   // host_out: pinned host word the kernel stores to
 int k_head_compact(const int64_t* labels, int T, int n, int32_t* cnt, int32_t* m_off, int32_t* l_off, int32_t* counts,
-                   int32_t* row_idx, int32_t* sel_src, int32_t* sel_label, int32_t* sel_tok, hipStream_t st);
+                   int32_t* row_idx, int32_t* sel_src, int32_t* sel_label, int32_t* sel_tok, int32_t* blk_tot, int32_t* slot_hist,
+                   hipStream_t st);     // slot_hist: nullptr, or the slot-sorted head's state (k_head_slot_sort follows in the same forward)
+size_t k_head_compact_ws_bytes(int T);
 int k_gather_rows(const void* src, const int32_t* idx, const int32_t* count, void* dst, int cap, int d, int scatter,
                   hipStream_t st);
+int k_gather_rows_remap(const void* src, int32_t* idx, const int32_t* count, const int32_t* pad2c, void* dst, int cap, int d, int pad_row,
+                        int32_t* status, hipStream_t st);     // var-len remap of idx (in place) + gather, one launch
 int k_ce_fwd_bwd(const void* logits, int ld, const int32_t* labels, const int32_t* sel_tok, const float* sample_wgt, int S,
                  const int32_t* n_rows_dev, int n_rows_cap, int V, float* loss_sum, void* dlogits, float scale_base,
                  int mean_over_rows, float* loss_out, hipStream_t st, float focal_gamma = 0.f, float* loss_part = nullptr,

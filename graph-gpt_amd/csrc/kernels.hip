@@ -825,73 +825,88 @@ __global__ void __launch_bounds__(64) lengths_kernel(const int64_t* __restrict__
 // K11  SMTP head compaction (modeling_helpers.py:263-301): positions with >=1 masked feature -> M rows,
 // masked (row,f) cells -> Lm rows, in (b,s,f) row-major order, without leaving the device.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) head_flags_kernel(const int64_t* __restrict__ labels, int32_t* __restrict__ cnt,
-                                                            int T, int n) {
-  const int t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= T) return;
-  int c = n;
-  if (labels) {
-    c = 0;
-    for (int f = 0; f < n; ++f) c += labels[(size_t)t * n + f] != -100;
-  }
-  cnt[t] = c;
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
 }
-
-// single block: exclusive scans of (cnt>0) and cnt over T tokens; counts[0]=M, counts[1]=Lm.  Every thread owns a contiguous
-// run of tokens (serial scan in registers), the 1024 run totals are scanned with wave shuffles + one pass over the 16 wave
-// totals: two barriers in all (a Hillis-Steele scan over LDS took 160 barriers, 21 us at T = 8192).
-__global__ void __launch_bounds__(1024) head_scan_kernel(const int32_t* __restrict__ cnt, int32_t* __restrict__ m_off,
-                                                         int32_t* __restrict__ l_off, int32_t* __restrict__ counts,
-                                                         int T) {
-  __shared__ int wm[16], wl[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (T + 1023) / 1024;
-  const int beg = min(T, tid * per), end = min(T, beg + per);
-  int tm = 0, tl = 0;
-  for (int t = beg; t < end; ++t) {
-    const int c = cnt[t];
-    tm += c > 0;
-    tl += c;
+// Two launches (round 6; before: flags -> a single-block scan over all T tokens, 12 us at T = 8192 -> fill):
+// (1) label count of every token and the (selected rows, labelled cells) totals of every kBlock-token block;
+__global__ void __launch_bounds__(kBlock) head_count_kernel(const int64_t* __restrict__ labels, int32_t* __restrict__ cnt,
+                                                            int32_t* __restrict__ blk_tot, int T, int n) {
+  __shared__ int sm[kBlock / 64], sl[kBlock / 64];
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  int c = 0;
+  if (t < T) {
+    c = n;
+    if (labels) {
+      c = 0;
+      for (int f = 0; f < n; ++f) c += labels[(size_t)t * n + f] != -100;
+    }
+    cnt[t] = c;
   }
-  int im = tm, il = tl;   // inclusive scan inside the wave
+  const int wm = wave_sum_i32(c > 0), wl = wave_sum_i32(c);
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = wm; sl[threadIdx.x >> 6] = wl; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int m = 0, l = 0;
+    for (int w = 0; w < kBlock / 64; ++w) { m += sm[w]; l += sl[w]; }
+    blk_tot[2 * blockIdx.x] = m;
+    blk_tot[2 * blockIdx.x + 1] = l;
+  }
+}
+// (2) every block sums the totals of the blocks before it (T / kBlock pairs at most), scans its own kBlock tokens - exclusive offsets of
+// (cnt > 0) and cnt in token order, counts[0] = M, counts[1] = Lm from the last block - and writes its rows / cells.
+__global__ void __launch_bounds__(kBlock) head_fill_kernel(const int64_t* __restrict__ labels, const int32_t* __restrict__ cnt,
+                                                           const int32_t* __restrict__ blk_tot, int32_t* __restrict__ m_off,
+                                                           int32_t* __restrict__ l_off, int32_t* __restrict__ counts,
+                                                           int32_t* __restrict__ row_idx, int32_t* __restrict__ sel_src,
+                                                           int32_t* __restrict__ sel_label, int32_t* __restrict__ sel_tok,
+                                                           int32_t* __restrict__ slot_hist, int T, int n) {
+  __shared__ int pm_s[kBlock / 64], pl_s[kBlock / 64], wm_s[kBlock / 64], wl_s[kBlock / 64], hist[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (slot_hist && threadIdx.x < 32) hist[threadIdx.x] = 0;     // (ordered before its use by the barrier below)
+  int pm = 0, pl = 0;
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += kBlock) { pm += blk_tot[2 * j]; pl += blk_tot[2 * j + 1]; }
+  pm = wave_sum_i32(pm);
+  pl = wave_sum_i32(pl);
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  const int c = t < T ? cnt[t] : 0;
+  int im = c > 0, il = c;   // inclusive scan inside the wave
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const int am = __shfl_up(im, o, 64), al = __shfl_up(il, o, 64);
     if (lane >= o) { im += am; il += al; }
   }
-  if (lane == 63) { wm[wave] = im; wl[wave] = il; }
+  if (lane == 63) { wm_s[wave] = im; wl_s[wave] = il; }
+  if (lane == 0) { pm_s[wave] = pm; pl_s[wave] = pl; }
   __syncthreads();
-  int bm = 0, bl = 0;     // totals of the waves before this one
-  for (int w = 0; w < wave; ++w) { bm += wm[w]; bl += wl[w]; }
-  int m = bm + im - tm, l = bl + il - tl;
-  for (int t = beg; t < end; ++t) {
-    const int c = cnt[t];
+  int bm = 0, bl = 0;
+  for (int w = 0; w < kBlock / 64; ++w) { bm += pm_s[w]; bl += pl_s[w]; }
+  for (int w = 0; w < wave; ++w) { bm += wm_s[w]; bl += wl_s[w]; }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) { counts[0] = bm + im; counts[1] = bl + il; }
+  if (t < T) {
+    const int m = bm + im - (c > 0);
+    int j = bl + il - c;
     m_off[t] = m;
-    l_off[t] = l;
-    m += c > 0;
-    l += c;
-  }
-  if (tid == 1023) { counts[0] = bm + im; counts[1] = bl + il; }
-}
-
-__global__ void __launch_bounds__(kBlock) head_fill_kernel(const int64_t* __restrict__ labels, const int32_t* __restrict__ cnt,
-                                                           const int32_t* __restrict__ m_off, const int32_t* __restrict__ l_off,
-                                                           int32_t* __restrict__ row_idx, int32_t* __restrict__ sel_src,
-                                                           int32_t* __restrict__ sel_label, int32_t* __restrict__ sel_tok,
-                                                           int T, int n) {
-  const int t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= T || cnt[t] == 0) return;
-  const int m = m_off[t];
-  row_idx[m] = t;
-  int j = l_off[t];
-  for (int f = 0; f < n; ++f) {
-    const int64_t lab = labels ? labels[(size_t)t * n + f] : 0;
-    if (!labels || lab != -100) {
-      sel_src[j] = m * n + f;
-      sel_label[j] = (int32_t)lab;
-      sel_tok[j] = t;
-      ++j;
+    l_off[t] = j;
+    if (c > 0) {
+      row_idx[m] = t;
+      for (int f = 0; f < n; ++f) {
+        const int64_t lab = labels ? labels[(size_t)t * n + f] : 0;
+        if (!labels || lab != -100) {
+          sel_src[j] = m * n + f;
+          sel_label[j] = (int32_t)lab;
+          sel_tok[j] = t;
+          if (slot_hist) atomicAdd(&hist[f], 1);
+          ++j;
+        }
+      }
     }
+  }
+  if (slot_hist) {     // cells per slot (the slot-sorted head below; n <= 32): one global atomic per slot and block
+    __syncthreads();
+    if ((int)threadIdx.x < n && hist[threadIdx.x]) atomicAdd(&slot_hist[threadIdx.x], hist[threadIdx.x]);
   }
 }
 
@@ -904,75 +919,79 @@ __global__ void __launch_bounds__(kBlock) head_fill_kernel(const int64_t* __rest
 //   dXs[p] = dP[cell(p)] . W_f(p)             (backward: one row per cell; head_cell_sum adds a token's cells into d hidden)
 // slot_state: [0, n) cell counts, [n, 2n) fill cursors, [2n, 3n + 1) padded slot starts.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) slot_hist_kernel(const int32_t* __restrict__ sel_src, const int32_t* __restrict__ count,
-                                                           int32_t* __restrict__ slot_state, int cap, int n) {
-  __shared__ int hist[32];
-  if (threadIdx.x < 32) hist[threadIdx.x] = 0;
-  __syncthreads();
-  const int lm = min(cap, *count);
-  for (int l = blockIdx.x * kBlock + threadIdx.x; l < lm; l += gridDim.x * kBlock) atomicAdd(&hist[sel_src[l] % n], 1);
-  __syncthreads();
-  if ((int)threadIdx.x < n && hist[threadIdx.x]) atomicAdd(&slot_state[threadIdx.x], hist[threadIdx.x]);
-}
-// one block: padded slot starts, the cursors, the per-row-tile weight offsets, the defaults of the pad rows, the padded total
-__global__ void __launch_bounds__(kBlock) slot_plan_kernel(int32_t* __restrict__ slot_state, int32_t* __restrict__ a_tok,
-                                                           int32_t* __restrict__ a_cell, int32_t* __restrict__ c_l,
-                                                           int32_t* __restrict__ tile_off, int32_t* __restrict__ total_p, int n,
-                                                           long slot_elems, int kSlotPad) {     // kSlotPad = row-tile height of the consuming GEMM
-  __shared__ int start[33];
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int f = 0; f < n; ++f) {
-      start[f] = acc;
-      slot_state[n + f] = acc;              // cursor
-      slot_state[2 * n + f] = acc;
-      acc += (slot_state[f] + kSlotPad - 1) / kSlotPad * kSlotPad;
-    }
-    start[n] = acc;
-    slot_state[3 * n] = acc;
-    *total_p = acc;
-  }
-  __syncthreads();
-  for (int f = 0; f < n; ++f) {
-    const int lo = start[f] + slot_state[f], hi = start[f + 1];
-    for (int p = lo + threadIdx.x; p < hi; p += kBlock) { a_tok[p] = 0; a_cell[p] = 0; c_l[p] = -1; }     // pad rows: read row 0, store nothing
-    for (int t = start[f] / kSlotPad + threadIdx.x; t < start[f + 1] / kSlotPad; t += kBlock) tile_off[t] = (int32_t)((long)f * slot_elems);
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < n) slot_state[threadIdx.x] = 0;     // the histogram of the NEXT forward starts from zero (no memset launch)
-}
-// positions inside a slot: every block ranks the cells of its chunk per slot in LDS and reserves ONE range per slot from the global
-// cursors (13 global atomics per block; one per cell - 37 k atomics on 13 addresses - took 83 us)
+// ONE launch (round 6; histogram / plan / fill before): the per-slot cell counts come from head_fill_kernel (slot_state[0, n)); every
+// block derives the padded slot starts from them; block 0 writes what the one-block plan kernel wrote (the per-row-tile weight offsets,
+// the defaults of the pad rows, the padded total); positions inside a slot: every block ranks the cells of its chunk per slot in LDS
+// and reserves ONE range per slot from the global cursors (13 global atomics per block; one per cell - 37 k atomics on 13 addresses -
+// took 83 us); the LAST block to finish (ticket slot_state[3 n + 1]) clears counts, cursors and the ticket for the next forward.
 constexpr int kFillItems = 4;
 __global__ void __launch_bounds__(kBlock) slot_fill_kernel(const int32_t* __restrict__ sel_src, const int32_t* __restrict__ row_idx,
                                                            const int32_t* __restrict__ count, int32_t* __restrict__ slot_state,
                                                            int32_t* __restrict__ a_tok, int32_t* __restrict__ a_cell,
-                                                           int32_t* __restrict__ c_l, int32_t* __restrict__ cellpos, int cap, int n) {
-  __shared__ int cnt_s[32], base_s[32];
+                                                           int32_t* __restrict__ c_l, int32_t* __restrict__ cellpos,
+                                                           int32_t* __restrict__ tile_off, int32_t* __restrict__ total_p, int cap, int n,
+                                                           long slot_elems, int kSlotPad) {     // kSlotPad = row-tile height of the consuming GEMM
+  __shared__ int cnt_s[32], base_s[32], start[64], cells[64];
   const int lm = min(cap, *count);
   const int l0 = blockIdx.x * (kBlock * kFillItems);
-  if (l0 >= lm) return;
   if (threadIdx.x < 32) cnt_s[threadIdx.x] = 0;
-  __syncthreads();
-  int cell[kFillItems], rank[kFillItems];
+  if (threadIdx.x < 64) {     // padded slot starts: the n counts in one round trip, an exclusive scan across the first wave (n <= 32)
+    const int lane = threadIdx.x;
+    const int cf = lane < n ? slot_state[lane] : 0;
+    const int pc = (cf + kSlotPad - 1) / kSlotPad * kSlotPad;
+    int inc = pc;
 #pragma unroll
-  for (int i = 0; i < kFillItems; ++i) {
-    const int l = l0 + i * kBlock + threadIdx.x;
-    cell[i] = l < lm ? sel_src[l] : -1;
-    rank[i] = cell[i] >= 0 ? atomicAdd(&cnt_s[cell[i] % n], 1) : 0;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += y;
+    }
+    cells[lane] = cf;
+    start[lane] = inc - pc;     // (start[n] = the padded total)
   }
   __syncthreads();
-  if ((int)threadIdx.x < n) base_s[threadIdx.x] = cnt_s[threadIdx.x] ? atomicAdd(&slot_state[n + threadIdx.x], cnt_s[threadIdx.x]) : 0;
-  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) *total_p = start[n];
+    if ((int)threadIdx.x <= n) slot_state[2 * n + threadIdx.x] = start[threadIdx.x];
+    for (int f = 0; f < n; ++f) {
+      const int lo = start[f] + cells[f], hi = start[f + 1];
+      for (int p = lo + threadIdx.x; p < hi; p += kBlock) { a_tok[p] = 0; a_cell[p] = 0; c_l[p] = -1; }     // pad rows: read row 0, store nothing
+      for (int t = start[f] / kSlotPad + threadIdx.x; t < start[f + 1] / kSlotPad; t += kBlock) tile_off[t] = (int32_t)((long)f * slot_elems);
+    }
+  }
+  if (l0 < lm) {
+    int cell[kFillItems], rank[kFillItems], tok[kFillItems];
 #pragma unroll
-  for (int i = 0; i < kFillItems; ++i) {
-    if (cell[i] < 0) continue;
-    const int l = l0 + i * kBlock + threadIdx.x;
-    const int p = base_s[cell[i] % n] + rank[i];     // (order inside a slot is arbitrary: every row of the products is independent)
-    a_tok[p] = row_idx[cell[i] / n];
-    a_cell[p] = cell[i];
-    c_l[p] = l;
-    cellpos[l] = p;
+    for (int i = 0; i < kFillItems; ++i) {
+      const int l = l0 + i * kBlock + threadIdx.x;
+      cell[i] = l < lm ? sel_src[l] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < kFillItems; ++i) {
+      tok[i] = cell[i] >= 0 ? row_idx[cell[i] / n] : 0;     // (requested before the cursor atomics: one dependent round trip less)
+      rank[i] = cell[i] >= 0 ? atomicAdd(&cnt_s[cell[i] % n], 1) : 0;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n)
+      base_s[threadIdx.x] = start[threadIdx.x] + (cnt_s[threadIdx.x] ? atomicAdd(&slot_state[n + threadIdx.x], cnt_s[threadIdx.x]) : 0);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kFillItems; ++i) {
+      if (cell[i] < 0) continue;
+      const int l = l0 + i * kBlock + threadIdx.x;
+      const int p = base_s[cell[i] % n] + rank[i];     // (order inside a slot is arbitrary: every row of the products is independent)
+      a_tok[p] = tok[i];
+      a_cell[p] = cell[i];
+      c_l[p] = l;
+      cellpos[l] = p;
+    }
+  }
+  __syncthreads();     // (every read of the counts by this block lies before its ticket)
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&slot_state[3 * n + 1], 1) == (int)gridDim.x - 1) {
+      for (int f = 0; f < 2 * n; ++f) slot_state[f] = 0;
+      slot_state[3 * n + 1] = 0;
+    }
   }
 }
 // d hidden[row_idx[m]] = sum over the labelled cells of selected row m of dXs[cellpos[l]] (fp32 sum in slot order, one bf16 rounding);
@@ -988,9 +1007,40 @@ __global__ void __launch_bounds__(kBlock) head_cell_sum_kernel(const bf16_t* __r
   if (c == 0) return;
   const int l0 = l_off[t];
   int row = t;
-  if (pad2c) { row = pad2c[t]; if (row < 0) row = pad_row; }       // var-len layout: the token's compact row (remap_rows_kernel's rule)
+  if (pad2c) { row = pad2c[t]; if (row < 0) row = pad_row; }       // var-len layout: the token's compact row (gather_rows_remap_kernel's rule)
   // the token's cell rows (<= 32 of them): lane j holds the row of cell j, broadcast below; four row loads in flight per lane
   const int myrow = lane < c ? cellpos[l0 + lane] : 0;
+  if ((d >> 3) <= 128) {
+    // d <= 1024: both channel passes of a cell batch in one go - eight row loads in flight per lane instead of four, half as many
+    // dependent round trips per token (24.8 -> 23.1 us at the headline shape: the launch is bound elsewhere); same sums in the same order
+    const bool on1 = lane + 64 < (d >> 3), on0 = lane < (d >> 3);
+    float a0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, a1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < c; j += 4) {
+      uint4 q0[4], q1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = __shfl(myrow, min(j + u, c - 1), 64);
+        const bf16_t* src = dxs + (size_t)r * d + lane * 8;
+        q0[u] = on0 ? ldg16(src) : make_uint4(0u, 0u, 0u, 0u);
+        q1[u] = on1 ? ldg16(src + 512) : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (j + u < c) {
+          float v[8];
+          unpack8(q0[u], v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a0[e] += v[e];
+          unpack8(q1[u], v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a1[e] += v[e];
+        }
+      }
+    }
+    if (on0) stg16(dhid + (size_t)row * d + lane * 8, pack8(a0));
+    if (on1) stg16(dhid + (size_t)row * d + lane * 8 + 512, pack8(a1));
+    return;
+  }
   // the trip count is wave-uniform (ch0, not ch): __shfl reads from the lanes that hold the cell rows, which must be active in the
   // last partial pass over the channels too (d/8 % 64 != 0: d = 576, 1152, ...) - loads and the store are predicated instead
   for (int ch0 = 0; ch0 < (d >> 3); ch0 += 64) {
@@ -1032,6 +1082,29 @@ __global__ void __launch_bounds__(kBlock) gather_rows_kernel(const bf16_t* __res
     if (scatter) stg16(dst + r * d + c * 8, ldg16(src + i * d + c * 8));
     else stg16(dst + i * d + c * 8, ldg16(src + r * d + c * 8));
   }
+}
+
+// SMTP head on the var-len layout: the selected rows (padded token indices, head_fill_kernel) -> rows of the compact layout, and the
+// gather of those rows, in one launch (a remap launch + gather_rows_kernel before round 6).  One wave per row i reads idx[i], maps it
+// through pad2c, gathers the row and writes the mapped index back - only this wave touches idx[i], and its store follows its loads in
+// program order.  A label != -100 at a PADDED position (the reference's collator never writes one: labels are padded with -100)
+// selects a row the compact layout does not hold: it is sent to `pad_row` (a pad-token row behind the real tokens when the row count
+// was rounded up, else row 0) and the sticky flag status[2] is raised - gget_deferred_status reports that this step's loss differs
+// from the padded layout's.
+__global__ void __launch_bounds__(kBlock) gather_rows_remap_kernel(const bf16_t* __restrict__ src, int32_t* __restrict__ idx,
+                                                                   const int32_t* __restrict__ count, const int32_t* __restrict__ pad2c,
+                                                                   bf16_t* __restrict__ dst, int cap, int d, int pad_row,
+                                                                   int32_t* __restrict__ status) {
+  const int n = min(cap, *count);
+  const int lane = threadIdx.x & 63, cpr = d >> 3;
+  bool bad = false;
+  for (int i = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); i < n; i += gridDim.x * (kBlock / 64)) {
+    int r = pad2c[idx[i]];
+    if (r < 0) { bad = true; r = pad_row; }
+    for (int c = lane; c < cpr; c += 64) stg16(dst + (size_t)i * d + c * 8, ldg16(src + (size_t)r * d + c * 8));
+    if (lane == 0) idx[i] = r;
+  }
+  if (status && bad && lane == 0) status[2] = 1;     // (status == nullptr: inference selects EVERY cell of the padded grid on purpose)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2382,25 +2455,12 @@ __global__ void __launch_bounds__(kBlock) varlen_fill_kernel(const int64_t* __re
     c2p[r] = (int)i;          // (behind the padded grid: a coordinate no real token has)
   }
 }
-// SMTP head: the selected rows (padded token indices, head_fill_kernel) -> rows of the compact layout.  A label != -100 at a PADDED
-// position (the reference's collator never writes one: labels are padded with -100) selects a row the compact layout does not hold: it
-// is sent to `pad_row` (a pad-token row behind the real tokens when the row count was rounded up, else row 0) and the sticky flag
-// status[2] is raised - gget_deferred_status reports that this step's loss differs from the padded layout's.
-__global__ void __launch_bounds__(kBlock) remap_rows_kernel(int32_t* __restrict__ idx, const int32_t* __restrict__ count,
-                                                            const int32_t* __restrict__ pad2c, int cap, int pad_row,
-                                                            int32_t* __restrict__ status) {
-  const int n = min(cap, *count);
-  bool bad = false;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const int r = pad2c[idx[i]];
-    bad |= r < 0;
-    idx[i] = r < 0 ? pad_row : r;
-  }
-  if (status && __any(bad) && (threadIdx.x & 63) == 0) status[2] = 1;     // (status == nullptr: inference selects EVERY cell of the padded grid on purpose)
-}
 // sum of the key lengths of a batch (one block): the real-token count the host reads back when it asked the engine to count
 // (gget_set_token_count(GGET_TOKENS_AUTO))
-__global__ void __launch_bounds__(1024) sum_lengths_kernel(const int32_t* __restrict__ key_len, int B, int32_t* __restrict__ out) {
+// host_out (may be NULL): a word of pinned host memory - the kernel stores the count there itself and the host reads it behind an event
+// with the system-scope fence (no device-to-host copy packet in the stream: a 4 us blit kernel + a 5.6 us bubble before round 6)
+__global__ void __launch_bounds__(1024) sum_lengths_kernel(const int32_t* __restrict__ key_len, int B, int32_t* __restrict__ out,
+                                                           int32_t* __restrict__ host_out) {
   __shared__ int tot;
   if (threadIdx.x == 0) tot = 0;
   __syncthreads();
@@ -2408,7 +2468,10 @@ __global__ void __launch_bounds__(1024) sum_lengths_kernel(const int32_t* __rest
   for (int b = threadIdx.x; b < B; b += 1024) v += key_len[b];
   if (v) atomicAdd(&tot, v);
   __syncthreads();
-  if (threadIdx.x == 0) *out = tot;
+  if (threadIdx.x == 0) {
+    *out = tot;
+    if (host_out) __hip_atomic_store(host_out, tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // position ids handed to a forward index the precomputed RoPE table [max_pos][32]: a copy clamped to [0, max_pos) keeps every table read
@@ -2494,14 +2557,8 @@ int k_poison_loss(const int32_t* flag, float* loss, hipStream_t st) {
   GGET_LAUNCH_CHECK();
   return 0;
 }
-int k_sum_lengths(const int32_t* key_len, int B, int32_t* out, hipStream_t st) {
-  hipLaunchKernelGGL(sum_lengths_kernel, dim3(1), dim3(1024), 0, st, key_len, B, out);
-  GGET_LAUNCH_CHECK();
-  return 0;
-}
-int k_remap_rows(int32_t* idx, const int32_t* count, const int32_t* pad2c, int cap, int pad_row, int32_t* status, hipStream_t st) {
-  if (cap == 0) return 0;
-  hipLaunchKernelGGL(remap_rows_kernel, dim3(grid_for(cap)), dim3(kBlock), 0, st, idx, count, pad2c, cap, pad_row, status);
+int k_sum_lengths(const int32_t* key_len, int B, int32_t* out, hipStream_t st, int32_t* host_out) {
+  hipLaunchKernelGGL(sum_lengths_kernel, dim3(1), dim3(1024), 0, st, key_len, B, out, host_out);
   GGET_LAUNCH_CHECK();
   return 0;
 }
@@ -2510,11 +2567,10 @@ int k_head_slot_sort(const int32_t* sel_src, const int32_t* row_idx, const int32
                      int32_t* a_cell, int32_t* c_l, int32_t* cellpos, int32_t* tile_off, int32_t* total_p, int cap, int n, long slot_elems,
                      int tile_rows, hipStream_t st) {
   if (n > 32) { gget_set_error("slot-sorted head: next_n_token %d > 32", n); return 2; }
-  // (slot_state[0, n) is zero here: cleared with the workspace at creation and by every slot_plan_kernel after it consumed the counts)
-  hipLaunchKernelGGL(slot_hist_kernel, dim3(grid_for(cap, kBlock, 256)), dim3(kBlock), 0, st, sel_src, lm_count, slot_state, cap, n);
-  hipLaunchKernelGGL(slot_plan_kernel, dim3(1), dim3(kBlock), 0, st, slot_state, a_tok, a_cell, c_l, tile_off, total_p, n, slot_elems, tile_rows);
+  // (slot_state[0, n) holds the cells per slot, counted by k_head_compact with slot_hist = slot_state; [n, 2 n) and the ticket are zero:
+  //  cleared with the workspace at creation and by the last block of every slot_fill_kernel)
   hipLaunchKernelGGL(slot_fill_kernel, dim3((cap + kBlock * kFillItems - 1) / (kBlock * kFillItems)), dim3(kBlock), 0, st, sel_src, row_idx, lm_count, slot_state, a_tok,
-                     a_cell, c_l, cellpos, cap, n);
+                     a_cell, c_l, cellpos, tile_off, total_p, cap, n, slot_elems, tile_rows);
   GGET_LAUNCH_CHECK();
   return 0;
 }
@@ -2527,21 +2583,31 @@ int k_head_cell_sum(const void* dxs, const int32_t* cellpos, const int32_t* cnt,
 }
 
 int k_head_compact(const int64_t* labels, int T, int n, int32_t* cnt, int32_t* m_off, int32_t* l_off, int32_t* counts,
-                   int32_t* row_idx, int32_t* sel_src, int32_t* sel_label, int32_t* sel_tok, hipStream_t st) {
+                   int32_t* row_idx, int32_t* sel_src, int32_t* sel_label, int32_t* sel_tok, int32_t* blk_tot, int32_t* slot_hist,
+                   hipStream_t st) {
   const int g = (T + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(head_flags_kernel, dim3(g), dim3(kBlock), 0, st, labels, cnt, T, n);
-  hipLaunchKernelGGL(head_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, m_off, l_off, counts, T);
-  hipLaunchKernelGGL(head_fill_kernel, dim3(g), dim3(kBlock), 0, st, labels, cnt, m_off, l_off, row_idx, sel_src,
-                     sel_label, sel_tok, T, n);
+  hipLaunchKernelGGL(head_count_kernel, dim3(g), dim3(kBlock), 0, st, labels, cnt, blk_tot, T, n);
+  hipLaunchKernelGGL(head_fill_kernel, dim3(g), dim3(kBlock), 0, st, labels, cnt, blk_tot, m_off, l_off, counts, row_idx, sel_src,
+                     sel_label, sel_tok, n <= 32 ? slot_hist : nullptr, T, n);
   GGET_LAUNCH_CHECK();
   return 0;
 }
+size_t k_head_compact_ws_bytes(int T) { return (size_t)((T + kBlock - 1) / kBlock) * 8; }
 
 int k_gather_rows(const void* src, const int32_t* idx, const int32_t* count, void* dst, int cap, int d, int scatter,
                   hipStream_t st) {
   if (cap == 0) return 0;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)cap * (d / 8))), dim3(kBlock), 0, st, (const bf16_t*)src,
                      idx, count, (bf16_t*)dst, cap, d, scatter);
+  GGET_LAUNCH_CHECK();
+  return 0;
+}
+
+int k_gather_rows_remap(const void* src, int32_t* idx, const int32_t* count, const int32_t* pad2c, void* dst, int cap, int d, int pad_row,
+                        int32_t* status, hipStream_t st) {
+  if (cap == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_remap_kernel, dim3(grid_for((long)cap * 64)), dim3(kBlock), 0, st, (const bf16_t*)src, idx, count, pad2c,
+                     (bf16_t*)dst, cap, d, pad_row, status);
   GGET_LAUNCH_CHECK();
   return 0;
 }

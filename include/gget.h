@@ -132,11 +132,13 @@ int gget_set_dropout(gget_handle_t h, float attention_p, float path_p, uint32_t 
  * sum(attention_mask) of the NEXT gget_forward_pretrain / gget_forward_task batch, one of
  *     n > 0              the caller's count (the host knows it from its collator): no device->host traffic at all;
  *     GGET_TOKENS_AUTO   counted by the engine: the key lengths are summed on the device and the total is read back before the
- *                        launches are sized - 4 bytes and ONE host wait per forward (an event behind the copy; the launches that do
- *                        not need the count - head compaction, packed o weights - are enqueued in front of the wait).  This is what the model classes
+ *                        launches are sized - 4 bytes and ONE host wait per forward (the counting kernel stores the total into a
+ *                        pinned, coherent host word and the host polls it: no copy packet and no event in the stream since round 6;
+ *                        the launches that do not need the count - head compaction, packed o weights - are enqueued in front of the
+ *                        wait).  This is what the model classes
  *                        pass for a device-resident mask, i.e. for a call shaped exactly like the reference's step, which has just
  *                        synchronised on `.to(device)` of every batch tensor (src/utils/training_utils.py:17-26): the stream is
- *                        drained, the read costs a kernel launch + a 4-byte copy (measured: bench.py `layouts`);
+ *                        drained, the read costs a kernel launch + a 4-byte store over the host link (measured: bench.py `layouts`);
  *     anything else      unknown -> padded layout (the default of a bare C-ABI forward).
  * The count is consumed at the ENTRY of the next forward call, whether that call succeeds or not.
  * In the var-len layout the engine compacts the real tokens once (sample b owns rows [cu[b], cu[b] + len[b]))

@@ -1422,6 +1422,9 @@ int backbone_forward(gget_engine* h, long tc_hint, const int64_t* ids, int ldF, 
         int32_t v = kNoCount;
         const auto t0 = std::chrono::steady_clock::now();
         for (long spin = 0; (v = __atomic_load_n(h->host_word, __ATOMIC_ACQUIRE)) == kNoCount; ++spin) {
+#if defined(__x86_64__)
+          __builtin_ia32_pause();     // (a polite spin: the sibling hyper-thread may be a data-loader worker)
+#endif
           if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
             // (a stream that is held up - another process on the GPU, a debugger - or a failed launch: wait for the stream, then look again)
             GGET_HIP_CHECK(hipStreamSynchronize(st));

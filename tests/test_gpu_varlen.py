@@ -673,3 +673,40 @@ def test_prefetched_batches_give_the_bit_identical_training_run():
     assert v0 and v1
     assert l0 == l1, (l0, l1)
     assert torch.equal(w0, w1)
+
+
+def test_counted_token_total_polled_word_equals_copy_and_event():
+    """Round 6: a reference-shaped call (device mask, no count) gets the counted total through a store of `sum_lengths_kernel` into a
+    pinned host word the host polls; `GGET_COUNT_COPY=1` is the 4-byte device-to-host copy + event of rounds 3 - 5.  The knob is read
+    once per process, so the two forms run in two child processes: the same rows, loss bits and master weights after three steps over
+    batches whose row count changes from step to step."""
+    import json, os, subprocess, sys
+    code = r'''
+import importlib, json, sys, numpy as np, torch
+M = importlib.import_module("graph-gpt_amd.modeling"); tr = importlib.import_module("graph-gpt_amd.training"); synth = importlib.import_module("graph-gpt_amd.synth")
+cfg = dict(hidden_act="gelu", vocab_size=756, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+           max_position_embeddings=1024, causal_attention=False, stacked_feat=13, next_n_token=13)
+model = M.GraphGPTPretrainBase(M.GraphGPTConfig(**cfg), seed=1).cuda().eval()
+eng = tr.initialize(model, tr.OptimConfig(lr=1e-3, max_grad_norm=1.0))
+out = {"loss": [], "rows": []}
+for i in range(3):
+    b = synth.make_pretrain_batch(B=32, S=32, F=13, V=756, seed=20 + i)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in b.items() if k != "lengths"}     # (device tensors, no num_tokens: the engine counts)
+    out["loss"].append(float(tr.batch_training(dev, eng)).hex())
+    out["rows"].append(list(model._engine.varlen_status()) + [(synth.real_tokens(b) + 63) // 64 * 64])
+torch.cuda.synchronize(); model.check_deferred()
+out["master"] = float(np.abs(model._engine.master.detach().cpu().numpy()).sum()).hex()
+print("RESULT " + json.dumps(out))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for knob in ("0", "1"):
+        env = dict(os.environ, GGET_COUNT_COPY=knob, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+        assert r.returncode == 0 and line, r.stderr[-2000:]
+        res.append(json.loads(line[-1][7:]))
+    polled, copied = res
+    for st in polled["rows"]:
+        assert st[0] is True and st[1] == st[3] and st[2] is False        # var-len ran on exactly the counted rows
+    assert polled == copied
